@@ -1,0 +1,145 @@
+/*
+ * rrl_hip.h -- C ABI of librrl_hip.so, the MI355X (gfx950) hot path of Recovery RL.
+ *
+ * Drop-in boundary.  The reference has no FFI layer; its operator
+ * boundary for this path is the gym env protocol (env/navigation1.py:55-97), the replay
+ * protocol (recovery_rl/replay_memory.py:11-75) and the CEM optimiser
+ * (recovery_rl/optimizers.py:73-124).  Every entry point below names the reference
+ * interface it replaces.  INTEGRATION.md shows the ctypes stub a reference maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr());
+ *     the library allocates nothing and keeps no global state; all calls are re-entrant;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously on it
+ *     (NULL = the default stream) and is safe to capture in a hipGraph;
+ *   - return value: 0 on success, a negative RRL_E* code on error; nothing throws;
+ *   - random draws come from Philox4x32-10 keyed by `seed`, counter words
+ *     (row index, stream id, counter lo, counter hi).  `counter_dev` (nullable) points to
+ *     device uint64[2] = {tick, ticket(internal, keep 0)}: tick is ADDED to `counter`, and
+ *     where a function takes `counter_inc` the last workgroup to finish does
+ *     tick += counter_inc, so a captured hipGraph advances its own RNG counter on replay;
+ *   - env kinds: 0 navigation1, 1 navigation2, 2 maze.
+ */
+#ifndef RRL_HIP_H
+#define RRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRL_OK 0
+#define RRL_EINVAL (-1)   /* bad argument (unknown env kind, negative size, null pointer) */
+#define RRL_ELAUNCH (-2)  /* hipLaunchKernel failed; see rrl_last_hip_error() */
+#define RRL_ERANGE (-3)   /* size outside what the kernel supports (e.g. batch > 1024) */
+
+enum { RRL_ENV_NAV1 = 0, RRL_ENV_NAV2 = 1, RRL_ENV_MAZE = 2 };
+
+enum {
+    RRL_STREAM_STEP = 0,       /* env transition noise           */
+    RRL_STREAM_RESET = 1,      /* env reset noise                */
+    RRL_STREAM_OFFLINE = 2,    /* offline constraint data        */
+    RRL_STREAM_SAMPLE = 3,     /* replay sampling (positives)    */
+    RRL_STREAM_SAMPLE_NEG = 4, /* replay sampling (negatives)    */
+    RRL_STREAM_CEM = 5,        /* CEM truncated-normal samples   */
+    RRL_STREAM_ACTION = 6      /* uniform random actions         */
+};
+
+/* ABI version, bumped on any signature change. */
+int rrl_abi_version(void);
+/* hipGetLastError() of the calling thread's last failed launch, as an int (0 = none). */
+int rrl_last_hip_error(void);
+/* *ctr += inc on the stream (one thread).  Lets a captured graph advance its RNG counter. */
+int rrl_counter_add(uint64_t* ctr, uint64_t inc, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Environments.  Replaces Navigation1.step / Navigation2.step (env/navigation1.py:71-89,
+ * env/navigation2.py:70-88) + the horizon rule of the driver (recovery_rl/experiment.py:434-435)
+ * for n independent envs in lock-step.
+ *   pos        [n,2] f64  in/out  env state (the reference keeps float64 state)
+ *   action     [n,2] f32  in      raw action; clipped to [-1,1] inside (process_action :50-51)
+ *   noise      [n,2] f64  in      N(0,1) draws to use instead of Philox, or NULL
+ *   next_obs   [n,2] f32  out     s' BEFORE any auto-reset (what replay / info["next_state"] get)
+ *   obs        [n,2] f32  out     observation for the next policy call (post-reset), nullable
+ *   reward     [n]   f32  out     -||s|| of the OLD state (step_cost :106-110)
+ *   done       [n]   u8   out     reward > -4 or obstacle(s')            (:80)
+ *   constraint [n]   u8   out     obstacle(s')                           (:82)
+ *   success    [n]   u8   out     reward > -4                            (:88)
+ *   ep_done    [n]   u8   out     done or t == horizon (experiment.py:435), nullable
+ *   t          [n]   i32  in/out  per-env step count (self.time :78)
+ *   auto_reset != 0: where ep_done, pos <- [-50,0] + N(0,I) (reset :91-97) and t <- 0.
+ * ------------------------------------------------------------------------------------------ */
+int rrl_nav_step(int env_kind, int64_t n, double* pos, const float* action, const double* noise,
+                 uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                 float* next_obs, float* obs, float* reward, uint8_t* done, uint8_t* constraint,
+                 uint8_t* success, uint8_t* ep_done, int32_t* t, int32_t horizon, int auto_reset,
+                 void* stream);
+
+/* Replaces Navigation*.reset (env/navigation1.py:91-97) for n envs. `mask` (nullable, u8[n])
+ * restricts the reset to rows with mask != 0.  obs / t nullable. */
+int rrl_nav_reset(int env_kind, int64_t n, double* pos, float* obs, int32_t* t,
+                  const uint8_t* mask, const double* noise, uint64_t seed, uint64_t counter,
+                  const uint64_t* counter_dev, void* stream);
+
+/* T open-loop steps with the state held in registers (no auto-reset, no horizon):
+ * actions [T,n,2]; outputs [T,n,...] (each nullable).  The CEM ground-truth-dynamics mode
+ * and the roofline sweep use it. Step k uses counter + k. */
+int rrl_nav_rollout(int env_kind, int64_t n, int32_t T, double* pos, const float* actions,
+                    uint64_t seed, uint64_t counter, const uint64_t* counter_dev,
+                    float* obs_seq, float* reward_seq, uint8_t* constraint_seq, uint8_t* done_seq,
+                    void* stream);
+
+/* Replaces get_offline_data (env/navigation1.py:133-164, env/navigation2.py:133-243): one
+ * scripted <=10-step rollout per thread, stream-compacted in rollout order into replay-row
+ * arrays (s,a,constraint,s',mask) of `capacity` rows.  *count_dev (device int64) receives the
+ * number of rows written.  scratch: device int32[n_rollouts + 1]. Use rrl_nav_offline_rollouts()
+ * for n_rollouts. */
+int64_t rrl_nav_offline_rollouts(int env_kind, int64_t num_transitions);
+int rrl_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed, float* s, float* a,
+                    float* c, float* s2, float* m, int64_t capacity, int64_t* count_dev,
+                    int32_t* scratch, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Replay.  Replaces ReplayMemory / ConstraintReplayMemory (recovery_rl/replay_memory.py).
+ * Layout: structure-of-arrays ring, f32: s[cap,2] a[cap,2] r[cap] s2[cap,2] m[cap] = 32 B/row.
+ *   state   device int64[4]: {position, size, ticket(internal, keep 0), error flag}
+ *   pos_cnt device int32[ceil(cap/64)] or NULL: number of rows with r != 0 per 64-slot chunk,
+ *           maintained by push, consumed by the stratified sampler (replay_memory.py:50,58-66).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float* s;
+    float* a;
+    float* r;
+    float* s2;
+    float* m;
+    int64_t cap;
+    int64_t* state;
+    int32_t* pos_cnt;
+} rrl_replay_t;
+
+/* push (replay_memory.py:21-25,47-52) of n rows in row order; `valid` (nullable u8[n]) drops
+ * rows with valid == 0 (used for add_both_transitions, experiment.py:446-448).
+ * scratch: device int32[ceil(n/1024) + 1], only read when valid != NULL. */
+int rrl_replay_push(const rrl_replay_t* rb, int64_t n, const float* s, const float* a,
+                    const float* r, const float* s2, const float* m, const uint8_t* valid,
+                    int32_t* scratch, void* stream);
+
+/* sample (replay_memory.py:27-30): B distinct uniform rows gathered into 5 batch tensors.
+ * idx_out (nullable, int64[B]) receives the chosen slots.  B <= 1024.  If B > size the error
+ * flag state[3] is set to 1 and the outputs are left untouched (the reference raises
+ * ValueError; callers guard, experiment.py:397,403). */
+int rrl_replay_sample_gather(const rrl_replay_t* rb, int32_t B, uint64_t seed, uint64_t counter,
+                             uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a, float* r, float* s2,
+                             float* m, int64_t* idx_out, void* stream);
+
+/* stratified sample (replay_memory.py:54-72): first n_pos rows uniform among slots with r != 0,
+ * then n_neg rows uniform among filled slots with r == 0.  Needs rb->pos_cnt. cap <= 2^21. */
+int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_neg, uint64_t seed,
+                              uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a,
+                              float* r, float* s2, float* m, int64_t* idx_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

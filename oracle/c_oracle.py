@@ -1,0 +1,202 @@
+"""ctypes binding of oracle/librrl_oracle.so (the C CPU oracle) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+numpy arrays in, numpy arrays out; mirrors the argument order of include/rrl_hip.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librrl_oracle.so")
+
+ENV_KIND = {"navigation1": 0, "navigation2": 1, "maze": 2}
+STREAM_STEP, STREAM_RESET, STREAM_OFFLINE, STREAM_SAMPLE, STREAM_SAMPLE_NEG, STREAM_CEM, STREAM_ACTION = range(7)
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.rrl_oracle_uniform01.restype = C.c_double
+        _lib.rrl_oracle_uniform01.argtypes = [C.c_uint64]
+        _lib.rrl_oracle_nav_offline.restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def philox4x32(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().rrl_oracle_philox4x32(*[C.c_uint32(int(c)) for c in ctr], *[C.c_uint32(int(k)) for k in key], out)
+    return [int(x) for x in out]
+
+
+def normal2(seed, idx, stream, counter):
+    z = (C.c_double * 2)()
+    lib().rrl_oracle_normal2(C.c_uint64(seed), C.c_uint32(idx), C.c_uint32(stream), C.c_uint64(counter), z)
+    return np.array([z[0], z[1]])
+
+
+def normals(seed, n, stream, counter):
+    return np.stack([normal2(seed, i, stream, counter) for i in range(n)])
+
+
+def obstacle(env_name, x, y):
+    return int(lib().rrl_oracle_obstacle(ENV_KIND[env_name], C.c_double(x), C.c_double(y)))
+
+
+def nav_step(env_name, pos, action, t, noise=None, seed=0, counter=0, horizon=100, auto_reset=False):
+    """Returns dict with next_obs, obs, reward, done, constraint, success, ep_done, pos, t,
+    next_pos64, reward64.  `pos`/`t` are not modified (copies are advanced)."""
+    n = len(pos)
+    pos = np.ascontiguousarray(pos, dtype=np.float64).copy()
+    action = np.ascontiguousarray(action, dtype=np.float32)
+    t = np.ascontiguousarray(t, dtype=np.int32).copy()
+    if noise is not None:
+        noise = np.ascontiguousarray(noise, dtype=np.float64)
+    o = dict(next_obs=np.zeros((n, 2), np.float32), obs=np.zeros((n, 2), np.float32),
+             reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
+             constraint=np.zeros(n, np.uint8), success=np.zeros(n, np.uint8),
+             ep_done=np.zeros(n, np.uint8), next_pos64=np.zeros((n, 2)), reward64=np.zeros(n))
+    rc = lib().rrl_oracle_nav_step(
+        ENV_KIND[env_name], C.c_int64(n), _p(pos), _p(action), _p(noise), C.c_uint64(seed),
+        C.c_uint64(counter), _p(o["next_obs"]), _p(o["obs"]), _p(o["reward"]), _p(o["done"]),
+        _p(o["constraint"]), _p(o["success"]), _p(o["ep_done"]), _p(t), C.c_int32(horizon),
+        C.c_int(int(auto_reset)), _p(o["next_pos64"]), _p(o["reward64"]))
+    assert rc == 0
+    o["pos"], o["t"] = pos, t
+    return o
+
+
+def nav_reset(env_name, n, noise=None, seed=0, counter=0):
+    pos = np.zeros((n, 2))
+    obs = np.zeros((n, 2), np.float32)
+    t = np.zeros(n, np.int32)
+    if noise is not None:
+        noise = np.ascontiguousarray(noise, dtype=np.float64)
+    rc = lib().rrl_oracle_nav_reset(ENV_KIND[env_name], C.c_int64(n), _p(pos), _p(obs), _p(t),
+                                    _p(noise), C.c_uint64(seed), C.c_uint64(counter))
+    assert rc == 0
+    return pos, obs, t
+
+
+def nav_rollout(env_name, pos, actions, seed=0, counter=0):
+    T, n = actions.shape[0], actions.shape[1]
+    pos = np.ascontiguousarray(pos, dtype=np.float64).copy()
+    actions = np.ascontiguousarray(actions, dtype=np.float32)
+    obs = np.zeros((T, n, 2), np.float32)
+    rew = np.zeros((T, n), np.float32)
+    cons = np.zeros((T, n), np.uint8)
+    done = np.zeros((T, n), np.uint8)
+    rc = lib().rrl_oracle_nav_rollout(ENV_KIND[env_name], C.c_int64(n), C.c_int32(T), _p(pos),
+                                      _p(actions), C.c_uint64(seed), C.c_uint64(counter),
+                                      _p(obs), _p(rew), _p(cons), _p(done))
+    assert rc == 0
+    return dict(pos=pos, obs=obs, reward=rew, constraint=cons, done=done)
+
+
+def nav_offline(env_name, num_transitions, seed):
+    cap = 10 * (num_transitions // 10 // 3 + 4 * (num_transitions // 10 // 4) + num_transitions // 10) + 16
+    s = np.zeros((cap, 2), np.float32)
+    a = np.zeros((cap, 2), np.float32)
+    c = np.zeros(cap, np.float32)
+    s2 = np.zeros((cap, 2), np.float32)
+    m = np.zeros(cap, np.float32)
+    w = lib().rrl_oracle_nav_offline(ENV_KIND[env_name], C.c_int64(num_transitions),
+                                     C.c_uint64(seed), _p(s), _p(a), _p(c), _p(s2), _p(m),
+                                     C.c_int64(cap))
+    assert w >= 0, w
+    return s[:w], a[:w], c[:w], s2[:w], m[:w]
+
+
+class _Replay(C.Structure):
+    _fields_ = [("s", C.c_void_p), ("a", C.c_void_p), ("r", C.c_void_p), ("s2", C.c_void_p),
+                ("m", C.c_void_p), ("cap", C.c_int64), ("pos", C.c_int64), ("size", C.c_int64)]
+
+
+class OracleReplay:
+    """Ring buffer with the reference's push/sample semantics (replay_memory.py)."""
+
+    def __init__(self, capacity):
+        self.cap = capacity
+        self.s = np.zeros((capacity, 2), np.float32)
+        self.a = np.zeros((capacity, 2), np.float32)
+        self.r = np.zeros(capacity, np.float32)
+        self.s2 = np.zeros((capacity, 2), np.float32)
+        self.m = np.zeros(capacity, np.float32)
+        self._c = _Replay(self.s.ctypes.data, self.a.ctypes.data, self.r.ctypes.data,
+                          self.s2.ctypes.data, self.m.ctypes.data, capacity, 0, 0)
+
+    @property
+    def pos(self):
+        return int(self._c.pos)
+
+    @property
+    def size(self):
+        return int(self._c.size)
+
+    def __len__(self):
+        return self.size
+
+    def push(self, s, a, r, s2, m, valid=None):
+        s, a, s2 = (np.ascontiguousarray(x, np.float32).reshape(-1, 2) for x in (s, a, s2))
+        r, m = (np.ascontiguousarray(x, np.float32).reshape(-1) for x in (r, m))
+        if valid is not None:
+            valid = np.ascontiguousarray(valid, np.uint8)
+        rc = lib().rrl_oracle_replay_push(C.byref(self._c), C.c_int64(len(r)), _p(s), _p(a),
+                                          _p(r), _p(s2), _p(m), _p(valid))
+        assert rc == 0
+
+    def sample_indices(self, B, seed, counter):
+        idx = np.zeros(B, np.int64)
+        rc = lib().rrl_oracle_sample_indices(C.c_int64(self.size), C.c_int32(B), C.c_uint64(seed),
+                                             C.c_uint64(counter), C.c_uint32(STREAM_SAMPLE), _p(idx))
+        if rc != 0:
+            raise ValueError("Sample larger than population or is negative")
+        return idx
+
+    def sample_stratified_indices(self, n_pos, n_neg, seed, counter):
+        idx = np.zeros(n_pos + n_neg, np.int64)
+        rc = lib().rrl_oracle_sample_stratified(C.byref(self._c), C.c_int32(n_pos), C.c_int32(n_neg),
+                                                C.c_uint64(seed), C.c_uint64(counter), _p(idx))
+        if rc != 0:
+            raise ValueError("Sample larger than population or is negative")
+        return idx
+
+    def gather(self, idx):
+        B = len(idx)
+        idx = np.ascontiguousarray(idx, np.int64)
+        s = np.zeros((B, 2), np.float32)
+        a = np.zeros((B, 2), np.float32)
+        r = np.zeros(B, np.float32)
+        s2 = np.zeros((B, 2), np.float32)
+        m = np.zeros(B, np.float32)
+        rc = lib().rrl_oracle_gather(C.byref(self._c), C.c_int32(B), _p(idx), _p(s), _p(a), _p(r),
+                                     _p(s2), _p(m))
+        assert rc == 0
+        return s, a, r, s2, m
+
+    def sample(self, B, seed, counter, pos_fraction=None):
+        if pos_fraction is not None:
+            n_pos = int(B * pos_fraction)
+            idx = self.sample_stratified_indices(n_pos, B - n_pos, seed, counter)
+        else:
+            idx = self.sample_indices(B, seed, counter)
+        return self.gather(idx)

@@ -1,0 +1,445 @@
+/*
+ * rrl_oracle.c -- CPU ORACLE (test infrastructure, see rrl_oracle.h).
+ *
+ * Plain C, scalar, one thread.  Build: `make -C oracle` (gcc -O2 -ffp-contract=off).
+ * All env arithmetic is IEEE double with no FMA contraction so that the HIP kernels
+ * (which are written independently against the same specification, DESIGN.md
+ * "Deterministic math") can be compared bit-for-bit.
+ */
+#include "rrl_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon et al., SC'11) -- counter-based RNG.  The reference draws from the
+ * global numpy MT19937 stream (env/navigation1.py:93,103); a sequential stream cannot be
+ * vectorised, so the build keys a counter RNG by (seed | env index, stream, step counter).
+ * ---------------------------------------------------------------------------------------- */
+void rrl_oracle_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                           uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)M0 * c0;
+        uint64_t p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void philox_bits(uint64_t seed, uint32_t idx, uint32_t stream, uint64_t counter,
+                        uint64_t* b0, uint64_t* b1)
+{
+    uint32_t w[4];
+    rrl_oracle_philox4x32(idx, stream, (uint32_t)counter, (uint32_t)(counter >> 32),
+                          (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    *b0 = ((uint64_t)w[1] << 32) | w[0];
+    *b1 = ((uint64_t)w[3] << 32) | w[2];
+}
+
+/* u = (k + 0.5) * 2^-52 with k the top 52 bits: exact, strictly inside (0,1). */
+double rrl_oracle_uniform01(uint64_t bits)
+{
+    return ((double)(bits >> 12) + 0.5) * 0x1.0p-52;
+}
+
+/* log(u), u in (0,1): exponent split + atanh series, basic IEEE ops only. */
+static double det_log(double u)
+{
+    uint64_t b;
+    memcpy(&b, &u, 8);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m;
+    memcpy(&m, &b, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double z = s * s;
+    double p = 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+}
+
+/* sin and cos of x in (0, pi/4]: Taylor/Horner in x^2. */
+static void det_sincos(double x, double* sn, double* cs)
+{
+    double z = x * x;
+    double ps = -1.0 / 355687428096000.0;            /* -1/17! */
+    ps = ps * z + 1.0 / 1307674368000.0;              /*  1/15! */
+    ps = ps * z - 1.0 / 6227020800.0;                 /* -1/13! */
+    ps = ps * z + 1.0 / 39916800.0;                   /*  1/11! */
+    ps = ps * z - 1.0 / 362880.0;                     /* -1/9!  */
+    ps = ps * z + 1.0 / 5040.0;                       /*  1/7!  */
+    ps = ps * z - 1.0 / 120.0;                        /* -1/5!  */
+    ps = ps * z - 1.0 / 6.0;                        /* -1/3!  */
+    ps = ps * z + 1.0;
+    *sn = x * ps;
+    double pc = 1.0 / 20922789888000.0;               /*  1/16! */
+    pc = pc * z - 1.0 / 87178291200.0;                /* -1/14! */
+    pc = pc * z + 1.0 / 479001600.0;                  /*  1/12! */
+    pc = pc * z - 1.0 / 3628800.0;                    /* -1/10! */
+    pc = pc * z + 1.0 / 40320.0;                      /*  1/8!  */
+    pc = pc * z - 1.0 / 720.0;                        /* -1/6!  */
+    pc = pc * z + 1.0 / 24.0;                         /*  1/4!  */
+    pc = pc * z - 0.5;                                /* -1/2!  */
+    pc = pc * z + 1.0;
+    *cs = pc;
+}
+
+/* Box-Muller on two 64-bit words; the angle is reduced to an octant with integer ops. */
+static void normal2_from_bits(uint64_t b0, uint64_t b1, double z[2])
+{
+    double u1 = rrl_oracle_uniform01(b0);
+    double r = sqrt(-2.0 * det_log(u1));
+    uint64_t k = b1 >> 12;                         /* 52 bits: 3 octant + 49 fraction */
+    uint32_t oct = (uint32_t)(k >> 49);
+    uint64_t frac = k & ((1ULL << 49) - 1);
+    if (oct & 1u) frac = ((1ULL << 49) - 1) - frac;  /* 1 - f, exactly */
+    double phi = ((double)frac + 0.5) * 0x1.0p-49 * 0.7853981633974483;
+    double sn, cs, c, s;
+    det_sincos(phi, &sn, &cs);
+    if (oct & 1u) { c = sn; s = cs; } else { c = cs; s = sn; }
+    switch (oct >> 1) {
+        case 0: z[0] = r * c;  z[1] = r * s;  break;
+        case 1: z[0] = -(r * s); z[1] = r * c;  break;
+        case 2: z[0] = -(r * c); z[1] = -(r * s); break;
+        default: z[0] = r * s;  z[1] = -(r * c); break;
+    }
+}
+
+void rrl_oracle_normal2(uint64_t seed, uint32_t idx, uint32_t stream, uint64_t counter,
+                        double z[2])
+{
+    uint64_t b0, b1;
+    philox_bits(seed, idx, stream, counter, &b0, &b1);
+    normal2_from_bits(b0, b1, z);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Obstacles: env/obstacle.py:13-15 (closed intervals), ComplexObstacle :44-45 (max over boxes)
+ * Box tables: env/navigation1.py:41-42, env/navigation2.py:41.
+ * ---------------------------------------------------------------------------------------- */
+static const double NAV1_BOXES[3][4] = {
+    {-100.0, 150.0, 5.0, 10.0}, {-100.0, -80.0, -10.0, 10.0}, {-100.0, 150.0, -10.0, -5.0}};
+static const double NAV2_BOXES[1][4] = {{-30.0, -20.0, -7.5, 7.5}};
+
+int rrl_oracle_obstacle(int env_kind, double x, double y)
+{
+    const double (*boxes)[4] = env_kind == RRL_ENV_NAV1 ? NAV1_BOXES : NAV2_BOXES;
+    int nb = env_kind == RRL_ENV_NAV1 ? 3 : 1;
+    int hit = 0;
+    for (int k = 0; k < nb; ++k)
+        hit |= (boxes[k][0] <= x && x <= boxes[k][1] && boxes[k][2] <= y && y <= boxes[k][3]);
+    return hit;
+}
+
+static double clip1(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* one transition; returns next state in nx,ny.  env/navigation1.py:71-89,99-110 */
+static void nav_transition(int env_kind, double x, double y, double ax, double ay,
+                           double ex, double ey, double* nx, double* ny, double* cost)
+{
+    ax = clip1(ax, -1.0, 1.0);                           /* process_action :50-51 */
+    ay = clip1(ay, -1.0, 1.0);
+    if (rrl_oracle_obstacle(env_kind, x, y)) {            /* _next_state :100-102: stuck, no noise */
+        *nx = x; *ny = y;
+    } else {                                              /* :103-104  A s + B a + 0.05 eps */
+        *nx = (x + ax) + 0.05 * ex;
+        *ny = (y + ay) + 0.05 * ey;
+    }
+    /* step_cost :106-110 on the OLD state.  np.linalg.norm -> sqrt(ddot(s,s)); OpenBLAS' ddot
+     * accumulates with FMA (dot = fma(y,y, x*x)) -- pinned by the golden vectors, where this
+     * form reproduces all 5514 reference rewards bit-for-bit and the plain form misses 159. */
+    *cost = -sqrt(fma(y, y, x * x));
+}
+
+int rrl_oracle_nav_step(int env_kind, int64_t n, double* pos, const float* action,
+                        const double* noise, uint64_t seed, uint64_t counter,
+                        float* next_obs, float* obs, float* reward, uint8_t* done,
+                        uint8_t* constraint, uint8_t* success, uint8_t* ep_done,
+                        int32_t* t, int32_t horizon, int auto_reset,
+                        double* next_pos64, double* reward64)
+{
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        double x = pos[2 * i], y = pos[2 * i + 1];
+        double e[2];
+        if (noise) { e[0] = noise[2 * i]; e[1] = noise[2 * i + 1]; }
+        else rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_STEP, counter, e);
+        double nx, ny, cost;
+        nav_transition(env_kind, x, y, (double)action[2 * i], (double)action[2 * i + 1],
+                       e[0], e[1], &nx, &ny, &cost);
+        int cons = rrl_oracle_obstacle(env_kind, nx, ny);
+        int succ = cost > -4.0;                           /* :88 */
+        int dn = succ || cons;                            /* :80 */
+        int32_t ti = t[i] + 1;                            /* :78 */
+        int epd = dn || (ti == horizon);                  /* experiment.py:435 */
+        if (next_pos64) { next_pos64[2 * i] = nx; next_pos64[2 * i + 1] = ny; }
+        if (reward64) reward64[i] = cost;
+        next_obs[2 * i] = (float)nx; next_obs[2 * i + 1] = (float)ny;
+        reward[i] = (float)cost;
+        done[i] = (uint8_t)dn; constraint[i] = (uint8_t)cons; success[i] = (uint8_t)succ;
+        if (ep_done) ep_done[i] = (uint8_t)epd;
+        if (auto_reset && epd) {                          /* reset :91-97 */
+            double z[2];
+            rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_RESET, counter, z);
+            nx = -50.0 + z[0]; ny = 0.0 + z[1];
+            ti = 0;
+        }
+        pos[2 * i] = nx; pos[2 * i + 1] = ny;
+        t[i] = ti;
+        if (obs) { obs[2 * i] = (float)nx; obs[2 * i + 1] = (float)ny; }
+    }
+    return 0;
+}
+
+int rrl_oracle_nav_reset(int env_kind, int64_t n, double* pos, float* obs, int32_t* t,
+                         const double* noise, uint64_t seed, uint64_t counter)
+{
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        double z[2];
+        if (noise) { z[0] = noise[2 * i]; z[1] = noise[2 * i + 1]; }
+        else rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_RESET, counter, z);
+        pos[2 * i] = -50.0 + z[0];                        /* START_STATE + randn(2), :92 */
+        pos[2 * i + 1] = 0.0 + z[1];
+        if (t) t[i] = 0;
+        if (obs) { obs[2 * i] = (float)pos[2 * i]; obs[2 * i + 1] = (float)pos[2 * i + 1]; }
+    }
+    return 0;
+}
+
+int rrl_oracle_nav_rollout(int env_kind, int64_t n, int32_t T, double* pos,
+                           const float* actions, uint64_t seed, uint64_t counter,
+                           float* obs_seq, float* reward_seq, uint8_t* constraint_seq,
+                           uint8_t* done_seq)
+{
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        double x = pos[2 * i], y = pos[2 * i + 1];
+        for (int32_t k = 0; k < T; ++k) {
+            const float* a = actions + ((int64_t)k * n + i) * 2;
+            double e[2], nx, ny, cost;
+            rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_STEP, counter + (uint64_t)k, e);
+            nav_transition(env_kind, x, y, (double)a[0], (double)a[1], e[0], e[1], &nx, &ny, &cost);
+            int cons = rrl_oracle_obstacle(env_kind, nx, ny);
+            int64_t o = (int64_t)k * n + i;
+            obs_seq[2 * o] = (float)nx; obs_seq[2 * o + 1] = (float)ny;
+            reward_seq[o] = (float)cost;
+            constraint_seq[o] = (uint8_t)cons;
+            done_seq[o] = (uint8_t)((cost > -4.0) || cons);
+            x = nx; y = ny;
+        }
+        pos[2 * i] = x; pos[2 * i + 1] = y;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Offline constraint data (env/navigation1.py:133-164, env/navigation2.py:133-243).
+ * Rollout i draws from Philox(seed; i, OFFLINE, k, hi): k=0 start uniforms, k=1 second start
+ * uniforms, per step j: k=2+3j action normals, 3+3j action uniforms, 4+3j noise normals;
+ * hi=1+r is the r-th start re-draw of the nav2 phase-0 rejection loop.
+ * ---------------------------------------------------------------------------------------- */
+static void offline_uniform2(uint64_t seed, uint32_t i, uint64_t k, uint32_t hi, double u[2])
+{
+    uint64_t b0, b1;
+    philox_bits(seed, i, RRL_STREAM_OFFLINE, k | ((uint64_t)hi << 32), &b0, &b1);
+    u[0] = rrl_oracle_uniform01(b0);
+    u[1] = rrl_oracle_uniform01(b1);
+}
+
+static int nav2_phase(int64_t i, int64_t n0, int64_t n1)
+{
+    if (i < n0) return 0;
+    return 1 + (int)((i - n0) / (n1 > 0 ? n1 : 1));
+}
+
+int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed,
+                               float* s, float* a, float* c, float* s2, float* m,
+                               int64_t capacity)
+{
+    int64_t n_roll, n0 = 0, n1 = 0;
+    if (env_kind == RRL_ENV_NAV1) n_roll = num_transitions / 10;
+    else if (env_kind == RRL_ENV_NAV2) {
+        n0 = num_transitions / 10 / 3;                    /* navigation2.py:138 */
+        n1 = num_transitions / 10 / 4;                    /* :160,180,200,220 */
+        n_roll = n0 + 4 * n1;
+    } else return -1;
+    int64_t w = 0;
+    for (int64_t i = 0; i < n_roll; ++i) {
+        double u[2], v[2], x, y;
+        int phase = 0;
+        offline_uniform2(seed, (uint32_t)i, 0, 0, u);
+        offline_uniform2(seed, (uint32_t)i, 1, 0, v);
+        if (env_kind == RRL_ENV_NAV1) {                   /* navigation1.py:140-147 */
+            x = -80.0 + 130.0 * u[1];
+            y = (u[0] < 0.5) ? (-5.0 + 3.0 * v[0]) : (2.0 + 3.0 * v[0]);
+        } else {
+            phase = nav2_phase(i, n0, n1);
+            switch (phase) {
+                case 0: {                                  /* navigation2.py:140-146 */
+                    x = -40.0 + 50.0 * u[0]; y = -25.0 + 50.0 * u[1];
+                    uint32_t r = 0;
+                    while (rrl_oracle_obstacle(env_kind, x, y)) {
+                        double q[2];
+                        offline_uniform2(seed, (uint32_t)i, 0, 1 + r, q);
+                        x = -40.0 + 50.0 * q[0]; y = -25.0 + 50.0 * q[1];
+                        ++r;
+                    }
+                    break;
+                }
+                case 1: x = -35.0 + 5.0 * u[0]; y = -12.0 + 24.0 * u[1]; break;   /* :162-164 */
+                case 2: x = -20.0 + 5.0 * u[0]; y = -12.0 + 24.0 * u[1]; break;   /* :182-184 */
+                case 3: x = -30.0 + 10.0 * u[0]; y = 10.0 + 5.0 * u[1]; break;    /* :202-204 */
+                default: x = -30.0 + 10.0 * u[0]; y = -15.0 + 5.0 * u[1]; break;  /* :222-224 */
+            }
+        }
+        for (int j = 0; j < 10; ++j) {
+            double z[2], q[2], e[2], ax, ay;
+            rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_OFFLINE, (uint64_t)(2 + 3 * j), z);
+            offline_uniform2(seed, (uint32_t)i, (uint64_t)(3 + 3 * j), 0, q);
+            rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_OFFLINE, (uint64_t)(4 + 3 * j), e);
+            ax = clip1(z[0], -1.0, 1.0); ay = clip1(z[1], -1.0, 1.0);
+            switch (phase) {                               /* navigation2.py:166-168,186-188,206-208,226-228 */
+                case 1: ax = 0.5 + 0.5 * q[0]; break;
+                case 2: ax = -1.0 + 0.5 * q[0]; break;
+                case 3: ay = -1.0 + 0.5 * q[0]; break;
+                case 4: ay = 0.5 + 0.5 * q[0]; break;
+                default: break;
+            }
+            float axf = (float)ax, ayf = (float)ay;        /* replay rows are f32; keep (s,a,s') consistent */
+            double nx, ny, cost;
+            nav_transition(env_kind, x, y, (double)axf, (double)ayf, e[0], e[1], &nx, &ny, &cost);
+            int cons = rrl_oracle_obstacle(env_kind, nx, ny);
+            if (w >= capacity) return -2;
+            s[2 * w] = (float)x; s[2 * w + 1] = (float)y;
+            a[2 * w] = axf; a[2 * w + 1] = ayf;
+            c[w] = (float)cons;
+            s2[2 * w] = (float)nx; s2[2 * w + 1] = (float)ny;
+            m[w] = (float)(!cons);                         /* (state, action, constraint, next_state, not constraint) */
+            ++w;
+            x = nx; y = ny;
+            if (cons) break;
+        }
+    }
+    return w;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Replay (recovery_rl/replay_memory.py)
+ * ---------------------------------------------------------------------------------------- */
+int rrl_oracle_replay_push(rrl_oracle_replay* rb, int64_t n, const float* s, const float* a,
+                           const float* r, const float* s2, const float* m,
+                           const uint8_t* valid)
+{
+    for (int64_t i = 0; i < n; ++i) {                     /* push :21-25 / :47-52, row by row */
+        if (valid && !valid[i]) continue;
+        int64_t p = rb->pos;
+        rb->s[2 * p] = s[2 * i]; rb->s[2 * p + 1] = s[2 * i + 1];
+        rb->a[2 * p] = a[2 * i]; rb->a[2 * p + 1] = a[2 * i + 1];
+        rb->r[p] = r[i];
+        rb->s2[2 * p] = s2[2 * i]; rb->s2[2 * p + 1] = s2[2 * i + 1];
+        rb->m[p] = m[i];
+        rb->pos = (p + 1) % rb->cap;
+        if (rb->size < rb->cap) rb->size += 1;
+    }
+    return 0;
+}
+
+static uint64_t mulhi64(uint64_t a, uint64_t b)
+{
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+}
+
+/* B distinct draws from [0,size): every slot draws independently; a slot loses a round when an
+ * already-accepted slot, or a lower-numbered slot of the same round, holds the same value;
+ * losers redraw with the round number bumped.  By symmetry under value relabelling the result
+ * is uniform over ordered B-subsets == random.sample (replay_memory.py:28). */
+int rrl_oracle_sample_indices(int64_t size, int32_t B, uint64_t seed, uint64_t counter,
+                              uint32_t stream, int64_t* idx)
+{
+    if (B > size || B <= 0) return -1;                    /* random.sample raises ValueError */
+    uint8_t* acc = (uint8_t*)calloc((size_t)B, 1);
+    uint8_t* lose = (uint8_t*)calloc((size_t)B, 1);
+    int pending = B;
+    for (uint32_t round = 0; pending > 0; ++round) {
+        if (round > 4096) { free(acc); free(lose); return -2; }
+        for (int32_t i = 0; i < B; ++i) {
+            if (acc[i]) continue;
+            uint64_t b0, b1;
+            philox_bits(seed, (uint32_t)i, stream, (counter << 12) | round, &b0, &b1);
+            idx[i] = (int64_t)mulhi64(b0, (uint64_t)size);
+        }
+        for (int32_t i = 0; i < B; ++i) {
+            lose[i] = 0;
+            if (acc[i]) continue;
+            for (int32_t j = 0; j < B; ++j)
+                if (j != i && idx[j] == idx[i] && (acc[j] || j < i)) { lose[i] = 1; break; }
+        }
+        for (int32_t i = 0; i < B; ++i)
+            if (!acc[i] && !lose[i]) { acc[i] = 1; --pending; }
+    }
+    free(acc); free(lose);
+    return 0;
+}
+
+/* rank -> slot of the k-th positive (r != 0) / negative (r == 0) among filled slots, slot order
+ * (np.argwhere is sorted, replay_memory.py:58-66) */
+static int64_t kth_slot(const rrl_oracle_replay* rb, int64_t k, int want_pos)
+{
+    for (int64_t p = 0; p < rb->size; ++p) {
+        int is_pos = rb->r[p] != 0.0f;
+        if (is_pos == want_pos) { if (k == 0) return p; --k; }
+    }
+    return -1;
+}
+
+int rrl_oracle_sample_stratified(const rrl_oracle_replay* rb, int32_t n_pos, int32_t n_neg,
+                                 uint64_t seed, uint64_t counter, int64_t* idx)
+{
+    int64_t npos_total = 0;
+    for (int64_t p = 0; p < rb->size; ++p) npos_total += rb->r[p] != 0.0f;
+    int64_t nneg_total = rb->size - npos_total;
+    if (n_pos > npos_total || n_neg > nneg_total) return -1;
+    if (n_pos > 0) {
+        if (rrl_oracle_sample_indices(npos_total, n_pos, seed, counter, RRL_STREAM_SAMPLE, idx)) return -2;
+        for (int32_t i = 0; i < n_pos; ++i) idx[i] = kth_slot(rb, idx[i], 1);
+    }
+    if (n_neg > 0) {
+        if (rrl_oracle_sample_indices(nneg_total, n_neg, seed, counter, RRL_STREAM_SAMPLE_NEG, idx + n_pos)) return -2;
+        for (int32_t i = 0; i < n_neg; ++i) idx[n_pos + i] = kth_slot(rb, idx[n_pos + i], 0);
+    }
+    return 0;
+}
+
+int rrl_oracle_gather(const rrl_oracle_replay* rb, int32_t B, const int64_t* idx, float* s,
+                      float* a, float* r, float* s2, float* m)
+{
+    for (int32_t i = 0; i < B; ++i) {                     /* np.stack over the batch :29 */
+        int64_t p = idx[i];
+        if (p < 0 || p >= rb->size) return -1;
+        s[2 * i] = rb->s[2 * p]; s[2 * i + 1] = rb->s[2 * p + 1];
+        a[2 * i] = rb->a[2 * p]; a[2 * i + 1] = rb->a[2 * p + 1];
+        r[i] = rb->r[p];
+        s2[2 * i] = rb->s2[2 * p]; s2[2 * i + 1] = rb->s2[2 * p + 1];
+        m[i] = rb->m[p];
+    }
+    return 0;
+}

@@ -1,0 +1,104 @@
+/*
+ * rrl_oracle.h -- CPU ORACLE for the Recovery-RL hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the reference's algorithms (abalakrishna123/recovery-rl)
+ * used as the checker for the HIP path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product (recovery_rl_amd)
+ * never links, imports or calls it.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   navigation1 / navigation2 step, reset, offline data : PINNED against golden vectors
+ *       captured by importing the reference (tests/golden/nav_step_golden.npz,
+ *       nav_offline_golden.npz; generator tests/golden/gen_env_golden.py).
+ *   replay push / sample / stratified sample           : PINNED on composition + ring
+ *       semantics against tests/golden/replay_golden.npz (index streams cannot match:
+ *       the reference uses python `random`).
+ *   maze                                                : PARITY UNPINNED (MuJoCo 1.50 is a
+ *       third-party dependency absent from the reference tree and this image).
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#ifndef RRL_ORACLE_H
+#define RRL_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RRL_ENV_NAV1 = 0, RRL_ENV_NAV2 = 1, RRL_ENV_MAZE = 2 };
+
+/* Philox stream ids (word 1 of the counter) -- same numbering as include/rrl_hip.h */
+enum {
+    RRL_STREAM_STEP = 0,
+    RRL_STREAM_RESET = 1,
+    RRL_STREAM_OFFLINE = 2,
+    RRL_STREAM_SAMPLE = 3,
+    RRL_STREAM_SAMPLE_NEG = 4,
+    RRL_STREAM_CEM = 5,
+    RRL_STREAM_ACTION = 6
+};
+
+/* ---- RNG primitives (exposed for tests) ---- */
+void rrl_oracle_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                           uint32_t k0, uint32_t k1, uint32_t out[4]);
+void rrl_oracle_normal2(uint64_t seed, uint32_t idx, uint32_t stream, uint64_t counter,
+                        double z[2]);
+double rrl_oracle_uniform01(uint64_t bits);
+
+/* ---- navigation1 / navigation2 (env/navigation1.py, env/navigation2.py) ---- */
+int rrl_oracle_obstacle(int env_kind, double x, double y);
+
+int rrl_oracle_nav_step(int env_kind, int64_t n, double* pos, const float* action,
+                        const double* noise, uint64_t seed, uint64_t counter,
+                        float* next_obs, float* obs, float* reward, uint8_t* done,
+                        uint8_t* constraint, uint8_t* success, uint8_t* ep_done,
+                        int32_t* t, int32_t horizon, int auto_reset,
+                        double* next_pos64, double* reward64);
+
+int rrl_oracle_nav_reset(int env_kind, int64_t n, double* pos, float* obs, int32_t* t,
+                         const double* noise, uint64_t seed, uint64_t counter);
+
+/* T-step open-loop rollout: actions [T,n,2]; outputs per-step arrays [T,n,...] */
+int rrl_oracle_nav_rollout(int env_kind, int64_t n, int32_t T, double* pos,
+                           const float* actions, uint64_t seed, uint64_t counter,
+                           float* obs_seq, float* reward_seq, uint8_t* constraint_seq,
+                           uint8_t* done_seq);
+
+/* offline constraint data, one Philox-driven rollout per index (env/navigation1.py:133-164,
+ * env/navigation2.py:133-243).  Outputs are stream-compacted in rollout order.
+ * Returns the number of transitions written (<= 10 * n_rollouts), negative on error. */
+int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed,
+                               float* s, float* a, float* c, float* s2, float* m,
+                               int64_t capacity);
+
+/* ---- replay (recovery_rl/replay_memory.py) ---- */
+typedef struct {
+    float* s;       /* [cap,2] */
+    float* a;       /* [cap,2] */
+    float* r;       /* [cap]   */
+    float* s2;      /* [cap,2] */
+    float* m;       /* [cap]   */
+    int64_t cap;
+    int64_t pos;    /* next write slot */
+    int64_t size;   /* filled rows */
+} rrl_oracle_replay;
+
+int rrl_oracle_replay_push(rrl_oracle_replay* rb, int64_t n, const float* s, const float* a,
+                           const float* r, const float* s2, const float* m,
+                           const uint8_t* valid);
+/* B distinct uniform indices in [0,size) (random.sample semantics, replay_memory.py:27-30) */
+int rrl_oracle_sample_indices(int64_t size, int32_t B, uint64_t seed, uint64_t counter,
+                              uint32_t stream, int64_t* idx);
+/* stratified: first n_pos indices are slots with r!=0 ("positives"), then n_neg negatives
+ * (replay_memory.py:54-72) */
+int rrl_oracle_sample_stratified(const rrl_oracle_replay* rb, int32_t n_pos, int32_t n_neg,
+                                 uint64_t seed, uint64_t counter, int64_t* idx);
+int rrl_oracle_gather(const rrl_oracle_replay* rb, int32_t B, const int64_t* idx, float* s,
+                      float* a, float* r, float* s2, float* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,5 @@
+"""recovery_rl_amd -- MI355X-native hot path of Recovery RL (batched env step -> device replay
+-> SAC / Q_risk updates -> PETS/CEM recovery), behind the reference's env / replay / agent
+interfaces.  HIP kernels + C ABI in csrc/ (include/rrl_hip.h); no CPU fallback."""
+
+__version__ = "0.1.0"

@@ -1,0 +1,131 @@
+"""Loader for librrl_hip.so (the C-ABI HIP library, include/rrl_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a GPU is not
+present, the callers raise.  `build()` compiles the library in-tree with hipcc for gfx950
+(cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "librrl_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+HIP_SOURCES = ["nav_kernels.hip", "replay_kernels.hip", "maze_kernels.hip", "cem_kernels.hip",
+               "mlp_kernels.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+EXPORTS = [
+    "rrl_abi_version", "rrl_last_hip_error", "rrl_counter_add",
+    "rrl_nav_step", "rrl_nav_reset", "rrl_nav_rollout", "rrl_nav_offline_rollouts",
+    "rrl_nav_offline",
+    "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather",
+]
+
+
+class RRLError(RuntimeError):
+    pass
+
+
+def _sources():
+    return [os.path.join(CSRC, f) for f in HIP_SOURCES if os.path.exists(os.path.join(CSRC, f))]
+
+
+def _stale():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = _sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps.append(os.path.join(INCLUDE, "rrl_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip into csrc/librrl_hip.so for gfx950."""
+    if not force and not _stale():
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", SO_PATH] + _sources()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+class rrl_replay_t(C.Structure):
+    _fields_ = [("s", C.c_void_p), ("a", C.c_void_p), ("r", C.c_void_p), ("s2", C.c_void_p),
+                ("m", C.c_void_p), ("cap", C.c_int64), ("state", C.c_void_p),
+                ("pos_cnt", C.c_void_p)]
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, i32, i64, u64, ci = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int
+    rp = C.POINTER(rrl_replay_t)
+    sig = {
+        "rrl_abi_version": (ci, []),
+        "rrl_last_hip_error": (ci, []),
+        "rrl_counter_add": (ci, [vp, u64, vp]),
+        "rrl_nav_step": (ci, [ci, i64, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, vp, vp, vp,
+                              vp, i32, ci, vp]),
+        "rrl_nav_reset": (ci, [ci, i64, vp, vp, vp, vp, vp, u64, u64, vp, vp]),
+        "rrl_nav_rollout": (ci, [ci, i64, i32, vp, vp, u64, u64, vp, vp, vp, vp, vp, vp]),
+        "rrl_nav_offline_rollouts": (i64, [ci, i64]),
+        "rrl_nav_offline": (ci, [ci, i64, u64, vp, vp, vp, vp, vp, i64, vp, vp, vp]),
+        "rrl_replay_push": (ci, [rp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_replay_sample_gather": (ci, [rp, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_creplay_sample_gather": (ci, [rp, i32, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp,
+                                           vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    for name in EXPORTS:
+        if name not in sig:
+            getattr(lib, name)
+
+
+def load():
+    """Load the library (after torch, so that both share torch's libamdhip64 runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  -- must come first: same HIP runtime instance as torch
+    if not os.path.exists(SO_PATH):
+        raise RRLError(
+            "librrl_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'`; there is no CPU fallback for the hot path." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    _declare(lib)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        lib = load()
+        raise RRLError("%s failed: rc=%d hipError=%d" % (what, rc, lib.rrl_last_hip_error()))
+
+
+def require_gpu(device):
+    import torch
+    dev = torch.device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        raise RRLError("recovery_rl_amd runs its hot path on an MI355X only (device=%r, "
+                       "cuda available=%s); there is no CPU fallback." % (device, torch.cuda.is_available()))
+    return dev
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,392 @@
+// nav_kernels.hip -- batched Navigation1 / Navigation2 env kernels for gfx950 (MI355X).
+//
+// One lane per env, structure-of-arrays state in HBM, every access unit-stride across the
+// 64-lane wavefront.  The kernels are HBM-bound streaming kernels (DESIGN.md "nav_step"):
+// 28 B read + 43 B written per env-step; all arithmetic in registers (Philox + Box-Muller +
+// two fp64 adds), no LDS, no inter-lane traffic.  Grid: <=2048 workgroups of 256 threads,
+// grid-stride, so a launch covers the 256 CUs (8 XCDs) with 8 workgroups per CU.
+#include <hip/hip_runtime.h>
+
+#include "rrl_device.hpp"
+#include "rrl_host.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+using rrl_host::check_launch;
+using rrl_host::grid_for;
+using rrl_host::kBlock;
+
+struct StepArgs {
+    int64_t n;
+    double2* pos;
+    const float2* action;
+    const double2* noise;
+    uint64_t seed;
+    uint64_t counter;
+    uint64_t* counter_dev;
+    uint64_t counter_inc;
+    float2* next_obs;
+    float2* obs;
+    float* reward;
+    uint8_t* done;
+    uint8_t* constraint;
+    uint8_t* success;
+    uint8_t* ep_done;
+    int32_t* t;
+    int32_t horizon;
+    int32_t auto_reset;
+};
+
+template <int KIND, bool EXT_NOISE>
+__global__ __launch_bounds__(kBlock) void nav_step_kernel(StepArgs a) {
+    const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < a.n; i += stride) {
+        const double2 p = a.pos[i];
+        const float2 act = a.action[i];
+        int32_t ti = a.t[i];
+        double ex, ey;
+        if constexpr (EXT_NOISE) {
+            const double2 e = a.noise[i];
+            ex = e.x;
+            ey = e.y;
+        } else {
+            rrl::normal_at(a.seed, uint32_t(i), rrl::kStreamStep, ctr, ex, ey);
+        }
+        double nx, ny, cost;
+        rrl::nav_transition<KIND>(p.x, p.y, double(act.x), double(act.y), ex, ey, nx, ny, cost);
+        const bool cons = rrl::in_obstacle<KIND>(nx, ny);
+        const bool succ = cost > -4.0;
+        const bool dn = succ | cons;
+        ti += 1;
+        const bool epd = dn | (ti == a.horizon);
+        a.next_obs[i] = make_float2(float(nx), float(ny));
+        a.reward[i] = float(cost);
+        a.done[i] = uint8_t(dn);
+        a.constraint[i] = uint8_t(cons);
+        a.success[i] = uint8_t(succ);
+        if (a.ep_done) a.ep_done[i] = uint8_t(epd);
+        if (a.auto_reset && epd) {
+            double z0, z1;
+            rrl::normal_at(a.seed, uint32_t(i), rrl::kStreamReset, ctr, z0, z1);
+            nx = -50.0 + z0;
+            ny = 0.0 + z1;
+            ti = 0;
+        }
+        a.pos[i] = make_double2(nx, ny);
+        a.t[i] = ti;
+        if (a.obs) a.obs[i] = make_float2(float(nx), float(ny));
+    }
+    rrl::advance_counter(a.counter_dev, a.counter_inc);
+}
+
+__global__ __launch_bounds__(kBlock) void nav_reset_kernel(int64_t n, double2* pos, float2* obs,
+                                                           int32_t* t, const uint8_t* mask,
+                                                           const double2* noise, uint64_t seed,
+                                                           uint64_t counter,
+                                                           const uint64_t* counter_dev) {
+    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        if (mask && !mask[i]) continue;
+        double z0, z1;
+        if (noise) {
+            z0 = noise[i].x;
+            z1 = noise[i].y;
+        } else {
+            rrl::normal_at(seed, uint32_t(i), rrl::kStreamReset, ctr, z0, z1);
+        }
+        const double x = -50.0 + z0, y = 0.0 + z1;  // START_STATE + randn(2), navigation1.py:92
+        pos[i] = make_double2(x, y);
+        if (t) t[i] = 0;
+        if (obs) obs[i] = make_float2(float(x), float(y));
+    }
+}
+
+// T open-loop steps per env with the state in registers; per step only the action (8 B) is
+// read and the requested outputs are written.
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void nav_rollout_kernel(int64_t n, int32_t T, double2* pos,
+                                                             const float2* actions, uint64_t seed,
+                                                             uint64_t counter,
+                                                             const uint64_t* counter_dev,
+                                                             float2* obs_seq, float* reward_seq,
+                                                             uint8_t* constraint_seq,
+                                                             uint8_t* done_seq) {
+    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        double2 p = pos[i];
+        for (int32_t k = 0; k < T; ++k) {
+            const int64_t o = int64_t(k) * n + i;
+            const float2 act = actions[o];
+            double ex, ey, nx, ny, cost;
+            rrl::normal_at(seed, uint32_t(i), rrl::kStreamStep, ctr + uint64_t(k), ex, ey);
+            rrl::nav_transition<KIND>(p.x, p.y, double(act.x), double(act.y), ex, ey, nx, ny, cost);
+            const bool cons = rrl::in_obstacle<KIND>(nx, ny);
+            if (obs_seq) obs_seq[o] = make_float2(float(nx), float(ny));
+            if (reward_seq) reward_seq[o] = float(cost);
+            if (constraint_seq) constraint_seq[o] = uint8_t(cons);
+            if (done_seq) done_seq[o] = uint8_t((cost > -4.0) | cons);
+            p = make_double2(nx, ny);
+        }
+        pos[i] = p;
+    }
+}
+
+// ---- offline constraint data (env/navigation1.py:133-164, env/navigation2.py:133-243) ----
+struct OfflinePlan {
+    int64_t n_roll, n0, n1;
+};
+
+inline OfflinePlan offline_plan(int env_kind, int64_t num) {
+    OfflinePlan p{0, 0, 0};
+    if (env_kind == RRL_ENV_NAV1) {
+        p.n_roll = num / 10;
+    } else {
+        p.n0 = num / 10 / 3;
+        p.n1 = num / 10 / 4;
+        p.n_roll = p.n0 + 4 * p.n1;
+    }
+    return p;
+}
+
+__device__ __forceinline__ void offline_uniform2(uint64_t seed, uint32_t row, uint64_t k,
+                                                 uint32_t hi, double& u0, double& u1) {
+    const rrl::Bits128 b = rrl::philox_at(seed, row, rrl::kStreamOffline, k | (uint64_t(hi) << 32));
+    u0 = rrl::unit_open(b.lo);
+    u1 = rrl::unit_open(b.hi);
+}
+
+// Simulates rollout `i`; when WRITE, stores its rows starting at row `base`. Returns its length.
+template <int KIND, bool WRITE>
+__device__ __forceinline__ int offline_rollout(int64_t i, int64_t n0, int64_t n1, uint64_t seed,
+                                               int64_t base, float2* s, float2* a, float* c,
+                                               float2* s2, float* m) {
+    const uint32_t row = uint32_t(i);
+    double u0, u1, v0, v1, x, y;
+    offline_uniform2(seed, row, 0, 0, u0, u1);
+    offline_uniform2(seed, row, 1, 0, v0, v1);
+    int phase = 0;
+    if constexpr (KIND == 0) {
+        x = -80.0 + 130.0 * u1;
+        y = (u0 < 0.5) ? (-5.0 + 3.0 * v0) : (2.0 + 3.0 * v0);
+    } else {
+        phase = (i < n0) ? 0 : 1 + int((i - n0) / (n1 > 0 ? n1 : 1));
+        if (phase == 0) {
+            x = -40.0 + 50.0 * u0;
+            y = -25.0 + 50.0 * u1;
+            for (uint32_t r = 0; rrl::in_obstacle<KIND>(x, y); ++r) {
+                double q0, q1;
+                offline_uniform2(seed, row, 0, 1 + r, q0, q1);
+                x = -40.0 + 50.0 * q0;
+                y = -25.0 + 50.0 * q1;
+            }
+        } else if (phase == 1) {
+            x = -35.0 + 5.0 * u0;
+            y = -12.0 + 24.0 * u1;
+        } else if (phase == 2) {
+            x = -20.0 + 5.0 * u0;
+            y = -12.0 + 24.0 * u1;
+        } else if (phase == 3) {
+            x = -30.0 + 10.0 * u0;
+            y = 10.0 + 5.0 * u1;
+        } else {
+            x = -30.0 + 10.0 * u0;
+            y = -15.0 + 5.0 * u1;
+        }
+    }
+    int len = 0;
+    for (int j = 0; j < 10; ++j) {
+        double z0, z1, q0, q1, e0, e1;
+        rrl::normal_at(seed, row, rrl::kStreamOffline, uint64_t(2 + 3 * j), z0, z1);
+        offline_uniform2(seed, row, uint64_t(3 + 3 * j), 0, q0, q1);
+        rrl::normal_at(seed, row, rrl::kStreamOffline, uint64_t(4 + 3 * j), e0, e1);
+        double ax = rrl::clamp_unit(z0), ay = rrl::clamp_unit(z1);
+        if (phase == 1) ax = 0.5 + 0.5 * q0;
+        else if (phase == 2) ax = -1.0 + 0.5 * q0;
+        else if (phase == 3) ay = -1.0 + 0.5 * q0;
+        else if (phase == 4) ay = 0.5 + 0.5 * q0;
+        const float axf = float(ax), ayf = float(ay);
+        double nx, ny, cost;
+        rrl::nav_transition<KIND>(x, y, double(axf), double(ayf), e0, e1, nx, ny, cost);
+        const bool cons = rrl::in_obstacle<KIND>(nx, ny);
+        if constexpr (WRITE) {
+            const int64_t w = base + len;
+            s[w] = make_float2(float(x), float(y));
+            a[w] = make_float2(axf, ayf);
+            c[w] = cons ? 1.0f : 0.0f;
+            s2[w] = make_float2(float(nx), float(ny));
+            m[w] = cons ? 0.0f : 1.0f;
+        }
+        ++len;
+        x = nx;
+        y = ny;
+        if (cons) break;
+    }
+    return len;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void offline_count_kernel(int64_t n_roll, int64_t n0,
+                                                               int64_t n1, uint64_t seed,
+                                                               int32_t* lens) {
+    const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n_roll)
+        lens[i] = offline_rollout<KIND, false>(i, n0, n1, seed, 0, nullptr, nullptr, nullptr,
+                                               nullptr, nullptr);
+}
+
+// single workgroup: in-place exclusive scan of lens[0..n), total -> lens[n] and *count_dev
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(int32_t* lens, int64_t n,
+                                                              int64_t* count_dev) {
+    __shared__ int32_t part[1024];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int32_t v = (i < n) ? lens[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int32_t add = (int(threadIdx.x) >= off) ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int32_t incl = part[threadIdx.x];
+        const int32_t c0 = carry;
+        if (i < n) lens[i] = c0 + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c0 + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        lens[n] = carry;
+        if (count_dev) *count_dev = carry;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void offline_write_kernel(int64_t n_roll, int64_t n0,
+                                                               int64_t n1, uint64_t seed,
+                                                               const int32_t* offs, int64_t capacity,
+                                                               float2* s, float2* a, float* c,
+                                                               float2* s2, float* m) {
+    const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n_roll) return;
+    const int64_t base = offs[i];
+    if (int64_t(offs[i + 1]) > capacity) return;  // caller sized the arrays too small: drop
+    offline_rollout<KIND, true>(i, n0, n1, seed, base, s, a, c, s2, m);
+}
+
+__global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
+
+}  // namespace
+
+thread_local int rrl_host::last_hip_error = 0;
+
+extern "C" {
+
+int rrl_abi_version(void) { return 1; }
+
+int rrl_last_hip_error(void) { return rrl_host::last_hip_error; }
+
+int rrl_counter_add(uint64_t* ctr, uint64_t inc, void* stream) {
+    if (!ctr) return RRL_EINVAL;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc);
+    return check_launch();
+}
+
+int rrl_nav_step(int env_kind, int64_t n, double* pos, const float* action, const double* noise,
+                 uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                 float* next_obs,
+                 float* obs, float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success,
+                 uint8_t* ep_done, int32_t* t, int32_t horizon, int auto_reset, void* stream) {
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
+    if (n < 0 || n > 0xffffffffLL) return RRL_ERANGE;
+    if (!pos || !action || !next_obs || !reward || !done || !constraint || !success || !t)
+        return RRL_EINVAL;
+    if (n == 0) return RRL_OK;
+    StepArgs a{n, (double2*)pos, (const float2*)action, (const double2*)noise, seed, counter,
+               counter_dev, counter_inc, (float2*)next_obs, (float2*)obs, reward, done, constraint, success,
+               ep_done, t, horizon, auto_reset};
+    const dim3 grid(grid_for(n)), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (env_kind == RRL_ENV_NAV1) {
+        if (noise) hipLaunchKernelGGL((nav_step_kernel<0, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((nav_step_kernel<0, false>), grid, block, 0, st, a);
+    } else {
+        if (noise) hipLaunchKernelGGL((nav_step_kernel<1, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((nav_step_kernel<1, false>), grid, block, 0, st, a);
+    }
+    return check_launch();
+}
+
+int rrl_nav_reset(int env_kind, int64_t n, double* pos, float* obs, int32_t* t,
+                  const uint8_t* mask, const double* noise, uint64_t seed, uint64_t counter,
+                  const uint64_t* counter_dev, void* stream) {
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
+    if (n < 0 || n > 0xffffffffLL) return RRL_ERANGE;
+    if (!pos) return RRL_EINVAL;
+    if (n == 0) return RRL_OK;
+    hipLaunchKernelGGL(nav_reset_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       n, (double2*)pos, (float2*)obs, t, mask, (const double2*)noise, seed,
+                       counter, counter_dev);
+    return check_launch();
+}
+
+int rrl_nav_rollout(int env_kind, int64_t n, int32_t T, double* pos, const float* actions,
+                    uint64_t seed, uint64_t counter, const uint64_t* counter_dev, float* obs_seq,
+                    float* reward_seq, uint8_t* constraint_seq, uint8_t* done_seq, void* stream) {
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
+    if (n < 0 || n > 0xffffffffLL || T < 0) return RRL_ERANGE;
+    if (!pos || !actions) return RRL_EINVAL;
+    if (n == 0 || T == 0) return RRL_OK;
+    const dim3 grid(grid_for(n)), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (env_kind == RRL_ENV_NAV1)
+        hipLaunchKernelGGL((nav_rollout_kernel<0>), grid, block, 0, st, n, T, (double2*)pos,
+                           (const float2*)actions, seed, counter, counter_dev, (float2*)obs_seq,
+                           reward_seq, constraint_seq, done_seq);
+    else
+        hipLaunchKernelGGL((nav_rollout_kernel<1>), grid, block, 0, st, n, T, (double2*)pos,
+                           (const float2*)actions, seed, counter, counter_dev, (float2*)obs_seq,
+                           reward_seq, constraint_seq, done_seq);
+    return check_launch();
+}
+
+int64_t rrl_nav_offline_rollouts(int env_kind, int64_t num_transitions) {
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
+    if (num_transitions < 0) return RRL_EINVAL;
+    return offline_plan(env_kind, num_transitions).n_roll;
+}
+
+int rrl_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed, float* s, float* a,
+                    float* c, float* s2, float* m, int64_t capacity, int64_t* count_dev,
+                    int32_t* scratch, void* stream) {
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
+    if (num_transitions < 0 || !s || !a || !c || !s2 || !m || !scratch) return RRL_EINVAL;
+    const OfflinePlan p = offline_plan(env_kind, num_transitions);
+    if (p.n_roll > 0x7fffffffLL / 10) return RRL_ERANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((p.n_roll + kBlock - 1) / kBlock > 0 ? (p.n_roll + kBlock - 1) / kBlock : 1)),
+        block(kBlock);
+    if (env_kind == RRL_ENV_NAV1)
+        hipLaunchKernelGGL((offline_count_kernel<0>), grid, block, 0, st, p.n_roll, p.n0, p.n1, seed, scratch);
+    else
+        hipLaunchKernelGGL((offline_count_kernel<1>), grid, block, 0, st, p.n_roll, p.n0, p.n1, seed, scratch);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, scratch, p.n_roll, count_dev);
+    if (env_kind == RRL_ENV_NAV1)
+        hipLaunchKernelGGL((offline_write_kernel<0>), grid, block, 0, st, p.n_roll, p.n0, p.n1, seed,
+                           scratch, capacity, (float2*)s, (float2*)a, c, (float2*)s2, m);
+    else
+        hipLaunchKernelGGL((offline_write_kernel<1>), grid, block, 0, st, p.n_roll, p.n0, p.n1, seed,
+                           scratch, capacity, (float2*)s, (float2*)a, c, (float2*)s2, m);
+    return check_launch();
+}
+
+}  // extern "C"

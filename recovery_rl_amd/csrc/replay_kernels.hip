@@ -1,0 +1,403 @@
+// replay_kernels.hip -- device-resident replay buffers for gfx950 (MI355X).
+//
+// Replaces recovery_rl/replay_memory.py (python list of tuples + random.sample + np.stack +
+// five host->device copies per batch) with a structure-of-arrays ring in HBM:
+//   push           : n rows x 32 B, coalesced (lane i -> slot pos+i), one launch
+//   sample+gather  : ONE workgroup draws B distinct slots (Philox + LDS all-pairs dedupe) and
+//                    gathers the rows into five contiguous batch tensors -- 16 KB moved for
+//                    B=256; latency-bound by design (DESIGN.md "replay")
+//   stratified     : per-64-slot positive counts maintained by push; the sampler scans the
+//                    count table in LDS and touches 64 rewards per drawn row instead of the
+//                    reference's O(capacity) argwhere per call (replay_memory.py:58-66)
+#include <hip/hip_runtime.h>
+
+#include "rrl_device.hpp"
+#include "rrl_host.hpp"
+
+namespace {
+
+using rrl_host::check_launch;
+using rrl_host::grid_for;
+using rrl_host::kBlock;
+
+constexpr int kTile = 1024;   // rows per workgroup in the masked push
+constexpr int kChunk = 64;    // slots per positive-count chunk
+
+struct Rows {
+    const float2* s;
+    const float2* a;
+    const float* r;
+    const float2* s2;
+    const float* m;
+};
+
+__device__ __forceinline__ void store_row(const rrl_replay_t& rb, int64_t slot, int64_t size,
+                                          const Rows& in, int64_t i) {
+    const float rn = in.r[i];
+    if (rb.pos_cnt) {  // keep the per-chunk positive counts exact (pos_idx, replay_memory.py:50)
+        const int was = (slot < size) ? int(rb.r[slot] != 0.0f) : 0;
+        const int delta = int(rn != 0.0f) - was;
+        if (delta) atomicAdd(&rb.pos_cnt[slot / kChunk], delta);
+    }
+    ((float2*)rb.s)[slot] = in.s[i];
+    ((float2*)rb.a)[slot] = in.a[i];
+    rb.r[slot] = rn;
+    ((float2*)rb.s2)[slot] = in.s2[i];
+    rb.m[slot] = in.m[i];
+}
+
+// Last workgroup to finish advances {position, size}; every workgroup has read them before it
+// takes its ticket, so no workgroup can observe the new values.
+__device__ __forceinline__ void advance_ring(const rrl_replay_t& rb, int64_t pos, int64_t size,
+                                             int64_t pushed) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long ticket = atomicAdd((unsigned long long*)&rb.state[2], 1ULL);
+        if (ticket == gridDim.x - 1) {
+            rb.state[0] = (pos + pushed) % rb.cap;
+            const int64_t ns = size + pushed;
+            rb.state[1] = ns > rb.cap ? rb.cap : ns;
+            rb.state[2] = 0;
+            __threadfence();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void push_kernel(rrl_replay_t rb, int64_t n, Rows in) {
+    const int64_t pos = rb.state[0], size = rb.state[1];
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+        store_row(rb, (pos + i) % rb.cap, size, in, i);
+    advance_ring(rb, pos, size, n);
+}
+
+// masked push, pass 1: valid rows per 1024-row tile
+__global__ __launch_bounds__(kBlock) void mask_count_kernel(const uint8_t* valid, int64_t n,
+                                                            int32_t* tile_cnt) {
+    __shared__ int32_t wave_cnt[kBlock / 64];
+    const int64_t base = int64_t(blockIdx.x) * kTile;
+    int32_t c = 0;
+    for (int k = 0; k < kTile / kBlock; ++k) {
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        c += (i < n && valid[i]) ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t tot = 0;
+        for (int w = 0; w < kBlock / 64; ++w) tot += wave_cnt[w];
+        tile_cnt[blockIdx.x] = tot;
+    }
+}
+
+// masked push, pass 2: rows keep their order; tile offsets come from the pass-1 counts
+__global__ __launch_bounds__(kBlock) void push_masked_kernel(rrl_replay_t rb, int64_t n, Rows in,
+                                                             const uint8_t* valid,
+                                                             const int32_t* tile_cnt) {
+    __shared__ int64_t red[kBlock];
+    __shared__ int32_t wave_off[kBlock / 64];
+    const int64_t pos = rb.state[0], size = rb.state[1];
+    // exclusive offset of this tile and the grand total
+    int64_t before = 0, total = 0;
+    for (int j = threadIdx.x; j < int(gridDim.x); j += kBlock) {
+        const int32_t c = tile_cnt[j];
+        total += c;
+        if (j < int(blockIdx.x)) before += c;
+    }
+    red[threadIdx.x] = before;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (int(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    before = red[0];
+    __syncthreads();
+    red[threadIdx.x] = total;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (int(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    total = red[0];
+    __syncthreads();
+    int64_t run = before;
+    const int64_t base = int64_t(blockIdx.x) * kTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < kTile / kBlock; ++k) {
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        const bool v = (i < n) && valid[i];
+        const unsigned long long bal = __ballot(v);
+        const int rank_in_wave = __popcll(bal & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wave_off[wave] = __popcll(bal);
+        __syncthreads();
+        int32_t woff = 0, tile_tot = 0;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            const int32_t c = wave_off[w];
+            if (w < wave) woff += c;
+            tile_tot += c;
+        }
+        if (v) store_row(rb, (pos + run + woff + rank_in_wave) % rb.cap, size, in, i);
+        run += tile_tot;
+        __syncthreads();
+    }
+    advance_ring(rb, pos, size, total);
+}
+
+// ---- sampling -------------------------------------------------------------------------------
+struct BatchOut {
+    float2* s;
+    float2* a;
+    float* r;
+    float2* s2;
+    float* m;
+    int64_t* idx;
+};
+
+// B distinct draws per group from [0, population): each slot draws independently; a slot loses
+// a round when an accepted slot, or a lower-numbered pending slot of its group, holds the same
+// value, and redraws with the round number bumped (uniform over ordered subsets by symmetry).
+// cand / acc live in LDS.  Returns false if the round cap is hit.
+__device__ __forceinline__ bool draw_distinct(int i, int B, int g_lo, int g_hi, uint64_t population,
+                                              uint64_t seed, uint32_t stream, uint64_t ctr,
+                                              uint64_t* cand, uint8_t* acc) {
+    const bool active = i < B;
+    bool mine = !active;  // inactive lanes count as settled
+    if (active) acc[i] = 0;
+    __syncthreads();
+    for (uint32_t round = 0; round <= 4096; ++round) {
+        if (active && !mine) {
+            const rrl::Bits128 b = rrl::philox_at(seed, uint32_t(i), stream, (ctr << 12) | round);
+            cand[i] = __umul64hi(b.lo, population);
+        }
+        __syncthreads();
+        bool lose = false;
+        if (active && !mine) {
+            const uint64_t v = cand[i];
+            for (int j = g_lo; j < g_hi; ++j)
+                lose |= (j != i) & (cand[j] == v) & (bool(acc[j]) | (j < i));
+        }
+        __syncthreads();
+        if (active && !mine && !lose) {
+            acc[i] = 1;
+            mine = true;
+        }
+        if (__syncthreads_count(!mine) == 0) return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void gather_row(const rrl_replay_t& rb, int64_t slot, int i,
+                                           const BatchOut& out) {
+    out.s[i] = ((const float2*)rb.s)[slot];
+    out.a[i] = ((const float2*)rb.a)[slot];
+    out.r[i] = rb.r[slot];
+    out.s2[i] = ((const float2*)rb.s2)[slot];
+    out.m[i] = rb.m[slot];
+    if (out.idx) out.idx[i] = slot;
+}
+
+__global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, int B, uint64_t seed,
+                                                             uint64_t counter,
+                                                             uint64_t* counter_dev,
+                                                             uint64_t counter_inc, BatchOut out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* cand = (uint64_t*)smem;
+    uint8_t* acc = (uint8_t*)(cand + B);
+    const int64_t size = rb.state[1];
+    if (int64_t(B) > size) {  // random.sample would raise ValueError
+        if (threadIdx.x == 0) rb.state[3] = 1;
+        return;
+    }
+    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
+    rrl::advance_counter(counter_dev, counter_inc);
+    const int i = threadIdx.x;
+    if (!draw_distinct(i, B, 0, B, uint64_t(size), seed, rrl::kStreamSample, ctr, cand, acc)) {
+        if (threadIdx.x == 0) rb.state[3] = 2;
+        return;
+    }
+    if (i < B) gather_row(rb, int64_t(cand[i]), i, out);
+}
+
+// Stratified: lanes [0,n_pos) draw ranks among positives, lanes [n_pos,B) among negatives.
+__global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_t rb, int n_pos,
+                                                                     int n_neg, int n_chunks,
+                                                                     uint64_t seed, uint64_t counter,
+                                                                     uint64_t* counter_dev,
+                                                                     uint64_t counter_inc,
+                                                                     BatchOut out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int B = n_pos + n_neg;
+    uint64_t* cand = (uint64_t*)smem;
+    int32_t* prefix = (int32_t*)(cand + B);           // [n_chunks + 1] exclusive positive counts
+    int32_t* part = prefix + (n_chunks + 1);          // [blockDim.x]
+    uint8_t* acc = (uint8_t*)(part + blockDim.x);
+    const int64_t size = rb.state[1];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // exclusive scan of pos_cnt into LDS: contiguous segment per thread, then a block scan
+    const int seg = (n_chunks + nt - 1) / nt;
+    const int lo = tid * seg, hi = min(lo + seg, n_chunks);
+    int32_t local = 0;
+    for (int c = lo; c < hi; ++c) local += rb.pos_cnt[c];
+    part[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {
+        const int32_t add = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    int32_t run = part[tid] - local;
+    for (int c = lo; c < hi; ++c) {
+        prefix[c] = run;
+        run += rb.pos_cnt[c];
+    }
+    const int64_t total_pos = part[nt - 1];
+    if (tid == nt - 1) prefix[n_chunks] = int32_t(total_pos);
+    __syncthreads();
+    const int64_t total_neg = size - total_pos;
+    if (int64_t(n_pos) > total_pos || int64_t(n_neg) > total_neg) {
+        if (tid == 0) rb.state[3] = 1;
+        return;
+    }
+    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
+    rrl::advance_counter(counter_dev, counter_inc);
+    const bool is_pos = tid < n_pos;
+    const int g_lo = is_pos ? 0 : n_pos, g_hi = is_pos ? n_pos : B;
+    const uint64_t population = uint64_t(is_pos ? total_pos : total_neg);
+    const uint32_t stream = is_pos ? rrl::kStreamSample : rrl::kStreamSampleNeg;
+    // lanes of the negative group are numbered from 0 within their group, like a separate call
+    const int gi = is_pos ? tid : tid - n_pos;
+    // draw_distinct indexes LDS by absolute lane but keys Philox by the group-relative row
+    {
+        const bool active = tid < B;
+        bool mine = !active;
+        if (active) acc[tid] = 0;
+        __syncthreads();
+        bool ok = false;
+        for (uint32_t round = 0; round <= 4096; ++round) {
+            if (active && !mine) {
+                const rrl::Bits128 b = rrl::philox_at(seed, uint32_t(gi), stream, (ctr << 12) | round);
+                cand[tid] = __umul64hi(b.lo, population);
+            }
+            __syncthreads();
+            bool lose = false;
+            if (active && !mine) {
+                const uint64_t v = cand[tid];
+                for (int j = g_lo; j < g_hi; ++j)
+                    lose |= (j != tid) & (cand[j] == v) & (bool(acc[j]) | (j < tid));
+            }
+            __syncthreads();
+            if (active && !mine && !lose) {
+                acc[tid] = 1;
+                mine = true;
+            }
+            if (__syncthreads_count(!mine) == 0) {
+                ok = true;
+                break;
+            }
+        }
+        if (!ok) {
+            if (tid == 0) rb.state[3] = 2;
+            return;
+        }
+    }
+    if (tid >= B) return;
+    // rank -> slot: binary search the chunk, then scan its 64 rewards
+    const int64_t k = int64_t(cand[tid]);
+    auto before = [&](int c) -> int64_t {  // rows of my class in chunks [0,c)
+        const int64_t filled = min(size, int64_t(c) * kChunk);
+        return is_pos ? int64_t(prefix[c]) : filled - int64_t(prefix[c]);
+    };
+    int a = 0, b = n_chunks;  // invariant: before(a) <= k < before(b)
+    while (b - a > 1) {
+        const int mid = (a + b) >> 1;
+        if (before(mid) <= k) a = mid; else b = mid;
+    }
+    int64_t rem = k - before(a);
+    int64_t slot = -1;
+    const int64_t c0 = int64_t(a) * kChunk;
+    for (int j = 0; j < kChunk; ++j) {
+        const int64_t p = c0 + j;
+        if (p >= size) break;
+        const bool pos_row = rb.r[p] != 0.0f;
+        if (pos_row == is_pos) {
+            if (rem == 0) { slot = p; break; }
+            --rem;
+        }
+    }
+    if (slot < 0) {  // count table out of sync with the rows: flag, never read out of bounds
+        rb.state[3] = 3;
+        return;
+    }
+    gather_row(rb, slot, tid, out);
+}
+
+inline bool valid_rb(const rrl_replay_t* rb) {
+    return rb && rb->s && rb->a && rb->r && rb->s2 && rb->m && rb->state && rb->cap > 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rrl_replay_push(const rrl_replay_t* rb, int64_t n, const float* s, const float* a,
+                    const float* r, const float* s2, const float* m, const uint8_t* valid,
+                    int32_t* scratch, void* stream) {
+    if (!valid_rb(rb) || !s || !a || !r || !s2 || !m || n < 0) return RRL_EINVAL;
+    if (n > rb->cap) return RRL_ERANGE;
+    if (n == 0) return RRL_OK;
+    const Rows in{(const float2*)s, (const float2*)a, r, (const float2*)s2, m};
+    hipStream_t st = (hipStream_t)stream;
+    if (!valid) {
+        hipLaunchKernelGGL(push_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, *rb, n, in);
+        return check_launch();
+    }
+    if (!scratch) return RRL_EINVAL;
+    const int64_t tiles = (n + kTile - 1) / kTile;
+    if (tiles > 65535 * 16) return RRL_ERANGE;
+    hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, st, valid, n, scratch);
+    hipLaunchKernelGGL(push_masked_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, st, *rb, n, in,
+                       valid, (const int32_t*)scratch);
+    return check_launch();
+}
+
+int rrl_replay_sample_gather(const rrl_replay_t* rb, int32_t B, uint64_t seed, uint64_t counter,
+                             uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a, float* r, float* s2,
+                             float* m, int64_t* idx_out, void* stream) {
+    if (!valid_rb(rb) || !s || !a || !r || !s2 || !m) return RRL_EINVAL;
+    if (B <= 0 || B > 1024) return RRL_ERANGE;
+    const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out};
+    const int threads = ((B + 63) / 64) * 64;
+    const size_t lds = size_t(B) * 9 + 16;
+    hipLaunchKernelGGL(sample_gather_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, *rb,
+                       B, seed, counter, counter_dev, counter_inc, out);
+    return check_launch();
+}
+
+int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_neg, uint64_t seed,
+                              uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a,
+                              float* r, float* s2, float* m, int64_t* idx_out, void* stream) {
+    if (!valid_rb(rb) || !rb->pos_cnt || !s || !a || !r || !s2 || !m) return RRL_EINVAL;
+    const int B = n_pos + n_neg;
+    if (n_pos < 0 || n_neg < 0 || B <= 0 || B > 1024) return RRL_ERANGE;
+    if (rb->cap > (int64_t(1) << 21)) return RRL_ERANGE;
+    const int n_chunks = int((rb->cap + kChunk - 1) / kChunk);
+    int threads = ((B + 63) / 64) * 64;
+    if (threads < 256) threads = 256;
+    const size_t lds = size_t(B) * 8 + size_t(n_chunks + 1) * 4 + size_t(threads) * 4 + size_t(B) + 16;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)creplay_sample_gather_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out};
+    hipLaunchKernelGGL(creplay_sample_gather_kernel, dim3(1), dim3(threads), lds,
+                       (hipStream_t)stream, *rb, n_pos, n_neg, n_chunks, seed, counter, counter_dev,
+                       counter_inc, out);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// rrl_device.hpp -- device-side primitives shared by the gfx950 kernels:
+// Philox4x32-10, bit-reproducible uniform / normal generation, obstacle tables.
+//
+// "Deterministic math" contract: every floating-point result below is produced
+// by IEEE-754 double add / mul / div / sqrt / fma only, in a fixed order, with FMA
+// contraction disabled, so that the values are identical on the GPU and in the CPU checker.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace rrl {
+
+constexpr uint32_t kStreamStep = 0, kStreamReset = 1, kStreamOffline = 2, kStreamSample = 3,
+                   kStreamSampleNeg = 4, kStreamCem = 5, kStreamAction = 6;
+
+struct Bits128 {
+    uint64_t lo, hi;
+};
+
+// Philox4x32-10, counter (c0..c3), key (k0,k1).
+__device__ __forceinline__ Bits128 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                          uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0;
+        c1 = l1;
+        c2 = h0 ^ c3 ^ k1;
+        c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Bits128{(uint64_t(c1) << 32) | c0, (uint64_t(c3) << 32) | c2};
+}
+
+__device__ __forceinline__ Bits128 philox_at(uint64_t seed, uint32_t row, uint32_t stream,
+                                             uint64_t counter) {
+    return philox(row, stream, uint32_t(counter), uint32_t(counter >> 32), uint32_t(seed),
+                  uint32_t(seed >> 32));
+}
+
+// (k + 1/2) / 2^52 for the top 52 bits k: exact in double, strictly inside (0,1).
+__device__ __forceinline__ double unit_open(uint64_t bits) {
+    return (double(bits >> 12) + 0.5) * 0x1.0p-52;
+}
+
+template <int N>
+__device__ __forceinline__ double horner(const double (&coef)[N], double z) {
+    double acc = coef[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) acc = acc * z + coef[i];
+    return acc;
+}
+
+// natural log on (0,1): split exponent, fold mantissa into (sqrt(1/2), sqrt(2)], atanh series.
+__device__ __forceinline__ double log_unit(double u) {
+    constexpr double kAtanh[11] = {1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0,
+                                   1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0,  1.0 / 7.0,
+                                   1.0 / 5.0,  1.0 / 3.0,  1.0};
+    const uint64_t raw = (uint64_t)__double_as_longlong(u);
+    int expo = int((raw >> 52) & 0x7ffu) - 1023;
+    double mant =
+        __longlong_as_double((long long)((raw & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
+    if (mant > 1.4142135623730951) {
+        mant = mant * 0.5;
+        expo += 1;
+    }
+    const double s = (mant - 1.0) / (mant + 1.0);
+    const double p = horner(kAtanh, s * s);
+    return double(expo) * 0.6931471805599453 + 2.0 * s * p;
+}
+
+// sin / cos on (0, pi/4] by Taylor polynomials in x^2.
+__device__ __forceinline__ void sincos_octant(double x, double& sn, double& cs) {
+    constexpr double kSin[9] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0,
+                                -1.0 / 6227020800.0,      1.0 / 39916800.0,
+                                -1.0 / 362880.0,          1.0 / 5040.0,
+                                -1.0 / 120.0,             -1.0 / 6.0,
+                                1.0};
+    constexpr double kCos[9] = {1.0 / 20922789888000.0, -1.0 / 87178291200.0,
+                                1.0 / 479001600.0,      -1.0 / 3628800.0,
+                                1.0 / 40320.0,          -1.0 / 720.0,
+                                1.0 / 24.0,             -0.5,
+                                1.0};
+    const double z = x * x;
+    sn = x * horner(kSin, z);
+    cs = horner(kCos, z);
+}
+
+// Two independent N(0,1) draws from 128 random bits (Box-Muller, integer octant reduction).
+__device__ __forceinline__ void normal_pair(Bits128 b, double& z0, double& z1) {
+    const double radius = sqrt(-2.0 * log_unit(unit_open(b.lo)));
+    const uint64_t k = b.hi >> 12;
+    const uint32_t octant = uint32_t(k >> 49);
+    uint64_t frac = k & ((1ULL << 49) - 1);
+    if (octant & 1u) frac = ((1ULL << 49) - 1) - frac;
+    const double phi = (double(frac) + 0.5) * 0x1.0p-49 * 0.7853981633974483;
+    double sn, cs;
+    sincos_octant(phi, sn, cs);
+    const double c = (octant & 1u) ? sn : cs;
+    const double s = (octant & 1u) ? cs : sn;
+    const double rc = radius * c, rs = radius * s;
+    switch (octant >> 1) {
+        case 0: z0 = rc; z1 = rs; break;
+        case 1: z0 = -rs; z1 = rc; break;
+        case 2: z0 = -rc; z1 = -rs; break;
+        default: z0 = rs; z1 = -rc; break;
+    }
+}
+
+__device__ __forceinline__ void normal_at(uint64_t seed, uint32_t row, uint32_t stream,
+                                          uint64_t counter, double& z0, double& z1) {
+    normal_pair(philox_at(seed, row, stream, counter), z0, z1);
+}
+
+// ---- obstacles: closed axis-aligned boxes (env/obstacle.py:13-15,44-45) ----
+template <int KIND>
+__device__ __forceinline__ bool in_obstacle(double x, double y) {
+    if constexpr (KIND == 0) {  // env/navigation1.py:41-42
+        const bool xr = (-100.0 <= x) & (x <= 150.0);
+        const bool top = xr & (5.0 <= y) & (y <= 10.0);
+        const bool bot = xr & (-10.0 <= y) & (y <= -5.0);
+        const bool left = (-100.0 <= x) & (x <= -80.0) & (-10.0 <= y) & (y <= 10.0);
+        return top | bot | left;
+    } else {  // env/navigation2.py:41
+        return (-30.0 <= x) & (x <= -20.0) & (-7.5 <= y) & (y <= 7.5);
+    }
+}
+
+__device__ __forceinline__ double clamp_unit(double v) {
+    return v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+}
+
+// One transition of Navigation1/2 (env/navigation1.py:71-89,99-110).
+template <int KIND>
+__device__ __forceinline__ void nav_transition(double x, double y, double ax, double ay, double ex,
+                                               double ey, double& nx, double& ny, double& cost) {
+    ax = clamp_unit(ax);
+    ay = clamp_unit(ay);
+    if (in_obstacle<KIND>(x, y)) {  // stuck inside an obstacle, no noise applied (:100-102)
+        nx = x;
+        ny = y;
+    } else {
+        nx = (x + ax) + 0.05 * ex;
+        ny = (y + ay) + 0.05 * ey;
+    }
+    // -||s|| of the OLD state; the reference's norm is sqrt(ddot) with an FMA-accumulated dot
+    cost = -sqrt(fma(y, y, x * x));
+}
+
+__device__ __forceinline__ uint64_t effective_counter(uint64_t counter, const uint64_t* dev) {
+    return dev ? counter + *dev : counter;
+}
+
+// tick += inc by the last workgroup to finish (dev = {tick, ticket}); every workgroup read the
+// tick before taking its ticket, so none can observe the new value.
+__device__ __forceinline__ void advance_counter(uint64_t* dev, uint64_t inc) {
+    if (!dev || !inc) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long ticket = atomicAdd((unsigned long long*)&dev[1], 1ULL);
+        if (ticket == gridDim.x - 1) {
+            dev[0] += inc;
+            dev[1] = 0;
+            __threadfence();
+        }
+    }
+}
+
+}  // namespace rrl

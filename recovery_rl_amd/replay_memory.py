@@ -1,0 +1,134 @@
+"""Device-resident replay buffers: host-side mirror of recovery_rl/replay_memory.py over
+rrl_replay_push / rrl_replay_sample_gather / rrl_creplay_sample_gather.
+
+Same names and call shapes as the reference (`push`, `sample`, `__len__`), batched:
+`push` takes N rows per call (one row per env) and `sample` returns five CUDA tensors
+`(state[B,2], action[B,2], reward[B], next_state[B,2], mask[B])` instead of numpy arrays.
+Rows are float32, 32 B each, structure-of-arrays in HBM (1e6 rows = 32 MB).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class ReplayMemory:
+    """Ring buffer for the SAC task policy (replay_memory.py:11-33)."""
+
+    _WITH_POS_COUNTS = False
+    _SEED_SALT = 0  # the two buffers share one seed in the reference (replay_memory.py:16,41)
+
+    def __init__(self, capacity, seed, device="cuda", obs_dim=2, act_dim=2):
+        if obs_dim != 2 or act_dim != 2:
+            raise ValueError("the HIP replay rows are laid out for 2-D states and actions")
+        self.device = _lib.require_gpu(device)
+        self.lib = _lib.load()
+        self.capacity = int(capacity)
+        self.seed = (int(seed) ^ self._SEED_SALT) & 0xFFFFFFFFFFFFFFFF
+        cap, dev = self.capacity, self.device
+        self.s = torch.zeros(cap, 2, dtype=torch.float32, device=dev)
+        self.a = torch.zeros(cap, 2, dtype=torch.float32, device=dev)
+        self.r = torch.zeros(cap, dtype=torch.float32, device=dev)
+        self.s2 = torch.zeros(cap, 2, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(cap, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(4, dtype=torch.int64, device=dev)   # position, size, ticket, error
+        self.tick = torch.zeros(2, dtype=torch.int64, device=dev)    # sampling RNG tick
+        self.pos_cnt = (torch.zeros((cap + 63) // 64, dtype=torch.int32, device=dev)
+                        if self._WITH_POS_COUNTS else None)
+        self._desc = _lib.rrl_replay_t(self.s.data_ptr(), self.a.data_ptr(), self.r.data_ptr(),
+                                       self.s2.data_ptr(), self.m.data_ptr(), cap,
+                                       self.state.data_ptr(),
+                                       self.pos_cnt.data_ptr() if self.pos_cnt is not None else None)
+        self._len = 0          # host mirror of `size`; exact unless masked pushes were used
+        self._len_exact = True
+        self._scratch = None
+        self._out = {}
+
+    # -- push ---------------------------------------------------------------------------------
+    def push(self, state, action, reward, next_state, done, valid=None):
+        """Append N rows (row i = env i). `done` is the reference's 5th tuple field: the
+        bootstrap mask float(not done) (experiment.py:434,439)."""
+        n = int(reward.shape[0])
+        for x in (state, action, reward, next_state, done):
+            assert x.dtype == torch.float32 and x.is_contiguous() and x.device == self.s.device
+        scratch = None
+        if valid is not None:
+            assert valid.dtype == torch.uint8 and valid.is_contiguous()
+            need = (n + 1023) // 1024 + 1
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.zeros(need, dtype=torch.int32, device=self.device)
+            scratch = self._scratch
+            self._len_exact = False
+        rc = self.lib.rrl_replay_push(C.byref(self._desc), n, _lib.ptr(state), _lib.ptr(action),
+                                      _lib.ptr(reward), _lib.ptr(next_state), _lib.ptr(done),
+                                      _lib.ptr(valid), _lib.ptr(scratch), _lib.current_stream())
+        _lib.check(rc, "rrl_replay_push")
+        if valid is None:
+            self._len = min(self._len + n, self.capacity)
+
+    def __len__(self):
+        if not self._len_exact:
+            self._len = int(self.state[1].item())
+            self._len_exact = True
+        return self._len
+
+    @property
+    def position(self):
+        return int(self.state[0].item())
+
+    def check_error(self):
+        """Raise if a sampler flagged an error on the device (one sync)."""
+        code = int(self.state[3].item())
+        if code == 1:
+            raise ValueError("Sample larger than population or is negative")
+        if code:
+            raise _lib.RRLError("replay sampler error flag %d" % code)
+
+    # -- sample -------------------------------------------------------------------------------
+    def _batch(self, B):
+        if B not in self._out:
+            dev = self.device
+            self._out[B] = (torch.empty(B, 2, dtype=torch.float32, device=dev),
+                            torch.empty(B, 2, dtype=torch.float32, device=dev),
+                            torch.empty(B, dtype=torch.float32, device=dev),
+                            torch.empty(B, 2, dtype=torch.float32, device=dev),
+                            torch.empty(B, dtype=torch.float32, device=dev),
+                            torch.empty(B, dtype=torch.int64, device=dev))
+        return self._out[B]
+
+    def sample(self, batch_size, out=None):
+        """B distinct uniform rows (random.sample semantics, replay_memory.py:27-30).
+        Returns persistent batch tensors (overwritten by the next sample of the same size)."""
+        B = int(batch_size)
+        if self._len_exact and B > self._len:
+            raise ValueError("Sample larger than population or is negative")
+        s, a, r, s2, m, idx = out if out is not None else self._batch(B)
+        rc = self.lib.rrl_replay_sample_gather(C.byref(self._desc), B, self.seed, 0,
+                                               _lib.ptr(self.tick), 1, _lib.ptr(s), _lib.ptr(a),
+                                               _lib.ptr(r), _lib.ptr(s2), _lib.ptr(m), _lib.ptr(idx),
+                                               _lib.current_stream())
+        _lib.check(rc, "rrl_replay_sample_gather")
+        return s, a, r, s2, m
+
+
+class ConstraintReplayMemory(ReplayMemory):
+    """Ring buffer for the safety critic (replay_memory.py:36-75): `reward` holds the constraint
+    indicator and `sample(..., pos_fraction)` stratifies on it."""
+
+    _WITH_POS_COUNTS = True
+    _SEED_SALT = 0x9E3779B97F4A7C15  # decorrelate its index stream from the task buffer's
+
+    def sample(self, batch_size, pos_fraction=None, out=None):
+        if pos_fraction is None:
+            return super().sample(batch_size, out=out)
+        B = int(batch_size)
+        n_pos = int(B * pos_fraction)          # replay_memory.py:56-57
+        n_neg = B - n_pos
+        s, a, r, s2, m, idx = out if out is not None else self._batch(B)
+        rc = self.lib.rrl_creplay_sample_gather(C.byref(self._desc), n_pos, n_neg, self.seed, 0,
+                                                _lib.ptr(self.tick), 1, _lib.ptr(s), _lib.ptr(a),
+                                                _lib.ptr(r), _lib.ptr(s2), _lib.ptr(m),
+                                                _lib.ptr(idx), _lib.current_stream())
+        _lib.check(rc, "rrl_creplay_sample_gather")
+        return s, a, r, s2, m

@@ -1,0 +1,65 @@
+"""CPU suite: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/rrl_hip.h declares.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+from recovery_rl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "rrl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rrl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    _lib.build()
+    assert os.path.exists(_lib.SO_PATH)
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    names = _declared()
+    assert len(names) >= 10
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_loader_declares_signatures_and_abi_version():
+    lib = _lib.load()
+    assert lib.rrl_abi_version() >= 1
+    assert lib.rrl_nav_offline_rollouts(0, 20000) == 2000
+    assert lib.rrl_nav_offline_rollouts(1, 20000) == 666 + 4 * 500
+    assert lib.rrl_nav_offline_rollouts(7, 10) < 0            # unknown env kind -> error code
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    # null pointers / bad kinds are rejected before any launch
+    assert lib.rrl_nav_step(9, 4, None, None, None, 0, 0, None, 0, None, None, None, None, None, None,
+                            None, None, 100, 0, None) == -1
+    assert lib.rrl_nav_step(0, 4, None, None, None, 0, 0, None, 0, None, None, None, None, None, None,
+                            None, None, 100, 0, None) == -1
+    assert lib.rrl_counter_add(None, 1, None) == -1
+
+
+def test_product_has_no_cpu_fallback():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from recovery_rl_amd.env import make_vec_env
+    with pytest.raises(_lib.RRLError):
+        make_vec_env("navigation1", 4, device="cuda")
+    with pytest.raises(_lib.RRLError):
+        make_vec_env("navigation1", 4, device="cpu")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "recovery_rl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower() or f in (), (dirpath, f)

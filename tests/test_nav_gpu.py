@@ -1,0 +1,200 @@
+"""GPU parity tests for the navigation kernels: HIP (through the C ABI) vs the golden vectors
+captured from the reference, and vs the C oracle on seeded inputs.  Bit-exact throughout."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from recovery_rl_amd import _lib
+from recovery_rl_amd.env import make_env, make_vec_env, register_env
+from recovery_rl_amd.env.navigation import offline_data
+
+pytestmark = pytest.mark.gpu
+ENVS = ("navigation1", "navigation2")
+DEV = "cuda:0"
+
+
+def hip_step(env_name, pos, action, t, noise=None, seed=0, counter=0, horizon=100, auto_reset=False,
+             tick=None, inc=0):
+    lib = _lib.load()
+    n = len(pos)
+    d = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=DEV)
+    pos_t, act_t, t_t = d(pos, np.float64), d(action, np.float32), d(t, np.int32)
+    noise_t = None if noise is None else d(noise, np.float64)
+    o = dict(next_obs=torch.zeros(n, 2, device=DEV), obs=torch.zeros(n, 2, device=DEV),
+             reward=torch.zeros(n, device=DEV))
+    for k in ("done", "constraint", "success", "ep_done"):
+        o[k] = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    rc = lib.rrl_nav_step(co.ENV_KIND[env_name], n, _lib.ptr(pos_t), _lib.ptr(act_t), _lib.ptr(noise_t),
+                          seed, counter, _lib.ptr(tick), inc, _lib.ptr(o["next_obs"]), _lib.ptr(o["obs"]),
+                          _lib.ptr(o["reward"]), _lib.ptr(o["done"]), _lib.ptr(o["constraint"]),
+                          _lib.ptr(o["success"]), _lib.ptr(o["ep_done"]), _lib.ptr(t_t), horizon,
+                          int(auto_reset), _lib.current_stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in o.items()}
+    out["pos"], out["t"] = pos_t.cpu().numpy(), t_t.cpu().numpy()
+    return out
+
+
+def assert_same(a, b, keys=("pos", "t", "next_obs", "obs", "reward", "done", "constraint", "success", "ep_done")):
+    for k in keys:
+        assert np.array_equal(a[k], b[k]), "%s differs in %d rows" % (k, int((a[k] != b[k]).sum()))
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_step_matches_reference_golden_bit_exact(env, golden_dir):
+    """G1: explicit (s, a, eps) rows incl. every box edge +-ulp, the stuck-in-obstacle branch and
+    ||s|| straddling 4.  Masks bit-exact; s' and reward equal to the fp64 reference rounded to f32."""
+    g = np.load(os.path.join(golden_dir, "nav_step_golden.npz"))
+    S, A, E = g[env + "_s"], g[env + "_a"], g[env + "_eps"]
+    o = hip_step(env, S, A, np.zeros(len(S), np.int32), noise=E)
+    assert np.array_equal(o["pos"], g[env + "_s2"])                     # fp64 state, exact
+    assert np.array_equal(o["next_obs"], g[env + "_s2"].astype(np.float32))
+    assert np.array_equal(o["reward"], g[env + "_reward"].astype(np.float32))
+    for k in ("done", "constraint", "success"):
+        assert np.array_equal(o[k], g[env + "_" + k]), k
+
+
+@pytest.mark.parametrize("env", ENVS)
+@pytest.mark.parametrize("n", (1, 63, 64, 257, 4096, 100003))
+def test_step_matches_oracle_with_philox_noise(env, n):
+    rng = np.random.RandomState(n)
+    pos = np.c_[rng.uniform(-60, 10, n), rng.uniform(-12, 12, n)]
+    act = rng.uniform(-1.5, 1.5, (n, 2)).astype(np.float32)
+    t = rng.randint(0, 100, n).astype(np.int32)
+    for auto in (False, True):
+        ref = co.nav_step(env, pos, act, t, seed=0xDEADBEEF12345, counter=17, auto_reset=auto)
+        got = hip_step(env, pos, act, t, seed=0xDEADBEEF12345, counter=17, auto_reset=auto)
+        assert_same(got, ref)
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_trajectories_stay_bit_identical_over_an_episode(env):
+    """300 lock-step vector steps with auto-reset through the host mirror (VecEnv) vs the oracle:
+    state, masks and the device-side RNG tick must never drift."""
+    n = 1024
+    venv = make_vec_env(env, n, device=DEV, seed=99)
+    venv.reset()
+    pos = venv.pos.cpu().numpy().copy()
+    t = np.zeros(n, np.int32)
+    ref_pos, _, _ = co.nav_reset(env, n, seed=99, counter=0)
+    assert np.array_equal(pos, ref_pos)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    viol = succ = 0
+    for k in range(300):
+        act = venv.sample_actions(g) * 1.2 + torch.tensor([0.9, 0.0], device=DEV)
+        obs, rew, done, info = venv.step(act.contiguous())
+        ref = co.nav_step(env, pos, act.cpu().numpy(), t, seed=99, counter=1 + k, auto_reset=True)
+        pos, t = ref["pos"], ref["t"]
+        assert np.array_equal(venv.pos.cpu().numpy(), pos), k
+        assert np.array_equal(venv.t.cpu().numpy(), t)
+        assert np.array_equal(rew.cpu().numpy(), ref["reward"])
+        assert np.array_equal(done.cpu().numpy(), ref["done"])
+        assert np.array_equal(info["constraint"].cpu().numpy(), ref["constraint"])
+        assert np.array_equal(info["ep_done"].cpu().numpy(), ref["ep_done"])
+        assert np.array_equal(info["next_state"].cpu().numpy(), ref["next_obs"])
+        assert np.array_equal(obs.cpu().numpy(), ref["obs"])
+        viol += int(ref["constraint"].sum())
+        succ += int(ref["success"].sum())
+    assert int(venv.tick[0].item()) == 301 and int(venv.tick[1].item()) == 0
+    assert viol > 0
+
+
+def test_reset_matches_oracle_and_mask():
+    lib = _lib.load()
+    n = 5000
+    pos = torch.full((n, 2), 7.0, dtype=torch.float64, device=DEV)
+    obs = torch.zeros(n, 2, device=DEV)
+    t = torch.full((n,), 5, dtype=torch.int32, device=DEV)
+    mask = (torch.arange(n, device=DEV) % 3 == 0).to(torch.uint8)
+    assert lib.rrl_nav_reset(0, n, _lib.ptr(pos), _lib.ptr(obs), _lib.ptr(t), _lib.ptr(mask), None, 42, 9,
+                             None, _lib.current_stream()) == 0
+    ref_pos, ref_obs, _ = co.nav_reset("navigation1", n, seed=42, counter=9)
+    m = mask.cpu().numpy().astype(bool)
+    assert np.array_equal(pos.cpu().numpy()[m], ref_pos[m])
+    assert np.array_equal(obs.cpu().numpy()[m], ref_obs[m])
+    assert (pos.cpu().numpy()[~m] == 7.0).all() and (t.cpu().numpy()[~m] == 5).all()
+    assert (t.cpu().numpy()[m] == 0).all()
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_rollout_kernel_matches_oracle(env):
+    lib = _lib.load()
+    n, T = 3000, 12
+    rng = np.random.RandomState(3)
+    pos = np.c_[rng.uniform(-60, 10, n), rng.uniform(-6, 6, n)]
+    acts = rng.uniform(-1.2, 1.2, (T, n, 2)).astype(np.float32)
+    ref = co.nav_rollout(env, pos, acts, seed=77, counter=1000)
+    pos_t = torch.as_tensor(pos, device=DEV)
+    acts_t = torch.as_tensor(acts, device=DEV)
+    obs = torch.zeros(T, n, 2, device=DEV)
+    rew = torch.zeros(T, n, device=DEV)
+    cons = torch.zeros(T, n, dtype=torch.uint8, device=DEV)
+    done = torch.zeros(T, n, dtype=torch.uint8, device=DEV)
+    assert lib.rrl_nav_rollout(co.ENV_KIND[env], n, T, _lib.ptr(pos_t), _lib.ptr(acts_t), 77, 1000, None,
+                               _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(cons), _lib.ptr(done),
+                               _lib.current_stream()) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(pos_t.cpu().numpy(), ref["pos"])
+    assert np.array_equal(obs.cpu().numpy(), ref["obs"])
+    assert np.array_equal(rew.cpu().numpy(), ref["reward"])
+    assert np.array_equal(cons.cpu().numpy(), ref["constraint"])
+    assert np.array_equal(done.cpu().numpy(), ref["done"])
+
+
+@pytest.mark.parametrize("env", ENVS)
+@pytest.mark.parametrize("num", (0, 9, 1000, 20000))
+def test_offline_data_matches_oracle(env, num):
+    s, a, c, s2, m = (x.cpu().numpy() for x in offline_data(env, num, seed=1, device=DEV))
+    rs, ra, rc_, rs2, rm = co.nav_offline(env, num, 1)
+    assert len(s) == len(rs)
+    for got, ref in ((s, rs), (a, ra), (c, rc_), (s2, rs2), (m, rm)):
+        assert np.array_equal(got, ref)
+
+
+def test_single_env_gym_protocol_reads_like_the_reference():
+    """make_env/register_env (env/make_utils.py:23-31) and reset/step/info keys
+    (env/navigation1.py:71-97)."""
+    with pytest.raises(KeyError):
+        register_env("no_such_env")
+    register_env("navigation1")
+    env = make_env("navigation1", device=DEV, seed=0)
+    assert env._max_episode_steps == 100 and env.action_space.shape == (2,)
+    assert env.observation_space.shape == (2,) and list(env.goal) == [0, 0]
+    s = env.reset()
+    assert s.shape == (2,) and s.dtype == np.float64 and abs(s[0] + 50) < 6
+    obs, r, done, info = env.step(np.array([2.0, -3.0]))
+    assert set(info) == {"constraint", "reward", "state", "next_state", "action", "success"}
+    assert np.array_equal(info["action"], [1.0, -1.0]) and np.array_equal(info["state"], s)
+    assert np.isclose(r, -np.hypot(*s)) and not done
+    assert np.allclose(obs - s, [1, -1], atol=0.4)
+    data = env.transition_function(200)
+    assert len(data) > 50 and len(data[0]) == 5
+
+
+def test_full_size_properties_4096x100():
+    """BASELINE size (4096 envs, 100-step horizon): properties that need no oracle run."""
+    n = 4096
+    env = make_vec_env("navigation1", n, device=DEV, seed=1)
+    obs = env.reset()
+    ep_ends = torch.zeros(n, device=DEV)
+    for k in range(100):
+        prev = obs.clone()
+        act = torch.zeros(n, 2, device=DEV)
+        act[:, 0] = 1.0
+        obs, rew, done, info = env.step(act)
+        # reward is -||previous obs|| (f64 state rounded): tight tolerance
+        assert torch.allclose(rew, -prev.double().norm(dim=1).float(), rtol=0, atol=2e-5)
+        assert torch.equal(info["ep_done"] >= done, torch.ones_like(done, dtype=torch.bool))
+        moved = info["next_state"] - prev
+        stuck = info["constraint"].bool() & (moved.abs().sum(1) == 0)
+        free = ~stuck
+        assert (moved[free, 0] - 1.0).abs().max() < 0.4          # 0.05 * |N(0,1)| < 0.4
+        ep_ends += info["ep_done"].float()
+    assert (env.t <= 100).all() and (env.t >= 0).all()
+    # driving right at unit speed from x=-50 reaches the goal radius (4) after ~46 steps
+    assert ep_ends.min() >= 1 and ep_ends.max() <= 4

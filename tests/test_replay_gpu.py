@@ -1,0 +1,174 @@
+"""GPU parity tests for the device replay kernels vs the C oracle (bit-exact rows and indices)
+and vs the reference's golden semantics (tests/golden/replay_golden.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rows(rng, n, pos_rate=0.0):
+    s = rng.randn(n, 2).astype(np.float32)
+    a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    r = (rng.uniform(size=n) < pos_rate).astype(np.float32) if pos_rate else rng.randn(n).astype(np.float32)
+    s2 = rng.randn(n, 2).astype(np.float32)
+    m = (rng.uniform(size=n) < 0.9).astype(np.float32)
+    return s, a, r, s2, m
+
+
+def dev(xs):
+    return [torch.as_tensor(x, device=DEV) for x in xs]
+
+
+def assert_buffers_equal(mem, ora):
+    assert len(mem) == len(ora) and mem.position == ora.pos
+    for got, ref in ((mem.s, ora.s), (mem.a, ora.a), (mem.r, ora.r), (mem.s2, ora.s2), (mem.m, ora.m)):
+        assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_ring_semantics_rowwise(golden_dir):
+    g = np.load(os.path.join(golden_dir, "replay_golden.npz"))
+    mem = ReplayMemory(10, 3, device=DEV)
+    for lo, hi in ((0, 7), (7, 13)):
+        i = np.arange(lo, hi, dtype=np.float32)
+        mem.push(*dev([np.c_[i, i], np.c_[-i, -i], 100 + i, np.c_[i + .5, i + .5], (i % 2).astype(np.float32)]))
+    assert len(mem) == int(g["ring_len"]) and mem.position == int(g["ring_position"])
+    assert np.array_equal(mem.r.cpu().numpy(), g["ring_rewards_by_slot"].astype(np.float32))
+    assert np.array_equal(mem.m.cpu().numpy(), g["ring_masks_by_slot"].astype(np.float32))
+    with pytest.raises(ValueError):
+        mem.sample(11)                       # random.sample raises (golden: oversample_raises)
+    assert int(g["oversample_raises"]) == 1
+    big = rows(np.random.RandomState(0), 13)
+    with pytest.raises(Exception):
+        mem.push(*dev(big))                  # more rows than capacity in one call is rejected
+
+
+@pytest.mark.parametrize("cap,chunks", ((1000, (300, 300, 300, 300, 1000)), (5000, (4096, 4096, 7)),
+                                        (70000, (65536, 4096, 4096))))
+def test_push_matches_oracle_including_wraparound(cap, chunks):
+    rng = np.random.RandomState(cap)
+    mem, ora = ConstraintReplayMemory(cap, 1, device=DEV), co.OracleReplay(cap)
+    for n in chunks:
+        b = rows(rng, n, pos_rate=0.07)
+        mem.push(*dev(b))
+        ora.push(*b)
+        assert_buffers_equal(mem, ora)
+        # per-chunk positive counts stay exact
+        filled = ora.r[:len(ora)] != 0
+        ref_cnt = np.add.reduceat(np.r_[filled, np.zeros((-len(filled)) % 64, bool)].astype(np.int32),
+                                  np.arange(0, len(filled), 64)) if len(filled) else np.zeros(0)
+        got = mem.pos_cnt.cpu().numpy()
+        assert np.array_equal(got[:len(ref_cnt)], ref_cnt) and not got[len(ref_cnt):].any()
+
+
+def test_masked_push_matches_oracle():
+    rng = np.random.RandomState(5)
+    mem, ora = ConstraintReplayMemory(9000, 1, device=DEV), co.OracleReplay(9000)
+    for n in (4096, 4096, 4096, 1, 2500):
+        b = rows(rng, n, pos_rate=0.2)
+        valid = (rng.uniform(size=n) < 0.37).astype(np.uint8)
+        mem.push(*dev(b), valid=torch.as_tensor(valid, device=DEV))
+        ora.push(*b, valid=valid)
+        assert_buffers_equal(mem, ora)
+    b = rows(rng, 64, pos_rate=0.2)
+    mem.push(*dev(b), valid=torch.zeros(64, dtype=torch.uint8, device=DEV))   # nothing valid
+    assert_buffers_equal(mem, ora)
+
+
+@pytest.mark.parametrize("B", (1, 64, 100, 256, 1024))
+def test_uniform_sample_indices_and_rows_match_oracle(B):
+    rng = np.random.RandomState(B)
+    cap = 50000
+    mem, ora = ReplayMemory(cap, 77, device=DEV), co.OracleReplay(cap)
+    b = rows(rng, 30000)
+    mem.push(*dev(b))
+    ora.push(*b)
+    for call in range(4):
+        s, a, r, s2, m = mem.sample(B)
+        idx = mem._batch(B)[5].cpu().numpy()
+        ref_idx = ora.sample_indices(B, seed=77, counter=call)
+        assert np.array_equal(idx, ref_idx)
+        assert len(set(idx)) == B
+        for got, ref in zip((s, a, r, s2, m), ora.gather(ref_idx)):
+            assert np.array_equal(got.cpu().numpy(), ref)
+    assert int(mem.tick[0].item()) == 4
+
+
+def test_sample_when_batch_equals_population_is_a_permutation():
+    mem = ReplayMemory(300, 5, device=DEV)
+    rng = np.random.RandomState(0)
+    mem.push(*dev(rows(rng, 256)))
+    mem.sample(256)
+    idx = mem._batch(256)[5].cpu().numpy()
+    assert sorted(idx) == list(range(256))
+    ora = co.OracleReplay(300)
+    ora.push(*rows(np.random.RandomState(0), 256))
+    assert np.array_equal(idx, ora.sample_indices(256, seed=5, counter=0))
+
+
+def test_device_error_flag_when_oversampling_after_masked_push():
+    mem = ReplayMemory(300, 5, device=DEV)
+    rng = np.random.RandomState(0)
+    valid = torch.zeros(100, dtype=torch.uint8, device=DEV)
+    valid[:10] = 1
+    mem.push(*dev(rows(rng, 100)), valid=valid)
+    mem._len_exact = False                       # host does not know the size: the device must flag
+    mem.sample(64)
+    with pytest.raises(ValueError):
+        mem.check_error()
+
+
+def test_stratified_sample_matches_oracle_and_reference_composition(golden_dir):
+    g = np.load(os.path.join(golden_dir, "replay_golden.npz"))
+    n = len(g["constraint"])
+    z = np.zeros((n, 2), np.float32)
+    z[:, 0] = np.arange(n)
+    b = (z, z, g["constraint"].astype(np.float32), z, np.ones(n, np.float32))
+    mem, ora = ConstraintReplayMemory(4096, 1, device=DEV), co.OracleReplay(4096)
+    mem.push(*dev(b))
+    ora.push(*b)
+    B, pf = int(g["B"]), float(g["pos_fraction"])
+    for call in range(3):
+        s, a, r, s2, m = mem.sample(B, pos_fraction=pf)
+        idx = mem._batch(B)[5].cpu().numpy()
+        ref = ora.sample_stratified_indices(76, B - 76, seed=mem.seed, counter=call)
+        assert np.array_equal(idx, ref)
+        r = r.cpu().numpy()
+        assert r[:76].all() and not r[76:].any() and len(set(idx)) == B       # G6 composition
+        assert np.array_equal(s.cpu().numpy()[:, 0], idx.astype(np.float32))
+    mem.check_error()
+
+
+def test_stratified_sample_on_wrapped_million_row_buffer():
+    """Reference default capacity 1e6, pushed past wrap-around in 4096-row vector steps."""
+    cap = 1000000
+    rng = np.random.RandomState(1)
+    mem, ora = ConstraintReplayMemory(cap, 3, device=DEV), co.OracleReplay(cap)
+    for k in range(4):
+        n = 300000
+        b = rows(rng, n, pos_rate=0.03)
+        mem.push(*dev(b))
+        ora.push(*b)
+    assert len(mem) == cap and mem.position == ora.pos
+    s, a, r, s2, m = mem.sample(256, pos_fraction=0.3)
+    idx = mem._batch(256)[5].cpu().numpy()
+    assert np.array_equal(idx, ora.sample_stratified_indices(76, 180, seed=mem.seed, counter=0))
+    assert np.array_equal(r.cpu().numpy(), ora.r[idx])
+    mem.check_error()
+
+
+def test_sampling_is_uniform():
+    mem = ReplayMemory(4096, 9, device=DEV)
+    mem.push(*dev(rows(np.random.RandomState(0), 4096)))
+    hits = torch.zeros(4096, device=DEV)
+    for _ in range(400):
+        mem.sample(256)
+        hits[mem._batch(256)[5]] += 1
+    h = hits.cpu().numpy()
+    assert abs(h.mean() - 25.0) < 1e-6 and 3.5 < h.std() < 6.5    # binomial(400, 1/16): std 4.84
