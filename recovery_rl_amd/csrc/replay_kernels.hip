@@ -387,11 +387,12 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
     int threads = ((B + 63) / 64) * 64;
     if (threads < 256) threads = 256;
     const size_t lds = size_t(B) * 8 + size_t(n_chunks + 1) * 4 + size_t(threads) * 4 + size_t(B) + 16;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)creplay_sample_gather_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opt in above the 64 KiB default
+        if (hipFuncSetAttribute((const void*)creplay_sample_gather_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
+            (void)hipGetLastError();
+            return RRL_ERANGE;
+        }
     }
     const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out};
     hipLaunchKernelGGL(creplay_sample_gather_kernel, dim3(1), dim3(threads), lds,
