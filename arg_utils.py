@@ -1,0 +1,98 @@
+"""Command-line surface of `python -m rrl_main` -- flag-for-flag the reference's
+arg_utils.get_args (arg_utils.py:8-257): same 55 flags, names, types, defaults and the same
+argparse quirks (`--eval` / `--automatic_entropy_tuning` are `type=bool`, so any non-empty
+string is True; prefix matching lets scripts write `--lambda 1000`).  The three flags in
+ADDITIVE are new and default to the reference's behaviour.
+"""
+import argparse
+
+F, I, S = float, int, None
+# (flags, type-or-'store_true'-or-'append2', default, help)
+REFERENCE_FLAGS = [
+    # global
+    (("--env-name",), S, "maze", "Gym environment (default: maze)"),
+    (("--logdir",), S, "runs", "exterior log directory"),
+    (("--logdir_suffix",), S, "", "log directory suffix"),
+    (("--cuda",), "store_true", None, "run on the GPU (ROCm keeps the 'cuda' device name)"),
+    (("--cnn",), "store_true", None, "visual observations (out of scope here)"),
+    (("--lr",), F, 0.0003, "learning rate"),
+    (("--updates_per_step",), I, 1, "model updates per simulator step"),
+    (("--start_steps",), I, 100, "steps sampling random actions"),
+    (("--target_update_interval",), I, 1, "value target update per no. of updates per step"),
+    # task policy (SAC)
+    (("--policy",), S, "Gaussian", "Gaussian | Deterministic"),
+    (("--eval",), bool, True, "evaluate the policy every 10 episodes"),
+    (("--gamma",), F, 0.99, "discount factor for reward"),
+    (("--tau",), F, 0.005, "target smoothing coefficient"),
+    (("--alpha",), F, 0.2, "entropy temperature"),
+    (("--automatic_entropy_tuning",), bool, False, "automatically adjust alpha"),
+    (("--seed",), I, 123456, "random seed"),
+    (("--batch_size",), I, 256, "batch size"),
+    (("--num_steps",), I, 1000000, "maximum number of steps"),
+    (("--num_eps",), I, 1000000, "maximum number of episodes"),
+    (("--hidden_size",), I, 256, "hidden size"),
+    (("--replay_size",), I, 1000000, "size of replay buffer"),
+    (("--task_demos",), "store_true", None, "use task demos to pretrain the task critic"),
+    (("--num_task_transitions",), I, 10000000, "number of task transitions"),
+    (("--critic_pretraining_steps",), I, 3000, "gradient steps for critic pretraining"),
+    # Q risk
+    (("--pos_fraction",), F, -1, "fraction of positive examples for critic training"),
+    (("--gamma_safe",), F, 0.5, "discount factor for constraints"),
+    (("--eps_safe",), F, 0.1, "Qrisk threshold"),
+    (("--tau_safe",), F, 0.0002, "Qrisk target smoothing coefficient"),
+    (("--safe_replay_size",), I, 1000000, "size of replay buffer for Qrisk"),
+    (("--num_unsafe_transitions",), I, 10000, "number of unsafe transitions"),
+    (("--critic_safe_pretraining_steps",), I, 10000, "gradient steps for Qrisk pretraining"),
+    # recovery
+    (("--use_recovery",), "store_true", None, "use recovery policy"),
+    (("--MF_recovery",), "store_true", None, "model free recovery policy"),
+    (("--Q_sampling_recovery",), "store_true", None, "sample actions over Qrisk for recovery"),
+    (("-ca", "--ctrl_arg"), "append2", [], "controller arguments (parsed, inert -- as in the reference)"),
+    (("-o", "--override"), "append2", [], "config overrides (parsed, inert -- as in the reference)"),
+    (("--recovery_policy_update_freq",), I, 1, "model updated every this many episodes"),
+    (("--vismpc_recovery",), "store_true", None, "visual model-based recovery (out of scope here)"),
+    (("--load_vismpc",), "store_true", None, "load pre-trained visual dynamics model"),
+    (("--model_fname",), S, "image_maze_dynamics", "path to pre-trained visual dynamics model"),
+    (("--beta",), F, 10, "beta for the visual dynamics VAE"),
+    # ablations
+    (("--disable_offline_updates",), "store_true", None, "only train Qrisk online"),
+    (("--disable_online_updates",), "store_true", None, "only train Qrisk on offline data"),
+    (("--disable_action_relabeling",), "store_true", None, "train task policy on recovery policy actions"),
+    (("--add_both_transitions",), "store_true", None, "use both task and recovery transitions"),
+    # comparisons
+    (("--constraint_reward_penalty",), F, 0, "reward penalty when a constraint is violated"),
+    (("--DGD_constraints",), "store_true", None, "dual gradient descent on task reward + constraints"),
+    (("--use_constraint_sampling",), "store_true", None, "sample actions with task policy, filter with Qrisk"),
+    (("--nu",), F, 0.01, "penalty term in Lagrangian objective"),
+    (("--update_nu",), "store_true", None, "update Lagrangian penalty term"),
+    (("--nu_schedule",), "store_true", None, "linear schedule for nu"),
+    (("--nu_start",), F, 1e3, "start value for nu"),
+    (("--nu_end",), F, 0, "end value for nu"),
+    (("--RCPO",), "store_true", None, "use RCPO"),
+    (("--lambda_RCPO",), F, 0.01, "penalty term for RCPO"),
+]
+
+ADDITIVE = [
+    (("--num_envs",), I, 1, "independent envs advanced in lock-step on the GPU (1 = reference loop)"),
+    (("--log_every",), I, 0, "vector steps between metric aggregations across ranks (0 = per episode)"),
+    (("--mb_dynamics",), S, "model", "CEM rollouts through the learned ensemble ('model', reference) "
+                                     "or the env kernels ('env', extension)"),
+]
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Recovery RL Arguments')
+    for flags, kind, default, help_ in REFERENCE_FLAGS + ADDITIVE:
+        if kind == "store_true":
+            parser.add_argument(*flags, action='store_true', help=help_)
+        elif kind == "append2":
+            parser.add_argument(*flags, action='append', nargs=2, default=default, help=help_)
+        elif kind is None:
+            parser.add_argument(*flags, default=default, help=help_)
+        else:
+            parser.add_argument(*flags, type=kind, default=default, help=help_)
+    return parser
+
+
+def get_args(argv=None):
+    return build_parser().parse_args(argv)

@@ -1,0 +1,192 @@
+"""SAC task agent with the Recovery-RL hooks (reference: recovery_rl/sac.py).
+
+Same constructor and method names as the reference's `SAC` -- `select_action(state, eval)`,
+`update_parameters(memory, batch_size, updates, nu, safety_critic)` -- over batched CUDA
+tensors.  Differences that are deliberate and documented (DESIGN.md "SAC update order"):
+  * critic and policy gradients are BOTH taken at the pre-update weights, then both
+    optimisers step.  The reference builds policy_loss before critic_optim.step() and
+    back-propagates it afterwards (sac.py:216-239), which torch>=1.5 rejects and torch 1.4
+    silently evaluated at mixed weights;
+  * the five returned statistics are device tensors unless `as_floats=True` (the reference's
+    five `.item()` calls, sac.py:276-277, are five host syncs per update).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.optim import Adam
+
+from .model import DeterministicPolicy, GaussianPolicy, QNetwork
+from .qrisk import QRiskWrapper
+from .utils import hard_update, soft_update
+
+
+def _adam(params, lr, capturable):
+    return Adam(params, lr=lr, capturable=capturable, foreach=True)
+
+
+class SAC(object):
+    def __init__(self, observation_space, action_space, args, logdir, im_shape=None, tmp_env=None):
+        if getattr(args, "cnn", False):
+            raise NotImplementedError("image observations are outside the hot path (SURVEY.md section 2)")
+        self.gamma = args.gamma
+        self.tau = args.tau
+        self.alpha = args.alpha
+        self.env_name = args.env_name
+        self.logdir = logdir
+        self.policy_type = args.policy
+        self.target_update_interval = args.target_update_interval
+        self.automatic_entropy_tuning = args.automatic_entropy_tuning
+        self.device = torch.device("cuda" if args.cuda else "cpu")
+        self.updates = 0
+        capturable = self.device.type == "cuda"
+
+        self.gamma_safe = args.gamma_safe
+        self.eps_safe = args.eps_safe
+        self.DGD_constraints = args.DGD_constraints
+        self.nu = args.nu
+        self.update_nu = args.update_nu
+        self.use_constraint_sampling = args.use_constraint_sampling
+        # dual variables (sac.py:58-70): Adam at 0.1 * lr
+        self.log_nu = torch.tensor(np.log(self.nu), dtype=torch.float32, requires_grad=True,
+                                   device=self.device)
+        self.nu_optim = _adam([self.log_nu], 0.1 * args.lr, capturable)
+        self.RCPO = args.RCPO
+        self.lambda_RCPO = args.lambda_RCPO
+        self.log_lambda_RCPO = torch.tensor(np.log(self.lambda_RCPO), dtype=torch.float32,
+                                            requires_grad=True, device=self.device)
+        self.lambda_RCPO_optim = _adam([self.log_lambda_RCPO], 0.1 * args.lr, capturable)
+
+        d_obs, d_act = observation_space.shape[0], action_space.shape[0]
+        self.critic = QNetwork(d_obs, d_act, args.hidden_size).to(self.device)
+        self.critic_target = QNetwork(d_obs, d_act, args.hidden_size).to(self.device)
+        self.critic_optim = _adam(self.critic.parameters(), args.lr, capturable)
+        hard_update(self.critic_target, self.critic)
+
+        if self.policy_type == "Gaussian":
+            if self.automatic_entropy_tuning is True:
+                self.target_entropy = -float(np.prod(action_space.shape))     # -dim(A), sac.py:94-95
+                self.log_alpha = torch.zeros(1, requires_grad=True, device=self.device)
+                self.alpha_optim = _adam([self.log_alpha], args.lr, capturable)
+            self.policy = GaussianPolicy(d_obs, d_act, args.hidden_size, action_space).to(self.device)
+        else:
+            self.alpha = 0
+            self.automatic_entropy_tuning = False
+            self.policy = DeterministicPolicy(d_obs, d_act, args.hidden_size, action_space).to(self.device)
+        self.policy_optim = _adam(self.policy.parameters(), args.lr, capturable)
+
+        self.safety_critic = QRiskWrapper(observation_space, action_space, args.hidden_size, logdir,
+                                          args, tmp_env=tmp_env)
+
+    # -- acting ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def select_action(self, state, eval=False):
+        """Task action (sac.py:133-168).  [N,2] CUDA tensor in -> tensor out; a single numpy state
+        in -> numpy out (the reference's calling convention)."""
+        single = not torch.is_tensor(state)
+        if single:
+            state = torch.as_tensor(np.asarray(state, dtype=np.float32), device=self.device).unsqueeze(0)
+        if self.use_constraint_sampling:
+            action = self._sqrl_action(state)
+        else:
+            sampled, _, mean = self.policy.sample(state)
+            action = mean if eval else sampled
+        return action[0].cpu().numpy() if single else action
+
+    def _sqrl_action(self, state, safe_samples=100):
+        """SQRL rejection sampling (sac.py:139-161) for every env of the batch at once: draw 100
+        actions, keep those with Q_risk <= eps_safe and pick one with probability proportional to
+        exp(log pi); if none is safe take the argmin of Q_risk."""
+        n, k = state.shape[0], safe_samples
+        sb = state.unsqueeze(1).expand(n, k, state.shape[1]).reshape(n * k, -1)
+        pi, log_pi, _ = self.policy.sample(sb)
+        q = self.safety_critic.get_value(sb, pi).reshape(n, k)
+        w = torch.exp(log_pi.reshape(n, k)) * (q <= self.eps_safe)
+        none_safe = w.sum(1) <= 0
+        fallback = F.one_hot(q.argmin(1), k).to(w.dtype)
+        w = torch.where(none_safe.unsqueeze(1), fallback, w)
+        pick = torch.multinomial(w, 1).squeeze(1)
+        return pi.reshape(n, k, -1)[torch.arange(n, device=state.device), pick]
+
+    # -- learning ----------------------------------------------------------------------------
+    def update_parameters(self, memory, batch_size, updates, nu=None, safety_critic=None,
+                          batch=None, eps_next=None, eps_pi=None, as_floats=False):
+        """One SAC step (sac.py:170-277).  `batch` / `eps_*` inject a fixed batch and policy
+        noise (KAT tests)."""
+        if nu is None:
+            nu = self.nu
+        if batch is None:
+            batch = memory.sample(batch_size=batch_size)
+        state, action, reward, next_state, mask = batch
+        reward = reward.reshape(-1, 1)
+        mask = mask.reshape(-1, 1)
+
+        qsafe = None
+        with torch.no_grad():
+            next_action, next_log_pi, _ = self.policy.sample(next_state, eps_next)
+            q1n, q2n = self.critic_target(next_state, next_action)
+            min_qn = torch.min(q1n, q2n) - self.alpha * next_log_pi
+            next_q = reward + mask * self.gamma * min_qn                        # :199-201
+            if self.RCPO:                                                       # :202-205
+                qsafe = torch.max(*safety_critic(state, action))
+                next_q = next_q - self.lambda_RCPO * qsafe
+        q1, q2 = self.critic(state, action)
+        q1_loss = F.mse_loss(q1, next_q)
+        q2_loss = F.mse_loss(q2, next_q)
+
+        pi, log_pi, _ = self.policy.sample(state, eps_pi)
+        q1_pi, q2_pi = self.critic(state, pi)
+        min_q_pi = torch.min(q1_pi, q2_pi)
+        max_sqf_pi = None
+        if self.DGD_constraints or self.update_nu:
+            sq1, sq2 = self.safety_critic(state, pi)
+            max_sqf_pi = torch.max(sq1, sq2)
+        if self.DGD_constraints:                                                # :224-228
+            policy_loss = ((self.alpha * log_pi) + nu * (max_sqf_pi - self.eps_safe) - 1. * min_q_pi).mean()
+        else:
+            policy_loss = ((self.alpha * log_pi) - min_q_pi).mean()
+
+        # both gradients at the pre-update weights, then both steps
+        critic_params = list(self.critic.parameters())
+        policy_params = list(self.policy.parameters())
+        c_grads = torch.autograd.grad(q1_loss + q2_loss, critic_params)
+        p_grads = torch.autograd.grad(policy_loss, policy_params)
+        for p, g in zip(critic_params, c_grads):
+            p.grad = g
+        for p, g in zip(policy_params, p_grads):
+            p.grad = g
+        self.critic_optim.step()
+        self.policy_optim.step()
+
+        if self.automatic_entropy_tuning:                                       # :241-250
+            alpha_loss = -(self.log_alpha * (log_pi + self.target_entropy).detach()).mean()
+            self.alpha_optim.zero_grad(set_to_none=True)
+            alpha_loss.backward()
+            self.alpha_optim.step()
+            self.alpha = self.log_alpha.exp().detach()
+            alpha_t = self.alpha.clone().reshape(())
+        else:
+            alpha_loss = torch.zeros((), device=self.device)
+            alpha_t = torch.as_tensor(float(self.alpha), device=self.device)
+
+        if self.update_nu:                                                      # :256-262
+            nu_loss = (self.log_nu * (self.eps_safe - max_sqf_pi).detach()).mean()
+            self.nu_optim.zero_grad(set_to_none=True)
+            nu_loss.backward()
+            self.nu_optim.step()
+            self.nu = self.log_nu.exp().detach()
+
+        if self.RCPO:                                                           # :265-271
+            lam_loss = (self.log_lambda_RCPO * (self.eps_safe - qsafe).detach()).mean()
+            self.lambda_RCPO_optim.zero_grad(set_to_none=True)
+            lam_loss.backward()
+            self.lambda_RCPO_optim.step()
+            self.lambda_RCPO = self.log_lambda_RCPO.exp().detach()
+
+        if updates % self.target_update_interval == 0:                          # :273-274
+            soft_update(self.critic_target, self.critic, self.tau)
+
+        out = (q1_loss.detach(), q2_loss.detach(), policy_loss.detach(), alpha_loss.detach().reshape(()),
+               alpha_t)
+        if as_floats:
+            return tuple(float(x) for x in out)
+        return out
