@@ -1,0 +1,66 @@
+"""Multi-GPU fan-out: replicas only.  One process per GPU, each rank runs
+its own seed / env shard, replay and networks; the ONLY collective on the path is a small
+all-reduce(sum) of the counter vector at logging cadence (RCCL via torch.distributed backend
+"nccl" on the GPU box, gloo in the CPU tests)."""
+import os
+
+import torch
+
+METRIC_KEYS = ("env_steps", "episodes", "num_viols", "viol_and_recovery", "viol_and_no_recovery",
+               "num_successes", "recovery_steps", "constraint_steps", "sac_updates", "qrisk_updates",
+               "reward_sum", "episode_return_sum")
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), \
+        int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for one process)."""
+    import torch.distributed as dist
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def rank_seed(base_seed, rank):
+    """Rank g runs seed base+g -- the reference's unit of parallelism is the seed loop
+    (scripts/navigation1.sh:4-8)."""
+    return int(base_seed) + int(rank)
+
+
+def aggregate_stats(stats, world_size, device):
+    """Sum the metric vector over ranks: one 96-byte all-reduce (latency-bound; xGMI bandwidth is
+    irrelevant at this size, so it runs at logging cadence, never per step)."""
+    import torch.distributed as dist
+    if world_size <= 1 or not dist.is_initialized():
+        return dict(stats)
+    vec = torch.tensor([float(stats[k]) for k in METRIC_KEYS], dtype=torch.float64, device=device)
+    dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    out = dict(stats)
+    for k, v in zip(METRIC_KEYS, vec.tolist()):
+        out[k] = int(round(v)) if k not in ("reward_sum", "episode_return_sum") else v
+    return out
+
+
+def max_over_ranks(value, world_size, device):
+    import torch.distributed as dist
+    if world_size <= 1 or not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier(world_size):
+    import torch.distributed as dist
+    if world_size > 1 and dist.is_initialized():
+        dist.barrier()

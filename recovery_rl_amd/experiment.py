@@ -1,0 +1,499 @@
+"""Experiment driver (reference: recovery_rl/experiment.py:42-577).
+
+`Experiment(exp_cfg).run()` keeps the reference's surface: log-dir naming, args.pkl,
+run_stats.pkl, the printed lines, the update -> act -> step -> push order of one loop
+iteration and the counters.  Two loop bodies share the same building blocks:
+
+  * num_envs == 1: `get_train_rollout` / `get_test_rollout`, episode by episode, exactly the
+    reference's event order (experiment.py:379-491, 493-538);
+  * num_envs  > 1: `VectorLoop.vector_step`, all envs in lock-step with device-side counters
+    and no host synchronisation; once in steady state the whole iteration (replay sample ->
+    SAC update -> Q_risk update -> policy/Q_risk forward -> env step -> replay push ->
+    counters) is captured in ONE hipGraph and replayed.
+
+Vectorisation semantics (SURVEY.md section 8a "Vectorisation semantics"): every env has its own
+step count and Philox sub-stream and auto-resets where done or t == horizon; `start_steps`
+counts env-steps over all envs; one iteration performs `updates_per_step` updates, so the
+update-to-data ratio is updates_per_step / num_envs; episode-keyed events use the global
+completed-episode counter.
+"""
+import datetime
+import itertools
+import os
+import os.path as osp
+import pickle
+
+import numpy as np
+import torch
+
+from . import distributed as dist_utils
+from .env import make_env, make_vec_env, register_env
+from .replay_memory import ConstraintReplayMemory, ReplayMemory
+from .sac import SAC
+from .utils import linear_schedule
+
+# order of the device-side counter vector (also the RCCL-aggregated metric vector)
+STAT_KEYS = ("env_steps", "episodes", "num_viols", "viol_and_recovery", "viol_and_no_recovery",
+             "num_successes", "recovery_steps", "constraint_steps", "sac_updates", "qrisk_updates")
+
+
+def uses_constraint_buffer(cfg):
+    return cfg.use_recovery or cfg.DGD_constraints or cfg.RCPO          # experiment.py:442
+
+
+def uses_mb_recovery(cfg):
+    return cfg.use_recovery and not (cfg.MF_recovery or cfg.Q_sampling_recovery)   # :92-94
+
+
+class VectorLoop:
+    """One lock-step iteration over all envs, device-resident (counterpart of the body of
+    experiment.py:396-452 for N envs)."""
+
+    def __init__(self, cfg, env, agent, memory, recovery_memory, recovery_policy=None,
+                 nu_schedule=None):
+        self.cfg, self.env, self.agent = cfg, env, agent
+        self.memory, self.recovery_memory = memory, recovery_memory
+        self.recovery_policy = recovery_policy
+        self.nu_schedule = nu_schedule or (lambda ep: cfg.nu)
+        self.n = env.num_envs
+        dev = env.device
+        self.device = dev
+        self.obs = None
+        self.stats = torch.zeros(len(STAT_KEYS), dtype=torch.int64, device=dev)
+        self.reward_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.ep_reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.ep_return_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.total_numsteps = 0           # host mirror: every iteration adds num_envs
+        self.updates = 0
+        self.num_constraint_violations = 0  # offline violations pushed during pre-training
+        self.graph = None
+        self._one = torch.ones((), dtype=torch.int64, device=dev)
+
+    # -- pieces --------------------------------------------------------------------------------
+    def start(self):
+        self.obs = self.env.reset()
+        return self.obs
+
+    def do_updates(self, i_episode=1, online_qrisk=True):
+        """experiment.py:397-416.  The caller has checked len(memory) > batch_size."""
+        cfg = self.cfg
+        for _ in range(cfg.updates_per_step):
+            self.agent.update_parameters(self.memory, cfg.batch_size, self.updates,
+                                         safety_critic=self.agent.safety_critic,
+                                         nu=self.nu_schedule(i_episode))
+            self.stats[8] += self._one
+            if online_qrisk:
+                self.agent.safety_critic.update_parameters(memory=self.recovery_memory,
+                                                           policy=self.agent.policy,
+                                                           batch_size=cfg.batch_size, plot=0)
+                self.stats[9] += self._one
+            self.updates += 1
+
+    def act(self, obs, random_actions=False, train=True):
+        """Batched get_action (experiment.py:546-577): (task action, executed action, recovery)."""
+        cfg = self.cfg
+        if random_actions:
+            action = self.env.sample_actions()
+        else:
+            action = self.agent.select_action(obs, eval=not train)
+        if not cfg.use_recovery:
+            return action, action, None
+        risk = self.agent.safety_critic.get_value(obs, action).squeeze(1)
+        recovery = risk > cfg.eps_safe                                      # :568
+        if cfg.MF_recovery or cfg.Q_sampling_recovery:
+            rec_action = self.agent.safety_critic.select_action(obs)
+        else:
+            rec_action = self.recovery_policy.act(obs, 0, mask=recovery)
+        real_action = torch.where(recovery.unsqueeze(1), rec_action, action)
+        return action, real_action, recovery
+
+    def step_and_store(self, action, real_action, recovery):
+        """env.step + reward penalty + mask + pushes + counters (experiment.py:420-461)."""
+        cfg = self.cfg
+        real_action = real_action.contiguous()
+        obs, reward, done, info = self.env.step(real_action)
+        state, next_state = info["state"], info["next_state"]
+        constraint_f = info["constraint"].to(torch.float32)
+        push_reward = reward - cfg.constraint_reward_penalty * constraint_f if \
+            cfg.constraint_reward_penalty else reward                       # :431-432
+        mask = 1.0 - done.to(torch.float32)                                 # :434 (before the horizon)
+        task_action = real_action if cfg.disable_action_relabeling else action.contiguous()
+        self.memory.push(state, task_action, push_reward, next_state, mask)
+        if uses_constraint_buffer(cfg):
+            self.recovery_memory.push(state, real_action, constraint_f, next_state, mask)
+            if cfg.add_both_transitions and recovery is not None:           # :446-448
+                self.memory.push(state, real_action, push_reward, next_state, mask,
+                                 valid=recovery.to(torch.uint8))
+        # counters (experiment.py:66-74,455-461), all on the device
+        ep_done = info["ep_done"].bool()
+        cons = info["constraint"].bool()
+        end_viol = ep_done & cons
+        rec = recovery if recovery is not None else torch.zeros_like(cons)
+        st = self.stats
+        st[0] += self.n
+        st[1] += ep_done.sum()
+        st[2] += end_viol.sum()
+        st[3] += (end_viol & rec).sum()
+        st[4] += (end_viol & ~rec).sum()
+        st[5] += (ep_done & info["success"].bool()).sum()
+        st[6] += rec.sum()
+        st[7] += cons.sum()
+        self.reward_sum += reward.sum(dtype=torch.float64)
+        self.ep_reward += reward
+        self.ep_return_sum += torch.where(ep_done, self.ep_reward, torch.zeros_like(reward)).sum(dtype=torch.float64)
+        self.ep_reward *= (~ep_done).to(torch.float32)
+        self.obs = obs
+        self.total_numsteps += self.n
+        return obs
+
+    # -- whole iteration -----------------------------------------------------------------------
+    def vector_step(self, do_update=True, random_actions=False, online_qrisk=True, i_episode=1):
+        if do_update:
+            self.do_updates(i_episode, online_qrisk)
+        action, real_action, recovery = self.act(self.obs, random_actions)
+        return self.step_and_store(action, real_action, recovery)
+
+    def capture(self, online_qrisk=True, warmup=3):
+        """Capture the steady-state iteration (updates + act + step + push + counters) into one
+        hipGraph.  Host-side bookkeeping (total_numsteps, updates) is advanced by replay()."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.vector_step(True, False, online_qrisk)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        saved = (self.total_numsteps, self.updates)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.vector_step(True, False, online_qrisk)
+        self.total_numsteps, self.updates = saved
+        self.graph = g
+        self._graph_obs = self.obs
+        return g
+
+    def replay(self):
+        self.graph.replay()
+        self.total_numsteps += self.n
+        self.updates += self.cfg.updates_per_step
+        self.agent.safety_critic.updates += self.cfg.updates_per_step
+        return self._graph_obs
+
+    def read_stats(self):
+        """One device->host copy of the counter vector."""
+        vals = self.stats.cpu().tolist()
+        out = dict(zip(STAT_KEYS, vals))
+        out["reward_sum"] = float(self.reward_sum.item())
+        out["episode_return_sum"] = float(self.ep_return_sum.item())
+        return out
+
+
+class Experiment:
+    def __init__(self, exp_cfg, rank=0, world_size=1):
+        self.exp_cfg = exp_cfg
+        self.rank, self.world_size = rank, world_size
+        if not hasattr(exp_cfg, "num_envs"):
+            exp_cfg.num_envs = 1
+        # logging setup (experiment.py:46-55)
+        self.logdir = os.path.join(
+            exp_cfg.logdir, '{}_SAC_{}_{}_{}'.format(
+                datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"), exp_cfg.env_name,
+                exp_cfg.policy, exp_cfg.logdir_suffix))
+        if not os.path.exists(self.logdir):
+            os.makedirs(self.logdir)
+        print("LOGDIR: ", self.logdir)
+        pickle.dump(exp_cfg, open(os.path.join(self.logdir, "args.pkl"), "wb"))
+
+        self.experiment_setup()
+
+        dev = self.device
+        self.memory = ReplayMemory(exp_cfg.replay_size, exp_cfg.seed, device=dev)
+        self.recovery_memory = ConstraintReplayMemory(exp_cfg.safe_replay_size, exp_cfg.seed, device=dev)
+        self.all_ep_data = []
+
+        self.total_numsteps = 0
+        self.updates = 0
+        self.num_constraint_violations = 0
+        self.num_unsafe_transitions = 0
+        self.num_viols = 0
+        self.num_successes = 0
+        self.viol_and_recovery = 0
+        self.viol_and_no_recovery = 0
+        self.task_demos = exp_cfg.task_demos
+        self.constraint_demo_data, self.task_demo_data = self.get_offline_data()
+
+        if exp_cfg.nu_schedule:                                             # :81-87
+            self.nu_schedule = linear_schedule(exp_cfg.nu_start, exp_cfg.nu_end, exp_cfg.num_eps)
+        else:
+            self.nu_schedule = linear_schedule(exp_cfg.nu, exp_cfg.nu, 0)
+        self.loop = VectorLoop(exp_cfg, self.env, self.agent, self.memory, self.recovery_memory,
+                               self.recovery_policy, self.nu_schedule)
+
+    # -- setup -----------------------------------------------------------------------------------
+    def experiment_setup(self):
+        cfg = self.exp_cfg
+        if not cfg.cuda:
+            raise RuntimeError("recovery_rl_amd runs on the GPU only: pass --cuda (no CPU fallback)")
+        torch.manual_seed(cfg.seed)
+        np.random.seed(cfg.seed)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        register_env(cfg.env_name)
+        self.env = make_vec_env(cfg.env_name, cfg.num_envs, device=self.device, seed=cfg.seed)
+        self.env.seed(cfg.seed)
+        self.env.action_space.seed(cfg.seed)
+        self.agent = self.agent_setup(self.env)
+        self.recovery_policy = None
+        if uses_mb_recovery(cfg):
+            from .MPC import MPC
+            from .config import create_config
+            mpc_cfg = create_config(cfg.env_name, "MPC", dict(cfg.ctrl_arg), cfg.override, self.logdir,
+                                    env=self.env)
+            self.recovery_policy = MPC(mpc_cfg.ctrl_cfg, mb_dynamics=getattr(cfg, "mb_dynamics", "model"))
+            self.recovery_policy.update_value_func(self.agent.safety_critic)
+
+    def agent_setup(self, env):
+        return SAC(env.observation_space, env.action_space, self.exp_cfg, self.logdir, tmp_env=None)
+
+    def get_offline_data(self):
+        """Constraint demonstrations (experiment.py:177-249) as device tensors."""
+        cfg = self.exp_cfg
+        if cfg.task_demos:
+            raise NotImplementedError("task demos exist only for the extraction envs (out of scope)")
+        data = self.env.transition_function(cfg.num_unsafe_transitions)
+        return data, None
+
+    # -- pre-training ----------------------------------------------------------------------------
+    def pretrain_critic_recovery(self):
+        """experiment.py:261-305."""
+        cfg = self.exp_cfg
+        s, a, c, s2, m = (x[:cfg.num_unsafe_transitions].contiguous() for x in self.constraint_demo_data)
+        n_demo = int(c.shape[0])
+        if n_demo:
+            self.recovery_memory.push(s, a, c, s2, m)
+        self.num_unsafe_transitions = n_demo
+        self.num_constraint_violations += int(c.sum().item())
+        self.loop.num_constraint_violations = self.num_constraint_violations
+        print("Number of Constraint Transitions: ", self.num_unsafe_transitions)
+        print("Number of Constraint Violations: ", self.num_constraint_violations)
+        batch = min(cfg.batch_size, int(self.constraint_demo_data[2].shape[0]))
+        for i in range(cfg.critic_safe_pretraining_steps):
+            if i % 100 == 0:
+                print("CRITIC SAFE UPDATE STEP: ", i)
+            self.agent.safety_critic.update_parameters(memory=self.recovery_memory,
+                                                       policy=self.agent.policy, batch_size=batch)
+        if not (cfg.MF_recovery or cfg.Q_sampling_recovery or cfg.DGD_constraints or cfg.RCPO):
+            self.train_MB_recovery(s, a, s2, epochs=50)
+
+    def train_MB_recovery(self, states, actions, next_states=None, epochs=50):
+        if next_states is not None:
+            self.recovery_policy.train(states, actions, random=True, next_obs=next_states, epochs=epochs)
+        else:
+            self.recovery_policy.train(states, actions)
+
+    # -- main loop -------------------------------------------------------------------------------
+    def online_qrisk_enabled(self, num_viols=None):
+        """Gate of experiment.py:407-410."""
+        cfg = self.exp_cfg
+        nv = self.num_viols if num_viols is None else num_viols
+        return (not cfg.disable_online_updates
+                and len(self.recovery_memory) > cfg.batch_size
+                and (nv + self.num_constraint_violations) / cfg.batch_size > cfg.pos_fraction)
+
+    def run(self):
+        cfg = self.exp_cfg
+        if not cfg.disable_offline_updates and uses_constraint_buffer(cfg):
+            self.pretrain_critic_recovery()
+        if cfg.num_envs > 1:
+            return self.run_vectorized()
+        train_rollouts, test_rollouts = [], []
+        for i_episode in itertools.count(1):
+            train_rollouts.append(self.get_train_rollout(i_episode))
+            if i_episode % 10 == 0 and cfg.eval:
+                test_rollouts.append(self.get_test_rollout(i_episode))
+            if self.total_numsteps > cfg.num_steps or i_episode > cfg.num_eps:
+                break
+            self.dump_logs(train_rollouts, test_rollouts)
+
+    def _single_env(self):
+        if not hasattr(self, "_env1"):
+            self._env1 = SingleEnvView(self.env)
+        return self._env1
+
+    def get_train_rollout(self, i_episode):
+        """One training episode at num_envs == 1 in the reference's event order
+        (experiment.py:379-491)."""
+        cfg, loop = self.exp_cfg, self.loop
+        env = self._single_env()
+        episode_reward, episode_steps, done = 0, 0, False
+        state = env.reset()
+        train_rollout_info = []
+        ep_states, ep_actions = [state], []
+        if i_episode % 10 == 0:
+            print("SEED: ", cfg.seed)
+            print("LOGDIR: ", self.logdir)
+        while not done:
+            if len(self.memory) > cfg.batch_size:
+                for _ in range(cfg.updates_per_step):
+                    self.agent.update_parameters(self.memory, min(cfg.batch_size, len(self.memory)),
+                                                 self.updates, safety_critic=self.agent.safety_critic,
+                                                 nu=self.nu_schedule(i_episode))
+                    if self.online_qrisk_enabled():
+                        self.agent.safety_critic.update_parameters(
+                            memory=self.recovery_memory, policy=self.agent.policy,
+                            batch_size=cfg.batch_size, plot=0)
+                    self.updates += 1
+            action, real_action, recovery = loop.act(
+                env.obs_tensor, random_actions=cfg.start_steps > self.total_numsteps)
+            recovery_used = bool(recovery[0].item()) if recovery is not None else False
+            next_state, reward, done, info = env.step(real_action)
+            info['recovery'] = recovery_used
+            train_rollout_info.append(info)
+            episode_steps += 1
+            episode_reward += reward
+            self.total_numsteps += 1
+            push_reward = reward - cfg.constraint_reward_penalty if info['constraint'] else reward
+            mask = float(not done)
+            done = done or episode_steps == env._max_episode_steps
+            env.push_transition(self.memory, real_action if cfg.disable_action_relabeling else action,
+                                push_reward, mask)
+            if uses_constraint_buffer(cfg):
+                env.push_transition(self.recovery_memory, real_action, float(info['constraint']), mask)
+                if recovery_used and cfg.add_both_transitions:
+                    env.push_transition(self.memory, real_action, push_reward, mask)
+            state = next_state
+            ep_states.append(state)
+            ep_actions.append(info['action'])
+        if info['constraint']:
+            self.num_viols += 1
+            if info['recovery']:
+                self.viol_and_recovery += 1
+            else:
+                self.viol_and_no_recovery += 1
+        self.num_successes += int(info['success'])
+        if cfg.use_recovery and not cfg.disable_online_updates:
+            self.all_ep_data.append({'obs': np.array(ep_states), 'ac': np.array(ep_actions)})
+            if i_episode % cfg.recovery_policy_update_freq == 0 and uses_mb_recovery(cfg) \
+                    and not cfg.DGD_constraints:
+                dev = self.device
+                self.train_MB_recovery(
+                    [torch.as_tensor(d['obs'], dtype=torch.float32, device=dev) for d in self.all_ep_data],
+                    [torch.as_tensor(d['ac'], dtype=torch.float32, device=dev) for d in self.all_ep_data])
+                self.all_ep_data = []
+        print("Episode: {}, total numsteps: {}, episode steps: {}, reward: {}".format(
+            i_episode, self.total_numsteps, episode_steps, round(episode_reward, 2)))
+        print("Num Violations So Far: %d" % self.num_viols)
+        print("Violations with Recovery: %d" % self.viol_and_recovery)
+        print("Violations with No Recovery: %d" % self.viol_and_no_recovery)
+        print("Num Successes So Far: %d" % self.num_successes)
+        return train_rollout_info
+
+    def get_test_rollout(self, i_episode):
+        """experiment.py:493-538 (deterministic task actions; images/gifs are out of scope)."""
+        env = self._single_env()
+        test_rollout_info = []
+        env.reset()
+        episode_reward, episode_steps, done = 0, 0, False
+        while not done:
+            action, real_action, recovery = self.loop.act(env.obs_tensor, train=False)
+            _, reward, done, info = env.step(real_action)
+            info['recovery'] = bool(recovery[0].item()) if recovery is not None else False
+            done = done or episode_steps == env._max_episode_steps        # :515 (checked before ++)
+            test_rollout_info.append(info)
+            episode_reward += reward
+            episode_steps += 1
+        print("----------------------------------------")
+        print("Avg. Reward: {}".format(round(episode_reward, 2)))
+        print("----------------------------------------")
+        return test_rollout_info
+
+    def dump_logs(self, train_rollouts, test_rollouts):
+        data = {"test_stats": test_rollouts, "train_stats": train_rollouts}
+        with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
+            pickle.dump(data, f)
+
+    # -- vectorised loop -------------------------------------------------------------------------
+    def run_vectorized(self):
+        """num_envs > 1: lock-step loop; the steady state is replayed from one hipGraph.  Stops
+        when env-steps > num_steps or completed episodes > num_eps (experiment.py:375)."""
+        cfg, loop = self.exp_cfg, self.loop
+        n = cfg.num_envs
+        loop.start()
+        log_every = cfg.log_every if getattr(cfg, "log_every", 0) else max(1, 100)
+        history = []
+        it = 0
+        captured_gate = None
+        mb = uses_mb_recovery(cfg)
+        while True:
+            have_batch = len(self.memory) > cfg.batch_size
+            random_actions = cfg.start_steps > loop.total_numsteps
+            gate = self.online_qrisk_enabled() if uses_constraint_buffer(cfg) else False
+            steady = have_batch and not random_actions and not mb
+            if steady and (loop.graph is None or captured_gate != gate):
+                loop.capture(online_qrisk=gate)
+                captured_gate = gate
+            if steady:
+                loop.replay()
+            else:
+                loop.vector_step(do_update=have_batch, random_actions=random_actions, online_qrisk=gate)
+            it += 1
+            if it % log_every == 0:
+                stats = loop.read_stats()
+                self._absorb(stats)
+                agg = dist_utils.aggregate_stats(stats, self.world_size, self.device)
+                history.append(dict(stats, iteration=it))
+                if self.rank == 0:
+                    print("Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(
+                        it, agg["env_steps"], agg["episodes"],
+                        round(agg["episode_return_sum"] / max(agg["episodes"], 1), 2)))
+                    print("Num Violations So Far: %d" % agg["num_viols"])
+                    print("Violations with Recovery: %d" % agg["viol_and_recovery"])
+                    print("Violations with No Recovery: %d" % agg["viol_and_no_recovery"])
+                    print("Num Successes So Far: %d" % agg["num_successes"])
+                with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
+                    pickle.dump({"vector_stats": history, "num_envs": n}, f)
+                if stats["env_steps"] > cfg.num_steps or stats["episodes"] > cfg.num_eps:
+                    break
+        return history
+
+    def _absorb(self, stats):
+        self.total_numsteps = stats["env_steps"]
+        self.num_viols = stats["num_viols"]
+        self.viol_and_recovery = stats["viol_and_recovery"]
+        self.viol_and_no_recovery = stats["viol_and_no_recovery"]
+        self.num_successes = stats["num_successes"]
+        self.updates = self.loop.updates
+
+
+class SingleEnvView:
+    """num_envs == 1 adapter giving the driver the reference's numpy step protocol while the
+    state, action and transition rows stay on the device."""
+
+    def __init__(self, vec_env):
+        assert vec_env.num_envs == 1
+        self.vec = vec_env
+        self.vec.auto_reset = False
+        self._max_episode_steps = vec_env._max_episode_steps
+        self.obs_tensor = None
+
+    def reset(self):
+        self.obs_tensor = self.vec.reset()
+        return self.vec.pos[0].cpu().numpy().copy()
+
+    def step(self, real_action):
+        real_action = real_action.contiguous()
+        old_state = self.vec.pos[0].cpu().numpy().copy()
+        obs, reward, done, info = self.vec.step(real_action)
+        self.obs_tensor = obs
+        self._last = (info["state"].clone(), info["next_state"].clone())
+        state = self.vec.pos[0].cpu().numpy().copy()
+        cost = float(reward[0].item())
+        return state, cost, bool(done[0].item()), {
+            "constraint": int(info["constraint"][0].item()), "reward": cost, "state": old_state,
+            "next_state": state, "action": info["action"][0].cpu().numpy(),
+            "success": bool(info["success"][0].item())}
+
+    def push_transition(self, memory, action, reward, mask):
+        dev = self.vec.device
+        memory.push(self._last[0], action.contiguous(),
+                    torch.full((1,), float(reward), dtype=torch.float32, device=dev), self._last[1],
+                    torch.full((1,), float(mask), dtype=torch.float32, device=dev))

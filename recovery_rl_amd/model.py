@@ -164,7 +164,7 @@ class StochasticPolicy(_PolicyBase):
         mean = torch.tanh(self.mean(self.trunk(state))) * self.action_scale + self.action_bias
         log_std = torch.clamp(self.log_std, min=self.min_log_std)
         std = torch.exp(log_std).unsqueeze(0).expand_as(mean)
-        return Normal(mean, std)
+        return Normal(mean, std, validate_args=False)  # validation would sync the stream
 
     def sample(self, state, eps=None):
         dist = self.forward(state)

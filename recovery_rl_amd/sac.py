@@ -76,6 +76,19 @@ class SAC(object):
 
         self.safety_critic = QRiskWrapper(observation_space, action_space, args.hidden_size, logdir,
                                           args, tmp_env=tmp_env)
+        # constants returned as statistics; created once (no host->device copy inside a hipGraph)
+        self._zero = torch.zeros((), device=self.device)
+        self._alpha_const = torch.tensor(float(self.alpha), device=self.device)
+
+    @torch.no_grad()
+    def _set_dual(self, name, log_param):
+        """self.<name> = exp(log_param), written IN PLACE into one persistent tensor so a captured
+        hipGraph keeps reading the live value on replay."""
+        cur = getattr(self, name)
+        if not torch.is_tensor(cur):
+            cur = torch.zeros_like(log_param.detach())
+            setattr(self, name, cur)
+        cur.copy_(log_param.detach().exp())
 
     # -- acting ------------------------------------------------------------------------------
     @torch.no_grad()
@@ -162,25 +175,25 @@ class SAC(object):
             self.alpha_optim.zero_grad(set_to_none=True)
             alpha_loss.backward()
             self.alpha_optim.step()
-            self.alpha = self.log_alpha.exp().detach()
-            alpha_t = self.alpha.clone().reshape(())
+            self._set_dual("alpha", self.log_alpha)
+            alpha_t = self.alpha.reshape(())
         else:
-            alpha_loss = torch.zeros((), device=self.device)
-            alpha_t = torch.as_tensor(float(self.alpha), device=self.device)
+            alpha_loss = self._zero
+            alpha_t = self._alpha_const
 
         if self.update_nu:                                                      # :256-262
             nu_loss = (self.log_nu * (self.eps_safe - max_sqf_pi).detach()).mean()
             self.nu_optim.zero_grad(set_to_none=True)
             nu_loss.backward()
             self.nu_optim.step()
-            self.nu = self.log_nu.exp().detach()
+            self._set_dual("nu", self.log_nu)
 
         if self.RCPO:                                                           # :265-271
             lam_loss = (self.log_lambda_RCPO * (self.eps_safe - qsafe).detach()).mean()
             self.lambda_RCPO_optim.zero_grad(set_to_none=True)
             lam_loss.backward()
             self.lambda_RCPO_optim.step()
-            self.lambda_RCPO = self.log_lambda_RCPO.exp().detach()
+            self._set_dual("lambda_RCPO", self.log_lambda_RCPO)
 
         if updates % self.target_update_interval == 0:                          # :273-274
             soft_update(self.critic_target, self.critic, self.tau)

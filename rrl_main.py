@@ -1,0 +1,13 @@
+"""`python -m rrl_main --env-name navigation1 --cuda ...` -- same entry point as the reference
+(rrl_main.py:1-9).  Under torchrun each rank runs seed + rank on its own GPU."""
+from arg_utils import get_args
+from recovery_rl_amd import distributed as dist_utils
+from recovery_rl_amd.experiment import Experiment
+
+if __name__ == '__main__':
+    exp_cfg = get_args()
+    rank, local_rank, world = dist_utils.init()
+    if world > 1:
+        exp_cfg.seed = dist_utils.rank_seed(exp_cfg.seed, rank)
+    experiment = Experiment(exp_cfg, rank=rank, world_size=world)
+    experiment.run()
