@@ -1,0 +1,140 @@
+"""GPU tests of the driver: lock-step loop bookkeeping, hipGraph replay, and the reference-order
+single-env loop (run_stats.pkl schema, counters)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import arg_utils
+from recovery_rl_amd.experiment import STAT_KEYS, Experiment, VectorLoop
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_cfg(tmp_path, extra=()):
+    return arg_utils.get_args(["--env-name", "navigation1", "--cuda", "--hidden_size", "32", "--logdir",
+                               str(tmp_path), "--seed", "3", "--num_unsafe_transitions", "2000",
+                               "--critic_safe_pretraining_steps", "20"] + list(extra))
+
+
+def test_vector_loop_bookkeeping_eager(tmp_path, capsys):
+    cfg = make_cfg(tmp_path, ["--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe", "0.3",
+                              "--num_envs", "128"])
+    exp = Experiment(cfg)
+    exp.pretrain_critic_recovery()
+    assert len(exp.recovery_memory) == exp.num_unsafe_transitions > 1000
+    assert exp.num_constraint_violations == int(exp.constraint_demo_data[2].sum().item())
+    loop = exp.loop
+    loop.start()
+    ep_done_total = 0
+    for k in range(30):
+        loop.vector_step(do_update=len(exp.memory) > cfg.batch_size, random_actions=k < 2,
+                         online_qrisk=True)
+        ep_done_total += int(exp.env.ep_done.sum().item())
+    st = loop.read_stats()
+    assert st["env_steps"] == 30 * 128 == loop.total_numsteps
+    assert len(exp.memory) == 30 * 128
+    assert len(exp.recovery_memory) == exp.num_unsafe_transitions + 30 * 128
+    assert st["episodes"] == ep_done_total
+    assert st["num_viols"] == st["viol_and_recovery"] + st["viol_and_no_recovery"]
+    assert st["sac_updates"] == 27 and st["qrisk_updates"] == 27        # len(memory) > 256 from iteration 3 on
+    # the rows in memory are what the env produced on the last step
+    m = exp.memory
+    last = slice(29 * 128, 30 * 128)
+    assert torch.equal(m.s2[last], exp.env.next_obs)
+    assert torch.equal(m.r[last], exp.env.reward)
+    assert torch.equal(m.m[last], 1.0 - exp.env.done.float())
+    rm = exp.recovery_memory
+    off = exp.num_unsafe_transitions
+    assert torch.equal(rm.r[off + 29 * 128: off + 30 * 128], exp.env.constraint.float())
+
+
+def test_graph_replay_advances_everything(tmp_path):
+    cfg = make_cfg(tmp_path, ["--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe", "0.3",
+                              "--num_envs", "256"])
+    exp = Experiment(cfg)
+    exp.pretrain_critic_recovery()
+    loop = exp.loop
+    loop.start()
+    for k in range(3):
+        loop.vector_step(do_update=k > 1, random_actions=True)
+    loop.capture(online_qrisk=True)
+    st0 = loop.read_stats()
+    w0 = exp.agent.critic.linear2.weight.clone()
+    tick0 = int(exp.env.tick[0].item())
+    mtick0 = int(exp.memory.tick[0].item())
+    pos0 = exp.env.pos.clone()
+    size0 = int(exp.memory.state[1].item())
+    for _ in range(10):
+        loop.replay()
+    torch.cuda.synchronize()
+    st1 = loop.read_stats()
+    assert st1["env_steps"] - st0["env_steps"] == 10 * 256
+    assert st1["sac_updates"] - st0["sac_updates"] == 10
+    assert st1["qrisk_updates"] - st0["qrisk_updates"] == 10
+    assert int(exp.env.tick[0].item()) == tick0 + 10            # in-kernel RNG tick advanced by the graph
+    assert int(exp.memory.tick[0].item()) == mtick0 + 10
+    assert int(exp.memory.state[1].item()) == size0 + 10 * 256
+    assert not torch.equal(exp.env.pos, pos0)
+    assert not torch.equal(exp.agent.critic.linear2.weight, w0)
+    assert torch.isfinite(exp.agent.critic.linear2.weight).all()
+    exp.memory.check_error()
+    exp.recovery_memory.check_error()
+    # successive replays draw different noise: per-step positions are not a fixed increment
+    p1 = exp.env.pos.clone()
+    loop.replay()
+    p2 = exp.env.pos.clone()
+    loop.replay()
+    p3 = exp.env.pos.clone()
+    assert not torch.equal(p2 - p1, p3 - p2)
+
+
+def test_reference_order_single_env_run(tmp_path, capsys):
+    """num_envs == 1: same prints, counters and run_stats.pkl schema as the reference
+    (experiment.py:483-490, 540-543; info keys env/navigation1.py:82-89 + 'recovery')."""
+    cfg = make_cfg(tmp_path, ["--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe", "0.3",
+                              "--num_eps", "11", "--start_steps", "20", "--batch_size", "64"])
+    exp = Experiment(cfg)
+    exp.run()
+    out = capsys.readouterr().out
+    assert "LOGDIR: " in out and "CRITIC SAFE UPDATE STEP:  0" in out
+    assert "Number of Constraint Transitions: " in out and "Number of Constraint Violations: " in out
+    assert "Episode: 1, total numsteps: " in out and "Num Violations So Far: " in out
+    assert "Violations with Recovery: " in out and "Num Successes So Far: " in out
+    assert "Avg. Reward: " in out                                    # eval after episode 10
+    assert os.path.basename(exp.logdir).endswith("_SAC_navigation1_Gaussian_")
+    args = pickle.load(open(os.path.join(exp.logdir, "args.pkl"), "rb"))
+    assert args.env_name == "navigation1" and args.seed == 3
+    data = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))
+    assert set(data) == {"test_stats", "train_stats"}
+    assert len(data["train_stats"]) == 11 and len(data["test_stats"]) == 1
+    steps = sum(len(ep) for ep in data["train_stats"])
+    # the reference runs episode num_eps+1 before breaking and skips that last dump (experiment.py:375-377)
+    assert steps < exp.total_numsteps <= steps + 100 and exp.total_numsteps == len(exp.memory)
+    info = data["train_stats"][0][0]
+    assert set(info) == {"constraint", "reward", "state", "next_state", "action", "success", "recovery"}
+    assert info["state"].dtype == np.float64 and info["state"].shape == (2,)
+    for ep in data["train_stats"]:
+        assert 1 <= len(ep) <= 100
+        # only the last step may be a violation (done on constraint)
+        assert not any(s["constraint"] for s in ep[:-1])
+    viols = sum(int(ep[-1]["constraint"]) for ep in data["train_stats"])
+    assert viols <= exp.num_viols <= viols + 1
+    assert exp.num_viols == exp.viol_and_recovery + exp.viol_and_no_recovery
+    assert exp.updates == exp.total_numsteps - 65                    # one update per step once len(memory) > 64
+    assert len(exp.recovery_memory) == exp.num_unsafe_transitions + exp.total_numsteps
+
+
+def test_vectorized_run_stops_and_logs(tmp_path, capsys):
+    cfg = make_cfg(tmp_path, ["--num_envs", "64", "--num_steps", "3000", "--log_every", "10"])
+    exp = Experiment(cfg)
+    hist = exp.run()
+    assert hist[-1]["env_steps"] > 3000 and hist[-1]["env_steps"] % 64 == 0
+    assert set(STAT_KEYS) <= set(hist[-1])
+    data = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))
+    assert data["num_envs"] == 64 and len(data["vector_stats"]) == len(hist)
+    assert exp.loop.graph is not None                                # steady state ran from the hipGraph
+    assert "Num Violations So Far: " in capsys.readouterr().out
