@@ -101,6 +101,24 @@ int rrl_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed, float*
                     int32_t* scratch, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Maze.  Replaces MazeNavigation.step / reset / get_offline_data (env/maze.py:139-213, 34-107).
+ * The reference steps MuJoCo 1.50 (third-party, absent); these kernels run the kinematic
+ * surrogate of DESIGN.md section 6 -- same control flow, reward, termination and geometry.
+ * Buffers as rrl_nav_step; `done` already contains the env's own horizon (env/maze.py:153).
+ * Reset modes: 0 'h' (default), 1 'e', 2 'm', 3 None (env/maze.py:187-196).
+ * ------------------------------------------------------------------------------------------ */
+int rrl_maze_step(int64_t n, double* pos, const float* action, uint64_t seed, uint64_t counter,
+                  uint64_t* counter_dev, uint64_t counter_inc, float* next_obs, float* obs,
+                  float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success,
+                  uint8_t* ep_done, int32_t* t, int32_t horizon, int auto_reset, void* stream);
+int rrl_maze_reset(int64_t n, double* pos, float* obs, int32_t* t, const uint8_t* mask, int mode,
+                   int check_constraint, uint64_t seed, uint64_t counter,
+                   const uint64_t* counter_dev, void* stream);
+/* writes exactly 2 * (num_transitions / 2) rows (half random, half expert actions) */
+int rrl_maze_offline(int64_t num_transitions, uint64_t seed, float* s, float* a, float* c,
+                     float* s2, float* m, int64_t capacity, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Replay.  Replaces ReplayMemory / ConstraintReplayMemory (recovery_rl/replay_memory.py).
  * Layout: structure-of-arrays ring, f32: s[cap,2] a[cap,2] r[cap] s2[cap,2] m[cap] = 32 B/row.
  *   state   device int64[4]: {position, size, ticket(internal, keep 0), error flag}

@@ -35,6 +35,7 @@ def lib():
         _lib.rrl_oracle_uniform01.restype = C.c_double
         _lib.rrl_oracle_uniform01.argtypes = [C.c_uint64]
         _lib.rrl_oracle_nav_offline.restype = C.c_int64
+        _lib.rrl_oracle_maze_offline.restype = C.c_int64
     return _lib
 
 
@@ -122,6 +123,58 @@ def nav_offline(env_name, num_transitions, seed):
     w = lib().rrl_oracle_nav_offline(ENV_KIND[env_name], C.c_int64(num_transitions),
                                      C.c_uint64(seed), _p(s), _p(a), _p(c), _p(s2), _p(m),
                                      C.c_int64(cap))
+    assert w >= 0, w
+    return s[:w], a[:w], c[:w], s2[:w], m[:w]
+
+
+def maze_contact(x, y):
+    return int(lib().rrl_oracle_maze_contact(C.c_double(x), C.c_double(y)))
+
+
+def maze_step(pos, action, t, seed=0, counter=0, horizon=100, auto_reset=False):
+    n = len(pos)
+    pos = np.ascontiguousarray(pos, dtype=np.float64).copy()
+    action = np.ascontiguousarray(action, dtype=np.float32)
+    t = np.ascontiguousarray(t, dtype=np.int32).copy()
+    o = dict(next_obs=np.zeros((n, 2), np.float32), obs=np.zeros((n, 2), np.float32),
+             reward=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
+             constraint=np.zeros(n, np.uint8), success=np.zeros(n, np.uint8),
+             ep_done=np.zeros(n, np.uint8), next_pos64=np.zeros((n, 2)), reward64=np.zeros(n))
+    rc = lib().rrl_oracle_maze_step(
+        C.c_int64(n), _p(pos), _p(action), C.c_uint64(seed), C.c_uint64(counter), _p(o["next_obs"]),
+        _p(o["obs"]), _p(o["reward"]), _p(o["done"]), _p(o["constraint"]), _p(o["success"]),
+        _p(o["ep_done"]), _p(t), C.c_int32(horizon), C.c_int(int(auto_reset)), _p(o["next_pos64"]),
+        _p(o["reward64"]))
+    assert rc == 0
+    o["pos"], o["t"] = pos, t
+    return o
+
+
+def maze_reset(n, mode=0, check_constraint=True, seed=0, counter=0):
+    pos = np.zeros((n, 2))
+    obs = np.zeros((n, 2), np.float32)
+    t = np.zeros(n, np.int32)
+    rc = lib().rrl_oracle_maze_reset(C.c_int64(n), _p(pos), _p(obs), _p(t), C.c_int(mode),
+                                     C.c_int(int(check_constraint)), C.c_uint64(seed), C.c_uint64(counter))
+    assert rc == 0
+    return pos, obs, t
+
+
+def maze_expert_action(x, y):
+    act = (C.c_double * 2)()
+    lib().rrl_oracle_maze_expert_action(C.c_double(x), C.c_double(y), act)
+    return np.array([act[0], act[1]])
+
+
+def maze_offline(num_transitions, seed):
+    cap = max(2 * (num_transitions // 2), 1)
+    s = np.zeros((cap, 2), np.float32)
+    a = np.zeros((cap, 2), np.float32)
+    c = np.zeros(cap, np.float32)
+    s2 = np.zeros((cap, 2), np.float32)
+    m = np.zeros(cap, np.float32)
+    w = lib().rrl_oracle_maze_offline(C.c_int64(num_transitions), C.c_uint64(seed), _p(s), _p(a), _p(c),
+                                      _p(s2), _p(m), C.c_int64(cap))
     assert w >= 0, w
     return s[:w], a[:w], c[:w], s2[:w], m[:w]
 

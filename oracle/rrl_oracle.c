@@ -343,6 +343,185 @@ int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t s
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Maze (env/maze.py:139-232, env/assets/simple_maze.xml).  PARITY UNPINNED: the reference steps
+ * MuJoCo 1.50 (mujoco_py==1.50.1.68, install.sh:13), a third-party binary absent from the
+ * reference tree and from this image.  Control flow, reward, termination, reset ranges, wall
+ * placement and the expert follow env/maze.py line by line; the physics is replaced by the
+ * kinematic surrogate documented in DESIGN.md section 6:
+ *   - point cylinder r = 0.025 on two slide joints; motor gear 0.05, joint damping 0.01,
+ *     mass 1000 * pi r^2 h = 0.09817 kg, 500 semi-implicit Euler steps of dt = 0.002 from rest
+ *     => straight-line displacement MAZE_GAIN * a per env step (a in [-0.1, 0.1]);
+ *   - contact (ncon > 3) <=> the disc touches a wall rectangle or an arena plane;
+ *   - the disc stops at the first of 64 equal sub-steps that is in contact.
+ * ---------------------------------------------------------------------------------------- */
+#define MAZE_GAIN 0.24667750873451577   /* metres per unit control per env step */
+#define MAZE_R 0.025                    /* toolgeom size, simple_maze.xml:28 */
+#define MAZE_LIM 0.3                    /* planes / joint range, simple_maze.xml:16-19,29-30 */
+#define MAZE_MAX_FORCE 0.1              /* env/maze.py:17 */
+#define MAZE_GOAL_X 0.25                /* env/maze.py:135-137 */
+#define MAZE_GOAL_Y 0.0
+#define MAZE_GOAL_THRESH 0.03           /* env/maze.py:19 */
+#define MAZE_SUBSTEPS 64
+
+/* wall rectangles {cx, cy, half x, half y} after reset() moves them (env/maze.py:199-206):
+ * geoms 5..8 = wall1A, wall2A, wall1B, wall2B; y centres 0.5-0.08, 0.4+0.08, -0.25-0.08, -0.25+0.08 */
+static const double MAZE_WALLS[4][4] = {
+    {-0.1, 0.42, 0.005, 0.2}, {0.1, 0.48, 0.005, 0.2}, {-0.1, -0.33, 0.005, 0.2}, {0.1, -0.17, 0.005, 0.2}};
+
+int rrl_oracle_maze_contact(double x, double y)
+{
+    if (MAZE_LIM - x <= MAZE_R || x + MAZE_LIM <= MAZE_R) return 1;
+    if (MAZE_LIM - y <= MAZE_R || y + MAZE_LIM <= MAZE_R) return 1;
+    for (int k = 0; k < 4; ++k) {
+        double dx = fabs(x - MAZE_WALLS[k][0]) - MAZE_WALLS[k][2];
+        double dy = fabs(y - MAZE_WALLS[k][1]) - MAZE_WALLS[k][3];
+        if (dx < 0.0) dx = 0.0;
+        if (dy < 0.0) dy = 0.0;
+        if (dx * dx + dy * dy <= MAZE_R * MAZE_R) return 1;
+    }
+    return 0;
+}
+
+static double maze_dist(double x, double y)
+{   /* get_distance_score, env/maze.py:215-220: sqrt(mean((goal - qpos)^2)) */
+    double ex = MAZE_GOAL_X - x, ey = MAZE_GOAL_Y - y;
+    return sqrt((ex * ex + ey * ey) / 2.0);
+}
+
+static void maze_move(double* x, double* y, double ax, double ay)
+{   /* env/maze.py:141-147: no motion when already in contact, else 500 sim steps */
+    ax = clip1(ax, -MAZE_MAX_FORCE, MAZE_MAX_FORCE);
+    ay = clip1(ay, -MAZE_MAX_FORCE, MAZE_MAX_FORCE);
+    if (rrl_oracle_maze_contact(*x, *y)) return;
+    double dx = MAZE_GAIN * ax, dy = MAZE_GAIN * ay, qx = *x, qy = *y;
+    for (int k = 1; k <= MAZE_SUBSTEPS; ++k) {
+        double f = (double)k * (1.0 / MAZE_SUBSTEPS);
+        qx = clip1(*x + dx * f, -MAZE_LIM, MAZE_LIM);
+        qy = clip1(*y + dy * f, -MAZE_LIM, MAZE_LIM);
+        if (rrl_oracle_maze_contact(qx, qy)) break;
+    }
+    *x = qx; *y = qy;
+}
+
+static void maze_reset_one(uint64_t seed, uint32_t i, uint64_t counter, int mode, int check,
+                           double* x, double* y)
+{   /* env/maze.py:184-213: redraw while in contact (recursion at :209-211) */
+    for (uint32_t r = 0;; ++r) {
+        uint64_t b0, b1;
+        philox_bits(seed, i, RRL_STREAM_RESET, counter | ((uint64_t)r << 48), &b0, &b1);
+        double u0 = rrl_oracle_uniform01(b0), u1 = rrl_oracle_uniform01(b1);
+        switch (mode) {
+            case 1: *x = 0.14 + 0.08 * u0; break;            /* 'e' :191 */
+            case 2: *x = -0.04 + 0.08 * u0; break;           /* 'm' :193 */
+            case 3: *x = -0.27 + 0.54 * u0; break;           /* None :189 */
+            default: *x = -0.22 + 0.09 * u0; break;          /* 'h' :195 */
+        }
+        *y = -0.22 + 0.44 * u1;                              /* :196 */
+        if (!check || !rrl_oracle_maze_contact(*x, *y) || r >= 1000) return;
+    }
+}
+
+int rrl_oracle_maze_step(int64_t n, double* pos, const float* action, uint64_t seed, uint64_t counter,
+                         float* next_obs, float* obs, float* reward, uint8_t* done,
+                         uint8_t* constraint, uint8_t* success, uint8_t* ep_done, int32_t* t,
+                         int32_t horizon, int auto_reset, double* next_pos64, double* reward64)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double x = pos[2 * i], y = pos[2 * i + 1];
+        maze_move(&x, &y, (double)action[2 * i], (double)action[2 * i + 1]);
+        int32_t ti = t[i] + 1;                                /* self.steps += 1, :151 */
+        int cons = rrl_oracle_maze_contact(x, y);             /* :152 */
+        double d = maze_dist(x, y);
+        int dn = (ti >= horizon) || cons || (d < MAZE_GOAL_THRESH);   /* :153-154 */
+        double rew = -d;                                      /* dense reward :158 */
+        int succ = rew > -0.03;                               /* :166 */
+        int epd = dn || (ti == horizon);
+        if (next_pos64) { next_pos64[2 * i] = x; next_pos64[2 * i + 1] = y; }
+        if (reward64) reward64[i] = rew;
+        next_obs[2 * i] = (float)x; next_obs[2 * i + 1] = (float)y;
+        reward[i] = (float)rew;
+        done[i] = (uint8_t)dn; constraint[i] = (uint8_t)cons; success[i] = (uint8_t)succ;
+        if (ep_done) ep_done[i] = (uint8_t)epd;
+        if (auto_reset && epd) {
+            maze_reset_one(seed, (uint32_t)i, counter, 0, 1, &x, &y);
+            ti = 0;
+        }
+        pos[2 * i] = x; pos[2 * i + 1] = y;
+        t[i] = ti;
+        if (obs) { obs[2 * i] = (float)x; obs[2 * i + 1] = (float)y; }
+    }
+    return 0;
+}
+
+int rrl_oracle_maze_reset(int64_t n, double* pos, float* obs, int32_t* t, int mode,
+                          int check_constraint, uint64_t seed, uint64_t counter)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double x, y;
+        maze_reset_one(seed, (uint32_t)i, counter, mode, check_constraint, &x, &y);
+        pos[2 * i] = x; pos[2 * i + 1] = y;
+        if (t) t[i] = 0;
+        if (obs) { obs[2 * i] = (float)x; obs[2 * i + 1] = (float)y; }
+    }
+    return 0;
+}
+
+void rrl_oracle_maze_expert_action(double x, double y, double act[2])
+{   /* env/maze.py:222-232, gain 1.05 (:134) */
+    double tx, ty;
+    if (x <= -0.151) { tx = -0.15; ty = -0.125; }
+    else if (x <= 0.149) { tx = 0.15; ty = 0.125; }
+    else { tx = MAZE_GOAL_X; ty = MAZE_GOAL_Y; }
+    act[0] = 1.05 * (tx - x);
+    act[1] = 1.05 * (ty - y);
+}
+
+int64_t rrl_oracle_maze_offline(int64_t num_transitions, uint64_t seed, float* s, float* a, float* c,
+                                float* s2, float* m, int64_t capacity)
+{   /* env/maze.py:34-107: half random, half expert actions; reset (no contact check) every 20
+     * steps with mode e/m/h drawn 30/30/40 %; rows (state, raw action, constraint, next, not done) */
+    int64_t half = num_transitions / 2;
+    if (2 * half > capacity) return -2;
+    int64_t w = 0;
+    for (int part = 0; part < 2; ++part) {
+        int64_t n_seg = (half + 19) / 20;
+        for (int64_t g = 0; g < n_seg; ++g) {
+            uint32_t row = (uint32_t)(part * n_seg + g);
+            uint64_t b0, b1;
+            philox_bits(seed, row, RRL_STREAM_OFFLINE, 0, &b0, &b1);
+            double sample = rrl_oracle_uniform01(b0);
+            int mode = sample < 0.3 ? 1 : (sample < 0.6 ? 2 : 0);      /* :45-51 */
+            double x, y;
+            maze_reset_one(seed, row, 1ULL << 40, mode, 0, &x, &y);
+            int32_t steps = 0;
+            int64_t len = (g == n_seg - 1) ? half - 20 * g : 20;
+            for (int64_t j = 0; j < len; ++j) {
+                double act[2];
+                if (part == 0) {                                       /* action_space.sample() :58 */
+                    philox_bits(seed, row, RRL_STREAM_OFFLINE, (uint64_t)(1 + j), &b0, &b1);
+                    act[0] = -0.1 + 0.2 * rrl_oracle_uniform01(b0);
+                    act[1] = -0.1 + 0.2 * rrl_oracle_uniform01(b1);
+                } else rrl_oracle_maze_expert_action(x, y, act);       /* :88 */
+                float axf = (float)act[0], ayf = (float)act[1];
+                double nx = x, ny = y;
+                maze_move(&nx, &ny, (double)axf, (double)ayf);
+                steps += 1;
+                int cons = rrl_oracle_maze_contact(nx, ny);
+                int dn = (steps >= 100) || cons || (maze_dist(nx, ny) < MAZE_GOAL_THRESH);
+                s[2 * w] = (float)x; s[2 * w + 1] = (float)y;
+                a[2 * w] = axf; a[2 * w + 1] = ayf;
+                c[w] = (float)cons;
+                s2[2 * w] = (float)nx; s2[2 * w + 1] = (float)ny;
+                m[w] = (float)(!dn);
+                ++w;
+                x = nx; y = ny;
+            }
+        }
+    }
+    return w;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Replay (recovery_rl/replay_memory.py)
  * ---------------------------------------------------------------------------------------- */
 int rrl_oracle_replay_push(rrl_oracle_replay* rb, int64_t n, const float* s, const float* a,

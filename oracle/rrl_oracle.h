@@ -73,6 +73,20 @@ int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t s
                                float* s, float* a, float* c, float* s2, float* m,
                                int64_t capacity);
 
+/* ---- maze (env/maze.py; kinematic surrogate of the MuJoCo model, PARITY UNPINNED) ---- */
+int rrl_oracle_maze_contact(double x, double y);
+int rrl_oracle_maze_step(int64_t n, double* pos, const float* action, uint64_t seed, uint64_t counter,
+                         float* next_obs, float* obs, float* reward, uint8_t* done,
+                         uint8_t* constraint, uint8_t* success, uint8_t* ep_done, int32_t* t,
+                         int32_t horizon, int auto_reset, double* next_pos64, double* reward64);
+/* mode: 0 'h' (default), 1 'e', 2 'm', 3 None (env/maze.py:184-197) */
+int rrl_oracle_maze_reset(int64_t n, double* pos, float* obs, int32_t* t, int mode,
+                          int check_constraint, uint64_t seed, uint64_t counter);
+void rrl_oracle_maze_expert_action(double x, double y, double act[2]);
+/* env/maze.py:34-107; writes exactly 2*(num_transitions/2) rows, returns that count */
+int64_t rrl_oracle_maze_offline(int64_t num_transitions, uint64_t seed, float* s, float* a, float* c,
+                                float* s2, float* m, int64_t capacity);
+
 /* ---- replay (recovery_rl/replay_memory.py) ---- */
 typedef struct {
     float* s;       /* [cap,2] */

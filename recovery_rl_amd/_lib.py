@@ -16,12 +16,14 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 HIP_SOURCES = ["nav_kernels.hip", "replay_kernels.hip", "maze_kernels.hip", "cem_kernels.hip",
                "mlp_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+               "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+               "-Wno-bitwise-instead-of-logical"]
 
 EXPORTS = [
     "rrl_abi_version", "rrl_last_hip_error", "rrl_counter_add",
     "rrl_nav_step", "rrl_nav_reset", "rrl_nav_rollout", "rrl_nav_offline_rollouts",
     "rrl_nav_offline",
+    "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather",
 ]
 
@@ -77,6 +79,9 @@ def _declare(lib):
         "rrl_nav_rollout": (ci, [ci, i64, i32, vp, vp, u64, u64, vp, vp, vp, vp, vp, vp]),
         "rrl_nav_offline_rollouts": (i64, [ci, i64]),
         "rrl_nav_offline": (ci, [ci, i64, u64, vp, vp, vp, vp, vp, i64, vp, vp, vp]),
+        "rrl_maze_step": (ci, [i64, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, i32, ci, vp]),
+        "rrl_maze_reset": (ci, [i64, vp, vp, vp, vp, ci, ci, u64, u64, vp, vp]),
+        "rrl_maze_offline": (ci, [i64, u64, vp, vp, vp, vp, vp, i64, vp]),
         "rrl_replay_push": (ci, [rp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_replay_sample_gather": (ci, [rp, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_creplay_sample_gather": (ci, [rp, i32, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp,

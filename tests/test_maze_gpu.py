@@ -1,0 +1,110 @@
+"""GPU parity tests for the Maze kernels vs the C oracle (bit-exact).  The oracle itself is
+PARITY UNPINNED w.r.t. MuJoCo."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from recovery_rl_amd import _lib
+from recovery_rl_amd.env import make_env, make_vec_env, register_env
+from recovery_rl_amd.env.maze import offline_data
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def hip_step(pos, action, t, seed=0, counter=0, horizon=100, auto_reset=False):
+    lib = _lib.load()
+    n = len(pos)
+    d = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=DEV)
+    pos_t, act_t, t_t = d(pos, np.float64), d(action, np.float32), d(t, np.int32)
+    o = dict(next_obs=torch.zeros(n, 2, device=DEV), obs=torch.zeros(n, 2, device=DEV),
+             reward=torch.zeros(n, device=DEV))
+    for k in ("done", "constraint", "success", "ep_done"):
+        o[k] = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    rc = lib.rrl_maze_step(n, _lib.ptr(pos_t), _lib.ptr(act_t), seed, counter, None, 0,
+                           _lib.ptr(o["next_obs"]), _lib.ptr(o["obs"]), _lib.ptr(o["reward"]),
+                           _lib.ptr(o["done"]), _lib.ptr(o["constraint"]), _lib.ptr(o["success"]),
+                           _lib.ptr(o["ep_done"]), _lib.ptr(t_t), horizon, int(auto_reset),
+                           _lib.current_stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in o.items()}
+    out["pos"], out["t"] = pos_t.cpu().numpy(), t_t.cpu().numpy()
+    return out
+
+
+def test_step_matches_oracle_golden_rows(golden_dir):
+    g = np.load(os.path.join(golden_dir, "maze_oracle_golden.npz"))
+    got = hip_step(g["pos"], g["act"], g["t"], seed=5, counter=3, auto_reset=True)
+    for k in ("done", "constraint", "success", "ep_done", "pos", "t", "obs"):
+        assert np.array_equal(got[k], g["out_" + k]), k
+    assert np.array_equal(got["next_obs"], g["out_next_pos64"].astype(np.float32))
+    assert np.array_equal(got["reward"], g["out_reward64"].astype(np.float32))
+
+
+@pytest.mark.parametrize("n", (1, 65, 4096, 70001))
+def test_step_matches_oracle_random(n):
+    rng = np.random.RandomState(n)
+    pos = rng.uniform(-0.29, 0.29, (n, 2))
+    act = rng.uniform(-0.12, 0.12, (n, 2)).astype(np.float32)
+    t = rng.randint(0, 100, n).astype(np.int32)
+    for auto in (False, True):
+        ref = co.maze_step(pos, act, t, seed=77, counter=5, auto_reset=auto)
+        got = hip_step(pos, act, t, seed=77, counter=5, auto_reset=auto)
+        for k in ("pos", "t", "next_obs", "obs", "reward", "done", "constraint", "success", "ep_done"):
+            assert np.array_equal(got[k], ref[k]), k
+
+
+def test_vec_env_episode_matches_oracle():
+    n = 512
+    env = make_vec_env("maze", n, device=DEV, seed=21)
+    env.reset()
+    pos, _, t = co.maze_reset(n, seed=21, counter=0)
+    assert np.array_equal(env.pos.cpu().numpy(), pos)
+    for k in range(150):
+        act = (env.expert_action() if k % 3 else env.sample_actions()).contiguous()
+        obs, rew, done, info = env.step(act)
+        ref = co.maze_step(pos, act.cpu().numpy(), t, seed=21, counter=1 + k, auto_reset=True)
+        pos, t = ref["pos"], ref["t"]
+        assert np.array_equal(env.pos.cpu().numpy(), pos), k
+        assert np.array_equal(rew.cpu().numpy(), ref["reward"])
+        assert np.array_equal(done.cpu().numpy(), ref["done"])
+        assert np.array_equal(info["constraint"].cpu().numpy(), ref["constraint"])
+        assert np.array_equal(info["success"].cpu().numpy(), ref["success"])
+
+
+@pytest.mark.parametrize("mode,name", ((0, 'h'), (1, 'e'), (2, 'm'), (3, None)))
+def test_reset_modes_match_oracle(mode, name):
+    env = make_vec_env("maze", 3000, device=DEV, seed=8)
+    env.reset(difficulty=name)
+    pos, obs, _ = co.maze_reset(3000, mode=mode, seed=8, counter=0)
+    assert np.array_equal(env.pos.cpu().numpy(), pos)
+    assert np.array_equal(env.obs.cpu().numpy(), obs)
+
+
+@pytest.mark.parametrize("num", (0, 41, 10000))
+def test_offline_data_matches_oracle(num):
+    got = [x.cpu().numpy() for x in offline_data(num, seed=4, device=DEV)]
+    ref = co.maze_offline(num, 4)
+    assert len(got[0]) == len(ref[0]) == 2 * (num // 2)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+
+
+def test_single_env_protocol():
+    register_env("maze")
+    env = make_env("maze", device=DEV, seed=2)
+    assert env._max_episode_steps == 100 and env.action_space.high[0] == pytest.approx(0.1)
+    assert env.observation_space.shape == (2,)
+    s = env.reset()
+    assert -0.22 <= s[0] <= -0.13
+    env.reset(pos=(0.2, 0.0))
+    obs, r, done, info = env.step(env.expert_action())
+    assert set(info) == {"constraint", "reward", "state", "next_state", "action", "success"}
+    assert r == pytest.approx(-env.get_distance_score(), abs=1e-6)
+    for _ in range(5):
+        obs, r, done, info = env.step(env.expert_action())
+    assert done and info["success"] and not info["constraint"]
