@@ -157,6 +157,29 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
                               uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a,
                               float* r, float* s2, float* m, int64_t* idx_out, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * CEM.  Replaces the bookkeeping of CEMOptimizer.obtain_solution (recovery_rl/optimizers.py:73-124)
+ * for M independent planning problems (one per env that needs a recovery action); the cost
+ * function in between stays with the caller (MPC._compile_cost, recovery_rl/MPC.py:374-416).
+ *   mean, var [M,dim] f64 in/out; lb, ub [dim] f64; samples [M,pop,dim] f32; costs [M,pop] f32;
+ *   active [M] u8.
+ * rrl_cem_sample : active[m] = max(var[m]) > epsilon (the while-condition, :94; an env that went
+ *                  inactive stays inactive if `sticky` != 0); for active envs
+ *                  constrained_var = min(((mean-lb)/2)^2, ((ub-mean)/2)^2, var)   (:95-99)
+ *                  samples = truncnorm(-2,2) * sqrt(constrained_var) + mean -> f32 (:100-102)
+ * rrl_cem_update : for active envs: elites = the num_elites lowest-cost samples (NaN cost -> 1e6,
+ *                  MPC.py:415; ties broken by sample index), mean <- alpha*mean + (1-alpha)*mean(elites),
+ *                  var <- alpha*var + (1-alpha)*var(elites)                        (:111-117)
+ * pop <= 1024, dim <= 64.
+ * ------------------------------------------------------------------------------------------ */
+int rrl_cem_sample(int64_t M, int32_t pop, int32_t dim, const double* mean, const double* var,
+                   const double* lb, const double* ub, double epsilon, int sticky, uint8_t* active,
+                   uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                   float* samples, void* stream);
+int rrl_cem_update(int64_t M, int32_t pop, int32_t dim, int32_t num_elites, double alpha,
+                   const float* samples, const float* costs, double* mean, double* var,
+                   const uint8_t* active, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

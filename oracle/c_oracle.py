@@ -179,6 +179,33 @@ def maze_offline(num_transitions, seed):
     return s[:w], a[:w], c[:w], s2[:w], m[:w]
 
 
+def cem_sample(mean, var, lb, ub, pop, epsilon=1e-3, sticky=False, active=None, seed=0, counter=0):
+    M, dim = mean.shape
+    mean, var = (np.ascontiguousarray(x, np.float64) for x in (mean, var))
+    lb, ub = (np.ascontiguousarray(x, np.float64) for x in (lb, ub))
+    active = np.ones(M, np.uint8) if active is None else np.ascontiguousarray(active, np.uint8).copy()
+    samples = np.zeros((M, pop, dim), np.float32)
+    rc = lib().rrl_oracle_cem_sample(C.c_int64(M), C.c_int32(pop), C.c_int32(dim), _p(mean), _p(var), _p(lb),
+                                     _p(ub), C.c_double(epsilon), C.c_int(int(sticky)), _p(active),
+                                     C.c_uint64(seed), C.c_uint64(counter), _p(samples))
+    assert rc == 0
+    return samples, active
+
+
+def cem_update(samples, costs, mean, var, num_elites, alpha, active=None):
+    M, pop, dim = samples.shape
+    samples = np.ascontiguousarray(samples, np.float32)
+    costs = np.ascontiguousarray(costs, np.float32)
+    mean, var = (np.ascontiguousarray(x, np.float64).copy() for x in (mean, var))
+    if active is not None:
+        active = np.ascontiguousarray(active, np.uint8)
+    rc = lib().rrl_oracle_cem_update(C.c_int64(M), C.c_int32(pop), C.c_int32(dim), C.c_int32(num_elites),
+                                     C.c_double(alpha), _p(samples), _p(costs), _p(mean), _p(var), _p(active))
+    if rc != 0:
+        raise ValueError("Number of elites must be at most the population size.")
+    return mean, var
+
+
 class _Replay(C.Structure):
     _fields_ = [("s", C.c_void_p), ("a", C.c_void_p), ("r", C.c_void_p), ("s2", C.c_void_p),
                 ("m", C.c_void_p), ("cap", C.c_int64), ("pos", C.c_int64), ("size", C.c_int64)]

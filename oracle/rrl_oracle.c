@@ -622,3 +622,83 @@ int rrl_oracle_gather(const rrl_oracle_replay* rb, int32_t B, const int64_t* idx
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * CEM bookkeeping (recovery_rl/optimizers.py:73-124), M independent problems.
+ * Truncated normal: Philox normal redrawn until |z| <= 2 (scipy.stats.truncnorm(-2,2).rvs in the
+ * reference, :86-89,100 -- same distribution, different generator).
+ * ---------------------------------------------------------------------------------------- */
+static double truncnorm2(uint64_t seed, uint32_t row, uint64_t counter, uint32_t d)
+{
+    for (uint32_t attempt = 0;; ++attempt) {
+        double z[2];
+        rrl_oracle_normal2(seed, row, RRL_STREAM_CEM, (counter << 20) | ((uint64_t)d << 8) | attempt, z);
+        if ((z[0] >= -2.0 && z[0] <= 2.0) || attempt >= 255) return clip1(z[0], -2.0, 2.0);
+    }
+}
+
+int rrl_oracle_cem_sample(int64_t M, int32_t pop, int32_t dim, const double* mean, const double* var,
+                          const double* lb, const double* ub, double epsilon, int sticky,
+                          uint8_t* active, uint64_t seed, uint64_t counter, float* samples)
+{
+    for (int64_t m = 0; m < M; ++m) {
+        double vmax = var[m * dim];
+        for (int d = 1; d < dim; ++d) if (var[m * dim + d] > vmax) vmax = var[m * dim + d];
+        int act = vmax > epsilon;                                     /* optimizers.py:94 */
+        if (sticky && !active[m]) act = 0;
+        active[m] = (uint8_t)act;
+        if (!act) continue;
+        for (int32_t i = 0; i < pop; ++i)
+            for (int d = 0; d < dim; ++d) {
+                double mu = mean[m * dim + d];
+                double lo = (mu - lb[d]) / 2.0, hi = (ub[d] - mu) / 2.0;
+                double cv = lo * lo < hi * hi ? lo * lo : hi * hi;    /* :95-99 */
+                if (var[m * dim + d] < cv) cv = var[m * dim + d];
+                double z = truncnorm2(seed, (uint32_t)(m * pop + i), counter, (uint32_t)d);
+                samples[(m * pop + i) * dim + d] = (float)(z * sqrt(cv) + mu);   /* :100-102 */
+            }
+    }
+    return 0;
+}
+
+typedef struct { float cost; int32_t idx; } cem_key;
+static int cem_cmp(const void* a, const void* b)
+{
+    const cem_key* x = (const cem_key*)a; const cem_key* y = (const cem_key*)b;
+    if (x->cost < y->cost) return -1;
+    if (x->cost > y->cost) return 1;
+    return x->idx - y->idx;
+}
+
+int rrl_oracle_cem_update(int64_t M, int32_t pop, int32_t dim, int32_t num_elites, double alpha,
+                          const float* samples, const float* costs, double* mean, double* var,
+                          const uint8_t* active)
+{
+    if (num_elites > pop) return -1;                                  /* optimizers.py:66-68 */
+    cem_key* keys = (cem_key*)malloc(sizeof(cem_key) * (size_t)pop);
+    for (int64_t m = 0; m < M; ++m) {
+        if (active && !active[m]) continue;
+        for (int32_t i = 0; i < pop; ++i) {
+            float c = costs[m * pop + i];
+            keys[i].cost = (c != c) ? 1e6f : c;                       /* NaN -> 1e6, MPC.py:415 */
+            keys[i].idx = i;
+        }
+        qsort(keys, (size_t)pop, sizeof(cem_key), cem_cmp);           /* argsort(costs)[:num_elites], :111 */
+        for (int d = 0; d < dim; ++d) {
+            double sum = 0.0;
+            for (int32_t e = 0; e < num_elites; ++e)
+                sum += (double)samples[(m * pop + keys[e].idx) * dim + d];
+            double em = sum / (double)num_elites;                     /* np.mean(elites, 0) :113 */
+            double sq = 0.0;
+            for (int32_t e = 0; e < num_elites; ++e) {
+                double dv = (double)samples[(m * pop + keys[e].idx) * dim + d] - em;
+                sq += dv * dv;
+            }
+            double ev = sq / (double)num_elites;                      /* np.var(elites, 0) :114 */
+            mean[m * dim + d] = alpha * mean[m * dim + d] + (1.0 - alpha) * em;   /* :116 */
+            var[m * dim + d] = alpha * var[m * dim + d] + (1.0 - alpha) * ev;     /* :117 */
+        }
+    }
+    free(keys);
+    return 0;
+}

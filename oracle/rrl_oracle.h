@@ -112,6 +112,14 @@ int rrl_oracle_sample_stratified(const rrl_oracle_replay* rb, int32_t n_pos, int
 int rrl_oracle_gather(const rrl_oracle_replay* rb, int32_t B, const int64_t* idx, float* s,
                       float* a, float* r, float* s2, float* m);
 
+/* ---- CEM bookkeeping (recovery_rl/optimizers.py:73-124) ---- */
+int rrl_oracle_cem_sample(int64_t M, int32_t pop, int32_t dim, const double* mean, const double* var,
+                          const double* lb, const double* ub, double epsilon, int sticky,
+                          uint8_t* active, uint64_t seed, uint64_t counter, float* samples);
+int rrl_oracle_cem_update(int64_t M, int32_t pop, int32_t dim, int32_t num_elites, double alpha,
+                          const float* samples, const float* costs, double* mean, double* var,
+                          const uint8_t* active);
+
 #ifdef __cplusplus
 }
 #endif

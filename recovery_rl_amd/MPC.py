@@ -1,0 +1,232 @@
+"""PETS / CEM model-based recovery controller (reference: recovery_rl/MPC.py:55-467), batched
+over the envs that need a recovery action and resident on the GPU.
+
+Same method names as the reference: `train(obs_trajs, acs_trajs, random, next_obs, epochs)`,
+`act(obs, t)`, `update_value_func(vf)`, `reset()`, `_compile_cost`, `_predict_next_obs`,
+`_expand_to_ts_format`, `_flatten_to_matrix`.  Differences:
+  * `act(obs[N,2], t, mask)` plans for the rows with mask != 0 only (compacted), each with its own
+    persistent `prev_sol` row; a single numpy observation works as in the reference;
+  * the candidate rollout is chunked over envs to bound activation memory
+    (popsize * npart = 8000 rows per planning env);
+  * `mb_dynamics="env"` (extension) propagates candidates through the navigation step kernels
+    instead of the learned ensemble; the default "model" is the reference behaviour.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .optimizers import CEMOptimizer
+
+
+def shuffle_rows(arr):
+    """Independent permutation of every row (MPC.py:50-52)."""
+    idxs = torch.argsort(torch.rand(arr.shape, device=arr.device), dim=-1)
+    return torch.gather(arr, 1, idxs)
+
+
+def _required(cfg, key, message):
+    if cfg.get(key, None) is None:
+        raise ValueError(message)                                    # utils.get_required_argument
+    return cfg[key]
+
+
+class MPC:
+    optimizers = {"CEM": CEMOptimizer}
+    MAX_ROWS = 1 << 21       # rows per rollout chunk (activations: rows x 200 x 4 B x few)
+
+    def __init__(self, params, mb_dynamics="model", seed=0):
+        env = params.env
+        self.env = env
+        self.device = env.device
+        self.dO, self.dU = env.observation_space.shape[0], env.action_space.shape[0]
+        self.ac_ub = np.minimum(env.action_space.high, params.get("ac_ub", env.action_space.high))
+        self.ac_lb = np.maximum(env.action_space.low, params.get("ac_lb", env.action_space.low))
+        self.per = params.get("per", 1)
+        assert self.per == 1, "only per=1 (re-plan at every call) is supported, as config/default.py sets"
+        prop, opt = params.prop_cfg, params.opt_cfg
+        self.model_init_cfg = prop.get("model_init_cfg", {})
+        self.model_train_cfg = prop.get("model_train_cfg", {})
+        self.prop_mode = _required(prop, "mode", "Must provide propagation method.")
+        self.npart = _required(prop, "npart", "Must provide number of particles.")
+        self.obs_postproc = prop.get("obs_postproc", lambda obs, model_out: model_out)
+        self.targ_proc = prop.get("targ_proc", lambda obs, next_obs: next_obs)
+        self.opt_mode = _required(opt, "mode", "Must provide optimization method.")
+        self.plan_hor = _required(opt, "plan_hor", "Must provide planning horizon.")
+        self.obs_cost_fn = _required(opt, "obs_cost_fn", "Must provide cost on observations.")
+        self.ac_cost_fn = _required(opt, "ac_cost_fn", "Must provide cost on actions.")
+        assert self.opt_mode == 'CEM'
+        assert self.prop_mode == 'TSinf', 'only TSinf propagation mode is supported'
+        assert self.npart % self.model_init_cfg["num_nets"] == 0, \
+            "Number of particles must be a multiple of the ensemble size."
+        assert mb_dynamics in ("model", "env")
+        self.mb_dynamics = mb_dynamics
+
+        self.optimizer = CEMOptimizer(sol_dim=self.plan_hor * self.dU,
+                                      lower_bound=np.tile(self.ac_lb, [self.plan_hor]),
+                                      upper_bound=np.tile(self.ac_ub, [self.plan_hor]),
+                                      cost_function=self._compile_cost, device=self.device, seed=seed,
+                                      **opt.get("cfg", {}))
+        self.has_been_trained = prop.get("model_pretrained", False)
+        n = getattr(env, "num_envs", 1)
+        mid = np.tile((self.ac_lb + self.ac_ub) / 2, [self.plan_hor])           # MPC.py:174
+        self.prev_sol = torch.as_tensor(mid, dtype=torch.float64, device=self.device).repeat(n, 1)
+        self.init_var = torch.as_tensor(np.tile(np.square(self.ac_ub - self.ac_lb) / 16, [self.plan_hor]),
+                                        dtype=torch.float64, device=self.device)            # :175-176
+        self.train_in = torch.zeros(0, self.dO + self.dU, device=self.device)
+        self.train_targs = torch.zeros(0, self.dO, device=self.device)
+        print("Created an MPC controller, prop mode %s, %d particles. " % (self.prop_mode, self.npart))
+        print("Trajectory prediction logging is disabled.")
+        self.model = _required(self.model_init_cfg, "model_constructor",
+                               "Must provide a model constructor.")(self.model_init_cfg)
+        self.value_func = None
+        self._lb = torch.as_tensor(self.ac_lb, dtype=torch.float32, device=self.device)
+        self._ub = torch.as_tensor(self.ac_ub, dtype=torch.float32, device=self.device)
+
+    # -- model fitting (MPC.py:213-309) --------------------------------------------------------
+    def train(self, obs_trajs, acs_trajs, random=False, next_obs=False, epochs=None, batch_size=32,
+              progress=False):
+        dev = self.device
+        t = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev)
+        if random:
+            assert next_obs is not None
+            new_in = [torch.cat([t(obs_trajs), t(acs_trajs)], dim=-1)]
+            new_targ = [self.targ_proc(t(obs_trajs), t(next_obs))]
+        else:
+            new_in, new_targ = [], []
+            for obs, acs in zip(obs_trajs, acs_trajs):
+                obs, acs = t(obs), t(acs)
+                new_in.append(torch.cat([obs[:-1], acs], dim=-1))
+                new_targ.append(self.targ_proc(obs[:-1], obs[1:]))
+        self.train_in = torch.cat([self.train_in] + new_in, dim=0)
+        self.train_targs = torch.cat([self.train_targs] + new_targ, dim=0)
+        self.has_been_trained = True
+        self.model.fit_input_stats(self.train_in)
+        n = self.train_in.shape[0]
+        idxs = torch.randint(n, (self.model.num_nets, n), device=dev)          # bootstrap, :255-257
+        if epochs is None:
+            epochs = self.model_train_cfg['epochs']
+        num_batch = int(np.ceil(n / batch_size))
+        losses = None
+        for _ in range(epochs):
+            for b in range(num_batch):
+                bi = idxs[:, b * batch_size:(b + 1) * batch_size]
+                loss = 0.01 * (self.model.max_logvar.sum() - self.model.min_logvar.sum())
+                loss = loss + self.model.compute_decays()
+                mean, logvar = self.model(self.train_in[bi], ret_logvar=True)
+                inv_var = torch.exp(-logvar)
+                tl = ((mean - self.train_targs[bi]) ** 2) * inv_var + logvar
+                loss = loss + tl.mean(-1).mean(-1).sum()                       # :282-287
+                self.model.optim.zero_grad(set_to_none=True)
+                loss.backward()
+                self.model.optim.step()
+            idxs = shuffle_rows(idxs)
+            if progress:
+                with torch.no_grad():
+                    mean, _ = self.model(self.train_in[idxs[:, :5000]])
+                    losses = ((mean - self.train_targs[idxs[:, :5000]]) ** 2).mean(-1).mean(-1)
+                print("Network training: MSE per net", losses.cpu().numpy())
+        return losses
+
+    def reset(self):
+        mid = np.tile((self.ac_lb + self.ac_ub) / 2, [self.plan_hor])
+        self.prev_sol[:] = torch.as_tensor(mid, dtype=torch.float64, device=self.device)
+        self.optimizer.reset()
+
+    def update_value_func(self, value_func):
+        self.value_func = value_func
+
+    # -- acting (MPC.py:322-347) ---------------------------------------------------------------
+    @torch.no_grad()
+    def act(self, obs, t, mask=None, get_pred_cost=False):
+        single = not torch.is_tensor(obs)
+        if single:
+            obs = torch.as_tensor(np.asarray(obs, dtype=np.float32)[None], device=self.device)
+        n = obs.shape[0]
+        if not self.has_been_trained:                                         # :333-334
+            out = self._lb + (self._ub - self._lb) * torch.rand(n, self.dU, device=self.device)
+            return out[0].cpu().numpy() if single else out
+        out = torch.zeros(n, self.dU, dtype=torch.float32, device=self.device)
+        idx = torch.arange(n, device=self.device) if mask is None else mask.nonzero().squeeze(1)
+        if idx.numel() == 0:
+            return out
+        self.sy_cur_obs = obs[idx].contiguous()
+        rows = idx if self.prev_sol.shape[0] == n else torch.zeros_like(idx)
+        soln = self.optimizer.obtain_solution(self.prev_sol[rows], self.init_var.expand(idx.numel(), -1))
+        shifted = torch.cat([soln[:, self.per * self.dU:],
+                             torch.zeros(idx.numel(), self.per * self.dU, dtype=soln.dtype,
+                                         device=self.device)], dim=1)          # :342-344
+        self.prev_sol[rows] = shifted
+        out[idx] = soln[:, :self.dU].to(torch.float32)
+        return out[0].cpu().numpy() if single else out
+
+    # -- candidate evaluation (MPC.py:374-416) -------------------------------------------------
+    @torch.no_grad()
+    def _compile_cost(self, ac_seqs, cur_obs=None):
+        """ac_seqs [M, pop, plan_hor*dU] -> mean over particles of sum_t Q_risk(obs_t, ac_t): [M, pop]."""
+        single = not torch.is_tensor(ac_seqs)
+        if single:
+            ac_seqs = torch.as_tensor(ac_seqs, dtype=torch.float32, device=self.device)[None]
+        if cur_obs is None:
+            cur_obs = self.sy_cur_obs
+        cur_obs = torch.as_tensor(cur_obs, dtype=torch.float32, device=self.device).reshape(-1, self.dO)
+        M, pop = ac_seqs.shape[0], ac_seqs.shape[1]
+        per_env = pop * self.npart
+        chunk = max(1, self.MAX_ROWS // per_env)
+        outs = []
+        for lo in range(0, M, chunk):
+            outs.append(self._compile_cost_chunk(ac_seqs[lo:lo + chunk], cur_obs[lo:lo + chunk]))
+        costs = torch.cat(outs, dim=0)
+        return costs[0].cpu().numpy() if single else costs
+
+    def _compile_cost_chunk(self, ac_seqs, cur_obs):
+        M, pop = ac_seqs.shape[0], ac_seqs.shape[1]
+        H, P = self.plan_hor, self.npart
+        acs = ac_seqs.reshape(M, pop, H, self.dU).permute(2, 0, 1, 3)            # [H, M, pop, dU]
+        acs = acs[:, :, :, None, :].expand(H, M, pop, P, self.dU).reshape(H, M * pop * P, self.dU)
+        obs = cur_obs[:, None, None, :].expand(M, pop, P, self.dO).reshape(M * pop * P, self.dO)
+        costs = torch.zeros(M * pop, P, device=self.device)
+        if self.mb_dynamics == "env":
+            obs_seq = self._rollout_through_env(obs, acs.contiguous())
+        for t in range(H):
+            cur_acs = acs[t]
+            cost = self.value_func.get_value(obs, cur_acs).reshape(-1, P)
+            costs += cost
+            if self.mb_dynamics == "env":
+                obs = obs_seq[t]
+            else:
+                obs = self._predict_next_obs(obs, cur_acs)
+        costs = torch.where(costs != costs, torch.full_like(costs, 1e6), costs)     # NaN -> 1e6 (:415)
+        return costs.mean(dim=1).reshape(M, pop)
+
+    def _predict_next_obs(self, obs, acs):
+        """One TS-infinity step through the ensemble (MPC.py:421-439)."""
+        inputs = torch.cat((self._expand_to_ts_format(obs), self._expand_to_ts_format(acs)), dim=-1)
+        mean, var = self.model(inputs)
+        predictions = mean + torch.randn_like(mean) * var.sqrt()
+        return self.obs_postproc(obs, self._flatten_to_matrix(predictions))
+
+    def _expand_to_ts_format(self, mat):
+        """[rows, dim] -> [num_nets, rows / num_nets, dim]; particle p of every candidate is bound
+        to net p // (npart / num_nets) for the whole rollout (MPC.py:441-455)."""
+        dim = mat.shape[-1]
+        E = self.model.num_nets
+        return mat.reshape(-1, E, self.npart // E, dim).transpose(0, 1).reshape(E, -1, dim)
+
+    def _flatten_to_matrix(self, ts_fmt_arr):
+        """Inverse of _expand_to_ts_format (MPC.py:457-467)."""
+        dim = ts_fmt_arr.shape[-1]
+        E = self.model.num_nets
+        return ts_fmt_arr.reshape(E, -1, self.npart // E, dim).transpose(0, 1).reshape(-1, dim)
+
+    def _rollout_through_env(self, obs, acs):
+        """Extension (not the reference behaviour): ground-truth dynamics via rrl_nav_rollout."""
+        kind = {"navigation1": 0, "navigation2": 1}[self.env.env_name]
+        H, rows = acs.shape[0], acs.shape[1]
+        pos = obs.to(torch.float64).contiguous()
+        obs_seq = torch.empty(H, rows, 2, dtype=torch.float32, device=self.device)
+        lib = _lib.load()
+        rc = lib.rrl_nav_rollout(kind, rows, H, _lib.ptr(pos), _lib.ptr(acs), self.optimizer.seed ^ 0x5151,
+                                 0, _lib.ptr(self.optimizer.tick), _lib.ptr(obs_seq), None, None, None,
+                                 _lib.current_stream())
+        _lib.check(rc, "rrl_nav_rollout")
+        return obs_seq

@@ -25,6 +25,7 @@ EXPORTS = [
     "rrl_nav_offline",
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather",
+    "rrl_cem_sample", "rrl_cem_update",
 ]
 
 
@@ -67,7 +68,7 @@ _lib = None
 
 
 def _declare(lib):
-    vp, i32, i64, u64, ci = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int
+    vp, i32, i64, u64, ci, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int, C.c_double
     rp = C.POINTER(rrl_replay_t)
     sig = {
         "rrl_abi_version": (ci, []),
@@ -86,6 +87,8 @@ def _declare(lib):
         "rrl_replay_sample_gather": (ci, [rp, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_creplay_sample_gather": (ci, [rp, i32, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp,
                                            vp, vp]),
+        "rrl_cem_sample": (ci, [i64, i32, i32, vp, vp, vp, vp, f64, ci, vp, u64, u64, vp, u64, vp, vp]),
+        "rrl_cem_update": (ci, [i64, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -423,11 +423,18 @@ class Experiment:
         it = 0
         captured_gate = None
         mb = uses_mb_recovery(cfg)
+        # model-based recovery: the ensemble is re-fitted on the transitions gathered since the last
+        # fit every recovery_policy_update_freq * horizon iterations (the reference re-fits every
+        # recovery_policy_update_freq episodes, experiment.py:464-480); the batch size scales with
+        # num_envs so that an epoch keeps the reference's number of optimiser steps per env-step
+        mb_new = []
+        mb_every = cfg.recovery_policy_update_freq * self.env._max_episode_steps
+        graph_ok = (cfg.target_update_interval == 1 and not cfg.nu_schedule and not mb)
         while True:
             have_batch = len(self.memory) > cfg.batch_size
             random_actions = cfg.start_steps > loop.total_numsteps
             gate = self.online_qrisk_enabled() if uses_constraint_buffer(cfg) else False
-            steady = have_batch and not random_actions and not mb
+            steady = have_batch and not random_actions and graph_ok
             if steady and (loop.graph is None or captured_gate != gate):
                 loop.capture(online_qrisk=gate)
                 captured_gate = gate
@@ -436,6 +443,13 @@ class Experiment:
             else:
                 loop.vector_step(do_update=have_batch, random_actions=random_actions, online_qrisk=gate)
             it += 1
+            if mb and not cfg.disable_online_updates:
+                info_s, info_a, info_s2 = self.env.prev_obs, self.env.action_clipped, self.env.next_obs
+                mb_new.append((info_s.clone(), info_a.clone(), info_s2.clone()))
+                if it % mb_every == 0:
+                    S, A, S2 = (torch.cat(x) for x in zip(*mb_new))
+                    self.recovery_policy.train(S, A, random=True, next_obs=S2, batch_size=32 * n)
+                    mb_new = []
             if it % log_every == 0:
                 stats = loop.read_stats()
                 self._absorb(stats)

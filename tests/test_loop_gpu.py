@@ -138,3 +138,27 @@ def test_vectorized_run_stops_and_logs(tmp_path, capsys):
     assert data["num_envs"] == 64 and len(data["vector_stats"]) == len(hist)
     assert exp.loop.graph is not None                                # steady state ran from the hipGraph
     assert "Num Violations So Far: " in capsys.readouterr().out
+
+
+def test_model_based_recovery_runs_single_and_vectorised(tmp_path, capsys):
+    """RRL-MB (scripts/navigation2.sh:14): PETS ensemble pre-trained on the demos, CEM planner queried
+    where Q_risk > eps_safe, ensemble re-fitted online."""
+    base = ["--env-name", "navigation2", "--cuda", "--hidden_size", "32", "--logdir", str(tmp_path),
+            "--seed", "2", "--num_unsafe_transitions", "1500", "--critic_safe_pretraining_steps", "30",
+            "--use_recovery", "--gamma_safe", "0.65", "--eps_safe", "0.05", "--batch_size", "64",
+            "--start_steps", "10"]
+    cfg = arg_utils.get_args(base + ["--num_eps", "1"])
+    exp = Experiment(cfg)
+    assert exp.recovery_policy is not None and exp.recovery_policy.value_func is exp.agent.safety_critic
+    exp.run()
+    assert exp.recovery_policy.has_been_trained
+    n_demo = exp.num_unsafe_transitions
+    assert exp.recovery_policy.train_in.shape[0] >= n_demo          # demos + online episodes
+    data = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))
+    assert len(data["train_stats"]) == 1
+    cfg = arg_utils.get_args(base + ["--num_envs", "16", "--num_steps", "1700", "--log_every", "20"])
+    exp = Experiment(cfg)
+    hist = exp.run()
+    assert hist[-1]["env_steps"] > 1700
+    assert exp.recovery_policy.train_in.shape[0] > exp.num_unsafe_transitions   # online re-fit happened
+    assert exp.loop.graph is None                                    # MB planning is not graph-captured

@@ -1,0 +1,177 @@
+"""GPU parity tests: CEM kernels vs the C oracle (bit-exact) and vs the reference's CEM iteration
+(G8); MPC._compile_cost vs the reference KAT (G7c); batched planning end to end."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import arg_utils
+from oracle import c_oracle as co
+from recovery_rl_amd import _lib
+from recovery_rl_amd.MPC import MPC
+from recovery_rl_amd.config import create_config
+from recovery_rl_amd.env import make_vec_env
+from recovery_rl_amd.optimizers import CEMOptimizer
+from recovery_rl_amd.sac import SAC
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "mpc_golden.npz"))
+
+
+def T(x, dt=None):
+    return torch.as_tensor(np.ascontiguousarray(x), device=DEV) if dt is None else \
+        torch.as_tensor(np.ascontiguousarray(x, dtype=dt), device=DEV)
+
+
+def hip_cem_sample(mean, var, lb, ub, pop, epsilon=1e-3, sticky=False, active=None, seed=0, counter=0):
+    lib = _lib.load()
+    M, dim = mean.shape
+    mean_t, var_t, lb_t, ub_t = T(mean, np.float64), T(var, np.float64), T(lb, np.float64), T(ub, np.float64)
+    act = T(np.ones(M, np.uint8) if active is None else active, np.uint8)
+    samples = torch.zeros(M, pop, dim, device=DEV)
+    rc = lib.rrl_cem_sample(M, pop, dim, _lib.ptr(mean_t), _lib.ptr(var_t), _lib.ptr(lb_t), _lib.ptr(ub_t),
+                            epsilon, int(sticky), _lib.ptr(act), seed, counter, None, 0, _lib.ptr(samples),
+                            _lib.current_stream())
+    assert rc == 0
+    return samples.cpu().numpy(), act.cpu().numpy()
+
+
+def hip_cem_update(samples, costs, mean, var, ne, alpha, active=None):
+    lib = _lib.load()
+    M, pop, dim = samples.shape
+    s, c = T(samples, np.float32), T(costs, np.float32)
+    m, v = T(mean, np.float64).clone(), T(var, np.float64).clone()
+    a = None if active is None else T(active, np.uint8)
+    rc = lib.rrl_cem_update(M, pop, dim, ne, alpha, _lib.ptr(s), _lib.ptr(c), _lib.ptr(m), _lib.ptr(v),
+                            _lib.ptr(a), _lib.current_stream())
+    assert rc == 0
+    return m.cpu().numpy(), v.cpu().numpy()
+
+
+@pytest.mark.parametrize("M,pop,dim", ((1, 400, 10), (37, 400, 10), (5, 400, 30), (300, 64, 4), (2, 1000, 7)))
+def test_cem_kernels_match_oracle_bit_exact(M, pop, dim):
+    rng = np.random.RandomState(M * 1000 + pop + dim)
+    mean = rng.uniform(-0.9, 0.9, (M, dim))
+    var = rng.uniform(0.0, 0.3, (M, dim))
+    var[M // 2] = 1e-5
+    lb, ub = -np.ones(dim), np.ones(dim)
+    ref_s, ref_a = co.cem_sample(mean, var, lb, ub, pop, seed=9, counter=4)
+    got_s, got_a = hip_cem_sample(mean, var, lb, ub, pop, seed=9, counter=4)
+    assert np.array_equal(got_a, ref_a) and np.array_equal(got_s, ref_s)
+    costs = rng.randn(M, pop).astype(np.float32)
+    costs[0, :3] = np.nan                                   # NaN -> 1e6
+    costs[-1, 5] = costs[-1, 6]                             # tie -> lower index first
+    ne = max(1, pop // 10)
+    ref_m, ref_v = co.cem_update(ref_s, costs, mean, var, ne, 0.1, active=ref_a)
+    got_m, got_v = hip_cem_update(ref_s, costs, mean, var, ne, 0.1, active=ref_a)
+    assert np.array_equal(got_m, ref_m) and np.array_equal(got_v, ref_v)
+    assert np.array_equal(got_m[M // 2], mean[M // 2])      # inactive env untouched
+
+
+@pytest.mark.parametrize("case", ("mid", "edge"))
+def test_cem_update_kernel_matches_reference_iteration(G, case):
+    pre = "cem." + case + "."
+    m, v = hip_cem_update(G[pre + "samples"][None], G[pre + "costs"][None], G[pre + "init_mean"][None],
+                          G[pre + "init_var"][None], int(G["cem.num_elites"]), float(G["cem.alpha"]))
+    assert np.allclose(m[0], G[pre + "new_mean"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(v[0], G[pre + "new_var"], rtol=1e-4, atol=1e-7)
+
+
+def test_cem_optimizer_minimises_a_quadratic_for_many_problems():
+    M, dim = 64, 10
+    target = torch.rand(M, 1, dim, device=DEV) * 1.6 - 0.8
+    opt = CEMOptimizer(dim, max_iters=8, popsize=400, num_elites=40,
+                       cost_function=lambda s: ((s - target) ** 2).sum(-1), upper_bound=np.ones(dim),
+                       lower_bound=-np.ones(dim), alpha=0.1, device=DEV, seed=3)
+    sol = opt.obtain_solution(torch.zeros(M, dim, dtype=torch.float64, device=DEV),
+                              torch.full((M, dim), 0.25, dtype=torch.float64, device=DEV))
+    assert sol.shape == (M, dim) and (sol - target.squeeze(1)).abs().max() < 0.08
+    assert int(opt.tick[0].item()) == 8
+    with pytest.raises(ValueError):
+        CEMOptimizer(dim, 5, 10, 11, None, np.ones(dim), -np.ones(dim), device=DEV)
+    one = opt.obtain_solution(np.zeros(dim), np.full(dim, 0.25))
+    assert isinstance(one, np.ndarray) and one.shape == (dim,)
+
+
+def build_mpc(n_envs=1, mb_dynamics="model"):
+    env = make_vec_env("navigation2", n_envs, device=DEV, seed=1)
+    cfg = create_config("navigation2", "MPC", {}, [], "/tmp", env=env)
+    return env, MPC(cfg.ctrl_cfg, mb_dynamics=mb_dynamics, seed=1)
+
+
+def test_compile_cost_matches_reference(G):
+    """G7c: same ensemble weights, Q_risk weights, action sequences and injected particle noise."""
+    env, mpc = build_mpc()
+    sd = {k[3:]: T(G[k]) for k in G.files if k.startswith("pt.") and k[3:] in mpc.model.state_dict()}
+    mpc.model.load_state_dict(sd, strict=True)
+    mpc.model.inputs_mu.data = T(G["pt.fit_mu"])
+    mpc.model.inputs_sigma.data = T(G["pt.fit_sigma"])
+    args = arg_utils.get_args(["--env-name", "navigation2", "--hidden_size", "16", "--cuda", "--use_recovery",
+                               "--gamma_safe", "0.65", "--eps_safe", "0.2"])
+    agent = SAC(env.observation_space, env.action_space, args, "/tmp")
+    qsd = {k[len("cc.qrisk."):]: T(G[k]) for k in G.files if k.startswith("cc.qrisk.")}
+    agent.safety_critic.safety_critic.load_state_dict(qsd, strict=True)
+    mpc.update_value_func(agent.safety_critic)
+    noises = [T(n) for n in G["cc.noise"]]
+    real = torch.randn_like
+    torch.randn_like = lambda t, **k: noises.pop(0)
+    try:
+        costs = mpc._compile_cost(T(G["cc.ac_seqs"])[None], T(G["cc.cur_obs"], np.float32)[None])
+    finally:
+        torch.randn_like = real
+    assert costs.shape == (1, 6)
+    assert np.allclose(costs[0].cpu().numpy(), G["cc.costs"], rtol=2e-4, atol=1e-5)
+
+
+def test_untrained_controller_returns_uniform_actions_and_train_fits_dynamics():
+    env, mpc = build_mpc(n_envs=8)
+    a = mpc.act(env.reset(), 0)
+    assert a.shape == (8, 2) and (a.abs() <= 1).all() and not mpc.has_been_trained
+    # transitions of the true dynamics: s' = s + a + 0.05 eps
+    g = torch.Generator(device=DEV).manual_seed(0)
+    s = torch.rand(4000, 2, device=DEV, generator=g) * torch.tensor([40.0, 30.0], device=DEV) - \
+        torch.tensor([45.0, 15.0], device=DEV)
+    ac = torch.rand(4000, 2, device=DEV, generator=g) * 2 - 1
+    s2 = s + ac + 0.05 * torch.randn(4000, 2, device=DEV, generator=g)
+    mse = mpc.train(s, ac, random=True, next_obs=s2, epochs=6, progress=True)
+    assert mpc.has_been_trained and mpc.train_in.shape == (4000, 4) and mpc.train_targs.shape == (4000, 2)
+    assert float(mse.max()) < 0.05                           # learned delta = a (+ noise var 0.0025)
+    # incremental call with trajectories appends obs[:-1], acs -> obs[1:] - obs[:-1]
+    traj_o, traj_a = torch.cumsum(torch.ones(6, 2, device=DEV), 0), torch.ones(5, 2, device=DEV)
+    mpc.train([traj_o], [traj_a], epochs=1)
+    assert mpc.train_in.shape == (4005, 4)
+    assert torch.equal(mpc.train_targs[-5:], torch.ones(5, 2, device=DEV))
+
+
+@pytest.mark.parametrize("mb_dynamics", ("model", "env"))
+def test_batched_planning_steers_away_from_the_obstacle(mb_dynamics):
+    """Envs left of the box (navigation2.py:41) heading right: a value function that is high inside
+    the box makes the planner choose actions with a negative x component."""
+    env, mpc = build_mpc(n_envs=16, mb_dynamics=mb_dynamics)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    s = torch.rand(6000, 2, device=DEV, generator=g) * torch.tensor([30.0, 30.0], device=DEV) - \
+        torch.tensor([45.0, 15.0], device=DEV)
+    ac = torch.rand(6000, 2, device=DEV, generator=g) * 2 - 1
+    mpc.train(s, ac, random=True, next_obs=s + ac, epochs=8)
+
+    class BoxRisk:
+        def get_value(self, states, actions, encoded=False):
+            nxt = states + actions
+            inside = (nxt[:, 0] >= -31.5) & (nxt[:, 0] <= -20) & (nxt[:, 1].abs() <= 7.5)
+            return inside.float().unsqueeze(1)
+    mpc.update_value_func(BoxRisk())
+    obs = torch.tensor([[-32.0, 0.0]], device=DEV).repeat(16, 1)
+    mask = torch.zeros(16, dtype=torch.bool, device=DEV)
+    mask[::2] = True
+    act = mpc.act(obs, 0, mask=mask)
+    assert act.shape == (16, 2)
+    assert (act[1::2] == 0).all()                            # rows outside the mask are not planned
+    assert (act[::2, 0] < 0.3).all() and act[::2, 0].mean() < 0
+    assert not torch.equal(mpc.prev_sol[0], mpc.prev_sol[1])  # planned rows shifted their warm start
+    assert torch.equal(mpc.prev_sol[1], torch.zeros(10, dtype=torch.float64, device=DEV))
