@@ -39,7 +39,7 @@ def config2_argv(seed, num_envs=NUM_ENVS):
             "--num_envs", str(num_envs), "--seed", str(seed)]
 
 
-def build_loop(cfg, device):
+def build_loop(cfg, device, fast=True):
     from recovery_rl_amd.env import make_vec_env, register_env
     from recovery_rl_amd.experiment import VectorLoop
     from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
@@ -48,6 +48,8 @@ def build_loop(cfg, device):
     register_env(cfg.env_name)
     env = make_vec_env(cfg.env_name, cfg.num_envs, device=device, seed=cfg.seed)
     agent = SAC(env.observation_space, env.action_space, cfg, "/tmp")
+    if fast:
+        agent.enable_fast_path(cfg.batch_size)
     memory = ReplayMemory(cfg.replay_size, cfg.seed, device=device)
     recovery_memory = ConstraintReplayMemory(cfg.safe_replay_size, cfg.seed, device=device)
     # offline constraint demonstrations + a short (untimed) Q_risk pre-training
@@ -161,6 +163,8 @@ def main():
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_sweep", action="store_true")
+    ap.add_argument("--autograd_updates", action="store_true",
+                    help="PyTorch autograd + vendor GEMMs for the updates instead of the fused HIP kernels")
     a = ap.parse_args()
 
     rank, local_rank, world = dist_utils.init()
@@ -170,7 +174,7 @@ def main():
     device = torch.device("cuda", local_rank)
 
     cfg = arg_utils.get_args(config2_argv(dist_utils.rank_seed(1, rank), a.num_envs))
-    loop = build_loop(cfg, device)
+    loop = build_loop(cfg, device, fast=not a.autograd_updates)
     step = loop.replay if not a.no_graph else (lambda: loop.vector_step(True, False, True))
     if not a.no_graph:
         loop.capture(online_qrisk=True)
@@ -232,6 +236,8 @@ def main():
                        "num_envs_per_gpu": a.num_envs, "batch_size": cfg.batch_size,
                        "hidden_size": cfg.hidden_size, "updates_per_step": cfg.updates_per_step,
                        "launch": "eager" if a.no_graph else "hipGraph replay",
+                       "updates": "autograd + vendor GEMM" if a.autograd_updates else
+                                  "hand-written HIP forward/backward (f32 MFMA) + fused Adam",
                        "parallelism": "replicas x%d (RCCL metric all-reduce only)" % world},
             "episodes": agg["episodes"], "violations": agg["num_viols"], "successes": agg["num_successes"],
         }

@@ -180,6 +180,61 @@ int rrl_cem_update(int64_t M, int32_t pop, int32_t dim, int32_t num_elites, doub
                    const float* samples, const float* costs, double* mean, double* var,
                    const uint8_t* active, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * MLP building block.  Replaces the nn.Linear forward/backward of the SAC / Q_risk networks
+ * (recovery_rl/model.py:49-76,172-199,295-343,489-530) for G heads in one launch; exact f32
+ * (v_mfma_f32_32x32x2_f32), one wavefront per 32x32 output tile.  Row-major, leading dimensions
+ * in elements, per-head strides s*.
+ *   mode 0 (NT): C[g] = A[g] . B[g]^T (+ bias[g][n]) (relu)          A [M,K], B [N,K]
+ *   mode 1 (NN): C[g] = A[g] . B[g]   (zeroed where mask[g] <= 0)    A [M,K], B [K,N], mask like C
+ *   mode 2 (TN): C[g] = A[g]^T . B[g] ; colsum[g][m] = sum_k A[k][m] A [K,M], B [K,N]
+ *   accumulate != 0: C += result.
+ * ------------------------------------------------------------------------------------------ */
+int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, long long sA,
+                 const float* B, int ldb, long long sB, float* C, int ldc, long long sC,
+                 const float* bias, long long sBias, int relu, const float* mask, int ldmask,
+                 long long sMask, float* colsum, long long sColsum, int accumulate, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Fused element-wise pieces of the updates (one launch each instead of a chain of PyTorch ops).
+ *   rrl_gauss_head_fwd/bwd   GaussianPolicy.sample and its backward (recovery_rl/model.py:324-340);
+ *                            head[b] = (mean0, mean1, log_std0, log_std1) raw linear outputs
+ *   rrl_sac_critic_grad      target r + m gamma (min Q' - alpha log pi') and d(mse1+mse2)/dq
+ *                            (recovery_rl/sac.py:192-214); q, qt are [2,B]; loss[2] = the two MSEs
+ *   rrl_sac_policy_grad      d mean(alpha log pi - min Q)/dq (sac.py:216-231); loss[1]
+ *   rrl_qrisk_critic_grad    target c + m gamma_safe max sigmoid(z') and d(mse1+mse2)/dz on PRE-sigmoid
+ *                            outputs (recovery_rl/qrisk.py:118-148)
+ *   rrl_qrisk_policy_grad    d mean(max sigmoid(z))/dz (qrisk.py:150-154)
+ *   rrl_stoch_head_fwd/bwd   StochasticPolicy.sample and its backward (model.py:511-525)
+ *   rrl_adam_step            torch.optim.Adam step over one flat f32 buffer + optional Polyak update
+ *                            of a target buffer (recovery_rl/utils.py:46-49); step_dev = uint64[2]
+ *                            {t, ticket}, t is incremented by the kernel
+ *   rrl_recovery_select      recovery gate max sigmoid(z) > eps_safe and action select
+ *                            (recovery_rl/experiment.py:546-577)
+ * ------------------------------------------------------------------------------------------ */
+int rrl_gauss_head_fwd(int B, const float* head, const float* eps, const float* scale, const float* bias,
+                       float* action, int ld_action, float* logp, float* mean_action, void* stream);
+int rrl_gauss_head_bwd(int B, const float* head, const float* eps, const float* scale,
+                       const float* d_action, int ld, float dlogp, float* dhead, void* stream);
+int rrl_sac_critic_grad(int B, const float* q, const float* qt, const float* logp2, const float* r,
+                        const float* m, float gamma, const float* alpha, const float* penalty, float* dq,
+                        float* loss, void* stream);
+int rrl_sac_policy_grad(int B, const float* qp, const float* logp, const float* alpha, float* dqp,
+                        float* loss, void* stream);
+int rrl_qrisk_critic_grad(int B, const float* z, const float* zt, const float* c, const float* m,
+                          float gamma_safe, float* dz, float* loss, void* stream);
+int rrl_qrisk_policy_grad(int B, const float* zp, float* dzp, float* loss, void* stream);
+int rrl_stoch_head_fwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
+                       const float* scale, const float* bias, float* action, int ld_action, float* mean_out,
+                       void* stream);
+int rrl_stoch_head_bwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
+                       const float* scale, const float* d_action, int ld, float* draw, float* dlog_std,
+                       void* stream);
+int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uint64_t* step_dev, float lr,
+                  float beta1, float beta2, float eps, float* target, float tau, void* stream);
+int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task_action,
+                        const float* rec_action, float* real_action, uint8_t* recovery, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ SO_PATH = os.path.join(CSRC, "librrl_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["nav_kernels.hip", "replay_kernels.hip", "maze_kernels.hip", "cem_kernels.hip",
-               "mlp_kernels.hip"]
+               "mlp_kernels.hip", "update_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                "-Wno-bitwise-instead-of-logical"]
@@ -26,6 +26,10 @@ EXPORTS = [
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather",
     "rrl_cem_sample", "rrl_cem_update",
+    "rrl_gemm_f32",
+    "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
+    "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
+    "rrl_adam_step", "rrl_recovery_select",
 ]
 
 
@@ -68,7 +72,8 @@ _lib = None
 
 
 def _declare(lib):
-    vp, i32, i64, u64, ci, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int, C.c_double
+    vp, i32, i64, u64, ci, f64, f32 = (C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int, C.c_double,
+                                      C.c_float)
     rp = C.POINTER(rrl_replay_t)
     sig = {
         "rrl_abi_version": (ci, []),
@@ -89,6 +94,19 @@ def _declare(lib):
                                            vp, vp]),
         "rrl_cem_sample": (ci, [i64, i32, i32, vp, vp, vp, vp, f64, ci, vp, u64, u64, vp, u64, vp, vp]),
         "rrl_cem_update": (ci, [i64, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]),
+        "rrl_gemm_f32": (ci, [ci, ci, ci, ci, ci, vp, ci, C.c_longlong, vp, ci, C.c_longlong, vp, ci,
+                              C.c_longlong, vp, C.c_longlong, ci, vp, ci, C.c_longlong, vp, C.c_longlong,
+                              ci, vp]),
+        "rrl_gauss_head_fwd": (ci, [ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]),
+        "rrl_gauss_head_bwd": (ci, [ci, vp, vp, vp, vp, ci, f32, vp, vp]),
+        "rrl_sac_critic_grad": (ci, [ci, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
+        "rrl_sac_policy_grad": (ci, [ci, vp, vp, vp, vp, vp, vp]),
+        "rrl_qrisk_critic_grad": (ci, [ci, vp, vp, vp, vp, f32, vp, vp, vp]),
+        "rrl_qrisk_policy_grad": (ci, [ci, vp, vp, vp, vp]),
+        "rrl_stoch_head_fwd": (ci, [ci, vp, vp, vp, f32, vp, vp, vp, ci, vp, vp]),
+        "rrl_stoch_head_bwd": (ci, [ci, vp, vp, vp, f32, vp, vp, ci, vp, vp, vp]),
+        "rrl_adam_step": (ci, [C.c_longlong, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, f32, vp]),
+        "rrl_recovery_select": (ci, [ci, vp, f32, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

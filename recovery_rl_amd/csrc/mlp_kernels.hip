@@ -1,0 +1,200 @@
+// mlp_kernels.hip -- f32 MFMA building blocks for the SAC / Q_risk multilayer perceptrons on
+// gfx950 (MI355X).
+//
+// The MLPs of the hot path are tiny (2 -> 256 -> 256 -> {1,2,4}; batch 256 for updates, 4096 rows
+// for acting).  Vendor GEMMs pick 256x256 macro-tiles for them (one workgroup, 40-60 us per
+// layer); here every 16x16 output tile is one wavefront running v_mfma_f32_16x16x4_f32 (exact
+// f32, bitwise an fmaf chain; 32-cycle issue, two accumulators cover its 40-cycle latency), so a
+// 256x256x256 layer is 256 independent waves (x heads), each 64 MFMAs deep, K staged through LDS
+// in 128-wide panels with the next panel's global loads in flight under the MFMAs.  One kernel, three operand layouts, fused prologue/epilogue:
+//
+//   mode NT :  C[g] = A[g] . B[g]^T (+ bias[g]) (relu)          forward   Y = X W^T + b
+//   mode NN :  C[g] = A[g] . B[g]   (* [S[g] > 0])              backward  dX = dY W   (relu mask of
+//                                                                          the producing layer)
+//   mode TN :  C[g] = A[g]^T . B[g] ; colsum[g] = sum_k A[g]    backward  dW = dY^T X ; db = sum dY
+//
+// All matrices row-major with explicit leading dimensions and per-head strides (g = blockIdx.z),
+// arbitrary M, N, K (edges are zero-filled / bounds-checked).
+#include <hip/hip_runtime.h>
+
+#include "rrl_host.hpp"
+
+namespace {
+
+using rrl_host::check_launch;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTile = 16;    // output tile edge: one wavefront per 16x16 tile (v_mfma_f32_16x16x4_f32)
+constexpr int kPanel = 128;  // K elements per panel
+constexpr int kLd = 20;      // LDS tile[k][20]: 16 columns + 4 pad, rows 16-byte aligned
+constexpr int kVec = 8;      // float4 per lane per operand per panel
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;    // NT: [N] per head, nullable
+    const float* mask;    // NN: saved activation, same shape as C, nullable
+    float* colsum;        // TN: [M] per head, nullable (written by the blockIdx.x == 0 tiles)
+    int M, N, K;
+    int lda, ldb, ldc, ldmask;
+    long long sA, sB, sC, sBias, sMask, sColsum;  // per-head strides (elements)
+    int relu;
+    int accumulate;       // C += result
+};
+
+struct Frag {
+    float4 v[kVec];
+};
+
+__device__ __forceinline__ float4 load4(const float* p, int avail) {
+    // avail = number of valid floats at p (may be <= 0)
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (avail >= 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+        q = *reinterpret_cast<const float4*>(p);
+    } else {
+        if (avail > 0) q.x = p[0];
+        if (avail > 1) q.y = p[1];
+        if (avail > 2) q.z = p[2];
+        if (avail > 3) q.w = p[3];
+    }
+    return q;
+}
+
+// The K order inside a panel is permuted (the sum over k does not care): MFMA step s = 4 j + t of
+// lane group q = lane >> 4 consumes k = 16 j + 4 q + t.  An operand whose k index is contiguous in
+// memory (rows = M or N index) is then exactly element t of the lane's j-th float4 of its own row
+// i = lane & 15 -- it feeds the MFMA straight from registers, no LDS.
+__device__ __forceinline__ void load_direct(Frag& f, const float* __restrict__ src, int ld, int row0,
+                                            int rows, int k0, int K, int lane) {
+    const int gr = row0 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+        const int k = k0 + 16 * j + 4 * (lane >> 4);
+        f.v[j] = (gr < rows) ? load4(src + (long long)gr * ld + k, K - k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// An operand stored [k][col] (col contiguous) is staged through LDS: coalesced float4 loads along
+// the columns, one ds_write_b128 each, read back as tile[k][i].
+__device__ __forceinline__ void load_staged(Frag& f, const float* __restrict__ src, int ld, int col0,
+                                            int cols, int k0, int K, int lane) {
+    const int c = col0 + (lane & 3) * 4;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+        const int k = k0 + (lane >> 2) + 16 * j;
+        f.v[j] = (k < K) ? load4(src + (long long)k * ld + c, cols - c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void store_staged(const Frag& f, float* tile, int lane) {
+#pragma unroll
+    for (int j = 0; j < kVec; ++j)
+        *reinterpret_cast<float4*>(tile + ((lane >> 2) + 16 * j) * kLd + (lane & 3) * 4) = f.v[j];
+}
+
+__device__ __forceinline__ float elem(const float4& q, int t) {
+    return t == 0 ? q.x : (t == 1 ? q.y : (t == 2 ? q.z : q.w));
+}
+
+template <int MODE>  // 0 NT, 1 NN, 2 TN
+__global__ __launch_bounds__(64) void gemm16_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[MODE == 2 ? kPanel * kLd : 4];
+    __shared__ __attribute__((aligned(16))) float Bs[MODE != 0 ? kPanel * kLd : 4];
+    const int lane = threadIdx.x;
+    const int g = blockIdx.z;
+    const int m0 = blockIdx.y * kTile, n0 = blockIdx.x * kTile;
+    const float* A = a.A + g * a.sA;
+    const float* B = a.B + g * a.sB;
+    float* C = a.C + g * a.sC;
+    constexpr bool kStageA = MODE == 2, kStageB = MODE != 0;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float asum = 0.f;  // TN: running sum of my A operands (for colsum)
+    Frag fa, fb;
+
+    auto load = [&](int k0) {
+        if (kStageA) load_staged(fa, A, a.lda, m0, a.M, k0, a.K, lane);
+        else load_direct(fa, A, a.lda, m0, a.M, k0, a.K, lane);
+        if (kStageB) load_staged(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
+        else load_direct(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
+    };
+
+    const int np = (a.K + kPanel - 1) / kPanel;
+    const int i = lane & 15, q = lane >> 4;
+    load(0);
+    for (int p = 0; p < np; ++p) {
+        Frag ca = fa, cb = fb;           // operands of this panel (registers)
+        if (kStageA || kStageB) {
+            if (p) __syncthreads();      // the previous panel's LDS reads are done
+            if (kStageA) store_staged(fa, As, lane);
+            if (kStageB) store_staged(fb, Bs, lane);
+            __syncthreads();
+        }
+        if (p + 1 < np) load((p + 1) * kPanel);   // next panel's global loads fly under the MFMAs
+        const int klen = min(kPanel, a.K - p * kPanel);
+#pragma unroll
+        for (int j = 0; j < kVec; ++j) {
+            if (16 * j < klen) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int k = 16 * j + 4 * q + t;
+                    const float av = kStageA ? As[k * kLd + i] : elem(ca.v[j], t);
+                    const float bv = kStageB ? Bs[k * kLd + i] : elem(cb.v[j], t);
+                    if (MODE == 2) asum += av;
+                    if (t & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
+                }
+            }
+        }
+    }
+    const f32x4 acc = acc0 + acc1;
+
+    // epilogue: lane holds C[row][col], col = lane & 15, row = 4 (lane >> 4) + r
+    const int col = n0 + (lane & 15);
+    const float bias = (MODE == 0 && a.bias && col < a.N) ? a.bias[g * a.sBias + col] : 0.f;
+    if (col < a.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 4 * (lane >> 4) + r;
+            if (row < a.M) {
+                float v = acc[r] + bias;
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                if (MODE == 1 && a.mask) {
+                    const float s = a.mask[g * a.sMask + (long long)row * a.ldmask + col];
+                    v = s > 0.f ? v : 0.f;
+                }
+                float* dst = C + (long long)row * a.ldc + col;
+                *dst = a.accumulate ? (*dst + v) : v;
+            }
+        }
+    }
+    if (MODE == 2 && a.colsum && blockIdx.x == 0) {
+        float tot = asum + __shfl_xor(asum, 16);
+        tot += __shfl_xor(tot, 32);
+        const int row = m0 + (lane & 15);
+        if (lane < 16 && row < a.M) a.colsum[g * a.sColsum + row] = tot;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, long long sA,
+                 const float* B, int ldb, long long sB, float* C, int ldc, long long sC,
+                 const float* bias, long long sBias, int relu, const float* mask, int ldmask,
+                 long long sMask, float* colsum, long long sColsum, int accumulate, void* stream) {
+    if (mode < 0 || mode > 2 || !A || !B || !C) return RRL_EINVAL;
+    if (G <= 0 || M <= 0 || N <= 0 || K <= 0 || G > 65535) return RRL_ERANGE;
+    GemmArgs a{A, B, C, bias, mask, colsum, M, N, K, lda, ldb, ldc, ldmask,
+               sA, sB, sC, sBias, sMask, sColsum, relu, accumulate};
+    const dim3 grid((N + kTile - 1) / kTile, (M + kTile - 1) / kTile, G), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL((gemm16_kernel<0>), grid, block, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((gemm16_kernel<1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm16_kernel<2>), grid, block, 0, st, a);
+    return check_launch();
+}
+
+}  // extern "C"

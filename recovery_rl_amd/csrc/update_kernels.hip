@@ -1,0 +1,338 @@
+// update_kernels.hip -- fused element-wise pieces of the SAC / Q_risk updates on gfx950.
+//
+// Each kernel replaces a chain of 5-30 PyTorch element-wise launches of recovery_rl/sac.py:192-239,
+// qrisk.py:118-158 and model.py:324-340 (and their autograd backward) by one launch; together with
+// rrl_gemm_f32 they give a hand-written forward + backward for the 2-hidden-layer MLPs.
+// Batches are tiny (B = 256): one workgroup, latency-bound by design.
+#include <hip/hip_runtime.h>
+
+#include "rrl_device.hpp"
+#include "rrl_host.hpp"
+
+namespace {
+
+using rrl_host::check_launch;
+using rrl_host::grid_for;
+using rrl_host::kBlock;
+
+constexpr float kLogSigMax = 2.f, kLogSigMin = -20.f, kEps = 1e-6f;   // model.py:14-16
+constexpr float kHalfLog2Pi = 0.918938533204672742f;
+
+__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
+
+// ---- tanh-Gaussian head (GaussianPolicy.sample, model.py:324-340) -------------------------------
+// head[b] = (mean0, mean1, log_std0, log_std1) raw outputs of the last linear layer
+__global__ void gauss_head_fwd_kernel(int B, const float* head, const float* eps, const float* scale,
+                                      const float* bias, float* action, int ld_action, float* logp,
+                                      float* mean_action) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float lp = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float mean = head[4 * b + j];
+        const float ls = fminf(fmaxf(head[4 * b + 2 + j], kLogSigMin), kLogSigMax);
+        const float e = eps[2 * b + j];
+        const float y = tanhf(mean + expf(ls) * e);
+        action[(long long)b * ld_action + j] = y * scale[j] + bias[j];
+        lp += -0.5f * e * e - ls - kHalfLog2Pi - logf(scale[j] * (1.f - y * y) + kEps);
+        if (mean_action) mean_action[2 * b + j] = tanhf(mean) * scale[j] + bias[j];
+    }
+    if (logp) logp[b] = lp;
+}
+
+// backward of the head: given dL/d action[b,j] (d_action, leading dim ld) and dL/d logp[b] = dlogp
+// (a constant, alpha / B) produce dL/d head[b, 0..3]
+__global__ void gauss_head_bwd_kernel(int B, const float* head, const float* eps, const float* scale,
+                                      const float* d_action, int ld, float dlogp, float* dhead) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float mean = head[4 * b + j];
+        const float raw = head[4 * b + 2 + j];
+        const float ls = fminf(fmaxf(raw, kLogSigMin), kLogSigMax);
+        const float std = expf(ls), e = eps[2 * b + j];
+        const float y = tanhf(mean + std * e);
+        const float one_m = 1.f - y * y;
+        // action = y scale + bias ; logp term = -log(scale (1 - y^2) + eps)
+        const float dx = d_action[(long long)b * ld + j] * scale[j] * one_m +
+                         dlogp * (2.f * scale[j] * y * one_m) / (scale[j] * one_m + kEps);
+        const bool inside = (raw >= kLogSigMin) & (raw <= kLogSigMax);   // clamp passes gradient inside
+        dhead[4 * b + j] = dx;
+        dhead[4 * b + 2 + j] = inside ? (dx * std * e - dlogp) : 0.f;
+    }
+}
+
+// ---- SAC critic target + loss gradient (sac.py:192-214) -----------------------------------------
+// q, qt: [2, B] (online on (s,a); target on (s', a')); dq = d(mse1 + mse2)/dq ; loss[0..1] = mse
+__global__ void sac_critic_grad_kernel(int B, const float* q, const float* qt, const float* logp2,
+                                       const float* r, const float* m, float gamma, const float* alpha,
+                                       const float* penalty, float* dq, float* loss) {
+    __shared__ float red[2][kBlock];
+    float l0 = 0.f, l1 = 0.f;
+    for (int b = threadIdx.x; b < B; b += kBlock) {
+        float y = r[b] + m[b] * gamma * (fminf(qt[b], qt[B + b]) - alpha[0] * logp2[b]);
+        if (penalty) y -= penalty[b];                 // RCPO: lambda * Q_risk (sac.py:202-205)
+        const float e0 = q[b] - y, e1 = q[B + b] - y;
+        dq[b] = 2.f * e0 / B;
+        dq[B + b] = 2.f * e1 / B;
+        l0 += e0 * e0;
+        l1 += e1 * e1;
+    }
+    red[0][threadIdx.x] = l0;
+    red[1][threadIdx.x] = l1;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) { loss[0] = red[0][0] / B; loss[1] = red[1][0] / B; }
+}
+
+// ---- SAC policy loss gradient (sac.py:216-231) ---------------------------------------------------
+// loss = mean(alpha logp - min(q1,q2)); dqp[i][b] = -1/B on the smaller head (ties split)
+__global__ void sac_policy_grad_kernel(int B, const float* qp, const float* logp, const float* alpha,
+                                       float* dqp, float* loss) {
+    __shared__ float red[kBlock];
+    float l = 0.f;
+    for (int b = threadIdx.x; b < B; b += kBlock) {
+        const float a = qp[b], c = qp[B + b];
+        const float w0 = a < c ? 1.f : (a == c ? 0.5f : 0.f);
+        dqp[b] = -w0 / B;
+        dqp[B + b] = -(1.f - w0) / B;
+        l += alpha[0] * logp[b] - fminf(a, c);
+    }
+    red[threadIdx.x] = l;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) loss[0] = red[0] / B;
+}
+
+// ---- Q_risk critic target + loss gradient (qrisk.py:118-148) ------------------------------------
+// z, zt: [2,B] PRE-sigmoid outputs; q = sigmoid(z); y = c + m gamma_safe max(sigmoid(zt))
+__global__ void qrisk_critic_grad_kernel(int B, const float* z, const float* zt, const float* c,
+                                         const float* m, float gamma_safe, float* dz, float* loss) {
+    __shared__ float red[2][kBlock];
+    float l0 = 0.f, l1 = 0.f;
+    for (int b = threadIdx.x; b < B; b += kBlock) {
+        const float y = c[b] + m[b] * gamma_safe * fmaxf(sigmoidf(zt[b]), sigmoidf(zt[B + b]));
+        const float q0 = sigmoidf(z[b]), q1 = sigmoidf(z[B + b]);
+        const float e0 = q0 - y, e1 = q1 - y;
+        dz[b] = 2.f * e0 / B * q0 * (1.f - q0);
+        dz[B + b] = 2.f * e1 / B * q1 * (1.f - q1);
+        l0 += e0 * e0;
+        l1 += e1 * e1;
+    }
+    red[0][threadIdx.x] = l0;
+    red[1][threadIdx.x] = l1;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) { loss[0] = red[0][0] / B; loss[1] = red[1][0] / B; }
+}
+
+// loss = mean(max(sigmoid(z1), sigmoid(z2))) (qrisk.py:150-154): dz on the larger head
+__global__ void qrisk_policy_grad_kernel(int B, const float* zp, float* dzp, float* loss) {
+    __shared__ float red[kBlock];
+    float l = 0.f;
+    for (int b = threadIdx.x; b < B; b += kBlock) {
+        const float q0 = sigmoidf(zp[b]), q1 = sigmoidf(zp[B + b]);
+        const float w0 = q0 > q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
+        dzp[b] = w0 / B * q0 * (1.f - q0);
+        dzp[B + b] = (1.f - w0) / B * q1 * (1.f - q1);
+        l += fmaxf(q0, q1);
+    }
+    red[threadIdx.x] = l;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) loss[0] = red[0] / B;
+}
+
+// ---- model-free recovery policy head (StochasticPolicy, model.py:511-525) ------------------------
+// raw[b] = last linear output (2); mean = tanh(raw) scale + bias; action = mean + exp(max(log_std, min)) eps
+__global__ void stoch_head_fwd_kernel(int B, const float* raw, const float* eps, const float* log_std,
+                                      float min_log_std, const float* scale, const float* bias,
+                                      float* action, int ld_action, float* mean_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float mean = tanhf(raw[2 * b + j]) * scale[j] + bias[j];
+        const float std = expf(fmaxf(log_std[j], min_log_std));
+        const float e = eps ? eps[2 * b + j] : 0.f;
+        action[(long long)b * ld_action + j] = mean + std * e;
+        if (mean_out) mean_out[2 * b + j] = mean;
+    }
+}
+
+// d_action [B,2] (leading dim ld) -> draw [B,2] and dlog_std[2] (sum over the batch; single workgroup)
+__global__ void stoch_head_bwd_kernel(int B, const float* raw, const float* eps, const float* log_std,
+                                      float min_log_std, const float* scale, const float* d_action, int ld,
+                                      float* draw, float* dlog_std) {
+    __shared__ float red[2][kBlock];
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = threadIdx.x; b < B; b += kBlock) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float t = tanhf(raw[2 * b + j]);
+            const float da = d_action[(long long)b * ld + j];
+            draw[2 * b + j] = da * scale[j] * (1.f - t * t);
+            const float std = expf(fmaxf(log_std[j], min_log_std));
+            const float g = (log_std[j] >= min_log_std) ? da * std * eps[2 * b + j] : 0.f;
+            if (j == 0) s0 += g; else s1 += g;
+        }
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { dlog_std[0] = red[0][0]; dlog_std[1] = red[1][0]; }
+}
+
+// ---- Adam (+ Polyak target update) over one flat parameter buffer -------------------------------
+// torch.optim.Adam semantics (no weight decay, no amsgrad):
+//   m <- m + (g - m)(1 - b1) ; v <- b2 v + (1 - b2) g^2 ; p <- p - lr/(1 - b1^t) m / (sqrt(v)/sqrt(1 - b2^t) + eps)
+// then, if target: target <- (1 - tau) target + tau p     (utils.soft_update, utils.py:46-49)
+// step_dev = {t, ticket}: t is read by every workgroup, the last one to finish stores t + 1.
+__global__ __launch_bounds__(kBlock) void adam_kernel(long long n, float* p, const float* g, float* m,
+                                                      float* v, uint64_t* step_dev, float lr, float b1,
+                                                      float b2, float eps, float* target, float tau) {
+    const double t = double(step_dev[0] + 1);
+    const float bc1 = float(1.0 - pow(double(b1), t));
+    const float bc2_sqrt = float(sqrt(1.0 - pow(double(b2), t)));
+    const float step_size = lr / bc1;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float pi = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        p[i] = pi;
+        if (target) target[i] = target[i] * (1.f - tau) + pi * tau;
+    }
+    rrl::advance_counter(step_dev, 1);
+}
+
+// ---- acting: recovery gate (experiment.py:546-577) ------------------------------------------------
+// z [2,N] pre-sigmoid Q_risk(s, a_task); recovery = max(sigmoid) > eps_safe; real = recovery ? rec : task
+__global__ void recovery_select_kernel(int N, const float* z, float eps_safe, const float* task_action,
+                                       const float* rec_action, float* real_action, uint8_t* recovery) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    const bool rec = fmaxf(sigmoidf(z[b]), sigmoidf(z[N + b])) > eps_safe;
+    recovery[b] = uint8_t(rec);
+    real_action[2 * b] = rec ? rec_action[2 * b] : task_action[2 * b];
+    real_action[2 * b + 1] = rec ? rec_action[2 * b + 1] : task_action[2 * b + 1];
+}
+
+inline dim3 rows_grid(int B) { return dim3((B + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+extern "C" {
+
+int rrl_gauss_head_fwd(int B, const float* head, const float* eps, const float* scale, const float* bias,
+                       float* action, int ld_action, float* logp, float* mean_action, void* stream) {
+    if (!head || !eps || !scale || !bias || !action || B <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(gauss_head_fwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, eps,
+                       scale, bias, action, ld_action, logp, mean_action);
+    return check_launch();
+}
+
+int rrl_gauss_head_bwd(int B, const float* head, const float* eps, const float* scale,
+                       const float* d_action, int ld, float dlogp, float* dhead, void* stream) {
+    if (!head || !eps || !scale || !d_action || !dhead || B <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(gauss_head_bwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, eps,
+                       scale, d_action, ld, dlogp, dhead);
+    return check_launch();
+}
+
+int rrl_sac_critic_grad(int B, const float* q, const float* qt, const float* logp2, const float* r,
+                        const float* m, float gamma, const float* alpha, const float* penalty, float* dq,
+                        float* loss, void* stream) {
+    if (!q || !qt || !logp2 || !r || !m || !alpha || !dq || B <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(sac_critic_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, q, qt, logp2, r,
+                       m, gamma, alpha, penalty, dq, loss);
+    return check_launch();
+}
+
+int rrl_sac_policy_grad(int B, const float* qp, const float* logp, const float* alpha, float* dqp,
+                        float* loss, void* stream) {
+    if (!qp || !logp || !alpha || !dqp || B <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(sac_policy_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, qp, logp, alpha,
+                       dqp, loss);
+    return check_launch();
+}
+
+int rrl_qrisk_critic_grad(int B, const float* z, const float* zt, const float* c, const float* m,
+                          float gamma_safe, float* dz, float* loss, void* stream) {
+    if (!z || !zt || !c || !m || !dz || B <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(qrisk_critic_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, z, zt, c, m,
+                       gamma_safe, dz, loss);
+    return check_launch();
+}
+
+int rrl_qrisk_policy_grad(int B, const float* zp, float* dzp, float* loss, void* stream) {
+    if (!zp || !dzp || B <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(qrisk_policy_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, zp, dzp, loss);
+    return check_launch();
+}
+
+int rrl_stoch_head_fwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
+                       const float* scale, const float* bias, float* action, int ld_action, float* mean_out,
+                       void* stream) {
+    if (!raw || !log_std || !scale || !bias || !action || B <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(stoch_head_fwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, raw, eps,
+                       log_std, min_log_std, scale, bias, action, ld_action, mean_out);
+    return check_launch();
+}
+
+int rrl_stoch_head_bwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
+                       const float* scale, const float* d_action, int ld, float* draw, float* dlog_std,
+                       void* stream) {
+    if (!raw || !eps || !log_std || !scale || !d_action || !draw || !dlog_std || B <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(stoch_head_bwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, raw, eps, log_std,
+                       min_log_std, scale, d_action, ld, draw, dlog_std);
+    return check_launch();
+}
+
+int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uint64_t* step_dev, float lr,
+                  float beta1, float beta2, float eps, float* target, float tau, void* stream) {
+    if (!p || !g || !m || !v || !step_dev || n <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, p, g, m, v,
+                       step_dev, lr, beta1, beta2, eps, target, tau);
+    return check_launch();
+}
+
+int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task_action,
+                        const float* rec_action, float* real_action, uint8_t* recovery, void* stream) {
+    if (!z || !task_action || !rec_action || !real_action || !recovery || N <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(recovery_select_kernel, rows_grid(N), dim3(kBlock), 0, (hipStream_t)stream, N, z, eps_safe,
+                       task_action, rec_action, real_action, recovery);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -226,6 +226,9 @@ class Experiment:
             self.nu_schedule = linear_schedule(exp_cfg.nu_start, exp_cfg.nu_end, exp_cfg.num_eps)
         else:
             self.nu_schedule = linear_schedule(exp_cfg.nu, exp_cfg.nu, 0)
+        from .fast_update import fast_path_supported
+        if fast_path_supported(exp_cfg) and not getattr(exp_cfg, "no_fast_path", False):
+            self.agent.enable_fast_path(exp_cfg.batch_size)
         self.loop = VectorLoop(exp_cfg, self.env, self.agent, self.memory, self.recovery_memory,
                                self.recovery_policy, self.nu_schedule)
 

@@ -1,0 +1,279 @@
+"""Hand-written forward + backward of the SAC / Q_risk updates on the fused HIP kernels
+(csrc/mlp_kernels.hip, csrc/update_kernels.hip) -- the `fast path` of `SAC.update_parameters`
+(recovery_rl/sac.py:170-277) and `QRiskWrapper.update_parameters` (recovery_rl/qrisk.py:86-163).
+
+Same mathematics as the autograd path in sac.py / qrisk.py (which stays as the general path for
+the baseline flags: DGD / RSPO / RCPO / SQRL / automatic entropy tuning / Deterministic policy);
+`tests/test_fast_update_gpu.py` checks the two paths against each other and against the
+reference KATs.  ~37 launches per update instead of ~150, no vendor GEMM.
+
+Parameters of every network live in ONE flat f32 buffer (the nn.Module parameters are views into
+it), twin heads stacked on a leading dimension so both heads run in one batched launch; Adam and
+the Polyak target update are one kernel over the flat buffer.
+"""
+import math
+
+import torch
+
+from . import _lib
+from .fused import NN, NT, TN, gemm
+
+
+class FlatNet:
+    """Flat parameter / gradient / Adam-state storage for one network, plus the layer views."""
+
+    def __init__(self, named_shapes, device):
+        self.device = device
+        self.shapes = dict(named_shapes)
+        total = sum(int(torch.Size(s).numel()) for _, s in named_shapes)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.step = torch.zeros(2, dtype=torch.int64, device=device)   # {t, ticket}
+        self.p, self.g = {}, {}
+        off = 0
+        for name, shape in named_shapes:
+            n = int(torch.Size(shape).numel())
+            self.p[name] = self.flat[off:off + n].view(shape)
+            self.g[name] = self.grad[off:off + n].view(shape)
+            off += n
+
+    def adopt(self, name, params):
+        """Copy the current values of `params` (list of nn.Parameter, stacked along dim 0 when more
+        than one) into the flat buffer and re-point them at it."""
+        dst = self.p[name]
+        with torch.no_grad():
+            if len(params) == 1:
+                dst.copy_(params[0].data.reshape(dst.shape))
+                params[0].data = dst.view(params[0].shape)
+            else:
+                for i, prm in enumerate(params):
+                    dst[i].copy_(prm.data.reshape(dst[i].shape))
+                    prm.data = dst[i].view(prm.shape)
+
+    def adam(self, lr, target=None, tau=0.0, betas=(0.9, 0.999), eps=1e-8):
+        lib = _lib.load()
+        rc = lib.rrl_adam_step(self.flat.numel(), self.flat.data_ptr(), self.grad.data_ptr(),
+                               self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(), lr, betas[0],
+                               betas[1], eps, None if target is None else target.flat.data_ptr(), tau,
+                               _lib.current_stream())
+        _lib.check(rc, "rrl_adam_step")
+
+
+def flatten_twin_q(net, device):
+    """QNetwork / QNetworkConstraint -> FlatNet with heads stacked: W1 [2,H,din] ... b3 [2,1]."""
+    H, din = net.linear1.weight.shape
+    shapes = [("W1", (2, H, din)), ("b1", (2, H)), ("W2", (2, H, H)), ("b2", (2, H)),
+              ("W3", (2, 1, H)), ("b3", (2, 1))]
+    has_bn = hasattr(net, "bn1")
+    if has_bn:
+        shapes += [("bn_w", (din,)), ("bn_b", (din,))]
+    f = FlatNet(shapes, device)
+    f.adopt("W1", [net.linear1.weight, net.linear4.weight])
+    f.adopt("b1", [net.linear1.bias, net.linear4.bias])
+    f.adopt("W2", [net.linear2.weight, net.linear5.weight])
+    f.adopt("b2", [net.linear2.bias, net.linear5.bias])
+    f.adopt("W3", [net.linear3.weight, net.linear6.weight])
+    f.adopt("b3", [net.linear3.bias, net.linear6.bias])
+    if has_bn:
+        f.adopt("bn_w", [net.bn1.weight])
+        f.adopt("bn_b", [net.bn1.bias])
+    f.G, f.H, f.din, f.dout = 2, H, din, 1
+    return f
+
+
+def flatten_policy(net, device):
+    """GaussianPolicy (head = [mean; log_std], 4 rows) or StochasticPolicy (head = mean, 2 rows +
+    log_std[2]) -> FlatNet with a leading head dimension of 1."""
+    H, din = net.linear1.weight.shape
+    gaussian = hasattr(net, "mean_linear")
+    dout = 4 if gaussian else 2
+    shapes = [("W1", (1, H, din)), ("b1", (1, H)), ("W2", (1, H, H)), ("b2", (1, H)),
+              ("W3", (1, dout, H)), ("b3", (1, dout))]
+    if not gaussian:
+        shapes.append(("log_std", (2,)))
+    f = FlatNet(shapes, device)
+    f.adopt("W1", [net.linear1.weight])
+    f.adopt("b1", [net.linear1.bias])
+    f.adopt("W2", [net.linear2.weight])
+    f.adopt("b2", [net.linear2.bias])
+    with torch.no_grad():
+        if gaussian:
+            W3, b3 = f.p["W3"][0], f.p["b3"][0]
+            W3[0:2].copy_(net.mean_linear.weight.data)
+            W3[2:4].copy_(net.log_std_linear.weight.data)
+            b3[0:2].copy_(net.mean_linear.bias.data)
+            b3[2:4].copy_(net.log_std_linear.bias.data)
+            net.mean_linear.weight.data, net.log_std_linear.weight.data = W3[0:2], W3[2:4]
+            net.mean_linear.bias.data, net.log_std_linear.bias.data = b3[0:2], b3[2:4]
+        else:
+            f.adopt("W3", [net.mean.weight])
+            f.adopt("b3", [net.mean.bias])
+            f.adopt("log_std", [net.log_std])
+    f.G, f.H, f.din, f.dout = 1, H, din, dout
+    return f
+
+
+class Stack:
+    """Workspace + forward / backward of one 2-hidden-layer MLP stack at batch size B."""
+
+    def __init__(self, net, B):
+        self.net, self.B = net, B
+        dev, G, H = net.device, net.G, net.H
+        z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.h1, self.h2, self.out = z(G, B, H), z(G, B, H), z(G, B, net.dout)
+        self.dh1, self.dh2, self.dx = z(G, B, H), z(G, B, H), z(G, B, net.din)
+
+    def forward(self, x, params=None):
+        """x [B, din] shared by all heads.  `params` lets a target network reuse this workspace."""
+        P = (params or self.net).p
+        G = self.net.G
+        xg = x.unsqueeze(0).expand(G, -1, -1)
+        gemm(NT, xg, P["W1"], out=self.h1, bias=P["b1"], relu=True)
+        gemm(NT, self.h1, P["W2"], out=self.h2, bias=P["b2"], relu=True)
+        gemm(NT, self.h2, P["W3"], out=self.out, bias=P["b3"])
+        self.x = x
+        return self.out
+
+    def backward(self, dout, weight_grads=True, input_grad=False):
+        """dout [G, B, dout].  Writes parameter gradients into net.g (weight_grads) and/or returns
+        dL/dx per head [G, B, din] (input_grad)."""
+        P, Gr = self.net.p, self.net.g
+        G = self.net.G
+        xg = self.x.unsqueeze(0).expand(G, -1, -1)
+        if weight_grads:
+            gemm(TN, dout, self.h2, out=Gr["W3"], colsum=Gr["b3"])
+        gemm(NN, dout, P["W3"], out=self.dh2, mask=self.h2)
+        if weight_grads:
+            gemm(TN, self.dh2, self.h1, out=Gr["W2"], colsum=Gr["b2"])
+        gemm(NN, self.dh2, P["W2"], out=self.dh1, mask=self.h1)
+        if weight_grads:
+            gemm(TN, self.dh1, xg, out=Gr["W1"], colsum=Gr["b1"])
+        if input_grad:
+            gemm(NN, self.dh1, P["W1"], out=self.dx)
+            return self.dx
+        return None
+
+
+class FastUpdater:
+    """Fused-kernel implementation of one SAC step and one Q_risk (+ model-free recovery) step for the
+    default Recovery-RL configuration.  Owns the flat parameter storage of the agent's networks."""
+
+    def __init__(self, agent, batch_size):
+        self.agent = agent
+        self.qr = agent.safety_critic
+        self.B = B = batch_size
+        dev = self.dev = agent.device
+        self.lib = _lib.load()
+        self.critic = flatten_twin_q(agent.critic, dev)
+        self.critic_target = flatten_twin_q(agent.critic_target, dev)
+        self.policy = flatten_policy(agent.policy, dev)
+        self.qrisk = flatten_twin_q(self.qr.safety_critic, dev)
+        self.qrisk_target = flatten_twin_q(self.qr.safety_critic_target, dev)
+        self.recpolicy = flatten_policy(self.qr.policy, dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        # stacks (workspaces) -- a network evaluated twice with saved activations needs two
+        self.pol_a, self.pol_b = Stack(self.policy, B), Stack(self.policy, B)
+        self.cri_a, self.cri_b = Stack(self.critic, B), Stack(self.critic, B)
+        self.qr_a, self.qr_b = Stack(self.qrisk, B), Stack(self.qrisk, B)
+        self.rec_a = Stack(self.recpolicy, B)
+        self.xu, self.x2u, self.xpu = z(B, 4), z(B, 4), z(B, 4)     # [s|a], [s'|a'], [s|pi]
+        self.logp2, self.logp = z(B), z(B)
+        self.dq, self.dhead, self.draw = z(2, B, 1), z(1, B, 4), z(1, B, 2)
+        self.dact = z(B, 2)
+        self.losses = z(8)   # q1, q2, policy, (pad) | qr1, qr2, recpolicy, (pad)
+        self.alpha = torch.full((1,), float(agent.alpha), dtype=torch.float32, device=dev)
+        self.scale = agent.policy.action_scale.to(dev).float().contiguous()
+        self.bias = agent.policy.action_bias.to(dev).float().contiguous()
+        self.rscale = self.qr.policy.action_scale.to(dev).float().contiguous()
+        self.rbias = self.qr.policy.action_bias.to(dev).float().contiguous()
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        _lib.check(rc, what)
+
+    def _load_batch(self, batch):
+        s, a, r, s2, m = batch
+        self.xu[:, 0:2] = s
+        self.xu[:, 2:4] = a
+        self.x2u[:, 0:2] = s2
+        self.xpu[:, 0:2] = s
+        return s, a, r.reshape(-1), s2, m.reshape(-1)
+
+    def _gauss_fwd(self, head, eps, action_view, logp):
+        st = _lib.current_stream()
+        self._check(self.lib.rrl_gauss_head_fwd(self.B, head.data_ptr(), eps.data_ptr(), self.scale.data_ptr(),
+                                                self.bias.data_ptr(), action_view.data_ptr(),
+                                                action_view.stride(0), logp.data_ptr(), None, st),
+                    "rrl_gauss_head_fwd")
+
+    # -- SAC -------------------------------------------------------------------------------------
+    def sac_update(self, batch, eps_next, eps_pi):
+        ag, B, lib, st = self.agent, self.B, self.lib, _lib.current_stream()
+        s, a, r, s2, m = self._load_batch(batch)
+        # target: a' ~ pi(s'), min Q_target(s', a') - alpha log pi  (sac.py:192-201)
+        head2 = self.pol_a.forward(s2)
+        self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
+        qt = self.cri_b.forward(self.x2u, params=self.critic_target)
+        q = self.cri_a.forward(self.xu)
+        self._check(lib.rrl_sac_critic_grad(B, q.data_ptr(), qt.data_ptr(), self.logp2.data_ptr(), r.data_ptr(),
+                                            m.data_ptr(), ag.gamma, self.alpha.data_ptr(), None,
+                                            self.dq.data_ptr(), self.losses.data_ptr(), st), "rrl_sac_critic_grad")
+        self.cri_a.backward(self.dq)                                   # critic gradients (sac.py:233-235)
+        # policy loss at the PRE-update critic (both gradients before either step)
+        head = self.pol_b.forward(s)
+        self._gauss_fwd(head, eps_pi, self.xpu[:, 2:4], self.logp)
+        qp = self.cri_b.forward(self.xpu)
+        self._check(lib.rrl_sac_policy_grad(B, qp.data_ptr(), self.logp.data_ptr(), self.alpha.data_ptr(),
+                                            self.dq.data_ptr(), self.losses[2:].data_ptr(), st),
+                    "rrl_sac_policy_grad")
+        dx = self.cri_b.backward(self.dq, weight_grads=False, input_grad=True)      # [2,B,4]
+        torch.add(dx[0, :, 2:4], dx[1, :, 2:4], out=self.dact)
+        self._check(lib.rrl_gauss_head_bwd(B, head.data_ptr(), eps_pi.data_ptr(), self.scale.data_ptr(),
+                                           self.dact.data_ptr(), 2, float(ag.alpha) / B, self.dhead.data_ptr(),
+                                           st), "rrl_gauss_head_bwd")
+        self.pol_b.backward(self.dhead)
+        self.critic.adam(ag.lr, target=self.critic_target, tau=ag.tau)        # + soft update (:273-274)
+        self.policy.adam(ag.lr)
+        return self.losses
+
+    # -- Q_risk ------------------------------------------------------------------------------------
+    def qrisk_update(self, batch, eps_next, eps_pi):
+        qr, B, lib, st = self.qr, self.B, self.lib, _lib.current_stream()
+        s, a, c, s2, m = self._load_batch(batch)
+        head2 = self.pol_a.forward(s2)                                 # a' from the TASK policy (qrisk.py:119-120)
+        self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
+        zt = self.qr_b.forward(self.x2u, params=self.qrisk_target)
+        z = self.qr_a.forward(self.xu)
+        self._check(lib.rrl_qrisk_critic_grad(B, z.data_ptr(), zt.data_ptr(), c.data_ptr(), m.data_ptr(),
+                                              qr.gamma_safe, self.dq.data_ptr(), self.losses[4:].data_ptr(), st),
+                    "rrl_qrisk_critic_grad")
+        self.qr_a.backward(self.dq)
+        self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau)
+        if qr.MF_recovery:                                              # qrisk.py:150-158, at the UPDATED critic
+            raw = self.rec_a.forward(s)
+            ls = self.recpolicy.p["log_std"]
+            self._check(lib.rrl_stoch_head_fwd(B, raw.data_ptr(), eps_pi.data_ptr(), ls.data_ptr(),
+                                               qr.policy.min_log_std, self.rscale.data_ptr(), self.rbias.data_ptr(),
+                                               self.xpu[:, 2:4].data_ptr(), 4, None, st), "rrl_stoch_head_fwd")
+            zp = self.qr_b.forward(self.xpu)
+            self._check(lib.rrl_qrisk_policy_grad(B, zp.data_ptr(), self.dq.data_ptr(), self.losses[6:].data_ptr(),
+                                                  st), "rrl_qrisk_policy_grad")
+            dx = self.qr_b.backward(self.dq, weight_grads=False, input_grad=True)
+            torch.add(dx[0, :, 2:4], dx[1, :, 2:4], out=self.dact)
+            self._check(lib.rrl_stoch_head_bwd(B, raw.data_ptr(), eps_pi.data_ptr(), ls.data_ptr(),
+                                               qr.policy.min_log_std, self.rscale.data_ptr(), self.dact.data_ptr(),
+                                               2, self.draw.data_ptr(), self.recpolicy.g["log_std"].data_ptr(), st),
+                        "rrl_stoch_head_bwd")
+            self.rec_a.backward(self.draw)
+            self.recpolicy.adam(qr.lr)
+        return self.losses
+
+
+def fast_path_supported(cfg):
+    """The fused path covers the Recovery-RL configurations (task SAC + Q_risk, model-free or
+    model-based recovery, reward penalty); the comparison algorithms use the autograd path."""
+    return (cfg.policy == "Gaussian" and not cfg.automatic_entropy_tuning and not cfg.DGD_constraints
+            and not cfg.RCPO and not cfg.update_nu and not cfg.use_constraint_sampling
+            and cfg.target_update_interval == 1 and not getattr(cfg, "cnn", False))

@@ -44,6 +44,7 @@ class QRiskWrapper:
         self.Q_sampling_recovery = args.Q_sampling_recovery
         self.tmp_env = tmp_env
         self.last_losses = None
+        self.fast = None
 
     # -- training ----------------------------------------------------------------------------
     def clamp_batch_size(self, batch_size, memory_len):
@@ -60,6 +61,14 @@ class QRiskWrapper:
         if batch is None:
             batch_size = self.clamp_batch_size(batch_size, len(memory))
             batch = memory.sample(batch_size=batch_size, pos_fraction=self.pos_fraction)
+        if self.fast is not None and batch[2].shape[0] == self.fast.B:
+            if eps_next is None:
+                noise = torch.randn(2, self.fast.B, 2, device=self.device)
+                eps_next, eps_pi = noise[0], noise[1]
+            losses = self.fast.qrisk_update(batch, eps_next, eps_pi)
+            self.updates += 1
+            self.last_losses = (losses[4], losses[5], losses[6] if self.MF_recovery else None)
+            return
         state, action, constraint, next_state, mask = batch
         constraint = constraint.reshape(-1, 1)
         mask = mask.reshape(-1, 1)

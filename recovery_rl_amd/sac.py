@@ -38,6 +38,8 @@ class SAC(object):
         self.automatic_entropy_tuning = args.automatic_entropy_tuning
         self.device = torch.device("cuda" if args.cuda else "cpu")
         self.updates = 0
+        self.lr = args.lr
+        self.fast = None
         capturable = self.device.type == "cuda"
 
         self.gamma_safe = args.gamma_safe
@@ -121,6 +123,14 @@ class SAC(object):
         return pi.reshape(n, k, -1)[torch.arange(n, device=state.device), pick]
 
     # -- learning ----------------------------------------------------------------------------
+    def enable_fast_path(self, batch_size):
+        """Route update_parameters (and the safety critic's) through the fused HIP kernels
+        (fast_update.FastUpdater).  Only for configurations fast_path_supported() accepts."""
+        from .fast_update import FastUpdater
+        self.fast = FastUpdater(self, batch_size)
+        self.safety_critic.fast = self.fast
+        return self.fast
+
     def update_parameters(self, memory, batch_size, updates, nu=None, safety_critic=None,
                           batch=None, eps_next=None, eps_pi=None, as_floats=False):
         """One SAC step (sac.py:170-277).  `batch` / `eps_*` inject a fixed batch and policy
@@ -129,6 +139,13 @@ class SAC(object):
             nu = self.nu
         if batch is None:
             batch = memory.sample(batch_size=batch_size)
+        if self.fast is not None and batch[2].shape[0] == self.fast.B:
+            if eps_next is None:
+                noise = torch.randn(2, self.fast.B, 2, device=self.device)
+                eps_next, eps_pi = noise[0], noise[1]
+            losses = self.fast.sac_update(batch, eps_next, eps_pi)
+            out = (losses[0], losses[1], losses[2], self._zero, self._alpha_const)
+            return tuple(float(x) for x in out) if as_floats else out
         state, action, reward, next_state, mask = batch
         reward = reward.reshape(-1, 1)
         mask = mask.reshape(-1, 1)

@@ -1,0 +1,60 @@
+"""GPU tests of the hand-written f32 MFMA GEMM (csrc/mlp_kernels.hip) against torch fp32 matmul.
+f32 MFMA is an exact fmaf chain; tolerance covers summation-order differences only."""
+import pytest
+import torch
+
+from recovery_rl_amd import fused
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SHAPES = [(256, 256, 256), (256, 256, 4), (256, 1, 256), (256, 4, 256), (8, 16, 4), (8, 1, 16), (8, 16, 16),
+          (4096, 256, 256), (4096, 2, 256), (100, 70, 33), (33, 1, 1), (1, 5, 300), (64, 64, 17)]
+
+
+def ref64(x):
+    return x.double()
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("G", (1, 2))
+def test_all_modes_match_torch(M, N, K, G):
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N * 3 + K + G)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    tol = dict(rtol=2e-5, atol=2e-5 * max(1, K) ** 0.5)
+    # NT with bias + relu
+    A, B, bias = r(G, M, K), r(G, N, K), r(G, N)
+    want = torch.relu(torch.einsum("gmk,gnk->gmn", ref64(A), ref64(B)) + ref64(bias)[:, None]).float()
+    assert torch.allclose(fused.gemm(fused.NT, A, B, bias=bias, relu=True), want, **tol)
+    want = torch.einsum("gmk,gnk->gmn", ref64(A), ref64(B)).float()
+    assert torch.allclose(fused.gemm(fused.NT, A, B), want, **tol)
+    # NN with relu mask
+    Bn, mask = r(G, K, N), r(G, M, N)
+    want = (torch.einsum("gmk,gkn->gmn", ref64(A), ref64(Bn)) * (mask > 0)).float()
+    assert torch.allclose(fused.gemm(fused.NN, A, Bn, mask=mask), want, **tol)
+    # TN with column sums and accumulation
+    At = r(G, K, M)
+    out = r(G, M, N)
+    base = out.clone()
+    colsum = torch.zeros(G, M, device=DEV)
+    want = (ref64(base) + torch.einsum("gkm,gkn->gmn", ref64(At), ref64(Bn))).float()
+    fused.gemm(fused.TN, At, Bn, out=out, colsum=colsum, accumulate=True)
+    assert torch.allclose(out, want, **tol)
+    assert torch.allclose(colsum, At.double().sum(1).float(), **tol)
+
+
+def test_2d_strided_views_and_unaligned_leading_dims():
+    g = torch.Generator(device=DEV).manual_seed(1)
+    big = torch.randn(300, 300, device=DEV, generator=g)
+    A = big[3:131, 5:74]          # ld 300, offset not 16-byte aligned
+    W = big[140:270, 1:70]
+    got = fused.gemm(fused.NT, A, W)
+    assert torch.allclose(got, (A.double() @ W.double().t()).float(), rtol=2e-5, atol=2e-4)
+    out = torch.zeros(128, 140, device=DEV)
+    fused.gemm(fused.NT, A, W, out=out[:, 5:135])
+    assert torch.equal(out[:, 5:135], got) and out[:, :5].abs().sum() == 0 and out[:, 135:].abs().sum() == 0
+
+
+def test_f32_mfma_is_an_exact_fma_chain_for_small_integers():
+    A = torch.randint(-8, 8, (2, 64, 96), device=DEV).float()
+    B = torch.randint(-8, 8, (2, 48, 96), device=DEV).float()
+    assert torch.equal(fused.gemm(fused.NT, A, B), torch.einsum("gmk,gnk->gmn", A, B))
