@@ -195,6 +195,15 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
                  const float* bias, long long sBias, int relu, const float* mask, int ldmask,
                  long long sMask, float* colsum, long long sColsum, int accumulate, void* stream);
 
+/* Whole 2-hidden-layer stack forward in one launch (QNetwork / QNetworkConstraint heads,
+ * GaussianPolicy / StochasticPolicy trunks + last linear; model.py:66-76,188-199,317-323,511-515):
+ *   out[g] = W3[g] relu(W2[g] relu(W1[g] x + b1[g]) + b2[g]) + b3[g],  x [M,din] (leading dim ldx)
+ * shared by the G heads.  W1 [G,H,din], W2 [G,H,H], W3 [G,dout,H]; h1/h2 [G,M,H] receive the hidden
+ * activations when non-null (needed by the backward pass).  H % 16 == 0, H <= 256, din, dout <= 4. */
+int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int ldx, const float* W1,
+                     const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                     float* h1, float* h2, float* out, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Fused element-wise pieces of the updates (one launch each instead of a chain of PyTorch ops).
  *   rrl_gauss_head_fwd/bwd   GaussianPolicy.sample and its backward (recovery_rl/model.py:324-340);
@@ -232,8 +241,9 @@ int rrl_stoch_head_bwd(int B, const float* raw, const float* eps, const float* l
                        void* stream);
 int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uint64_t* step_dev, float lr,
                   float beta1, float beta2, float eps, float* target, float tau, void* stream);
-int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task_action,
-                        const float* rec_action, float* real_action, uint8_t* recovery, void* stream);
+int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task_action, int ld_task,
+                        const float* rec_action, float* real_action, uint8_t* recovery, float* task_out,
+                        void* stream);
 
 #ifdef __cplusplus
 }

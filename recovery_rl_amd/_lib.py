@@ -26,7 +26,7 @@ EXPORTS = [
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather",
     "rrl_cem_sample", "rrl_cem_update",
-    "rrl_gemm_f32",
+    "rrl_gemm_f32", "rrl_mlp3_forward",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_recovery_select",
@@ -97,6 +97,7 @@ def _declare(lib):
         "rrl_gemm_f32": (ci, [ci, ci, ci, ci, ci, vp, ci, C.c_longlong, vp, ci, C.c_longlong, vp, ci,
                               C.c_longlong, vp, C.c_longlong, ci, vp, ci, C.c_longlong, vp, C.c_longlong,
                               ci, vp]),
+        "rrl_mlp3_forward": (ci, [ci, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_gauss_head_fwd": (ci, [ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]),
         "rrl_gauss_head_bwd": (ci, [ci, vp, vp, vp, vp, ci, f32, vp, vp]),
         "rrl_sac_critic_grad": (ci, [ci, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
@@ -106,7 +107,7 @@ def _declare(lib):
         "rrl_stoch_head_fwd": (ci, [ci, vp, vp, vp, f32, vp, vp, vp, ci, vp, vp]),
         "rrl_stoch_head_bwd": (ci, [ci, vp, vp, vp, f32, vp, vp, ci, vp, vp, vp]),
         "rrl_adam_step": (ci, [C.c_longlong, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, f32, vp]),
-        "rrl_recovery_select": (ci, [ci, vp, f32, vp, vp, vp, vp, vp]),
+        "rrl_recovery_select": (ci, [ci, vp, f32, vp, ci, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -177,6 +177,103 @@ __global__ __launch_bounds__(64) void gemm16_kernel(GemmArgs a) {
     }
 }
 
+// ---- fused forward of a whole 2-hidden-layer stack -----------------------------------------------
+//   out[g] = W3[g] relu(W2[g] relu(W1[g] x + b1[g]) + b2[g]) + b3[g]      x [M, din] shared by the heads
+// One workgroup (16 waves) per 16 rows and head: layer 1 on the VALU (din <= 4), layer 2 on MFMA with
+// the 16 x H activation tile in LDS shared by all waves (wave w owns output columns 16w..16w+15 and
+// streams its 16 rows of W2 straight from L2 into MFMA operands), layer 3 by 16-lane dot products.
+// No intermediate activation touches HBM unless the caller asks for h1 / h2 (needed by backward).
+struct StackArgs {
+    const float* x;       // [M, din]
+    const float* W1; const float* b1;   // [G,H,din], [G,H]
+    const float* W2; const float* b2;   // [G,H,H],   [G,H]
+    const float* W3; const float* b3;   // [G,dout,H],[G,dout]
+    float* h1; float* h2;               // [G,M,H] or null
+    float* out;                          // [G,M,dout]
+    int M, H, din, dout, ldx;
+};
+
+constexpr int kStackRows = 16;
+constexpr int kStackMaxH = 256;
+
+__global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[kStackRows * 4];
+    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 4)];
+    __shared__ __attribute__((aligned(16))) float h2s[kStackRows * (kStackMaxH + 4)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y, m0 = blockIdx.x * kStackRows;
+    const int H = a.H, ldh = H + 4;
+    const float* W1 = a.W1 + (long long)g * H * a.din;
+    const float* b1 = a.b1 + (long long)g * H;
+    const float* W2 = a.W2 + (long long)g * H * H;
+    const float* b2 = a.b2 + (long long)g * H;
+    const float* W3 = a.W3 + (long long)g * a.dout * H;
+    const float* b3 = a.b3 + (long long)g * a.dout;
+
+    if (tid < kStackRows * 4) {
+        const int r = tid >> 2, d = tid & 3, row = m0 + r;
+        xs[tid] = (row < a.M && d < a.din) ? a.x[(long long)row * a.ldx + d] : 0.f;
+    }
+    __syncthreads();
+    // layer 1: h1[r][n] = relu(b1[n] + sum_d x[r][d] W1[n][d])
+    for (int e = tid; e < kStackRows * H; e += 1024) {
+        const int r = e / H, n = e - r * H;
+        float v = b1[n];
+        for (int d = 0; d < a.din; ++d) v = fmaf(xs[r * 4 + d], W1[n * a.din + d], v);
+        v = v > 0.f ? v : 0.f;
+        h1s[r * ldh + n] = v;
+        if (a.h1 && m0 + r < a.M) a.h1[((long long)g * a.M + m0 + r) * H + n] = v;
+    }
+    __syncthreads();
+    // layer 2: wave w -> output columns [16 w, 16 w + 16); K order permuted as in gemm16_kernel
+    const int i = lane & 15, q = lane >> 4;
+    for (int nt = wave; nt * 16 < H; nt += 16) {
+        const int n0 = nt * 16;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* wrow = W2 + (long long)(n0 + i) * H + 4 * q;
+        const float* arow = h1s + i * ldh + 4 * q;
+        float4 wv[kStackMaxH / 16];
+#pragma unroll
+        for (int j = 0; j < kStackMaxH / 16; ++j)
+            if (16 * j < H) wv[j] = *reinterpret_cast<const float4*>(wrow + 16 * j);
+#pragma unroll
+        for (int j = 0; j < kStackMaxH / 16; ++j) {
+            if (16 * j < H) {
+                const float4 av = *reinterpret_cast<const float4*>(arow + 16 * j);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[j].w, acc1, 0, 0, 0);
+            }
+        }
+        const f32x4 acc = acc0 + acc1;
+        const int col = n0 + i;
+        const float bias = b2[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * q + r;
+            float v = acc[r] + bias;
+            v = v > 0.f ? v : 0.f;
+            h2s[rr * ldh + col] = v;
+            if (a.h2 && m0 + rr < a.M) a.h2[((long long)g * a.M + m0 + rr) * H + col] = v;
+        }
+    }
+    __syncthreads();
+    // layer 3: wave w = row, 16-lane groups = output index
+    {
+        const int r = wave, o = lane >> 4, part = lane & 15;
+        float v = 0.f;
+        if (o < a.dout)
+            for (int k = part; k < H; k += 16) v = fmaf(h2s[r * ldh + k], W3[o * H + k], v);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        if (part == 0 && o < a.dout && m0 + r < a.M)
+            a.out[((long long)g * a.M + m0 + r) * a.dout + o] = v + b3[o];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -194,6 +291,18 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
     if (mode == 0) hipLaunchKernelGGL((gemm16_kernel<0>), grid, block, 0, st, a);
     else if (mode == 1) hipLaunchKernelGGL((gemm16_kernel<1>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((gemm16_kernel<2>), grid, block, 0, st, a);
+    return check_launch();
+}
+
+int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int ldx, const float* W1,
+                     const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                     float* h1, float* h2, float* out, void* stream) {
+    if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return RRL_EINVAL;
+    if (G <= 0 || G > 65535 || M <= 0 || din <= 0 || din > 4 || dout <= 0 || dout > 4) return RRL_ERANGE;
+    if (H <= 0 || H > kStackMaxH || (H % 16) != 0) return RRL_ERANGE;
+    StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx};
+    hipLaunchKernelGGL(mlp3_fwd_kernel, dim3((M + kStackRows - 1) / kStackRows, G), dim3(1024), 0,
+                       (hipStream_t)stream, a);
     return check_launch();
 }
 

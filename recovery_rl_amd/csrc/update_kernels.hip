@@ -239,13 +239,16 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(long long n, float* p, con
 // ---- acting: recovery gate (experiment.py:546-577) ------------------------------------------------
 // z [2,N] pre-sigmoid Q_risk(s, a_task); recovery = max(sigmoid) > eps_safe; real = recovery ? rec : task
 __global__ void recovery_select_kernel(int N, const float* z, float eps_safe, const float* task_action,
-                                       const float* rec_action, float* real_action, uint8_t* recovery) {
+                                       int ld_task, const float* rec_action, float* real_action,
+                                       uint8_t* recovery, float* task_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= N) return;
     const bool rec = fmaxf(sigmoidf(z[b]), sigmoidf(z[N + b])) > eps_safe;
     recovery[b] = uint8_t(rec);
-    real_action[2 * b] = rec ? rec_action[2 * b] : task_action[2 * b];
-    real_action[2 * b + 1] = rec ? rec_action[2 * b + 1] : task_action[2 * b + 1];
+    const float t0 = task_action[(long long)b * ld_task], t1 = task_action[(long long)b * ld_task + 1];
+    real_action[2 * b] = rec ? rec_action[2 * b] : t0;
+    real_action[2 * b + 1] = rec ? rec_action[2 * b + 1] : t1;
+    if (task_out) { task_out[2 * b] = t0; task_out[2 * b + 1] = t1; }
 }
 
 inline dim3 rows_grid(int B) { return dim3((B + kBlock - 1) / kBlock); }
@@ -327,11 +330,12 @@ int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uin
     return check_launch();
 }
 
-int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task_action,
-                        const float* rec_action, float* real_action, uint8_t* recovery, void* stream) {
+int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task_action, int ld_task,
+                        const float* rec_action, float* real_action, uint8_t* recovery, float* task_out,
+                        void* stream) {
     if (!z || !task_action || !rec_action || !real_action || !recovery || N <= 0) return RRL_EINVAL;
     hipLaunchKernelGGL(recovery_select_kernel, rows_grid(N), dim3(kBlock), 0, (hipStream_t)stream, N, z, eps_safe,
-                       task_action, rec_action, real_action, recovery);
+                       task_action, ld_task, rec_action, real_action, recovery, task_out);
     return check_launch();
 }
 

@@ -67,6 +67,7 @@ class VectorLoop:
         self.updates = 0
         self.num_constraint_violations = 0  # offline violations pushed during pre-training
         self.graph = None
+        self._actor = None
         self._one = torch.ones((), dtype=torch.int64, device=dev)
 
     # -- pieces --------------------------------------------------------------------------------
@@ -92,6 +93,14 @@ class VectorLoop:
     def act(self, obs, random_actions=False, train=True):
         """Batched get_action (experiment.py:546-577): (task action, executed action, recovery)."""
         cfg = self.cfg
+        fast = getattr(self.agent, "fast", None)
+        if (fast is not None and train and not random_actions and obs.shape[0] == self.n
+                and (not cfg.use_recovery or cfg.MF_recovery)):
+            if self._actor is None:
+                from .fast_update import FastActor
+                self._actor = FastActor(fast, self.n)
+            action, real_action, rec = self._actor.act(obs, cfg.eps_safe, cfg.use_recovery, cfg.MF_recovery)
+            return action, real_action, (rec.bool() if rec is not None else None)
         if random_actions:
             action = self.env.sample_actions()
         else:

@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import _lib
-from .fused import NN, NT, TN, gemm
+from .fused import NN, NT, TN, gemm, mlp3_forward, mlp3_supported
 
 
 class FlatNet:
@@ -125,15 +125,19 @@ class Stack:
         self.h1, self.h2, self.out = z(G, B, H), z(G, B, H), z(G, B, net.dout)
         self.dh1, self.dh2, self.dx = z(G, B, H), z(G, B, H), z(G, B, net.din)
 
-    def forward(self, x, params=None):
-        """x [B, din] shared by all heads.  `params` lets a target network reuse this workspace."""
+    def forward(self, x, params=None, save=True):
+        """x [B, din] shared by all heads.  `params` lets a target network reuse this workspace;
+        `save` keeps the hidden activations for backward()."""
         P = (params or self.net).p
         G = self.net.G
+        self.x = x
+        if mlp3_supported(self.net.H, self.net.din, self.net.dout):     # one launch for the whole stack
+            return mlp3_forward(x, P["W1"], P["b1"], P["W2"], P["b2"], P["W3"], P["b3"], out=self.out,
+                                h1=self.h1 if save else None, h2=self.h2 if save else None)
         xg = x.unsqueeze(0).expand(G, -1, -1)
         gemm(NT, xg, P["W1"], out=self.h1, bias=P["b1"], relu=True)
         gemm(NT, self.h1, P["W2"], out=self.h2, bias=P["b2"], relu=True)
         gemm(NT, self.h2, P["W3"], out=self.out, bias=P["b3"])
-        self.x = x
         return self.out
 
     def backward(self, dout, weight_grads=True, input_grad=False):
@@ -213,9 +217,9 @@ class FastUpdater:
         ag, B, lib, st = self.agent, self.B, self.lib, _lib.current_stream()
         s, a, r, s2, m = self._load_batch(batch)
         # target: a' ~ pi(s'), min Q_target(s', a') - alpha log pi  (sac.py:192-201)
-        head2 = self.pol_a.forward(s2)
+        head2 = self.pol_a.forward(s2, save=False)
         self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
-        qt = self.cri_b.forward(self.x2u, params=self.critic_target)
+        qt = self.cri_b.forward(self.x2u, params=self.critic_target, save=False)
         q = self.cri_a.forward(self.xu)
         self._check(lib.rrl_sac_critic_grad(B, q.data_ptr(), qt.data_ptr(), self.logp2.data_ptr(), r.data_ptr(),
                                             m.data_ptr(), ag.gamma, self.alpha.data_ptr(), None,
@@ -242,9 +246,9 @@ class FastUpdater:
     def qrisk_update(self, batch, eps_next, eps_pi):
         qr, B, lib, st = self.qr, self.B, self.lib, _lib.current_stream()
         s, a, c, s2, m = self._load_batch(batch)
-        head2 = self.pol_a.forward(s2)                                 # a' from the TASK policy (qrisk.py:119-120)
+        head2 = self.pol_a.forward(s2, save=False)                     # a' from the TASK policy (qrisk.py:119-120)
         self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
-        zt = self.qr_b.forward(self.x2u, params=self.qrisk_target)
+        zt = self.qr_b.forward(self.x2u, params=self.qrisk_target, save=False)
         z = self.qr_a.forward(self.xu)
         self._check(lib.rrl_qrisk_critic_grad(B, z.data_ptr(), zt.data_ptr(), c.data_ptr(), m.data_ptr(),
                                               qr.gamma_safe, self.dq.data_ptr(), self.losses[4:].data_ptr(), st),
@@ -269,6 +273,49 @@ class FastUpdater:
             self.rec_a.backward(self.draw)
             self.recpolicy.adam(qr.lr)
         return self.losses
+
+
+class FastActor:
+    """Batched get_action (experiment.py:546-577) for N envs on the fused kernels: task policy sample,
+    Q_risk of (s, a_task), model-free recovery action and the recovery gate -- 8 launches instead of
+    ~60 PyTorch ones."""
+
+    def __init__(self, fast, n):
+        self.f, self.n = fast, n
+        dev = fast.dev
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.pol, self.qr, self.rec = Stack(fast.policy, n), Stack(fast.qrisk, n), Stack(fast.recpolicy, n)
+        self.xa = z(n, 4)                       # [s | a_task]
+        self.task_action, self.rec_action, self.real_action = z(n, 2), z(n, 2), z(n, 2)
+        self.recovery = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def act(self, obs, eps_safe, use_recovery, mf_recovery, noise=None):
+        """-> (task action [n,2], executed action [n,2], recovery u8[n] or None); persistent buffers."""
+        f, n, lib, st = self.f, self.n, self.f.lib, _lib.current_stream()
+        if noise is None:
+            noise = torch.randn(2, n, 2, device=f.dev)
+        head = self.pol.forward(obs, save=False)
+        if not use_recovery:
+            _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), noise[0].data_ptr(), f.scale.data_ptr(),
+                                              f.bias.data_ptr(), self.task_action.data_ptr(), 2, None, None, st),
+                       "rrl_gauss_head_fwd")
+            return self.task_action, self.task_action, None
+        self.xa[:, 0:2] = obs
+        _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), noise[0].data_ptr(), f.scale.data_ptr(),
+                                          f.bias.data_ptr(), self.xa[:, 2:4].data_ptr(), 4, None, None, st),
+                   "rrl_gauss_head_fwd")
+        zq = self.qr.forward(self.xa, save=False)
+        assert mf_recovery, "FastActor covers the model-free recovery policy"
+        raw = self.rec.forward(obs, save=False)
+        _lib.check(lib.rrl_stoch_head_fwd(n, raw.data_ptr(), noise[1].data_ptr(),
+                                          f.recpolicy.p["log_std"].data_ptr(), f.qr.policy.min_log_std,
+                                          f.rscale.data_ptr(), f.rbias.data_ptr(), self.rec_action.data_ptr(), 2,
+                                          None, st), "rrl_stoch_head_fwd")
+        _lib.check(lib.rrl_recovery_select(n, zq.data_ptr(), eps_safe, self.xa[:, 2:4].data_ptr(), 4,
+                                           self.rec_action.data_ptr(), self.real_action.data_ptr(),
+                                           self.recovery.data_ptr(), self.task_action.data_ptr(), st),
+                   "rrl_recovery_select")
+        return self.task_action, self.real_action, self.recovery
 
 
 def fast_path_supported(cfg):

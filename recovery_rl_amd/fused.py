@@ -40,3 +40,24 @@ def gemm(mode, A, B, out=None, bias=None, relu=False, mask=None, colsum=None, ac
         int(accumulate), _lib.current_stream())
     _lib.check(rc, "rrl_gemm_f32")
     return out[0] if squeeze else out
+
+
+def mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=None, h1=None, h2=None):
+    """Fused stack forward (rrl_mlp3_forward).  x [M,din]; W1 [G,H,din] ... W3 [G,dout,H] contiguous.
+    Returns out [G,M,dout]."""
+    lib = _lib.load()
+    G, H, din = W1.shape
+    dout = W3.shape[1]
+    M = x.shape[0]
+    assert x.stride(1) == 1 and W1.is_contiguous() and W2.is_contiguous() and W3.is_contiguous()
+    if out is None:
+        out = torch.empty(G, M, dout, dtype=torch.float32, device=x.device)
+    rc = lib.rrl_mlp3_forward(G, M, H, din, dout, x.data_ptr(), x.stride(0), W1.data_ptr(), b1.data_ptr(),
+                              W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(), _lib.ptr(h1),
+                              _lib.ptr(h2), out.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "rrl_mlp3_forward")
+    return out
+
+
+def mlp3_supported(H, din, dout):
+    return H % 16 == 0 and H <= 256 and din <= 4 and dout <= 4

@@ -164,3 +164,28 @@ def test_fast_path_matches_reference_kats(golden_dir, name):
         check(agent.safety_critic.safety_critic, post + ".qrisk")
         check(agent.safety_critic.safety_critic_target, post + ".qrisk_target")
         check(agent.safety_critic.policy, post + ".recpolicy")
+
+
+def test_fast_actor_matches_module_path():
+    """FastActor (fused kernels) vs the nn.Module path of VectorLoop.act on the same weights and noise."""
+    from recovery_rl_amd.fast_update import FastActor
+    _, agent, args = make_pair(256)
+    fast = agent.enable_fast_path(256)
+    n = 1000
+    actor = FastActor(fast, n)
+    obs = torch.randn(n, 2, device=DEV) * torch.tensor([20.0, 4.0], device=DEV) + torch.tensor([-30.0, 0.0], device=DEV)
+    noise = torch.randn(2, n, 2, device=DEV)
+    a_ref, _, _ = agent.policy.sample(obs, noise[0])
+    risk = agent.safety_critic.get_value(obs, a_ref).squeeze(1)
+    thr = float(risk.median())                       # a threshold that splits the batch
+    task, real, rec = actor.act(obs, thr, True, True, noise=noise)
+    r_ref, _, _ = agent.safety_critic.policy.sample(obs, noise[1])
+    assert torch.allclose(task, a_ref, rtol=1e-4, atol=1e-5)
+    gate = risk > thr
+    border = (risk - thr).abs() < 1e-5
+    assert torch.equal(rec.bool()[~border], gate[~border])
+    want = torch.where(rec.bool().unsqueeze(1), r_ref, a_ref)
+    assert torch.allclose(real, want, rtol=1e-4, atol=1e-5)
+    assert 0 < int(rec.sum()) < n
+    task2, real2, rec2 = actor.act(obs, thr, False, False, noise=noise)
+    assert rec2 is None and torch.allclose(task2, a_ref, rtol=1e-4, atol=1e-5)

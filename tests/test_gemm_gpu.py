@@ -58,3 +58,29 @@ def test_f32_mfma_is_an_exact_fma_chain_for_small_integers():
     A = torch.randint(-8, 8, (2, 64, 96), device=DEV).float()
     B = torch.randint(-8, 8, (2, 48, 96), device=DEV).float()
     assert torch.equal(fused.gemm(fused.NT, A, B), torch.einsum("gmk,gnk->gmn", A, B))
+
+
+@pytest.mark.parametrize("M,H,din,dout,G", ((256, 256, 4, 1, 2), (256, 256, 2, 4, 1), (4096, 256, 4, 1, 2),
+                                            (8, 16, 4, 1, 2), (64, 32, 2, 2, 1), (100, 48, 3, 4, 3), (1, 256, 2, 4, 1)))
+def test_fused_stack_forward_matches_torch(M, H, din, dout, G):
+    g = torch.Generator(device=DEV).manual_seed(M + H)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    x = r(M, din) * 5
+    W1, b1, W2, b2, W3, b3 = r(G, H, din), r(G, H), r(G, H, H) / H ** 0.5, r(G, H), r(G, dout, H) / H ** 0.5, r(G, dout)
+    h1, h2 = torch.empty(G, M, H, device=DEV), torch.empty(G, M, H, device=DEV)
+    out = fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, h1=h1, h2=h2)
+    xd = x.double()
+    rh1 = torch.relu(torch.einsum("md,ghd->gmh", xd, W1.double()) + b1.double()[:, None])
+    rh2 = torch.relu(torch.einsum("gmk,ghk->gmh", rh1, W2.double()) + b2.double()[:, None])
+    ro = torch.einsum("gmk,gok->gmo", rh2, W3.double()) + b3.double()[:, None]
+    assert torch.allclose(h1, rh1.float(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(h2, rh2.float(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(out, ro.float(), rtol=1e-4, atol=1e-4)
+    # strided input view (columns of a wider buffer) and no saved activations
+    wide = r(M, 7)
+    out2 = fused.mlp3_forward(wide[:, 1:1 + din], W1, b1, W2, b2, W3, b3)
+    xd = wide[:, 1:1 + din].double()
+    rh1 = torch.relu(torch.einsum("md,ghd->gmh", xd, W1.double()) + b1.double()[:, None])
+    rh2 = torch.relu(torch.einsum("gmk,ghk->gmh", rh1, W2.double()) + b2.double()[:, None])
+    ro = torch.einsum("gmk,gok->gmo", rh2, W3.double()) + b3.double()[:, None]
+    assert torch.allclose(out2, ro.float(), rtol=1e-4, atol=1e-4)
