@@ -157,6 +157,22 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
                               uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a,
                               float* r, float* s2, float* m, int64_t* idx_out, void* stream);
 
+/* Fused lock-step iteration tail: env step + reward penalty + bootstrap mask + memory.push +
+ * recovery_memory.push + episode counters in ONE launch (the body of recovery_rl/experiment.py:420-461
+ * for n navigation envs).  `obs` holds the current observation on entry (it is the stored `state`) and
+ * the next observation on return.  Rows stored: memory <- (obs, task_action or real_action if
+ * push_real_action, reward - penalty*constraint, next_obs, 1-done); recovery_memory (nullable) <- (obs,
+ * real_action, constraint, next_obs, 1-done).  stats = uint64[8] {env_steps, episodes, num_viols,
+ * viol_and_recovery, viol_and_no_recovery, num_successes, recovery_steps, constraint_steps};
+ * reward_sums = double[2] {sum of rewards, sum of finished-episode returns}; ep_reward = float[n]. */
+int rrl_nav_step_push(int env_kind, int64_t n, double* pos, int32_t* t, float* obs,
+                      const float* task_action, const float* real_action, const uint8_t* recovery,
+                      uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                      int32_t horizon, int auto_reset, float reward_penalty, int push_real_action,
+                      const rrl_replay_t* memory, const rrl_replay_t* recovery_memory, float* next_obs,
+                      float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success, uint8_t* ep_done,
+                      uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * CEM.  Replaces the bookkeeping of CEMOptimizer.obtain_solution (recovery_rl/optimizers.py:73-124)
  * for M independent planning problems (one per env that needs a recovery action); the cost

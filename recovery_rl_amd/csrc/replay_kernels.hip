@@ -11,6 +11,7 @@
 //                    reference's O(capacity) argwhere per call (replay_memory.py:58-66)
 #include <hip/hip_runtime.h>
 
+#include "replay_device.hpp"
 #include "rrl_device.hpp"
 #include "rrl_host.hpp"
 
@@ -21,7 +22,8 @@ using rrl_host::grid_for;
 using rrl_host::kBlock;
 
 constexpr int kTile = 1024;   // rows per workgroup in the masked push
-constexpr int kChunk = 64;    // slots per positive-count chunk
+using rrl_replay::advance_ring;
+using rrl_replay::kChunk;
 
 struct Rows {
     const float2* s;
@@ -33,35 +35,7 @@ struct Rows {
 
 __device__ __forceinline__ void store_row(const rrl_replay_t& rb, int64_t slot, int64_t size,
                                           const Rows& in, int64_t i) {
-    const float rn = in.r[i];
-    if (rb.pos_cnt) {  // keep the per-chunk positive counts exact (pos_idx, replay_memory.py:50)
-        const int was = (slot < size) ? int(rb.r[slot] != 0.0f) : 0;
-        const int delta = int(rn != 0.0f) - was;
-        if (delta) atomicAdd(&rb.pos_cnt[slot / kChunk], delta);
-    }
-    ((float2*)rb.s)[slot] = in.s[i];
-    ((float2*)rb.a)[slot] = in.a[i];
-    rb.r[slot] = rn;
-    ((float2*)rb.s2)[slot] = in.s2[i];
-    rb.m[slot] = in.m[i];
-}
-
-// Last workgroup to finish advances {position, size}; every workgroup has read them before it
-// takes its ticket, so no workgroup can observe the new values.
-__device__ __forceinline__ void advance_ring(const rrl_replay_t& rb, int64_t pos, int64_t size,
-                                             int64_t pushed) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned long long ticket = atomicAdd((unsigned long long*)&rb.state[2], 1ULL);
-        if (ticket == gridDim.x - 1) {
-            rb.state[0] = (pos + pushed) % rb.cap;
-            const int64_t ns = size + pushed;
-            rb.state[1] = ns > rb.cap ? rb.cap : ns;
-            rb.state[2] = 0;
-            __threadfence();
-        }
-    }
+    rrl_replay::store_values(rb, slot, size, in.s[i], in.a[i], in.r[i], in.s2[i], in.m[i]);
 }
 
 __global__ __launch_bounds__(kBlock) void push_kernel(rrl_replay_t rb, int64_t n, Rows in) {

@@ -60,9 +60,8 @@ class VectorLoop:
         self.device = dev
         self.obs = None
         self.stats = torch.zeros(len(STAT_KEYS), dtype=torch.int64, device=dev)
-        self.reward_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.reward_sums = torch.zeros(2, dtype=torch.float64, device=dev)   # rewards, finished-episode returns
         self.ep_reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
-        self.ep_return_sum = torch.zeros((), dtype=torch.float64, device=dev)
         self.total_numsteps = 0           # host mirror: every iteration adds num_envs
         self.updates = 0
         self.num_constraint_violations = 0  # offline violations pushed during pre-training
@@ -120,6 +119,8 @@ class VectorLoop:
         """env.step + reward penalty + mask + pushes + counters (experiment.py:420-461)."""
         cfg = self.cfg
         real_action = real_action.contiguous()
+        if self._can_fuse_step():
+            return self._fused_step(action.contiguous(), real_action, recovery)
         obs, reward, done, info = self.env.step(real_action)
         state, next_state = info["state"], info["next_state"]
         constraint_f = info["constraint"].to(torch.float32)
@@ -147,13 +148,43 @@ class VectorLoop:
         st[5] += (ep_done & info["success"].bool()).sum()
         st[6] += rec.sum()
         st[7] += cons.sum()
-        self.reward_sum += reward.sum(dtype=torch.float64)
+        self.reward_sums[0] += reward.sum(dtype=torch.float64)
         self.ep_reward += reward
-        self.ep_return_sum += torch.where(ep_done, self.ep_reward, torch.zeros_like(reward)).sum(dtype=torch.float64)
+        self.reward_sums[1] += torch.where(ep_done, self.ep_reward, torch.zeros_like(reward)).sum(dtype=torch.float64)
         self.ep_reward *= (~ep_done).to(torch.float32)
         self.obs = obs
         self.total_numsteps += self.n
         return obs
+
+    def _can_fuse_step(self):
+        from .env.navigation import NavigationVecEnv
+        return (isinstance(self.env, NavigationVecEnv) and self.env.auto_reset
+                and not self.cfg.add_both_transitions and not getattr(self.cfg, "no_fused_step", False))
+
+    def _fused_step(self, action, real_action, recovery):
+        """env step + both replay pushes + counters in ONE launch (rrl_nav_step_push)."""
+        import ctypes as C
+        from . import _lib
+        cfg, env, mem, rmem = self.cfg, self.env, self.memory, self.recovery_memory
+        rec_u8 = None
+        if recovery is not None:
+            rec_u8 = recovery if recovery.dtype == torch.uint8 else recovery.to(torch.uint8)
+        use_rmem = uses_constraint_buffer(cfg)
+        rc = env.lib.rrl_nav_step_push(
+            env.kind, self.n, _lib.ptr(env.pos), _lib.ptr(env.t), _lib.ptr(env.obs), _lib.ptr(action),
+            _lib.ptr(real_action), _lib.ptr(rec_u8), env.seed_value, 0, _lib.ptr(env.tick), 1, env.horizon, 1,
+            float(cfg.constraint_reward_penalty), int(bool(cfg.disable_action_relabeling)),
+            C.byref(mem._desc), C.byref(rmem._desc) if use_rmem else None, _lib.ptr(env.next_obs),
+            _lib.ptr(env.reward), _lib.ptr(env.done), _lib.ptr(env.constraint), _lib.ptr(env.success),
+            _lib.ptr(env.ep_done), _lib.ptr(self.stats), _lib.ptr(self.reward_sums), _lib.ptr(self.ep_reward),
+            _lib.current_stream())
+        _lib.check(rc, "rrl_nav_step_push")
+        mem._len = min(mem._len + self.n, mem.capacity)
+        if use_rmem:
+            rmem._len = min(rmem._len + self.n, rmem.capacity)
+        self.obs = env.obs
+        self.total_numsteps += self.n
+        return env.obs
 
     # -- whole iteration -----------------------------------------------------------------------
     def vector_step(self, do_update=True, random_actions=False, online_qrisk=True, i_episode=1):
@@ -192,8 +223,8 @@ class VectorLoop:
         """One device->host copy of the counter vector."""
         vals = self.stats.cpu().tolist()
         out = dict(zip(STAT_KEYS, vals))
-        out["reward_sum"] = float(self.reward_sum.item())
-        out["episode_return_sum"] = float(self.ep_return_sum.item())
+        sums = self.reward_sums.cpu().tolist()
+        out["reward_sum"], out["episode_return_sum"] = float(sums[0]), float(sums[1])
         return out
 
 
