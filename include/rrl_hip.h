@@ -144,18 +144,21 @@ int rrl_replay_push(const rrl_replay_t* rb, int64_t n, const float* s, const flo
                     int32_t* scratch, void* stream);
 
 /* sample (replay_memory.py:27-30): B distinct uniform rows gathered into 5 batch tensors.
- * idx_out (nullable, int64[B]) receives the chosen slots.  B <= 1024.  If B > size the error
+ * idx_out (nullable, int64[B]) receives the chosen slots.  xu / x2u / xpu (nullable, f32 [B,4]) receive the
+ * rows pre-assembled for the networks: xu = (s, a), x2u = (s', -, -), xpu = (s, -, -) (columns 2..3 of
+ * the latter two are written later by the policy-head kernels).  B <= 1024, cap < 2^31.  If B > size the error
  * flag state[3] is set to 1 and the outputs are left untouched (the reference raises
  * ValueError; callers guard, experiment.py:397,403). */
 int rrl_replay_sample_gather(const rrl_replay_t* rb, int32_t B, uint64_t seed, uint64_t counter,
                              uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a, float* r, float* s2,
-                             float* m, int64_t* idx_out, void* stream);
+                             float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu, void* stream);
 
 /* stratified sample (replay_memory.py:54-72): first n_pos rows uniform among slots with r != 0,
  * then n_neg rows uniform among filled slots with r == 0.  Needs rb->pos_cnt. cap <= 2^21. */
 int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_neg, uint64_t seed,
                               uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a,
-                              float* r, float* s2, float* m, int64_t* idx_out, void* stream);
+                              float* r, float* s2, float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu,
+                              void* stream);
 
 /* Fused lock-step iteration tail: env step + reward penalty + bootstrap mask + memory.push +
  * recovery_memory.push + episode counters in ONE launch (the body of recovery_rl/experiment.py:420-461

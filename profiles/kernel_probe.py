@@ -1,0 +1,54 @@
+"""Time individual hot-path kernels in isolation (200 back-to-back launches from one hipGraph)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recovery_rl_amd import _lib, fused  # noqa: E402
+
+dev = "cuda:0"
+
+
+def bench(fn, n=200):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+r = lambda *s: torch.randn(*s, device=dev)
+print("empty-ish kernel (counter_add): %.2f us" % bench(lambda: _lib.load().rrl_counter_add(
+    torch.zeros(2, dtype=torch.int64, device=dev).data_ptr(), 1, _lib.current_stream())))
+ctr = torch.zeros(2, dtype=torch.int64, device=dev)
+print("counter_add persistent: %.2f us" % bench(lambda: _lib.load().rrl_counter_add(ctr.data_ptr(), 1, _lib.current_stream())))
+for (M, H, din, dout, G) in ((256, 256, 4, 1, 2), (256, 256, 2, 4, 1), (4096, 256, 4, 1, 2), (4096, 256, 2, 4, 1)):
+    x = r(M, din)
+    W1, b1, W2, b2, W3, b3 = r(G, H, din), r(G, H), r(G, H, H), r(G, H), r(G, dout, H), r(G, dout)
+    out, h1, h2 = torch.empty(G, M, dout, device=dev), torch.empty(G, M, H, device=dev), torch.empty(G, M, H, device=dev)
+    t1 = bench(lambda: fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=out))
+    t2 = bench(lambda: fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=out, h1=h1, h2=h2))
+    print("mlp3_fwd M=%4d G=%d dout=%d: %.2f us (no save) %.2f us (save h1,h2)" % (M, G, dout, t1, t2))
+n = 134666
+p, g_, m, v = r(n), r(n), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+tgt = r(n)
+step = torch.zeros(2, dtype=torch.int64, device=dev)
+lib = _lib.load()
+print("adam %d: %.2f us" % (n, bench(lambda: lib.rrl_adam_step(n, p.data_ptr(), g_.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                                              step.data_ptr(), 3e-4, 0.9, 0.999, 1e-8, tgt.data_ptr(), 0.005,
+                                                              _lib.current_stream()))))
+for mode, name in ((fused.NT, "NT"), (fused.NN, "NN"), (fused.TN, "TN")):
+    for G in (1, 2):
+        A, B = r(G, 256, 256), r(G, 256, 256)
+        out = torch.empty(G, 256, 256, device=dev)
+        print("gemm %s 256^3 G=%d: %.2f us" % (name, G, bench(lambda: fused.gemm(mode, A, B, out=out))))

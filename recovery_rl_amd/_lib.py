@@ -89,9 +89,9 @@ def _declare(lib):
         "rrl_maze_reset": (ci, [i64, vp, vp, vp, vp, ci, ci, u64, u64, vp, vp]),
         "rrl_maze_offline": (ci, [i64, u64, vp, vp, vp, vp, vp, i64, vp]),
         "rrl_replay_push": (ci, [rp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
-        "rrl_replay_sample_gather": (ci, [rp, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_replay_sample_gather": (ci, [rp, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_creplay_sample_gather": (ci, [rp, i32, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp,
-                                           vp, vp]),
+                                           vp, vp, vp, vp, vp]),
         "rrl_nav_step_push": (ci, [ci, i64, vp, vp, vp, vp, vp, vp, u64, u64, vp, u64, i32, ci, f32, ci, rp, rp,
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_cem_sample": (ci, [i64, i32, i32, vp, vp, vp, vp, f64, ci, vp, u64, u64, vp, u64, vp, vp]),

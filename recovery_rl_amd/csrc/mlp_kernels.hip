@@ -48,43 +48,48 @@ struct Frag {
     float4 v[kVec];
 };
 
-__device__ __forceinline__ float4 load4(const float* p, int avail) {
-    // avail = number of valid floats at p (may be <= 0)
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (avail >= 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-        q = *reinterpret_cast<const float4*>(p);
-    } else {
-        if (avail > 0) q.x = p[0];
-        if (avail > 1) q.y = p[1];
-        if (avail > 2) q.z = p[2];
-        if (avail > 3) q.w = p[3];
+// Loads never branch: the FAST instantiation (every tile full, leading dimensions multiples of 4,
+// 16-byte aligned bases) issues plain float4 loads; the generic one clamps indices into range and
+// zeroes by predicate, so in both cases all loads of a panel are in flight together.
+template <bool FAST>
+__device__ __forceinline__ float4 load4(const float* __restrict__ base, long long row_off, int k, int K,
+                                        bool row_ok) {
+    if (FAST) return *reinterpret_cast<const float4*>(base + row_off + k);
+    float v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int kk = min(k + t, K - 1);
+        const float x = base[row_off + (kk < 0 ? 0 : kk)];
+        v[t] = (row_ok && k + t < K) ? x : 0.f;
     }
-    return q;
+    return make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // The K order inside a panel is permuted (the sum over k does not care): MFMA step s = 4 j + t of
 // lane group q = lane >> 4 consumes k = 16 j + 4 q + t.  An operand whose k index is contiguous in
 // memory (rows = M or N index) is then exactly element t of the lane's j-th float4 of its own row
 // i = lane & 15 -- it feeds the MFMA straight from registers, no LDS.
+template <bool FAST>
 __device__ __forceinline__ void load_direct(Frag& f, const float* __restrict__ src, int ld, int row0,
                                             int rows, int k0, int K, int lane) {
     const int gr = row0 + (lane & 15);
+    const bool ok = gr < rows;
+    const long long off = (long long)(ok ? gr : rows - 1) * ld;
 #pragma unroll
-    for (int j = 0; j < kVec; ++j) {
-        const int k = k0 + 16 * j + 4 * (lane >> 4);
-        f.v[j] = (gr < rows) ? load4(src + (long long)gr * ld + k, K - k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int j = 0; j < kVec; ++j) f.v[j] = load4<FAST>(src, off, k0 + 16 * j + 4 * (lane >> 4), K, ok);
 }
 
 // An operand stored [k][col] (col contiguous) is staged through LDS: coalesced float4 loads along
 // the columns, one ds_write_b128 each, read back as tile[k][i].
+template <bool FAST>
 __device__ __forceinline__ void load_staged(Frag& f, const float* __restrict__ src, int ld, int col0,
                                             int cols, int k0, int K, int lane) {
     const int c = col0 + (lane & 3) * 4;
 #pragma unroll
     for (int j = 0; j < kVec; ++j) {
         const int k = k0 + (lane >> 2) + 16 * j;
-        f.v[j] = (k < K) ? load4(src + (long long)k * ld + c, cols - c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = k < K;
+        f.v[j] = load4<FAST>(src, (long long)(ok ? k : K - 1) * ld, c, cols, ok);
     }
 }
 __device__ __forceinline__ void store_staged(const Frag& f, float* tile, int lane) {
@@ -97,7 +102,7 @@ __device__ __forceinline__ float elem(const float4& q, int t) {
     return t == 0 ? q.x : (t == 1 ? q.y : (t == 2 ? q.z : q.w));
 }
 
-template <int MODE>  // 0 NT, 1 NN, 2 TN
+template <int MODE, bool FAST>  // MODE: 0 NT, 1 NN, 2 TN
 __global__ __launch_bounds__(64) void gemm16_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float As[MODE == 2 ? kPanel * kLd : 4];
     __shared__ __attribute__((aligned(16))) float Bs[MODE != 0 ? kPanel * kLd : 4];
@@ -114,10 +119,10 @@ __global__ __launch_bounds__(64) void gemm16_kernel(GemmArgs a) {
     Frag fa, fb;
 
     auto load = [&](int k0) {
-        if (kStageA) load_staged(fa, A, a.lda, m0, a.M, k0, a.K, lane);
-        else load_direct(fa, A, a.lda, m0, a.M, k0, a.K, lane);
-        if (kStageB) load_staged(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
-        else load_direct(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
+        if (kStageA) load_staged<FAST>(fa, A, a.lda, m0, a.M, k0, a.K, lane);
+        else load_direct<FAST>(fa, A, a.lda, m0, a.M, k0, a.K, lane);
+        if (kStageB) load_staged<FAST>(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
+        else load_direct<FAST>(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
     };
 
     const int np = (a.K + kPanel - 1) / kPanel;
@@ -197,45 +202,59 @@ constexpr int kStackRows = 16;
 constexpr int kStackMaxH = 256;
 
 __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
-    __shared__ __attribute__((aligned(16))) float xs[kStackRows * 4];
-    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 4)];
-    __shared__ __attribute__((aligned(16))) float h2s[kStackRows * (kStackMaxH + 4)];
+    // row stride H + 20 floats: the 16 rows of a ds_read_b128 lane group land on distinct 16-byte slots
+    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 20)];
+    __shared__ __attribute__((aligned(16))) float h2s[kStackRows * (kStackMaxH + 20)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.y, m0 = blockIdx.x * kStackRows;
-    const int H = a.H, ldh = H + 4;
+    const int H = a.H, ldh = H + 20;
     const float* W1 = a.W1 + (long long)g * H * a.din;
     const float* b1 = a.b1 + (long long)g * H;
     const float* W2 = a.W2 + (long long)g * H * H;
     const float* b2 = a.b2 + (long long)g * H;
     const float* W3 = a.W3 + (long long)g * a.dout * H;
     const float* b3 = a.b3 + (long long)g * a.dout;
-
-    if (tid < kStackRows * 4) {
-        const int r = tid >> 2, d = tid & 3, row = m0 + r;
-        xs[tid] = (row < a.M && d < a.din) ? a.x[(long long)row * a.ldx + d] : 0.f;
-    }
-    __syncthreads();
-    // layer 1: h1[r][n] = relu(b1[n] + sum_d x[r][d] W1[n][d])
-    for (int e = tid; e < kStackRows * H; e += 1024) {
-        const int r = e / H, n = e - r * H;
-        float v = b1[n];
-        for (int d = 0; d < a.din; ++d) v = fmaf(xs[r * 4 + d], W1[n * a.din + d], v);
-        v = v > 0.f ? v : 0.f;
-        h1s[r * ldh + n] = v;
-        if (a.h1 && m0 + r < a.M) a.h1[((long long)g * a.M + m0 + r) * H + n] = v;
-    }
-    __syncthreads();
-    // layer 2: wave w -> output columns [16 w, 16 w + 16); K order permuted as in gemm16_kernel
     const int i = lane & 15, q = lane >> 4;
-    for (int nt = wave; nt * 16 < H; nt += 16) {
-        const int n0 = nt * 16;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const bool has_tile = wave * 16 < H;          // wave w owns hidden columns [16 w, 16 w + 16)
+    const int n0 = has_tile ? wave * 16 : 0;
+
+    // ---- every global read of the kernel is issued here, branch-free, before any use -------------
+    float4 wv[kStackMaxH / 16];                    // my 16 rows of W2: MFMA B operands of layer 2
+    {
         const float* wrow = W2 + (long long)(n0 + i) * H + 4 * q;
-        const float* arow = h1s + i * ldh + 4 * q;
-        float4 wv[kStackMaxH / 16];
 #pragma unroll
-        for (int j = 0; j < kStackMaxH / 16; ++j)
-            if (16 * j < H) wv[j] = *reinterpret_cast<const float4*>(wrow + 16 * j);
+        for (int j = 0; j < kStackMaxH / 16; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
+    }
+    // layer 1 as ONE MFMA step (K = din <= 4): A = x[row i][d = q], B = W1[n0 + i][d = q]
+    const int xrow = min(m0 + i, a.M - 1);
+    const float xa = (q < a.din) ? a.x[(long long)xrow * a.ldx + q] : 0.f;
+    const float w1b = (q < a.din) ? W1[(n0 + i) * a.din + q] : 0.f;
+    const float bias1 = b1[n0 + i], bias2 = b2[n0 + i];
+    // layer 3 operands: wave w = row, 16-lane group o = output index, 16 strided k per lane
+    const int o3 = min(q, a.dout - 1);
+    float w3v[kStackMaxH / 16];
+#pragma unroll
+    for (int it = 0; it < kStackMaxH / 16; ++it) w3v[it] = W3[o3 * H + min(i + 16 * it, H - 1)];
+    const float bias3 = b3[o3];
+
+    // ---- layer 1 ------------------------------------------------------------------------------------
+    if (has_tile) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, w1b, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * q + r;
+            float v = acc[r] + bias1;
+            v = v > 0.f ? v : 0.f;
+            h1s[rr * ldh + n0 + i] = v;
+            if (a.h1 && m0 + rr < a.M) a.h1[((long long)g * a.M + m0 + rr) * H + n0 + i] = v;
+        }
+    }
+    __syncthreads();
+    // ---- layer 2: 16 x H tile of h1 in LDS is the A operand of every wave; K order as in gemm16 -----
+    if (has_tile) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = h1s + i * ldh + 4 * q;
 #pragma unroll
         for (int j = 0; j < kStackMaxH / 16; ++j) {
             if (16 * j < H) {
@@ -247,30 +266,28 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
             }
         }
         const f32x4 acc = acc0 + acc1;
-        const int col = n0 + i;
-        const float bias = b2[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = 4 * q + r;
-            float v = acc[r] + bias;
+            float v = acc[r] + bias2;
             v = v > 0.f ? v : 0.f;
-            h2s[rr * ldh + col] = v;
-            if (a.h2 && m0 + rr < a.M) a.h2[((long long)g * a.M + m0 + rr) * H + col] = v;
+            h2s[rr * ldh + n0 + i] = v;
+            if (a.h2 && m0 + rr < a.M) a.h2[((long long)g * a.M + m0 + rr) * H + n0 + i] = v;
         }
     }
     __syncthreads();
-    // layer 3: wave w = row, 16-lane groups = output index
+    // ---- layer 3: 16-lane dot products -----------------------------------------------------------------
     {
-        const int r = wave, o = lane >> 4, part = lane & 15;
+        const int r = wave;
         float v = 0.f;
-        if (o < a.dout)
-            for (int k = part; k < H; k += 16) v = fmaf(h2s[r * ldh + k], W3[o * H + k], v);
+#pragma unroll
+        for (int it = 0; it < kStackMaxH / 16; ++it)
+            if (i + 16 * it < H) v = fmaf(h2s[r * ldh + i + 16 * it], w3v[it], v);
         v += __shfl_xor(v, 8);
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 1);
-        if (part == 0 && o < a.dout && m0 + r < a.M)
-            a.out[((long long)g * a.M + m0 + r) * a.dout + o] = v + b3[o];
+        if (i == 0 && q < a.dout && m0 + r < a.M) a.out[((long long)g * a.M + m0 + r) * a.dout + q] = v + bias3;
     }
 }
 
@@ -288,9 +305,20 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
                sA, sB, sC, sBias, sMask, sColsum, relu, accumulate};
     const dim3 grid((N + kTile - 1) / kTile, (M + kTile - 1) / kTile, G), block(64);
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0) hipLaunchKernelGGL((gemm16_kernel<0>), grid, block, 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((gemm16_kernel<1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm16_kernel<2>), grid, block, 0, st, a);
+    auto aligned = [](const void* p, int ld, long long stride) {
+        return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0 && (stride % 4) == 0;
+    };
+    const bool fast = (M % kTile) == 0 && (N % kTile) == 0 && (K % kPanel) == 0 && aligned(A, lda, sA) &&
+                      aligned(B, ldb, sB);
+    if (fast) {
+        if (mode == 0) hipLaunchKernelGGL((gemm16_kernel<0, true>), grid, block, 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((gemm16_kernel<1, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gemm16_kernel<2, true>), grid, block, 0, st, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((gemm16_kernel<0, false>), grid, block, 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((gemm16_kernel<1, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gemm16_kernel<2, false>), grid, block, 0, st, a);
+    }
     return check_launch();
 }
 

@@ -127,34 +127,39 @@ struct BatchOut {
     float2* s2;
     float* m;
     int64_t* idx;
+    float4* xu;    // optional [B,4] rows (s, a): the critics' input, written by the gather itself
+    float4* x2u;   // optional [B,4] rows (s', *, *): columns 2..3 are left for the policy head kernel
+    float4* xpu;   // optional [B,4] rows (s,  *, *)
 };
 
 // B distinct draws per group from [0, population): each slot draws independently; a slot loses
 // a round when an accepted slot, or a lower-numbered pending slot of its group, holds the same
 // value, and redraws with the round number bumped (uniform over ordered subsets by symmetry).
 // cand / acc live in LDS.  Returns false if the round cap is hit.
+// LDS key = candidate | accepted << 31 (populations are < 2^31): one broadcast read per comparison.
 __device__ __forceinline__ bool draw_distinct(int i, int B, int g_lo, int g_hi, uint64_t population,
-                                              uint64_t seed, uint32_t stream, uint64_t ctr,
-                                              uint64_t* cand, uint8_t* acc) {
+                                              uint64_t seed, uint32_t stream, uint64_t ctr, int row,
+                                              uint32_t* key) {
     const bool active = i < B;
     bool mine = !active;  // inactive lanes count as settled
-    if (active) acc[i] = 0;
-    __syncthreads();
+    uint32_t v = 0;
     for (uint32_t round = 0; round <= 4096; ++round) {
         if (active && !mine) {
-            const rrl::Bits128 b = rrl::philox_at(seed, uint32_t(i), stream, (ctr << 12) | round);
-            cand[i] = __umul64hi(b.lo, population);
+            const rrl::Bits128 b = rrl::philox_at(seed, uint32_t(row), stream, (ctr << 12) | round);
+            v = uint32_t(__umul64hi(b.lo, population));
+            key[i] = v;
         }
         __syncthreads();
         bool lose = false;
         if (active && !mine) {
-            const uint64_t v = cand[i];
-            for (int j = g_lo; j < g_hi; ++j)
-                lose |= (j != i) & (cand[j] == v) & (bool(acc[j]) | (j < i));
+            for (int j = g_lo; j < g_hi; ++j) {
+                const uint32_t k = key[j];
+                lose |= (j != i) & ((k & 0x7fffffffu) == v) & (bool(k >> 31) | (j < i));
+            }
         }
         __syncthreads();
         if (active && !mine && !lose) {
-            acc[i] = 1;
+            key[i] = v | 0x80000000u;
             mine = true;
         }
         if (__syncthreads_count(!mine) == 0) return true;
@@ -164,12 +169,17 @@ __device__ __forceinline__ bool draw_distinct(int i, int B, int g_lo, int g_hi, 
 
 __device__ __forceinline__ void gather_row(const rrl_replay_t& rb, int64_t slot, int i,
                                            const BatchOut& out) {
-    out.s[i] = ((const float2*)rb.s)[slot];
-    out.a[i] = ((const float2*)rb.a)[slot];
+    const float2 s = ((const float2*)rb.s)[slot], a = ((const float2*)rb.a)[slot];
+    const float2 s2 = ((const float2*)rb.s2)[slot];
+    out.s[i] = s;
+    out.a[i] = a;
     out.r[i] = rb.r[slot];
-    out.s2[i] = ((const float2*)rb.s2)[slot];
+    out.s2[i] = s2;
     out.m[i] = rb.m[slot];
     if (out.idx) out.idx[i] = slot;
+    if (out.xu) out.xu[i] = make_float4(s.x, s.y, a.x, a.y);
+    if (out.x2u) ((float2*)out.x2u)[2 * i] = s2;
+    if (out.xpu) ((float2*)out.xpu)[2 * i] = s;
 }
 
 __global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, int B, uint64_t seed,
@@ -177,8 +187,7 @@ __global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, in
                                                              uint64_t* counter_dev,
                                                              uint64_t counter_inc, BatchOut out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* cand = (uint64_t*)smem;
-    uint8_t* acc = (uint8_t*)(cand + B);
+    uint32_t* key = (uint32_t*)smem;
     const int64_t size = rb.state[1];
     if (int64_t(B) > size) {  // random.sample would raise ValueError
         if (threadIdx.x == 0) rb.state[3] = 1;
@@ -187,11 +196,11 @@ __global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, in
     const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
     rrl::advance_counter(counter_dev, counter_inc);
     const int i = threadIdx.x;
-    if (!draw_distinct(i, B, 0, B, uint64_t(size), seed, rrl::kStreamSample, ctr, cand, acc)) {
+    if (!draw_distinct(i, B, 0, B, uint64_t(size), seed, rrl::kStreamSample, ctr, i, key)) {
         if (threadIdx.x == 0) rb.state[3] = 2;
         return;
     }
-    if (i < B) gather_row(rb, int64_t(cand[i]), i, out);
+    if (i < B) gather_row(rb, int64_t(key[i] & 0x7fffffffu), i, out);
 }
 
 // Stratified: lanes [0,n_pos) draw ranks among positives, lanes [n_pos,B) among negatives.
@@ -203,10 +212,9 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
                                                                      BatchOut out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int B = n_pos + n_neg;
-    uint64_t* cand = (uint64_t*)smem;
-    int32_t* prefix = (int32_t*)(cand + B);           // [n_chunks + 1] exclusive positive counts
+    uint32_t* key = (uint32_t*)smem;
+    int32_t* prefix = (int32_t*)(key + B);            // [n_chunks + 1] exclusive positive counts
     int32_t* part = prefix + (n_chunks + 1);          // [blockDim.x]
-    uint8_t* acc = (uint8_t*)(part + blockDim.x);
     const int64_t size = rb.state[1];
     const int tid = threadIdx.x, nt = blockDim.x;
     // exclusive scan of pos_cnt into LDS: contiguous segment per thread, then a block scan
@@ -243,43 +251,13 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
     const uint32_t stream = is_pos ? rrl::kStreamSample : rrl::kStreamSampleNeg;
     // lanes of the negative group are numbered from 0 within their group, like a separate call
     const int gi = is_pos ? tid : tid - n_pos;
-    // draw_distinct indexes LDS by absolute lane but keys Philox by the group-relative row
-    {
-        const bool active = tid < B;
-        bool mine = !active;
-        if (active) acc[tid] = 0;
-        __syncthreads();
-        bool ok = false;
-        for (uint32_t round = 0; round <= 4096; ++round) {
-            if (active && !mine) {
-                const rrl::Bits128 b = rrl::philox_at(seed, uint32_t(gi), stream, (ctr << 12) | round);
-                cand[tid] = __umul64hi(b.lo, population);
-            }
-            __syncthreads();
-            bool lose = false;
-            if (active && !mine) {
-                const uint64_t v = cand[tid];
-                for (int j = g_lo; j < g_hi; ++j)
-                    lose |= (j != tid) & (cand[j] == v) & (bool(acc[j]) | (j < tid));
-            }
-            __syncthreads();
-            if (active && !mine && !lose) {
-                acc[tid] = 1;
-                mine = true;
-            }
-            if (__syncthreads_count(!mine) == 0) {
-                ok = true;
-                break;
-            }
-        }
-        if (!ok) {
-            if (tid == 0) rb.state[3] = 2;
-            return;
-        }
+    if (!draw_distinct(tid, B, g_lo, g_hi, population, seed, stream, ctr, gi, key)) {
+        if (tid == 0) rb.state[3] = 2;
+        return;
     }
     if (tid >= B) return;
     // rank -> slot: binary search the chunk, then scan its 64 rewards
-    const int64_t k = int64_t(cand[tid]);
+    const int64_t k = int64_t(key[tid] & 0x7fffffffu);
     auto before = [&](int c) -> int64_t {  // rows of my class in chunks [0,c)
         const int64_t filled = min(size, int64_t(c) * kChunk);
         return is_pos ? int64_t(prefix[c]) : filled - int64_t(prefix[c]);
@@ -339,12 +317,12 @@ int rrl_replay_push(const rrl_replay_t* rb, int64_t n, const float* s, const flo
 
 int rrl_replay_sample_gather(const rrl_replay_t* rb, int32_t B, uint64_t seed, uint64_t counter,
                              uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a, float* r, float* s2,
-                             float* m, int64_t* idx_out, void* stream) {
+                             float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu, void* stream) {
     if (!valid_rb(rb) || !s || !a || !r || !s2 || !m) return RRL_EINVAL;
-    if (B <= 0 || B > 1024) return RRL_ERANGE;
-    const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out};
+    if (B <= 0 || B > 1024 || rb->cap >= (int64_t(1) << 31)) return RRL_ERANGE;
+    const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out, (float4*)xu, (float4*)x2u, (float4*)xpu};
     const int threads = ((B + 63) / 64) * 64;
-    const size_t lds = size_t(B) * 9 + 16;
+    const size_t lds = size_t(B) * 4 + 16;
     hipLaunchKernelGGL(sample_gather_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, *rb,
                        B, seed, counter, counter_dev, counter_inc, out);
     return check_launch();
@@ -352,7 +330,8 @@ int rrl_replay_sample_gather(const rrl_replay_t* rb, int32_t B, uint64_t seed, u
 
 int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_neg, uint64_t seed,
                               uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a,
-                              float* r, float* s2, float* m, int64_t* idx_out, void* stream) {
+                              float* r, float* s2, float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu,
+                              void* stream) {
     if (!valid_rb(rb) || !rb->pos_cnt || !s || !a || !r || !s2 || !m) return RRL_EINVAL;
     const int B = n_pos + n_neg;
     if (n_pos < 0 || n_neg < 0 || B <= 0 || B > 1024) return RRL_ERANGE;
@@ -360,7 +339,7 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
     const int n_chunks = int((rb->cap + kChunk - 1) / kChunk);
     int threads = ((B + 63) / 64) * 64;
     if (threads < 256) threads = 256;
-    const size_t lds = size_t(B) * 8 + size_t(n_chunks + 1) * 4 + size_t(threads) * 4 + size_t(B) + 16;
+    const size_t lds = size_t(B) * 4 + size_t(n_chunks + 1) * 4 + size_t(threads) * 4 + 16;
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opt in above the 64 KiB default
         if (hipFuncSetAttribute((const void*)creplay_sample_gather_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
@@ -368,7 +347,7 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
             return RRL_ERANGE;
         }
     }
-    const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out};
+    const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out, (float4*)xu, (float4*)x2u, (float4*)xpu};
     hipLaunchKernelGGL(creplay_sample_gather_kernel, dim3(1), dim3(threads), lds,
                        (hipStream_t)stream, *rb, n_pos, n_neg, n_chunks, seed, counter, counter_dev,
                        counter_inc, out);

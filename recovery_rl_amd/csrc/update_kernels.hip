@@ -218,10 +218,14 @@ __global__ void stoch_head_bwd_kernel(int B, const float* raw, const float* eps,
 __global__ __launch_bounds__(kBlock) void adam_kernel(long long n, float* p, const float* g, float* m,
                                                       float* v, uint64_t* step_dev, float lr, float b1,
                                                       float b2, float eps, float* target, float tau) {
-    const double t = double(step_dev[0] + 1);
-    const float bc1 = float(1.0 - pow(double(b1), t));
-    const float bc2_sqrt = float(sqrt(1.0 - pow(double(b2), t)));
-    const float step_size = lr / bc1;
+    __shared__ float sh[2];
+    if (threadIdx.x == 0) {   // bias corrections once per workgroup (double pow is ~100 instructions)
+        const double t = double(step_dev[0] + 1);
+        sh[0] = lr / float(1.0 - pow(double(b1), t));
+        sh[1] = float(sqrt(1.0 - pow(double(b2), t)));
+    }
+    __syncthreads();
+    const float step_size = sh[0], bc2_sqrt = sh[1];
     const long long stride = (long long)gridDim.x * kBlock;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const float gi = g[i];
@@ -325,7 +329,9 @@ int rrl_stoch_head_bwd(int B, const float* raw, const float* eps, const float* l
 int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uint64_t* step_dev, float lr,
                   float beta1, float beta2, float eps, float* target, float tau, void* stream) {
     if (!p || !g || !m || !v || !step_dev || n <= 0) return RRL_EINVAL;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, p, g, m, v,
+    // <= 64 workgroups: the step ticket is one device-scope atomic per workgroup on a single word
+    const int grid = grid_for(n) < 64 ? grid_for(n) : 64;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, n, p, g, m, v,
                        step_dev, lr, beta1, beta2, eps, target, tau);
     return check_launch();
 }

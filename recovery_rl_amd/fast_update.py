@@ -187,6 +187,7 @@ class FastUpdater:
         self.dq, self.dhead, self.draw = z(2, B, 1), z(1, B, 4), z(1, B, 2)
         self.dact = z(B, 2)
         self.losses = z(8)   # q1, q2, policy, (pad) | qr1, qr2, recpolicy, (pad)
+        self._noise = None
         self.alpha = torch.full((1,), float(agent.alpha), dtype=torch.float32, device=dev)
         self.scale = agent.policy.action_scale.to(dev).float().contiguous()
         self.bias = agent.policy.action_bias.to(dev).float().contiguous()
@@ -197,13 +198,26 @@ class FastUpdater:
     def _check(self, rc, what):
         _lib.check(rc, what)
 
-    def _load_batch(self, batch):
+    def _load_batch(self, batch, rows_loaded=False):
         s, a, r, s2, m = batch
-        self.xu[:, 0:2] = s
-        self.xu[:, 2:4] = a
-        self.x2u[:, 0:2] = s2
-        self.xpu[:, 0:2] = s
+        if not rows_loaded:       # the sample-gather kernel normally writes these rows itself
+            self.xu[:, 0:2] = s
+            self.xu[:, 2:4] = a
+            self.x2u[:, 0:2] = s2
+            self.xpu[:, 0:2] = s
         return s, a, r.reshape(-1), s2, m.reshape(-1)
+
+    @property
+    def rows(self):
+        return (self.xu, self.x2u, self.xpu)
+
+    def noise(self, which):
+        """Policy noise for the two updates of one iteration: ONE randn launch serves both
+        (which = 0: SAC update draws fresh noise, 1: Q_risk update uses the second half)."""
+        if which == 0 or self._noise is None:
+            self._noise = torch.randn(4, self.B, 2, device=self.dev)
+        n = self._noise
+        return (n[0], n[1]) if which == 0 else (n[2], n[3])
 
     def _gauss_fwd(self, head, eps, action_view, logp):
         st = _lib.current_stream()
@@ -213,9 +227,9 @@ class FastUpdater:
                     "rrl_gauss_head_fwd")
 
     # -- SAC -------------------------------------------------------------------------------------
-    def sac_update(self, batch, eps_next, eps_pi):
+    def sac_update(self, batch, eps_next, eps_pi, rows_loaded=False):
         ag, B, lib, st = self.agent, self.B, self.lib, _lib.current_stream()
-        s, a, r, s2, m = self._load_batch(batch)
+        s, a, r, s2, m = self._load_batch(batch, rows_loaded)
         # target: a' ~ pi(s'), min Q_target(s', a') - alpha log pi  (sac.py:192-201)
         head2 = self.pol_a.forward(s2, save=False)
         self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
@@ -243,9 +257,9 @@ class FastUpdater:
         return self.losses
 
     # -- Q_risk ------------------------------------------------------------------------------------
-    def qrisk_update(self, batch, eps_next, eps_pi):
+    def qrisk_update(self, batch, eps_next, eps_pi, rows_loaded=False):
         qr, B, lib, st = self.qr, self.B, self.lib, _lib.current_stream()
-        s, a, c, s2, m = self._load_batch(batch)
+        s, a, c, s2, m = self._load_batch(batch, rows_loaded)
         head2 = self.pol_a.forward(s2, save=False)                     # a' from the TASK policy (qrisk.py:119-120)
         self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
         zt = self.qr_b.forward(self.x2u, params=self.qrisk_target, save=False)

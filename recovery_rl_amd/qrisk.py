@@ -58,14 +58,18 @@ class QRiskWrapper:
         """One Q_risk step (+ one recovery-policy step if MF_recovery), qrisk.py:86-163.
         `policy` is the TASK policy: the target action a' ~ pi_task(s') (:119-120).
         `batch` / `eps_*` inject a fixed batch and policy noise (KAT tests)."""
+        rows_loaded = False
         if batch is None:
             batch_size = self.clamp_batch_size(batch_size, len(memory))
-            batch = memory.sample(batch_size=batch_size, pos_fraction=self.pos_fraction)
+            if self.fast is not None and batch_size == self.fast.B and hasattr(memory, "_desc"):
+                batch = memory.sample(batch_size=batch_size, pos_fraction=self.pos_fraction, rows=self.fast.rows)
+                rows_loaded = True
+            else:
+                batch = memory.sample(batch_size=batch_size, pos_fraction=self.pos_fraction)
         if self.fast is not None and batch[2].shape[0] == self.fast.B:
             if eps_next is None:
-                noise = torch.randn(2, self.fast.B, 2, device=self.device)
-                eps_next, eps_pi = noise[0], noise[1]
-            losses = self.fast.qrisk_update(batch, eps_next, eps_pi)
+                eps_next, eps_pi = self.fast.noise(1)
+            losses = self.fast.qrisk_update(batch, eps_next, eps_pi, rows_loaded=rows_loaded)
             self.updates += 1
             self.last_losses = (losses[4], losses[5], losses[6] if self.MF_recovery else None)
             return

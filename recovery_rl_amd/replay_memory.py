@@ -97,16 +97,19 @@ class ReplayMemory:
                             torch.empty(B, dtype=torch.int64, device=dev))
         return self._out[B]
 
-    def sample(self, batch_size, out=None):
+    def sample(self, batch_size, out=None, rows=None):
         """B distinct uniform rows (random.sample semantics, replay_memory.py:27-30).
-        Returns persistent batch tensors (overwritten by the next sample of the same size)."""
+        Returns persistent batch tensors (overwritten by the next sample of the same size).
+        `rows` = (xu, x2u, xpu) [B,4] buffers that additionally receive (s,a), (s',-,-), (s,-,-)."""
         B = int(batch_size)
         if self._len_exact and B > self._len:
             raise ValueError("Sample larger than population or is negative")
         s, a, r, s2, m, idx = out if out is not None else self._batch(B)
+        xu, x2u, xpu = rows if rows is not None else (None, None, None)
         rc = self.lib.rrl_replay_sample_gather(C.byref(self._desc), B, self.seed, 0,
                                                _lib.ptr(self.tick), 1, _lib.ptr(s), _lib.ptr(a),
                                                _lib.ptr(r), _lib.ptr(s2), _lib.ptr(m), _lib.ptr(idx),
+                                               _lib.ptr(xu), _lib.ptr(x2u), _lib.ptr(xpu),
                                                _lib.current_stream())
         _lib.check(rc, "rrl_replay_sample_gather")
         return s, a, r, s2, m
@@ -119,16 +122,18 @@ class ConstraintReplayMemory(ReplayMemory):
     _WITH_POS_COUNTS = True
     _SEED_SALT = 0x9E3779B97F4A7C15  # decorrelate its index stream from the task buffer's
 
-    def sample(self, batch_size, pos_fraction=None, out=None):
+    def sample(self, batch_size, pos_fraction=None, out=None, rows=None):
         if pos_fraction is None:
-            return super().sample(batch_size, out=out)
+            return super().sample(batch_size, out=out, rows=rows)
         B = int(batch_size)
         n_pos = int(B * pos_fraction)          # replay_memory.py:56-57
         n_neg = B - n_pos
         s, a, r, s2, m, idx = out if out is not None else self._batch(B)
+        xu, x2u, xpu = rows if rows is not None else (None, None, None)
         rc = self.lib.rrl_creplay_sample_gather(C.byref(self._desc), n_pos, n_neg, self.seed, 0,
                                                 _lib.ptr(self.tick), 1, _lib.ptr(s), _lib.ptr(a),
                                                 _lib.ptr(r), _lib.ptr(s2), _lib.ptr(m),
-                                                _lib.ptr(idx), _lib.current_stream())
+                                                _lib.ptr(idx), _lib.ptr(xu), _lib.ptr(x2u), _lib.ptr(xpu),
+                                                _lib.current_stream())
         _lib.check(rc, "rrl_creplay_sample_gather")
         return s, a, r, s2, m

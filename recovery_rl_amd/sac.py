@@ -137,13 +137,17 @@ class SAC(object):
         noise (KAT tests)."""
         if nu is None:
             nu = self.nu
+        rows_loaded = False
         if batch is None:
-            batch = memory.sample(batch_size=batch_size)
+            if self.fast is not None and batch_size == self.fast.B and hasattr(memory, "_desc"):
+                batch = memory.sample(batch_size=batch_size, rows=self.fast.rows)   # gather fills the net inputs
+                rows_loaded = True
+            else:
+                batch = memory.sample(batch_size=batch_size)
         if self.fast is not None and batch[2].shape[0] == self.fast.B:
             if eps_next is None:
-                noise = torch.randn(2, self.fast.B, 2, device=self.device)
-                eps_next, eps_pi = noise[0], noise[1]
-            losses = self.fast.sac_update(batch, eps_next, eps_pi)
+                eps_next, eps_pi = self.fast.noise(0)
+            losses = self.fast.sac_update(batch, eps_next, eps_pi, rows_loaded=rows_loaded)
             out = (losses[0], losses[1], losses[2], self._zero, self._alpha_const)
             return tuple(float(x) for x in out) if as_floats else out
         state, action, reward, next_state, mask = batch
