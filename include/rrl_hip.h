@@ -223,6 +223,15 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
                      const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
                      float* h1, float* h2, float* out, void* stream);
 
+/* Thin ends of the stack backward (one side 1..4 wide, so no MFMA tile):
+ *   rrl_mlp_head_backward : dW3 = dOut^T h2, db3 = sum_b dOut, dh2 = [h2 > 0] (dOut W3)   (dW3/db3 nullable)
+ *   rrl_mlp_input_backward: dW1 = dh1^T x, db1 = sum_b dh1 (nullable pair), dx = dh1 W1    (dx nullable)
+ * dOut [G,B,dout], h2/dh2/dh1 [G,B,H], W3 [G,dout,H], W1 [G,H,din], x [B,din] shared by the heads. */
+int rrl_mlp_head_backward(int G, int B, int H, int dout, const float* dOut, const float* h2, const float* W3,
+                          float* dW3, float* db3, float* dh2, void* stream);
+int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const float* x, int ldx,
+                           const float* W1, float* dW1, float* db1, float* dx, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Fused element-wise pieces of the updates (one launch each instead of a chain of PyTorch ops).
  *   rrl_gauss_head_fwd/bwd   GaussianPolicy.sample and its backward (recovery_rl/model.py:324-340);

@@ -52,3 +52,15 @@ for mode, name in ((fused.NT, "NT"), (fused.NN, "NN"), (fused.TN, "TN")):
         A, B = r(G, 256, 256), r(G, 256, 256)
         out = torch.empty(G, 256, 256, device=dev)
         print("gemm %s 256^3 G=%d: %.2f us" % (name, G, bench(lambda: fused.gemm(mode, A, B, out=out))))
+for G, dout, din in ((2, 1, 4), (1, 4, 2)):
+    B, H = 256, 256
+    dO, h2, W3 = r(G, B, dout), r(G, B, H), r(G, dout, H)
+    dW3, db3, dh2 = torch.empty(G, dout, H, device=dev), torch.empty(G, dout, device=dev), torch.empty(G, B, H, device=dev)
+    print("head_bwd G=%d dout=%d: %.2f us" % (G, dout, bench(lambda: lib.rrl_mlp_head_backward(
+        G, B, H, dout, dO.data_ptr(), h2.data_ptr(), W3.data_ptr(), dW3.data_ptr(), db3.data_ptr(), dh2.data_ptr(),
+        _lib.current_stream()))))
+    x, W1 = r(B, din), r(G, H, din)
+    dW1, db1, dx = torch.empty(G, H, din, device=dev), torch.empty(G, H, device=dev), torch.empty(G, B, din, device=dev)
+    print("input_bwd G=%d din=%d (w+x): %.2f us" % (G, din, bench(lambda: lib.rrl_mlp_input_backward(
+        G, B, H, din, dh2.data_ptr(), x.data_ptr(), din, W1.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dx.data_ptr(),
+        _lib.current_stream()))))

@@ -26,7 +26,7 @@ EXPORTS = [
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_nav_step_push",
     "rrl_cem_sample", "rrl_cem_update",
-    "rrl_gemm_f32", "rrl_mlp3_forward",
+    "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp_head_backward", "rrl_mlp_input_backward",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_recovery_select",
@@ -100,6 +100,8 @@ def _declare(lib):
                               C.c_longlong, vp, C.c_longlong, ci, vp, ci, C.c_longlong, vp, C.c_longlong,
                               ci, vp]),
         "rrl_mlp3_forward": (ci, [ci, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_mlp_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_mlp_input_backward": (ci, [ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_gauss_head_fwd": (ci, [ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]),
         "rrl_gauss_head_bwd": (ci, [ci, vp, vp, vp, vp, ci, f32, vp, vp]),
         "rrl_sac_critic_grad": (ci, [ci, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]),

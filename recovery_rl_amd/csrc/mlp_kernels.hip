@@ -291,6 +291,115 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
     }
 }
 
+// ---- thin-dimension pieces of the stack backward (dout <= 4, din <= 4) ------------------------------
+// They are far from GEMM-shaped (one side is 1..4 wide), so each gets a dedicated streaming kernel
+// instead of a padded MFMA tile.
+
+// head backward: given dOut [G,B,dout] (gradient w.r.t. the last linear layer's output),
+//   dW3[g][o][h] = sum_b dOut[g][b][o] h2[g][b][h]      db3[g][o] = sum_b dOut[g][b][o]
+//   dh2[g][b][h] = [h2 > 0] sum_o dOut[g][b][o] W3[g][o][h]
+// grid (H / 64, G); 1024 threads = 64 hidden columns x 16 batch slices; the batch loop is unrolled so
+// all of a thread's loads are in flight together; slices are summed in a fixed order (deterministic).
+constexpr int kSlices = 16;
+
+__global__ __launch_bounds__(1024) void head_bwd_kernel(int B, int H, int dout,
+                                                        const float* __restrict__ dOut,
+                                                        const float* __restrict__ h2,
+                                                        const float* __restrict__ W3, float* __restrict__ dW3,
+                                                        float* __restrict__ db3, float* __restrict__ dh2,
+                                                        int need_w) {
+    __shared__ float red[kSlices][4][64];
+    __shared__ float dsh[1024 * 4];   // dOut of this head (B <= 1024)
+    const int g = blockIdx.y, hc = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + hc;
+    const float* dO = dOut + (long long)g * B * dout;
+    for (int e = threadIdx.x; e < B * dout; e += 1024) dsh[e] = dO[e];
+    float w[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (h < H)
+        for (int o = 0; o < dout; ++o) w[o] = W3[((long long)g * dout + o) * H + h];
+    __syncthreads();
+    if (h < H) {
+#pragma unroll 16
+        for (int b = slice; b < B; b += kSlices) {
+            const long long idx = ((long long)g * B + b) * H + h;
+            const float a = h2[idx];
+            float d = 0.f;
+            for (int o = 0; o < dout; ++o) {
+                const float go = dsh[b * dout + o];
+                d = fmaf(go, w[o], d);
+                acc[o] = fmaf(go, a, acc[o]);
+            }
+            dh2[idx] = a > 0.f ? d : 0.f;
+        }
+    }
+    if (!need_w) return;
+    for (int o = 0; o < 4; ++o) red[slice][o][hc] = acc[o];
+    __syncthreads();
+    if (slice < dout && h < H) {
+        float sum = 0.f;
+        for (int sl = 0; sl < kSlices; ++sl) sum += red[sl][slice][hc];
+        dW3[((long long)g * dout + slice) * H + h] = sum;
+    }
+    if (blockIdx.x == 0 && threadIdx.x >= 512 && threadIdx.x < 512 + (unsigned)dout) {   // bias gradient
+        const int o = threadIdx.x - 512;
+        float sum = 0.f;
+        for (int b = 0; b < B; ++b) sum += dsh[b * dout + o];
+        db3[g * dout + o] = sum;
+    }
+}
+
+// input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
+//   dW1[g][h][d] = sum_b dh1[g][b][h] x[b][d]     db1[g][h] = sum_b dh1[g][b][h]          (need_w)
+//   dx[g][b][d]  = sum_h dh1[g][b][h] W1[g][h][d]                                         (need_x)
+// grid (H / 64 + B / 16, G) x 1024 threads: the first H/64 blocks do the weight gradients (64 columns x
+// 16 batch slices), the remaining ones the input gradients (one wave per batch row).
+__global__ __launch_bounds__(1024) void input_bwd_kernel(int B, int H, int din,
+                                                         const float* __restrict__ dh1,
+                                                         const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ W1, float* __restrict__ dW1,
+                                                         float* __restrict__ db1, float* __restrict__ dx,
+                                                         int need_w, int need_x) {
+    __shared__ float red[kSlices][5][64];
+    const int g = blockIdx.y;
+    const int wblocks = need_w ? (H + 63) / 64 : 0;
+    if ((int)blockIdx.x < wblocks) {
+        const int hc = threadIdx.x & 63, slice = threadIdx.x >> 6, h = blockIdx.x * 64 + hc;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (h < H) {
+#pragma unroll 16
+            for (int b = slice; b < B; b += kSlices) {
+                const float d = dh1[((long long)g * B + b) * H + h];
+                for (int k = 0; k < din; ++k) acc[k] = fmaf(d, x[(long long)b * ldx + k], acc[k]);
+                acc[4] += d;
+            }
+        }
+        for (int k = 0; k < 5; ++k) red[slice][k][hc] = acc[k];
+        __syncthreads();
+        if (slice < 5 && h < H && (slice == 4 || slice < din)) {
+            float sum = 0.f;
+            for (int sl = 0; sl < kSlices; ++sl) sum += red[sl][slice][hc];
+            if (slice == 4) db1[(long long)g * H + h] = sum;
+            else dW1[((long long)g * H + h) * din + slice] = sum;
+        }
+        return;
+    }
+    if (!need_x) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = ((int)blockIdx.x - wblocks) * 16 + wave;
+    if (b >= B) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int h = lane; h < H; h += 64) {
+        const float d = dh1[((long long)g * B + b) * H + h];
+        for (int k = 0; k < din; ++k) acc[k] = fmaf(d, W1[((long long)g * H + h) * din + k], acc[k]);
+    }
+    for (int k = 0; k < din; ++k) {
+        float v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) dx[((long long)g * B + b) * din + k] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -331,6 +440,28 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
     StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx};
     hipLaunchKernelGGL(mlp3_fwd_kernel, dim3((M + kStackRows - 1) / kStackRows, G), dim3(1024), 0,
                        (hipStream_t)stream, a);
+    return check_launch();
+}
+
+int rrl_mlp_head_backward(int G, int B, int H, int dout, const float* dOut, const float* h2, const float* W3,
+                          float* dW3, float* db3, float* dh2, void* stream) {
+    if (!dOut || !h2 || !W3 || !dh2) return RRL_EINVAL;
+    if (G <= 0 || B <= 0 || B > 1024 || H <= 0 || dout <= 0 || dout > 4) return RRL_ERANGE;
+    const int need_w = dW3 != nullptr && db3 != nullptr;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((H + 63) / 64, G), dim3(1024), 0, (hipStream_t)stream, B, H, dout, dOut,
+                       h2, W3, dW3, db3, dh2, need_w);
+    return check_launch();
+}
+
+int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const float* x, int ldx,
+                           const float* W1, float* dW1, float* db1, float* dx, void* stream) {
+    if (!dh1 || !x || !W1) return RRL_EINVAL;
+    if (G <= 0 || B <= 0 || H <= 0 || din <= 0 || din > 4) return RRL_ERANGE;
+    const int need_w = dW1 != nullptr && db1 != nullptr, need_x = dx != nullptr;
+    if (!need_w && !need_x) return RRL_OK;
+    const int blocks = (need_w ? (H + 63) / 64 : 0) + (need_x ? (B + 15) / 16 : 0);
+    hipLaunchKernelGGL(input_bwd_kernel, dim3(blocks, G), dim3(1024), 0, (hipStream_t)stream, B, H, din, dh1, x, ldx,
+                       W1, dW1, db1, dx, need_w, need_x);
     return check_launch();
 }
 

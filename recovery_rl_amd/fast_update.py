@@ -144,20 +144,26 @@ class Stack:
         """dout [G, B, dout].  Writes parameter gradients into net.g (weight_grads) and/or returns
         dL/dx per head [G, B, din] (input_grad)."""
         P, Gr = self.net.p, self.net.g
-        G = self.net.G
-        xg = self.x.unsqueeze(0).expand(G, -1, -1)
-        if weight_grads:
-            gemm(TN, dout, self.h2, out=Gr["W3"], colsum=Gr["b3"])
-        gemm(NN, dout, P["W3"], out=self.dh2, mask=self.h2)
+        net, lib, st = self.net, _lib.load(), _lib.current_stream()
+        G, B, H = net.G, self.B, net.H
+        assert dout.is_contiguous() and self.x.stride(1) == 1
+        # last layer (1..4 outputs): dW3, db3 and the masked dh2 in one streaming kernel
+        _lib.check(lib.rrl_mlp_head_backward(G, B, H, net.dout, dout.data_ptr(), self.h2.data_ptr(),
+                                             P["W3"].data_ptr(), Gr["W3"].data_ptr() if weight_grads else None,
+                                             Gr["b3"].data_ptr() if weight_grads else None, self.dh2.data_ptr(), st),
+                   "rrl_mlp_head_backward")
+        # hidden layer: the two H x H GEMMs on the MFMA kernel
         if weight_grads:
             gemm(TN, self.dh2, self.h1, out=Gr["W2"], colsum=Gr["b2"])
         gemm(NN, self.dh2, P["W2"], out=self.dh1, mask=self.h1)
-        if weight_grads:
-            gemm(TN, self.dh1, xg, out=Gr["W1"], colsum=Gr["b1"])
-        if input_grad:
-            gemm(NN, self.dh1, P["W1"], out=self.dx)
-            return self.dx
-        return None
+        # first layer (2..4 inputs): dW1, db1 and/or dx in one streaming kernel
+        _lib.check(lib.rrl_mlp_input_backward(G, B, H, net.din, self.dh1.data_ptr(), self.x.data_ptr(),
+                                              self.x.stride(0), P["W1"].data_ptr(),
+                                              Gr["W1"].data_ptr() if weight_grads else None,
+                                              Gr["b1"].data_ptr() if weight_grads else None,
+                                              self.dx.data_ptr() if input_grad else None, st),
+                   "rrl_mlp_input_backward")
+        return self.dx if input_grad else None
 
 
 class FastUpdater:
