@@ -105,6 +105,8 @@ def cpu_baseline(budget_s=15.0):
     from recovery_rl_amd.sac import SAC
     from recovery_rl_amd.spaces import Box
     cfg = arg_utils.get_args([a for a in config2_argv(1, 1) if a != "--cuda"])
+    # batch-256 MLP updates do not scale past a few threads; oversubscribing a 128-core host is slower
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     torch.manual_seed(1)
     act_space = Box(-np.ones(2), np.ones(2))
     obs_space = Box(-np.ones(2) * np.inf, np.ones(2) * np.inf)
