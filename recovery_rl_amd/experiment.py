@@ -108,6 +108,9 @@ class VectorLoop:
             return action, action, None
         risk = self.agent.safety_critic.get_value(obs, action).squeeze(1)
         recovery = risk > cfg.eps_safe                                      # :568
+        if self.n == 1 and not bool(recovery[0].item()):
+            # one env: the recovery policy is queried only when the gate fires, as in the reference
+            return action, action.clone(), recovery
         if cfg.MF_recovery or cfg.Q_sampling_recovery:
             rec_action = self.agent.safety_critic.select_action(obs)
         else:

@@ -118,6 +118,7 @@ def install():
     sys.modules["mujoco_py"].load_model_from_path = None
     sys.modules["mujoco_py"].MjSim = None
     sys.modules["torchvision.utils"].save_image = None
+    sys.modules["torchvision.utils"].make_grid = None
     sys.modules["moviepy"].editor = sys.modules["moviepy.editor"]
     sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
     import matplotlib
