@@ -32,14 +32,14 @@ __device__ __forceinline__ void advance_ring(const rrl_replay_t& rb, int64_t pos
                                              int64_t pushed) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        // no fence: the ticket only orders this workgroup's READS of {position, size} (already consumed)
+        // before the last arriver's write; the write itself is published by the kernel boundary
         const unsigned long long ticket = atomicAdd((unsigned long long*)&rb.state[2], 1ULL);
         if (ticket == gridDim.x - 1) {
             rb.state[0] = (pos + pushed) % rb.cap;
             const int64_t ns = size + pushed;
             rb.state[1] = ns > rb.cap ? rb.cap : ns;
             rb.state[2] = 0;
-            __threadfence();
         }
     }
 }

@@ -162,12 +162,12 @@ __device__ __forceinline__ void advance_counter(uint64_t* dev, uint64_t inc) {
     if (!dev || !inc) return;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        // no fence: the ticket only orders this workgroup's READ of dev[0] (already consumed) before the
+        // last arriver's write; the write itself is published by the kernel boundary
         const unsigned long long ticket = atomicAdd((unsigned long long*)&dev[1], 1ULL);
         if (ticket == gridDim.x - 1) {
             dev[0] += inc;
             dev[1] = 0;
-            __threadfence();
         }
     }
 }
