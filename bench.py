@@ -172,8 +172,8 @@ def main():
     rank, local_rank, world = dist_utils.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = dist_utils.local_device(local_rank)
+    torch.cuda.set_device(device)
 
     cfg = arg_utils.get_args(config2_argv(dist_utils.rank_seed(1, rank), a.num_envs))
     loop = build_loop(cfg, device, fast=not a.autograd_updates)

@@ -24,11 +24,18 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("RRL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def local_device(local_rank):
+    """cuda:<local_rank>; with RRL_DIST_BACKEND=gloo several ranks may share one GPU (dry runs of the
+    multi-rank path on a single-GPU box), so the index wraps around the visible devices."""
+    n = torch.cuda.device_count()
+    return torch.device("cuda", local_rank % n if n else 0)
 
 
 def rank_seed(base_seed, rank):

@@ -7,6 +7,9 @@ from recovery_rl_amd.experiment import Experiment
 if __name__ == '__main__':
     exp_cfg = get_args()
     rank, local_rank, world = dist_utils.init()
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.set_device(dist_utils.local_device(local_rank))
     if world > 1:
         exp_cfg.seed = dist_utils.rank_seed(exp_cfg.seed, rank)
     experiment = Experiment(exp_cfg, rank=rank, world_size=world)

@@ -162,3 +162,23 @@ def test_model_based_recovery_runs_single_and_vectorised(tmp_path, capsys):
     assert hist[-1]["env_steps"] > 1700
     assert exp.recovery_policy.train_in.shape[0] > exp.num_unsafe_transitions   # online re-fit happened
     assert exp.loop.graph is None                                    # MB planning is not graph-captured
+
+
+def test_maze_config3_vectorised_with_stratified_replay(tmp_path, capsys):
+    """BASELINE config 3 at reduced size: Maze, model-free recovery, pos_fraction 0.3 (scripts/maze.sh:7)."""
+    cfg = arg_utils.get_args(["--env-name", "maze", "--cuda", "--logdir", str(tmp_path), "--seed", "5",
+                              "--use_recovery", "--MF_recovery", "--gamma_safe", "0.5", "--eps_safe", "0.15",
+                              "--pos_fraction", "0.3", "--num_unsafe_transitions", "4000",
+                              "--critic_safe_pretraining_steps", "20", "--num_envs", "256", "--num_steps", "8000",
+                              "--log_every", "10"])
+    exp = Experiment(cfg)
+    assert exp.agent.fast is not None and exp.agent.safety_critic.pos_fraction == 0.3
+    hist = exp.run()
+    assert exp.num_constraint_violations > 77                       # enough positives for the stratified batches
+    assert hist[-1]["env_steps"] > 8000 and hist[-1]["qrisk_updates"] > 0
+    assert hist[-1]["episodes"] > 0
+    exp.recovery_memory.check_error()
+    exp.memory.check_error()
+    assert exp.loop.graph is not None
+    for p in exp.agent.safety_critic.safety_critic.parameters():
+        assert torch.isfinite(p).all()
