@@ -98,6 +98,23 @@ def time_nav_step_kernel(device, n, reps=200):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def pmc_traffic(n):
+    """HBM bytes per nav_step launch measured with rocprofv3 PMC counters (committed under profiles/;
+    PMC passes cannot run inside this process).  None when no measurement exists for this size."""
+    path = os.path.join(ROOT, "profiles", "round1_nav_step_pmc.json")
+    try:
+        rec = json.load(open(path)).get(str(n))
+        return None if rec is None else rec["fetch_bytes"] + rec["write_bytes"]
+    except (OSError, ValueError):
+        return None
+
+
+# algorithmic FLOPs of one lock-step iteration (SURVEY.md section 8d): SAC update 0.685 GFLOP, Q_risk + recovery
+# update 0.62 GFLOP, acting = per env 2 x (policy 67 072 + twin Q_risk 133 632 + recovery policy 66 560) MAC
+def iteration_flops(num_envs):
+    return 0.685e9 + 0.62e9 + num_envs * 2.0 * (67072 + 133632 + 66560)
+
+
 def cpu_baseline(budget_s=15.0):
     """The reference-style loop (1 env, 1 SAC + 1 Q_risk update per env step; experiment.py:396-452)
     on the host cores: C oracle env + oracle replay + the same torch modules on the CPU."""
@@ -207,7 +224,7 @@ def main():
             "kernel": "nav_step_kernel<0,false> (rrl_nav_step)", "bound": "hbm",
             "achieved": a.num_envs * NAV_STEP_ALGO_BYTES / t_k / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": a.num_envs * NAV_STEP_ALGO_BYTES / t_k / 1e9 / HBM_PEAK_GBS,
-            "traffic": None, "launch_us": t_k * 1e6,
+            "traffic": pmc_traffic(a.num_envs), "launch_us": t_k * 1e6,
             "note": "N=%d moves only %d KB per launch: latency-bound; see roofline_sweep for the "
                     "bandwidth regime" % (a.num_envs, a.num_envs * NAV_STEP_ALGO_BYTES // 1024)}
         if not a.no_sweep:
@@ -242,6 +259,12 @@ def main():
                                   "hand-written HIP forward/backward (f32 MFMA) + fused Adam",
                        "parallelism": "replicas x%d (RCCL metric all-reduce only)" % world},
             "episodes": agg["episodes"], "violations": agg["num_viols"], "successes": agg["num_successes"],
+            # the MLP side of the iteration against the f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+            "roofline_mlp": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
+                             "achieved": iteration_flops(a.num_envs) * a.steps * world / elapsed / 1e12,
+                             "frac": iteration_flops(a.num_envs) * a.steps * world / elapsed / 1e12 / (157.3 * world),
+                             "note": "algorithmic FLOPs of SAC + Q_risk updates (B=256) and acting (N envs) per "
+                                     "iteration / iteration time; tiny problems: launch- and latency-bound"},
         }
         out.update(extra)
         print(json.dumps(out))

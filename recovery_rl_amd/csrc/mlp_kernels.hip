@@ -298,50 +298,63 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
 // head backward: given dOut [G,B,dout] (gradient w.r.t. the last linear layer's output),
 //   dW3[g][o][h] = sum_b dOut[g][b][o] h2[g][b][h]      db3[g][o] = sum_b dOut[g][b][o]
 //   dh2[g][b][h] = [h2 > 0] sum_o dOut[g][b][o] W3[g][o][h]
-// grid (H / 64, G); 1024 threads = 64 hidden columns x 16 batch slices; the batch loop is unrolled so
-// all of a thread's loads are in flight together; slices are summed in a fixed order (deterministic).
-constexpr int kSlices = 16;
+// grid (H / 16, G); 256 threads = 16 hidden columns x 16 batch slices.  The batch loop has a fixed,
+// fully unrolled trip count (predicated), so all of a thread's loads are in flight together; the
+// slices are summed in a fixed order (deterministic).
+constexpr int kCols = 16, kSlices = 16, kUnroll = 16;
 
-__global__ __launch_bounds__(1024) void head_bwd_kernel(int B, int H, int dout,
-                                                        const float* __restrict__ dOut,
-                                                        const float* __restrict__ h2,
-                                                        const float* __restrict__ W3, float* __restrict__ dW3,
-                                                        float* __restrict__ db3, float* __restrict__ dh2,
-                                                        int need_w) {
-    __shared__ float red[kSlices][4][64];
+__global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int dout,
+                                                       const float* __restrict__ dOut,
+                                                       const float* __restrict__ h2,
+                                                       const float* __restrict__ W3, float* __restrict__ dW3,
+                                                       float* __restrict__ db3, float* __restrict__ dh2,
+                                                       int need_w) {
+    __shared__ float red[kSlices][4][kCols];
     __shared__ float dsh[1024 * 4];   // dOut of this head (B <= 1024)
-    const int g = blockIdx.y, hc = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int h = blockIdx.x * 64 + hc;
+    const int g = blockIdx.y, hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols;
+    const int h = blockIdx.x * kCols + hc;
+    const bool hok = h < H;
+    const int hh = hok ? h : H - 1;
     const float* dO = dOut + (long long)g * B * dout;
-    for (int e = threadIdx.x; e < B * dout; e += 1024) dsh[e] = dO[e];
-    float w[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (h < H)
-        for (int o = 0; o < dout; ++o) w[o] = W3[((long long)g * dout + o) * H + h];
+    for (int e = threadIdx.x; e < B * dout; e += 256) dsh[e] = dO[e];
+    float w[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) w[o] = o < dout ? W3[((long long)g * dout + o) * H + hh] : 0.f;
     __syncthreads();
-    if (h < H) {
-#pragma unroll 16
-        for (int b = slice; b < B; b += kSlices) {
-            const long long idx = ((long long)g * B + b) * H + h;
-            const float a = h2[idx];
-            float d = 0.f;
-            for (int o = 0; o < dout; ++o) {
-                const float go = dsh[b * dout + o];
-                d = fmaf(go, w[o], d);
-                acc[o] = fmaf(go, a, acc[o]);
+    for (int b0 = 0; b0 < B; b0 += kSlices * kUnroll) {
+        float a[kUnroll];
+#pragma unroll
+        for (int it = 0; it < kUnroll; ++it) {
+            const int b = min(b0 + slice + kSlices * it, B - 1);
+            a[it] = h2[((long long)g * B + b) * H + hh];
+        }
+#pragma unroll
+        for (int it = 0; it < kUnroll; ++it) {
+            const int b = b0 + slice + kSlices * it;
+            if (b < B) {
+                float d = 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const float go = o < dout ? dsh[b * dout + o] : 0.f;
+                    d = fmaf(go, w[o], d);
+                    acc[o] = fmaf(go, a[it], acc[o]);
+                }
+                if (hok) dh2[((long long)g * B + b) * H + h] = a[it] > 0.f ? d : 0.f;
             }
-            dh2[idx] = a > 0.f ? d : 0.f;
         }
     }
     if (!need_w) return;
+#pragma unroll
     for (int o = 0; o < 4; ++o) red[slice][o][hc] = acc[o];
     __syncthreads();
-    if (slice < dout && h < H) {
+    if (slice < dout && hok) {
         float sum = 0.f;
+#pragma unroll
         for (int sl = 0; sl < kSlices; ++sl) sum += red[sl][slice][hc];
         dW3[((long long)g * dout + slice) * H + h] = sum;
     }
-    if (blockIdx.x == 0 && threadIdx.x >= 512 && threadIdx.x < 512 + (unsigned)dout) {   // bias gradient
-        const int o = threadIdx.x - 512;
+    if (blockIdx.x == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + (unsigned)dout) {   // bias gradient
+        const int o = threadIdx.x - 128;
         float sum = 0.f;
         for (int b = 0; b < B; ++b) sum += dsh[b * dout + o];
         db3[g * dout + o] = sum;
@@ -351,32 +364,46 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(int B, int H, int dout,
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
 //   dW1[g][h][d] = sum_b dh1[g][b][h] x[b][d]     db1[g][h] = sum_b dh1[g][b][h]          (need_w)
 //   dx[g][b][d]  = sum_h dh1[g][b][h] W1[g][h][d]                                         (need_x)
-// grid (H / 64 + B / 16, G) x 1024 threads: the first H/64 blocks do the weight gradients (64 columns x
-// 16 batch slices), the remaining ones the input gradients (one wave per batch row).
-__global__ __launch_bounds__(1024) void input_bwd_kernel(int B, int H, int din,
-                                                         const float* __restrict__ dh1,
-                                                         const float* __restrict__ x, int ldx,
-                                                         const float* __restrict__ W1, float* __restrict__ dW1,
-                                                         float* __restrict__ db1, float* __restrict__ dx,
-                                                         int need_w, int need_x) {
-    __shared__ float red[kSlices][5][64];
+// grid (H / 16 + B / 4, G) x 256 threads: the first H/16 blocks do the weight gradients (16 columns x 16
+// batch slices, as above), the remaining ones the input gradients (one wavefront per batch row).
+__global__ __launch_bounds__(256) void input_bwd_kernel(int B, int H, int din,
+                                                        const float* __restrict__ dh1,
+                                                        const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ W1, float* __restrict__ dW1,
+                                                        float* __restrict__ db1, float* __restrict__ dx,
+                                                        int need_w, int need_x) {
+    __shared__ float red[kSlices][5][kCols];
     const int g = blockIdx.y;
-    const int wblocks = need_w ? (H + 63) / 64 : 0;
+    const int wblocks = need_w ? (H + kCols - 1) / kCols : 0;
     if ((int)blockIdx.x < wblocks) {
-        const int hc = threadIdx.x & 63, slice = threadIdx.x >> 6, h = blockIdx.x * 64 + hc;
+        const int hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols, h = blockIdx.x * kCols + hc;
+        const bool hok = h < H;
+        const int hh = hok ? h : H - 1;
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (h < H) {
-#pragma unroll 16
-            for (int b = slice; b < B; b += kSlices) {
-                const float d = dh1[((long long)g * B + b) * H + h];
-                for (int k = 0; k < din; ++k) acc[k] = fmaf(d, x[(long long)b * ldx + k], acc[k]);
-                acc[4] += d;
+        for (int b0 = 0; b0 < B; b0 += kSlices * kUnroll) {
+            float d[kUnroll], xv[kUnroll][4];
+#pragma unroll
+            for (int it = 0; it < kUnroll; ++it) {
+                const int b = min(b0 + slice + kSlices * it, B - 1);
+                d[it] = dh1[((long long)g * B + b) * H + hh];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[it][k] = k < din ? x[(long long)b * ldx + k] : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < kUnroll; ++it) {
+                if (b0 + slice + kSlices * it < B) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] = fmaf(d[it], xv[it][k], acc[k]);
+                    acc[4] += d[it];
+                }
             }
         }
+#pragma unroll
         for (int k = 0; k < 5; ++k) red[slice][k][hc] = acc[k];
         __syncthreads();
-        if (slice < 5 && h < H && (slice == 4 || slice < din)) {
+        if (slice < 5 && hok && (slice == 4 || slice < din)) {
             float sum = 0.f;
+#pragma unroll
             for (int sl = 0; sl < kSlices; ++sl) sum += red[sl][slice][hc];
             if (slice == 4) db1[(long long)g * H + h] = sum;
             else dW1[((long long)g * H + h) * din + slice] = sum;
@@ -385,18 +412,29 @@ __global__ __launch_bounds__(1024) void input_bwd_kernel(int B, int H, int din,
     }
     if (!need_x) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = ((int)blockIdx.x - wblocks) * 16 + wave;
+    const int b = ((int)blockIdx.x - wblocks) * 4 + wave;
     if (b >= B) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int h = lane; h < H; h += 64) {
-        const float d = dh1[((long long)g * B + b) * H + h];
-        for (int k = 0; k < din; ++k) acc[k] = fmaf(d, W1[((long long)g * H + h) * din + k], acc[k]);
+    for (int h0 = 0; h0 < H; h0 += 256) {
+        float d[4], wv[4][4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int h = min(h0 + lane + 64 * it, H - 1);
+            d[it] = dh1[((long long)g * B + b) * H + h];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wv[it][k] = k < din ? W1[((long long)g * H + h) * din + k] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (h0 + lane + 64 * it < H)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = fmaf(d[it], wv[it][k], acc[k]);
     }
-    for (int k = 0; k < din; ++k) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
         float v = acc[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) dx[((long long)g * B + b) * din + k] = v;
+        if (lane == 0 && k < din) dx[((long long)g * B + b) * din + k] = v;
     }
 }
 
@@ -448,7 +486,7 @@ int rrl_mlp_head_backward(int G, int B, int H, int dout, const float* dOut, cons
     if (!dOut || !h2 || !W3 || !dh2) return RRL_EINVAL;
     if (G <= 0 || B <= 0 || B > 1024 || H <= 0 || dout <= 0 || dout > 4) return RRL_ERANGE;
     const int need_w = dW3 != nullptr && db3 != nullptr;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((H + 63) / 64, G), dim3(1024), 0, (hipStream_t)stream, B, H, dout, dOut,
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((H + kCols - 1) / kCols, G), dim3(256), 0, (hipStream_t)stream, B, H, dout, dOut,
                        h2, W3, dW3, db3, dh2, need_w);
     return check_launch();
 }
@@ -459,8 +497,8 @@ int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const
     if (G <= 0 || B <= 0 || H <= 0 || din <= 0 || din > 4) return RRL_ERANGE;
     const int need_w = dW1 != nullptr && db1 != nullptr, need_x = dx != nullptr;
     if (!need_w && !need_x) return RRL_OK;
-    const int blocks = (need_w ? (H + 63) / 64 : 0) + (need_x ? (B + 15) / 16 : 0);
-    hipLaunchKernelGGL(input_bwd_kernel, dim3(blocks, G), dim3(1024), 0, (hipStream_t)stream, B, H, din, dh1, x, ldx,
+    const int blocks = (need_w ? (H + kCols - 1) / kCols : 0) + (need_x ? (B + 3) / 4 : 0);
+    hipLaunchKernelGGL(input_bwd_kernel, dim3(blocks, G), dim3(256), 0, (hipStream_t)stream, B, H, din, dh1, x, ldx,
                        W1, dW1, db1, dx, need_w, need_x);
     return check_launch();
 }
