@@ -64,3 +64,9 @@ for G, dout, din in ((2, 1, 4), (1, 4, 2)):
     print("input_bwd G=%d din=%d (w+x): %.2f us" % (G, din, bench(lambda: lib.rrl_mlp_input_backward(
         G, B, H, din, dh2.data_ptr(), x.data_ptr(), din, W1.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dx.data_ptr(),
         _lib.current_stream()))))
+for H in (256, 128, 64, 32):
+    M, din, dout, G = 256, 4, 1, 2
+    x = r(M, din)
+    W1, b1, W2, b2, W3, b3 = r(G, H, din), r(G, H), r(G, H, H), r(G, H), r(G, dout, H), r(G, dout)
+    out = torch.empty(G, M, dout, device=dev)
+    print("mlp3_fwd M=256 G=2 H=%d: %.2f us" % (H, bench(lambda: fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=out))))

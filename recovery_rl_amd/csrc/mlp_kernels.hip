@@ -218,18 +218,19 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
     const bool has_tile = wave * 16 < H;          // wave w owns hidden columns [16 w, 16 w + 16)
     const int n0 = has_tile ? wave * 16 : 0;
 
-    // ---- every global read of the kernel is issued here, branch-free, before any use -------------
+    // ---- every global read of the kernel is issued up front, branch-free, in the order of first use ---
+    // layer 1 as ONE MFMA step (K = din <= 4): A = x[row i][d = q], B = W1[n0 + i][d = q]
+    const int xrow = min(m0 + i, a.M - 1);
+    const float xa = (q < a.din) ? a.x[(long long)xrow * a.ldx + q] : 0.f;
+    const float w1b = (q < a.din) ? W1[(n0 + i) * a.din + q] : 0.f;
+    const float bias1 = b1[n0 + i];
     float4 wv[kStackMaxH / 16];                    // my 16 rows of W2: MFMA B operands of layer 2
     {
         const float* wrow = W2 + (long long)(n0 + i) * H + 4 * q;
 #pragma unroll
         for (int j = 0; j < kStackMaxH / 16; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
     }
-    // layer 1 as ONE MFMA step (K = din <= 4): A = x[row i][d = q], B = W1[n0 + i][d = q]
-    const int xrow = min(m0 + i, a.M - 1);
-    const float xa = (q < a.din) ? a.x[(long long)xrow * a.ldx + q] : 0.f;
-    const float w1b = (q < a.din) ? W1[(n0 + i) * a.din + q] : 0.f;
-    const float bias1 = b1[n0 + i], bias2 = b2[n0 + i];
+    const float bias2 = b2[n0 + i];
     // layer 3 operands: wave w = row, 16-lane group o = output index, 16 strided k per lane
     const int o3 = min(q, a.dout - 1);
     float w3v[kStackMaxH / 16];
