@@ -466,6 +466,8 @@ class Experiment:
         loop.start()
         log_every = cfg.log_every if getattr(cfg, "log_every", 0) else max(1, 100)
         history = []
+        evals = []
+        next_eval = 10 * n                  # eval every 10 episodes per env (experiment.py:372)
         it = 0
         captured_gate = None
         mb = uses_mb_recovery(cfg)
@@ -509,11 +511,45 @@ class Experiment:
                     print("Violations with Recovery: %d" % agg["viol_and_recovery"])
                     print("Violations with No Recovery: %d" % agg["viol_and_no_recovery"])
                     print("Num Successes So Far: %d" % agg["num_successes"])
+                if cfg.eval and stats["episodes"] >= next_eval:
+                    evals.append(self.get_test_rollout_vectorized(stats["episodes"]))
+                    next_eval += 10 * n
                 with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
-                    pickle.dump({"vector_stats": history, "num_envs": n}, f)
+                    pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n}, f)
                 if stats["env_steps"] > cfg.num_steps or stats["episodes"] > cfg.num_eps:
                     break
         return history
+
+    def get_test_rollout_vectorized(self, label):
+        """Deterministic-policy evaluation (experiment.py:493-538) for all envs at once on a separate
+        env instance, so the training episodes are not disturbed: every env runs ONE episode; returns
+        the mean episode return, success rate and violation rate."""
+        cfg = self.exp_cfg
+        if not hasattr(self, "_eval_env"):
+            self._eval_env = make_vec_env(cfg.env_name, cfg.num_envs, device=self.device,
+                                          seed=cfg.seed + 7919, auto_reset=False)
+        env = self._eval_env
+        obs = env.reset()
+        n = cfg.num_envs
+        alive = torch.ones(n, dtype=torch.bool, device=self.device)
+        ret = torch.zeros(n, device=self.device)
+        succ = torch.zeros(n, dtype=torch.bool, device=self.device)
+        viol = torch.zeros(n, dtype=torch.bool, device=self.device)
+        for _ in range(env._max_episode_steps + 1):                  # the reference runs horizon + 1 steps (:515)
+            action, real_action, _ = self.loop.act(obs, train=False)
+            obs, reward, done, info = env.step(real_action.contiguous())
+            ret += torch.where(alive, reward, torch.zeros_like(reward))
+            succ |= alive & info["success"].bool()
+            viol |= alive & info["constraint"].bool()
+            alive &= ~done.bool()
+            obs = obs.clone()
+        out = {"label": label, "avg_reward": float(ret.mean().item()), "success_rate": float(succ.float().mean().item()),
+               "violation_rate": float(viol.float().mean().item())}
+        if self.rank == 0:
+            print("----------------------------------------")
+            print("Avg. Reward: {}".format(round(out["avg_reward"], 2)))
+            print("----------------------------------------")
+        return out
 
     def _absorb(self, stats):
         self.total_numsteps = stats["env_steps"]

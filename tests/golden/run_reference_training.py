@@ -1,0 +1,76 @@
+"""Run the REFERENCE's training loop (rrl_main configuration of scripts/navigation1.sh:7) on the CPU in
+this container and record the learning-level statistics that plotting/plot_runs.py:214-235 derives from
+run_stats.pkl (cumulative task successes / constraint violations, episode lengths).  Used as the
+learning-level anchor of SURVEY.md section 8d ("parity gates"); RNG streams differ, so only the statistics
+are comparable.
+
+Harness patches, applied from outside: (a) torchify -> CPU, (b) critic step deferred until the
+policy loss has been back-propagated (torch >= 1.5 rejects the reference's order), (c) float32 log_std.
+
+Run: python tests/golden/run_reference_training.py [seed] [num_eps] -> tests/golden/ref_learning_nav1_seed<seed>.json
+"""
+import contextlib
+import io
+import json
+import os
+import pickle
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_shims  # noqa: E402
+
+_ref_shims.install()
+import torch  # noqa: E402
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    num_eps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    import arg_utils
+    import recovery_rl.experiment as rexp
+    import recovery_rl.sac as rsac
+    rexp.torchify = lambda x: torch.FloatTensor(x)                                  # (a)
+    orig_init = rsac.SAC.__init__
+
+    def patched_init(self, *a, **k):
+        orig_init(self, *a, **k)
+        self.safety_critic.policy.log_std.data = self.safety_critic.policy.log_std.data.float()   # (c)
+        real_c, real_p, snap = self.critic_optim.step, self.policy_optim.step, {}
+
+        def deferred():
+            snap["g"] = [p.grad.clone() for p in self.critic.parameters()]
+
+        def both():
+            real_p()
+            for p, g in zip(self.critic.parameters(), snap["g"]):
+                p.grad = g
+            real_c()
+        self.critic_optim.step, self.policy_optim.step = deferred, both              # (b)
+    rsac.SAC.__init__ = patched_init
+    tmp = tempfile.mkdtemp()
+    sys.argv = ["rrl_main", "--env-name", "navigation1", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.8",
+                "--eps_safe", "0.3", "--logdir", tmp, "--logdir_suffix", "RRL_MF", "--num_eps", str(num_eps),
+                "--num_unsafe_transitions", "20000", "--seed", str(seed), "--eval", ""]
+    cfg = arg_utils.get_args()
+    t0 = time.time()
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        exp = rexp.Experiment(cfg)
+        exp.run()
+    stats = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))["train_stats"]
+    viol = [int(any(s["constraint"] for s in ep)) for ep in stats]
+    succ = [int(ep[-1]["reward"] > -4) for ep in stats]
+    res = {"argv": sys.argv[1:], "seed": seed, "episodes": len(stats), "episode_lengths": [len(ep) for ep in stats],
+           "violations": viol, "successes": succ, "total_violations": sum(viol), "total_successes": sum(succ),
+           "num_constraint_transitions": exp.num_unsafe_transitions,
+           "num_constraint_violations_offline": exp.num_constraint_violations, "wall_seconds": time.time() - t0,
+           "env_steps": exp.total_numsteps}
+    json.dump(res, open(os.path.join(HERE, "ref_learning_nav1_seed%d.json" % seed), "w"))
+    print({k: v for k, v in res.items() if not isinstance(v, list)})
+
+
+if __name__ == "__main__":
+    main()
