@@ -218,10 +218,13 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
  * GaussianPolicy / StochasticPolicy trunks + last linear; model.py:66-76,188-199,317-323,511-515):
  *   out[g] = W3[g] relu(W2[g] relu(W1[g] x + b1[g]) + b2[g]) + b3[g],  x [M,din] (leading dim ldx)
  * shared by the G heads.  W1 [G,H,din], W2 [G,H,H], W3 [G,dout,H]; h1/h2 [G,M,H] receive the hidden
- * activations when non-null (needed by the backward pass).  H % 16 == 0, H <= 256, din, dout <= 4. */
+ * activations when non-null (needed by the backward pass).  H % 16 == 0, H <= 256, din, dout <= 4.
+ * scratch (nullable, f32 [4*G*M*dout]): when given and M <= 1024, H % 64 == 0 the hidden-2 columns are
+ * split over 4 workgroups per row tile (small batches are bound by streaming W2 through one CU) and their
+ * partial last-layer sums are added in a fixed order by a second tiny kernel. */
 int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int ldx, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
-                     float* h1, float* h2, float* out, void* stream);
+                     float* h1, float* h2, float* out, float* scratch, void* stream);
 
 /* Thin ends of the stack backward (one side 1..4 wide, so no MFMA tile):
  *   rrl_mlp_head_backward : dW3 = dOut^T h2, db3 = sum_b dOut, dh2 = [h2 > 0] (dOut W3)   (dW3/db3 nullable)

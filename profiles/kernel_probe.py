@@ -38,7 +38,9 @@ for (M, H, din, dout, G) in ((256, 256, 4, 1, 2), (256, 256, 2, 4, 1), (4096, 25
     out, h1, h2 = torch.empty(G, M, dout, device=dev), torch.empty(G, M, H, device=dev), torch.empty(G, M, H, device=dev)
     t1 = bench(lambda: fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=out))
     t2 = bench(lambda: fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=out, h1=h1, h2=h2))
-    print("mlp3_fwd M=%4d G=%d dout=%d: %.2f us (no save) %.2f us (save h1,h2)" % (M, G, dout, t1, t2))
+    scr = torch.empty(4, G, M, dout, device=dev)
+    t3 = bench(lambda: fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=out, h1=h1, h2=h2, scratch=scr))
+    print("mlp3_fwd M=%4d G=%d dout=%d: %.2f us (no save) %.2f us (save h1,h2) %.2f us (split+sum, save)" % (M, G, dout, t1, t2, t3))
 n = 134666
 p, g_, m, v = r(n), r(n), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
 tgt = r(n)

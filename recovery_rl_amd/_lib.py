@@ -99,7 +99,7 @@ def _declare(lib):
         "rrl_gemm_f32": (ci, [ci, ci, ci, ci, ci, vp, ci, C.c_longlong, vp, ci, C.c_longlong, vp, ci,
                               C.c_longlong, vp, C.c_longlong, ci, vp, ci, C.c_longlong, vp, C.c_longlong,
                               ci, vp]),
-        "rrl_mlp3_forward": (ci, [ci, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_mlp3_forward": (ci, [ci, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_mlp_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_mlp_input_backward": (ci, [ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_gauss_head_fwd": (ci, [ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]),

@@ -292,6 +292,124 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
     }
 }
 
+// ---- small-batch variant of the fused stack forward: hidden-2 columns split over S = 4 workgroups -----
+// With B = 256 rows the kernel above has only 16 workgroups (x heads) and each must pull all of W2
+// (256 KB, ~600 wave-level loads) through ONE compute unit, which is what bounds it (~13 us).  Here each
+// (16-row tile, head) is served by 4 workgroups of 4 waves; each recomputes the cheap layer 1 for all
+// columns, owns 64 hidden-2 columns (64 KB of W2) and emits a PARTIAL last-layer sum; a tiny second kernel
+// adds the four partials in a fixed order (deterministic).
+constexpr int kSplit = 4;
+
+__global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
+    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 20)];
+    __shared__ float h2s[kStackRows * (kStackMaxH / kSplit + 1)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y, m0 = blockIdx.x * kStackRows, z = blockIdx.z;
+    const int H = a.H, ldh = H + 20, HS = H / kSplit, ld2 = HS + 1;
+    const int colbase = z * HS;
+    const float* W1 = a.W1 + (long long)g * H * a.din;
+    const float* b1 = a.b1 + (long long)g * H;
+    const float* W2 = a.W2 + (long long)g * H * H;
+    const float* b2 = a.b2 + (long long)g * H;
+    const float* W3 = a.W3 + (long long)g * a.dout * H;
+    const float* b3 = a.b3 + (long long)g * a.dout;
+    const int i = lane & 15, q = lane >> 4;
+    const int ntiles1 = H / 16;                    // layer-1 column tiles, 4 waves take them round-robin
+    const bool has_tile2 = wave * 16 < HS;         // my layer-2 tile inside this group's columns
+    const int n2 = colbase + (has_tile2 ? wave * 16 : 0);
+
+    // ---- all global reads up front, branch-free ---------------------------------------------------------
+    const int xrow = min(m0 + i, a.M - 1);
+    const float xa = (q < a.din) ? a.x[(long long)xrow * a.ldx + q] : 0.f;
+    float w1b[kStackMaxH / 64], bias1[kStackMaxH / 64];
+#pragma unroll
+    for (int u = 0; u < kStackMaxH / 64; ++u) {
+        const int t = min(wave + 4 * u, ntiles1 - 1);
+        w1b[u] = (q < a.din) ? W1[(t * 16 + i) * a.din + q] : 0.f;
+        bias1[u] = b1[t * 16 + i];
+    }
+    float4 wv[kStackMaxH / 16];
+    {
+        const float* wrow = W2 + (long long)(n2 + i) * H + 4 * q;
+#pragma unroll
+        for (int j = 0; j < kStackMaxH / 16; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
+    }
+    const float bias2 = b2[n2 + i];
+    const int o3 = min(q, a.dout - 1);
+    float w3v[kStackMaxH / (16 * kSplit)];
+#pragma unroll
+    for (int it = 0; it < kStackMaxH / (16 * kSplit); ++it) w3v[it] = W3[o3 * H + colbase + min(i + 16 * it, HS - 1)];
+    const float bias3 = (z == 0) ? b3[o3] : 0.f;
+
+    // ---- layer 1 (all H columns; one MFMA step per 16-column tile) ---------------------------------------
+#pragma unroll
+    for (int u = 0; u < kStackMaxH / 64; ++u) {
+        const int t = wave + 4 * u;
+        if (t < ntiles1) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, w1b[u], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 4 * q + r;
+                float v = acc[r] + bias1[u];
+                v = v > 0.f ? v : 0.f;
+                h1s[rr * ldh + t * 16 + i] = v;
+                if (a.h1 && z == 0 && m0 + rr < a.M) a.h1[((long long)g * a.M + m0 + rr) * H + t * 16 + i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 2: my 16 columns ------------------------------------------------------------------------------
+    if (has_tile2) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = h1s + i * ldh + 4 * q;
+#pragma unroll
+        for (int j = 0; j < kStackMaxH / 16; ++j) {
+            if (16 * j < H) {
+                const float4 av = *reinterpret_cast<const float4*>(arow + 16 * j);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[j].w, acc1, 0, 0, 0);
+            }
+        }
+        const f32x4 acc = acc0 + acc1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * q + r;
+            float v = acc[r] + bias2;
+            v = v > 0.f ? v : 0.f;
+            h2s[rr * ld2 + wave * 16 + i] = v;
+            if (a.h2 && m0 + rr < a.M) a.h2[((long long)g * a.M + m0 + rr) * H + n2 + i] = v;
+        }
+    }
+    __syncthreads();
+    // ---- layer 3 partial over my HS columns: wave w -> rows 4 w .. 4 w + 3 -----------------------------
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr;
+        float v = 0.f;
+#pragma unroll
+        for (int it = 0; it < kStackMaxH / (16 * kSplit); ++it)
+            if (i + 16 * it < HS) v = fmaf(h2s[r * ld2 + i + 16 * it], w3v[it], v);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        if (i == 0 && q < a.dout && m0 + r < a.M)
+            partial[(((long long)z * gridDim.y + g) * a.M + m0 + r) * a.dout + q] = v + bias3;
+    }
+}
+
+__global__ void sum_partials_kernel(int n, const float* __restrict__ partial, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float v = partial[e];
+#pragma unroll
+    for (int z = 1; z < kSplit; ++z) v += partial[(long long)z * n + e];
+    out[e] = v;
+}
+
 // ---- thin-dimension pieces of the stack backward (dout <= 4, din <= 4) ------------------------------
 // They are far from GEMM-shaped (one side is 1..4 wide), so each gets a dedicated streaming kernel
 // instead of a padded MFMA tile.
@@ -472,11 +590,20 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
 
 int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int ldx, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
-                     float* h1, float* h2, float* out, void* stream) {
+                     float* h1, float* h2, float* out, float* scratch, void* stream) {
     if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return RRL_EINVAL;
     if (G <= 0 || G > 65535 || M <= 0 || din <= 0 || din > 4 || dout <= 0 || dout > 4) return RRL_ERANGE;
     if (H <= 0 || H > kStackMaxH || (H % 16) != 0) return RRL_ERANGE;
     StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx};
+    if (scratch && M <= 1024 && (H % (16 * kSplit)) == 0) {
+        // small batch: 4 workgroups per row tile + fixed-order sum of their partial last-layer outputs
+        hipLaunchKernelGGL(mlp3_fwd_split_kernel, dim3((M + kStackRows - 1) / kStackRows, G, kSplit), dim3(256), 0,
+                           (hipStream_t)stream, a, scratch);
+        const int n = G * M * dout;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, scratch,
+                           out);
+        return check_launch();
+    }
     hipLaunchKernelGGL(mlp3_fwd_kernel, dim3((M + kStackRows - 1) / kStackRows, G), dim3(1024), 0,
                        (hipStream_t)stream, a);
     return check_launch();

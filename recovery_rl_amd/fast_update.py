@@ -124,6 +124,7 @@ class Stack:
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.h1, self.h2, self.out = z(G, B, H), z(G, B, H), z(G, B, net.dout)
         self.dh1, self.dh2, self.dx = z(G, B, H), z(G, B, H), z(G, B, net.din)
+        self.scratch = z(4, G, B, net.dout)         # partial last-layer sums of the small-batch forward
 
     def forward(self, x, params=None, save=True):
         """x [B, din] shared by all heads.  `params` lets a target network reuse this workspace;
@@ -133,7 +134,7 @@ class Stack:
         self.x = x
         if mlp3_supported(self.net.H, self.net.din, self.net.dout):     # one launch for the whole stack
             return mlp3_forward(x, P["W1"], P["b1"], P["W2"], P["b2"], P["W3"], P["b3"], out=self.out,
-                                h1=self.h1 if save else None, h2=self.h2 if save else None)
+                                h1=self.h1 if save else None, h2=self.h2 if save else None, scratch=self.scratch)
         xg = x.unsqueeze(0).expand(G, -1, -1)
         gemm(NT, xg, P["W1"], out=self.h1, bias=P["b1"], relu=True)
         gemm(NT, self.h1, P["W2"], out=self.h2, bias=P["b2"], relu=True)

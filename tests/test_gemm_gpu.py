@@ -69,6 +69,12 @@ def test_fused_stack_forward_matches_torch(M, H, din, dout, G):
     W1, b1, W2, b2, W3, b3 = r(G, H, din), r(G, H), r(G, H, H) / H ** 0.5, r(G, H), r(G, dout, H) / H ** 0.5, r(G, dout)
     h1, h2 = torch.empty(G, M, H, device=DEV), torch.empty(G, M, H, device=DEV)
     out = fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, h1=h1, h2=h2)
+    # small-batch variant (hidden-2 columns split over 4 workgroups + fixed-order partial sums)
+    h1s, h2s = torch.empty_like(h1), torch.empty_like(h2)
+    outs = fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, h1=h1s, h2=h2s,
+                              scratch=torch.empty(4, G, M, dout, device=DEV))
+    assert torch.equal(h1s, h1) and torch.equal(h2s, h2)
+    assert torch.allclose(outs, out, rtol=1e-5, atol=1e-5)
     xd = x.double()
     rh1 = torch.relu(torch.einsum("md,ghd->gmh", xd, W1.double()) + b1.double()[:, None])
     rh2 = torch.relu(torch.einsum("gmk,ghk->gmh", rh1, W2.double()) + b2.double()[:, None])
