@@ -238,7 +238,8 @@ int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const
 /* --------------------------------------------------------------------------------------------
  * Fused element-wise pieces of the updates (one launch each instead of a chain of PyTorch ops).
  *   rrl_gauss_head_fwd/bwd   GaussianPolicy.sample and its backward (recovery_rl/model.py:324-340);
- *                            head[b] = (mean0, mean1, log_std0, log_std1) raw linear outputs
+ *                            head[b] = (mean0, mean1, log_std0, log_std1) raw linear outputs; the backward
+ *                            sums d_action over n_heads critic heads (pointer + head_stride, row stride ld)
  *   rrl_sac_critic_grad      target r + m gamma (min Q' - alpha log pi') and d(mse1+mse2)/dq
  *                            (recovery_rl/sac.py:192-214); q, qt are [2,B]; loss[2] = the two MSEs
  *   rrl_sac_policy_grad      d mean(alpha log pi - min Q)/dq (sac.py:216-231); loss[1]
@@ -255,7 +256,8 @@ int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const
 int rrl_gauss_head_fwd(int B, const float* head, const float* eps, const float* scale, const float* bias,
                        float* action, int ld_action, float* logp, float* mean_action, void* stream);
 int rrl_gauss_head_bwd(int B, const float* head, const float* eps, const float* scale,
-                       const float* d_action, int ld, float dlogp, float* dhead, void* stream);
+                       const float* d_action, int ld, int n_heads, long long head_stride, float dlogp,
+                       float* dhead, void* stream);
 int rrl_sac_critic_grad(int B, const float* q, const float* qt, const float* logp2, const float* r,
                         const float* m, float gamma, const float* alpha, const float* penalty, float* dq,
                         float* loss, void* stream);
@@ -268,8 +270,8 @@ int rrl_stoch_head_fwd(int B, const float* raw, const float* eps, const float* l
                        const float* scale, const float* bias, float* action, int ld_action, float* mean_out,
                        void* stream);
 int rrl_stoch_head_bwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
-                       const float* scale, const float* d_action, int ld, float* draw, float* dlog_std,
-                       void* stream);
+                       const float* scale, const float* d_action, int ld, int n_heads, long long head_stride,
+                       float* draw, float* dlog_std, void* stream);
 int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uint64_t* step_dev, float lr,
                   float beta1, float beta2, float eps, float* target, float tau, void* stream);
 int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task_action, int ld_task,

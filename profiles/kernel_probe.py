@@ -72,3 +72,10 @@ for H in (256, 128, 64, 32):
     W1, b1, W2, b2, W3, b3 = r(G, H, din), r(G, H), r(G, H, H), r(G, H), r(G, dout, H), r(G, dout)
     out = torch.empty(G, M, dout, device=dev)
     print("mlp3_fwd M=256 G=2 H=%d: %.2f us" % (H, bench(lambda: fused.mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=out))))
+from recovery_rl_amd.replay_memory import ReplayMemory
+for cap, fill in ((1000000, 300000), (4096, 4096)):
+    mem = ReplayMemory(cap, 1, device=dev)
+    rows = (r(fill, 2), r(fill, 2), r(fill), r(fill, 2), r(fill))
+    mem.push(*rows)
+    for B in (64, 256, 1024):
+        print("sample_gather cap=%d size=%d B=%d: %.2f us" % (cap, fill, B, bench(lambda: mem.sample(B))))

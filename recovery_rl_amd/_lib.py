@@ -103,13 +103,13 @@ def _declare(lib):
         "rrl_mlp_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_mlp_input_backward": (ci, [ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_gauss_head_fwd": (ci, [ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]),
-        "rrl_gauss_head_bwd": (ci, [ci, vp, vp, vp, vp, ci, f32, vp, vp]),
+        "rrl_gauss_head_bwd": (ci, [ci, vp, vp, vp, vp, ci, ci, C.c_longlong, f32, vp, vp]),
         "rrl_sac_critic_grad": (ci, [ci, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
         "rrl_sac_policy_grad": (ci, [ci, vp, vp, vp, vp, vp, vp]),
         "rrl_qrisk_critic_grad": (ci, [ci, vp, vp, vp, vp, f32, vp, vp, vp]),
         "rrl_qrisk_policy_grad": (ci, [ci, vp, vp, vp, vp]),
         "rrl_stoch_head_fwd": (ci, [ci, vp, vp, vp, f32, vp, vp, vp, ci, vp, vp]),
-        "rrl_stoch_head_bwd": (ci, [ci, vp, vp, vp, f32, vp, vp, ci, vp, vp, vp]),
+        "rrl_stoch_head_bwd": (ci, [ci, vp, vp, vp, f32, vp, vp, ci, ci, C.c_longlong, vp, vp, vp]),
         "rrl_adam_step": (ci, [C.c_longlong, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, f32, vp]),
         "rrl_recovery_select": (ci, [ci, vp, f32, vp, ci, vp, vp, vp, vp, vp]),
     }

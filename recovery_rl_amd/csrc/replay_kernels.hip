@@ -136,31 +136,55 @@ struct BatchOut {
 // a round when an accepted slot, or a lower-numbered pending slot of its group, holds the same
 // value, and redraws with the round number bumped (uniform over ordered subsets by symmetry).
 // cand / acc live in LDS.  Returns false if the round cap is hit.
-// LDS key = candidate | accepted << 31 (populations are < 2^31): one broadcast read per comparison.
-__device__ __forceinline__ bool draw_distinct(int i, int B, int g_lo, int g_hi, uint64_t population,
-                                              uint64_t seed, uint32_t stream, uint64_t ctr, int row,
-                                              uint32_t* key) {
+// Implementation: per round an LDS hash table maps value -> lowest claiming tag (accepted lanes claim
+// with tag 0, pending lane i with tag i + 1) through 64-bit atomicMin on (value << 32 | tag); the table
+// content that matters (minimum tag per value) does not depend on insertion order, so the outcome is the
+// same as the sequential all-pairs rule of the oracle.  O(B) work per round instead of O(B^2).
+// `group` (0/1) keeps the two populations of the stratified sampler apart.  key[i] = value | accepted << 31.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ bool draw_distinct(int i, int B, int group, uint64_t population, uint64_t seed,
+                                              uint32_t stream, uint64_t ctr, int row, uint32_t* key,
+                                              unsigned long long* table, int table_mask) {
+    const unsigned long long kEmpty = ~0ULL;
     const bool active = i < B;
     bool mine = !active;  // inactive lanes count as settled
     uint32_t v = 0;
     for (uint32_t round = 0; round <= 4096; ++round) {
+        for (int e = threadIdx.x; e <= table_mask; e += blockDim.x) table[e] = kEmpty;
         if (active && !mine) {
             const rrl::Bits128 b = rrl::philox_at(seed, uint32_t(row), stream, (ctr << 12) | round);
             v = uint32_t(__umul64hi(b.lo, population));
-            key[i] = v;
         }
         __syncthreads();
-        bool lose = false;
-        if (active && !mine) {
-            for (int j = g_lo; j < g_hi; ++j) {
-                const uint32_t k = key[j];
-                lose |= (j != i) & ((k & 0x7fffffffu) == v) & (bool(k >> 31) | (j < i));
+        const uint32_t hv = v | (uint32_t(group) << 31);            // value tagged with its population
+        if (active) {                                                // claim: accepted lanes with tag 0
+            const unsigned long long pack = ((unsigned long long)hv << 32) | (mine ? 0u : uint32_t(i + 1));
+            uint32_t h = hash32(hv) & table_mask;
+            for (;;) {
+                unsigned long long cur = table[h];
+                if (cur == kEmpty) {
+                    cur = atomicCAS(&table[h], kEmpty, pack);
+                    if (cur == kEmpty) break;
+                }
+                if (uint32_t(cur >> 32) == hv) {
+                    atomicMin(&table[h], pack);
+                    break;
+                }
+                h = (h + 1) & table_mask;
             }
         }
         __syncthreads();
-        if (active && !mine && !lose) {
-            key[i] = v | 0x80000000u;
-            mine = true;
+        if (active && !mine) {
+            uint32_t h = hash32(hv) & table_mask;
+            while (uint32_t(table[h] >> 32) != hv) h = (h + 1) & table_mask;
+            if (uint32_t(table[h]) == uint32_t(i + 1)) {             // lowest claimant of this value: accepted
+                mine = true;
+                key[i] = v | 0x80000000u;
+            }
         }
         if (__syncthreads_count(!mine) == 0) return true;
     }
@@ -185,9 +209,11 @@ __device__ __forceinline__ void gather_row(const rrl_replay_t& rb, int64_t slot,
 __global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, int B, uint64_t seed,
                                                              uint64_t counter,
                                                              uint64_t* counter_dev,
-                                                             uint64_t counter_inc, BatchOut out) {
+                                                             uint64_t counter_inc, int table_mask,
+                                                             BatchOut out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t* key = (uint32_t*)smem;
+    unsigned long long* table = (unsigned long long*)smem;      // [table_mask + 1]
+    uint32_t* key = (uint32_t*)(table + table_mask + 1);
     const int64_t size = rb.state[1];
     if (int64_t(B) > size) {  // random.sample would raise ValueError
         if (threadIdx.x == 0) rb.state[3] = 1;
@@ -196,7 +222,7 @@ __global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, in
     const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
     rrl::advance_counter(counter_dev, counter_inc);
     const int i = threadIdx.x;
-    if (!draw_distinct(i, B, 0, B, uint64_t(size), seed, rrl::kStreamSample, ctr, i, key)) {
+    if (!draw_distinct(i, B, 0, uint64_t(size), seed, rrl::kStreamSample, ctr, i, key, table, table_mask)) {
         if (threadIdx.x == 0) rb.state[3] = 2;
         return;
     }
@@ -208,11 +234,12 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
                                                                      int n_neg, int n_chunks,
                                                                      uint64_t seed, uint64_t counter,
                                                                      uint64_t* counter_dev,
-                                                                     uint64_t counter_inc,
+                                                                     uint64_t counter_inc, int table_mask,
                                                                      BatchOut out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int B = n_pos + n_neg;
-    uint32_t* key = (uint32_t*)smem;
+    unsigned long long* table = (unsigned long long*)smem;      // [table_mask + 1]
+    uint32_t* key = (uint32_t*)(table + table_mask + 1);
     int32_t* prefix = (int32_t*)(key + B);            // [n_chunks + 1] exclusive positive counts
     int32_t* part = prefix + (n_chunks + 1);          // [blockDim.x]
     const int64_t size = rb.state[1];
@@ -246,12 +273,11 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
     const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
     rrl::advance_counter(counter_dev, counter_inc);
     const bool is_pos = tid < n_pos;
-    const int g_lo = is_pos ? 0 : n_pos, g_hi = is_pos ? n_pos : B;
     const uint64_t population = uint64_t(is_pos ? total_pos : total_neg);
     const uint32_t stream = is_pos ? rrl::kStreamSample : rrl::kStreamSampleNeg;
     // lanes of the negative group are numbered from 0 within their group, like a separate call
     const int gi = is_pos ? tid : tid - n_pos;
-    if (!draw_distinct(tid, B, g_lo, g_hi, population, seed, stream, ctr, gi, key)) {
+    if (!draw_distinct(tid, B, is_pos ? 0 : 1, population, seed, stream, ctr, gi, key, table, table_mask)) {
         if (tid == 0) rb.state[3] = 2;
         return;
     }
@@ -322,9 +348,11 @@ int rrl_replay_sample_gather(const rrl_replay_t* rb, int32_t B, uint64_t seed, u
     if (B <= 0 || B > 1024 || rb->cap >= (int64_t(1) << 31)) return RRL_ERANGE;
     const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out, (float4*)xu, (float4*)x2u, (float4*)xpu};
     const int threads = ((B + 63) / 64) * 64;
-    const size_t lds = size_t(B) * 4 + 16;
+    int table_size = 64;
+    while (table_size < 4 * B) table_size <<= 1;
+    const size_t lds = size_t(table_size) * 8 + size_t(B) * 4 + 16;
     hipLaunchKernelGGL(sample_gather_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, *rb,
-                       B, seed, counter, counter_dev, counter_inc, out);
+                       B, seed, counter, counter_dev, counter_inc, table_size - 1, out);
     return check_launch();
 }
 
@@ -339,7 +367,9 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
     const int n_chunks = int((rb->cap + kChunk - 1) / kChunk);
     int threads = ((B + 63) / 64) * 64;
     if (threads < 256) threads = 256;
-    const size_t lds = size_t(B) * 4 + size_t(n_chunks + 1) * 4 + size_t(threads) * 4 + 16;
+    int table_size = 64;
+    while (table_size < 4 * B) table_size <<= 1;
+    const size_t lds = size_t(table_size) * 8 + size_t(B) * 4 + size_t(n_chunks + 1) * 4 + size_t(threads) * 4 + 16;
     if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opt in above the 64 KiB default
         if (hipFuncSetAttribute((const void*)creplay_sample_gather_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
@@ -350,7 +380,7 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
     const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out, (float4*)xu, (float4*)x2u, (float4*)xpu};
     hipLaunchKernelGGL(creplay_sample_gather_kernel, dim3(1), dim3(threads), lds,
                        (hipStream_t)stream, *rb, n_pos, n_neg, n_chunks, seed, counter, counter_dev,
-                       counter_inc, out);
+                       counter_inc, table_size - 1, out);
     return check_launch();
 }
 

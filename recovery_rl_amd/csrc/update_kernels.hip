@@ -44,11 +44,14 @@ __global__ void gauss_head_fwd_kernel(int B, const float* head, const float* eps
 // backward of the head: given dL/d action[b,j] (d_action, leading dim ld) and dL/d logp[b] = dlogp
 // (a constant, alpha / B) produce dL/d head[b, 0..3]
 __global__ void gauss_head_bwd_kernel(int B, const float* head, const float* eps, const float* scale,
-                                      const float* d_action, int ld, float dlogp, float* dhead) {
+                                      const float* d_action, int ld, int n_heads, long long head_stride,
+                                      float dlogp, float* dhead) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+        float da = 0.f;   // dL/d action summed over the critic heads that consumed it
+        for (int hd = 0; hd < n_heads; ++hd) da += d_action[hd * head_stride + (long long)b * ld + j];
         const float mean = head[4 * b + j];
         const float raw = head[4 * b + 2 + j];
         const float ls = fminf(fmaxf(raw, kLogSigMin), kLogSigMax);
@@ -56,8 +59,7 @@ __global__ void gauss_head_bwd_kernel(int B, const float* head, const float* eps
         const float y = tanhf(mean + std * e);
         const float one_m = 1.f - y * y;
         // action = y scale + bias ; logp term = -log(scale (1 - y^2) + eps)
-        const float dx = d_action[(long long)b * ld + j] * scale[j] * one_m +
-                         dlogp * (2.f * scale[j] * y * one_m) / (scale[j] * one_m + kEps);
+        const float dx = da * scale[j] * one_m + dlogp * (2.f * scale[j] * y * one_m) / (scale[j] * one_m + kEps);
         const bool inside = (raw >= kLogSigMin) & (raw <= kLogSigMax);   // clamp passes gradient inside
         dhead[4 * b + j] = dx;
         dhead[4 * b + 2 + j] = inside ? (dx * std * e - dlogp) : 0.f;
@@ -183,14 +185,15 @@ __global__ void stoch_head_fwd_kernel(int B, const float* raw, const float* eps,
 // d_action [B,2] (leading dim ld) -> draw [B,2] and dlog_std[2] (sum over the batch; single workgroup)
 __global__ void stoch_head_bwd_kernel(int B, const float* raw, const float* eps, const float* log_std,
                                       float min_log_std, const float* scale, const float* d_action, int ld,
-                                      float* draw, float* dlog_std) {
+                                      int n_heads, long long head_stride, float* draw, float* dlog_std) {
     __shared__ float red[2][kBlock];
     float s0 = 0.f, s1 = 0.f;
     for (int b = threadIdx.x; b < B; b += kBlock) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float t = tanhf(raw[2 * b + j]);
-            const float da = d_action[(long long)b * ld + j];
+            float da = 0.f;
+            for (int hd = 0; hd < n_heads; ++hd) da += d_action[hd * head_stride + (long long)b * ld + j];
             draw[2 * b + j] = da * scale[j] * (1.f - t * t);
             const float std = expf(fmaxf(log_std[j], min_log_std));
             const float g = (log_std[j] >= min_log_std) ? da * std * eps[2 * b + j] : 0.f;
@@ -270,10 +273,11 @@ int rrl_gauss_head_fwd(int B, const float* head, const float* eps, const float* 
 }
 
 int rrl_gauss_head_bwd(int B, const float* head, const float* eps, const float* scale,
-                       const float* d_action, int ld, float dlogp, float* dhead, void* stream) {
-    if (!head || !eps || !scale || !d_action || !dhead || B <= 0) return RRL_EINVAL;
+                       const float* d_action, int ld, int n_heads, long long head_stride, float dlogp,
+                       float* dhead, void* stream) {
+    if (!head || !eps || !scale || !d_action || !dhead || B <= 0 || n_heads <= 0) return RRL_EINVAL;
     hipLaunchKernelGGL(gauss_head_bwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, eps,
-                       scale, d_action, ld, dlogp, dhead);
+                       scale, d_action, ld, n_heads, head_stride, dlogp, dhead);
     return check_launch();
 }
 
@@ -318,11 +322,12 @@ int rrl_stoch_head_fwd(int B, const float* raw, const float* eps, const float* l
 }
 
 int rrl_stoch_head_bwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
-                       const float* scale, const float* d_action, int ld, float* draw, float* dlog_std,
-                       void* stream) {
-    if (!raw || !eps || !log_std || !scale || !d_action || !draw || !dlog_std || B <= 0) return RRL_EINVAL;
+                       const float* scale, const float* d_action, int ld, int n_heads, long long head_stride,
+                       float* draw, float* dlog_std, void* stream) {
+    if (!raw || !eps || !log_std || !scale || !d_action || !draw || !dlog_std || B <= 0 || n_heads <= 0)
+        return RRL_EINVAL;
     hipLaunchKernelGGL(stoch_head_bwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, raw, eps, log_std,
-                       min_log_std, scale, d_action, ld, draw, dlog_std);
+                       min_log_std, scale, d_action, ld, n_heads, head_stride, draw, dlog_std);
     return check_launch();
 }
 

@@ -66,6 +66,8 @@ class VectorLoop:
         self.updates = 0
         self.num_constraint_violations = 0  # offline violations pushed during pre-training
         self.graph = None
+        self.host_updates = [0, 0]        # SAC / Q_risk update counts are known on the host
+        self._graph_updates = (0, 0)
         self._actor = None
         self._one = torch.ones((), dtype=torch.int64, device=dev)
 
@@ -81,12 +83,12 @@ class VectorLoop:
             self.agent.update_parameters(self.memory, cfg.batch_size, self.updates,
                                          safety_critic=self.agent.safety_critic,
                                          nu=self.nu_schedule(i_episode))
-            self.stats[8] += self._one
+            self.host_updates[0] += 1
             if online_qrisk:
                 self.agent.safety_critic.update_parameters(memory=self.recovery_memory,
                                                            policy=self.agent.policy,
                                                            batch_size=cfg.batch_size, plot=0)
-                self.stats[9] += self._one
+                self.host_updates[1] += 1
             self.updates += 1
 
     def act(self, obs, random_actions=False, train=True):
@@ -206,11 +208,12 @@ class VectorLoop:
                 self.vector_step(True, False, online_qrisk)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        saved = (self.total_numsteps, self.updates)
+        saved = (self.total_numsteps, self.updates, list(self.host_updates))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.vector_step(True, False, online_qrisk)
-        self.total_numsteps, self.updates = saved
+        self._graph_updates = (self.host_updates[0] - saved[2][0], self.host_updates[1] - saved[2][1])
+        self.total_numsteps, self.updates, self.host_updates = saved
         self.graph = g
         self._graph_obs = self.obs
         return g
@@ -218,6 +221,8 @@ class VectorLoop:
     def replay(self):
         self.graph.replay()
         self.total_numsteps += self.n
+        self.host_updates[0] += self._graph_updates[0]
+        self.host_updates[1] += self._graph_updates[1]
         self.updates += self.cfg.updates_per_step
         self.agent.safety_critic.updates += self.cfg.updates_per_step
         return self._graph_obs
@@ -225,6 +230,7 @@ class VectorLoop:
     def read_stats(self):
         """One device->host copy of the counter vector."""
         vals = self.stats.cpu().tolist()
+        vals[8], vals[9] = self.host_updates
         out = dict(zip(STAT_KEYS, vals))
         sums = self.reward_sums.cpu().tolist()
         out["reward_sum"], out["episode_return_sum"] = float(sums[0]), float(sums[1])

@@ -254,10 +254,10 @@ class FastUpdater:
                                             self.dq.data_ptr(), self.losses[2:].data_ptr(), st),
                     "rrl_sac_policy_grad")
         dx = self.cri_b.backward(self.dq, weight_grads=False, input_grad=True)      # [2,B,4]
-        torch.add(dx[0, :, 2:4], dx[1, :, 2:4], out=self.dact)
+        # d pi = action columns of dx, summed over the two critic heads inside the head kernel
         self._check(lib.rrl_gauss_head_bwd(B, head.data_ptr(), eps_pi.data_ptr(), self.scale.data_ptr(),
-                                           self.dact.data_ptr(), 2, float(ag.alpha) / B, self.dhead.data_ptr(),
-                                           st), "rrl_gauss_head_bwd")
+                                           dx[0, :, 2:4].data_ptr(), dx.stride(1), 2, dx.stride(0),
+                                           float(ag.alpha) / B, self.dhead.data_ptr(), st), "rrl_gauss_head_bwd")
         self.pol_b.backward(self.dhead)
         self.critic.adam(ag.lr, target=self.critic_target, tau=ag.tau)        # + soft update (:273-274)
         self.policy.adam(ag.lr)
@@ -286,10 +286,10 @@ class FastUpdater:
             self._check(lib.rrl_qrisk_policy_grad(B, zp.data_ptr(), self.dq.data_ptr(), self.losses[6:].data_ptr(),
                                                   st), "rrl_qrisk_policy_grad")
             dx = self.qr_b.backward(self.dq, weight_grads=False, input_grad=True)
-            torch.add(dx[0, :, 2:4], dx[1, :, 2:4], out=self.dact)
             self._check(lib.rrl_stoch_head_bwd(B, raw.data_ptr(), eps_pi.data_ptr(), ls.data_ptr(),
-                                               qr.policy.min_log_std, self.rscale.data_ptr(), self.dact.data_ptr(),
-                                               2, self.draw.data_ptr(), self.recpolicy.g["log_std"].data_ptr(), st),
+                                               qr.policy.min_log_std, self.rscale.data_ptr(),
+                                               dx[0, :, 2:4].data_ptr(), dx.stride(1), 2, dx.stride(0),
+                                               self.draw.data_ptr(), self.recpolicy.g["log_std"].data_ptr(), st),
                         "rrl_stoch_head_bwd")
             self.rec_a.backward(self.draw)
             self.recpolicy.adam(qr.lr)
