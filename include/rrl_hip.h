@@ -221,10 +221,13 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
  * activations when non-null (needed by the backward pass).  H % 16 == 0, H <= 256, din, dout <= 4.
  * scratch (nullable, f32 [4*G*M*dout]): when given and M <= 1024, H % 64 == 0 the hidden-2 columns are
  * split over 4 workgroups per row tile (small batches are bound by streaming W2 through one CU) and their
- * partial last-layer sums are added in a fixed order by a second tiny kernel. */
+ * partial last-layer sums [4,G,M,dout] are either added in a fixed order by a second tiny kernel
+ * (finalize != 0 -> out) or left in scratch for a consumer that sums them itself (finalize == 0). */
 int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int ldx, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
-                     float* h1, float* h2, float* out, float* scratch, void* stream);
+                     float* h1, float* h2, float* out, float* scratch, int finalize, void* stream);
+/* 1 if rrl_mlp3_forward(M, H, scratch != NULL) takes the split path (so finalize == 0 leaves partials) */
+int rrl_mlp3_is_split(int M, int H);
 
 /* Thin ends of the stack backward (one side 1..4 wide, so no MFMA tile):
  *   rrl_mlp_head_backward : dW3 = dOut^T h2, db3 = sum_b dOut, dh2 = [h2 > 0] (dOut W3)   (dW3/db3 nullable)
@@ -252,26 +255,31 @@ int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const
  *                            {t, ticket}, t is incremented by the kernel
  *   rrl_recovery_select      recovery gate max sigmoid(z) > eps_safe and action select
  *                            (recovery_rl/experiment.py:546-577)
+ * Operands that are stack outputs (head, q, qt, qp, z, zt, zp, raw) take (n_part, part_stride): the value of
+ * element i is p[i] + p[part_stride + i] + ... (n_part terms, fixed order) -- the partial last-layer sums of
+ * rrl_mlp3_forward(scratch, finalize = 0); n_part = 1 for a plain tensor.
  * ------------------------------------------------------------------------------------------ */
-int rrl_gauss_head_fwd(int B, const float* head, const float* eps, const float* scale, const float* bias,
-                       float* action, int ld_action, float* logp, float* mean_action, void* stream);
-int rrl_gauss_head_bwd(int B, const float* head, const float* eps, const float* scale,
-                       const float* d_action, int ld, int n_heads, long long head_stride, float dlogp,
-                       float* dhead, void* stream);
-int rrl_sac_critic_grad(int B, const float* q, const float* qt, const float* logp2, const float* r,
-                        const float* m, float gamma, const float* alpha, const float* penalty, float* dq,
-                        float* loss, void* stream);
-int rrl_sac_policy_grad(int B, const float* qp, const float* logp, const float* alpha, float* dqp,
-                        float* loss, void* stream);
-int rrl_qrisk_critic_grad(int B, const float* z, const float* zt, const float* c, const float* m,
-                          float gamma_safe, float* dz, float* loss, void* stream);
-int rrl_qrisk_policy_grad(int B, const float* zp, float* dzp, float* loss, void* stream);
-int rrl_stoch_head_fwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
-                       const float* scale, const float* bias, float* action, int ld_action, float* mean_out,
-                       void* stream);
-int rrl_stoch_head_bwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
+int rrl_gauss_head_fwd(int B, const float* head, int n_part, long long part_stride, const float* eps,
+                       const float* scale, const float* bias, float* action, int ld_action, float* logp,
+                       float* mean_action, void* stream);
+int rrl_gauss_head_bwd(int B, const float* head, int n_part, long long part_stride, const float* eps,
                        const float* scale, const float* d_action, int ld, int n_heads, long long head_stride,
-                       float* draw, float* dlog_std, void* stream);
+                       float dlogp, float* dhead, void* stream);
+int rrl_sac_critic_grad(int B, const float* q, const float* qt, int n_part, long long part_stride,
+                        const float* logp2, const float* r, const float* m, float gamma, const float* alpha,
+                        const float* penalty, float* dq, float* loss, void* stream);
+int rrl_sac_policy_grad(int B, const float* qp, int n_part, long long part_stride, const float* logp,
+                        const float* alpha, float* dqp, float* loss, void* stream);
+int rrl_qrisk_critic_grad(int B, const float* z, const float* zt, int n_part, long long part_stride,
+                          const float* c, const float* m, float gamma_safe, float* dz, float* loss, void* stream);
+int rrl_qrisk_policy_grad(int B, const float* zp, int n_part, long long part_stride, float* dzp, float* loss,
+                          void* stream);
+int rrl_stoch_head_fwd(int B, const float* raw, int n_part, long long part_stride, const float* eps,
+                       const float* log_std, float min_log_std, const float* scale, const float* bias,
+                       float* action, int ld_action, float* mean_out, void* stream);
+int rrl_stoch_head_bwd(int B, const float* raw, int n_part, long long part_stride, const float* eps,
+                       const float* log_std, float min_log_std, const float* scale, const float* d_action, int ld,
+                       int n_heads, long long head_stride, float* draw, float* dlog_std, void* stream);
 int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uint64_t* step_dev, float lr,
                   float beta1, float beta2, float eps, float* target, float tau, void* stream);
 int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task_action, int ld_task,

@@ -26,7 +26,7 @@ EXPORTS = [
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_nav_step_push",
     "rrl_cem_sample", "rrl_cem_update",
-    "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp_head_backward", "rrl_mlp_input_backward",
+    "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_input_backward",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_recovery_select",
@@ -72,8 +72,8 @@ _lib = None
 
 
 def _declare(lib):
-    vp, i32, i64, u64, ci, f64, f32 = (C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int, C.c_double,
-                                      C.c_float)
+    vp, i32, i64, u64, ci, f64, f32, ll = (C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int, C.c_double,
+                                          C.c_float, C.c_longlong)
     rp = C.POINTER(rrl_replay_t)
     sig = {
         "rrl_abi_version": (ci, []),
@@ -99,17 +99,18 @@ def _declare(lib):
         "rrl_gemm_f32": (ci, [ci, ci, ci, ci, ci, vp, ci, C.c_longlong, vp, ci, C.c_longlong, vp, ci,
                               C.c_longlong, vp, C.c_longlong, ci, vp, ci, C.c_longlong, vp, C.c_longlong,
                               ci, vp]),
-        "rrl_mlp3_forward": (ci, [ci, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_mlp3_forward": (ci, [ci, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
+        "rrl_mlp3_is_split": (ci, [ci, ci]),
         "rrl_mlp_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_mlp_input_backward": (ci, [ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
-        "rrl_gauss_head_fwd": (ci, [ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]),
-        "rrl_gauss_head_bwd": (ci, [ci, vp, vp, vp, vp, ci, ci, C.c_longlong, f32, vp, vp]),
-        "rrl_sac_critic_grad": (ci, [ci, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
-        "rrl_sac_policy_grad": (ci, [ci, vp, vp, vp, vp, vp, vp]),
-        "rrl_qrisk_critic_grad": (ci, [ci, vp, vp, vp, vp, f32, vp, vp, vp]),
-        "rrl_qrisk_policy_grad": (ci, [ci, vp, vp, vp, vp]),
-        "rrl_stoch_head_fwd": (ci, [ci, vp, vp, vp, f32, vp, vp, vp, ci, vp, vp]),
-        "rrl_stoch_head_bwd": (ci, [ci, vp, vp, vp, f32, vp, vp, ci, ci, C.c_longlong, vp, vp, vp]),
+        "rrl_gauss_head_fwd": (ci, [ci, vp, ci, ll, vp, vp, vp, vp, ci, vp, vp, vp]),
+        "rrl_gauss_head_bwd": (ci, [ci, vp, ci, ll, vp, vp, vp, ci, ci, ll, f32, vp, vp]),
+        "rrl_sac_critic_grad": (ci, [ci, vp, vp, ci, ll, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
+        "rrl_sac_policy_grad": (ci, [ci, vp, ci, ll, vp, vp, vp, vp, vp]),
+        "rrl_qrisk_critic_grad": (ci, [ci, vp, vp, ci, ll, vp, vp, f32, vp, vp, vp]),
+        "rrl_qrisk_policy_grad": (ci, [ci, vp, ci, ll, vp, vp, vp]),
+        "rrl_stoch_head_fwd": (ci, [ci, vp, ci, ll, vp, vp, f32, vp, vp, vp, ci, vp, vp]),
+        "rrl_stoch_head_bwd": (ci, [ci, vp, ci, ll, vp, vp, f32, vp, vp, ci, ci, ll, vp, vp, vp]),
         "rrl_adam_step": (ci, [C.c_longlong, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, f32, vp]),
         "rrl_recovery_select": (ci, [ci, vp, f32, vp, ci, vp, vp, vp, vp, vp]),
     }

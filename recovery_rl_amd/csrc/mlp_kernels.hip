@@ -588,20 +588,24 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
     return check_launch();
 }
 
+int rrl_mlp3_is_split(int M, int H) { return M <= 1024 && (H % (16 * kSplit)) == 0 && H <= kStackMaxH; }
+
 int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int ldx, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
-                     float* h1, float* h2, float* out, float* scratch, void* stream) {
+                     float* h1, float* h2, float* out, float* scratch, int finalize, void* stream) {
     if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return RRL_EINVAL;
     if (G <= 0 || G > 65535 || M <= 0 || din <= 0 || din > 4 || dout <= 0 || dout > 4) return RRL_ERANGE;
     if (H <= 0 || H > kStackMaxH || (H % 16) != 0) return RRL_ERANGE;
     StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx};
-    if (scratch && M <= 1024 && (H % (16 * kSplit)) == 0) {
+    if (scratch && rrl_mlp3_is_split(M, H)) {
         // small batch: 4 workgroups per row tile + fixed-order sum of their partial last-layer outputs
         hipLaunchKernelGGL(mlp3_fwd_split_kernel, dim3((M + kStackRows - 1) / kStackRows, G, kSplit), dim3(256), 0,
                            (hipStream_t)stream, a, scratch);
-        const int n = G * M * dout;
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, scratch,
-                           out);
+        if (finalize) {
+            const int n = G * M * dout;
+            hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n,
+                               scratch, out);
+        }
         return check_launch();
     }
     hipLaunchKernelGGL(mlp3_fwd_kernel, dim3((M + kStackRows - 1) / kStackRows, G), dim3(1024), 0,

@@ -139,7 +139,7 @@ struct BatchOut {
 // Implementation: per round an LDS hash table maps value -> lowest claiming tag (accepted lanes claim
 // with tag 0, pending lane i with tag i + 1) through 64-bit atomicMin on (value << 32 | tag); the table
 // content that matters (minimum tag per value) does not depend on insertion order, so the outcome is the
-// same as the sequential all-pairs rule of the oracle.  O(B) work per round instead of O(B^2).
+// same as the sequential all-pairs rule of the CPU checker.  O(B) work per round instead of O(B^2).
 // `group` (0/1) keeps the two populations of the stratified sampler apart.  key[i] = value | accepted << 31.
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;

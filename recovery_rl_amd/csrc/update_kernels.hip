@@ -20,18 +20,26 @@ constexpr float kHalfLog2Pi = 0.918938533204672742f;
 
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
 
+// A stack output may arrive as `np` partial sums (rrl_mlp3_forward with scratch and no final sum): element
+// idx = p[idx] + p[ps + idx] + ... in that fixed order (the order of the stand-alone sum kernel).
+__device__ __forceinline__ float psum(const float* p, long long idx, int np, long long ps) {
+    float v = p[idx];
+    for (int z = 1; z < np; ++z) v += p[z * ps + idx];
+    return v;
+}
+
 // ---- tanh-Gaussian head (GaussianPolicy.sample, model.py:324-340) -------------------------------
 // head[b] = (mean0, mean1, log_std0, log_std1) raw outputs of the last linear layer
-__global__ void gauss_head_fwd_kernel(int B, const float* head, const float* eps, const float* scale,
-                                      const float* bias, float* action, int ld_action, float* logp,
-                                      float* mean_action) {
+__global__ void gauss_head_fwd_kernel(int B, const float* head, int np, long long ps, const float* eps,
+                                      const float* scale, const float* bias, float* action, int ld_action,
+                                      float* logp, float* mean_action) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float lp = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const float mean = head[4 * b + j];
-        const float ls = fminf(fmaxf(head[4 * b + 2 + j], kLogSigMin), kLogSigMax);
+        const float mean = psum(head, 4 * b + j, np, ps);
+        const float ls = fminf(fmaxf(psum(head, 4 * b + 2 + j, np, ps), kLogSigMin), kLogSigMax);
         const float e = eps[2 * b + j];
         const float y = tanhf(mean + expf(ls) * e);
         action[(long long)b * ld_action + j] = y * scale[j] + bias[j];
@@ -43,8 +51,8 @@ __global__ void gauss_head_fwd_kernel(int B, const float* head, const float* eps
 
 // backward of the head: given dL/d action[b,j] (d_action, leading dim ld) and dL/d logp[b] = dlogp
 // (a constant, alpha / B) produce dL/d head[b, 0..3]
-__global__ void gauss_head_bwd_kernel(int B, const float* head, const float* eps, const float* scale,
-                                      const float* d_action, int ld, int n_heads, long long head_stride,
+__global__ void gauss_head_bwd_kernel(int B, const float* head, int np, long long ps, const float* eps,
+                                      const float* scale, const float* d_action, int ld, int n_heads, long long head_stride,
                                       float dlogp, float* dhead) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -52,8 +60,8 @@ __global__ void gauss_head_bwd_kernel(int B, const float* head, const float* eps
     for (int j = 0; j < 2; ++j) {
         float da = 0.f;   // dL/d action summed over the critic heads that consumed it
         for (int hd = 0; hd < n_heads; ++hd) da += d_action[hd * head_stride + (long long)b * ld + j];
-        const float mean = head[4 * b + j];
-        const float raw = head[4 * b + 2 + j];
+        const float mean = psum(head, 4 * b + j, np, ps);
+        const float raw = psum(head, 4 * b + 2 + j, np, ps);
         const float ls = fminf(fmaxf(raw, kLogSigMin), kLogSigMax);
         const float std = expf(ls), e = eps[2 * b + j];
         const float y = tanhf(mean + std * e);
@@ -68,15 +76,16 @@ __global__ void gauss_head_bwd_kernel(int B, const float* head, const float* eps
 
 // ---- SAC critic target + loss gradient (sac.py:192-214) -----------------------------------------
 // q, qt: [2, B] (online on (s,a); target on (s', a')); dq = d(mse1 + mse2)/dq ; loss[0..1] = mse
-__global__ void sac_critic_grad_kernel(int B, const float* q, const float* qt, const float* logp2,
+__global__ void sac_critic_grad_kernel(int B, const float* q, const float* qt, int np, long long ps,
+                                       const float* logp2,
                                        const float* r, const float* m, float gamma, const float* alpha,
                                        const float* penalty, float* dq, float* loss) {
     __shared__ float red[2][kBlock];
     float l0 = 0.f, l1 = 0.f;
     for (int b = threadIdx.x; b < B; b += kBlock) {
-        float y = r[b] + m[b] * gamma * (fminf(qt[b], qt[B + b]) - alpha[0] * logp2[b]);
+        float y = r[b] + m[b] * gamma * (fminf(psum(qt, b, np, ps), psum(qt, B + b, np, ps)) - alpha[0] * logp2[b]);
         if (penalty) y -= penalty[b];                 // RCPO: lambda * Q_risk (sac.py:202-205)
-        const float e0 = q[b] - y, e1 = q[B + b] - y;
+        const float e0 = psum(q, b, np, ps) - y, e1 = psum(q, B + b, np, ps) - y;
         dq[b] = 2.f * e0 / B;
         dq[B + b] = 2.f * e1 / B;
         l0 += e0 * e0;
@@ -97,12 +106,12 @@ __global__ void sac_critic_grad_kernel(int B, const float* q, const float* qt, c
 
 // ---- SAC policy loss gradient (sac.py:216-231) ---------------------------------------------------
 // loss = mean(alpha logp - min(q1,q2)); dqp[i][b] = -1/B on the smaller head (ties split)
-__global__ void sac_policy_grad_kernel(int B, const float* qp, const float* logp, const float* alpha,
-                                       float* dqp, float* loss) {
+__global__ void sac_policy_grad_kernel(int B, const float* qp, int np, long long ps, const float* logp,
+                                       const float* alpha, float* dqp, float* loss) {
     __shared__ float red[kBlock];
     float l = 0.f;
     for (int b = threadIdx.x; b < B; b += kBlock) {
-        const float a = qp[b], c = qp[B + b];
+        const float a = psum(qp, b, np, ps), c = psum(qp, B + b, np, ps);
         const float w0 = a < c ? 1.f : (a == c ? 0.5f : 0.f);
         dqp[b] = -w0 / B;
         dqp[B + b] = -(1.f - w0) / B;
@@ -119,13 +128,15 @@ __global__ void sac_policy_grad_kernel(int B, const float* qp, const float* logp
 
 // ---- Q_risk critic target + loss gradient (qrisk.py:118-148) ------------------------------------
 // z, zt: [2,B] PRE-sigmoid outputs; q = sigmoid(z); y = c + m gamma_safe max(sigmoid(zt))
-__global__ void qrisk_critic_grad_kernel(int B, const float* z, const float* zt, const float* c,
+__global__ void qrisk_critic_grad_kernel(int B, const float* z, const float* zt, int np, long long ps,
+                                         const float* c,
                                          const float* m, float gamma_safe, float* dz, float* loss) {
     __shared__ float red[2][kBlock];
     float l0 = 0.f, l1 = 0.f;
     for (int b = threadIdx.x; b < B; b += kBlock) {
-        const float y = c[b] + m[b] * gamma_safe * fmaxf(sigmoidf(zt[b]), sigmoidf(zt[B + b]));
-        const float q0 = sigmoidf(z[b]), q1 = sigmoidf(z[B + b]);
+        const float y = c[b] + m[b] * gamma_safe *
+                                   fmaxf(sigmoidf(psum(zt, b, np, ps)), sigmoidf(psum(zt, B + b, np, ps)));
+        const float q0 = sigmoidf(psum(z, b, np, ps)), q1 = sigmoidf(psum(z, B + b, np, ps));
         const float e0 = q0 - y, e1 = q1 - y;
         dz[b] = 2.f * e0 / B * q0 * (1.f - q0);
         dz[B + b] = 2.f * e1 / B * q1 * (1.f - q1);
@@ -146,11 +157,11 @@ __global__ void qrisk_critic_grad_kernel(int B, const float* z, const float* zt,
 }
 
 // loss = mean(max(sigmoid(z1), sigmoid(z2))) (qrisk.py:150-154): dz on the larger head
-__global__ void qrisk_policy_grad_kernel(int B, const float* zp, float* dzp, float* loss) {
+__global__ void qrisk_policy_grad_kernel(int B, const float* zp, int np, long long ps, float* dzp, float* loss) {
     __shared__ float red[kBlock];
     float l = 0.f;
     for (int b = threadIdx.x; b < B; b += kBlock) {
-        const float q0 = sigmoidf(zp[b]), q1 = sigmoidf(zp[B + b]);
+        const float q0 = sigmoidf(psum(zp, b, np, ps)), q1 = sigmoidf(psum(zp, B + b, np, ps));
         const float w0 = q0 > q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
         dzp[b] = w0 / B * q0 * (1.f - q0);
         dzp[B + b] = (1.f - w0) / B * q1 * (1.f - q1);
@@ -167,14 +178,15 @@ __global__ void qrisk_policy_grad_kernel(int B, const float* zp, float* dzp, flo
 
 // ---- model-free recovery policy head (StochasticPolicy, model.py:511-525) ------------------------
 // raw[b] = last linear output (2); mean = tanh(raw) scale + bias; action = mean + exp(max(log_std, min)) eps
-__global__ void stoch_head_fwd_kernel(int B, const float* raw, const float* eps, const float* log_std,
+__global__ void stoch_head_fwd_kernel(int B, const float* raw, int np, long long ps, const float* eps,
+                                      const float* log_std,
                                       float min_log_std, const float* scale, const float* bias,
                                       float* action, int ld_action, float* mean_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const float mean = tanhf(raw[2 * b + j]) * scale[j] + bias[j];
+        const float mean = tanhf(psum(raw, 2 * b + j, np, ps)) * scale[j] + bias[j];
         const float std = expf(fmaxf(log_std[j], min_log_std));
         const float e = eps ? eps[2 * b + j] : 0.f;
         action[(long long)b * ld_action + j] = mean + std * e;
@@ -183,7 +195,8 @@ __global__ void stoch_head_fwd_kernel(int B, const float* raw, const float* eps,
 }
 
 // d_action [B,2] (leading dim ld) -> draw [B,2] and dlog_std[2] (sum over the batch; single workgroup)
-__global__ void stoch_head_bwd_kernel(int B, const float* raw, const float* eps, const float* log_std,
+__global__ void stoch_head_bwd_kernel(int B, const float* raw, int np, long long ps, const float* eps,
+                                      const float* log_std,
                                       float min_log_std, const float* scale, const float* d_action, int ld,
                                       int n_heads, long long head_stride, float* draw, float* dlog_std) {
     __shared__ float red[2][kBlock];
@@ -191,7 +204,7 @@ __global__ void stoch_head_bwd_kernel(int B, const float* raw, const float* eps,
     for (int b = threadIdx.x; b < B; b += kBlock) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float t = tanhf(raw[2 * b + j]);
+            const float t = tanhf(psum(raw, 2 * b + j, np, ps));
             float da = 0.f;
             for (int hd = 0; hd < n_heads; ++hd) da += d_action[hd * head_stride + (long long)b * ld + j];
             draw[2 * b + j] = da * scale[j] * (1.f - t * t);
@@ -264,70 +277,75 @@ inline dim3 rows_grid(int B) { return dim3((B + kBlock - 1) / kBlock); }
 
 extern "C" {
 
-int rrl_gauss_head_fwd(int B, const float* head, const float* eps, const float* scale, const float* bias,
-                       float* action, int ld_action, float* logp, float* mean_action, void* stream) {
-    if (!head || !eps || !scale || !bias || !action || B <= 0) return RRL_EINVAL;
-    hipLaunchKernelGGL(gauss_head_fwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, eps,
-                       scale, bias, action, ld_action, logp, mean_action);
+int rrl_gauss_head_fwd(int B, const float* head, int n_part, long long part_stride, const float* eps,
+                       const float* scale, const float* bias, float* action, int ld_action, float* logp,
+                       float* mean_action, void* stream) {
+    if (!head || !eps || !scale || !bias || !action || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(gauss_head_fwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, n_part,
+                       part_stride, eps, scale, bias, action, ld_action, logp, mean_action);
     return check_launch();
 }
 
-int rrl_gauss_head_bwd(int B, const float* head, const float* eps, const float* scale,
-                       const float* d_action, int ld, int n_heads, long long head_stride, float dlogp,
-                       float* dhead, void* stream) {
-    if (!head || !eps || !scale || !d_action || !dhead || B <= 0 || n_heads <= 0) return RRL_EINVAL;
-    hipLaunchKernelGGL(gauss_head_bwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, eps,
-                       scale, d_action, ld, n_heads, head_stride, dlogp, dhead);
-    return check_launch();
-}
-
-int rrl_sac_critic_grad(int B, const float* q, const float* qt, const float* logp2, const float* r,
-                        const float* m, float gamma, const float* alpha, const float* penalty, float* dq,
-                        float* loss, void* stream) {
-    if (!q || !qt || !logp2 || !r || !m || !alpha || !dq || B <= 0) return RRL_EINVAL;
-    hipLaunchKernelGGL(sac_critic_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, q, qt, logp2, r,
-                       m, gamma, alpha, penalty, dq, loss);
-    return check_launch();
-}
-
-int rrl_sac_policy_grad(int B, const float* qp, const float* logp, const float* alpha, float* dqp,
-                        float* loss, void* stream) {
-    if (!qp || !logp || !alpha || !dqp || B <= 0) return RRL_EINVAL;
-    hipLaunchKernelGGL(sac_policy_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, qp, logp, alpha,
-                       dqp, loss);
-    return check_launch();
-}
-
-int rrl_qrisk_critic_grad(int B, const float* z, const float* zt, const float* c, const float* m,
-                          float gamma_safe, float* dz, float* loss, void* stream) {
-    if (!z || !zt || !c || !m || !dz || B <= 0) return RRL_EINVAL;
-    hipLaunchKernelGGL(qrisk_critic_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, z, zt, c, m,
-                       gamma_safe, dz, loss);
-    return check_launch();
-}
-
-int rrl_qrisk_policy_grad(int B, const float* zp, float* dzp, float* loss, void* stream) {
-    if (!zp || !dzp || B <= 0) return RRL_EINVAL;
-    hipLaunchKernelGGL(qrisk_policy_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, zp, dzp, loss);
-    return check_launch();
-}
-
-int rrl_stoch_head_fwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
-                       const float* scale, const float* bias, float* action, int ld_action, float* mean_out,
-                       void* stream) {
-    if (!raw || !log_std || !scale || !bias || !action || B <= 0) return RRL_EINVAL;
-    hipLaunchKernelGGL(stoch_head_fwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, raw, eps,
-                       log_std, min_log_std, scale, bias, action, ld_action, mean_out);
-    return check_launch();
-}
-
-int rrl_stoch_head_bwd(int B, const float* raw, const float* eps, const float* log_std, float min_log_std,
+int rrl_gauss_head_bwd(int B, const float* head, int n_part, long long part_stride, const float* eps,
                        const float* scale, const float* d_action, int ld, int n_heads, long long head_stride,
-                       float* draw, float* dlog_std, void* stream) {
-    if (!raw || !eps || !log_std || !scale || !d_action || !draw || !dlog_std || B <= 0 || n_heads <= 0)
+                       float dlogp, float* dhead, void* stream) {
+    if (!head || !eps || !scale || !d_action || !dhead || B <= 0 || n_heads <= 0 || n_part <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(gauss_head_bwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, n_part,
+                       part_stride, eps, scale, d_action, ld, n_heads, head_stride, dlogp, dhead);
+    return check_launch();
+}
+
+int rrl_sac_critic_grad(int B, const float* q, const float* qt, int n_part, long long part_stride,
+                        const float* logp2, const float* r, const float* m, float gamma, const float* alpha,
+                        const float* penalty, float* dq, float* loss, void* stream) {
+    if (!q || !qt || !logp2 || !r || !m || !alpha || !dq || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(sac_critic_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, q, qt, n_part,
+                       part_stride, logp2, r, m, gamma, alpha, penalty, dq, loss);
+    return check_launch();
+}
+
+int rrl_sac_policy_grad(int B, const float* qp, int n_part, long long part_stride, const float* logp,
+                        const float* alpha, float* dqp, float* loss, void* stream) {
+    if (!qp || !logp || !alpha || !dqp || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(sac_policy_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, qp, n_part,
+                       part_stride, logp, alpha, dqp, loss);
+    return check_launch();
+}
+
+int rrl_qrisk_critic_grad(int B, const float* z, const float* zt, int n_part, long long part_stride,
+                          const float* c, const float* m, float gamma_safe, float* dz, float* loss, void* stream) {
+    if (!z || !zt || !c || !m || !dz || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(qrisk_critic_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, z, zt, n_part,
+                       part_stride, c, m, gamma_safe, dz, loss);
+    return check_launch();
+}
+
+int rrl_qrisk_policy_grad(int B, const float* zp, int n_part, long long part_stride, float* dzp, float* loss,
+                          void* stream) {
+    if (!zp || !dzp || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(qrisk_policy_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, zp, n_part,
+                       part_stride, dzp, loss);
+    return check_launch();
+}
+
+int rrl_stoch_head_fwd(int B, const float* raw, int n_part, long long part_stride, const float* eps,
+                       const float* log_std, float min_log_std, const float* scale, const float* bias,
+                       float* action, int ld_action, float* mean_out, void* stream) {
+    if (!raw || !log_std || !scale || !bias || !action || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    hipLaunchKernelGGL(stoch_head_fwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, raw, n_part,
+                       part_stride, eps, log_std, min_log_std, scale, bias, action, ld_action, mean_out);
+    return check_launch();
+}
+
+int rrl_stoch_head_bwd(int B, const float* raw, int n_part, long long part_stride, const float* eps,
+                       const float* log_std, float min_log_std, const float* scale, const float* d_action, int ld,
+                       int n_heads, long long head_stride, float* draw, float* dlog_std, void* stream) {
+    if (!raw || !eps || !log_std || !scale || !d_action || !draw || !dlog_std || B <= 0 || n_heads <= 0 ||
+        n_part <= 0)
         return RRL_EINVAL;
-    hipLaunchKernelGGL(stoch_head_bwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, raw, eps, log_std,
-                       min_log_std, scale, d_action, ld, n_heads, head_stride, draw, dlog_std);
+    hipLaunchKernelGGL(stoch_head_bwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, raw, n_part,
+                       part_stride, eps, log_std, min_log_std, scale, d_action, ld, n_heads, head_stride, draw,
+                       dlog_std);
     return check_launch();
 }
 

@@ -125,6 +125,8 @@ class Stack:
         self.h1, self.h2, self.out = z(G, B, H), z(G, B, H), z(G, B, net.dout)
         self.dh1, self.dh2, self.dx = z(G, B, H), z(G, B, H), z(G, B, net.din)
         self.scratch = z(4, G, B, net.dout)         # partial last-layer sums of the small-batch forward
+        self.split = bool(_lib.load().rrl_mlp3_is_split(B, H)) and mlp3_supported(H, net.din, net.dout)
+        self.finalize = False                       # True: always hand back the summed output tensor
 
     def forward(self, x, params=None, save=True):
         """x [B, din] shared by all heads.  `params` lets a target network reuse this workspace;
@@ -132,14 +134,19 @@ class Stack:
         P = (params or self.net).p
         G = self.net.G
         self.x = x
+        self.parts = (self.out, 1, 0)       # (tensor, n_part, part_stride): how consumers read the output
         if mlp3_supported(self.net.H, self.net.din, self.net.dout):     # one launch for the whole stack
-            return mlp3_forward(x, P["W1"], P["b1"], P["W2"], P["b2"], P["W3"], P["b3"], out=self.out,
-                                h1=self.h1 if save else None, h2=self.h2 if save else None, scratch=self.scratch)
+            mlp3_forward(x, P["W1"], P["b1"], P["W2"], P["b2"], P["W3"], P["b3"], out=self.out,
+                         h1=self.h1 if save else None, h2=self.h2 if save else None, scratch=self.scratch,
+                         finalize=self.finalize)
+            if self.split and not self.finalize:   # partial last-layer sums: the consumer kernels add them up
+                self.parts = (self.scratch, 4, self.scratch.stride(0))
+            return self.parts
         xg = x.unsqueeze(0).expand(G, -1, -1)
         gemm(NT, xg, P["W1"], out=self.h1, bias=P["b1"], relu=True)
         gemm(NT, self.h1, P["W2"], out=self.h2, bias=P["b2"], relu=True)
         gemm(NT, self.h2, P["W3"], out=self.out, bias=P["b3"])
-        return self.out
+        return self.parts
 
     def backward(self, dout, weight_grads=True, input_grad=False):
         """dout [G, B, dout].  Writes parameter gradients into net.g (weight_grads) and/or returns
@@ -227,11 +234,11 @@ class FastUpdater:
         return (n[0], n[1]) if which == 0 else (n[2], n[3])
 
     def _gauss_fwd(self, head, eps, action_view, logp):
-        st = _lib.current_stream()
-        self._check(self.lib.rrl_gauss_head_fwd(self.B, head.data_ptr(), eps.data_ptr(), self.scale.data_ptr(),
-                                                self.bias.data_ptr(), action_view.data_ptr(),
-                                                action_view.stride(0), logp.data_ptr(), None, st),
-                    "rrl_gauss_head_fwd")
+        t, n_part, ps = head
+        self._check(self.lib.rrl_gauss_head_fwd(self.B, t.data_ptr(), n_part, ps, eps.data_ptr(),
+                                                self.scale.data_ptr(), self.bias.data_ptr(),
+                                                action_view.data_ptr(), action_view.stride(0), logp.data_ptr(),
+                                                None, _lib.current_stream()), "rrl_gauss_head_fwd")
 
     # -- SAC -------------------------------------------------------------------------------------
     def sac_update(self, batch, eps_next, eps_pi, rows_loaded=False):
@@ -240,22 +247,23 @@ class FastUpdater:
         # target: a' ~ pi(s'), min Q_target(s', a') - alpha log pi  (sac.py:192-201)
         head2 = self.pol_a.forward(s2, save=False)
         self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
-        qt = self.cri_b.forward(self.x2u, params=self.critic_target, save=False)
-        q = self.cri_a.forward(self.xu)
-        self._check(lib.rrl_sac_critic_grad(B, q.data_ptr(), qt.data_ptr(), self.logp2.data_ptr(), r.data_ptr(),
-                                            m.data_ptr(), ag.gamma, self.alpha.data_ptr(), None,
+        qt, n_part, ps = self.cri_b.forward(self.x2u, params=self.critic_target, save=False)
+        q, _, _ = self.cri_a.forward(self.xu)
+        self._check(lib.rrl_sac_critic_grad(B, q.data_ptr(), qt.data_ptr(), n_part, ps, self.logp2.data_ptr(),
+                                            r.data_ptr(), m.data_ptr(), ag.gamma, self.alpha.data_ptr(), None,
                                             self.dq.data_ptr(), self.losses.data_ptr(), st), "rrl_sac_critic_grad")
         self.cri_a.backward(self.dq)                                   # critic gradients (sac.py:233-235)
         # policy loss at the PRE-update critic (both gradients before either step)
         head = self.pol_b.forward(s)
         self._gauss_fwd(head, eps_pi, self.xpu[:, 2:4], self.logp)
-        qp = self.cri_b.forward(self.xpu)
-        self._check(lib.rrl_sac_policy_grad(B, qp.data_ptr(), self.logp.data_ptr(), self.alpha.data_ptr(),
-                                            self.dq.data_ptr(), self.losses[2:].data_ptr(), st),
-                    "rrl_sac_policy_grad")
+        qp, n_part, ps = self.cri_b.forward(self.xpu)
+        self._check(lib.rrl_sac_policy_grad(B, qp.data_ptr(), n_part, ps, self.logp.data_ptr(),
+                                            self.alpha.data_ptr(), self.dq.data_ptr(), self.losses[2:].data_ptr(),
+                                            st), "rrl_sac_policy_grad")
         dx = self.cri_b.backward(self.dq, weight_grads=False, input_grad=True)      # [2,B,4]
         # d pi = action columns of dx, summed over the two critic heads inside the head kernel
-        self._check(lib.rrl_gauss_head_bwd(B, head.data_ptr(), eps_pi.data_ptr(), self.scale.data_ptr(),
+        ht, hn, hs = head
+        self._check(lib.rrl_gauss_head_bwd(B, ht.data_ptr(), hn, hs, eps_pi.data_ptr(), self.scale.data_ptr(),
                                            dx[0, :, 2:4].data_ptr(), dx.stride(1), 2, dx.stride(0),
                                            float(ag.alpha) / B, self.dhead.data_ptr(), st), "rrl_gauss_head_bwd")
         self.pol_b.backward(self.dhead)
@@ -269,24 +277,24 @@ class FastUpdater:
         s, a, c, s2, m = self._load_batch(batch, rows_loaded)
         head2 = self.pol_a.forward(s2, save=False)                     # a' from the TASK policy (qrisk.py:119-120)
         self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
-        zt = self.qr_b.forward(self.x2u, params=self.qrisk_target, save=False)
-        z = self.qr_a.forward(self.xu)
-        self._check(lib.rrl_qrisk_critic_grad(B, z.data_ptr(), zt.data_ptr(), c.data_ptr(), m.data_ptr(),
-                                              qr.gamma_safe, self.dq.data_ptr(), self.losses[4:].data_ptr(), st),
-                    "rrl_qrisk_critic_grad")
+        zt, n_part, ps = self.qr_b.forward(self.x2u, params=self.qrisk_target, save=False)
+        z, _, _ = self.qr_a.forward(self.xu)
+        self._check(lib.rrl_qrisk_critic_grad(B, z.data_ptr(), zt.data_ptr(), n_part, ps, c.data_ptr(),
+                                              m.data_ptr(), qr.gamma_safe, self.dq.data_ptr(),
+                                              self.losses[4:].data_ptr(), st), "rrl_qrisk_critic_grad")
         self.qr_a.backward(self.dq)
         self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau)
         if qr.MF_recovery:                                              # qrisk.py:150-158, at the UPDATED critic
-            raw = self.rec_a.forward(s)
+            raw, rn, rs = self.rec_a.forward(s)
             ls = self.recpolicy.p["log_std"]
-            self._check(lib.rrl_stoch_head_fwd(B, raw.data_ptr(), eps_pi.data_ptr(), ls.data_ptr(),
+            self._check(lib.rrl_stoch_head_fwd(B, raw.data_ptr(), rn, rs, eps_pi.data_ptr(), ls.data_ptr(),
                                                qr.policy.min_log_std, self.rscale.data_ptr(), self.rbias.data_ptr(),
                                                self.xpu[:, 2:4].data_ptr(), 4, None, st), "rrl_stoch_head_fwd")
-            zp = self.qr_b.forward(self.xpu)
-            self._check(lib.rrl_qrisk_policy_grad(B, zp.data_ptr(), self.dq.data_ptr(), self.losses[6:].data_ptr(),
-                                                  st), "rrl_qrisk_policy_grad")
+            zp, n_part, ps = self.qr_b.forward(self.xpu)
+            self._check(lib.rrl_qrisk_policy_grad(B, zp.data_ptr(), n_part, ps, self.dq.data_ptr(),
+                                                  self.losses[6:].data_ptr(), st), "rrl_qrisk_policy_grad")
             dx = self.qr_b.backward(self.dq, weight_grads=False, input_grad=True)
-            self._check(lib.rrl_stoch_head_bwd(B, raw.data_ptr(), eps_pi.data_ptr(), ls.data_ptr(),
+            self._check(lib.rrl_stoch_head_bwd(B, raw.data_ptr(), rn, rs, eps_pi.data_ptr(), ls.data_ptr(),
                                                qr.policy.min_log_std, self.rscale.data_ptr(),
                                                dx[0, :, 2:4].data_ptr(), dx.stride(1), 2, dx.stride(0),
                                                self.draw.data_ptr(), self.recpolicy.g["log_std"].data_ptr(), st),
@@ -315,20 +323,21 @@ class FastActor:
         f, n, lib, st = self.f, self.n, self.f.lib, _lib.current_stream()
         if noise is None:
             noise = torch.randn(2, n, 2, device=f.dev)
-        head = self.pol.forward(obs, save=False)
+        head, hn, hs = self.pol.forward(obs, save=False)
         if not use_recovery:
-            _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), noise[0].data_ptr(), f.scale.data_ptr(),
+            _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), hn, hs, noise[0].data_ptr(), f.scale.data_ptr(),
                                               f.bias.data_ptr(), self.task_action.data_ptr(), 2, None, None, st),
                        "rrl_gauss_head_fwd")
             return self.task_action, self.task_action, None
         self.xa[:, 0:2] = obs
-        _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), noise[0].data_ptr(), f.scale.data_ptr(),
+        _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), hn, hs, noise[0].data_ptr(), f.scale.data_ptr(),
                                           f.bias.data_ptr(), self.xa[:, 2:4].data_ptr(), 4, None, None, st),
                    "rrl_gauss_head_fwd")
-        zq = self.qr.forward(self.xa, save=False)
+        self.qr.finalize = True                  # recovery_select reads a plain [2,n] tensor
+        zq, _, _ = self.qr.forward(self.xa, save=False)
         assert mf_recovery, "FastActor covers the model-free recovery policy"
-        raw = self.rec.forward(obs, save=False)
-        _lib.check(lib.rrl_stoch_head_fwd(n, raw.data_ptr(), noise[1].data_ptr(),
+        raw, rn, rs = self.rec.forward(obs, save=False)
+        _lib.check(lib.rrl_stoch_head_fwd(n, raw.data_ptr(), rn, rs, noise[1].data_ptr(),
                                           f.recpolicy.p["log_std"].data_ptr(), f.qr.policy.min_log_std,
                                           f.rscale.data_ptr(), f.rbias.data_ptr(), self.rec_action.data_ptr(), 2,
                                           None, st), "rrl_stoch_head_fwd")

@@ -42,7 +42,7 @@ def gemm(mode, A, B, out=None, bias=None, relu=False, mask=None, colsum=None, ac
     return out[0] if squeeze else out
 
 
-def mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=None, h1=None, h2=None, scratch=None):
+def mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=None, h1=None, h2=None, scratch=None, finalize=True):
     """Fused stack forward (rrl_mlp3_forward).  x [M,din]; W1 [G,H,din] ... W3 [G,dout,H] contiguous.
     Returns out [G,M,dout]."""
     lib = _lib.load()
@@ -54,7 +54,8 @@ def mlp3_forward(x, W1, b1, W2, b2, W3, b3, out=None, h1=None, h2=None, scratch=
         out = torch.empty(G, M, dout, dtype=torch.float32, device=x.device)
     rc = lib.rrl_mlp3_forward(G, M, H, din, dout, x.data_ptr(), x.stride(0), W1.data_ptr(), b1.data_ptr(),
                               W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(), _lib.ptr(h1),
-                              _lib.ptr(h2), out.data_ptr(), _lib.ptr(scratch), _lib.current_stream())
+                              _lib.ptr(h2), out.data_ptr(), _lib.ptr(scratch), int(finalize),
+                              _lib.current_stream())
     _lib.check(rc, "rrl_mlp3_forward")
     return out
 
