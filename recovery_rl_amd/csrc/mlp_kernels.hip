@@ -201,12 +201,15 @@ struct StackArgs {
 constexpr int kStackRows = 16;
 constexpr int kStackMaxH = 256;
 
+// R = row tiles (of 16 rows) per workgroup: they share the wave's W2 registers, so a big batch re-reads
+// W2 from L2 M / (16 R) times instead of M / 16 (the re-streaming is what bounds M = 4096).
+template <int R>
 __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
     // row stride H + 20 floats: the 16 rows of a ds_read_b128 lane group land on distinct 16-byte slots
-    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 20)];
-    __shared__ __attribute__((aligned(16))) float h2s[kStackRows * (kStackMaxH + 20)];
+    __shared__ __attribute__((aligned(16))) float h1s[R * kStackRows * (kStackMaxH + 20)];
+    __shared__ __attribute__((aligned(16))) float h2s[R * kStackRows * (kStackMaxH + 20)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.y, m0 = blockIdx.x * kStackRows;
+    const int g = blockIdx.y, m0 = blockIdx.x * (R * kStackRows);
     const int H = a.H, ldh = H + 20;
     const float* W1 = a.W1 + (long long)g * H * a.din;
     const float* b1 = a.b1 + (long long)g * H;
@@ -220,8 +223,12 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
 
     // ---- every global read of the kernel is issued up front, branch-free, in the order of first use ---
     // layer 1 as ONE MFMA step (K = din <= 4): A = x[row i][d = q], B = W1[n0 + i][d = q]
-    const int xrow = min(m0 + i, a.M - 1);
-    const float xa = (q < a.din) ? a.x[(long long)xrow * a.ldx + q] : 0.f;
+    float xa[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int xrow = min(m0 + 16 * t + i, a.M - 1);
+        xa[t] = (q < a.din) ? a.x[(long long)xrow * a.ldx + q] : 0.f;
+    }
     const float w1b = (q < a.din) ? W1[(n0 + i) * a.din + q] : 0.f;
     const float bias1 = b1[n0 + i];
     float4 wv[kStackMaxH / 16];                    // my 16 rows of W2: MFMA B operands of layer 2
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
         for (int j = 0; j < kStackMaxH / 16; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
     }
     const float bias2 = b2[n0 + i];
-    // layer 3 operands: wave w = row, 16-lane group o = output index, 16 strided k per lane
+    // layer 3 operands: wave w -> rows w, w + 16, ...; 16-lane group o = output index, 16 strided k per lane
     const int o3 = min(q, a.dout - 1);
     float w3v[kStackMaxH / 16];
 #pragma unroll
@@ -240,46 +247,60 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
 
     // ---- layer 1 ------------------------------------------------------------------------------------
     if (has_tile) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, w1b, acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = 4 * q + r;
-            float v = acc[r] + bias1;
-            v = v > 0.f ? v : 0.f;
-            h1s[rr * ldh + n0 + i] = v;
-            if (a.h1 && m0 + rr < a.M) a.h1[((long long)g * a.M + m0 + rr) * H + n0 + i] = v;
+        for (int t = 0; t < R; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t], w1b, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * t + 4 * q + r;
+                float v = acc[r] + bias1;
+                v = v > 0.f ? v : 0.f;
+                h1s[rr * ldh + n0 + i] = v;
+                if (a.h1 && m0 + rr < a.M) a.h1[((long long)g * a.M + m0 + rr) * H + n0 + i] = v;
+            }
         }
     }
     __syncthreads();
-    // ---- layer 2: 16 x H tile of h1 in LDS is the A operand of every wave; K order as in gemm16 -----
+    // ---- layer 2: R x 16 x H tile of h1 in LDS is the A operand of every wave; K order as in gemm16 ----
     if (has_tile) {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = h1s + i * ldh + 4 * q;
+        f32x4 acc0[R], acc1[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int j = 0; j < kStackMaxH / 16; ++j) {
             if (16 * j < H) {
-                const float4 av = *reinterpret_cast<const float4*>(arow + 16 * j);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[j].w, acc1, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    const float4 av = *reinterpret_cast<const float4*>(h1s + (16 * t + i) * ldh + 4 * q + 16 * j);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1[t], 0, 0, 0);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[j].w, acc1[t], 0, 0, 0);
+                }
             }
         }
-        const f32x4 acc = acc0 + acc1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = 4 * q + r;
-            float v = acc[r] + bias2;
-            v = v > 0.f ? v : 0.f;
-            h2s[rr * ldh + n0 + i] = v;
-            if (a.h2 && m0 + rr < a.M) a.h2[((long long)g * a.M + m0 + rr) * H + n0 + i] = v;
+        for (int t = 0; t < R; ++t) {
+            const f32x4 acc = acc0[t] + acc1[t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * t + 4 * q + r;
+                float v = acc[r] + bias2;
+                v = v > 0.f ? v : 0.f;
+                h2s[rr * ldh + n0 + i] = v;
+                if (a.h2 && m0 + rr < a.M) a.h2[((long long)g * a.M + m0 + rr) * H + n0 + i] = v;
+            }
         }
     }
     __syncthreads();
     // ---- layer 3: 16-lane dot products -----------------------------------------------------------------
-    {
-        const int r = wave;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int r = 16 * t + wave;
         float v = 0.f;
 #pragma unroll
         for (int it = 0; it < kStackMaxH / 16; ++it)
@@ -608,8 +629,13 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
         }
         return check_launch();
     }
-    hipLaunchKernelGGL(mlp3_fwd_kernel, dim3((M + kStackRows - 1) / kStackRows, G), dim3(1024), 0,
-                       (hipStream_t)stream, a);
+    // more than one workgroup per CU (256 CUs): two row tiles per workgroup halve the W2 re-streaming
+    if ((long long)((M + kStackRows - 1) / kStackRows) * G > 256)
+        hipLaunchKernelGGL((mlp3_fwd_kernel<2>), dim3((M + 2 * kStackRows - 1) / (2 * kStackRows), G), dim3(1024), 0,
+                           (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((mlp3_fwd_kernel<1>), dim3((M + kStackRows - 1) / kStackRows, G), dim3(1024), 0,
+                           (hipStream_t)stream, a);
     return check_launch();
 }
 
