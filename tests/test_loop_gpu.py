@@ -182,3 +182,30 @@ def test_maze_config3_vectorised_with_stratified_replay(tmp_path, capsys):
     assert exp.loop.graph is not None
     for p in exp.agent.safety_critic.safety_critic.parameters():
         assert torch.isfinite(p).all()
+
+
+def test_learning_level_parity_with_the_reference_run(tmp_path, golden_dir, capsys):
+    """scripts/navigation1.sh:7 (RRL-MF, seed 1, 400 episodes) end to end, against the statistics of the
+    REFERENCE's own run of the same command line (tests/golden/ref_learning_nav1_seed1.json, produced by
+    tests/golden/run_reference_training.py on the CPU: 397 successes, 0 violations, 19 924 env-steps).
+    RNG streams differ, so the comparison is at the level plotting/plot_runs.py:214-235 defines."""
+    import json
+    ref = json.load(open(os.path.join(golden_dir, "ref_learning_nav1_seed1.json")))
+    cfg = arg_utils.get_args(["--cuda", "--env-name", "navigation1", "--use_recovery", "--MF_recovery",
+                              "--gamma_safe", "0.8", "--eps_safe", "0.3", "--logdir", str(tmp_path),
+                              "--logdir_suffix", "RRL_MF", "--num_eps", "400", "--num_unsafe_transitions", "20000",
+                              "--seed", "1", "--eval", ""])
+    exp = Experiment(cfg)
+    exp.run()
+    capsys.readouterr()
+    data = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))["train_stats"]
+    assert len(data) == ref["episodes"] == 400
+    viol = sum(int(any(s["constraint"] for s in ep)) for ep in data)
+    succ = sum(int(ep[-1]["reward"] > -4) for ep in data)
+    steps = sum(len(ep) for ep in data)
+    assert viol <= ref["total_violations"] + 4                      # reference: 0 violations
+    assert succ >= ref["total_successes"] - 12                      # reference: 397 / 400 successes
+    assert abs(steps - ref["env_steps"]) < 0.1 * ref["env_steps"]   # reference: 19 924 env-steps
+    # the offline constraint data is distributed like the reference's (14 664 transitions, 903 violations)
+    assert abs(exp.num_unsafe_transitions - ref["num_constraint_transitions"]) < 0.04 * ref["num_constraint_transitions"]
+    assert abs(exp.num_constraint_violations - ref["num_constraint_violations_offline"]) < 0.15 * ref["num_constraint_violations_offline"]
