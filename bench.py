@@ -181,7 +181,10 @@ def main():
     ap.add_argument("--num_envs", type=int, default=NUM_ENVS)
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_sweep", action="store_true")
+    ap.add_argument("--sweep", action="store_true",
+                    help="also time rrl_nav_step at N = 2^12..2^24 (the bandwidth regime of the env kernel); off by "
+                         "default so that every nav_step_kernel launch of the default command has the bench size")
+    ap.add_argument("--no_sweep", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--autograd_updates", action="store_true",
                     help="PyTorch autograd + vendor GEMMs for the updates instead of the fused HIP kernels")
     a = ap.parse_args()
@@ -225,9 +228,10 @@ def main():
             "achieved": a.num_envs * NAV_STEP_ALGO_BYTES / t_k / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": a.num_envs * NAV_STEP_ALGO_BYTES / t_k / 1e9 / HBM_PEAK_GBS,
             "traffic": pmc_traffic(a.num_envs), "launch_us": t_k * 1e6,
-            "note": "N=%d moves only %d KB per launch: latency-bound; see roofline_sweep for the "
-                    "bandwidth regime" % (a.num_envs, a.num_envs * NAV_STEP_ALGO_BYTES // 1024)}
-        if not a.no_sweep:
+            "note": "N=%d moves only %d KB per launch: latency-bound; bandwidth regime (N up to 2^24, "
+                    "`bench.py --sweep`): profiles/round1_roofline_sweep.json"
+                    % (a.num_envs, a.num_envs * NAV_STEP_ALGO_BYTES // 1024)}
+        if a.sweep and not a.no_sweep:
             sweep = []
             for logn in (12, 16, 20, 24):
                 n = 1 << logn
