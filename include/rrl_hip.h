@@ -286,6 +286,33 @@ int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task
                         const float* rec_action, float* real_action, uint8_t* recovery, float* task_out,
                         void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Episode log.  The reference appends one info dict per env-step to run_stats.pkl and rewrites the whole
+ * file after every episode (recovery_rl/experiment.py:421,456-461,540-543, dump_logs :540-543); its plotting
+ * code reduces them per episode to: length, sum of rewards, last reward, any(constraint)
+ * (plotting/plot_runs.py:194-235).  This entry keeps exactly those per-episode quantities on the device:
+ * per-env accumulators (ep_len i32[n], ep_ret f64[n] summed in step order, ep_viol i32[n], ep_rec i32[n]) are
+ * advanced every step, and where ep_done[i] != 0 one record is appended and the accumulators are cleared.
+ *   rec_i32 [cap, RRL_EPLOG_I32] = {env, iteration, length, constraint steps, recovery steps,
+ *                                   flags (1 = success, 2 = constraint, 4 = recovery, all of the LAST step)}
+ *   rec_f64 [cap, 2]             = {episode return, last reward}
+ *   state   int64[3]             = {count, iteration, ticket}; count keeps growing past cap (overflow is
+ *                                  visible to the host; records beyond cap are dropped), iteration is
+ *                                  incremented by the kernel (hipGraph replay safe).
+ * Records land in completion order; (iteration, env) is unique, hosts sort by it.
+ * ------------------------------------------------------------------------------------------ */
+#define RRL_EPLOG_I32 6
+typedef struct {
+    int32_t* rec_i32;
+    double* rec_f64;
+    int64_t cap;
+    int64_t* state;
+} rrl_episode_log_t;
+
+int rrl_episode_log_append(int64_t n, const float* reward, const uint8_t* constraint, const uint8_t* success,
+                           const uint8_t* ep_done, const uint8_t* recovery, int32_t* ep_len, double* ep_ret,
+                           int32_t* ep_viol, int32_t* ep_rec, const rrl_episode_log_t* log, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ SO_PATH = os.path.join(CSRC, "librrl_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["nav_kernels.hip", "replay_kernels.hip", "maze_kernels.hip", "cem_kernels.hip",
-               "mlp_kernels.hip", "update_kernels.hip"]
+               "mlp_kernels.hip", "update_kernels.hip", "log_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                "-Wno-bitwise-instead-of-logical"]
@@ -29,7 +29,7 @@ EXPORTS = [
     "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_input_backward",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
-    "rrl_adam_step", "rrl_recovery_select",
+    "rrl_adam_step", "rrl_recovery_select", "rrl_episode_log_append",
 ]
 
 
@@ -67,6 +67,12 @@ class rrl_replay_t(C.Structure):
                 ("m", C.c_void_p), ("cap", C.c_int64), ("state", C.c_void_p),
                 ("pos_cnt", C.c_void_p)]
 
+
+class rrl_episode_log_t(C.Structure):
+    _fields_ = [("rec_i32", C.c_void_p), ("rec_f64", C.c_void_p), ("cap", C.c_int64), ("state", C.c_void_p)]
+
+
+EPLOG_I32 = 6
 
 _lib = None
 
@@ -113,6 +119,7 @@ def _declare(lib):
         "rrl_stoch_head_bwd": (ci, [ci, vp, ci, ll, vp, vp, f32, vp, vp, ci, ci, ll, vp, vp, vp]),
         "rrl_adam_step": (ci, [C.c_longlong, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, f32, vp]),
         "rrl_recovery_select": (ci, [ci, vp, f32, vp, ci, vp, vp, vp, vp, vp]),
+        "rrl_episode_log_append": (ci, [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(rrl_episode_log_t), vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -70,6 +70,7 @@ class VectorLoop:
         self._graph_updates = (0, 0)
         self._actor = None
         self._one = torch.ones((), dtype=torch.int64, device=dev)
+        self.episode_log = None           # optional EpisodeLog (per-episode records for run_stats)
 
     # -- pieces --------------------------------------------------------------------------------
     def start(self):
@@ -157,6 +158,8 @@ class VectorLoop:
         self.ep_reward += reward
         self.reward_sums[1] += torch.where(ep_done, self.ep_reward, torch.zeros_like(reward)).sum(dtype=torch.float64)
         self.ep_reward *= (~ep_done).to(torch.float32)
+        if self.episode_log is not None:
+            self.episode_log.append(reward, info["constraint"], info["success"], info["ep_done"], recovery)
         self.obs = obs
         self.total_numsteps += self.n
         return obs
@@ -187,6 +190,8 @@ class VectorLoop:
         mem._len = min(mem._len + self.n, mem.capacity)
         if use_rmem:
             rmem._len = min(rmem._len + self.n, rmem.capacity)
+        if self.episode_log is not None:
+            self.episode_log.append(env.reward, env.constraint, env.success, env.ep_done, rec_u8)
         self.obs = env.obs
         self.total_numsteps += self.n
         return env.obs
@@ -471,6 +476,10 @@ class Experiment:
         n = cfg.num_envs
         loop.start()
         log_every = cfg.log_every if getattr(cfg, "log_every", 0) else max(1, 100)
+        from .episode_log import EpisodeLog, EPISODE_DTYPE
+        loop.episode_log = EpisodeLog(n, n * log_every, self.device)
+        episodes = [np.zeros(0, dtype=EPISODE_DTYPE)]
+        ep_file = open(osp.join(self.logdir, "episode_stats.bin"), "wb")   # append-only, O(new) per log
         history = []
         evals = []
         next_eval = 10 * n                  # eval every 10 episodes per env (experiment.py:372)
@@ -507,6 +516,10 @@ class Experiment:
             if it % log_every == 0:
                 stats = loop.read_stats()
                 self._absorb(stats)
+                new = loop.episode_log.drain()
+                episodes.append(new)
+                ep_file.write(new.tobytes())
+                ep_file.flush()
                 agg = dist_utils.aggregate_stats(stats, self.world_size, self.device)
                 history.append(dict(stats, iteration=it))
                 if self.rank == 0:
@@ -524,6 +537,10 @@ class Experiment:
                     pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n}, f)
                 if stats["env_steps"] > cfg.num_steps or stats["episodes"] > cfg.num_eps:
                     break
+        ep_file.close()
+        with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
+            pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n,
+                         "episode_stats": np.concatenate(episodes)}, f)
         return history
 
     def get_test_rollout_vectorized(self, label):

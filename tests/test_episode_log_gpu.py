@@ -1,0 +1,116 @@
+"""rrl_episode_log_append on MI355X: bit-exact against the sequential checker (integer fields and the f64
+returns), hipGraph replay, overflow, and the run_stats.pkl written by the lock-step driver."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import arg_utils
+from oracle.log_oracle import EpisodeLogOracle
+from recovery_rl_amd import _lib
+from recovery_rl_amd.episode_log import (EPISODE_DTYPE, FLAG_CONSTRAINT, FLAG_SUCCESS, EpisodeLog, episode_metrics)
+from recovery_rl_amd.experiment import Experiment
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _inputs(rng, n):
+    reward = (-rng.uniform(0, 70, n)).astype(np.float32)
+    cons = (rng.rand(n) < 0.05).astype(np.uint8)
+    succ = (reward > -4).astype(np.uint8)
+    done = ((rng.rand(n) < 0.08) | (cons > 0)).astype(np.uint8)
+    rec = (rng.rand(n) < 0.2).astype(np.uint8)
+    return reward, cons, succ, done, rec
+
+
+@pytest.mark.parametrize("n,with_recovery", [(1, True), (1000, True), (5000, False)])
+def test_episode_log_equals_checker(n, with_recovery):
+    rng = np.random.RandomState(n)
+    log = EpisodeLog(n, n * 20, DEV)
+    chk = EpisodeLogOracle(n)
+    drained = []
+    for it in range(40):
+        r, c, s, d, rec = _inputs(rng, n)
+        t = [torch.as_tensor(x, device=DEV) for x in (r, c, s, d, rec)]
+        log.append(t[0], t[1], t[2], t[3], t[4] if with_recovery else None)
+        chk.append(r, c, s, d, rec if with_recovery else None)
+        if it % 20 == 19:
+            drained.append(log.drain())
+    got = np.concatenate(drained)
+    want = np.array(chk.records, dtype=EPISODE_DTYPE)
+    assert len(got) == len(want) > 0
+    for name in EPISODE_DTYPE.names:
+        np.testing.assert_array_equal(got[name], want[name], err_msg=name)
+    # open episodes: the accumulators equal the checker's
+    np.testing.assert_array_equal(log.ep_len.cpu().numpy(), chk.len)
+    np.testing.assert_array_equal(log.ep_ret.cpu().numpy(), chk.ret)
+    assert int(log.state[1].item()) == 40
+
+
+def test_episode_log_in_a_replayed_graph():
+    n = 300
+    rng = np.random.RandomState(5)
+    r, c, s, d, rec = _inputs(rng, n)
+    t = [torch.as_tensor(x, device=DEV) for x in (r, c, s, d, rec)]
+    log = EpisodeLog(n, n * 8, DEV)
+    chk = EpisodeLogOracle(n)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        log.append(*t)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        log.append(*t)
+    for _ in range(6):
+        g.replay()
+    torch.cuda.synchronize()
+    for _ in range(7):
+        chk.append(r, c, s, d, rec)
+    got, want = log.drain(), np.array(chk.records, dtype=EPISODE_DTYPE)
+    for name in EPISODE_DTYPE.names:
+        np.testing.assert_array_equal(got[name], want[name], err_msg=name)
+
+
+def test_episode_log_overflow_is_reported():
+    n = 64
+    log = EpisodeLog(n, 100, DEV)
+    ones = torch.ones(n, dtype=torch.uint8, device=DEV)
+    r = torch.zeros(n, device=DEV)
+    log.append(r, ones, ones, ones)
+    assert len(log.drain()) == 64
+    log.append(r, ones, ones, ones)
+    log.append(r, ones, ones, ones)
+    with pytest.raises(_lib.RRLError, match="overflow"):
+        log.drain()
+
+
+def test_lockstep_driver_writes_episode_table(tmp_path):
+    cfg = arg_utils.get_args(["--env-name", "navigation1", "--cuda", "--hidden_size", "32", "--logdir", str(tmp_path),
+                              "--seed", "3", "--num_unsafe_transitions", "2000", "--critic_safe_pretraining_steps",
+                              "20", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe", "0.3",
+                              "--num_envs", "64", "--num_eps", "150", "--log_every", "25"])
+    exp = Experiment(cfg)
+    exp.run()
+    data = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))
+    rec = data["episode_stats"]
+    last = data["vector_stats"][-1]
+    assert len(rec) == last["episodes"] > 150
+    assert int((rec["flags"] & FLAG_CONSTRAINT > 0).sum()) == last["num_viols"]
+    assert int((rec["flags"] & FLAG_SUCCESS > 0).sum()) == last["num_successes"]
+    assert int(rec["constraint_steps"].sum()) <= last["constraint_steps"]
+    assert rec["length"].min() >= 1 and rec["length"].max() <= 100
+    assert rec["length"].sum() <= last["env_steps"]
+    np.testing.assert_allclose(rec["ret"].sum(), last["episode_return_sum"], rtol=1e-5)
+    # nav1 success is judged on the reward of the last step (plot_runs.py:231 / navigation1.py:80)
+    np.testing.assert_array_equal(rec["last_reward"] > -4, rec["flags"] & FLAG_SUCCESS > 0)
+    raw = np.fromfile(os.path.join(exp.logdir, "episode_stats.bin"), dtype=EPISODE_DTYPE)
+    for name in EPISODE_DTYPE.names:
+        np.testing.assert_array_equal(raw[name], rec[name])
+    m = episode_metrics(data, "navigation1")
+    assert m["task_successes"][-1] == last["num_successes"]
+    assert m["train_violations"][-1] == int((rec["constraint_steps"] > 0).sum())
