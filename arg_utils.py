@@ -77,6 +77,10 @@ ADDITIVE = [
     (("--log_every",), I, 0, "vector steps between metric aggregations across ranks (0 = per episode)"),
     (("--mb_dynamics",), S, "model", "CEM rollouts through the learned ensemble ('model', reference) "
                                      "or the env kernels ('env', extension)"),
+    (("--checkpoint_every",), I, 0, "lock-step loop: write <logdir>/checkpoint.pt every this many log intervals "
+                                    "(0 = only at the end)"),
+    (("--no_fast_path",), "store_true", None, "SAC / Q_risk updates through autograd instead of the fused kernels"),
+    (("--resume",), S, "", "checkpoint.pt to continue from (lock-step loop; skips pre-training)"),
 ]
 
 

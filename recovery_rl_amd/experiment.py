@@ -205,7 +205,8 @@ class VectorLoop:
 
     def capture(self, online_qrisk=True, warmup=3):
         """Capture the steady-state iteration (updates + act + step + push + counters) into one
-        hipGraph.  Host-side bookkeeping (total_numsteps, updates) is advanced by replay()."""
+        hipGraph.  Host-side bookkeeping (total_numsteps, updates) is advanced by replay().  The `warmup`
+        iterations before the capture are real iterations; their number is returned."""
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -214,14 +215,20 @@ class VectorLoop:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         saved = (self.total_numsteps, self.updates, list(self.host_updates))
+        qr_updates = self.agent.safety_critic.updates
+        lens = (self.memory._len, self.recovery_memory._len)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.vector_step(True, False, online_qrisk)
         self._graph_updates = (self.host_updates[0] - saved[2][0], self.host_updates[1] - saved[2][1])
+        # rows one replay appends to each ring (host mirrors of the device-side sizes)
+        self._graph_rows = (self.n, self.n if uses_constraint_buffer(self.cfg) else 0)
         self.total_numsteps, self.updates, self.host_updates = saved
+        self.agent.safety_critic.updates = qr_updates      # the captured call only recorded launches
+        self.memory._len, self.recovery_memory._len = lens
         self.graph = g
         self._graph_obs = self.obs
-        return g
+        return warmup
 
     def replay(self):
         self.graph.replay()
@@ -229,7 +236,11 @@ class VectorLoop:
         self.host_updates[0] += self._graph_updates[0]
         self.host_updates[1] += self._graph_updates[1]
         self.updates += self.cfg.updates_per_step
-        self.agent.safety_critic.updates += self.cfg.updates_per_step
+        self.agent.safety_critic.updates += self._graph_updates[1]
+        for mem, rows in zip((self.memory, self.recovery_memory), self._graph_rows):
+            mem._len = min(mem._len + rows, mem.capacity)
+        if self.cfg.add_both_transitions:
+            self.memory._len_exact = False                 # masked pushes: the size is known on the device
         return self._graph_obs
 
     def read_stats(self):
@@ -358,7 +369,10 @@ class Experiment:
 
     def run(self):
         cfg = self.exp_cfg
-        if not cfg.disable_offline_updates and uses_constraint_buffer(cfg):
+        resume = getattr(cfg, "resume", "")
+        if resume and cfg.num_envs == 1:
+            raise NotImplementedError("--resume continues the lock-step loop (--num_envs > 1)")
+        if not resume and not cfg.disable_offline_updates and uses_constraint_buffer(cfg):
             self.pretrain_critic_recovery()
         if cfg.num_envs > 1:
             return self.run_vectorized()
@@ -476,21 +490,37 @@ class Experiment:
         n = cfg.num_envs
         loop.start()
         log_every = cfg.log_every if getattr(cfg, "log_every", 0) else max(1, 100)
+        from . import checkpoint
         from .episode_log import EpisodeLog, EPISODE_DTYPE
-        loop.episode_log = EpisodeLog(n, n * log_every, self.device)
+        loop.episode_log = EpisodeLog(n, n * (log_every + 4), self.device)   # a capture adds <= 3 iterations
         episodes = [np.zeros(0, dtype=EPISODE_DTYPE)]
-        ep_file = open(osp.join(self.logdir, "episode_stats.bin"), "wb")   # append-only, O(new) per log
         history = []
         evals = []
         next_eval = 10 * n                  # eval every 10 episodes per env (experiment.py:372)
         it = 0
+        mb_resume = []
+        if getattr(cfg, "resume", ""):
+            extra = checkpoint.load(self, cfg.resume)
+            it, next_eval = extra["iteration"], extra["next_eval"]
+            history, evals, episodes = extra["history"], extra["evals"], [extra["episodes"]]
+            mb_resume = [tuple(x.to(self.device) for x in row) for row in extra["mb_new"]]
+            print("Resumed from %s at iteration %d (%d env-steps)" % (cfg.resume, it, loop.total_numsteps))
+        logged = it // log_every
+        ckpt_every = getattr(cfg, "checkpoint_every", 0)
+        ckpt_path = osp.join(self.logdir, "checkpoint.pt")
+
+        def write_checkpoint():
+            checkpoint.save(self, ckpt_path, {"iteration": it, "next_eval": next_eval, "history": history,
+                                              "evals": evals, "episodes": np.concatenate(episodes), "mb_new": mb_new})
+        ep_file = open(osp.join(self.logdir, "episode_stats.bin"), "wb")   # append-only, O(new) per log
+        ep_file.write(episodes[0].tobytes())
         captured_gate = None
         mb = uses_mb_recovery(cfg)
         # model-based recovery: the ensemble is re-fitted on the transitions gathered since the last
         # fit every recovery_policy_update_freq * horizon iterations (the reference re-fits every
         # recovery_policy_update_freq episodes, experiment.py:464-480); the batch size scales with
         # num_envs so that an epoch keeps the reference's number of optimiser steps per env-step
-        mb_new = []
+        mb_new = mb_resume
         mb_every = cfg.recovery_policy_update_freq * self.env._max_episode_steps
         graph_ok = (cfg.target_update_interval == 1 and not cfg.nu_schedule and not mb)
         while True:
@@ -499,7 +529,7 @@ class Experiment:
             gate = self.online_qrisk_enabled() if uses_constraint_buffer(cfg) else False
             steady = have_batch and not random_actions and graph_ok
             if steady and (loop.graph is None or captured_gate != gate):
-                loop.capture(online_qrisk=gate)
+                it += loop.capture(online_qrisk=gate)
                 captured_gate = gate
             if steady:
                 loop.replay()
@@ -513,7 +543,8 @@ class Experiment:
                     S, A, S2 = (torch.cat(x) for x in zip(*mb_new))
                     self.recovery_policy.train(S, A, random=True, next_obs=S2, batch_size=32 * n)
                     mb_new = []
-            if it % log_every == 0:
+            if it // log_every > logged:
+                logged = it // log_every
                 stats = loop.read_stats()
                 self._absorb(stats)
                 new = loop.episode_log.drain()
@@ -535,9 +566,12 @@ class Experiment:
                     next_eval += 10 * n
                 with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
                     pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n}, f)
+                if ckpt_every and logged % ckpt_every == 0:
+                    write_checkpoint()
                 if stats["env_steps"] > cfg.num_steps or stats["episodes"] > cfg.num_eps:
                     break
         ep_file.close()
+        write_checkpoint()
         with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
             pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n,
                          "episode_stats": np.concatenate(episodes)}, f)
@@ -548,10 +582,7 @@ class Experiment:
         env instance, so the training episodes are not disturbed: every env runs ONE episode; returns
         the mean episode return, success rate and violation rate."""
         cfg = self.exp_cfg
-        if not hasattr(self, "_eval_env"):
-            self._eval_env = make_vec_env(cfg.env_name, cfg.num_envs, device=self.device,
-                                          seed=cfg.seed + 7919, auto_reset=False)
-        env = self._eval_env
+        env = self.eval_env()
         obs = env.reset()
         n = cfg.num_envs
         alive = torch.ones(n, dtype=torch.bool, device=self.device)
@@ -573,6 +604,13 @@ class Experiment:
             print("Avg. Reward: {}".format(round(out["avg_reward"], 2)))
             print("----------------------------------------")
         return out
+
+    def eval_env(self):
+        if getattr(self, "_eval_env", None) is None:
+            cfg = self.exp_cfg
+            self._eval_env = make_vec_env(cfg.env_name, cfg.num_envs, device=self.device,
+                                          seed=cfg.seed + 7919, auto_reset=False)
+        return self._eval_env
 
     def _absorb(self, stats):
         self.total_numsteps = stats["env_steps"]
