@@ -43,7 +43,8 @@ enum {
     RRL_STREAM_SAMPLE = 3,     /* replay sampling (positives)    */
     RRL_STREAM_SAMPLE_NEG = 4, /* replay sampling (negatives)    */
     RRL_STREAM_CEM = 5,        /* CEM truncated-normal samples   */
-    RRL_STREAM_ACTION = 6      /* uniform random actions         */
+    RRL_STREAM_ACTION = 6,     /* uniform random actions         */
+    RRL_STREAM_PLAN = 7        /* planner particle noise         */
 };
 
 /* ABI version, bumped on any signature change. */
@@ -312,6 +313,37 @@ typedef struct {
 int rrl_episode_log_append(int64_t n, const float* reward, const uint8_t* constraint, const uint8_t* success,
                            const uint8_t* ep_done, const uint8_t* recovery, int32_t* ep_len, double* ep_ret,
                            int32_t* ep_viol, int32_t* ep_rec, const rrl_episode_log_t* log, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Planner candidate evaluation.  Replaces MPC._compile_cost (recovery_rl/MPC.py:374-416) with
+ * _predict_next_obs (:421-439), the ensemble forward (config/navigation1.py:71-96) and
+ * QRiskWrapper.get_value (recovery_rl/qrisk.py:184-196) for M planning problems at once:
+ *   costs[m, c] = mean over npart particles of sum_{t < plan_hor} max(Q_risk1, Q_risk2)(obs_t, ac_seqs[m, c, t]),
+ *   obs_{t+1} = obs_t + mean_e(obs_t, ac_t) + z * sqrt(var_e(obs_t, ac_t)),  particle p uses member p / (npart / n_nets),
+ * NaN particle costs -> 1e6.  One MFMA kernel; activations never leave the chip.
+ *   rrl_plan_pack      re-packs the live weights into MFMA fragment order (call after every change of the
+ *                      safety critic or the ensemble).  Q_risk tensors are the stacked twin heads W1 [2,hq,4],
+ *                      b1 [2,hq], W2 [2,hq,hq], b2 [2,hq], W3 [2,1,hq], b3 [2,1] (nn.Linear layout, out x in);
+ *                      ensemble tensors are lin0_w [E,4,he], lin0_b [E,1,he], lin1_w/lin2_w [E,he,he],
+ *                      lin3_w [E,he,4], lin3_b [E,1,4] (in x out), inputs_mu/sigma [4], max/min_logvar [2].
+ *   rrl_plan_cost      cur_obs [M,2], ac_seqs [M,pop,plan_hor*2] f32; noise nullable f32 [plan_hor, M*pop*npart, 2]
+ *                      (row = (m*pop + c)*npart + p); when NULL the kernel draws Philox normals (stream
+ *                      RRL_STREAM_PLAN, row, counter*16 + t).  partial: scratch f32 [M*pop, n_nets]; costs [M,pop].
+ * Supported shape (rrl_plan_supported): hq = 256, he = 200, npart = 4 n_nets, 2-D obs and actions.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int hq, he, n_nets;
+    const float *q_w1, *q_b1, *q_w2, *q_b2, *q_w3, *q_b3;
+    const float *e_w0, *e_b0, *e_w1, *e_b1, *e_w2, *e_b2, *e_w3, *e_b3;
+    const float *inputs_mu, *inputs_sigma, *max_logvar, *min_logvar;
+} rrl_plan_weights_t;
+
+int rrl_plan_supported(int hq, int he, int n_nets, int npart, int d_obs, int d_act);
+long long rrl_plan_pack_floats(int hq, int he, int n_nets);
+int rrl_plan_pack(const rrl_plan_weights_t* w, float* packed, void* stream);
+int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
+                  const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
+                  uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream);
 
 #ifdef __cplusplus
 }

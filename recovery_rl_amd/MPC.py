@@ -79,6 +79,8 @@ class MPC:
         self.model = _required(self.model_init_cfg, "model_constructor",
                                "Must provide a model constructor.")(self.model_init_cfg)
         self.value_func = None
+        self.fused = None                  # FusedPlanner (rrl_plan_cost) when the shapes allow it
+        self.use_fused_planner = True
         self._lb = torch.as_tensor(self.ac_lb, dtype=torch.float32, device=self.device)
         self._ub = torch.as_tensor(self.ac_ub, dtype=torch.float32, device=self.device)
 
@@ -134,6 +136,11 @@ class MPC:
 
     def update_value_func(self, value_func):
         self.value_func = value_func
+        self.fused = None
+        if self.use_fused_planner:
+            from .planner import FusedPlanner
+            if FusedPlanner.supported(self):
+                self.fused = FusedPlanner(self)
 
     # -- acting (MPC.py:322-347) ---------------------------------------------------------------
     @torch.no_grad()
@@ -150,6 +157,8 @@ class MPC:
         if idx.numel() == 0:
             return out
         self.sy_cur_obs = obs[idx].contiguous()
+        if self.fused is not None:
+            self.fused.pack()              # weights moved since the last call (Q_risk update / re-fit)
         rows = idx if self.prev_sol.shape[0] == n else torch.zeros_like(idx)
         soln = self.optimizer.obtain_solution(self.prev_sol[rows], self.init_var.expand(idx.numel(), -1))
         shifted = torch.cat([soln[:, self.per * self.dU:],
@@ -161,8 +170,10 @@ class MPC:
 
     # -- candidate evaluation (MPC.py:374-416) -------------------------------------------------
     @torch.no_grad()
-    def _compile_cost(self, ac_seqs, cur_obs=None):
-        """ac_seqs [M, pop, plan_hor*dU] -> mean over particles of sum_t Q_risk(obs_t, ac_t): [M, pop]."""
+    def _compile_cost(self, ac_seqs, cur_obs=None, noise=None, fused=None):
+        """ac_seqs [M, pop, plan_hor*dU] -> mean over particles of sum_t Q_risk(obs_t, ac_t): [M, pop].
+        `noise` (optional, [plan_hor, M*pop*npart, dO], row = (m*pop + c)*npart + p) replaces the particle
+        noise draws; `fused` forces (True) or forbids (False) the rrl_plan_cost kernel."""
         single = not torch.is_tensor(ac_seqs)
         if single:
             ac_seqs = torch.as_tensor(ac_seqs, dtype=torch.float32, device=self.device)[None]
@@ -170,15 +181,22 @@ class MPC:
             cur_obs = self.sy_cur_obs
         cur_obs = torch.as_tensor(cur_obs, dtype=torch.float32, device=self.device).reshape(-1, self.dO)
         M, pop = ac_seqs.shape[0], ac_seqs.shape[1]
+        use_fused = (self.fused is not None) if fused is None else fused
+        if use_fused:
+            if self.fused is None:
+                raise _lib.RRLError("rrl_plan_cost does not support this planner shape")
+            costs = self.fused.cost(ac_seqs, cur_obs, noise)
+            return costs[0].cpu().numpy() if single else costs
         per_env = pop * self.npart
         chunk = max(1, self.MAX_ROWS // per_env)
         outs = []
         for lo in range(0, M, chunk):
-            outs.append(self._compile_cost_chunk(ac_seqs[lo:lo + chunk], cur_obs[lo:lo + chunk]))
+            nz = None if noise is None else noise[:, lo * per_env:(lo + chunk) * per_env]
+            outs.append(self._compile_cost_chunk(ac_seqs[lo:lo + chunk], cur_obs[lo:lo + chunk], nz))
         costs = torch.cat(outs, dim=0)
         return costs[0].cpu().numpy() if single else costs
 
-    def _compile_cost_chunk(self, ac_seqs, cur_obs):
+    def _compile_cost_chunk(self, ac_seqs, cur_obs, noise=None):
         M, pop = ac_seqs.shape[0], ac_seqs.shape[1]
         H, P = self.plan_hor, self.npart
         acs = ac_seqs.reshape(M, pop, H, self.dU).permute(2, 0, 1, 3)            # [H, M, pop, dU]
@@ -194,15 +212,16 @@ class MPC:
             if self.mb_dynamics == "env":
                 obs = obs_seq[t]
             else:
-                obs = self._predict_next_obs(obs, cur_acs)
+                obs = self._predict_next_obs(obs, cur_acs, None if noise is None else noise[t])
         costs = torch.where(costs != costs, torch.full_like(costs, 1e6), costs)     # NaN -> 1e6 (:415)
         return costs.mean(dim=1).reshape(M, pop)
 
-    def _predict_next_obs(self, obs, acs):
+    def _predict_next_obs(self, obs, acs, noise=None):
         """One TS-infinity step through the ensemble (MPC.py:421-439)."""
         inputs = torch.cat((self._expand_to_ts_format(obs), self._expand_to_ts_format(acs)), dim=-1)
         mean, var = self.model(inputs)
-        predictions = mean + torch.randn_like(mean) * var.sqrt()
+        eps = torch.randn_like(mean) if noise is None else self._expand_to_ts_format(noise)
+        predictions = mean + eps * var.sqrt()
         return self.obs_postproc(obs, self._flatten_to_matrix(predictions))
 
     def _expand_to_ts_format(self, mat):

@@ -14,7 +14,7 @@ SO_PATH = os.path.join(CSRC, "librrl_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["nav_kernels.hip", "replay_kernels.hip", "maze_kernels.hip", "cem_kernels.hip",
-               "mlp_kernels.hip", "update_kernels.hip", "log_kernels.hip"]
+               "mlp_kernels.hip", "update_kernels.hip", "log_kernels.hip", "plan_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                "-Wno-bitwise-instead-of-logical"]
@@ -30,6 +30,7 @@ EXPORTS = [
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_recovery_select", "rrl_episode_log_append",
+    "rrl_plan_supported", "rrl_plan_pack_floats", "rrl_plan_pack", "rrl_plan_cost",
 ]
 
 
@@ -73,6 +74,13 @@ class rrl_episode_log_t(C.Structure):
 
 
 EPLOG_I32 = 6
+
+
+class rrl_plan_weights_t(C.Structure):
+    _fields_ = [("hq", C.c_int), ("he", C.c_int), ("n_nets", C.c_int)] + [
+        (name, C.c_void_p) for name in ("q_w1", "q_b1", "q_w2", "q_b2", "q_w3", "q_b3", "e_w0", "e_b0", "e_w1",
+                                        "e_b1", "e_w2", "e_b2", "e_w3", "e_b3", "inputs_mu", "inputs_sigma",
+                                        "max_logvar", "min_logvar")]
 
 _lib = None
 
@@ -119,6 +127,10 @@ def _declare(lib):
         "rrl_stoch_head_bwd": (ci, [ci, vp, ci, ll, vp, vp, f32, vp, vp, ci, ci, ll, vp, vp, vp]),
         "rrl_adam_step": (ci, [C.c_longlong, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, f32, vp]),
         "rrl_recovery_select": (ci, [ci, vp, f32, vp, ci, vp, vp, vp, vp, vp]),
+        "rrl_plan_supported": (ci, [ci, ci, ci, ci, ci, ci]),
+        "rrl_plan_pack_floats": (ll, [ci, ci, ci]),
+        "rrl_plan_pack": (ci, [C.POINTER(rrl_plan_weights_t), vp, vp]),
+        "rrl_plan_cost": (ci, [vp, ci, ci, ci, ci, ll, ci, ci, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp]),
         "rrl_episode_log_append": (ci, [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(rrl_episode_log_t), vp]),
     }
     for name, (res, args) in sig.items():

@@ -1,0 +1,443 @@
+// plan_kernels.hip -- the candidate-evaluation inner loop of the model-based recovery controller
+// (MPC._compile_cost, recovery_rl/MPC.py:374-416, with _predict_next_obs :421-439, the PETS ensemble
+// forward config/navigation1.py:71-96 and QRiskWrapper.get_value recovery_rl/qrisk.py:184-196) as ONE
+// MFMA kernel for gfx950.
+//
+// For every (env m, candidate c, particle p) row the reference runs plan_hor steps of
+//     cost += max(sigmoid Q1, sigmoid Q2)(obs, ac_t);  obs += mean_e(obs, ac_t) + N(0,1) * sqrt(var_e(obs, ac_t))
+// through two 256-wide MLPs and one 200-wide ensemble member, materialising every [rows, 256] activation
+// in HBM between layers (26 GB per layer at 4096 envs).  Here a workgroup owns 64 rows for the whole
+// rollout: activations live in LDS, weights stream from L2 as pre-packed MFMA fragments, and only the
+// per-candidate cost leaves the chip.  Arithmetic is v_mfma_f32_16x16x4_f32 (exact f32 fma chains), so
+// results differ from the PyTorch path only by summation order.
+//
+// Row order inside a tile: 16 consecutive (m, c) groups x the 4 particles that are bound to ensemble member
+// e (TS-infinity: member = particle / (npart / nets), MPC.py:441-455); tile id = (group block, e).
+#include "rrl_device.hpp"
+#include "rrl_host.hpp"
+#include "plan_layout.hpp"
+
+using namespace rrl_host;
+using namespace rrl_plan;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRows = 64;                 // rows per workgroup
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kActStride = kHQ + 4;       // +4 floats: row r starts at bank 4r, ds_read_b128 conflict-free
+constexpr int kLdsFloats = kRows * kActStride + 2 * kRows * 4 + 2 * kWaves * kRows + 4 * kRows * 4;
+constexpr int kLdsBytes = kLdsFloats * 4;  // 76.5 KB: two workgroups per CU
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float reluf(float x) { return x < 0.f ? 0.f : x; }   // NaN stays NaN (F.relu)
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// acc[r][c] += act[rt[r] tile, :K] * W[:, ct[c] tile] over J chunks of 16 k.  A fragments come from LDS
+// (row-major, k contiguous), B fragments from the packed weight stream ([ct][j][lane] float4, one coalesced
+// 1 KB load per fragment).  Chunk step t uses k = 16 j + 4 (lane / 16) + t on both operands.
+template <int MR, int NC>
+__device__ __forceinline__ void layer_mma(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
+                                          const float* __restrict__ wpk, const int (&ct)[NC], int J, int lane) {
+    const int arow = lane & 15, kq = (lane >> 4) * 4;
+#pragma unroll 1
+    for (int j = 0; j < J; ++j) {
+        f32x4 a[MR], b[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ct[c] >= 0) b[c] = *reinterpret_cast<const f32x4*>(wpk + ((size_t)(ct[c] * J + j) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < MR; ++r)
+            a[r] = *reinterpret_cast<const f32x4*>(act + (rt[r] * 16 + arow) * kActStride + 16 * j + kq);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < MR; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (ct[c] >= 0) acc[r][c] = mfma(a[r][t], b[c][t], acc[r][c]);
+    }
+}
+
+// first layers: K = 4 inputs = ONE mfma per tile.  x is [64][4] in LDS, w1 packed [ct][lane].
+template <int MR, int NC>
+__device__ __forceinline__ void input_mma(f32x4 (&acc)[MR][NC], const float* x, const int (&rt)[MR],
+                                          const float* __restrict__ w1, const int (&ct)[NC], int lane) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const float a = x[(rt[r] * 16 + (lane & 15)) * 4 + (lane >> 4)];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ct[c] >= 0) acc[r][c] = mfma(a, w1[ct[c] * 64 + lane], acc[r][c]);
+    }
+}
+
+template <int MR, int NC>
+__device__ __forceinline__ void zero(f32x4 (&acc)[MR][NC]) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// act[row][col] = f(acc + bias[col]); C layout: row = 16 rt + 4 (lane / 16) + i, col = 16 ct + lane % 16
+template <bool SWISH, int MR, int NC>
+__device__ __forceinline__ void store_act(const f32x4 (&acc)[MR][NC], float* act, const int (&rt)[MR],
+                                          const float* __restrict__ bias, const int (&ct)[NC], int lane) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (ct[c] < 0) continue;
+        const int col = ct[c] * 16 + (lane & 15);
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < MR; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = acc[r][c][i] + bv;
+                act[(rt[r] * 16 + 4 * (lane >> 4) + i) * kActStride + col] = SWISH ? swishf(v) : reluf(v);
+            }
+    }
+}
+
+__device__ __forceinline__ float reduce16(float v) {   // sum over the 16 lanes that share lane / 16
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads, 2) void plan_cost_kernel(
+    const float* __restrict__ pk, int n_nets, int npart, long long n_groups, int pop, int plan_hor,
+    const float* __restrict__ cur_obs, const float* __restrict__ ac_seqs, const float* __restrict__ noise,
+    uint64_t seed, uint64_t counter, const uint64_t* __restrict__ counter_dev, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* act = lds;                                               // [64][260] activations
+    float* xs = act + kRows * kActStride;                           // [64][4] raw (obs, ac)
+    float* xn = xs + kRows * 4;                                     // [64][4] standardised ensemble input
+    float(*qpart)[kWaves][kRows] = reinterpret_cast<float(*)[kWaves][kRows]>(xn + kRows * 4);
+    float(*epart)[kRows][4] = reinterpret_cast<float(*)[kRows][4]>(xn + kRows * 4 + 2 * kWaves * kRows);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long tile = blockIdx.x;
+    const int e = int(tile % n_nets);
+    const long long gblock = tile / n_nets;
+    const int ppn = npart / n_nets;                       // particles per net (4)
+    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
+
+    // one thread per row keeps the row's rollout state
+    const bool owner = tid < kRows;
+    const long long group = gblock * 16 + (tid >> 2);
+    const bool live = owner && group < n_groups;
+    const int particle = e * ppn + (tid & 3);
+    const long long row_global = group * npart + particle;
+    float ox = 0.f, oy = 0.f, cost = 0.f;
+    if (live) {
+        const long long m = group / pop;
+        ox = cur_obs[m * 2];
+        oy = cur_obs[m * 2 + 1];
+    }
+    const float* qpk[2] = {pk + q_off(0), pk + q_off(1)};
+    const float* epk = pk + e_off(e);
+    const float* g = pk + glob_off(n_nets);                // mu[4], sigma[4], max_logvar[2], min_logvar[2]
+
+    // wave -> tile assignment
+    const int q_rt[4] = {0, 1, 2, 3};
+    const int q_ct[2] = {2 * wave, 2 * wave + 1};
+    const int rh = wave & 1, cs = wave >> 1;
+    const int e_rt[2] = {2 * rh, 2 * rh + 1};
+    const int e_ct[4] = {cs, cs + 4, cs + 8, cs + 12 < kETiles ? cs + 12 : -1};
+
+    for (int t = 0; t < plan_hor; ++t) {
+        if (owner) {
+            float ax = 0.f, ay = 0.f;
+            if (live) {
+                ax = ac_seqs[group * (plan_hor * 2) + 2 * t];
+                ay = ac_seqs[group * (plan_hor * 2) + 2 * t + 1];
+            }
+            const f32x4 x = {ox, oy, ax, ay};
+            *reinterpret_cast<f32x4*>(xs + tid * 4) = x;
+            f32x4 n;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) n[k] = (x[k] - g[k]) / g[4 + k];
+            *reinterpret_cast<f32x4*>(xn + tid * 4) = n;
+        }
+        __syncthreads();
+
+        // ---- Q_risk twin heads: 4 -> HQ relu -> HQ relu -> 1 ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float* w = qpk[h];
+            f32x4 acc[4][2];
+            zero(acc);
+            input_mma(acc, xs, q_rt, w + kQW1, q_ct, lane);
+            store_act<false>(acc, act, q_rt, w + kQB1, q_ct, lane);
+            __syncthreads();
+            zero(acc);
+            layer_mma(acc, act, q_rt, w + kQW2, q_ct, kQTiles, lane);
+            // last layer folded in: q[row] = sum_col relu(h2 + b2) w3[col]
+            float s[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[r][i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = q_ct[c] * 16 + (lane & 15);
+                const float bv = w[kQB2 + col], w3 = w[kQW3 + col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[r][i] += reluf(acc[r][c][i] + bv) * w3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = reduce16(s[r][i]);
+                    if ((lane & 15) == 0) qpart[h][wave][r * 16 + 4 * (lane >> 4) + i] = v;
+                }
+            __syncthreads();       // act is free again; qpart[h] complete
+        }
+
+        // ---- ensemble member e: 4 -> 200 swish -> 200 swish -> 200 swish -> 4 ----
+        {
+            f32x4 acc[2][4];
+            zero(acc);
+            input_mma(acc, xn, e_rt, epk + kEW0, e_ct, lane);
+            store_act<true>(acc, act, e_rt, epk + kEB0, e_ct, lane);
+            __syncthreads();
+            zero(acc);
+            layer_mma(acc, act, e_rt, epk + kEW1, e_ct, kETiles, lane);
+            __syncthreads();       // every wave has finished reading layer-1 input
+            store_act<true>(acc, act, e_rt, epk + kEB1, e_ct, lane);
+            __syncthreads();
+            zero(acc);
+            layer_mma(acc, act, e_rt, epk + kEW2, e_ct, kETiles, lane);
+            float s[2][4][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) s[r][i][o] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (e_ct[c] < 0) continue;
+                const int col = e_ct[c] * 16 + (lane & 15);
+                const float bv = epk[kEB2 + col];
+                const f32x4 w3 = *reinterpret_cast<const f32x4*>(epk + kEW3 + col * 4);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = swishf(acc[r][c][i] + bv);
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) s[r][i][o] += v * w3[o];
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const float v = reduce16(s[r][i][o]);
+                        if ((lane & 15) == 0) epart[cs][e_rt[r] * 16 + 4 * (lane >> 4) + i][o] = v;
+                    }
+            __syncthreads();
+        }
+
+        // ---- per-row tail: cost, predictive distribution, next observation ----
+        if (owner) {
+            float q[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v = qpk[h][kQB3];
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) v += qpart[h][w][tid];
+                q[h] = sigmoidf(v);
+            }
+            cost += (q[0] > q[1] || q[0] != q[0]) ? q[0] : q[1];      // torch.max: NaN propagates
+            float out[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                out[o] = epk[kEB3 + o] + ((epart[0][tid][o] + epart[1][tid][o]) + (epart[2][tid][o] + epart[3][tid][o]));
+            float z0 = 0.f, z1 = 0.f;
+            if (live) {
+                if (noise) {
+                    const long long nrows = n_groups * npart;
+                    z0 = noise[((long long)t * nrows + row_global) * 2];
+                    z1 = noise[((long long)t * nrows + row_global) * 2 + 1];
+                } else {
+                    double d0, d1;
+                    rrl::normal_at(seed, uint32_t(row_global), rrl::kStreamPlan, ctr * 16 + uint64_t(t), d0, d1);
+                    z0 = float(d0);
+                    z1 = float(d1);
+                }
+            }
+            float sd[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {          // config/navigation1.py:90-96
+                float lv = out[2 + k];
+                lv = g[8 + k] - softplusf(g[8 + k] - lv);
+                lv = g[10 + k] + softplusf(lv - g[10 + k]);
+                sd[k] = sqrtf(expf(lv));
+            }
+            ox = ox + (out[0] + z0 * sd[0]);        // obs_postproc: obs + prediction (:131-133)
+            oy = oy + (out[1] + z1 * sd[1]);
+        }
+        // xs / xn are rewritten by the owners only after every wave passed the barriers above
+    }
+
+    // sum of the member's particles per (m, c) group; NaN -> 1e6 per particle (MPC.py:415)
+    if (owner) {
+        float c = (cost != cost) ? 1e6f : cost;
+        c += __shfl_xor(c, 1, 64);
+        c += __shfl_xor(c, 2, 64);
+        if (live && (tid & 3) == 0) partial[group * n_nets + e] = c;
+    }
+}
+
+// costs[g] = (sum over members of partial[g][e]) / npart
+__global__ __launch_bounds__(kBlock) void plan_finish_kernel(long long n_groups, int n_nets, int npart,
+                                                             const float* __restrict__ partial,
+                                                             float* __restrict__ costs, uint64_t* counter_dev,
+                                                             uint64_t counter_inc) {
+    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < n_groups;
+         g += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int e = 0; e < n_nets; ++e) s += partial[g * n_nets + e];
+        costs[g] = s / float(npart);
+    }
+    rrl::advance_counter(counter_dev, counter_inc);
+}
+
+// ---- weight packing -----------------------------------------------------------------------------
+// fragment stream for one [N x K] layer: out[((ct * J + j) * 64 + lane) * 4 + t] = W[n = 16 ct + lane % 16]
+// [k = 16 j + 4 (lane / 16) + t], zero outside N x K.  W element (n, k) is at src[n * sn + k * sk].
+__global__ __launch_bounds__(kBlock) void pack_layer_kernel(const float* __restrict__ src, long long sn, long long sk,
+                                                            int N, int K, int tiles, int J, float* __restrict__ dst) {
+    const long long total = (long long)tiles * J * 256;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int t = int(i & 3), lane = int((i >> 2) & 63);
+        const long long f = i >> 8;
+        const int j = int(f % J), ct = int(f / J);
+        const int n = 16 * ct + (lane & 15), k = 16 * j + 4 * (lane >> 4) + t;
+        dst[i] = (n < N && k < K) ? src[n * sn + k * sk] : 0.f;
+    }
+}
+
+// first layers (K = 4): out[ct * 64 + lane] = W[n = 16 ct + lane % 16][k = lane / 16]
+__global__ __launch_bounds__(kBlock) void pack_input_kernel(const float* __restrict__ src, long long sn, long long sk,
+                                                            int N, int tiles, float* __restrict__ dst) {
+    const int total = tiles * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63, ct = i >> 6;
+        const int n = 16 * ct + (lane & 15), k = lane >> 4;
+        dst[i] = n < N ? src[n * sn + k * sk] : 0.f;
+    }
+}
+
+// vectors (bias, last-layer weights) copied with zero padding; src element i at src[i * stride]
+__global__ __launch_bounds__(kBlock) void pack_vector_kernel(const float* __restrict__ src, long long stride, int n,
+                                                             int n_pad, float* __restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x)
+        dst[i] = i < n ? src[i * stride] : 0.f;
+}
+
+// last ensemble layer [HE x 4] as [col][o] with zero rows up to the padded width
+__global__ __launch_bounds__(kBlock) void pack_head_kernel(const float* __restrict__ src, int he,
+                                                           float* __restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kHEPad * 4; i += gridDim.x * blockDim.x)
+        dst[i] = (i >> 2) < he ? src[i] : 0.f;          // lin3_w[e] is [HE][4] row-major already
+}
+
+}  // namespace
+
+extern "C" {
+
+long long rrl_plan_pack_floats(int hq, int he, int n_nets) {
+    if (hq != kHQ || he != kHE || n_nets <= 0) return RRL_EINVAL;
+    return (long long)packed_floats(n_nets);
+}
+
+int rrl_plan_supported(int hq, int he, int n_nets, int npart, int d_obs, int d_act) {
+    return hq == kHQ && he == kHE && n_nets > 0 && npart % n_nets == 0 && npart / n_nets == 4 && d_obs == 2 &&
+           d_act == 2;
+}
+
+int rrl_plan_pack(const rrl_plan_weights_t* w, float* packed, void* stream_) {
+    if (!w || !packed || !rrl_plan_supported(w->hq, w->he, w->n_nets, 4 * w->n_nets, 2, 2)) return RRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    const dim3 b(kBlock);
+    for (int h = 0; h < 2; ++h) {
+        float* d = packed + q_off(h);
+        hipLaunchKernelGGL(pack_input_kernel, dim3(4), b, 0, st, w->q_w1 + (size_t)h * kHQ * 4, 4LL, 1LL, kHQ,
+                           kQTiles, d + kQW1);
+        hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_b1 + h * kHQ, 1LL, kHQ, kHQ, d + kQB1);
+        hipLaunchKernelGGL(pack_layer_kernel, dim3(64), b, 0, st, w->q_w2 + (size_t)h * kHQ * kHQ, (long long)kHQ,
+                           1LL, kHQ, kHQ, kQTiles, kQTiles, d + kQW2);
+        hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_b2 + h * kHQ, 1LL, kHQ, kHQ, d + kQB2);
+        hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_w3 + h * kHQ, 1LL, kHQ, kHQ, d + kQW3);
+        hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_b3 + h, 1LL, 1, 4, d + kQB3);
+    }
+    for (int e = 0; e < w->n_nets; ++e) {
+        float* d = packed + e_off(e);
+        // ensemble weights are [in][out] (torch.baddbmm(b, x, w)): element (n = out, k = in) at w[k * out_dim + n]
+        hipLaunchKernelGGL(pack_input_kernel, dim3(4), b, 0, st, w->e_w0 + (size_t)e * 4 * kHE, 1LL, (long long)kHE,
+                           kHE, kETiles, d + kEW0);
+        hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b0 + e * kHE, 1LL, kHE, kHEPad, d + kEB0);
+        hipLaunchKernelGGL(pack_layer_kernel, dim3(64), b, 0, st, w->e_w1 + (size_t)e * kHE * kHE, 1LL,
+                           (long long)kHE, kHE, kHE, kETiles, kETiles, d + kEW1);
+        hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b1 + e * kHE, 1LL, kHE, kHEPad, d + kEB1);
+        hipLaunchKernelGGL(pack_layer_kernel, dim3(64), b, 0, st, w->e_w2 + (size_t)e * kHE * kHE, 1LL,
+                           (long long)kHE, kHE, kHE, kETiles, kETiles, d + kEW2);
+        hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b2 + e * kHE, 1LL, kHE, kHEPad, d + kEB2);
+        hipLaunchKernelGGL(pack_head_kernel, dim3(4), b, 0, st, w->e_w3 + (size_t)e * kHE * 4, kHE, d + kEW3);
+        hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b3 + e * 4, 1LL, 4, 4, d + kEB3);
+    }
+    float* gl = packed + glob_off(w->n_nets);
+    hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->inputs_mu, 1LL, 4, 4, gl);
+    hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->inputs_sigma, 1LL, 4, 4, gl + 4);
+    hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->max_logvar, 1LL, 2, 2, gl + 8);
+    hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->min_logvar, 1LL, 2, 2, gl + 10);
+    return check_launch();
+}
+
+int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
+                  const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
+                  uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream_) {
+    if (!packed || !cur_obs || !ac_seqs || !partial || !costs || M <= 0 || pop <= 0 || plan_hor <= 0 ||
+        plan_hor > 16 || !rrl_plan_supported(hq, he, n_nets, npart, 2, 2))
+        return RRL_EINVAL;
+    const long long n_groups = M * pop;
+    if (n_groups * npart >= (1LL << 32)) return RRL_EINVAL;      // Philox row index is 32 bits
+    const long long tiles = ((n_groups + 15) / 16) * n_nets;
+    if (tiles >= (1LL << 31)) return RRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    static bool lds_set = false;
+    if (!lds_set) {       // > 64 KB of LDS has to be granted explicitly
+        if (hipFuncSetAttribute((const void*)plan_cost_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLdsBytes) != hipSuccess) {
+            last_hip_error = int(hipGetLastError());
+            return RRL_ELAUNCH;
+        }
+        lds_set = true;
+    }
+    hipLaunchKernelGGL(plan_cost_kernel, dim3((unsigned)tiles), dim3(kThreads), kLdsBytes, st, packed, n_nets, npart,
+                       n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial);
+    hipLaunchKernelGGL(plan_finish_kernel, dim3(grid_for(n_groups)), dim3(kBlock), 0, st, n_groups, n_nets, npart,
+                       partial, costs, counter_dev, counter_inc);
+    return check_launch();
+}
+
+}  // extern "C"

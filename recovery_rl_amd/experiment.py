@@ -201,6 +201,7 @@ class VectorLoop:
         if do_update:
             self.do_updates(i_episode, online_qrisk)
         action, real_action, recovery = self.act(self.obs, random_actions)
+        self._last_recovery = recovery
         return self.step_and_store(action, real_action, recovery)
 
     def capture(self, online_qrisk=True, warmup=3):
