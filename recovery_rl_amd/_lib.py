@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "librrl_hip.so")
+SO_PATH = os.environ.get("RRL_HIP_LIB") or os.path.join(CSRC, "librrl_hip.so")   # override: A/B builds in profiles/
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["nav_kernels.hip", "replay_kernels.hip", "maze_kernels.hip", "cem_kernels.hip",

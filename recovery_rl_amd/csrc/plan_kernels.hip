@@ -24,6 +24,16 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// waves per SIMD the register allocator targets: 2 = one workgroup per CU (<= 256 VGPRs), 4 = two (<= 128)
+// timing ablations for profiles/ (wrong results!): 1 = no weight-fragment loads, 2 = no LDS fragment reads,
+// 4 = no activation stores / reductions
+#ifndef RRL_PLAN_ABLATE
+#define RRL_PLAN_ABLATE 0
+#endif
+#ifndef RRL_PLAN_WAVES_PER_EU
+#define RRL_PLAN_WAVES_PER_EU 4
+#endif
+
 constexpr int kRows = 64;                 // rows per workgroup
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
@@ -35,6 +45,13 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Identity the optimiser cannot see through: address arithmetic derived from opaque(lane) is redone per phase
+// instead of being hoisted out of the rollout loop and kept live (that hoisting costs > 100 VGPRs here).
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 __device__ __forceinline__ float reluf(float x) { return x < 0.f ? 0.f : x; }   // NaN stays NaN (F.relu)
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf(float x) { return x / (1.0f + __expf(-x)); }
@@ -42,40 +59,87 @@ __device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log
 
 // acc[r][c] += act[rt[r] tile, :K] * W[:, ct[c] tile] over J chunks of 16 k.  A fragments come from LDS
 // (row-major, k contiguous), B fragments from the packed weight stream ([ct][j][lane] float4, one coalesced
-// 1 KB load per fragment).  Chunk step t uses k = 16 j + 4 (lane / 16) + t on both operands.
-template <int MR, int NC>
-__device__ __forceinline__ void layer_mma(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
-                                          const float* __restrict__ wpk, const int (&ct)[NC], int J, int lane) {
-    const int arow = lane & 15, kq = (lane >> 4) * 4;
-#pragma unroll 1
-    for (int j = 0; j < J; ++j) {
-        f32x4 a[MR], b[NC];
+// 1 KB load per fragment).  Chunk step t uses k = 16 j + 4 (lane / 16) + t on both operands.  The loads of
+// Tile (r, c) of a wave's block is computed when c < 3 or r == XR: columns 0..2 for every row tile, the 4th
+// column (only the ensemble has one: its 13th column tile) for ONE row tile.
+template <int XR>
+__device__ __forceinline__ constexpr bool tile_on(int r, int c) {
+    return c < 3 || r == XR;
+}
+
+template <int NCV, int NC>
+__device__ __forceinline__ void load_b(f32x4 (&b)[NC], const float* __restrict__ wpk, const int (&ct)[NC], int J,
+                                       int j, int lane) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-            if (ct[c] >= 0) b[c] = *reinterpret_cast<const f32x4*>(wpk + ((size_t)(ct[c] * J + j) * 64 + lane) * 4);
+    for (int c = 0; c < NCV; ++c) {
+#if RRL_PLAN_ABLATE & 1
+        b[c] = f32x4{float(j), float(lane), 1.f, 2.f};
+#else
+        b[c] = *reinterpret_cast<const f32x4*>(wpk + ((size_t)(ct[c] * J + j) * 64 + lane) * 4);
+#endif
+    }
+}
+
+template <int NCV, int XR, int MR, int NC>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
+                                          const f32x4 (&b)[NC], int j, int lane) {
+    f32x4 a[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+#if RRL_PLAN_ABLATE & 2
+        a[r] = f32x4{float(j), float(lane), 1.f, float(r)};
+#else
+        a[r] = *reinterpret_cast<const f32x4*>(act + (rt[r] * 16 + (lane & 15)) * kActStride + 16 * j +
+                                               (lane >> 4) * 4);
+#endif
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < MR; ++r)
-            a[r] = *reinterpret_cast<const f32x4*>(act + (rt[r] * 16 + arow) * kActStride + 16 * j + kq);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < MR; ++r)
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (ct[c] >= 0) acc[r][c] = mfma(a[r][t], b[c][t], acc[r][c]);
+            for (int c = 0; c < NCV; ++c)
+                if (tile_on<XR>(r, c)) acc[r][c] = mfma(a[r][t], b[c][t], acc[r][c]);
+}
+
+// The weight fragments of chunk j + 1 are requested before the 4 MR NC MFMAs of chunk j (register double
+// buffer): their L2 latency hides behind ~1000 cycles of matrix work.  LDS fragments are read per chunk.
+template <int NCV, int J, int XR = -1, int MR, int NC>
+__device__ __forceinline__ void layer_mma(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
+                                          const float* __restrict__ wpk, const int (&ct)[NC], int lane) {
+    f32x4 b0[NC], b1[NC];
+    load_b<NCV>(b0, wpk, ct, J, 0, lane);
+    int j = 0;
+    // steady state without conditionals: the compiler's vmcnt tracking then waits for the OLDER fragment set
+    // only, leaving the prefetch of the next chunk in flight during the 4 MR NCV MFMAs
+#pragma unroll 1
+    for (; j + 2 < J; j += 2) {
+        load_b<NCV>(b1, wpk, ct, J, j + 1, lane);
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs it hides behind
+        mma_chunk<NCV, XR>(acc, act, rt, b0, j, lane);
+        load_b<NCV>(b0, wpk, ct, J, j + 2, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk<NCV, XR>(acc, act, rt, b1, j + 1, lane);
+    }
+    if constexpr (J % 2 == 0) {
+        load_b<NCV>(b1, wpk, ct, J, J - 1, lane);
+        mma_chunk<NCV, XR>(acc, act, rt, b0, J - 2, lane);
+        mma_chunk<NCV, XR>(acc, act, rt, b1, J - 1, lane);
+    } else {
+        mma_chunk<NCV, XR>(acc, act, rt, b0, J - 1, lane);
     }
 }
 
 // first layers: K = 4 inputs = ONE mfma per tile.  x is [64][4] in LDS, w1 packed [ct][lane].
-template <int MR, int NC>
+template <int NCV, int XR = -1, int MR, int NC>
 __device__ __forceinline__ void input_mma(f32x4 (&acc)[MR][NC], const float* x, const int (&rt)[MR],
                                           const float* __restrict__ w1, const int (&ct)[NC], int lane) {
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         const float a = x[(rt[r] * 16 + (lane & 15)) * 4 + (lane >> 4)];
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-            if (ct[c] >= 0) acc[r][c] = mfma(a, w1[ct[c] * 64 + lane], acc[r][c]);
+        for (int c = 0; c < NCV; ++c)
+            if (tile_on<XR>(r, c)) acc[r][c] = mfma(a, w1[ct[c] * 64 + lane], acc[r][c]);
     }
 }
 
@@ -88,18 +152,21 @@ __device__ __forceinline__ void zero(f32x4 (&acc)[MR][NC]) {
 }
 
 // act[row][col] = f(acc + bias[col]); C layout: row = 16 rt + 4 (lane / 16) + i, col = 16 ct + lane % 16
-template <bool SWISH, int MR, int NC>
+template <bool SWISH, int NCV, int XR = -1, int MR, int NC>
 __device__ __forceinline__ void store_act(const f32x4 (&acc)[MR][NC], float* act, const int (&rt)[MR],
-                                          const float* __restrict__ bias, const int (&ct)[NC], int lane) {
+                                          const float (&bias)[NC], const int (&ct)[NC], int lane) {
+#if RRL_PLAN_ABLATE & 4
+    if (bias[0] != 12345.f) return;
+#endif
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (ct[c] < 0) continue;
+    for (int c = 0; c < NCV; ++c) {
         const int col = ct[c] * 16 + (lane & 15);
-        const float bv = bias[col];
+        const float bv = bias[c];
 #pragma unroll
         for (int r = 0; r < MR; ++r)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (!tile_on<XR>(r, c)) continue;
                 const float v = acc[r][c][i] + bv;
                 act[(rt[r] * 16 + 4 * (lane >> 4) + i) * kActStride + col] = SWISH ? swishf(v) : reluf(v);
             }
@@ -114,7 +181,8 @@ __device__ __forceinline__ float reduce16(float v) {   // sum over the 16 lanes 
     return v;
 }
 
-__global__ __launch_bounds__(kThreads, 2) void plan_cost_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(RRL_PLAN_WAVES_PER_EU, RRL_PLAN_WAVES_PER_EU)))
+void plan_cost_kernel(
     const float* __restrict__ pk, int n_nets, int npart, long long n_groups, int pop, int plan_hor,
     const float* __restrict__ cur_obs, const float* __restrict__ ac_seqs, const float* __restrict__ noise,
     uint64_t seed, uint64_t counter, const uint64_t* __restrict__ counter_dev, float* __restrict__ partial) {
@@ -125,7 +193,8 @@ __global__ __launch_bounds__(kThreads, 2) void plan_cost_kernel(
     float(*qpart)[kWaves][kRows] = reinterpret_cast<float(*)[kWaves][kRows]>(xn + kRows * 4);
     float(*epart)[kRows][4] = reinterpret_cast<float(*)[kRows][4]>(xn + kRows * 4 + 2 * kWaves * kRows);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile indices live in SGPRs
     const long long tile = blockIdx.x;
     const int e = int(tile % n_nets);
     const long long gblock = tile / n_nets;
@@ -144,16 +213,17 @@ __global__ __launch_bounds__(kThreads, 2) void plan_cost_kernel(
         ox = cur_obs[m * 2];
         oy = cur_obs[m * 2 + 1];
     }
-    const float* qpk[2] = {pk + q_off(0), pk + q_off(1)};
     const float* epk = pk + e_off(e);
     const float* g = pk + glob_off(n_nets);                // mu[4], sigma[4], max_logvar[2], min_logvar[2]
 
+    const int order = __builtin_amdgcn_readfirstlane(int(blockIdx.x >> 8) & 1);
     // wave -> tile assignment
     const int q_rt[4] = {0, 1, 2, 3};
     const int q_ct[2] = {2 * wave, 2 * wave + 1};
     const int rh = wave & 1, cs = wave >> 1;
     const int e_rt[2] = {2 * rh, 2 * rh + 1};
-    const int e_ct[4] = {cs, cs + 4, cs + 8, cs + 12 < kETiles ? cs + 12 : -1};
+    const int e_ct[4] = {cs, cs + 4, cs + 8, wave < 4 ? 12 : cs};   // the 13th column: waves 0..3, one row tile each
+    const int xr = wave < 4 ? (wave >> 1) : -1;                     // which of the wave's two row tiles (0/1), or none
 
     for (int t = 0; t < plan_hor; ++t) {
         if (owner) {
@@ -171,88 +241,133 @@ __global__ __launch_bounds__(kThreads, 2) void plan_cost_kernel(
         }
         __syncthreads();
 
-        // ---- Q_risk twin heads: 4 -> HQ relu -> HQ relu -> 1 ----
+        // The two networks read the same (obs, ac) and are independent, so their order is free.  Workgroups that
+        // share a CU (dispatch slots alternate every 256 workgroups: 8 XCDs x 32 CUs) run them in opposite order,
+        // which keeps one of them in a matrix phase while the other is in an epilogue or at a barrier.
+#pragma unroll 1
+        for (int phase = 0; phase < 2; ++phase) {
+            if ((phase ^ order) == 0) {
+                // ---- Q_risk twin heads: 4 -> HQ relu -> HQ relu -> 1 ----
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    const float* __restrict__ w = pk + h * kQSize;
+                    // epilogue constants first: their latency hides behind the matrix work
+                    float b1v[2], b2v[2], w3v[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float* w = qpk[h];
-            f32x4 acc[4][2];
-            zero(acc);
-            input_mma(acc, xs, q_rt, w + kQW1, q_ct, lane);
-            store_act<false>(acc, act, q_rt, w + kQB1, q_ct, lane);
-            __syncthreads();
-            zero(acc);
-            layer_mma(acc, act, q_rt, w + kQW2, q_ct, kQTiles, lane);
-            // last layer folded in: q[row] = sum_col relu(h2 + b2) w3[col]
-            float s[4][4];
+                    for (int c = 0; c < 2; ++c) {
+                        const int col = q_ct[c] * 16 + (lane & 15);
+                        b1v[c] = w[kQB1 + col];
+                        b2v[c] = w[kQB2 + col];
+                        w3v[c] = w[kQW3 + col];
+                    }
+                    f32x4 acc[4][2];
+                    zero(acc);
+                    input_mma<2>(acc, xs, q_rt, w + kQW1, q_ct, opaque(lane));
+                    store_act<false, 2>(acc, act, q_rt, b1v, q_ct, opaque(lane));
+                    __syncthreads();
+                    zero(acc);
+                    layer_mma<2, kQTiles>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
+                    // last layer folded in: q[row] = sum_col relu(h2 + b2) w3[col]
+                    float s[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s[r][i] = 0.f;
+                        for (int i = 0; i < 4; ++i) s[r][i] = 0.f;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int col = q_ct[c] * 16 + (lane & 15);
-                const float bv = w[kQB2 + col], w3 = w[kQW3 + col];
+                    for (int c = 0; c < 2; ++c) {
+                        const float bv = b2v[c], w3 = w3v[c];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) s[r][i] += reluf(acc[r][c][i] + bv) * w3;
-            }
+                            for (int i = 0; i < 4; ++i) s[r][i] += reluf(acc[r][c][i] + bv) * w3;
+                    }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = reduce16(s[r][i]);
-                    if ((lane & 15) == 0) qpart[h][wave][r * 16 + 4 * (lane >> 4) + i] = v;
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = reduce16(s[r][i]);
+                            if ((lane & 15) == 0) qpart[h][wave][r * 16 + 4 * (lane >> 4) + i] = v;
+                        }
+                    __syncthreads();       // act is free again; qpart[h] complete
                 }
-            __syncthreads();       // act is free again; qpart[h] complete
-        }
-
-        // ---- ensemble member e: 4 -> 200 swish -> 200 swish -> 200 swish -> 4 ----
-        {
-            f32x4 acc[2][4];
-            zero(acc);
-            input_mma(acc, xn, e_rt, epk + kEW0, e_ct, lane);
-            store_act<true>(acc, act, e_rt, epk + kEB0, e_ct, lane);
-            __syncthreads();
-            zero(acc);
-            layer_mma(acc, act, e_rt, epk + kEW1, e_ct, kETiles, lane);
-            __syncthreads();       // every wave has finished reading layer-1 input
-            store_act<true>(acc, act, e_rt, epk + kEB1, e_ct, lane);
-            __syncthreads();
-            zero(acc);
-            layer_mma(acc, act, e_rt, epk + kEW2, e_ct, kETiles, lane);
-            float s[2][4][4];
+            } else {
+                // ---- ensemble member e: 4 -> 200 swish -> 200 swish -> 200 swish -> 4 ----
+                // 4 row tiles x 13 column tiles: every wave owns 2 row tiles x 3 column tiles (cs, cs+4, cs+8);
+                // the 13th column's four tiles go one each to waves 0..3 (row tile xr of their own pair), so
+                // every SIMD carries the same number of MFMAs.
+                // Wave-uniform dispatch on the extra tile: E_STAGE(f, args) = f<NCV, ..., XR>(args)
+#define E_STAGE(CALL4X0, CALL4X1, CALL3)  \
+    if (xr == 0) {                        \
+        CALL4X0;                          \
+    } else if (xr == 1) {                 \
+        CALL4X1;                          \
+    } else {                              \
+        CALL3;                            \
+    }
+                const int ecol[4] = {e_ct[0] * 16 + (lane & 15), e_ct[1] * 16 + (lane & 15),
+                                     e_ct[2] * 16 + (lane & 15), e_ct[3] * 16 + (lane & 15)};
+                // per-column constants are requested one phase ahead of their use, never all live at once
+                float eb[4];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB0 + ecol[c]];
+                f32x4 acc[2][4];
+                zero(acc);
+                E_STAGE((input_mma<4, 0>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
+                         store_act<true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+                        (input_mma<4, 1>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
+                         store_act<true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+                        (input_mma<3>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
+                         store_act<true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB1 + ecol[c]];
+                __syncthreads();
+                zero(acc);
+                E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                        (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                        (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
+                __syncthreads();       // every wave has finished reading layer-1 input
+                E_STAGE((store_act<true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+                        (store_act<true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+                        (store_act<true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) s[r][i][o] = 0.f;
+                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB2 + ecol[c]];
+                __syncthreads();
+                zero(acc);
+                E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                        (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                        (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
+#undef E_STAGE
+                // last layer (200 -> 4) folded in: out[row][o] = sum_col swish(h3 + b2) W3[col][o]
+                f32x4 ew3[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (e_ct[c] < 0) continue;
-                const int col = e_ct[c] * 16 + (lane & 15);
-                const float bv = epk[kEB2 + col];
-                const f32x4 w3 = *reinterpret_cast<const f32x4*>(epk + kEW3 + col * 4);
+                for (int c = 0; c < 4; ++c) ew3[c] = *reinterpret_cast<const f32x4*>(epk + kEW3 + ecol[c] * 4);
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                for (int r = 0; r < 2; ++r) {
+                    float s[4][4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = swishf(acc[r][c][i] + bv);
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int o = 0; o < 4; ++o) s[r][i][o] += v * w3[o];
+                        for (int o = 0; o < 4; ++o) s[i][o] = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c == 3 && xr != r) continue;          // acc[r][3] is zero there, but swish(b) is not
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = swishf(acc[r][c][i] + eb[c]);
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) s[i][o] += v * ew3[c][o];
+                        }
                     }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const float v = reduce16(s[i][o]);
+                            if ((lane & 15) == 0) epart[cs][e_rt[r] * 16 + 4 * (lane >> 4) + i][o] = v;
+                        }
+                }
+                __syncthreads();
             }
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        const float v = reduce16(s[r][i][o]);
-                        if ((lane & 15) == 0) epart[cs][e_rt[r] * 16 + 4 * (lane >> 4) + i][o] = v;
-                    }
-            __syncthreads();
         }
 
         // ---- per-row tail: cost, predictive distribution, next observation ----
@@ -260,7 +375,7 @@ __global__ __launch_bounds__(kThreads, 2) void plan_cost_kernel(
             float q[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float v = qpk[h][kQB3];
+                float v = pk[h * kQSize + kQB3];
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) v += qpart[h][w][tid];
                 q[h] = sigmoidf(v);
