@@ -115,6 +115,42 @@ def iteration_flops(num_envs):
     return 0.685e9 + 0.62e9 + num_envs * 2.0 * (67072 + 133632 + 66560)
 
 
+PLAN_FLOPS_PER_ROW_STEP = 267264 + 163200      # twin Q_risk (4-256-256-1 x2) + one ensemble member (4-200-200-200-4)
+F32_MFMA_PEAK_TF = 157.3                       # MI355X_MICROARCH.md; 155.4 measured on this pool (profiles/mfma_peak.hip)
+
+
+def time_planner_kernel(device, n_plans=256, reps=3):
+    """rrl_plan_cost (MPC._compile_cost of config 4: 400 candidates x 20 particles x 5 steps per planning
+    env): seconds per launch from HIP events on the launch stream."""
+    from recovery_rl_amd.MPC import MPC
+    from recovery_rl_amd.config import create_config
+    from recovery_rl_amd.env import make_vec_env
+    from recovery_rl_amd.sac import SAC
+    env = make_vec_env("navigation2", 4, device=device, seed=1)
+    mpc = MPC(create_config("navigation2", "MPC", {}, [], "/tmp", env=env).ctrl_cfg, seed=1)
+    args = arg_utils.get_args(["--env-name", "navigation2", "--cuda", "--use_recovery", "--gamma_safe", "0.65",
+                               "--eps_safe", "0.2"])
+    agent = SAC(env.observation_space, env.action_space, args, "/tmp")
+    mpc.model.fit_input_stats(torch.randn(500, 4, device=device))
+    mpc.has_been_trained = True
+    mpc.update_value_func(agent.safety_critic)
+    if mpc.fused is None:
+        raise _lib.RRLError("rrl_plan_cost is not available for the config-4 planner shape")
+    mpc.fused.pack()
+    pop = mpc.optimizer.popsize
+    acs = torch.rand(n_plans, pop, mpc.plan_hor * 2, device=device) * 2 - 1
+    obs = torch.randn(n_plans, 2, device=device)
+    mpc.fused.cost(acs, obs)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        mpc.fused.cost(acs, obs)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) * 1e-3 / reps, n_plans * pop * mpc.npart * mpc.plan_hor
+
+
 def cpu_baseline(budget_s=15.0):
     """The reference-style loop (1 env, 1 SAC + 1 Q_risk update per env step; experiment.py:396-452)
     on the host cores: C oracle env + oracle replay + the same torch modules on the CPU."""
@@ -181,6 +217,8 @@ def main():
     ap.add_argument("--num_envs", type=int, default=NUM_ENVS)
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--planner", action="store_true",
+                    help="also time the fused planner kernel of config 4 (MFMA roofline) -> roofline_planner")
     ap.add_argument("--sweep", action="store_true",
                     help="also time rrl_nav_step at N = 2^12..2^24 (the bandwidth regime of the env kernel); off by "
                          "default so that every nav_step_kernel launch of the default command has the bench size")
@@ -240,6 +278,15 @@ def main():
                               "achieved_GBs": n * NAV_STEP_ALGO_BYTES / tk / 1e9,
                               "frac": n * NAV_STEP_ALGO_BYTES / tk / 1e9 / HBM_PEAK_GBS})
             extra["roofline_sweep"] = sweep
+        if a.planner:
+            t_p, row_steps = time_planner_kernel(device)
+            tf = row_steps * PLAN_FLOPS_PER_ROW_STEP / t_p / 1e12
+            extra["roofline_planner"] = {
+                "kernel": "plan_cost_kernel (rrl_plan_cost, model-based recovery of config 4)", "bound": "mfma",
+                "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
+                "traffic": None, "launch_ms": t_p * 1e3, "row_steps_per_s": row_steps / t_p,
+                "note": "f32-in/f32-acc MFMA (exact f32); algorithmic %d FLOP per particle-step"
+                        % PLAN_FLOPS_PER_ROW_STEP}
         if not a.no_cpu_baseline and world == 1:
             extra["cpu_baseline"] = cpu_baseline()
 
