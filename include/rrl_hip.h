@@ -44,7 +44,8 @@ enum {
     RRL_STREAM_SAMPLE_NEG = 4, /* replay sampling (negatives)    */
     RRL_STREAM_CEM = 5,        /* CEM truncated-normal samples   */
     RRL_STREAM_ACTION = 6,     /* uniform random actions         */
-    RRL_STREAM_PLAN = 7        /* planner particle noise         */
+    RRL_STREAM_PLAN = 7,       /* planner particle noise         */
+    RRL_STREAM_NOISE = 8       /* policy noise (rrl_normal_fill) */
 };
 
 /* ABI version, bumped on any signature change. */
@@ -260,9 +261,10 @@ int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const
  * element i is p[i] + p[part_stride + i] + ... (n_part terms, fixed order) -- the partial last-layer sums of
  * rrl_mlp3_forward(scratch, finalize = 0); n_part = 1 for a plain tensor.
  * ------------------------------------------------------------------------------------------ */
+/* obs_in (nullable, [B,2]) is copied to obs_out (row stride ld_action): builds the [s | a] critic input in place */
 int rrl_gauss_head_fwd(int B, const float* head, int n_part, long long part_stride, const float* eps,
                        const float* scale, const float* bias, float* action, int ld_action, float* logp,
-                       float* mean_action, void* stream);
+                       float* mean_action, const float* obs_in, float* obs_out, void* stream);
 int rrl_gauss_head_bwd(int B, const float* head, int n_part, long long part_stride, const float* eps,
                        const float* scale, const float* d_action, int ld, int n_heads, long long head_stride,
                        float dlogp, float* dhead, void* stream);
@@ -283,6 +285,25 @@ int rrl_stoch_head_bwd(int B, const float* raw, int n_part, long long part_strid
                        int n_heads, long long head_stride, float* draw, float* dlog_std, void* stream);
 int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uint64_t* step_dev, float lr,
                   float beta1, float beta2, float eps, float* target, float tau, void* stream);
+/* rrl_adam_step for up to RRL_ADAM_MAX_SEGS flat buffers in one launch (e.g. critic + policy of one update);
+ * every segment has its own step counter and optional Polyak target. */
+#define RRL_ADAM_MAX_SEGS 4
+typedef struct {
+    long long n;
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    uint64_t* step_dev;
+    float* target;
+    float tau;
+} rrl_adam_seg_t;
+int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2, float eps,
+                        void* stream);
+/* out[2i], out[2i+1] = N(0,1) pair i of Philox stream RRL_STREAM_NOISE at counter (+ device tick): replaces
+ * torch.randn for the policy noise of recovery_rl/model.py:324-340,511-525 (x_t = mean + std * eps). */
+int rrl_normal_fill(long long n_pairs, uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                    float* out, void* stream);
 int rrl_recovery_select(int N, const float* z, float eps_safe, const float* task_action, int ld_task,
                         const float* rec_action, float* real_action, uint8_t* recovery, float* task_out,
                         void* stream);

@@ -29,7 +29,7 @@ EXPORTS = [
     "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_input_backward",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
-    "rrl_adam_step", "rrl_recovery_select", "rrl_episode_log_append",
+    "rrl_adam_step", "rrl_adam_step_multi", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
     "rrl_plan_supported", "rrl_plan_pack_floats", "rrl_plan_pack", "rrl_plan_cost",
 ]
 
@@ -74,6 +74,12 @@ class rrl_episode_log_t(C.Structure):
 
 
 EPLOG_I32 = 6
+ADAM_MAX_SEGS = 4
+
+
+class rrl_adam_seg_t(C.Structure):
+    _fields_ = [("n", C.c_longlong), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("step_dev", C.c_void_p), ("target", C.c_void_p), ("tau", C.c_float)]
 
 
 class rrl_plan_weights_t(C.Structure):
@@ -117,7 +123,7 @@ def _declare(lib):
         "rrl_mlp3_is_split": (ci, [ci, ci]),
         "rrl_mlp_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_mlp_input_backward": (ci, [ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
-        "rrl_gauss_head_fwd": (ci, [ci, vp, ci, ll, vp, vp, vp, vp, ci, vp, vp, vp]),
+        "rrl_gauss_head_fwd": (ci, [ci, vp, ci, ll, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_gauss_head_bwd": (ci, [ci, vp, ci, ll, vp, vp, vp, ci, ci, ll, f32, vp, vp]),
         "rrl_sac_critic_grad": (ci, [ci, vp, vp, ci, ll, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
         "rrl_sac_policy_grad": (ci, [ci, vp, ci, ll, vp, vp, vp, vp, vp]),
@@ -126,6 +132,8 @@ def _declare(lib):
         "rrl_stoch_head_fwd": (ci, [ci, vp, ci, ll, vp, vp, f32, vp, vp, vp, ci, vp, vp]),
         "rrl_stoch_head_bwd": (ci, [ci, vp, ci, ll, vp, vp, f32, vp, vp, ci, ci, ll, vp, vp, vp]),
         "rrl_adam_step": (ci, [C.c_longlong, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, f32, vp]),
+        "rrl_adam_step_multi": (ci, [ci, C.POINTER(rrl_adam_seg_t), f32, f32, f32, f32, vp]),
+        "rrl_normal_fill": (ci, [ll, u64, u64, vp, u64, vp, vp]),
         "rrl_recovery_select": (ci, [ci, vp, f32, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_plan_supported": (ci, [ci, ci, ci, ci, ci, ci]),
         "rrl_plan_pack_floats": (ll, [ci, ci, ci]),

@@ -74,6 +74,8 @@ def agent_state(agent):
     if agent.fast is not None:
         out["flat"] = {name: {"m": _cpu(net.m), "v": _cpu(net.v), "step": _cpu(net.step)}
                        for name, net in ((n, getattr(agent.fast, n)) for n in _FLAT_NETS)}
+        out["noise_tick"] = _cpu(agent.fast.noise_tick)
+        out["actor_rows"] = agent.fast.actor_rows        # layout of the per-iteration noise fill
     out["optim"] = {k: o.state_dict() for k, o in _optimisers(agent).items()}
     return out
 
@@ -111,6 +113,8 @@ def load_agent_state(agent, sd):
             net.m.copy_(sd["flat"][name]["m"])
             net.v.copy_(sd["flat"][name]["v"])
             net.step.copy_(sd["flat"][name]["step"])
+        agent.fast.noise_tick.copy_(sd["noise_tick"])
+        agent.fast.actor_rows = sd["actor_rows"]
     for k, o in _optimisers(agent).items():
         o.load_state_dict(sd["optim"][k])
 

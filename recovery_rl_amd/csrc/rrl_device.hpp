@@ -14,7 +14,7 @@
 namespace rrl {
 
 constexpr uint32_t kStreamStep = 0, kStreamReset = 1, kStreamOffline = 2, kStreamSample = 3,
-                   kStreamSampleNeg = 4, kStreamCem = 5, kStreamAction = 6, kStreamPlan = 7;
+                   kStreamSampleNeg = 4, kStreamCem = 5, kStreamAction = 6, kStreamPlan = 7, kStreamNoise = 8;
 
 struct Bits128 {
     uint64_t lo, hi;

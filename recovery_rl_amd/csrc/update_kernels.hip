@@ -30,11 +30,16 @@ __device__ __forceinline__ float psum(const float* p, long long idx, int np, lon
 
 // ---- tanh-Gaussian head (GaussianPolicy.sample, model.py:324-340) -------------------------------
 // head[b] = (mean0, mean1, log_std0, log_std1) raw outputs of the last linear layer
+// obs_in (nullable, [B,2]) is copied to obs_out (row stride ld_action): assembles the [s | a] critic input in place
 __global__ void gauss_head_fwd_kernel(int B, const float* head, int np, long long ps, const float* eps,
                                       const float* scale, const float* bias, float* action, int ld_action,
-                                      float* logp, float* mean_action) {
+                                      float* logp, float* mean_action, const float* obs_in, float* obs_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (obs_in) {
+        obs_out[(long long)b * ld_action] = obs_in[2 * b];
+        obs_out[(long long)b * ld_action + 1] = obs_in[2 * b + 1];
+    }
     float lp = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -231,6 +236,66 @@ __global__ void stoch_head_bwd_kernel(int B, const float* raw, int np, long long
 //   m <- m + (g - m)(1 - b1) ; v <- b2 v + (1 - b2) g^2 ; p <- p - lr/(1 - b1^t) m / (sqrt(v)/sqrt(1 - b2^t) + eps)
 // then, if target: target <- (1 - tau) target + tau p     (utils.soft_update, utils.py:46-49)
 // step_dev = {t, ticket}: t is read by every workgroup, the last one to finish stores t + 1.
+struct AdamSegs {
+    rrl_adam_seg_t seg[RRL_ADAM_MAX_SEGS];
+    int first_block[RRL_ADAM_MAX_SEGS + 1];      // workgroups [first_block[k], first_block[k+1]) serve segment k
+};
+
+__device__ __forceinline__ void adam_range(long long n, float* p, const float* g, float* m, float* v,
+                                           float step_size, float bc2_sqrt, float b1, float b2, float eps,
+                                           float* target, float tau, int block, int blocks) {
+    const long long stride = (long long)blocks * kBlock;
+    for (long long i = (long long)block * kBlock + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float pi = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        p[i] = pi;
+        if (target) target[i] = target[i] * (1.f - tau) + pi * tau;
+    }
+}
+
+// several flat buffers (e.g. critic + policy of one update) in ONE launch; every segment keeps its own step
+// counter, advanced by the last of ITS workgroups.
+__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_seg, float lr, float b1, float b2,
+                                                            float eps) {
+    __shared__ float sh[2];
+    int k = 0;
+    while (k + 1 < n_seg && (int)blockIdx.x >= a.first_block[k + 1]) ++k;
+    const rrl_adam_seg_t sg = a.seg[k];
+    const int block = blockIdx.x - a.first_block[k], blocks = a.first_block[k + 1] - a.first_block[k];
+    if (threadIdx.x == 0) {
+        const double t = double(sg.step_dev[0] + 1);
+        sh[0] = lr / float(1.0 - pow(double(b1), t));
+        sh[1] = float(sqrt(1.0 - pow(double(b2), t)));
+    }
+    __syncthreads();
+    adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, block, blocks);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket = atomicAdd((unsigned long long*)&sg.step_dev[1], 1ULL);
+        if (ticket == (unsigned long long)blocks - 1) {
+            sg.step_dev[0] += 1;
+            sg.step_dev[1] = 0;
+        }
+    }
+}
+
+// ---- N(0,1) fill: out[2i], out[2i+1] = the Philox normal pair of index i (stream RRL_STREAM_NOISE) ----
+__global__ __launch_bounds__(kBlock) void normal_fill_kernel(long long n_pairs, uint64_t seed, uint64_t counter,
+                                                             uint64_t* counter_dev, uint64_t counter_inc,
+                                                             float* __restrict__ out) {
+    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n_pairs; i += (long long)gridDim.x * kBlock) {
+        double z0, z1;
+        rrl::normal_at(seed, uint32_t(i), rrl::kStreamNoise, ctr, z0, z1);
+        reinterpret_cast<float2*>(out)[i] = make_float2(float(z0), float(z1));
+    }
+    rrl::advance_counter(counter_dev, counter_inc);
+}
+
 __global__ __launch_bounds__(kBlock) void adam_kernel(long long n, float* p, const float* g, float* m,
                                                       float* v, uint64_t* step_dev, float lr, float b1,
                                                       float b2, float eps, float* target, float tau) {
@@ -279,10 +344,11 @@ extern "C" {
 
 int rrl_gauss_head_fwd(int B, const float* head, int n_part, long long part_stride, const float* eps,
                        const float* scale, const float* bias, float* action, int ld_action, float* logp,
-                       float* mean_action, void* stream) {
-    if (!head || !eps || !scale || !bias || !action || B <= 0 || n_part <= 0) return RRL_EINVAL;
+                       float* mean_action, const float* obs_in, float* obs_out, void* stream) {
+    if (!head || !eps || !scale || !bias || !action || B <= 0 || n_part <= 0 || (obs_in && !obs_out))
+        return RRL_EINVAL;
     hipLaunchKernelGGL(gauss_head_fwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, n_part,
-                       part_stride, eps, scale, bias, action, ld_action, logp, mean_action);
+                       part_stride, eps, scale, bias, action, ld_action, logp, mean_action, obs_in, obs_out);
     return check_launch();
 }
 
@@ -356,6 +422,31 @@ int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uin
     const int grid = grid_for(n) < 64 ? grid_for(n) : 64;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, n, p, g, m, v,
                        step_dev, lr, beta1, beta2, eps, target, tau);
+    return check_launch();
+}
+
+int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2, float eps,
+                        void* stream) {
+    if (!segs || n_seg <= 0 || n_seg > RRL_ADAM_MAX_SEGS) return RRL_EINVAL;
+    AdamSegs a;
+    a.first_block[0] = 0;
+    for (int k = 0; k < n_seg; ++k) {
+        const rrl_adam_seg_t& sg = segs[k];
+        if (!sg.p || !sg.g || !sg.m || !sg.v || !sg.step_dev || sg.n <= 0) return RRL_EINVAL;
+        a.seg[k] = sg;
+        a.first_block[k + 1] = a.first_block[k] + (grid_for(sg.n) < 64 ? grid_for(sg.n) : 64);
+    }
+    for (int k = n_seg; k < RRL_ADAM_MAX_SEGS; ++k) a.first_block[k + 1] = a.first_block[n_seg];
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(a.first_block[n_seg]), dim3(kBlock), 0, (hipStream_t)stream, a, n_seg,
+                       lr, beta1, beta2, eps);
+    return check_launch();
+}
+
+int rrl_normal_fill(long long n_pairs, uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                    float* out, void* stream) {
+    if (!out || n_pairs <= 0 || n_pairs >= (1LL << 32)) return RRL_EINVAL;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3(grid_for(n_pairs)), dim3(kBlock), 0, (hipStream_t)stream, n_pairs,
+                       seed, counter, counter_dev, counter_inc, out);
     return check_launch();
 }
 

@@ -101,8 +101,8 @@ class VectorLoop:
             if self._actor is None:
                 from .fast_update import FastActor
                 self._actor = FastActor(fast, self.n)
-            action, real_action, rec = self._actor.act(obs, cfg.eps_safe, cfg.use_recovery, cfg.MF_recovery)
-            return action, real_action, (rec.bool() if rec is not None else None)
+            # recovery stays uint8 (what the step kernel reads): no dtype round trip in the captured graph
+            return self._actor.act(obs, cfg.eps_safe, cfg.use_recovery, cfg.MF_recovery)
         if random_actions:
             action = self.env.sample_actions()
         else:
@@ -139,12 +139,12 @@ class VectorLoop:
             self.recovery_memory.push(state, real_action, constraint_f, next_state, mask)
             if cfg.add_both_transitions and recovery is not None:           # :446-448
                 self.memory.push(state, real_action, push_reward, next_state, mask,
-                                 valid=recovery.to(torch.uint8))
+                                 valid=recovery.to(torch.uint8).contiguous())
         # counters (experiment.py:66-74,455-461), all on the device
         ep_done = info["ep_done"].bool()
         cons = info["constraint"].bool()
         end_viol = ep_done & cons
-        rec = recovery if recovery is not None else torch.zeros_like(cons)
+        rec = recovery.bool() if recovery is not None else torch.zeros_like(cons)
         st = self.stats
         st[0] += self.n
         st[1] += ep_done.sum()

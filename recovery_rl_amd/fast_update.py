@@ -61,6 +61,18 @@ class FlatNet:
         _lib.check(rc, "rrl_adam_step")
 
 
+def adam_multi(lr, nets, betas=(0.9, 0.999), eps=1e-8):
+    """One rrl_adam_step_multi launch over several FlatNets: nets = [(net, target or None, tau), ...]."""
+    lib = _lib.load()
+    segs = (_lib.rrl_adam_seg_t * len(nets))()
+    for k, (net, target, tau) in enumerate(nets):
+        segs[k] = _lib.rrl_adam_seg_t(net.flat.numel(), net.flat.data_ptr(), net.grad.data_ptr(), net.m.data_ptr(),
+                                      net.v.data_ptr(), net.step.data_ptr(),
+                                      None if target is None else target.flat.data_ptr(), tau)
+    _lib.check(lib.rrl_adam_step_multi(len(nets), segs, lr, betas[0], betas[1], eps, _lib.current_stream()),
+               "rrl_adam_step_multi")
+
+
 def flatten_twin_q(net, device):
     """QNetwork / QNetworkConstraint -> FlatNet with heads stacked: W1 [2,H,din] ... b3 [2,1]."""
     H, din = net.linear1.weight.shape
@@ -202,6 +214,10 @@ class FastUpdater:
         self.dact = z(B, 2)
         self.losses = z(8)   # q1, q2, policy, (pad) | qr1, qr2, recpolicy, (pad)
         self._noise = None
+        self._noise_buf, self._actor_noise, self._actor_noise_fresh = None, None, False
+        self.actor_rows = 0
+        self.noise_seed = (int(getattr(agent, "seed", 0)) ^ 0x6E6F697365) & 0xFFFFFFFFFFFFFFFF
+        self.noise_tick = torch.zeros(2, dtype=torch.int64, device=dev)
         self.alpha = torch.full((1,), float(agent.alpha), dtype=torch.float32, device=dev)
         self.scale = agent.policy.action_scale.to(dev).float().contiguous()
         self.bias = agent.policy.action_bias.to(dev).float().contiguous()
@@ -225,20 +241,44 @@ class FastUpdater:
     def rows(self):
         return (self.xu, self.x2u, self.xpu)
 
+    def _fill_noise(self):
+        """ONE rrl_normal_fill launch per lock-step iteration: the 4 [B,2] draws of the two updates followed
+        by the 2 [N,2] draws of the acting pass (Philox stream RRL_STREAM_NOISE, device-side tick)."""
+        n_act = self.actor_rows
+        need = 4 * self.B * 2 + 2 * n_act * 2
+        if self._noise_buf is None or self._noise_buf.numel() != need:
+            self._noise_buf = torch.zeros(need, dtype=torch.float32, device=self.dev)
+        self._check(self.lib.rrl_normal_fill(need // 2, self.noise_seed, 0, _lib.ptr(self.noise_tick), 1,
+                                             _lib.ptr(self._noise_buf), _lib.current_stream()), "rrl_normal_fill")
+        self._noise = self._noise_buf[:4 * self.B * 2].view(4, self.B, 2)
+        self._actor_noise = self._noise_buf[4 * self.B * 2:].view(2, n_act, 2) if n_act else None
+        self._actor_noise_fresh = n_act > 0
+
     def noise(self, which):
-        """Policy noise for the two updates of one iteration: ONE randn launch serves both
-        (which = 0: SAC update draws fresh noise, 1: Q_risk update uses the second half)."""
+        """Policy noise for the two updates of one iteration (which = 0: the SAC update draws fresh noise for
+        the whole iteration, 1: the Q_risk update uses the second half)."""
         if which == 0 or self._noise is None:
-            self._noise = torch.randn(4, self.B, 2, device=self.dev)
+            self._fill_noise()
         n = self._noise
         return (n[0], n[1]) if which == 0 else (n[2], n[3])
+
+    def actor_noise(self, n):
+        """[2, n, 2] draws for FastActor: the tail of this iteration's fill, or its own fill when the updates did
+        not run (or ran for a different n) since the last acting pass."""
+        if self.actor_rows != n:
+            self.actor_rows = n
+            self._actor_noise_fresh = False
+        if not self._actor_noise_fresh:
+            self._fill_noise()
+        self._actor_noise_fresh = False
+        return self._actor_noise
 
     def _gauss_fwd(self, head, eps, action_view, logp):
         t, n_part, ps = head
         self._check(self.lib.rrl_gauss_head_fwd(self.B, t.data_ptr(), n_part, ps, eps.data_ptr(),
                                                 self.scale.data_ptr(), self.bias.data_ptr(),
                                                 action_view.data_ptr(), action_view.stride(0), logp.data_ptr(),
-                                                None, _lib.current_stream()), "rrl_gauss_head_fwd")
+                                                None, None, None, _lib.current_stream()), "rrl_gauss_head_fwd")
 
     # -- SAC -------------------------------------------------------------------------------------
     def sac_update(self, batch, eps_next, eps_pi, rows_loaded=False):
@@ -267,8 +307,8 @@ class FastUpdater:
                                            dx[0, :, 2:4].data_ptr(), dx.stride(1), 2, dx.stride(0),
                                            float(ag.alpha) / B, self.dhead.data_ptr(), st), "rrl_gauss_head_bwd")
         self.pol_b.backward(self.dhead)
-        self.critic.adam(ag.lr, target=self.critic_target, tau=ag.tau)        # + soft update (:273-274)
-        self.policy.adam(ag.lr)
+        # both optimiser steps + the soft target update (:273-274) in one launch
+        adam_multi(ag.lr, [(self.critic, self.critic_target, ag.tau), (self.policy, None, 0.0)])
         return self.losses
 
     # -- Q_risk ------------------------------------------------------------------------------------
@@ -322,17 +362,17 @@ class FastActor:
         """-> (task action [n,2], executed action [n,2], recovery u8[n] or None); persistent buffers."""
         f, n, lib, st = self.f, self.n, self.f.lib, _lib.current_stream()
         if noise is None:
-            noise = torch.randn(2, n, 2, device=f.dev)
+            noise = f.actor_noise(n)
         head, hn, hs = self.pol.forward(obs, save=False)
         if not use_recovery:
             _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), hn, hs, noise[0].data_ptr(), f.scale.data_ptr(),
-                                              f.bias.data_ptr(), self.task_action.data_ptr(), 2, None, None, st),
-                       "rrl_gauss_head_fwd")
+                                              f.bias.data_ptr(), self.task_action.data_ptr(), 2, None, None, None,
+                                              None, st), "rrl_gauss_head_fwd")
             return self.task_action, self.task_action, None
-        self.xa[:, 0:2] = obs
+        # the head kernel also copies obs into columns 0..1 of xa: [s | a_task] is assembled without a copy launch
         _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), hn, hs, noise[0].data_ptr(), f.scale.data_ptr(),
-                                          f.bias.data_ptr(), self.xa[:, 2:4].data_ptr(), 4, None, None, st),
-                   "rrl_gauss_head_fwd")
+                                          f.bias.data_ptr(), self.xa[:, 2:4].data_ptr(), 4, None, None,
+                                          obs.data_ptr(), self.xa.data_ptr(), st), "rrl_gauss_head_fwd")
         self.qr.finalize = True                  # recovery_select reads a plain [2,n] tensor
         zq, _, _ = self.qr.forward(self.xa, save=False)
         assert mf_recovery, "FastActor covers the model-free recovery policy"

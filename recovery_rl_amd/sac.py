@@ -29,6 +29,7 @@ class SAC(object):
         if getattr(args, "cnn", False):
             raise NotImplementedError("image observations are outside the hot path (SURVEY.md section 2)")
         self.gamma = args.gamma
+        self.seed = int(getattr(args, "seed", 0))
         self.tau = args.tau
         self.alpha = args.alpha
         self.env_name = args.env_name

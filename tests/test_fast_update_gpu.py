@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import arg_utils
+from recovery_rl_amd import _lib
 from recovery_rl_amd.sac import SAC
 from recovery_rl_amd.spaces import Box
 
@@ -189,3 +190,47 @@ def test_fast_actor_matches_module_path():
     assert 0 < int(rec.sum()) < n
     task2, real2, rec2 = actor.act(obs, thr, False, False, noise=noise)
     assert rec2 is None and torch.allclose(task2, a_ref, rtol=1e-4, atol=1e-5)
+
+
+def test_normal_fill_is_the_documented_philox_stream():
+    """rrl_normal_fill: pair i = Philox normal (seed, i, stream 8, tick), f32-rounded; bit-exact vs the C checker;
+    the device tick advances per launch (graph-replay safe)."""
+    from oracle import c_oracle
+    lib = _lib.load()
+    n, seed = 1500, 0xABCDEF12345
+    out = torch.zeros(n, 2, device=DEV)
+    tick = torch.zeros(2, dtype=torch.int64, device=DEV)
+    for t in range(2):
+        _lib.check(lib.rrl_normal_fill(n, seed, 0, _lib.ptr(tick), 1, _lib.ptr(out), _lib.current_stream()), "fill")
+        want = c_oracle.normals(seed, n, 8, t).astype(np.float32)
+        assert np.array_equal(out.cpu().numpy(), want)
+    assert int(tick[0].item()) == 2
+    z = torch.zeros(1 << 18, 2, device=DEV)
+    _lib.check(lib.rrl_normal_fill(1 << 18, 7, 3, None, 0, _lib.ptr(z), _lib.current_stream()), "fill")
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1) < 5e-3
+
+
+def test_adam_multi_equals_separate_adam_steps():
+    from recovery_rl_amd.fast_update import FlatNet, adam_multi
+    torch.manual_seed(0)
+    shapes = [[("a", (300, 7)), ("b", (11,))], [("w", (40000,))], [("c", (5, 5))]]
+    nets_a = [FlatNet(sh, DEV) for sh in shapes]
+    nets_b = [FlatNet(sh, DEV) for sh in shapes]
+    tgt_a, tgt_b = FlatNet(shapes[0], DEV), FlatNet(shapes[0], DEV)
+    for na, nb in zip(nets_a, nets_b):
+        na.flat.normal_()
+        nb.flat.copy_(na.flat)
+    tgt_a.flat.normal_()
+    tgt_b.flat.copy_(tgt_a.flat)
+    for step in range(3):
+        for na, nb in zip(nets_a, nets_b):
+            na.grad.normal_()
+            nb.grad.copy_(na.grad)
+        nets_a[0].adam(3e-4, target=tgt_a, tau=0.005)
+        nets_a[1].adam(3e-4)
+        nets_a[2].adam(3e-4)
+        adam_multi(3e-4, [(nets_b[0], tgt_b, 0.005), (nets_b[1], None, 0.0), (nets_b[2], None, 0.0)])
+    for na, nb in zip(nets_a, nets_b):
+        assert torch.equal(na.flat, nb.flat) and torch.equal(na.m, nb.m) and torch.equal(na.v, nb.v)
+        assert int(nb.step[0].item()) == 3 and int(nb.step[1].item()) == 0
+    assert torch.equal(tgt_a.flat, tgt_b.flat)
