@@ -240,6 +240,37 @@ int rrl_mlp_head_backward(int G, int B, int H, int dout, const float* dOut, cons
 int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const float* x, int ldx,
                            const float* W1, float* dW1, float* db1, float* dx, void* stream);
 
+/* rrl_mlp_head_backward with dOut produced in the kernel from a loss description instead of read from memory:
+ * saves the stand-alone rrl_*_grad / rrl_*_head_bwd launch in front of every stack backward (same formulas,
+ * bit-identical dOut).  kind selects the formula and the meaning of the fields:
+ *   RRL_LOSS_SAC_CRITIC   (G=2,dout=1) out=q, out_t=qt, v0=logp2, v1=r, v2=m, v3=penalty (nullable), alpha,
+ *                         f0=gamma; loss[2] = the two MSEs                              (sac.py:192-214)
+ *   RRL_LOSS_SAC_POLICY   (G=2,dout=1) out=qp, v0=logp, alpha; loss[1]                  (sac.py:216-231)
+ *   RRL_LOSS_QRISK_CRITIC (G=2,dout=1) out=z, out_t=zt, v0=c, v1=m, f0=gamma_safe; loss[2]   (qrisk.py:118-148)
+ *   RRL_LOSS_QRISK_POLICY (G=2,dout=1) out=zp; loss[1]                                  (qrisk.py:150-154)
+ *   RRL_LOSS_GAUSS_HEAD   (G=1,dout=4) out=head, v0=eps, v1=scale, f0=dlogp, d_action/ld/n_heads/head_stride
+ *                         (the backward of GaussianPolicy.sample, model.py:324-340)
+ *   RRL_LOSS_STOCH_HEAD   (G=1,dout=2) out=raw, v0=eps, v1=log_std, v2=scale, f0=min_log_std, d_action...;
+ *                         loss[2] = dlog_std                                            (model.py:511-525)
+ * out / out_t take (n_part, part_stride) like the stand-alone kernels. */
+enum { RRL_LOSS_SAC_CRITIC = 0, RRL_LOSS_SAC_POLICY = 1, RRL_LOSS_QRISK_CRITIC = 2, RRL_LOSS_QRISK_POLICY = 3,
+       RRL_LOSS_GAUSS_HEAD = 4, RRL_LOSS_STOCH_HEAD = 5 };
+typedef struct {
+    int kind;
+    int n_part;
+    long long part_stride;
+    const float *out, *out_t;
+    const float *v0, *v1, *v2, *v3;
+    const float* alpha;
+    float f0;
+    int ld, n_heads;
+    long long head_stride;
+    const float* d_action;
+    float* loss;
+} rrl_loss_t;
+int rrl_mlp_head_backward_loss(const rrl_loss_t* loss, int G, int B, int H, int dout, const float* h2,
+                               const float* W3, float* dW3, float* db3, float* dh2, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Fused element-wise pieces of the updates (one launch each instead of a chain of PyTorch ops).
  *   rrl_gauss_head_fwd/bwd   GaussianPolicy.sample and its backward (recovery_rl/model.py:324-340);

@@ -1,0 +1,12 @@
+#!/bin/bash
+# rocprofv3 kernel stats of the default bench command -> gpurun_out/bench_prof/
+set -u
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/bench_prof
+mkdir -p $OUT
+rm -rf /tmp/bench_prof
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bench_prof -o p -- python $R/bench.py --no_cpu_baseline "$@" > $OUT/bench_under_rocprof.json 2>/tmp/bench_prof.err
+cp $(find /tmp/bench_prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+python $R/profiles/kernel_breakdown.py $OUT/kernel_stats.csv 333 > $OUT/breakdown.txt
+head -32 $OUT/breakdown.txt

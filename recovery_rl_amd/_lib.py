@@ -26,7 +26,8 @@ EXPORTS = [
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_nav_step_push",
     "rrl_cem_sample", "rrl_cem_update",
-    "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_input_backward",
+    "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss",
+    "rrl_mlp_input_backward",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_adam_step_multi", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
@@ -75,6 +76,15 @@ class rrl_episode_log_t(C.Structure):
 
 EPLOG_I32 = 6
 ADAM_MAX_SEGS = 4
+LOSS_SAC_CRITIC, LOSS_SAC_POLICY, LOSS_QRISK_CRITIC, LOSS_QRISK_POLICY, LOSS_GAUSS_HEAD, LOSS_STOCH_HEAD = range(6)
+
+
+class rrl_loss_t(C.Structure):
+    _fields_ = [("kind", C.c_int), ("n_part", C.c_int), ("part_stride", C.c_longlong), ("out", C.c_void_p),
+                ("out_t", C.c_void_p), ("v0", C.c_void_p), ("v1", C.c_void_p), ("v2", C.c_void_p),
+                ("v3", C.c_void_p), ("alpha", C.c_void_p), ("f0", C.c_float), ("ld", C.c_int),
+                ("n_heads", C.c_int), ("head_stride", C.c_longlong), ("d_action", C.c_void_p),
+                ("loss", C.c_void_p)]
 
 
 class rrl_adam_seg_t(C.Structure):
@@ -122,6 +132,7 @@ def _declare(lib):
         "rrl_mlp3_forward": (ci, [ci, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
         "rrl_mlp3_is_split": (ci, [ci, ci]),
         "rrl_mlp_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_mlp_head_backward_loss": (ci, [C.POINTER(rrl_loss_t), ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
         "rrl_mlp_input_backward": (ci, [ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_gauss_head_fwd": (ci, [ci, vp, ci, ll, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_gauss_head_bwd": (ci, [ci, vp, ci, ll, vp, vp, vp, ci, ci, ll, f32, vp, vp]),

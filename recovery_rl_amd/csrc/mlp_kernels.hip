@@ -501,6 +501,179 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int dout,
     }
 }
 
+// ---- the same kernel with dOut computed from a loss description (rrl_loss_t) ----------------------------
+// Formulas are those of update_kernels.hip (sac/qrisk *_grad, gauss/stoch_head_bwd), evaluated per (g, b, o).
+namespace loss {
+
+constexpr float kLogSigMax = 2.f, kLogSigMin = -20.f, kEps = 1e-6f;   // model.py:14-16
+
+__device__ __forceinline__ float sigm(float z) { return 1.f / (1.f + expf(-z)); }
+
+__device__ __forceinline__ float psum(const float* p, long long idx, int np, long long ps) {
+    float v = p[idx];
+    for (int z = 1; z < np; ++z) v += p[z * ps + idx];
+    return v;
+}
+
+// dOut[g][b][o]; `term` = this element's contribution to loss[g] (critics), loss[0] (policies, g == 0 only)
+// or dlog_std[o] (stochastic head)
+template <int KIND>
+__device__ __forceinline__ float dout_at(const rrl_loss_t& a, int B, int g, int b, int o, float& term) {
+    const int np = a.n_part;
+    const long long ps = a.part_stride;
+    term = 0.f;
+    if constexpr (KIND == RRL_LOSS_SAC_CRITIC) {
+        float y = a.v1[b] + a.v2[b] * a.f0 *
+                                (fminf(psum(a.out_t, b, np, ps), psum(a.out_t, B + b, np, ps)) - a.alpha[0] * a.v0[b]);
+        if (a.v3) y -= a.v3[b];
+        const float e = psum(a.out, (long long)g * B + b, np, ps) - y;
+        term = e * e;
+        return 2.f * e / B;
+    } else if constexpr (KIND == RRL_LOSS_SAC_POLICY) {
+        const float q0 = psum(a.out, b, np, ps), q1 = psum(a.out, B + b, np, ps);
+        const float w0 = q0 < q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
+        if (g == 0) term = a.alpha[0] * a.v0[b] - fminf(q0, q1);
+        return g == 0 ? -w0 / B : -(1.f - w0) / B;
+    } else if constexpr (KIND == RRL_LOSS_QRISK_CRITIC) {
+        const float y = a.v0[b] + a.v1[b] * a.f0 *
+                                      fmaxf(sigm(psum(a.out_t, b, np, ps)), sigm(psum(a.out_t, B + b, np, ps)));
+        const float q = sigm(psum(a.out, (long long)g * B + b, np, ps));
+        const float e = q - y;
+        term = e * e;
+        return 2.f * e / B * q * (1.f - q);
+    } else if constexpr (KIND == RRL_LOSS_QRISK_POLICY) {
+        const float q0 = sigm(psum(a.out, b, np, ps)), q1 = sigm(psum(a.out, B + b, np, ps));
+        const float w0 = q0 > q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
+        if (g == 0) term = fmaxf(q0, q1);
+        return g == 0 ? w0 / B * q0 * (1.f - q0) : (1.f - w0) / B * q1 * (1.f - q1);
+    } else if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
+        const int j = o & 1;
+        float da = 0.f;
+        for (int hd = 0; hd < a.n_heads; ++hd) da += a.d_action[hd * a.head_stride + (long long)b * a.ld + j];
+        const float mean = psum(a.out, 4 * b + j, np, ps);
+        const float raw = psum(a.out, 4 * b + 2 + j, np, ps);
+        const float ls = fminf(fmaxf(raw, kLogSigMin), kLogSigMax);
+        const float sd = expf(ls), e = a.v0[2 * b + j], sc = a.v1[j];
+        const float y = tanhf(mean + sd * e);
+        const float one_m = 1.f - y * y;
+        const float dx = da * sc * one_m + a.f0 * (2.f * sc * y * one_m) / (sc * one_m + kEps);
+        if (o < 2) return dx;
+        const bool inside = (raw >= kLogSigMin) & (raw <= kLogSigMax);
+        return inside ? (dx * sd * e - a.f0) : 0.f;
+    } else {
+        const int j = o;
+        const float t = tanhf(psum(a.out, 2 * b + j, np, ps));
+        float da = 0.f;
+        for (int hd = 0; hd < a.n_heads; ++hd) da += a.d_action[hd * a.head_stride + (long long)b * a.ld + j];
+        const float sd = expf(fmaxf(a.v1[j], a.f0));
+        term = (a.v1[j] >= a.f0) ? da * sd * a.v0[2 * b + j] : 0.f;
+        return da * a.v2[j] * (1.f - t * t);
+    }
+}
+
+}  // namespace loss
+
+template <int KIND>
+__global__ __launch_bounds__(256) void head_bwd_loss_kernel(rrl_loss_t la, int B, int H, int dout,
+                                                            const float* __restrict__ h2,
+                                                            const float* __restrict__ W3, float* __restrict__ dW3,
+                                                            float* __restrict__ db3, float* __restrict__ dh2,
+                                                            int need_w) {
+    __shared__ float red[kSlices][4][kCols];
+    __shared__ float dsh[1024 * 4];
+    const int g = blockIdx.y, hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols;
+    const int h = blockIdx.x * kCols + hc;
+    const bool hok = h < H;
+    const int hh = hok ? h : H - 1;
+    float lsum[2] = {0.f, 0.f};
+    if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
+        // one thread per (row, action dim): the mean and log-std gradients share tanh/exp
+        for (int e = threadIdx.x; e < B * 2; e += 256) {
+            const int b = e >> 1, j = e & 1;
+            float term;
+            const float dx = loss::dout_at<KIND>(la, B, g, b, j, term);
+            const float raw = loss::psum(la.out, 4 * b + 2 + j, la.n_part, la.part_stride);
+            const bool inside = (raw >= loss::kLogSigMin) & (raw <= loss::kLogSigMax);
+            const float sd = expf(fminf(fmaxf(raw, loss::kLogSigMin), loss::kLogSigMax));
+            dsh[4 * b + j] = dx;
+            dsh[4 * b + 2 + j] = inside ? (dx * sd * la.v0[2 * b + j] - la.f0) : 0.f;
+        }
+    } else {
+        for (int e = threadIdx.x; e < B * dout; e += 256) {
+            const int b = e / dout, o = e - b * dout;
+            float term;
+            dsh[e] = loss::dout_at<KIND>(la, B, g, b, o, term);
+            if (KIND == RRL_LOSS_STOCH_HEAD && o == 1) lsum[1] += term; else lsum[0] += term;
+        }
+    }
+    float w[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) w[o] = o < dout ? W3[((long long)g * dout + o) * H + hh] : 0.f;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += kSlices * kUnroll) {
+        float a[kUnroll];
+#pragma unroll
+        for (int it = 0; it < kUnroll; ++it) {
+            const int b = min(b0 + slice + kSlices * it, B - 1);
+            a[it] = h2[((long long)g * B + b) * H + hh];
+        }
+#pragma unroll
+        for (int it = 0; it < kUnroll; ++it) {
+            const int b = b0 + slice + kSlices * it;
+            if (b < B) {
+                float d = 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const float go = o < dout ? dsh[b * dout + o] : 0.f;
+                    d = fmaf(go, w[o], d);
+                    acc[o] = fmaf(go, a[it], acc[o]);
+                }
+                if (hok) dh2[((long long)g * B + b) * H + h] = a[it] > 0.f ? d : 0.f;
+            }
+        }
+    }
+    if (need_w) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) red[slice][o][hc] = acc[o];
+        __syncthreads();
+        if (slice < dout && hok) {
+            float sum = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < kSlices; ++sl) sum += red[sl][slice][hc];
+            dW3[((long long)g * dout + slice) * H + h] = sum;
+        }
+        if (blockIdx.x == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + (unsigned)dout) {   // bias gradient
+            const int o = threadIdx.x - 128;
+            float sum = 0.f;
+            for (int b = 0; b < B; ++b) sum += dsh[b * dout + o];
+            db3[g * dout + o] = sum;
+        }
+    }
+    // loss scalars / dlog_std: one workgroup per head reduces the per-thread terms in a fixed tree
+    constexpr bool per_head = KIND == RRL_LOSS_SAC_CRITIC || KIND == RRL_LOSS_QRISK_CRITIC;
+    if (blockIdx.x != 0 || !la.loss || KIND == RRL_LOSS_GAUSS_HEAD || (!per_head && g != 0)) return;
+    __syncthreads();
+    float* r0 = &red[0][0][0];          // 1024 floats: two arrays of 256
+    r0[threadIdx.x] = lsum[0];
+    r0[256 + threadIdx.x] = lsum[1];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            r0[threadIdx.x] += r0[threadIdx.x + off];
+            r0[256 + threadIdx.x] += r0[256 + threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if constexpr (KIND == RRL_LOSS_STOCH_HEAD) {
+            la.loss[0] = r0[0];
+            la.loss[1] = r0[256];
+        } else {
+            la.loss[per_head ? g : 0] = r0[0] / B;
+        }
+    }
+}
+
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
 //   dW1[g][h][d] = sum_b dh1[g][b][h] x[b][d]     db1[g][h] = sum_b dh1[g][b][h]          (need_w)
 //   dx[g][b][d]  = sum_h dh1[g][b][h] W1[g][h][d]                                         (need_x)
@@ -646,6 +819,35 @@ int rrl_mlp_head_backward(int G, int B, int H, int dout, const float* dOut, cons
     const int need_w = dW3 != nullptr && db3 != nullptr;
     hipLaunchKernelGGL(head_bwd_kernel, dim3((H + kCols - 1) / kCols, G), dim3(256), 0, (hipStream_t)stream, B, H, dout, dOut,
                        h2, W3, dW3, db3, dh2, need_w);
+    return check_launch();
+}
+
+int rrl_mlp_head_backward_loss(const rrl_loss_t* la, int G, int B, int H, int dout, const float* h2,
+                               const float* W3, float* dW3, float* db3, float* dh2, void* stream) {
+    if (!la || !la->out || !h2 || !W3 || !dh2) return RRL_EINVAL;
+    if (G <= 0 || B <= 0 || B > 1024 || H <= 0 || dout <= 0 || dout > 4 || la->n_part <= 0) return RRL_ERANGE;
+    const int heads = la->kind <= RRL_LOSS_QRISK_POLICY ? 2 : 1;
+    const int width = la->kind <= RRL_LOSS_QRISK_POLICY ? 1 : (la->kind == RRL_LOSS_GAUSS_HEAD ? 4 : 2);
+    if (G != heads || dout != width) return RRL_EINVAL;
+    const int need_w = dW3 != nullptr && db3 != nullptr;
+    const dim3 grid((H + kCols - 1) / kCols, G), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define RRL_LAUNCH_LOSS(K)                                                                                   \
+    case K:                                                                                                  \
+        hipLaunchKernelGGL((head_bwd_loss_kernel<K>), grid, block, 0, st, *la, B, H, dout, h2, W3, dW3, db3, \
+                           dh2, need_w);                                                                     \
+        break;
+    switch (la->kind) {
+        RRL_LAUNCH_LOSS(RRL_LOSS_SAC_CRITIC)
+        RRL_LAUNCH_LOSS(RRL_LOSS_SAC_POLICY)
+        RRL_LAUNCH_LOSS(RRL_LOSS_QRISK_CRITIC)
+        RRL_LAUNCH_LOSS(RRL_LOSS_QRISK_POLICY)
+        RRL_LAUNCH_LOSS(RRL_LOSS_GAUSS_HEAD)
+        RRL_LAUNCH_LOSS(RRL_LOSS_STOCH_HEAD)
+        default:
+            return RRL_EINVAL;
+    }
+#undef RRL_LAUNCH_LOSS
     return check_launch();
 }
 

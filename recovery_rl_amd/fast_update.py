@@ -13,6 +13,8 @@ the Polyak target update are one kernel over the flat buffer.
 """
 import math
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -161,17 +163,25 @@ class Stack:
         return self.parts
 
     def backward(self, dout, weight_grads=True, input_grad=False):
-        """dout [G, B, dout].  Writes parameter gradients into net.g (weight_grads) and/or returns
+        """dout: [G, B, dout] tensor, or an rrl_loss_t describing how the kernel computes it itself
+        (rrl_mlp_head_backward_loss).  Writes parameter gradients into net.g (weight_grads) and/or returns
         dL/dx per head [G, B, din] (input_grad)."""
         P, Gr = self.net.p, self.net.g
         net, lib, st = self.net, _lib.load(), _lib.current_stream()
         G, B, H = net.G, self.B, net.H
-        assert dout.is_contiguous() and self.x.stride(1) == 1
+        assert self.x.stride(1) == 1
+        gw3 = Gr["W3"].data_ptr() if weight_grads else None
+        gb3 = Gr["b3"].data_ptr() if weight_grads else None
         # last layer (1..4 outputs): dW3, db3 and the masked dh2 in one streaming kernel
-        _lib.check(lib.rrl_mlp_head_backward(G, B, H, net.dout, dout.data_ptr(), self.h2.data_ptr(),
-                                             P["W3"].data_ptr(), Gr["W3"].data_ptr() if weight_grads else None,
-                                             Gr["b3"].data_ptr() if weight_grads else None, self.dh2.data_ptr(), st),
-                   "rrl_mlp_head_backward")
+        if isinstance(dout, _lib.rrl_loss_t):
+            _lib.check(lib.rrl_mlp_head_backward_loss(C.byref(dout), G, B, H, net.dout, self.h2.data_ptr(),
+                                                      P["W3"].data_ptr(), gw3, gb3, self.dh2.data_ptr(), st),
+                       "rrl_mlp_head_backward_loss")
+        else:
+            assert dout.is_contiguous()
+            _lib.check(lib.rrl_mlp_head_backward(G, B, H, net.dout, dout.data_ptr(), self.h2.data_ptr(),
+                                                 P["W3"].data_ptr(), gw3, gb3, self.dh2.data_ptr(), st),
+                       "rrl_mlp_head_backward")
         # hidden layer: the two H x H GEMMs on the MFMA kernel
         if weight_grads:
             gemm(TN, self.dh2, self.h1, out=Gr["W2"], colsum=Gr["b2"])
@@ -213,6 +223,7 @@ class FastUpdater:
         self.dq, self.dhead, self.draw = z(2, B, 1), z(1, B, 4), z(1, B, 2)
         self.dact = z(B, 2)
         self.losses = z(8)   # q1, q2, policy, (pad) | qr1, qr2, recpolicy, (pad)
+        self.fuse_loss = True      # loss gradients computed inside the head-backward kernels (no grad launches)
         self._noise = None
         self._noise_buf, self._actor_noise, self._actor_noise_fresh = None, None, False
         self.actor_rows = 0
@@ -225,6 +236,18 @@ class FastUpdater:
         self.rbias = self.qr.policy.action_bias.to(dev).float().contiguous()
 
     # -- helpers ---------------------------------------------------------------------------------
+    def _loss(self, kind, out, n_part, part_stride, out_t=None, v0=None, v1=None, v2=None, v3=None, alpha=None,
+              f0=0.0, d_action=None, loss=None):
+        """rrl_loss_t for Stack.backward: the head-backward kernel evaluates the loss gradient itself.
+        d_action = the critic's input gradient dx [2, B, 4] whose action columns feed a policy head."""
+        p = _lib.ptr
+        ld = n_heads = hs = 0
+        da = None
+        if d_action is not None:
+            da, ld, n_heads, hs = d_action[0, :, 2:4].data_ptr(), d_action.stride(1), 2, d_action.stride(0)
+        return _lib.rrl_loss_t(kind, n_part, part_stride, p(out), p(out_t), p(v0), p(v1), p(v2), p(v3), p(alpha),
+                               float(f0), ld, n_heads, hs, da, p(loss))
+
     def _check(self, rc, what):
         _lib.check(rc, what)
 
@@ -289,24 +312,36 @@ class FastUpdater:
         self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
         qt, n_part, ps = self.cri_b.forward(self.x2u, params=self.critic_target, save=False)
         q, _, _ = self.cri_a.forward(self.xu)
-        self._check(lib.rrl_sac_critic_grad(B, q.data_ptr(), qt.data_ptr(), n_part, ps, self.logp2.data_ptr(),
-                                            r.data_ptr(), m.data_ptr(), ag.gamma, self.alpha.data_ptr(), None,
-                                            self.dq.data_ptr(), self.losses.data_ptr(), st), "rrl_sac_critic_grad")
-        self.cri_a.backward(self.dq)                                   # critic gradients (sac.py:233-235)
+        if self.fuse_loss:                                             # critic gradients (sac.py:233-235)
+            self.cri_a.backward(self._loss(_lib.LOSS_SAC_CRITIC, q, n_part, ps, out_t=qt, v0=self.logp2, v1=r, v2=m,
+                                           alpha=self.alpha, f0=ag.gamma, loss=self.losses))
+        else:
+            self._check(lib.rrl_sac_critic_grad(B, q.data_ptr(), qt.data_ptr(), n_part, ps, self.logp2.data_ptr(),
+                                                r.data_ptr(), m.data_ptr(), ag.gamma, self.alpha.data_ptr(), None,
+                                                self.dq.data_ptr(), self.losses.data_ptr(), st),
+                        "rrl_sac_critic_grad")
+            self.cri_a.backward(self.dq)
         # policy loss at the PRE-update critic (both gradients before either step)
         head = self.pol_b.forward(s)
         self._gauss_fwd(head, eps_pi, self.xpu[:, 2:4], self.logp)
         qp, n_part, ps = self.cri_b.forward(self.xpu)
-        self._check(lib.rrl_sac_policy_grad(B, qp.data_ptr(), n_part, ps, self.logp.data_ptr(),
-                                            self.alpha.data_ptr(), self.dq.data_ptr(), self.losses[2:].data_ptr(),
-                                            st), "rrl_sac_policy_grad")
-        dx = self.cri_b.backward(self.dq, weight_grads=False, input_grad=True)      # [2,B,4]
-        # d pi = action columns of dx, summed over the two critic heads inside the head kernel
         ht, hn, hs = head
-        self._check(lib.rrl_gauss_head_bwd(B, ht.data_ptr(), hn, hs, eps_pi.data_ptr(), self.scale.data_ptr(),
-                                           dx[0, :, 2:4].data_ptr(), dx.stride(1), 2, dx.stride(0),
-                                           float(ag.alpha) / B, self.dhead.data_ptr(), st), "rrl_gauss_head_bwd")
-        self.pol_b.backward(self.dhead)
+        if self.fuse_loss:
+            dx = self.cri_b.backward(self._loss(_lib.LOSS_SAC_POLICY, qp, n_part, ps, v0=self.logp, alpha=self.alpha,
+                                                loss=self.losses[2:]), weight_grads=False, input_grad=True)
+            # d pi = action columns of dx [2,B,4], summed over the two critic heads inside the policy's head backward
+            self.pol_b.backward(self._loss(_lib.LOSS_GAUSS_HEAD, ht, hn, hs, v0=eps_pi, v1=self.scale,
+                                           f0=float(ag.alpha) / B, d_action=dx))
+        else:
+            self._check(lib.rrl_sac_policy_grad(B, qp.data_ptr(), n_part, ps, self.logp.data_ptr(),
+                                                self.alpha.data_ptr(), self.dq.data_ptr(),
+                                                self.losses[2:].data_ptr(), st), "rrl_sac_policy_grad")
+            dx = self.cri_b.backward(self.dq, weight_grads=False, input_grad=True)      # [2,B,4]
+            self._check(lib.rrl_gauss_head_bwd(B, ht.data_ptr(), hn, hs, eps_pi.data_ptr(), self.scale.data_ptr(),
+                                               dx[0, :, 2:4].data_ptr(), dx.stride(1), 2, dx.stride(0),
+                                               float(ag.alpha) / B, self.dhead.data_ptr(), st),
+                        "rrl_gauss_head_bwd")
+            self.pol_b.backward(self.dhead)
         # both optimiser steps + the soft target update (:273-274) in one launch
         adam_multi(ag.lr, [(self.critic, self.critic_target, ag.tau), (self.policy, None, 0.0)])
         return self.losses
@@ -319,10 +354,14 @@ class FastUpdater:
         self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
         zt, n_part, ps = self.qr_b.forward(self.x2u, params=self.qrisk_target, save=False)
         z, _, _ = self.qr_a.forward(self.xu)
-        self._check(lib.rrl_qrisk_critic_grad(B, z.data_ptr(), zt.data_ptr(), n_part, ps, c.data_ptr(),
-                                              m.data_ptr(), qr.gamma_safe, self.dq.data_ptr(),
-                                              self.losses[4:].data_ptr(), st), "rrl_qrisk_critic_grad")
-        self.qr_a.backward(self.dq)
+        if self.fuse_loss:
+            self.qr_a.backward(self._loss(_lib.LOSS_QRISK_CRITIC, z, n_part, ps, out_t=zt, v0=c, v1=m,
+                                          f0=qr.gamma_safe, loss=self.losses[4:]))
+        else:
+            self._check(lib.rrl_qrisk_critic_grad(B, z.data_ptr(), zt.data_ptr(), n_part, ps, c.data_ptr(),
+                                                  m.data_ptr(), qr.gamma_safe, self.dq.data_ptr(),
+                                                  self.losses[4:].data_ptr(), st), "rrl_qrisk_critic_grad")
+            self.qr_a.backward(self.dq)
         self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau)
         if qr.MF_recovery:                                              # qrisk.py:150-158, at the UPDATED critic
             raw, rn, rs = self.rec_a.forward(s)
@@ -331,15 +370,22 @@ class FastUpdater:
                                                qr.policy.min_log_std, self.rscale.data_ptr(), self.rbias.data_ptr(),
                                                self.xpu[:, 2:4].data_ptr(), 4, None, st), "rrl_stoch_head_fwd")
             zp, n_part, ps = self.qr_b.forward(self.xpu)
-            self._check(lib.rrl_qrisk_policy_grad(B, zp.data_ptr(), n_part, ps, self.dq.data_ptr(),
-                                                  self.losses[6:].data_ptr(), st), "rrl_qrisk_policy_grad")
-            dx = self.qr_b.backward(self.dq, weight_grads=False, input_grad=True)
-            self._check(lib.rrl_stoch_head_bwd(B, raw.data_ptr(), rn, rs, eps_pi.data_ptr(), ls.data_ptr(),
-                                               qr.policy.min_log_std, self.rscale.data_ptr(),
-                                               dx[0, :, 2:4].data_ptr(), dx.stride(1), 2, dx.stride(0),
-                                               self.draw.data_ptr(), self.recpolicy.g["log_std"].data_ptr(), st),
-                        "rrl_stoch_head_bwd")
-            self.rec_a.backward(self.draw)
+            if self.fuse_loss:
+                dx = self.qr_b.backward(self._loss(_lib.LOSS_QRISK_POLICY, zp, n_part, ps, loss=self.losses[6:]),
+                                        weight_grads=False, input_grad=True)
+                self.rec_a.backward(self._loss(_lib.LOSS_STOCH_HEAD, raw, rn, rs, v0=eps_pi, v1=ls, v2=self.rscale,
+                                               f0=qr.policy.min_log_std, d_action=dx,
+                                               loss=self.recpolicy.g["log_std"]))
+            else:
+                self._check(lib.rrl_qrisk_policy_grad(B, zp.data_ptr(), n_part, ps, self.dq.data_ptr(),
+                                                      self.losses[6:].data_ptr(), st), "rrl_qrisk_policy_grad")
+                dx = self.qr_b.backward(self.dq, weight_grads=False, input_grad=True)
+                self._check(lib.rrl_stoch_head_bwd(B, raw.data_ptr(), rn, rs, eps_pi.data_ptr(), ls.data_ptr(),
+                                                   qr.policy.min_log_std, self.rscale.data_ptr(),
+                                                   dx[0, :, 2:4].data_ptr(), dx.stride(1), 2, dx.stride(0),
+                                                   self.draw.data_ptr(), self.recpolicy.g["log_std"].data_ptr(),
+                                                   st), "rrl_stoch_head_bwd")
+                self.rec_a.backward(self.draw)
             self.recpolicy.adam(qr.lr)
         return self.losses
 

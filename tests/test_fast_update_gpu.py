@@ -234,3 +234,29 @@ def test_adam_multi_equals_separate_adam_steps():
         assert torch.equal(na.flat, nb.flat) and torch.equal(na.m, nb.m) and torch.equal(na.v, nb.v)
         assert int(nb.step[0].item()) == 3 and int(nb.step[1].item()) == 0
     assert torch.equal(tgt_a.flat, tgt_b.flat)
+
+
+@pytest.mark.parametrize("hidden,B", ((32, 64), (256, 256)))
+def test_loss_fused_head_backward_is_bit_identical_to_the_separate_grad_kernels(hidden, B):
+    """rrl_mlp_head_backward_loss evaluates the formulas of the stand-alone *_grad / *_head_bwd kernels inside the
+    head-backward kernel: every parameter after 3 updates must be bit-identical, the logged losses close."""
+    _, a, _ = make_pair(hidden)
+    _, b, _ = make_pair(hidden)
+    for dst, src in ((b.critic, a.critic), (b.critic_target, a.critic_target), (b.policy, a.policy),
+                     (b.safety_critic.safety_critic, a.safety_critic.safety_critic),
+                     (b.safety_critic.safety_critic_target, a.safety_critic.safety_critic_target),
+                     (b.safety_critic.policy, a.safety_critic.policy)):
+        dst.load_state_dict(copy.deepcopy(src.state_dict()))
+    a.enable_fast_path(B)
+    b.enable_fast_path(B)
+    a.fast.fuse_loss, b.fast.fuse_loss = True, False
+    for step in range(3):
+        b_sac, b_qr, e1, e2 = batch(B, 40 + step)
+        for ag in (a, b):
+            ag.update_parameters(None, B, step, safety_critic=ag.safety_critic, batch=b_sac, eps_next=e1, eps_pi=e2)
+            ag.safety_critic.update_parameters(policy=ag.policy, batch=b_qr, eps_next=e1, eps_pi=e2)
+        for name in ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy"):
+            fa, fb = getattr(a.fast, name), getattr(b.fast, name)
+            assert torch.equal(fa.flat, fb.flat), (step, name)
+            assert torch.equal(fa.grad, fb.grad), (step, name)
+        torch.testing.assert_close(a.fast.losses, b.fast.losses, rtol=1e-5, atol=1e-7)
