@@ -30,6 +30,37 @@ def _required(cfg, key, message):
     return cfg[key]
 
 
+class _GraphedTrainStep:
+    """The ensemble training step (forward, NLL loss, backward, Adam) captured once per `MPC.train` call and
+    replayed per batch: the batch-32 loop of the reference (MPC.py:266-292) is ~40 tiny launches per step, i.e.
+    bound by launch latency from Python; a replay issues them back-to-back.  The first steps run eagerly (they are
+    ordinary training steps and double as the warm-up torch asks for before a capture)."""
+
+    WARMUP = 3
+
+    def __init__(self, mpc, batch_size):
+        self.mpc, self.graph, self.calls = mpc, None, 0
+        self.bi = torch.zeros(mpc.model.num_nets, batch_size, dtype=torch.long, device=mpc.device)
+
+    def __call__(self, bi):
+        mpc = self.mpc
+        if self.calls < self.WARMUP:
+            side = torch.cuda.Stream(device=mpc.device)
+            side.wait_stream(torch.cuda.current_stream(mpc.device))
+            with torch.cuda.stream(side):
+                mpc._train_step(bi)
+            torch.cuda.current_stream(mpc.device).wait_stream(side)
+        else:
+            self.bi.copy_(bi)
+            if self.graph is None:
+                mpc.model.optim.zero_grad(set_to_none=True)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    mpc._train_step(self.bi)            # recorded, not executed
+            self.graph.replay()
+        self.calls += 1
+
+
 class MPC:
     optimizers = {"CEM": CEMOptimizer}
     MAX_ROWS = 1 << 21       # rows per rollout chunk (activations: rows x 200 x 4 B x few)
@@ -79,6 +110,7 @@ class MPC:
         self.model = _required(self.model_init_cfg, "model_constructor",
                                "Must provide a model constructor.")(self.model_init_cfg)
         self.value_func = None
+        self.graph_train = True            # replay the ensemble training step from a hipGraph (same kernels)
         self.fused = None                  # FusedPlanner (rrl_plan_cost) when the shapes allow it
         self.use_fused_planner = True
         self._lb = torch.as_tensor(self.ac_lb, dtype=torch.float32, device=self.device)
@@ -109,18 +141,14 @@ class MPC:
             epochs = self.model_train_cfg['epochs']
         num_batch = int(np.ceil(n / batch_size))
         losses = None
+        step = _GraphedTrainStep(self, batch_size) if self.graph_train and epochs * (n // batch_size) >= 16 else None
         for _ in range(epochs):
             for b in range(num_batch):
                 bi = idxs[:, b * batch_size:(b + 1) * batch_size]
-                loss = 0.01 * (self.model.max_logvar.sum() - self.model.min_logvar.sum())
-                loss = loss + self.model.compute_decays()
-                mean, logvar = self.model(self.train_in[bi], ret_logvar=True)
-                inv_var = torch.exp(-logvar)
-                tl = ((mean - self.train_targs[bi]) ** 2) * inv_var + logvar
-                loss = loss + tl.mean(-1).mean(-1).sum()                       # :282-287
-                self.model.optim.zero_grad(set_to_none=True)
-                loss.backward()
-                self.model.optim.step()
+                if step is not None and bi.shape[1] == batch_size:
+                    step(bi)                          # one hipGraph replay: forward + backward + Adam
+                else:
+                    self._train_step(bi)
             idxs = shuffle_rows(idxs)
             if progress:
                 with torch.no_grad():
@@ -128,6 +156,18 @@ class MPC:
                     losses = ((mean - self.train_targs[idxs[:, :5000]]) ** 2).mean(-1).mean(-1)
                 print("Network training: MSE per net", losses.cpu().numpy())
         return losses
+
+    def _train_step(self, bi):
+        """One optimiser step on the bootstrap rows bi [num_nets, batch] (MPC.py:270-292)."""
+        loss = 0.01 * (self.model.max_logvar.sum() - self.model.min_logvar.sum())
+        loss = loss + self.model.compute_decays()
+        mean, logvar = self.model(self.train_in[bi], ret_logvar=True)
+        inv_var = torch.exp(-logvar)
+        tl = ((mean - self.train_targs[bi]) ** 2) * inv_var + logvar
+        loss = loss + tl.mean(-1).mean(-1).sum()                       # :282-287
+        self.model.optim.zero_grad(set_to_none=True)
+        loss.backward()
+        self.model.optim.step()
 
     def reset(self):
         mid = np.tile((self.ac_lb + self.ac_ub) / 2, [self.plan_hor])
