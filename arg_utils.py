@@ -79,6 +79,9 @@ ADDITIVE = [
                                      "or the env kernels ('env', extension)"),
     (("--checkpoint_every",), I, 0, "lock-step loop: write <logdir>/checkpoint.pt every this many log intervals "
                                     "(0 = only at the end)"),
+    (("--dp_mode",), S, "replicas", "multi-GPU mode under torchrun: 'replicas' = one independent seed per GPU "
+                                    "(reference semantics), 'env_shard' = ONE learner, envs and replay split over "
+                                    "the GPUs, gradients averaged with RCCL before every optimiser step"),
     (("--no_fast_path",), "store_true", None, "SAC / Q_risk updates through autograd instead of the fused kernels"),
     (("--resume",), S, "", "checkpoint.pt to continue from (lock-step loop; skips pre-training)"),
 ]

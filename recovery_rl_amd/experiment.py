@@ -260,11 +260,25 @@ class Experiment:
         self.rank, self.world_size = rank, world_size
         if not hasattr(exp_cfg, "num_envs"):
             exp_cfg.num_envs = 1
+        self.env_shard = world_size > 1 and getattr(exp_cfg, "dp_mode", "replicas") == "env_shard"
+        if getattr(exp_cfg, "dp_mode", "replicas") not in ("replicas", "env_shard"):
+            raise ValueError("--dp_mode must be 'replicas' or 'env_shard'")
+        if self.env_shard:
+            from .fast_update import fast_path_supported
+            if exp_cfg.num_envs < 2 or not fast_path_supported(exp_cfg) or getattr(exp_cfg, "no_fast_path", False) \
+                    or exp_cfg.batch_size % world_size or uses_mb_recovery(exp_cfg):
+                raise ValueError("--dp_mode env_shard needs the lock-step loop (--num_envs > 1), a configuration of "
+                                 "the fused update path, and batch_size divisible by the number of ranks")
+            # ONE learner with the reference's batch: every rank contributes batch_size / world rows
+            exp_cfg.global_batch_size = exp_cfg.batch_size
+            exp_cfg.batch_size = exp_cfg.batch_size // world_size
         # logging setup (experiment.py:46-55)
         self.logdir = os.path.join(
             exp_cfg.logdir, '{}_SAC_{}_{}_{}'.format(
                 datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"), exp_cfg.env_name,
                 exp_cfg.policy, exp_cfg.logdir_suffix))
+        if world_size > 1:
+            self.logdir += "_seed%d" % exp_cfg.seed      # one directory per rank (= per seed), as the reference's runs
         if not os.path.exists(self.logdir):
             os.makedirs(self.logdir)
         print("LOGDIR: ", self.logdir)
@@ -295,6 +309,8 @@ class Experiment:
         from .fast_update import fast_path_supported
         if fast_path_supported(exp_cfg) and not getattr(exp_cfg, "no_fast_path", False):
             self.agent.enable_fast_path(exp_cfg.batch_size)
+        if self.env_shard:
+            self.agent.fast.enable_grad_sync(world_size)
         self.loop = VectorLoop(exp_cfg, self.env, self.agent, self.memory, self.recovery_memory,
                                self.recovery_policy, self.nu_schedule)
 
@@ -364,6 +380,12 @@ class Experiment:
         """Gate of experiment.py:407-410."""
         cfg = self.exp_cfg
         nv = self.num_viols if num_viols is None else num_viols
+        if self.env_shard:
+            # every rank must take the same branch (the updates contain collectives): decide on the all-reduced
+            # counters (identical everywhere) and the learner's global batch
+            nv = self._global_viols
+            return (not cfg.disable_online_updates
+                    and (nv + self._global_offline_viols) / cfg.global_batch_size > cfg.pos_fraction)
         return (not cfg.disable_online_updates
                 and len(self.recovery_memory) > cfg.batch_size
                 and (nv + self.num_constraint_violations) / cfg.batch_size > cfg.pos_fraction)
@@ -489,6 +511,10 @@ class Experiment:
         when env-steps > num_steps or completed episodes > num_eps (experiment.py:375)."""
         cfg, loop = self.exp_cfg, self.loop
         n = cfg.num_envs
+        self._global_viols = 0
+        self._global_offline_viols = dist_utils.aggregate_stats(
+            {k: (self.num_constraint_violations if k == "num_viols" else 0) for k in dist_utils.METRIC_KEYS},
+            self.world_size, self.device)["num_viols"]
         loop.start()
         log_every = cfg.log_every if getattr(cfg, "log_every", 0) else max(1, 100)
         from . import checkpoint
@@ -523,7 +549,8 @@ class Experiment:
         # num_envs so that an epoch keeps the reference's number of optimiser steps per env-step
         mb_new = mb_resume
         mb_every = cfg.recovery_policy_update_freq * self.env._max_episode_steps
-        graph_ok = (cfg.target_update_interval == 1 and not cfg.nu_schedule and not mb)
+        # env_shard: the updates contain RCCL all-reduces, launched eagerly (not captured)
+        graph_ok = (cfg.target_update_interval == 1 and not cfg.nu_schedule and not mb and not self.env_shard)
         while True:
             have_batch = len(self.memory) > cfg.batch_size
             random_actions = cfg.start_steps > loop.total_numsteps
@@ -553,6 +580,7 @@ class Experiment:
                 ep_file.write(new.tobytes())
                 ep_file.flush()
                 agg = dist_utils.aggregate_stats(stats, self.world_size, self.device)
+                self._global_viols = agg["num_viols"]
                 history.append(dict(stats, iteration=it))
                 if self.rank == 0:
                     print("Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(
@@ -569,7 +597,10 @@ class Experiment:
                     pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n}, f)
                 if ckpt_every and logged % ckpt_every == 0:
                     write_checkpoint()
-                if stats["env_steps"] > cfg.num_steps or stats["episodes"] > cfg.num_eps:
+                # multi-rank: all ranks leave at the same log point (the next aggregate would hang otherwise);
+                # the thresholds apply to the per-rank mean
+                w = max(self.world_size, 1)
+                if agg["env_steps"] > cfg.num_steps * w or agg["episodes"] > cfg.num_eps * w:
                     break
         ep_file.close()
         write_checkpoint()

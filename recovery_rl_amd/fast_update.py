@@ -41,6 +41,17 @@ class FlatNet:
             self.g[name] = self.grad[off:off + n].view(shape)
             off += n
 
+    def rebind_grad(self, storage):
+        """Move the gradient buffer into `storage` (a slice of a bucket shared with other networks, so that one
+        collective reduces them together)."""
+        assert storage.numel() == self.flat.numel() and storage.is_contiguous()
+        self.grad = storage
+        off = 0
+        for name, shape in self.shapes.items():
+            n = int(torch.Size(shape).numel())
+            self.g[name] = storage[off:off + n].view(shape)
+            off += n
+
     def adopt(self, name, params):
         """Copy the current values of `params` (list of nn.Parameter, stacked along dim 0 when more
         than one) into the flat buffer and re-point them at it."""
@@ -223,6 +234,7 @@ class FastUpdater:
         self.dq, self.dhead, self.draw = z(2, B, 1), z(1, B, 4), z(1, B, 2)
         self.dact = z(B, 2)
         self.losses = z(8)   # q1, q2, policy, (pad) | qr1, qr2, recpolicy, (pad)
+        self.sync_world, self._avg, self.sac_bucket = 1, None, None
         self.fuse_loss = True      # loss gradients computed inside the head-backward kernels (no grad launches)
         self._noise = None
         self._noise_buf, self._actor_noise, self._actor_noise_fresh = None, None, False
@@ -236,6 +248,32 @@ class FastUpdater:
         self.rbias = self.qr.policy.action_bias.to(dev).float().contiguous()
 
     # -- helpers ---------------------------------------------------------------------------------
+    # -- env-shard data parallelism (one learner, envs and replay split over ranks) ---------------------------
+    def enable_grad_sync(self, world):
+        """Every rank holds the same weights and averages gradients before each optimiser step: three
+        all-reduces per iteration ([critic | policy] in one bucket, Q_risk, recovery policy -- the last two
+        cannot share one because the recovery policy's gradient is taken at the UPDATED Q_risk, qrisk.py:150).
+        Parameters, targets and Adam state start from rank 0's."""
+        import torch.distributed as dist
+        n1, n2 = self.critic.flat.numel(), self.policy.flat.numel()
+        self.sac_bucket = torch.zeros(n1 + n2, dtype=torch.float32, device=self.dev)
+        self.critic.rebind_grad(self.sac_bucket[:n1])
+        self.policy.rebind_grad(self.sac_bucket[n1:])
+        for net in (self.critic, self.critic_target, self.policy, self.qrisk, self.qrisk_target, self.recpolicy):
+            dist.broadcast(net.flat, 0)
+        self.sync_world = world
+        self._avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else None
+
+    def _sync(self, grad):
+        if self.sync_world <= 1:
+            return
+        import torch.distributed as dist
+        if self._avg is not None:
+            dist.all_reduce(grad, op=self._avg)               # RCCL ring over xGMI; <= 0.8 MB: latency-bound
+        else:                                                 # gloo (CPU-side reduction, tests): no AVG op
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+            grad.mul_(1.0 / self.sync_world)
+
     def _loss(self, kind, out, n_part, part_stride, out_t=None, v0=None, v1=None, v2=None, v3=None, alpha=None,
               f0=0.0, d_action=None, loss=None):
         """rrl_loss_t for Stack.backward: the head-backward kernel evaluates the loss gradient itself.
@@ -342,6 +380,8 @@ class FastUpdater:
                                                float(ag.alpha) / B, self.dhead.data_ptr(), st),
                         "rrl_gauss_head_bwd")
             self.pol_b.backward(self.dhead)
+        if self.sync_world > 1:
+            self._sync(self.sac_bucket)
         # both optimiser steps + the soft target update (:273-274) in one launch
         adam_multi(ag.lr, [(self.critic, self.critic_target, ag.tau), (self.policy, None, 0.0)])
         return self.losses
@@ -362,6 +402,7 @@ class FastUpdater:
                                                   m.data_ptr(), qr.gamma_safe, self.dq.data_ptr(),
                                                   self.losses[4:].data_ptr(), st), "rrl_qrisk_critic_grad")
             self.qr_a.backward(self.dq)
+        self._sync(self.qrisk.grad)
         self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau)
         if qr.MF_recovery:                                              # qrisk.py:150-158, at the UPDATED critic
             raw, rn, rs = self.rec_a.forward(s)
@@ -386,6 +427,7 @@ class FastUpdater:
                                                    self.draw.data_ptr(), self.recpolicy.g["log_std"].data_ptr(),
                                                    st), "rrl_stoch_head_bwd")
                 self.rec_a.backward(self.draw)
+            self._sync(self.recpolicy.grad)
             self.recpolicy.adam(qr.lr)
         return self.losses
 

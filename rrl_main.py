@@ -11,6 +11,6 @@ if __name__ == '__main__':
     if torch.cuda.is_available():
         torch.cuda.set_device(dist_utils.local_device(local_rank))
     if world > 1:
-        exp_cfg.seed = dist_utils.rank_seed(exp_cfg.seed, rank)
+        exp_cfg.seed = dist_utils.rank_seed(exp_cfg.seed, rank)     # env, replay and noise streams differ per rank
     experiment = Experiment(exp_cfg, rank=rank, world_size=world)
     experiment.run()
