@@ -59,7 +59,7 @@ def test_step_matches_reference_golden_bit_exact(env, golden_dir):
 
 
 @pytest.mark.parametrize("env", ENVS)
-@pytest.mark.parametrize("n", (1, 63, 64, 257, 4096, 100003))
+@pytest.mark.parametrize("n", (1, 63, 64, 257, 4096, 100003, 1 << 19, 600000))   # >= 2^19, n % 4 == 0: 4 envs/thread
 def test_step_matches_oracle_with_philox_noise(env, n):
     rng = np.random.RandomState(n)
     pos = np.c_[rng.uniform(-60, 10, n), rng.uniform(-12, 12, n)]
@@ -69,6 +69,24 @@ def test_step_matches_oracle_with_philox_noise(env, n):
         ref = co.nav_step(env, pos, act, t, seed=0xDEADBEEF12345, counter=17, auto_reset=auto)
         got = hip_step(env, pos, act, t, seed=0xDEADBEEF12345, counter=17, auto_reset=auto)
         assert_same(got, ref)
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_vector_path_with_explicit_noise_and_device_tick(env):
+    """The 4-envs-per-thread kernel (n >= 2^19) with caller-supplied noise, and its device-side tick."""
+    n = 1 << 19
+    rng = np.random.RandomState(5)
+    pos = np.c_[rng.uniform(-60, 10, n), rng.uniform(-12, 12, n)]
+    act = rng.uniform(-1.5, 1.5, (n, 2)).astype(np.float32)
+    t = rng.randint(0, 100, n).astype(np.int32)
+    noise = rng.randn(n, 2)
+    ref = co.nav_step(env, pos, act, t, noise=noise, seed=3, counter=9, auto_reset=True)
+    got = hip_step(env, pos, act, t, noise=noise, seed=3, counter=9, auto_reset=True)
+    assert_same(got, ref)
+    tick = torch.tensor([4, 0], dtype=torch.int64, device=DEV)
+    got = hip_step(env, pos, act, t, seed=3, counter=5, auto_reset=True, tick=tick, inc=2)
+    assert_same(got, co.nav_step(env, pos, act, t, seed=3, counter=9, auto_reset=True))
+    assert tick.tolist() == [6, 0]
 
 
 @pytest.mark.parametrize("env", ENVS)
