@@ -177,6 +177,14 @@ int rrl_nav_step_push(int env_kind, int64_t n, double* pos, int32_t* t, float* o
                       const rrl_replay_t* memory, const rrl_replay_t* recovery_memory, float* next_obs,
                       float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success, uint8_t* ep_done,
                       uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
+/* the same fused tail for the Maze env (env/maze.py:139-213 + experiment.py:420-461) */
+int rrl_maze_step_push(int64_t n, double* pos, int32_t* t, float* obs,
+                      const float* task_action, const float* real_action, const uint8_t* recovery,
+                      uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                      int32_t horizon, int auto_reset, float reward_penalty, int push_real_action,
+                      const rrl_replay_t* memory, const rrl_replay_t* recovery_memory, float* next_obs,
+                      float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success, uint8_t* ep_done,
+                      uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * CEM.  Replaces the bookkeeping of CEMOptimizer.obtain_solution (recovery_rl/optimizers.py:73-124)

@@ -24,7 +24,7 @@ EXPORTS = [
     "rrl_nav_step", "rrl_nav_reset", "rrl_nav_rollout", "rrl_nav_offline_rollouts",
     "rrl_nav_offline",
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
-    "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_nav_step_push",
+    "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_nav_step_push", "rrl_maze_step_push",
     "rrl_cem_sample", "rrl_cem_update",
     "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss",
     "rrl_mlp_input_backward",
@@ -124,6 +124,8 @@ def _declare(lib):
                                            vp, vp, vp, vp, vp]),
         "rrl_nav_step_push": (ci, [ci, i64, vp, vp, vp, vp, vp, vp, u64, u64, vp, u64, i32, ci, f32, ci, rp, rp,
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_maze_step_push": (ci, [i64, vp, vp, vp, vp, vp, vp, u64, u64, vp, u64, i32, ci, f32, ci, rp, rp,
+                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_cem_sample": (ci, [i64, i32, i32, vp, vp, vp, vp, f64, ci, vp, u64, u64, vp, u64, vp, vp]),
         "rrl_cem_update": (ci, [i64, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]),
         "rrl_gemm_f32": (ci, [ci, ci, ci, ci, ci, vp, ci, C.c_longlong, vp, ci, C.c_longlong, vp, ci,

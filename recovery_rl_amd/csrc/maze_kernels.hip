@@ -7,8 +7,11 @@
 // layout and launch shape as the navigation kernels: one lane per env, SoA, HBM-bound.
 #include <hip/hip_runtime.h>
 
+#include "maze_device.hpp"
+#include "replay_device.hpp"
 #include "rrl_device.hpp"
 #include "rrl_host.hpp"
+#include "step_push.hpp"
 
 #pragma clang fp contract(off)
 
@@ -18,76 +21,7 @@ using rrl_host::check_launch;
 using rrl_host::grid_for;
 using rrl_host::kBlock;
 
-constexpr double kGain = 0.24667750873451577;  // m per unit control per env step (500 x 2 ms from rest)
-constexpr double kRadius = 0.025;              // simple_maze.xml:28
-constexpr double kLim = 0.3;                   // arena planes / joint range
-constexpr double kMaxForce = 0.1;              // env/maze.py:17
-constexpr double kGoalX = 0.25, kGoalY = 0.0;  // env/maze.py:135-137
-constexpr double kGoalThresh = 0.03;           // env/maze.py:19
-constexpr int kSubsteps = 64;
-
-__device__ __forceinline__ bool touches_wall(double x, double y, double cx, double cy) {
-    double dx = fabs(x - cx) - 0.005, dy = fabs(y - cy) - 0.2;  // half sizes, simple_maze.xml:22-25
-    dx = dx < 0.0 ? 0.0 : dx;
-    dy = dy < 0.0 ? 0.0 : dy;
-    return dx * dx + dy * dy <= kRadius * kRadius;
-}
-
-// ncon > 3  <=>  the disc touches an arena plane or one of the four walls (env/maze.py:199-206)
-__device__ __forceinline__ bool in_contact(double x, double y) {
-    const bool plane = (kLim - x <= kRadius) | (x + kLim <= kRadius) | (kLim - y <= kRadius) |
-                       (y + kLim <= kRadius);
-    return plane | touches_wall(x, y, -0.1, 0.42) | touches_wall(x, y, 0.1, 0.48) |
-           touches_wall(x, y, -0.1, -0.33) | touches_wall(x, y, 0.1, -0.17);
-}
-
-__device__ __forceinline__ double clampd(double v, double lo, double hi) {
-    return v < lo ? lo : (v > hi ? hi : v);
-}
-
-__device__ __forceinline__ double goal_distance(double x, double y) {
-    const double ex = kGoalX - x, ey = kGoalY - y;
-    return sqrt((ex * ex + ey * ey) / 2.0);  // sqrt(mean(sq)), env/maze.py:219
-}
-
-__device__ __forceinline__ void move(double& x, double& y, double ax, double ay) {
-    ax = clampd(ax, -kMaxForce, kMaxForce);
-    ay = clampd(ay, -kMaxForce, kMaxForce);
-    if (in_contact(x, y)) return;  // env/maze.py:144-147: no sim steps while in contact
-    const double dx = kGain * ax, dy = kGain * ay;
-    double qx = x, qy = y;
-    for (int k = 1; k <= kSubsteps; ++k) {
-        const double f = double(k) * (1.0 / kSubsteps);
-        qx = clampd(x + dx * f, -kLim, kLim);
-        qy = clampd(y + dy * f, -kLim, kLim);
-        if (in_contact(qx, qy)) break;
-    }
-    x = qx;
-    y = qy;
-}
-
-__device__ __forceinline__ void reset_one(uint64_t seed, uint32_t row, uint64_t counter, int mode,
-                                          bool check, double& x, double& y) {
-    for (uint32_t r = 0;; ++r) {
-        const rrl::Bits128 b = rrl::philox_at(seed, row, rrl::kStreamReset, counter | (uint64_t(r) << 48));
-        const double u0 = rrl::unit_open(b.lo), u1 = rrl::unit_open(b.hi);
-        if (mode == 1) x = 0.14 + 0.08 * u0;
-        else if (mode == 2) x = -0.04 + 0.08 * u0;
-        else if (mode == 3) x = -0.27 + 0.54 * u0;
-        else x = -0.22 + 0.09 * u0;
-        y = -0.22 + 0.44 * u1;
-        if (!check || !in_contact(x, y) || r >= 1000) return;
-    }
-}
-
-__device__ __forceinline__ void expert_action(double x, double y, double& ax, double& ay) {
-    double tx, ty;  // env/maze.py:222-232
-    if (x <= -0.151) { tx = -0.15; ty = -0.125; }
-    else if (x <= 0.149) { tx = 0.15; ty = 0.125; }
-    else { tx = kGoalX; ty = kGoalY; }
-    ax = 1.05 * (tx - x);
-    ay = 1.05 * (ty - y);
-}
+using namespace rrl_maze;
 
 struct MazeArgs {
     int64_t n;
@@ -197,6 +131,27 @@ __global__ __launch_bounds__(kBlock) void maze_offline_kernel(int64_t half, int6
     }
 }
 
+// the maze transition plugged into the fused step + push kernel (step_push.hpp)
+struct MazeEnv {
+    static __device__ __forceinline__ rrl_step::Outcome step(const StepArgs& a, int64_t, uint64_t, double2 p,
+                                                             float2 act, int32_t t_after) {
+        double x = p.x, y = p.y;
+        move(x, y, double(act.x), double(act.y));
+        const double d = goal_distance(x, y);
+        rrl_step::Outcome o;
+        o.x = x;
+        o.y = y;
+        o.reward = float(-d);
+        o.constraint = in_contact(x, y);
+        o.success = -d > -0.03;
+        o.done = (t_after >= a.horizon) | o.constraint | (d < kGoalThresh);      // env/maze.py:207-213
+        return o;
+    }
+    static __device__ __forceinline__ void reset(const StepArgs& a, int64_t i, uint64_t ctr, double& x, double& y) {
+        reset_one(a.seed, uint32_t(i), ctr, 0, true, x, y);
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -238,6 +193,38 @@ int rrl_maze_offline(int64_t num_transitions, uint64_t seed, float* s, float* a,
     hipLaunchKernelGGL(maze_offline_kernel, dim3((unsigned)((2 * n_seg + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, (hipStream_t)stream, half, n_seg, seed, (float2*)s, (float2*)a, c,
                        (float2*)s2, m);
+    return check_launch();
+}
+
+int rrl_maze_step_push(int64_t n, double* pos, int32_t* t, float* obs, const float* task_action,
+                       const float* real_action, const uint8_t* recovery, uint64_t seed, uint64_t counter,
+                       uint64_t* counter_dev, uint64_t counter_inc, int32_t horizon, int auto_reset,
+                       float reward_penalty, int push_real_action, const rrl_replay_t* memory,
+                       const rrl_replay_t* recovery_memory, float* next_obs, float* reward, uint8_t* done,
+                       uint8_t* constraint, uint8_t* success, uint8_t* ep_done, uint64_t* stats, double* reward_sums,
+                       float* ep_reward, void* stream) {
+    if (n < 0 || n > 0xffffffffLL) return RRL_ERANGE;
+    if (!pos || !t || !obs || !task_action || !real_action || !memory || !next_obs || !reward || !done ||
+        !constraint || !success || !stats || !reward_sums || !ep_reward)
+        return RRL_EINVAL;
+    if (n > memory->cap || (recovery_memory && n > recovery_memory->cap)) return RRL_ERANGE;
+    if (n == 0) return RRL_OK;
+    rrl_step::StepPushArgs p;
+    p.step = StepArgs{n, (double2*)pos, (const float2*)real_action, nullptr, seed, counter, counter_dev,
+                      counter_inc, (float2*)next_obs, (float2*)obs, reward, done, constraint, success, ep_done,
+                      t, horizon, auto_reset};
+    p.task_action = (const float2*)task_action;
+    p.recovery = recovery;
+    p.reward_penalty = reward_penalty;
+    p.push_real_action = push_real_action;
+    p.memory = *memory;
+    p.use_recovery_memory = recovery_memory != nullptr;
+    p.recovery_memory = recovery_memory ? *recovery_memory : *memory;
+    p.stats = (unsigned long long*)stats;
+    p.reward_sums = reward_sums;
+    p.ep_reward = ep_reward;
+    hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv>), dim3(grid_for(n)), dim3(kBlock), 0,
+                       (hipStream_t)stream, p);
     return check_launch();
 }
 

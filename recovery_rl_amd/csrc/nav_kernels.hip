@@ -10,6 +10,7 @@
 #include "replay_device.hpp"
 #include "rrl_device.hpp"
 #include "rrl_host.hpp"
+#include "step_push.hpp"
 
 #pragma clang fp contract(off)
 
@@ -18,27 +19,6 @@ namespace {
 using rrl_host::check_launch;
 using rrl_host::grid_for;
 using rrl_host::kBlock;
-
-struct StepArgs {
-    int64_t n;
-    double2* pos;
-    const float2* action;
-    const double2* noise;
-    uint64_t seed;
-    uint64_t counter;
-    uint64_t* counter_dev;
-    uint64_t counter_inc;
-    float2* next_obs;
-    float2* obs;
-    float* reward;
-    uint8_t* done;
-    uint8_t* constraint;
-    uint8_t* success;
-    uint8_t* ep_done;
-    int32_t* t;
-    int32_t horizon;
-    int32_t auto_reset;
-};
 
 template <int KIND, bool EXT_NOISE>
 __global__ __launch_bounds__(kBlock) void nav_step_kernel(StepArgs a) {
@@ -214,111 +194,30 @@ __global__ __launch_bounds__(kBlock) void nav_rollout_kernel(int64_t n, int32_t 
 }
 
 
-// ---- fused env step + replay pushes + counters (one launch per lock-step iteration) -----------------
-// Counterpart of the body of recovery_rl/experiment.py:420-461 for n envs: env.step, reward penalty,
-// mask = not done (before the horizon check), memory.push, recovery_memory.push, episode counters.
-struct StepPushArgs {
-    StepArgs step;            // obs = observation buffer: read as the pre-step state, then overwritten
-    const float2* task_action;
-    const uint8_t* recovery;  // nullable
-    float reward_penalty;
-    int push_real_action;     // disable_action_relabeling (experiment.py:437-441)
-    rrl_replay_t memory;
-    rrl_replay_t recovery_memory;
-    int use_recovery_memory;
-    unsigned long long* stats;   // env_steps, episodes, num_viols, viol_and_recovery, viol_and_no_recovery,
-                                 // num_successes, recovery_steps, constraint_steps
-    double* reward_sums;         // {sum of rewards, sum of finished-episode returns}
-    float* ep_reward;            // [n] running episode return
-};
-
-__device__ __forceinline__ void wave_count_add(unsigned long long* dst, bool flag) {
-    const unsigned long long bal = __ballot(flag);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(dst, (unsigned long long)__popcll(bal));
-}
-
+// ---- fused step + push: the navigation transition plugged into step_push_kernel (step_push.hpp) ----
 template <int KIND>
-__global__ __launch_bounds__(kBlock) void nav_step_push_kernel(StepPushArgs p) {
-    const StepArgs& a = p.step;
-    const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
-    const int64_t mpos = p.memory.state[0], msize = p.memory.state[1];
-    int64_t rpos = 0, rsize = 0;
-    if (p.use_recovery_memory) { rpos = p.recovery_memory.state[0]; rsize = p.recovery_memory.state[1]; }
-    double rsum = 0.0, retsum = 0.0;
-    const int64_t stride = int64_t(gridDim.x) * kBlock;
-    const int64_t n_iter = (a.n + stride - 1) / stride;   // uniform trip count: ballots need whole waves
-    for (int64_t it = 0; it < n_iter; ++it) {
-        const int64_t i = it * stride + int64_t(blockIdx.x) * kBlock + threadIdx.x;
-        const bool live = i < a.n;
-        bool cons = false, succ = false, epd = false, rec = false;
-        if (live) {
-            const double2 pp = a.pos[i];
-            const float2 act = a.action[i];
-            const float2 prev = a.obs[i];
-            int32_t ti = a.t[i];
-            double ex, ey, nx, ny, cost;
-            rrl::normal_at(a.seed, uint32_t(i), rrl::kStreamStep, ctr, ex, ey);
-            rrl::nav_transition<KIND>(pp.x, pp.y, double(act.x), double(act.y), ex, ey, nx, ny, cost);
-            cons = rrl::in_obstacle<KIND>(nx, ny);
-            succ = cost > -4.0;
-            const bool dn = succ | cons;
-            ti += 1;
-            epd = dn | (ti == a.horizon);
-            rec = p.recovery ? p.recovery[i] != 0 : false;
-            const float2 nobs = make_float2(float(nx), float(ny));
-            const float rew = float(cost);
-            a.next_obs[i] = nobs;
-            a.reward[i] = rew;
-            a.done[i] = uint8_t(dn);
-            a.constraint[i] = uint8_t(cons);
-            a.success[i] = uint8_t(succ);
-            if (a.ep_done) a.ep_done[i] = uint8_t(epd);
-            // replay rows (experiment.py:431-448)
-            const float mask = dn ? 0.0f : 1.0f;
-            const float prew = rew - (cons ? p.reward_penalty : 0.0f);
-            const float2 stored = p.push_real_action ? act : p.task_action[i];
-            rrl_replay::store_values(p.memory, (mpos + i) % p.memory.cap, msize, prev, stored, prew, nobs, mask);
-            if (p.use_recovery_memory)
-                rrl_replay::store_values(p.recovery_memory, (rpos + i) % p.recovery_memory.cap, rsize, prev, act,
-                                         cons ? 1.0f : 0.0f, nobs, mask);
-            // episode accounting
-            const float er = p.ep_reward[i] + rew;
-            rsum += double(rew);
-            if (epd) retsum += double(er);
-            p.ep_reward[i] = epd ? 0.0f : er;
-            if (a.auto_reset && epd) {
-                double z0, z1;
-                rrl::normal_at(a.seed, uint32_t(i), rrl::kStreamReset, ctr, z0, z1);
-                nx = -50.0 + z0;
-                ny = 0.0 + z1;
-                ti = 0;
-            }
-            a.pos[i] = make_double2(nx, ny);
-            a.t[i] = ti;
-            a.obs[i] = make_float2(float(nx), float(ny));
-        }
-        const bool end_viol = epd & cons;
-        wave_count_add(p.stats + 1, epd);
-        wave_count_add(p.stats + 2, end_viol);
-        wave_count_add(p.stats + 3, end_viol & rec);
-        wave_count_add(p.stats + 4, end_viol & !rec);
-        wave_count_add(p.stats + 5, epd & succ);
-        wave_count_add(p.stats + 6, live & rec);
-        wave_count_add(p.stats + 7, cons);
+struct NavEnv {
+    static __device__ __forceinline__ rrl_step::Outcome step(const StepArgs& a, int64_t i, uint64_t ctr, double2 p,
+                                                             float2 act, int32_t t_after) {
+        double ex, ey, nx, ny, cost;
+        rrl::normal_at(a.seed, uint32_t(i), rrl::kStreamStep, ctr, ex, ey);
+        rrl::nav_transition<KIND>(p.x, p.y, double(act.x), double(act.y), ex, ey, nx, ny, cost);
+        rrl_step::Outcome o;
+        o.x = nx;
+        o.y = ny;
+        o.reward = float(cost);
+        o.constraint = rrl::in_obstacle<KIND>(nx, ny);
+        o.success = cost > -4.0;
+        o.done = o.success | o.constraint;
+        return o;
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        rsum += __shfl_down(rsum, off);
-        retsum += __shfl_down(retsum, off);
+    static __device__ __forceinline__ void reset(const StepArgs& a, int64_t i, uint64_t ctr, double& x, double& y) {
+        double z0, z1;
+        rrl::normal_at(a.seed, uint32_t(i), rrl::kStreamReset, ctr, z0, z1);
+        x = -50.0 + z0;
+        y = 0.0 + z1;
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (rsum != 0.0) atomicAdd(p.reward_sums, rsum);
-        if (retsum != 0.0) atomicAdd(p.reward_sums + 1, retsum);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(p.stats, (unsigned long long)a.n);
-    rrl_replay::advance_ring(p.memory, mpos, msize, a.n);
-    if (p.use_recovery_memory) rrl_replay::advance_ring(p.recovery_memory, rpos, rsize, a.n);
-    rrl::advance_counter(a.counter_dev, a.counter_inc);
-}
+};
 
 // ---- offline constraint data (env/navigation1.py:133-164, env/navigation2.py:133-243) ----
 struct OfflinePlan {
@@ -604,7 +503,7 @@ int rrl_nav_step_push(int env_kind, int64_t n, double* pos, int32_t* t, float* o
         return RRL_EINVAL;
     if (n > memory->cap || (recovery_memory && n > recovery_memory->cap)) return RRL_ERANGE;
     if (n == 0) return RRL_OK;
-    StepPushArgs p;
+    rrl_step::StepPushArgs p;
     p.step = StepArgs{n, (double2*)pos, (const float2*)real_action, nullptr, seed, counter, counter_dev,
                       counter_inc, (float2*)next_obs, (float2*)obs, reward, done, constraint, success, ep_done,
                       t, horizon, auto_reset};
@@ -620,9 +519,9 @@ int rrl_nav_step_push(int env_kind, int64_t n, double* pos, int32_t* t, float* o
     p.ep_reward = ep_reward;
     const dim3 grid(grid_for(n)), block(kBlock);
     if (env_kind == RRL_ENV_NAV1)
-        hipLaunchKernelGGL((nav_step_push_kernel<0>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<0>>), grid, block, 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((nav_step_push_kernel<1>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<1>>), grid, block, 0, (hipStream_t)stream, p);
     return check_launch();
 }
 

@@ -165,12 +165,13 @@ class VectorLoop:
         return obs
 
     def _can_fuse_step(self):
+        from .env.maze import MazeVecEnv
         from .env.navigation import NavigationVecEnv
-        return (isinstance(self.env, NavigationVecEnv) and self.env.auto_reset
+        return (isinstance(self.env, (NavigationVecEnv, MazeVecEnv)) and self.env.auto_reset
                 and not self.cfg.add_both_transitions and not getattr(self.cfg, "no_fused_step", False))
 
     def _fused_step(self, action, real_action, recovery):
-        """env step + both replay pushes + counters in ONE launch (rrl_nav_step_push)."""
+        """env step + both replay pushes + counters in ONE launch (rrl_nav_step_push / rrl_maze_step_push)."""
         import ctypes as C
         from . import _lib
         cfg, env, mem, rmem = self.cfg, self.env, self.memory, self.recovery_memory
@@ -178,15 +179,19 @@ class VectorLoop:
         if recovery is not None:
             rec_u8 = recovery if recovery.dtype == torch.uint8 else recovery.to(torch.uint8)
         use_rmem = uses_constraint_buffer(cfg)
-        rc = env.lib.rrl_nav_step_push(
-            env.kind, self.n, _lib.ptr(env.pos), _lib.ptr(env.t), _lib.ptr(env.obs), _lib.ptr(action),
+        if env.env_name == "maze":
+            entry, head = env.lib.rrl_maze_step_push, ()
+        else:
+            entry, head = env.lib.rrl_nav_step_push, (env.kind,)
+        rc = entry(
+            *head, self.n, _lib.ptr(env.pos), _lib.ptr(env.t), _lib.ptr(env.obs), _lib.ptr(action),
             _lib.ptr(real_action), _lib.ptr(rec_u8), env.seed_value, 0, _lib.ptr(env.tick), 1, env.horizon, 1,
             float(cfg.constraint_reward_penalty), int(bool(cfg.disable_action_relabeling)),
             C.byref(mem._desc), C.byref(rmem._desc) if use_rmem else None, _lib.ptr(env.next_obs),
             _lib.ptr(env.reward), _lib.ptr(env.done), _lib.ptr(env.constraint), _lib.ptr(env.success),
             _lib.ptr(env.ep_done), _lib.ptr(self.stats), _lib.ptr(self.reward_sums), _lib.ptr(self.ep_reward),
             _lib.current_stream())
-        _lib.check(rc, "rrl_nav_step_push")
+        _lib.check(rc, "rrl_step_push")
         mem._len = min(mem._len + self.n, mem.capacity)
         if use_rmem:
             rmem._len = min(rmem._len + self.n, rmem.capacity)

@@ -108,3 +108,59 @@ def test_single_env_protocol():
     for _ in range(5):
         obs, r, done, info = env.step(env.expert_action())
     assert done and info["success"] and not info["constraint"]
+
+
+def test_fused_step_push_matches_oracle_step_plus_pushes():
+    """rrl_maze_step_push == checker maze_step + two checker replay pushes + counters, over a ring wrap-around."""
+    import ctypes as C
+    from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
+    lib = _lib.load()
+    n, cap = 1500, 4000
+    rng = np.random.RandomState(4)
+    venv = make_vec_env("maze", n, device=DEV, seed=31)
+    venv.reset()
+    mem, rmem = ReplayMemory(cap, 1, device=DEV), ConstraintReplayMemory(cap, 1, device=DEV)
+    omem, ormem = co.OracleReplay(cap), co.OracleReplay(cap)
+    stats = torch.zeros(10, dtype=torch.int64, device=DEV)
+    sums = torch.zeros(2, dtype=torch.float64, device=DEV)
+    ep_reward = torch.zeros(n, device=DEV)
+    pos, t = venv.pos.cpu().numpy().copy(), np.zeros(n, np.int32)
+    tick0 = int(venv.tick[0].item())
+    ref_stats = np.zeros(8, np.int64)
+    ref_ep, ref_sums = np.zeros(n, np.float32), np.zeros(2)
+    for k in range(5):
+        obs_prev = venv.obs.cpu().numpy().copy()
+        task = torch.as_tensor(rng.uniform(-0.1, 0.1, (n, 2)).astype(np.float32), device=DEV)
+        real = torch.as_tensor(rng.uniform(-0.13, 0.13, (n, 2)).astype(np.float32), device=DEV)
+        rec = torch.as_tensor((rng.uniform(size=n) < 0.3).astype(np.uint8), device=DEV)
+        rc = lib.rrl_maze_step_push(
+            n, _lib.ptr(venv.pos), _lib.ptr(venv.t), _lib.ptr(venv.obs), _lib.ptr(task), _lib.ptr(real),
+            _lib.ptr(rec), venv.seed_value, 0, _lib.ptr(venv.tick), 1, 100, 1, 2.5, 0, C.byref(mem._desc),
+            C.byref(rmem._desc), _lib.ptr(venv.next_obs), _lib.ptr(venv.reward), _lib.ptr(venv.done),
+            _lib.ptr(venv.constraint), _lib.ptr(venv.success), _lib.ptr(venv.ep_done), _lib.ptr(stats),
+            _lib.ptr(sums), _lib.ptr(ep_reward), _lib.current_stream())
+        assert rc == 0
+        ref = co.maze_step(pos, real.cpu().numpy(), t, seed=venv.seed_value, counter=tick0 + k, auto_reset=True)
+        pos, t = ref["pos"], ref["t"]
+        mask = 1.0 - ref["done"].astype(np.float32)
+        cons = ref["constraint"].astype(np.float32)
+        omem.push(obs_prev, task.cpu().numpy(), ref["reward"] - 2.5 * cons, ref["next_obs"], mask)
+        ormem.push(obs_prev, real.cpu().numpy(), cons, ref["next_obs"], mask)
+        assert np.array_equal(venv.pos.cpu().numpy(), pos) and np.array_equal(venv.obs.cpu().numpy(), ref["obs"])
+        assert np.array_equal(venv.t.cpu().numpy(), t)
+        r = rec.cpu().numpy().astype(bool)
+        epd, c, s_ = ref["ep_done"].astype(bool), ref["constraint"].astype(bool), ref["success"].astype(bool)
+        ref_stats += [n, epd.sum(), (epd & c).sum(), (epd & c & r).sum(), (epd & c & ~r).sum(), (epd & s_).sum(),
+                      r.sum(), c.sum()]
+        ref_ep += ref["reward"]
+        ref_sums += [ref["reward"].astype(np.float64).sum(), ref_ep[epd].astype(np.float64).sum()]
+        ref_ep[epd] = 0
+    assert ref_stats[1] > 0 and ref_stats[7] > 0            # episodes ended and walls were hit
+    for got, want in ((mem, omem), (rmem, ormem)):
+        assert int(got.state[0].item()) == want.pos and int(got.state[1].item()) == want.size == cap
+        for a_, b_ in ((got.s, want.s), (got.a, want.a), (got.r, want.r), (got.s2, want.s2), (got.m, want.m)):
+            assert np.array_equal(a_.cpu().numpy(), b_)
+    assert np.array_equal(stats.cpu().numpy()[:8], ref_stats)
+    assert np.allclose(sums.cpu().numpy(), ref_sums, rtol=1e-9)
+    assert np.allclose(ep_reward.cpu().numpy(), ref_ep, rtol=1e-6, atol=1e-5)
+    assert int(venv.tick[0].item()) == tick0 + 5
