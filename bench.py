@@ -98,6 +98,30 @@ def time_nav_step_kernel(device, n, reps=200):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def time_nav_rollout_kernel(device, n=1 << 20, T=100):
+    """The fused-rollout variant of SURVEY 8d: T scripted steps per env in ONE launch with the state in registers
+    (rrl_nav_rollout); per env-step only the 8-byte action is read and the reward + constraint flag written."""
+    lib = _lib.load()
+    pos = torch.randn(n, 2, dtype=torch.float64, device=device) + torch.tensor([-50.0, 0.0], dtype=torch.float64,
+                                                                                device=device)
+    acts = torch.rand(T, n, 2, device=device) * 2 - 1
+    rew = torch.empty(T, n, device=device)
+    cons = torch.empty(T, n, dtype=torch.uint8, device=device)
+
+    def launch():
+        return lib.rrl_nav_rollout(0, n, T, _lib.ptr(pos), _lib.ptr(acts), 1, 0, None, None, _lib.ptr(rew),
+                                   _lib.ptr(cons), None, _lib.current_stream())
+    launch()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        launch()
+    e1.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) * 1e-3 / 3
+
+
 def pmc_traffic(n):
     """HBM bytes per nav_step launch measured with rocprofv3 PMC counters (committed under profiles/;
     PMC passes cannot run inside this process).  None when no measurement exists for this size."""
@@ -278,6 +302,14 @@ def main():
                               "achieved_GBs": n * NAV_STEP_ALGO_BYTES / tk / 1e9,
                               "frac": n * NAV_STEP_ALGO_BYTES / tk / 1e9 / HBM_PEAK_GBS})
             extra["roofline_sweep"] = sweep
+            n_r, t_r = 1 << 20, 100
+            tr = time_nav_rollout_kernel(device, n_r, t_r)
+            extra["roofline_rollout"] = {
+                "kernel": "nav_rollout_kernel<0> (rrl_nav_rollout), %d envs x %d steps in one launch" % (n_r, t_r),
+                "launch_ms": tr * 1e3, "env_steps_per_s": n_r * t_r / tr, "bytes_per_env_step": 13,
+                "achieved_GBs": n_r * t_r * 13 / tr / 1e9, "frac": n_r * t_r * 13 / tr / 1e9 / HBM_PEAK_GBS,
+                "note": "8 B action read + 4 B reward + 1 B constraint written per env-step; the state never leaves "
+                        "registers, so the f64 Philox / Box-Muller arithmetic, not HBM, is the limit"}
         if a.planner:
             t_p, row_steps = time_planner_kernel(device)
             tf = row_steps * PLAN_FLOPS_PER_ROW_STEP / t_p / 1e12
