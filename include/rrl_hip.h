@@ -248,6 +248,12 @@ int rrl_mlp_head_backward(int G, int B, int H, int dout, const float* dOut, cons
 int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const float* x, int ldx,
                            const float* W1, float* dW1, float* db1, float* dx, void* stream);
 
+/* Hidden layer of the stack backward in ONE launch (both products read dh2 and are independent):
+ *   dW2[g] = dh2[g]^T h1[g], db2[g] = column sums of dh2[g]   and   dh1[g] = (dh2[g] W2[g]) * [h1[g] > 0]
+ * dh2, h1, dh1 [G,B,H]; W2, dW2 [G,H,H]; db2 [G,H]. */
+int rrl_mlp_hidden_backward(int G, int B, int H, const float* dh2, const float* h1, const float* W2, float* dW2,
+                            float* db2, float* dh1, void* stream);
+
 /* rrl_mlp_head_backward with dOut produced in the kernel from a loss description instead of read from memory:
  * saves the stand-alone rrl_*_grad / rrl_*_head_bwd launch in front of every stack backward (same formulas,
  * bit-identical dOut).  kind selects the formula and the meaning of the fields:

@@ -26,7 +26,7 @@ EXPORTS = [
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_nav_step_push", "rrl_maze_step_push",
     "rrl_cem_sample", "rrl_cem_update",
-    "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss",
+    "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss", "rrl_mlp_hidden_backward",
     "rrl_mlp_input_backward",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
@@ -135,6 +135,7 @@ def _declare(lib):
         "rrl_mlp3_is_split": (ci, [ci, ci]),
         "rrl_mlp_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_mlp_head_backward_loss": (ci, [C.POINTER(rrl_loss_t), ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
+        "rrl_mlp_hidden_backward": (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_mlp_input_backward": (ci, [ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_gauss_head_fwd": (ci, [ci, vp, ci, ll, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_gauss_head_bwd": (ci, [ci, vp, ci, ll, vp, vp, vp, ci, ci, ll, f32, vp, vp]),

@@ -103,12 +103,9 @@ __device__ __forceinline__ float elem(const float4& q, int t) {
 }
 
 template <int MODE, bool FAST>  // MODE: 0 NT, 1 NN, 2 TN
-__global__ __launch_bounds__(64) void gemm16_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[MODE == 2 ? kPanel * kLd : 4];
-    __shared__ __attribute__((aligned(16))) float Bs[MODE != 0 ? kPanel * kLd : 4];
+__device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g) {
     const int lane = threadIdx.x;
-    const int g = blockIdx.z;
-    const int m0 = blockIdx.y * kTile, n0 = blockIdx.x * kTile;
+    const int m0 = by * kTile, n0 = bx * kTile;
     const float* A = a.A + g * a.sA;
     const float* B = a.B + g * a.sB;
     float* C = a.C + g * a.sC;
@@ -174,11 +171,35 @@ __global__ __launch_bounds__(64) void gemm16_kernel(GemmArgs a) {
             }
         }
     }
-    if (MODE == 2 && a.colsum && blockIdx.x == 0) {
+    if (MODE == 2 && a.colsum && bx == 0) {
         float tot = asum + __shfl_xor(asum, 16);
         tot += __shfl_xor(tot, 32);
         const int row = m0 + (lane & 15);
         if (lane < 16 && row < a.M) a.colsum[g * a.sColsum + row] = tot;
+    }
+}
+
+template <int MODE, bool FAST>
+__global__ __launch_bounds__(64) void gemm16_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[MODE == 2 ? kPanel * kLd : 4];
+    __shared__ __attribute__((aligned(16))) float Bs[MODE != 0 ? kPanel * kLd : 4];
+    gemm16_tile<MODE, FAST>(a, As, Bs, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The two H x H products of a stack backward share their left operand dh2 and do not depend on each other:
+//   dW2[g] = dh2[g]^T h1[g] (+ column sums = db2)   (TN)        dh1[g] = (dh2[g] W2[g]) * [h1[g] > 0]   (NN)
+// One launch: the first `tn_tiles` workgroups (per head) take the TN tiles, the rest the NN tiles.
+template <bool FAST>
+__global__ __launch_bounds__(64) void gemm16_pair_kernel(GemmArgs tn, GemmArgs nn, int tn_tiles_x, int tn_tiles,
+                                                         int nn_tiles_x) {
+    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
+    const int b = blockIdx.x, g = blockIdx.y;
+    if (b < tn_tiles) {
+        gemm16_tile<2, FAST>(tn, As, Bs, b % tn_tiles_x, b / tn_tiles_x, g);
+    } else {
+        const int c = b - tn_tiles;
+        gemm16_tile<1, FAST>(nn, As, Bs, c % nn_tiles_x, c / nn_tiles_x, g);
     }
 }
 
@@ -779,6 +800,25 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
         else if (mode == 1) hipLaunchKernelGGL((gemm16_kernel<1, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gemm16_kernel<2, false>), grid, block, 0, st, a);
     }
+    return check_launch();
+}
+
+int rrl_mlp_hidden_backward(int G, int B, int H, const float* dh2, const float* h1, const float* W2, float* dW2,
+                            float* db2, float* dh1, void* stream) {
+    if (!dh2 || !h1 || !W2 || !dW2 || !db2 || !dh1) return RRL_EINVAL;
+    if (G <= 0 || G > 65535 || B <= 0 || H <= 0) return RRL_ERANGE;
+    const long long sAct = (long long)B * H, sW = (long long)H * H;
+    // TN: dW2 [H,H] = dh2^T [H,B] . h1 [B,H], column sums of dh2 -> db2        (A = dh2, K = B)
+    GemmArgs tn{dh2, h1, dW2, nullptr, nullptr, db2, H, H, B, H, H, H, 0, sAct, sAct, sW, 0, 0, (long long)H, 0, 0};
+    // NN: dh1 [B,H] = dh2 [B,H] . W2 [H,H], masked by h1 > 0                     (K = H)
+    GemmArgs nn{dh2, W2, dh1, nullptr, h1, nullptr, B, H, H, H, H, H, H, sAct, sW, sAct, 0, sAct, 0, 0, 0};
+    const int tx = (H + kTile - 1) / kTile, ty = tx, nx = tx, ny = (B + kTile - 1) / kTile;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool fast = (H % kTile) == 0 && (B % kTile) == 0 && (H % kPanel) == 0 && (B % kPanel) == 0 && al(dh2) &&
+                      al(h1) && al(W2);
+    const dim3 grid(tx * ty + nx * ny, G), block(64);
+    if (fast) hipLaunchKernelGGL(gemm16_pair_kernel<true>, grid, block, 0, (hipStream_t)stream, tn, nn, tx, tx * ty, nx);
+    else hipLaunchKernelGGL(gemm16_pair_kernel<false>, grid, block, 0, (hipStream_t)stream, tn, nn, tx, tx * ty, nx);
     return check_launch();
 }
 

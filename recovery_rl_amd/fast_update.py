@@ -152,6 +152,7 @@ class Stack:
         self.scratch = z(4, G, B, net.dout)         # partial last-layer sums of the small-batch forward
         self.split = bool(_lib.load().rrl_mlp3_is_split(B, H)) and mlp3_supported(H, net.din, net.dout)
         self.finalize = False                       # True: always hand back the summed output tensor
+        self.pair_hidden = True                     # dW2 and dh1 of the backward in one launch
 
     def forward(self, x, params=None, save=True):
         """x [B, din] shared by all heads.  `params` lets a target network reuse this workspace;
@@ -193,10 +194,15 @@ class Stack:
             _lib.check(lib.rrl_mlp_head_backward(G, B, H, net.dout, dout.data_ptr(), self.h2.data_ptr(),
                                                  P["W3"].data_ptr(), gw3, gb3, self.dh2.data_ptr(), st),
                        "rrl_mlp_head_backward")
-        # hidden layer: the two H x H GEMMs on the MFMA kernel
-        if weight_grads:
-            gemm(TN, self.dh2, self.h1, out=Gr["W2"], colsum=Gr["b2"])
-        gemm(NN, self.dh2, P["W2"], out=self.dh1, mask=self.h1)
+        # hidden layer: the two H x H GEMMs on the MFMA kernel -- one launch when both are needed
+        if weight_grads and self.pair_hidden:
+            _lib.check(lib.rrl_mlp_hidden_backward(G, B, H, self.dh2.data_ptr(), self.h1.data_ptr(),
+                                                   P["W2"].data_ptr(), Gr["W2"].data_ptr(), Gr["b2"].data_ptr(),
+                                                   self.dh1.data_ptr(), st), "rrl_mlp_hidden_backward")
+        else:
+            if weight_grads:
+                gemm(TN, self.dh2, self.h1, out=Gr["W2"], colsum=Gr["b2"])
+            gemm(NN, self.dh2, P["W2"], out=self.dh1, mask=self.h1)
         # first layer (2..4 inputs): dW1, db1 and/or dx in one streaming kernel
         _lib.check(lib.rrl_mlp_input_backward(G, B, H, net.din, self.dh1.data_ptr(), self.x.data_ptr(),
                                               self.x.stride(0), P["W1"].data_ptr(),

@@ -239,7 +239,8 @@ def test_adam_multi_equals_separate_adam_steps():
 @pytest.mark.parametrize("hidden,B", ((32, 64), (256, 256)))
 def test_loss_fused_head_backward_is_bit_identical_to_the_separate_grad_kernels(hidden, B):
     """rrl_mlp_head_backward_loss evaluates the formulas of the stand-alone *_grad / *_head_bwd kernels inside the
-    head-backward kernel: every parameter after 3 updates must be bit-identical, the logged losses close."""
+    head-backward kernel, and rrl_mlp_hidden_backward runs the dW2 / dh1 tiles of rrl_gemm_f32 in one launch: every
+    parameter after 3 updates must be bit-identical to the unfused launches, the logged losses close."""
     _, a, _ = make_pair(hidden)
     _, b, _ = make_pair(hidden)
     for dst, src in ((b.critic, a.critic), (b.critic_target, a.critic_target), (b.policy, a.policy),
@@ -250,6 +251,8 @@ def test_loss_fused_head_backward_is_bit_identical_to_the_separate_grad_kernels(
     a.enable_fast_path(B)
     b.enable_fast_path(B)
     a.fast.fuse_loss, b.fast.fuse_loss = True, False
+    for name in ("pol_a", "pol_b", "cri_a", "cri_b", "qr_a", "qr_b", "rec_a"):
+        getattr(b.fast, name).pair_hidden = False          # ... and the two hidden-layer GEMMs as separate launches
     for step in range(3):
         b_sac, b_qr, e1, e2 = batch(B, 40 + step)
         for ag in (a, b):
