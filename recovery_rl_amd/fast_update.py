@@ -213,6 +213,32 @@ class Stack:
         return self.dx if input_grad else None
 
 
+class StackRows(Stack):
+    """Rows [lo, hi) of a single-head Stack whose forward ran on a taller batch (several inputs of the SAME
+    network stacked along the batch: one launch instead of one per input).  Shares the parent's activations and
+    outputs, owns the backward workspace of its rows."""
+
+    def __init__(self, parent, lo, hi):
+        assert parent.net.G == 1, "row slices of a multi-head stack are not contiguous"
+        self.parent, self.lo, self.hi = parent, lo, hi
+        self.net, self.B = parent.net, hi - lo
+        dev, H = parent.net.device, parent.net.H
+        z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.h1, self.h2 = parent.h1[:, lo:hi], parent.h2[:, lo:hi]
+        self.dh1, self.dh2, self.dx = z(1, self.B, H), z(1, self.B, H), z(1, self.B, parent.net.din)
+        self.pair_hidden = True
+
+    def forward(self, *a, **k):
+        raise RuntimeError("run the parent's forward, then use .after_forward()")
+
+    def after_forward(self):
+        """(tensor, n_part, part_stride) of this slice's outputs after the parent's forward."""
+        t, n_part, ps = self.parent.parts
+        self.x = self.parent.x[self.lo:self.hi]
+        self.parts = (t[0, 0, self.lo:self.hi] if n_part > 1 else t[0, self.lo:self.hi], n_part, ps)
+        return self.parts
+
+
 class FastUpdater:
     """Fused-kernel implementation of one SAC step and one Q_risk (+ model-free recovery) step for the
     default Recovery-RL configuration.  Owns the flat parameter storage of the agent's networks."""
@@ -231,11 +257,16 @@ class FastUpdater:
         self.recpolicy = flatten_policy(self.qr.policy, dev)
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         # stacks (workspaces) -- a network evaluated twice with saved activations needs two
-        self.pol_a, self.pol_b = Stack(self.policy, B), Stack(self.policy, B)
+        # SAC evaluates the policy on s' and on s with the same weights: one forward over 2B stacked rows
+        self.pol_a = Stack(self.policy, B)
+        self.pol_ab = Stack(self.policy, 2 * B)
+        self.pol_next, self.pol_b = StackRows(self.pol_ab, 0, B), StackRows(self.pol_ab, B, 2 * B)
         self.cri_a, self.cri_b = Stack(self.critic, B), Stack(self.critic, B)
         self.qr_a, self.qr_b = Stack(self.qrisk, B), Stack(self.qrisk, B)
         self.rec_a = Stack(self.recpolicy, B)
-        self.xu, self.x2u, self.xpu = z(B, 4), z(B, 4), z(B, 4)     # [s|a], [s'|a'], [s|pi]
+        self.xu = z(B, 4)                                           # [s | a]
+        self.x_pol = z(2 * B, 4)                                    # [s' | a'] stacked on [s | pi]
+        self.x2u, self.xpu = self.x_pol[:B], self.x_pol[B:]
         self.logp2, self.logp = z(B), z(B)
         self.dq, self.dhead, self.draw = z(2, B, 1), z(1, B, 4), z(1, B, 2)
         self.dact = z(B, 2)
@@ -351,8 +382,10 @@ class FastUpdater:
     def sac_update(self, batch, eps_next, eps_pi, rows_loaded=False):
         ag, B, lib, st = self.agent, self.B, self.lib, _lib.current_stream()
         s, a, r, s2, m = self._load_batch(batch, rows_loaded)
+        # pi(s') and pi(s) share the weights (both gradients are taken before either step): ONE policy forward
+        self.pol_ab.forward(self.x_pol[:, 0:2])
         # target: a' ~ pi(s'), min Q_target(s', a') - alpha log pi  (sac.py:192-201)
-        head2 = self.pol_a.forward(s2, save=False)
+        head2 = self.pol_next.after_forward()
         self._gauss_fwd(head2, eps_next, self.x2u[:, 2:4], self.logp2)
         qt, n_part, ps = self.cri_b.forward(self.x2u, params=self.critic_target, save=False)
         q, _, _ = self.cri_a.forward(self.xu)
@@ -366,7 +399,7 @@ class FastUpdater:
                         "rrl_sac_critic_grad")
             self.cri_a.backward(self.dq)
         # policy loss at the PRE-update critic (both gradients before either step)
-        head = self.pol_b.forward(s)
+        head = self.pol_b.after_forward()
         self._gauss_fwd(head, eps_pi, self.xpu[:, 2:4], self.logp)
         qp, n_part, ps = self.cri_b.forward(self.xpu)
         ht, hn, hs = head
