@@ -226,8 +226,20 @@ def cpu_baseline(budget_s=15.0):
         if now - t0 > 4 * budget_s:
             break
     dt = time.perf_counter() - (t_start or t0)
+    # attribution (SURVEY 8d "CPU side-by-side"): the env alone, batched on ONE core of the same host
+    n_env = 4096
+    p4, _, t4 = co.nav_reset("navigation1", n_env, seed=1, counter=0)
+    a4 = np.random.RandomState(0).uniform(-1, 1, (n_env, 2)).astype(np.float32)
+    te = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - te < 1.0:
+        o = co.nav_step("navigation1", p4, a4, t4, seed=1, counter=reps + 1, auto_reset=True)
+        p4, t4 = o["pos"], o["t"]
+        reps += 1
+    env_only = reps * n_env / (time.perf_counter() - te)
     return {"value": timed_steps / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(),
             "kind": "port", "grad_steps_per_s": timed_updates / dt,
+            "env_only_env_steps_per_s_1core": env_only,
             "sample": "%d env-steps of the reference-order loop (1 env, 1 SAC + 1 Q_risk/recovery update "
                       "per env-step, B=256, H=256) in %.1f s: C oracle env + oracle replay + torch CPU nets"
                       % (timed_steps, dt)}
