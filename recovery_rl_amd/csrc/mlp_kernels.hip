@@ -464,66 +464,10 @@ __global__ void sum_partials_kernel(int n, const float* __restrict__ partial, fl
 // slices are summed in a fixed order (deterministic).
 constexpr int kCols = 16, kSlices = 16, kUnroll = 16;
 
-__global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int dout,
-                                                       const float* __restrict__ dOut,
-                                                       const float* __restrict__ h2,
-                                                       const float* __restrict__ W3, float* __restrict__ dW3,
-                                                       float* __restrict__ db3, float* __restrict__ dh2,
-                                                       int need_w) {
-    __shared__ float red[kSlices][4][kCols];
-    __shared__ float dsh[1024 * 4];   // dOut of this head (B <= 1024)
-    const int g = blockIdx.y, hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols;
-    const int h = blockIdx.x * kCols + hc;
-    const bool hok = h < H;
-    const int hh = hok ? h : H - 1;
-    const float* dO = dOut + (long long)g * B * dout;
-    for (int e = threadIdx.x; e < B * dout; e += 256) dsh[e] = dO[e];
-    float w[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int o = 0; o < 4; ++o) w[o] = o < dout ? W3[((long long)g * dout + o) * H + hh] : 0.f;
-    __syncthreads();
-    for (int b0 = 0; b0 < B; b0 += kSlices * kUnroll) {
-        float a[kUnroll];
-#pragma unroll
-        for (int it = 0; it < kUnroll; ++it) {
-            const int b = min(b0 + slice + kSlices * it, B - 1);
-            a[it] = h2[((long long)g * B + b) * H + hh];
-        }
-#pragma unroll
-        for (int it = 0; it < kUnroll; ++it) {
-            const int b = b0 + slice + kSlices * it;
-            if (b < B) {
-                float d = 0.f;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const float go = o < dout ? dsh[b * dout + o] : 0.f;
-                    d = fmaf(go, w[o], d);
-                    acc[o] = fmaf(go, a[it], acc[o]);
-                }
-                if (hok) dh2[((long long)g * B + b) * H + h] = a[it] > 0.f ? d : 0.f;
-            }
-        }
-    }
-    if (!need_w) return;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) red[slice][o][hc] = acc[o];
-    __syncthreads();
-    if (slice < dout && hok) {
-        float sum = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < kSlices; ++sl) sum += red[sl][slice][hc];
-        dW3[((long long)g * dout + slice) * H + h] = sum;
-    }
-    if (blockIdx.x == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + (unsigned)dout) {   // bias gradient
-        const int o = threadIdx.x - 128;
-        float sum = 0.f;
-        for (int b = 0; b < B; ++b) sum += dsh[b * dout + o];
-        db3[g * dout + o] = sum;
-    }
-}
-
-// ---- the same kernel with dOut computed from a loss description (rrl_loss_t) ----------------------------
-// Formulas are those of update_kernels.hip (sac/qrisk *_grad, gauss/stoch_head_bwd), evaluated per (g, b, o).
+// dOut is either read from memory (KIND = kPlainDOut: la.out = dOut [G,B,dout]) or computed in place from a loss
+// description (rrl_loss_t): the formulas of update_kernels.hip (sac/qrisk *_grad, gauss/stoch_head_bwd),
+// evaluated per (g, b, o).
+constexpr int kPlainDOut = -1;
 namespace loss {
 
 constexpr float kLogSigMax = 2.f, kLogSigMin = -20.f, kEps = 1e-6f;   // model.py:14-16
@@ -607,7 +551,10 @@ __global__ __launch_bounds__(256) void head_bwd_loss_kernel(rrl_loss_t la, int B
     const bool hok = h < H;
     const int hh = hok ? h : H - 1;
     float lsum[2] = {0.f, 0.f};
-    if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
+    if constexpr (KIND == kPlainDOut) {
+        const float* dO = la.out + (long long)g * B * dout;
+        for (int e = threadIdx.x; e < B * dout; e += 256) dsh[e] = dO[e];
+    } else if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
         // one thread per (row, action dim): the mean and log-std gradients share tanh/exp
         for (int e = threadIdx.x; e < B * 2; e += 256) {
             const int b = e >> 1, j = e & 1;
@@ -672,7 +619,8 @@ __global__ __launch_bounds__(256) void head_bwd_loss_kernel(rrl_loss_t la, int B
     }
     // loss scalars / dlog_std: one workgroup per head reduces the per-thread terms in a fixed tree
     constexpr bool per_head = KIND == RRL_LOSS_SAC_CRITIC || KIND == RRL_LOSS_QRISK_CRITIC;
-    if (blockIdx.x != 0 || !la.loss || KIND == RRL_LOSS_GAUSS_HEAD || (!per_head && g != 0)) return;
+    if (KIND == kPlainDOut || KIND == RRL_LOSS_GAUSS_HEAD || blockIdx.x != 0 || !la.loss || (!per_head && g != 0))
+        return;
     __syncthreads();
     float* r0 = &red[0][0][0];          // 1024 floats: two arrays of 256
     r0[threadIdx.x] = lsum[0];
@@ -857,8 +805,10 @@ int rrl_mlp_head_backward(int G, int B, int H, int dout, const float* dOut, cons
     if (!dOut || !h2 || !W3 || !dh2) return RRL_EINVAL;
     if (G <= 0 || B <= 0 || B > 1024 || H <= 0 || dout <= 0 || dout > 4) return RRL_ERANGE;
     const int need_w = dW3 != nullptr && db3 != nullptr;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((H + kCols - 1) / kCols, G), dim3(256), 0, (hipStream_t)stream, B, H, dout, dOut,
-                       h2, W3, dW3, db3, dh2, need_w);
+    rrl_loss_t la{};
+    la.out = dOut;
+    hipLaunchKernelGGL((head_bwd_loss_kernel<kPlainDOut>), dim3((H + kCols - 1) / kCols, G), dim3(256), 0,
+                       (hipStream_t)stream, la, B, H, dout, h2, W3, dW3, db3, dh2, need_w);
     return check_launch();
 }
 
