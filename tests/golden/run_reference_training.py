@@ -7,7 +7,8 @@ are comparable.
 Harness patches, applied from outside: (a) torchify -> CPU, (b) critic step deferred until the
 policy loss has been back-propagated (torch >= 1.5 rejects the reference's order), (c) float32 log_std.
 
-Run: python tests/golden/run_reference_training.py [seed] [num_eps] -> tests/golden/ref_learning_nav1_seed<seed>.json
+Run: python tests/golden/run_reference_training.py [seed] [num_eps] [nav1|nav2]
+  -> tests/golden/ref_learning_<nav1|nav2>_seed<seed>.json   (nav2 = scripts/navigation2.sh:7)
 """
 import contextlib
 import io
@@ -29,6 +30,8 @@ import torch  # noqa: E402
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     num_eps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    which = sys.argv[3] if len(sys.argv) > 3 else "nav1"
+    env_name, gamma_safe, eps_safe = {"nav1": ("navigation1", "0.8", "0.3"), "nav2": ("navigation2", "0.65", "0.2")}[which]
     import arg_utils
     import recovery_rl.experiment as rexp
     import recovery_rl.sac as rsac
@@ -51,8 +54,8 @@ def main():
         self.critic_optim.step, self.policy_optim.step = deferred, both              # (b)
     rsac.SAC.__init__ = patched_init
     tmp = tempfile.mkdtemp()
-    sys.argv = ["rrl_main", "--env-name", "navigation1", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.8",
-                "--eps_safe", "0.3", "--logdir", tmp, "--logdir_suffix", "RRL_MF", "--num_eps", str(num_eps),
+    sys.argv = ["rrl_main", "--env-name", env_name, "--use_recovery", "--MF_recovery", "--gamma_safe", gamma_safe,
+                "--eps_safe", eps_safe, "--logdir", tmp, "--logdir_suffix", "RRL_MF", "--num_eps", str(num_eps),
                 "--num_unsafe_transitions", "20000", "--seed", str(seed), "--eval", ""]
     cfg = arg_utils.get_args()
     t0 = time.time()
@@ -68,7 +71,7 @@ def main():
            "num_constraint_transitions": exp.num_unsafe_transitions,
            "num_constraint_violations_offline": exp.num_constraint_violations, "wall_seconds": time.time() - t0,
            "env_steps": exp.total_numsteps}
-    json.dump(res, open(os.path.join(HERE, "ref_learning_nav1_seed%d.json" % seed), "w"))
+    json.dump(res, open(os.path.join(HERE, "ref_learning_%s_seed%d.json" % (which, seed)), "w"))
     print({k: v for k, v in res.items() if not isinstance(v, list)})
 
 
