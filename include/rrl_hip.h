@@ -332,7 +332,7 @@ int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uin
                   float beta1, float beta2, float eps, float* target, float tau, void* stream);
 /* rrl_adam_step for up to RRL_ADAM_MAX_SEGS flat buffers in one launch (e.g. critic + policy of one update);
  * every segment has its own step counter and optional Polyak target. */
-#define RRL_ADAM_MAX_SEGS 4
+#define RRL_ADAM_MAX_SEGS 12
 typedef struct {
     long long n;
     float* p;
@@ -410,6 +410,31 @@ int rrl_plan_pack(const rrl_plan_weights_t* w, float* packed, void* stream);
 int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
                   const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
                   uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Ensemble fitting.  One optimiser step of MPC.train (recovery_rl/MPC.py:266-292) for the PETS ensemble
+ * (PtModel, config/navigation1.py:23-96): gather of the bootstrap rows idx[e, 0..batch), forward, loss
+ *   sum_e mean((mean_e - y)^2 exp(-logvar_e) + logvar_e) + 0.01 (sum max_logvar - sum min_logvar) + decays (:52-59)
+ * and its gradient w.r.t. every parameter in ONE launch (+ a 4-thread reduction for the shared logvar bounds);
+ * the update itself is rrl_adam_step_multi over the same buffers (torch.optim.Adam, lr 1e-3).
+ *   parameters  w0 [E,4,H] b0 [E,1,H] w1,w2 [E,H,H] b1,b2 [E,1,H] w3 [E,H,4] b3 [E,1,4] (in x out), max/min_logvar [2],
+ *               mu/sigma [4] (input standardisation, not trained); g_* = gradients, same shapes;
+ *               g_logvar_part: scratch [E,4]
+ *   idx         int64 [E, >= batch] with row stride idx_stride (elements): rows of train_in [N,4] / train_targ [N,2]
+ *   scratch     float [rrl_ens_scratch_floats(E)]; loss_out (nullable) [E] = the per-net NLL term
+ * Supported shape (rrl_ens_train_supported): 4 inputs, H = 200, 4 outputs, batch 1..32 (the mean runs over the
+ * real rows, as for the shorter last batch of an epoch).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int n_nets, d_in, hidden, d_out;
+    float *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3, *max_logvar, *min_logvar;
+    const float *mu, *sigma;
+    float *g_w0, *g_b0, *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *g_max_logvar, *g_min_logvar, *g_logvar_part;
+} rrl_ens_t;
+int rrl_ens_train_supported(int d_in, int hidden, int d_out, int batch);
+long long rrl_ens_scratch_floats(int n_nets);
+int rrl_ens_train_grad(const rrl_ens_t* m, int batch, const float* train_in, const float* train_targ,
+                       const int64_t* idx, long long idx_stride, float* scratch, float* loss_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,8 @@ class MPC:
                                "Must provide a model constructor.")(self.model_init_cfg)
         self.value_func = None
         self.graph_train = True            # replay the ensemble training step from a hipGraph (same kernels)
+        self.fused_train = True            # ... or, for the reference's shapes, run it as one fused kernel
+        self._trainer = None
         self.fused = None                  # FusedPlanner (rrl_plan_cost) when the shapes allow it
         self.use_fused_planner = True
         self._lb = torch.as_tensor(self.ac_lb, dtype=torch.float32, device=self.device)
@@ -141,11 +143,18 @@ class MPC:
             epochs = self.model_train_cfg['epochs']
         num_batch = int(np.ceil(n / batch_size))
         losses = None
-        step = _GraphedTrainStep(self, batch_size) if self.graph_train and epochs * (n // batch_size) >= 16 else None
+        fused = self._fused_trainer(batch_size)
+        if fused is not None:
+            fused.begin(self.train_in, self.train_targs)
+        step = None
+        if fused is None and self.graph_train and epochs * (n // batch_size) >= 16:
+            step = _GraphedTrainStep(self, batch_size)
         for _ in range(epochs):
             for b in range(num_batch):
                 bi = idxs[:, b * batch_size:(b + 1) * batch_size]
-                if step is not None and bi.shape[1] == batch_size:
+                if fused is not None:
+                    fused.step(bi)                    # rrl_ens_train_grad + rrl_adam_step_multi: 3 launches
+                elif step is not None and bi.shape[1] == batch_size:
                     step(bi)                          # one hipGraph replay: forward + backward + Adam
                 else:
                     self._train_step(bi)
@@ -156,6 +165,16 @@ class MPC:
                     losses = ((mean - self.train_targs[idxs[:, :5000]]) ** 2).mean(-1).mean(-1)
                 print("Network training: MSE per net", losses.cpu().numpy())
         return losses
+
+    def _fused_trainer(self, batch_size):
+        """FusedEnsembleTrainer when the shapes are the kernel's (4-200-200-200-4, batch <= 32), else None.  The
+        fused path owns its Adam state, so once created it serves every later step of this controller."""
+        if not self.fused_train or self.train_in.device.type != "cuda":
+            return None
+        from .ensemble_train import FusedEnsembleTrainer
+        if self._trainer is None and FusedEnsembleTrainer.supported(self.model, batch_size):
+            self._trainer = FusedEnsembleTrainer(self.model, lr=self.model.optim.param_groups[0]["lr"])
+        return self._trainer if (self._trainer is not None and batch_size <= 32) else None
 
     def _train_step(self, bi):
         """One optimiser step on the bootstrap rows bi [num_nets, batch] (MPC.py:270-292)."""

@@ -14,7 +14,7 @@ SO_PATH = os.environ.get("RRL_HIP_LIB") or os.path.join(CSRC, "librrl_hip.so")  
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["nav_kernels.hip", "replay_kernels.hip", "maze_kernels.hip", "cem_kernels.hip",
-               "mlp_kernels.hip", "update_kernels.hip", "log_kernels.hip", "plan_kernels.hip"]
+               "mlp_kernels.hip", "update_kernels.hip", "log_kernels.hip", "plan_kernels.hip", "ens_train_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                "-Wno-bitwise-instead-of-logical"]
@@ -32,6 +32,7 @@ EXPORTS = [
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_adam_step_multi", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
     "rrl_plan_supported", "rrl_plan_pack_floats", "rrl_plan_pack", "rrl_plan_cost",
+    "rrl_ens_train_supported", "rrl_ens_scratch_floats", "rrl_ens_train_grad",
 ]
 
 
@@ -75,8 +76,15 @@ class rrl_episode_log_t(C.Structure):
 
 
 EPLOG_I32 = 6
-ADAM_MAX_SEGS = 4
+ADAM_MAX_SEGS = 12
 LOSS_SAC_CRITIC, LOSS_SAC_POLICY, LOSS_QRISK_CRITIC, LOSS_QRISK_POLICY, LOSS_GAUSS_HEAD, LOSS_STOCH_HEAD = range(6)
+
+
+class rrl_ens_t(C.Structure):
+    _fields_ = [("n_nets", C.c_int), ("d_in", C.c_int), ("hidden", C.c_int), ("d_out", C.c_int)] + [
+        (name, C.c_void_p) for name in ("w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3", "max_logvar", "min_logvar",
+                                        "mu", "sigma", "g_w0", "g_b0", "g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3",
+                                        "g_max_logvar", "g_min_logvar", "g_logvar_part")]
 
 
 class rrl_loss_t(C.Structure):
@@ -153,6 +161,9 @@ def _declare(lib):
         "rrl_plan_pack_floats": (ll, [ci, ci, ci]),
         "rrl_plan_pack": (ci, [C.POINTER(rrl_plan_weights_t), vp, vp]),
         "rrl_plan_cost": (ci, [vp, ci, ci, ci, ci, ll, ci, ci, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp]),
+        "rrl_ens_train_supported": (ci, [ci, ci, ci, ci]),
+        "rrl_ens_scratch_floats": (ll, [ci]),
+        "rrl_ens_train_grad": (ci, [C.POINTER(rrl_ens_t), ci, vp, vp, vp, ll, vp, vp, vp]),
         "rrl_episode_log_append": (ci, [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(rrl_episode_log_t), vp]),
     }
     for name, (res, args) in sig.items():

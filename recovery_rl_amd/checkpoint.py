@@ -153,6 +153,7 @@ def load_loop_state(loop, sd):
 def mpc_state(mpc):
     return {"model": {n: _cpu(v) for n, v in mpc.model.state_dict().items()},
             "optim": mpc.model.optim.state_dict() if hasattr(mpc.model, "optim") else None,
+            "trainer": mpc._trainer.state_dict() if mpc._trainer is not None else None,
             "train_in": _cpu(mpc.train_in), "train_targs": _cpu(mpc.train_targs),
             "has_been_trained": mpc.has_been_trained, "prev_sol": _cpu(mpc.prev_sol),
             "cem_tick": _cpu(mpc.optimizer.tick)}
@@ -162,6 +163,11 @@ def load_mpc_state(mpc, sd):
     mpc.model.load_state_dict(sd["model"])
     if sd["optim"] is not None:
         mpc.model.optim.load_state_dict(sd["optim"])
+    if sd.get("trainer") is not None:
+        from .ensemble_train import FusedEnsembleTrainer
+        if mpc._trainer is None:
+            mpc._trainer = FusedEnsembleTrainer(mpc.model, lr=mpc.model.optim.param_groups[0]["lr"])
+        mpc._trainer.load_state_dict(sd["trainer"])
     dev = mpc.device
     mpc.train_in, mpc.train_targs = sd["train_in"].to(dev), sd["train_targs"].to(dev)
     mpc.has_been_trained = sd["has_been_trained"]

@@ -1,0 +1,79 @@
+"""Fused optimiser step of the PETS ensemble: `rrl_ens_train_grad` (gather + forward + loss + backward in one
+launch) followed by `rrl_adam_step_multi` over the parameters -- the counterpart of one iteration of the batch
+loop of MPC.train (recovery_rl/MPC.py:266-292) with torch.optim.Adam(lr=1e-3) (config/navigation1.py:109).  The
+PyTorch step in MPC._train_step stays as the general path (other widths / batch sizes) and the cross-check."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+PARAMS = ("lin0_w", "lin0_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b", "lin3_w", "lin3_b", "max_logvar", "min_logvar")
+
+
+class FusedEnsembleTrainer:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.lib = _lib.load()
+        dev = model.lin0_w.device
+        self.device = dev
+        self.E = int(model.num_nets)
+        self.params = [getattr(model, n) for n in PARAMS]
+        for p in self.params:
+            assert p.dtype == torch.float32 and p.is_contiguous()
+        z = lambda p: torch.zeros_like(p.data)
+        self.grads = [z(p) for p in self.params]
+        self.m, self.v = [z(p) for p in self.params], [z(p) for p in self.params]
+        self.steps = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in self.params]    # {t, ticket}
+        self.part = torch.zeros(self.E, 4, device=dev)
+        self.scratch = torch.empty(int(self.lib.rrl_ens_scratch_floats(self.E)), device=dev)
+        self.loss = torch.zeros(self.E, device=dev)
+        self._segs = (_lib.rrl_adam_seg_t * len(self.params))()
+        for k, p in enumerate(self.params):
+            self._segs[k] = _lib.rrl_adam_seg_t(p.numel(), p.data_ptr(), self.grads[k].data_ptr(), self.m[k].data_ptr(),
+                                                self.v[k].data_ptr(), self.steps[k].data_ptr(), None, 0.0)
+
+    @staticmethod
+    def supported(model, batch_size):
+        lib = _lib.load()
+        return (model.lin0_w.is_cuda and
+                bool(lib.rrl_ens_train_supported(int(model.in_features), int(model.lin1_w.shape[1]),
+                                                 int(model.out_features), int(batch_size))))
+
+    def _desc(self):
+        m = self.model
+        ptrs = [p.data_ptr() for p in self.params]
+        mu = m.inputs_mu.data.reshape(-1).contiguous()
+        sigma = m.inputs_sigma.data.reshape(-1).contiguous()
+        self._keep = (mu, sigma)
+        return _lib.rrl_ens_t(self.E, int(m.in_features), int(m.lin1_w.shape[1]), int(m.out_features), *ptrs,
+                              mu.data_ptr(), sigma.data_ptr(), *[g.data_ptr() for g in self.grads],
+                              self.part.data_ptr())
+
+    def begin(self, train_in, train_targ):
+        """Bind the dataset and the current input statistics (they change with every MPC.train call)."""
+        assert train_in.is_contiguous() and train_targ.is_contiguous()
+        self._data = (train_in, train_targ)
+        self._d = self._desc()
+
+    def gradients(self, idx):
+        """idx: int64 [E, 1..32] (rows may be strided views of a wider table).  Fills self.grads / self.loss."""
+        assert idx.dtype == torch.int64 and idx.stride(1) == 1 and idx.shape[0] == self.E
+        rc = self.lib.rrl_ens_train_grad(C.byref(self._d), int(idx.shape[1]), _lib.ptr(self._data[0]),
+                                         _lib.ptr(self._data[1]), _lib.ptr(idx), idx.stride(0), _lib.ptr(self.scratch),
+                                         _lib.ptr(self.loss), _lib.current_stream())
+        _lib.check(rc, "rrl_ens_train_grad")
+
+    def step(self, idx):
+        self.gradients(idx)
+        rc = self.lib.rrl_adam_step_multi(len(self.params), self._segs, self.lr, self.betas[0], self.betas[1],
+                                          self.eps, _lib.current_stream())
+        _lib.check(rc, "rrl_adam_step_multi")
+
+    # -- checkpoint ------------------------------------------------------------------------------
+    def state_dict(self):
+        return {"m": [t.cpu() for t in self.m], "v": [t.cpu() for t in self.v], "steps": [t.cpu() for t in self.steps]}
+
+    def load_state_dict(self, sd):
+        for dst, src in zip(self.m + self.v + self.steps, sd["m"] + sd["v"] + sd["steps"]):
+            dst.copy_(src)
