@@ -254,7 +254,9 @@ def main():
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--planner", action="store_true",
-                    help="also time the fused planner kernel of config 4 (MFMA roofline) -> roofline_planner")
+                    help="time the fused planner kernel of config 4 (MFMA roofline) -> roofline_planner; "
+                         "on by default for single-GPU runs")
+    ap.add_argument("--no_planner", action="store_true")
     ap.add_argument("--sweep", action="store_true",
                     help="also time rrl_nav_step at N = 2^12..2^24 (the bandwidth regime of the env kernel); off by "
                          "default so that every nav_step_kernel launch of the default command has the bench size")
@@ -322,7 +324,7 @@ def main():
                 "achieved_GBs": n_r * t_r * 13 / tr / 1e9, "frac": n_r * t_r * 13 / tr / 1e9 / HBM_PEAK_GBS,
                 "note": "8 B action read + 4 B reward + 1 B constraint written per env-step; the state never leaves "
                         "registers, so the f64 Philox / Box-Muller arithmetic, not HBM, is the limit"}
-        if a.planner:
+        if (a.planner or world == 1) and not a.no_planner:
             t_p, row_steps = time_planner_kernel(device)
             tf = row_steps * PLAN_FLOPS_PER_ROW_STEP / t_p / 1e12
             extra["roofline_planner"] = {
