@@ -342,6 +342,7 @@ typedef struct {
     uint64_t* step_dev;
     float* target;
     float tau;
+    float weight_decay;   /* g <- g + weight_decay * p before the moment updates (torch.optim.Adam weight_decay) */
 } rrl_adam_seg_t;
 int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2, float eps,
                         void* stream);
@@ -415,7 +416,8 @@ int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, lo
  * Ensemble fitting.  One optimiser step of MPC.train (recovery_rl/MPC.py:266-292) for the PETS ensemble
  * (PtModel, config/navigation1.py:23-96): gather of the bootstrap rows idx[e, 0..batch), forward, loss
  *   sum_e mean((mean_e - y)^2 exp(-logvar_e) + logvar_e) + 0.01 (sum max_logvar - sum min_logvar) + decays (:52-59)
- * and its gradient w.r.t. every parameter in ONE launch (+ a 4-thread reduction for the shared logvar bounds);
+ * and its gradient w.r.t. every parameter EXCEPT the decay terms (pass them as the segments' weight_decay:
+ * 0.00025 / 0.0005 / 0.0005 / 0.00075 for w0..w3) in ONE launch (+ a 4-thread reduction for the shared logvar bounds);
  * the update itself is rrl_adam_step_multi over the same buffers (torch.optim.Adam, lr 1e-3).
  *   parameters  w0 [E,4,H] b0 [E,1,H] w1,w2 [E,H,H] b1,b2 [E,1,H] w3 [E,H,4] b3 [E,1,4] (in x out), max/min_logvar [2],
  *               mu/sigma [4] (input standardisation, not trained); g_* = gradients, same shapes;
@@ -433,6 +435,12 @@ typedef struct {
 } rrl_ens_t;
 int rrl_ens_train_supported(int d_in, int hidden, int d_out, int batch);
 long long rrl_ens_scratch_floats(int n_nets);
+/* one epoch = ceil(n_rows / batch) steps {rrl_ens_train_grad on idx[:, lo:lo+batch], rrl_adam_step_multi(segs)} issued
+ * from C (the batch loop of MPC.py:266-292); segs = the Adam segments of the ten parameter tensors */
+int rrl_ens_train_epoch(const rrl_ens_t* m, int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2,
+                        float eps, const float* train_in, const float* train_targ, const int64_t* idx,
+                        long long idx_stride, long long n_rows, int batch, float* scratch, float* loss_out,
+                        void* stream);
 int rrl_ens_train_grad(const rrl_ens_t* m, int batch, const float* train_in, const float* train_targ,
                        const int64_t* idx, long long idx_stride, float* scratch, float* loss_out, void* stream);
 

@@ -150,11 +150,11 @@ class MPC:
         if fused is None and self.graph_train and epochs * (n // batch_size) >= 16:
             step = _GraphedTrainStep(self, batch_size)
         for _ in range(epochs):
-            for b in range(num_batch):
+            if fused is not None:
+                fused.epoch(idxs, batch_size)         # every batch: rrl_ens_train_grad + rrl_adam_step_multi
+            for b in range(num_batch if fused is None else 0):
                 bi = idxs[:, b * batch_size:(b + 1) * batch_size]
-                if fused is not None:
-                    fused.step(bi)                    # rrl_ens_train_grad + rrl_adam_step_multi: 3 launches
-                elif step is not None and bi.shape[1] == batch_size:
+                if step is not None and bi.shape[1] == batch_size:
                     step(bi)                          # one hipGraph replay: forward + backward + Adam
                 else:
                     self._train_step(bi)

@@ -32,7 +32,7 @@ EXPORTS = [
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_adam_step_multi", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
     "rrl_plan_supported", "rrl_plan_pack_floats", "rrl_plan_pack", "rrl_plan_cost",
-    "rrl_ens_train_supported", "rrl_ens_scratch_floats", "rrl_ens_train_grad",
+    "rrl_ens_train_supported", "rrl_ens_scratch_floats", "rrl_ens_train_grad", "rrl_ens_train_epoch",
 ]
 
 
@@ -97,7 +97,7 @@ class rrl_loss_t(C.Structure):
 
 class rrl_adam_seg_t(C.Structure):
     _fields_ = [("n", C.c_longlong), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
-                ("step_dev", C.c_void_p), ("target", C.c_void_p), ("tau", C.c_float)]
+                ("step_dev", C.c_void_p), ("target", C.c_void_p), ("tau", C.c_float), ("weight_decay", C.c_float)]
 
 
 class rrl_plan_weights_t(C.Structure):
@@ -163,6 +163,8 @@ def _declare(lib):
         "rrl_plan_cost": (ci, [vp, ci, ci, ci, ci, ll, ci, ci, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp]),
         "rrl_ens_train_supported": (ci, [ci, ci, ci, ci]),
         "rrl_ens_scratch_floats": (ll, [ci]),
+        "rrl_ens_train_epoch": (ci, [C.POINTER(rrl_ens_t), ci, C.POINTER(rrl_adam_seg_t), f32, f32, f32, f32, vp, vp,
+                                     vp, ll, ll, ci, vp, vp, vp]),
         "rrl_ens_train_grad": (ci, [C.POINTER(rrl_ens_t), ci, vp, vp, vp, ll, vp, vp, vp]),
         "rrl_episode_log_append": (ci, [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(rrl_episode_log_t), vp]),
     }

@@ -5,8 +5,8 @@
 // The PyTorch step is ~45 launches of tiny kernels (batch 32 x 5 nets x 200-wide layers = 39 MFLOP), i.e. bound by
 // launch latency (0.12 ms per step even when replayed from a hipGraph); the re-fit after every episode is what
 // dominates the wall-clock of model-based recovery (experiment.py:464-480).  Here one workgroup (1024 threads) owns
-// one ensemble member for the whole step: activations and their gradients live in LDS (128 KB), weights are read
-// from L2 with coalesced accesses, every reduction has a fixed order (deterministic).
+// one ensemble member for the whole step: activations and their gradients live in LDS (128 KB), the layer
+// products run on the MFMA unit with weights read from L2, every reduction has a fixed order (deterministic).
 //
 // Shapes are the reference's: 4 inputs (obs 2 + action 2), 3 hidden layers of 200 with swish, 4 outputs (mean 2,
 // logvar 2), batch 32.  Weight layout [net][in][out] (torch.baddbmm(b, x, w)).
@@ -22,84 +22,159 @@ constexpr int kH = 200;          // hidden width
 constexpr int kB = 32;           // batch rows per net
 constexpr int kDin = 4, kDout = 4;
 constexpr int kThreads = 1024;
-constexpr int kLdsFloats = 5 * kB * kH + kB * (kDin + 2 + kDout + kDout) + 16;
-constexpr int kLdsBytes = kLdsFloats * 4;      // 130 KB
+constexpr int kSmall = 3 * kH + kH * kDout + kDout;   // b0, b1, b2, W3, b3 staged in LDS with the first loads
+constexpr int kLdsFloats = 5 * kB * kH + kB * (kDin + 2 + kDout + kDout) + 16 + kSmall;
+constexpr int kLdsBytes = kLdsFloats * 4;      // 136 KB
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus
 __device__ __forceinline__ float softplus_grad(float x) { return x > 20.f ? 1.f : sigm(x); }
 
-// pre[r][j] = b[j] + sum_k in[r][k] W[k][j]; writes h = swish(pre) to LDS and swish'(pre) to the global scratch.
-// thread -> column j = tid % 256 (< 200), row group tid / 256 (8 rows)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int kColTiles = (kH + 15) / 16;     // 13 (200 = 12.5 x 16: the last tile is half masked)
+constexpr int kWaves = kThreads / 64;
+
+// The three products of a layer are 16x16x4 f32 MFMA tiles (one ensemble member = one CU: an LDS-fed VALU
+// formulation was LDS-issue bound, 134 us per step).  MFMA step s uses k = 4 s + lane / 16; C layout: row =
+// 4 (lane / 16) + i, col = lane % 16.
+//
+// Work split of every product: wave w < 13 owns the 16-wide strip w of the 200-wide dimension and BOTH 16-row tiles of
+// the batch, so each weight element is requested once per step and a layer costs ONE L2 round trip per wave (the
+// 1024-thread workgroup caps a lane at 128 VGPRs: 50 dwords / 13 float4 of weights in flight fit, twice that spills).
+//
+// forward: pre[32 x 200] = in[32 x K] . W[K x 200] + b;  h = swish(pre) -> LDS, swish'(pre) -> global scratch
 template <int K>
 __device__ __forceinline__ void fwd_layer(const float* in, int ld_in, const float* __restrict__ W,
-                                          const float* __restrict__ b, float* h_out, float* __restrict__ sp, int tid) {
-    const int j = tid & 255, r0 = (tid >> 8) * 8;
-    if (j >= kH) return;
-    float acc[8];
-    const float bj = b[j];
+                                          const float* b /* LDS */, float* h_out, float* __restrict__ sp, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    if (wave >= kColTiles) return;
+    constexpr int S = K / 4;
+    const int col = wave * 16 + lr;
+    const bool cok = col < kH;
+    const float* bcol = W + (size_t)lq * kH + (cok ? col : kH - 1);
+    float bv[S];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = bj;
-#pragma unroll 8
-    for (int k = 0; k < K; ++k) {
-        const float w = W[k * kH + j];
+    for (int s = 0; s < S; ++s) bv[s] = bcol[(size_t)4 * s * kH];
+    const float* a0 = in + lr * ld_in + lq;
+    const float* a1 = in + (16 + lr) * ld_in + lq;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = fmaf(in[(r0 + r) * ld_in + k], w, acc[r]);
+    for (int s = 0; s < S; ++s) {
+        const float w = cok ? bv[s] : 0.f;
+        acc0 = mfma(a0[4 * s], w, acc0);
+        acc1 = mfma(a1[4 * s], w, acc1);
     }
+    if (cok) {
+        const float bj = b[col];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const float p = acc[r], s = sigm(p);
-        h_out[(r0 + r) * kH + j] = p * s;
-        sp[(r0 + r) * kH + j] = s * (1.f + p * (1.f - s));      // d swish / d pre
-    }
-}
-
-// gW[k][j] = sum_r h_in[r][k] dpre[r][j] + decay W[k][j];  gb[j] = sum_r dpre[r][j]
-// thread -> column j = tid % 256, k range = (tid / 256) * K/4 ...
-template <int K>
-__device__ __forceinline__ void grad_weights(const float* h_in, int ld_in, const float* dpre,
-                                             const float* __restrict__ W, float decay, float* __restrict__ gW,
-                                             float* __restrict__ gb, int tid) {
-    const int j = tid & 255, kg = tid >> 8;
-    if (j >= kH) return;
-    float d[kB];
-#pragma unroll
-    for (int r = 0; r < kB; ++r) d[r] = dpre[r * kH + j];
-    constexpr int per = (K + 3) / 4;
-    for (int k = kg * per; k < min(K, (kg + 1) * per); ++k) {
-        float acc = 0.f;
-#pragma unroll
-        for (int r = 0; r < kB; ++r) acc = fmaf(h_in[r * ld_in + k], d[r], acc);
-        gW[k * kH + j] = acc + decay * W[k * kH + j];
-    }
-    if (kg == 0) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < kB; ++r) s += d[r];
-        gb[j] = s;
-    }
-}
-
-// dprev[r][k] = sp_prev[r][k] * sum_j dpre[r][j] W[k][j]     (W row k contiguous: float4 along j)
-// thread -> k = tid % 256 (< 200), row group tid / 256 (8 rows)
-__device__ __forceinline__ void grad_input(const float* dpre, const float* __restrict__ W, const float* __restrict__ sp_prev,
-                                           float* dprev, int tid) {
-    const int k = tid & 255, r0 = (tid >> 8) * 8;
-    if (k >= kH) return;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float4* wrow = reinterpret_cast<const float4*>(W + k * kH);
-#pragma unroll 5
-    for (int jj = 0; jj < kH / 4; ++jj) {
-        const float4 w = wrow[jj];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const float4 d = *reinterpret_cast<const float4*>(dpre + (r0 + r) * kH + 4 * jj);
-            acc[r] = fmaf(d.x, w.x, fmaf(d.y, w.y, fmaf(d.z, w.z, fmaf(d.w, w.w, acc[r]))));
+        for (int i = 0; i < 8; ++i) {
+            const int row = (i >> 2) * 16 + 4 * lq + (i & 3);
+            const float p = (i < 4 ? acc0[i & 3] : acc1[i & 3]) + bj, sg = sigm(p);
+            h_out[row * kH + col] = p * sg;
+            sp[row * kH + col] = sg * (1.f + p * (1.f - sg));      // d swish / d pre
         }
     }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) dprev[(r0 + r) * kH + k] = acc[r] * sp_prev[(r0 + r) * kH + k];
 }
+
+// gW[K x 200] = h_in^T[K x 32] . dpre[32 x 200];  gb[j] = sum_r dpre[r][j]
+// (the weight-decay terms of the loss, config/navigation1.py:52-59, are added by the Adam kernel as
+// weight_decay * W: the same gradient without re-reading the weights here)
+// wave w: output columns 16 w .. 16 w + 15, all ceil(K / 16) row tiles; the dpre operand is read once
+template <int K>
+__device__ __forceinline__ void grad_weights(const float* h_in, int ld_in, const float* dpre,
+                                             float* __restrict__ gW, float* __restrict__ gb, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    if (wave < kColTiles) {
+        const int n = wave * 16 + lr;
+        const bool nok = n < kH;
+        float bvv[kB / 4];
+#pragma unroll
+        for (int s = 0; s < kB / 4; ++s) bvv[s] = nok ? dpre[(4 * s + lq) * kH + n] : 0.f;   // contraction over rows
+        constexpr int mtiles = (K + 15) / 16;
+#pragma unroll 1
+        for (int mt = 0; mt < mtiles; ++mt) {
+            const int m = mt * 16 + lr;
+            const bool mok = m < K;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < kB / 4; ++s) acc = mfma(mok ? h_in[(4 * s + lq) * ld_in + m] : 0.f, bvv[s], acc);
+            if (nok) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = mt * 16 + 4 * lq + i;
+                    if (row < K) gW[row * kH + n] = acc[i];
+                }
+            }
+        }
+    }
+    if (tid >= kThreads - 256 && tid - (kThreads - 256) < kH) {       // the otherwise idle waves 12..15
+        const int j = tid - (kThreads - 256);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < kB; ++r) sum += dpre[r * kH + j];
+        gb[j] = sum;
+    }
+}
+
+// dprev[32 x 200] = (dpre[32 x 200] . W^T)[r][k] * sp_prev[r][k]        (contraction over the layer's outputs j)
+// B[j][k] = W[k][j]: a lane owns row k of W, contiguous along j.  Reading it one dword per MFMA step touched every
+// 128-byte line eight times from sixteen waves (L1 thrash: 45 us per layer); with the K order permuted inside chunks
+// of 16 (step t of chunk c uses j = 16 c + 4 (lane / 16) + t on BOTH operands) a lane reads its row as 13 float4 and
+// the activations as matching ds_read_b128.  prefetch() issues the loads; the caller runs the LDS-only
+// weight-gradient tiles before compute() consumes them.
+struct GradInput {
+    static constexpr int chunks = (kH + 15) / 16;     // 13; the last one holds j = 192 .. 199 (lane groups 0, 1)
+    f32x4 bv[chunks];
+    float spv[8];
+    bool kok;
+
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W, const float* __restrict__ sp_prev, int tid) {
+        const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+        const int k = wave * 16 + lr;
+        kok = wave < kColTiles && k < kH;
+        const int kc = kok ? k : kH - 1;
+        const float* brow = W + (size_t)kc * kH + 4 * lq;
+#pragma unroll
+        for (int c = 0; c < chunks; ++c)
+            bv[c] = (16 * c + 4 * lq < kH) ? *reinterpret_cast<const f32x4*>(brow + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) spv[i] = sp_prev[((i >> 2) * 16 + 4 * lq + (i & 3)) * kH + kc];
+    }
+
+    __device__ __forceinline__ void compute(const float* dpre, float* dprev, int tid) const {
+        const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+        if (wave >= kColTiles) return;
+        const int k = wave * 16 + lr;
+        const float* a0 = dpre + lr * kH + 4 * lq;
+        const float* a1 = dpre + (16 + lr) * kH + 4 * lq;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < chunks; ++c) {
+            const bool jok = 16 * c + 4 * lq < kH;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 av0 = jok ? *reinterpret_cast<const f32x4*>(a0 + 16 * c) : z;
+            const f32x4 av1 = jok ? *reinterpret_cast<const f32x4*>(a1 + 16 * c) : z;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const float w = kok ? bv[c][tt] : 0.f;
+                acc0 = mfma(av0[tt], w, acc0);
+                acc1 = mfma(av1[tt], w, acc1);
+            }
+        }
+        if (kok) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (i >> 2) * 16 + 4 * lq + (i & 3);
+                dprev[row * kH + k] = (i < 4 ? acc0[i & 3] : acc1[i & 3]) * spv[i];
+            }
+        }
+    }
+};
 
 __global__ __launch_bounds__(kThreads) void ens_train_grad_kernel(rrl_ens_t m, const float* __restrict__ train_in,
                                                                   const float* __restrict__ train_targ,
@@ -118,8 +193,19 @@ __global__ __launch_bounds__(kThreads) void ens_train_grad_kernel(rrl_ens_t m, c
     float* out = yt + kB * 2;              // [32][4]
     float* dout = out + kB * kDout;        // [32][4]
     float* red = dout + kB * kDout;        // [16]
+    float* bs = red + 16;                  // b0 | b1 | b2  [3][200]
+    float* w3s = bs + 3 * kH;              // W3 [200][4]
+    float* b3s = w3s + kH * kDout;         // [4]
 
     const int e = blockIdx.x, tid = threadIdx.x;
+#ifdef RRL_ENS_TIMING      // phase stamps (s_memtime) of workgroup 0 in the tail of the scratch buffer (profiles/)
+    long long* stamps = reinterpret_cast<long long*>(scratch + (size_t)gridDim.x * 3 * kB * kH);
+    int n_stamp = 0;
+#define STAMP() do { if (e == 0 && tid == 0) stamps[n_stamp++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+    STAMP();
     const float* W0 = m.w0 + (size_t)e * kDin * kH;
     const float* b0 = m.b0 + (size_t)e * kH;
     const float* W1 = m.w1 + (size_t)e * kH * kH;
@@ -131,6 +217,16 @@ __global__ __launch_bounds__(kThreads) void ens_train_grad_kernel(rrl_ens_t m, c
     float* sp = scratch + (size_t)e * 3 * kB * kH;      // swish' of the three hidden layers (L2-resident)
 
     // ---- bootstrap rows of this net, standardised (config/navigation1.py:72) ----
+    // the small parameters ride in the same round trip as the batch gather
+    for (int i = tid; i < kSmall; i += kThreads) {
+        float v;
+        if (i < kH) v = b0[i];
+        else if (i < 2 * kH) v = b1[i - kH];
+        else if (i < 3 * kH) v = b2[i - 2 * kH];
+        else if (i < 3 * kH + kH * kDout) v = W3[i - 3 * kH];
+        else v = b3[i - 3 * kH - kH * kDout];
+        bs[i] = v;
+    }
     // nb <= 32 rows are real (the last batch of an epoch is shorter); the others contribute zero gradient
     if (tid < kB * kDin) {
         const int r = tid / kDin, k = tid % kDin;
@@ -139,20 +235,26 @@ __global__ __launch_bounds__(kThreads) void ens_train_grad_kernel(rrl_ens_t m, c
         if (k < 2) yt[r * 2 + k] = r < nb ? train_targ[row * 2 + k] : 0.f;
     }
     __syncthreads();
-    fwd_layer<kDin>(xin, kDin, W0, b0, h0, sp, tid);
+    STAMP();
+    fwd_layer<kDin>(xin, kDin, W0, bs, h0, sp, tid);
     __syncthreads();
-    fwd_layer<kH>(h0, kH, W1, b1, h1, sp + kB * kH, tid);
+    STAMP();
+    fwd_layer<kH>(h0, kH, W1, bs + kH, h1, sp + kB * kH, tid);
     __syncthreads();
-    fwd_layer<kH>(h1, kH, W2, b2, h2, sp + 2 * kB * kH, tid);
+    STAMP();
+    fwd_layer<kH>(h1, kH, W2, bs + 2 * kH, h2, sp + 2 * kB * kH, tid);
     __syncthreads();
+    STAMP();
     // ---- output layer (4 wide) ----
     if (tid < kB * kDout) {
         const int r = tid / kDout, o = tid % kDout;
-        float acc = b3[o];
-        for (int k = 0; k < kH; ++k) acc = fmaf(h2[r * kH + k], W3[k * kDout + o], acc);
+        float acc = b3s[o];
+#pragma unroll 8
+        for (int k = 0; k < kH; ++k) acc = fmaf(h2[r * kH + k], w3s[k * kDout + o], acc);
         out[tid] = acc;
     }
     __syncthreads();
+    STAMP();
     // ---- loss (MPC.py:276-287) and its gradient w.r.t. the outputs; one thread per (row, dim) ----
     if (tid < 64) {
         const int r = tid >> 1, k = tid & 1;
@@ -184,6 +286,7 @@ __global__ __launch_bounds__(kThreads) void ens_train_grad_kernel(rrl_ens_t m, c
         }
     }
     __syncthreads();
+    STAMP();
     if (tid == 0 && loss_out) loss_out[e] = red[0] + red[1];
     // ---- backward: output layer ----
     {
@@ -193,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void ens_train_grad_kernel(rrl_ens_t m, c
             float acc = 0.f;
 #pragma unroll
             for (int r = 0; r < kB; ++r) acc = fmaf(h2[r * kH + k], dout[r * kDout + o], acc);
-            m.g_w3[(size_t)e * kH * kDout + tid] = acc + 0.00075f * W3[tid];
+            m.g_w3[(size_t)e * kH * kDout + tid] = acc;
         } else if (tid < kH * kDout + kDout) {
             const int o = tid - kH * kDout;
             float s = 0.f;
@@ -203,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void ens_train_grad_kernel(rrl_ens_t m, c
         // dpre2[r][k] = sp2[r][k] * sum_o dout[r][o] W3[k][o]
         const int k = tid & 255, r0 = (tid >> 8) * 8;
         if (k < kH) {
-            const float4 w = *reinterpret_cast<const float4*>(W3 + k * kDout);
+            const float4 w = *reinterpret_cast<const float4*>(w3s + k * kDout);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const float4 d = *reinterpret_cast<const float4*>(dout + (r0 + r) * kDout);
@@ -213,16 +316,30 @@ __global__ __launch_bounds__(kThreads) void ens_train_grad_kernel(rrl_ens_t m, c
         }
     }
     __syncthreads();
+    STAMP();
     // ---- hidden layer 2: grads of W2/b2 from (h1, da), then dpre1 -> db ----
-    grad_weights<kH>(h1, kH, da, W2, 0.0005f, m.g_w2 + (size_t)e * kH * kH, m.g_b2 + (size_t)e * kH, tid);
-    grad_input(da, W2, sp + kB * kH, db, tid);
+    {
+        GradInput gi;
+        gi.prefetch(W2, sp + kB * kH, tid);           // the L2 round trip hides behind the weight-gradient tiles
+        grad_weights<kH>(h1, kH, da, m.g_w2 + (size_t)e * kH * kH, m.g_b2 + (size_t)e * kH, tid);
+        gi.compute(da, db, tid);
+    }
     __syncthreads();
+    STAMP();
     // ---- hidden layer 1 ----
-    grad_weights<kH>(h0, kH, db, W1, 0.0005f, m.g_w1 + (size_t)e * kH * kH, m.g_b1 + (size_t)e * kH, tid);
-    grad_input(db, W1, sp, da, tid);
+    {
+        GradInput gi;
+        gi.prefetch(W1, sp, tid);
+        grad_weights<kH>(h0, kH, db, m.g_w1 + (size_t)e * kH * kH, m.g_b1 + (size_t)e * kH, tid);
+        gi.compute(db, da, tid);
+    }
     __syncthreads();
+    STAMP();
     // ---- input layer ----
-    grad_weights<kDin>(xin, kDin, da, W0, 0.00025f, m.g_w0 + (size_t)e * kDin * kH, m.g_b0 + (size_t)e * kH, tid);
+    grad_weights<kDin>(xin, kDin, da, m.g_w0 + (size_t)e * kDin * kH, m.g_b0 + (size_t)e * kH, tid);
+    __syncthreads();
+    STAMP();
+#undef STAMP
 }
 
 // g_max_logvar[k] = 0.01 + sum_e part[e][k];  g_min_logvar[k] = -0.01 + sum_e part[e][2 + k]     (MPC.py:271)
@@ -244,7 +361,7 @@ int rrl_ens_train_supported(int d_in, int hidden, int d_out, int batch) {
     return d_in == kDin && hidden == kH && d_out == kDout && batch >= 1 && batch <= kB;
 }
 
-long long rrl_ens_scratch_floats(int n_nets) { return (long long)n_nets * 3 * kB * kH; }
+long long rrl_ens_scratch_floats(int n_nets) { return (long long)n_nets * 3 * kB * kH + 64; }   // + timing stamps
 
 int rrl_ens_train_grad(const rrl_ens_t* m, int batch, const float* train_in, const float* train_targ,
                        const int64_t* idx, long long idx_stride, float* scratch, float* loss_out, void* stream) {
@@ -269,6 +386,24 @@ int rrl_ens_train_grad(const rrl_ens_t* m, int batch, const float* train_in, con
     hipLaunchKernelGGL(ens_logvar_grad_kernel, dim3(1), dim3(64), 0, st, m->n_nets, m->g_logvar_part,
                        m->g_max_logvar, m->g_min_logvar);
     return check_launch();
+}
+
+// One epoch of MPC.train's batch loop (MPC.py:266-292) issued from C: ceil(n_rows / batch) x {gradient kernel,
+// logvar reduction, Adam}.  Launching from a C loop costs ~4 us per launch on the host instead of ~20 us through
+// Python, which keeps the 35-us optimiser step GPU-bound.
+int rrl_ens_train_epoch(const rrl_ens_t* m, int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2,
+                        float eps, const float* train_in, const float* train_targ, const int64_t* idx,
+                        long long idx_stride, long long n_rows, int batch, float* scratch, float* loss_out,
+                        void* stream) {
+    if (!idx || n_rows <= 0 || batch <= 0 || !segs) return RRL_EINVAL;
+    for (long long lo = 0; lo < n_rows; lo += batch) {
+        const int nb = int(n_rows - lo < batch ? n_rows - lo : batch);
+        int rc = rrl_ens_train_grad(m, nb, train_in, train_targ, idx + lo, idx_stride, scratch, loss_out, stream);
+        if (rc != RRL_OK) return rc;
+        rc = rrl_adam_step_multi(n_seg, segs, lr, beta1, beta2, eps, stream);
+        if (rc != RRL_OK) return rc;
+    }
+    return RRL_OK;
 }
 
 }  // extern "C"

@@ -8,6 +8,9 @@ import torch
 
 from . import _lib
 
+# weight-decay terms of the loss (config/navigation1.py:52-59: (0.00025 |W0|^2 + 0.0005 |W1|^2 + 0.0005 |W2|^2 +
+# 0.00075 |W3|^2) / 2), applied by the Adam kernel as g += weight_decay * W
+DECAY = {"lin0_w": 0.00025, "lin1_w": 0.0005, "lin2_w": 0.0005, "lin3_w": 0.00075}
 PARAMS = ("lin0_w", "lin0_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b", "lin3_w", "lin3_b", "max_logvar", "min_logvar")
 
 
@@ -31,7 +34,8 @@ class FusedEnsembleTrainer:
         self._segs = (_lib.rrl_adam_seg_t * len(self.params))()
         for k, p in enumerate(self.params):
             self._segs[k] = _lib.rrl_adam_seg_t(p.numel(), p.data_ptr(), self.grads[k].data_ptr(), self.m[k].data_ptr(),
-                                                self.v[k].data_ptr(), self.steps[k].data_ptr(), None, 0.0)
+                                                self.v[k].data_ptr(), self.steps[k].data_ptr(), None, 0.0,
+                                                DECAY.get(PARAMS[k], 0.0))
 
     @staticmethod
     def supported(model, batch_size):
@@ -57,7 +61,8 @@ class FusedEnsembleTrainer:
         self._d = self._desc()
 
     def gradients(self, idx):
-        """idx: int64 [E, 1..32] (rows may be strided views of a wider table).  Fills self.grads / self.loss."""
+        """idx: int64 [E, 1..32] (rows may be strided views of a wider table).  Fills self.grads (without the
+        weight-decay terms, which Adam adds) and self.loss."""
         assert idx.dtype == torch.int64 and idx.stride(1) == 1 and idx.shape[0] == self.E
         rc = self.lib.rrl_ens_train_grad(C.byref(self._d), int(idx.shape[1]), _lib.ptr(self._data[0]),
                                          _lib.ptr(self._data[1]), _lib.ptr(idx), idx.stride(0), _lib.ptr(self.scratch),
@@ -69,6 +74,15 @@ class FusedEnsembleTrainer:
         rc = self.lib.rrl_adam_step_multi(len(self.params), self._segs, self.lr, self.betas[0], self.betas[1],
                                           self.eps, _lib.current_stream())
         _lib.check(rc, "rrl_adam_step_multi")
+
+    def epoch(self, idxs, batch_size):
+        """All ceil(n / batch_size) steps over the columns of idxs [E, n], launched from one C loop."""
+        assert idxs.dtype == torch.int64 and idxs.stride(1) == 1 and idxs.shape[0] == self.E
+        rc = self.lib.rrl_ens_train_epoch(C.byref(self._d), len(self.params), self._segs, self.lr, self.betas[0],
+                                          self.betas[1], self.eps, _lib.ptr(self._data[0]), _lib.ptr(self._data[1]),
+                                          _lib.ptr(idxs), idxs.stride(0), int(idxs.shape[1]), int(batch_size),
+                                          _lib.ptr(self.scratch), _lib.ptr(self.loss), _lib.current_stream())
+        _lib.check(rc, "rrl_ens_train_epoch")
 
     # -- checkpoint ------------------------------------------------------------------------------
     def state_dict(self):
