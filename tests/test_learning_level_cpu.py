@@ -1,0 +1,43 @@
+"""Learning-level parity (SURVEY 8d "parity gates"): cumulative task successes / constraint violations over 400
+episodes of scripts/navigation1.sh:7, this stack (profiles/round1_learning_seeds.json, 8 seeds on one MI355X) against
+the REFERENCE's own runs of the same command line (tests/golden/ref_learning_nav1_seed*.json, produced by
+tests/golden/run_reference_training.py on the CPU of the build container).  RNG streams differ, so the comparison
+is between the seed-to-seed distributions, with the definitions of plotting/plot_runs.py:214-235."""
+import glob
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load():
+    ref = [json.load(open(p)) for p in sorted(glob.glob(os.path.join(HERE, "golden", "ref_learning_nav1_seed*.json")))]
+    mine = json.load(open(os.path.join(HERE, "..", "profiles", "round1_learning_seeds.json")))["runs"]
+    return ref, mine
+
+
+def test_success_and_violation_counts_lie_in_the_reference_spread():
+    ref, mine = _load()
+    assert len(ref) >= 3 and len(mine) == 8
+    for key, slack in (("total_successes", 6), ("total_violations", 2), ("env_steps", 800)):
+        r = np.array([x[key] for x in ref], dtype=np.float64)
+        m = np.array([x[key] for x in mine], dtype=np.float64)
+        spread = max(r.std(), m.std(), 1.0)
+        # means within two pooled standard deviations (+ a small absolute slack for the nearly constant counts)
+        assert abs(r.mean() - m.mean()) <= 2.0 * spread + slack, (key, r.tolist(), m.tolist())
+        assert m.min() >= r.min() - 3 * spread - slack and m.max() <= r.max() + 3 * spread + slack, (key, r, m)
+
+
+def test_learning_curves_have_the_reference_shape():
+    """Cumulative successes after 100 / 200 / 400 episodes (the y axis of plot_runs.py PLOT_TYPE 'success')."""
+    ref, mine = _load()
+    for upto in (100, 200, 400):
+        r = np.array([sum(x["successes"][:upto]) for x in ref], dtype=np.float64)
+        m = np.array([sum(x["successes"][:upto]) for x in mine], dtype=np.float64)
+        assert abs(r.mean() - m.mean()) <= 2.0 * max(r.std(), m.std(), 1.0) + 0.03 * upto, (upto, r, m)
+    # offline constraint data: same generator statistics
+    r = np.array([x["num_constraint_transitions"] for x in ref], dtype=np.float64)
+    m = np.array([x["num_constraint_transitions"] for x in mine], dtype=np.float64)
+    assert abs(r.mean() - m.mean()) < 0.03 * r.mean()
