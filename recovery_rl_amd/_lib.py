@@ -213,5 +213,11 @@ def ptr(t):
 
 
 def current_stream():
+    """Raw hipStream_t of torch's current stream on the current device.  Called once per kernel launch, so it uses
+    torch's C accessors when they exist (0.3 us) instead of building a torch.cuda.Stream object (9 us)."""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    dev = getattr(torch._C, "_cuda_getDevice", None)
+    if raw is not None and dev is not None:
+        return raw(dev())
     return torch.cuda.current_stream().cuda_stream
