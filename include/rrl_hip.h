@@ -343,6 +343,7 @@ typedef struct {
     float* target;
     float tau;
     float weight_decay;   /* g <- g + weight_decay * p before the moment updates (torch.optim.Adam weight_decay) */
+    const float* g2;      /* nullable: second partial gradient, g <- g + g2 (rrl_ens_train_grad) */
 } rrl_adam_seg_t;
 int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2, float eps,
                         void* stream);
@@ -421,7 +422,9 @@ int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, lo
  * the update itself is rrl_adam_step_multi over the same buffers (torch.optim.Adam, lr 1e-3).
  *   parameters  w0 [E,4,H] b0 [E,1,H] w1,w2 [E,H,H] b1,b2 [E,1,H] w3 [E,H,4] b3 [E,1,4] (in x out), max/min_logvar [2],
  *               mu/sigma [4] (input standardisation, not trained); g_* = gradients, same shapes;
- *               g_logvar_part: scratch [E,4]
+ *               g_logvar_part: scratch [2E,4].  A member's 32 rows are processed by two workgroups of 16 rows:
+ *               rows 0..15 write g_*, rows 16..31 write g2_* (same shapes); pass g2 as the Adam segment's second
+ *               gradient so that the update uses g + g2
  *   idx         int64 [E, >= batch] with row stride idx_stride (elements): rows of train_in [N,4] / train_targ [N,2]
  *   scratch     float [rrl_ens_scratch_floats(E)]; loss_out (nullable) [E] = the per-net NLL term
  * Supported shape (rrl_ens_train_supported): 4 inputs, H = 200, 4 outputs, batch 1..32 (the mean runs over the
@@ -432,6 +435,8 @@ typedef struct {
     float *w0, *b0, *w1, *b1, *w2, *b2, *w3, *b3, *max_logvar, *min_logvar;
     const float *mu, *sigma;
     float *g_w0, *g_b0, *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *g_max_logvar, *g_min_logvar, *g_logvar_part;
+    float *g2_w0, *g2_b0, *g2_w1, *g2_b1, *g2_w2, *g2_b2, *g2_w3, *g2_b3;   /* second half of the batch (see above) */
+    float* loss_part;                                                       /* scratch [2 E] */
 } rrl_ens_t;
 int rrl_ens_train_supported(int d_in, int hidden, int d_out, int batch);
 long long rrl_ens_scratch_floats(int n_nets);

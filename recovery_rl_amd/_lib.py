@@ -84,7 +84,8 @@ class rrl_ens_t(C.Structure):
     _fields_ = [("n_nets", C.c_int), ("d_in", C.c_int), ("hidden", C.c_int), ("d_out", C.c_int)] + [
         (name, C.c_void_p) for name in ("w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3", "max_logvar", "min_logvar",
                                         "mu", "sigma", "g_w0", "g_b0", "g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3",
-                                        "g_max_logvar", "g_min_logvar", "g_logvar_part")]
+                                        "g_max_logvar", "g_min_logvar", "g_logvar_part", "g2_w0", "g2_b0", "g2_w1",
+                                        "g2_b1", "g2_w2", "g2_b2", "g2_w3", "g2_b3", "loss_part")]
 
 
 class rrl_loss_t(C.Structure):
@@ -97,7 +98,8 @@ class rrl_loss_t(C.Structure):
 
 class rrl_adam_seg_t(C.Structure):
     _fields_ = [("n", C.c_longlong), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
-                ("step_dev", C.c_void_p), ("target", C.c_void_p), ("tau", C.c_float), ("weight_decay", C.c_float)]
+                ("step_dev", C.c_void_p), ("target", C.c_void_p), ("tau", C.c_float), ("weight_decay", C.c_float),
+                ("g2", C.c_void_p)]
 
 
 class rrl_plan_weights_t(C.Structure):

@@ -243,10 +243,11 @@ struct AdamSegs {
 
 __device__ __forceinline__ void adam_range(long long n, float* p, const float* g, float* m, float* v,
                                            float step_size, float bc2_sqrt, float b1, float b2, float eps,
-                                           float* target, float tau, float wd, int block, int blocks) {
+                                           float* target, float tau, float wd, const float* g2, int block,
+                                           int blocks) {
     const long long stride = (long long)blocks * kBlock;
     for (long long i = (long long)block * kBlock + threadIdx.x; i < n; i += stride) {
-        const float gi = g[i] + wd * p[i];
+        const float gi = (g2 ? g[i] + g2[i] : g[i]) + wd * p[i];
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi;
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_se
         sh[1] = float(sqrt(1.0 - pow(double(b2), t)));
     }
     __syncthreads();
-    adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, sg.weight_decay, block,
-               blocks);
+    adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, sg.weight_decay, sg.g2,
+               block, blocks);
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long ticket = atomicAdd((unsigned long long*)&sg.step_dev[1], 1ULL);

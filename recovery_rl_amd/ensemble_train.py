@@ -26,16 +26,21 @@ class FusedEnsembleTrainer:
             assert p.dtype == torch.float32 and p.is_contiguous()
         z = lambda p: torch.zeros_like(p.data)
         self.grads = [z(p) for p in self.params]
+        # a member's 32 rows are split over two workgroups: rows 16..31 write a second partial gradient (weights and
+        # biases only), Adam adds the two
+        self.grads2 = [z(p) for p in self.params[:8]]
         self.m, self.v = [z(p) for p in self.params], [z(p) for p in self.params]
         self.steps = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in self.params]    # {t, ticket}
-        self.part = torch.zeros(self.E, 4, device=dev)
+        self.part = torch.zeros(2 * self.E, 4, device=dev)
+        self.loss_part = torch.zeros(2 * self.E, device=dev)
         self.scratch = torch.empty(int(self.lib.rrl_ens_scratch_floats(self.E)), device=dev)
         self.loss = torch.zeros(self.E, device=dev)
         self._segs = (_lib.rrl_adam_seg_t * len(self.params))()
         for k, p in enumerate(self.params):
             self._segs[k] = _lib.rrl_adam_seg_t(p.numel(), p.data_ptr(), self.grads[k].data_ptr(), self.m[k].data_ptr(),
                                                 self.v[k].data_ptr(), self.steps[k].data_ptr(), None, 0.0,
-                                                DECAY.get(PARAMS[k], 0.0))
+                                                DECAY.get(PARAMS[k], 0.0),
+                                                self.grads2[k].data_ptr() if k < 8 else None)
 
     @staticmethod
     def supported(model, batch_size):
@@ -52,7 +57,7 @@ class FusedEnsembleTrainer:
         self._keep = (mu, sigma)
         return _lib.rrl_ens_t(self.E, int(m.in_features), int(m.lin1_w.shape[1]), int(m.out_features), *ptrs,
                               mu.data_ptr(), sigma.data_ptr(), *[g.data_ptr() for g in self.grads],
-                              self.part.data_ptr())
+                              self.part.data_ptr(), *[g.data_ptr() for g in self.grads2], self.loss_part.data_ptr())
 
     def begin(self, train_in, train_targ):
         """Bind the dataset and the current input statistics (they change with every MPC.train call)."""
@@ -61,8 +66,8 @@ class FusedEnsembleTrainer:
         self._d = self._desc()
 
     def gradients(self, idx):
-        """idx: int64 [E, 1..32] (rows may be strided views of a wider table).  Fills self.grads (without the
-        weight-decay terms, which Adam adds) and self.loss."""
+        """idx: int64 [E, 1..32] (rows may be strided views of a wider table).  Fills self.grads + self.grads2 (the two
+        row halves; without the weight-decay terms, which Adam adds) and self.loss."""
         assert idx.dtype == torch.int64 and idx.stride(1) == 1 and idx.shape[0] == self.E
         rc = self.lib.rrl_ens_train_grad(C.byref(self._d), int(idx.shape[1]), _lib.ptr(self._data[0]),
                                          _lib.ptr(self._data[1]), _lib.ptr(idx), idx.stride(0), _lib.ptr(self.scratch),

@@ -81,7 +81,7 @@ def adam_multi(lr, nets, betas=(0.9, 0.999), eps=1e-8):
     for k, (net, target, tau) in enumerate(nets):
         segs[k] = _lib.rrl_adam_seg_t(net.flat.numel(), net.flat.data_ptr(), net.grad.data_ptr(), net.m.data_ptr(),
                                       net.v.data_ptr(), net.step.data_ptr(),
-                                      None if target is None else target.flat.data_ptr(), tau, 0.0)
+                                      None if target is None else target.flat.data_ptr(), tau, 0.0, None)
     _lib.check(lib.rrl_adam_step_multi(len(nets), segs, lr, betas[0], betas[1], eps, _lib.current_stream()),
                "rrl_adam_step_multi")
 
