@@ -133,6 +133,15 @@ def pmc_traffic(n):
         return None
 
 
+def planner_traffic(n_plans):
+    """HBM bytes per plan_cost_kernel launch from the committed PMC passes (profiles/pmc_plan_traffic.sh)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "round1_planner_traffic.json"))).get(str(n_plans))
+        return None if rec is None else rec["fetch_bytes"] + rec["write_bytes"]
+    except (OSError, ValueError):
+        return None
+
+
 # algorithmic FLOPs of one lock-step iteration (SURVEY.md section 8d): SAC update 0.685 GFLOP, Q_risk + recovery
 # update 0.62 GFLOP, acting = per env 2 x (policy 67 072 + twin Q_risk 133 632 + recovery policy 66 560) MAC
 def iteration_flops(num_envs):
@@ -330,7 +339,7 @@ def main():
             extra["roofline_planner"] = {
                 "kernel": "plan_cost_kernel (rrl_plan_cost, model-based recovery of config 4)", "bound": "mfma",
                 "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
-                "traffic": None, "launch_ms": t_p * 1e3, "row_steps_per_s": row_steps / t_p,
+                "traffic": planner_traffic(256), "launch_ms": t_p * 1e3, "row_steps_per_s": row_steps / t_p,
                 "note": "f32-in/f32-acc MFMA (exact f32); algorithmic %d FLOP per particle-step"
                         % PLAN_FLOPS_PER_ROW_STEP}
         if not a.no_cpu_baseline and world == 1:

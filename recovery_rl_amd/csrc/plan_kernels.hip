@@ -38,8 +38,8 @@ constexpr int kRows = 64;                 // rows per workgroup
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kActStride = kHQ + 4;       // +4 floats: row r starts at bank 4r, ds_read_b128 conflict-free
-constexpr int kLdsFloats = kRows * kActStride + 2 * kRows * 4 + 2 * kWaves * kRows + 4 * kRows * 4;
-constexpr int kLdsBytes = kLdsFloats * 4;  // 76.5 KB: two workgroups per CU
+constexpr int kLdsFloats = kRows * kActStride + 3 * kRows * 4 + 2 * kWaves * kRows + 4 * kRows * 4;
+constexpr int kLdsBytes = kLdsFloats * 4;  // 77.5 KB: two workgroups per CU
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -192,6 +192,7 @@ void plan_cost_kernel(
     float* xn = xs + kRows * 4;                                     // [64][4] standardised ensemble input
     float(*qpart)[kWaves][kRows] = reinterpret_cast<float(*)[kWaves][kRows]>(xn + kRows * 4);
     float(*epart)[kRows][4] = reinterpret_cast<float(*)[kRows][4]>(xn + kRows * 4 + 2 * kWaves * kRows);
+    float* rowstate = xn + kRows * 4 + 2 * kWaves * kRows + 4 * kRows * 4;      // [64][4] = {obs x, obs y, cost, -}
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile indices live in SGPRs
@@ -201,17 +202,18 @@ void plan_cost_kernel(
     const int ppn = npart / n_nets;                       // particles per net (4)
     const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
 
-    // one thread per row keeps the row's rollout state
+    // one thread per row advances the row's rollout state, which lives in LDS between the steps (registers that stay
+    // live across the matrix phases are what the 128-VGPR budget of two workgroups per CU is short of)
     const bool owner = tid < kRows;
-    const long long group = gblock * 16 + (tid >> 2);
-    const bool live = owner && group < n_groups;
-    const int particle = e * ppn + (tid & 3);
-    const long long row_global = group * npart + particle;
-    float ox = 0.f, oy = 0.f, cost = 0.f;
-    if (live) {
-        const long long m = group / pop;
-        ox = cur_obs[m * 2];
-        oy = cur_obs[m * 2 + 1];
+    if (owner) {
+        const long long group = gblock * 16 + (tid >> 2);
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+        if (group < n_groups) {
+            const long long m = group / pop;
+            st[0] = cur_obs[m * 2];
+            st[1] = cur_obs[m * 2 + 1];
+        }
+        *reinterpret_cast<f32x4*>(rowstate + tid * 4) = st;
     }
     const float* epk = pk + e_off(e);
     const float* g = pk + glob_off(n_nets);                // mu[4], sigma[4], max_logvar[2], min_logvar[2]
@@ -226,13 +228,18 @@ void plan_cost_kernel(
     const int xr = wave < 4 ? (wave >> 1) : -1;                     // which of the wave's two row tiles (0/1), or none
 
     for (int t = 0; t < plan_hor; ++t) {
+        // per-step copy of the lane id the optimiser cannot see through: the lane-dependent addresses of the bias /
+        // last-layer constants are recomputed every step instead of being hoisted out of the loop and spilled
+        const int ln = opaque(lane);
         if (owner) {
+            const int otid = opaque(tid);        // keeps the 64-bit row addresses out of the loop-invariant (spilled) set
+            const long long group = gblock * 16 + (otid >> 2);
             float ax = 0.f, ay = 0.f;
-            if (live) {
+            if (group < n_groups) {
                 ax = ac_seqs[group * (plan_hor * 2) + 2 * t];
                 ay = ac_seqs[group * (plan_hor * 2) + 2 * t + 1];
             }
-            const f32x4 x = {ox, oy, ax, ay};
+            const f32x4 x = {rowstate[tid * 4], rowstate[tid * 4 + 1], ax, ay};
             *reinterpret_cast<f32x4*>(xs + tid * 4) = x;
             f32x4 n;
 #pragma unroll
@@ -255,7 +262,7 @@ void plan_cost_kernel(
                     float b1v[2], b2v[2], w3v[2];
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        const int col = q_ct[c] * 16 + (lane & 15);
+                        const int col = q_ct[c] * 16 + (ln & 15);
                         b1v[c] = w[kQB1 + col];
                         b2v[c] = w[kQB2 + col];
                         w3v[c] = w[kQW3 + col];
@@ -286,7 +293,7 @@ void plan_cost_kernel(
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const float v = reduce16(s[r][i]);
-                            if ((lane & 15) == 0) qpart[h][wave][r * 16 + 4 * (lane >> 4) + i] = v;
+                            if ((ln & 15) == 0) qpart[h][wave][r * 16 + 4 * (ln >> 4) + i] = v;
                         }
                     __syncthreads();       // act is free again; qpart[h] complete
                 }
@@ -304,12 +311,12 @@ void plan_cost_kernel(
     } else {                              \
         CALL3;                            \
     }
-                const int ecol[4] = {e_ct[0] * 16 + (lane & 15), e_ct[1] * 16 + (lane & 15),
-                                     e_ct[2] * 16 + (lane & 15), e_ct[3] * 16 + (lane & 15)};
+                // column of this lane in column tile c, re-derived at every use (not kept live across the phases)
+                auto ecol = [&](int c) { return e_ct[c] * 16 + (opaque(lane) & 15); };
                 // per-column constants are requested one phase ahead of their use, never all live at once
                 float eb[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB0 + ecol[c]];
+                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB0 + ecol(c)];
                 f32x4 acc[2][4];
                 zero(acc);
                 E_STAGE((input_mma<4, 0>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
@@ -319,7 +326,7 @@ void plan_cost_kernel(
                         (input_mma<3>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
                          store_act<true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
 #pragma unroll
-                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB1 + ecol[c]];
+                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB1 + ecol(c)];
                 __syncthreads();
                 zero(acc);
                 E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
@@ -330,7 +337,7 @@ void plan_cost_kernel(
                         (store_act<true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
                         (store_act<true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
 #pragma unroll
-                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB2 + ecol[c]];
+                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB2 + ecol(c)];
                 __syncthreads();
                 zero(acc);
                 E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
@@ -340,7 +347,7 @@ void plan_cost_kernel(
                 // last layer (200 -> 4) folded in: out[row][o] = sum_col swish(h3 + b2) W3[col][o]
                 f32x4 ew3[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) ew3[c] = *reinterpret_cast<const f32x4*>(epk + kEW3 + ecol[c] * 4);
+                for (int c = 0; c < 4; ++c) ew3[c] = *reinterpret_cast<const f32x4*>(epk + kEW3 + ecol(c) * 4);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     float s[4][4];
@@ -363,7 +370,7 @@ void plan_cost_kernel(
 #pragma unroll
                         for (int o = 0; o < 4; ++o) {
                             const float v = reduce16(s[i][o]);
-                            if ((lane & 15) == 0) epart[cs][e_rt[r] * 16 + 4 * (lane >> 4) + i][o] = v;
+                            if ((ln & 15) == 0) epart[cs][e_rt[r] * 16 + 4 * (ln >> 4) + i][o] = v;
                         }
                 }
                 __syncthreads();
@@ -380,7 +387,12 @@ void plan_cost_kernel(
                 for (int w = 0; w < kWaves; ++w) v += qpart[h][w][tid];
                 q[h] = sigmoidf(v);
             }
-            cost += (q[0] > q[1] || q[0] != q[0]) ? q[0] : q[1];      // torch.max: NaN propagates
+            const int otid = opaque(tid);
+            const long long group = gblock * 16 + (otid >> 2);
+            const bool live = group < n_groups;
+            const long long row_global = group * npart + e * ppn + (otid & 3);
+            f32x4 st = *reinterpret_cast<f32x4*>(rowstate + tid * 4);
+            st[2] += (q[0] > q[1] || q[0] != q[0]) ? q[0] : q[1];      // torch.max: NaN propagates
             float out[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o)
@@ -406,18 +418,21 @@ void plan_cost_kernel(
                 lv = g[10 + k] + softplusf(lv - g[10 + k]);
                 sd[k] = sqrtf(expf(lv));
             }
-            ox = ox + (out[0] + z0 * sd[0]);        // obs_postproc: obs + prediction (:131-133)
-            oy = oy + (out[1] + z1 * sd[1]);
+            st[0] = st[0] + (out[0] + z0 * sd[0]);  // obs_postproc: obs + prediction (:131-133)
+            st[1] = st[1] + (out[1] + z1 * sd[1]);
+            *reinterpret_cast<f32x4*>(rowstate + tid * 4) = st;
         }
         // xs / xn are rewritten by the owners only after every wave passed the barriers above
     }
 
     // sum of the member's particles per (m, c) group; NaN -> 1e6 per particle (MPC.py:415)
     if (owner) {
+        const long long group = gblock * 16 + (tid >> 2);
+        const float cost = rowstate[tid * 4 + 2];
         float c = (cost != cost) ? 1e6f : cost;
         c += __shfl_xor(c, 1, 64);
         c += __shfl_xor(c, 2, 64);
-        if (live && (tid & 3) == 0) partial[group * n_nets + e] = c;
+        if (group < n_groups && (tid & 3) == 0) partial[group * n_nets + e] = c;
     }
 }
 
