@@ -23,8 +23,14 @@ def cat(name):
     return 'other: ' + name[:50]
 
 
+# kernels of the planner roofline probe that bench.py runs after the timed loop: not part of the iteration
+PROBE = ('plan_cost_kernel', 'plan_finish_kernel', 'pack_layer_kernel', 'pack_input_kernel', 'pack_vector_kernel',
+         'pack_head_kernel')
+
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
+    if any(p in r['Name'] for p in PROBE):
+        continue
     k = cat(r['Name'])
     agg[k][0] += int(r['Calls'])
     agg[k][1] += float(r['TotalDurationNs'])
