@@ -334,7 +334,9 @@ def main():
                 "note": "8 B action read + 4 B reward + 1 B constraint written per env-step; the state never leaves "
                         "registers, so the f64 Philox / Box-Muller arithmetic, not HBM, is the limit"}
         if (a.planner or world == 1) and not a.no_planner:
-            t_p, row_steps = time_planner_kernel(device)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):       # the controller announces itself: stdout carries the JSON line only
+                t_p, row_steps = time_planner_kernel(device)
             tf = row_steps * PLAN_FLOPS_PER_ROW_STEP / t_p / 1e12
             extra["roofline_planner"] = {
                 "kernel": "plan_cost_kernel (rrl_plan_cost, model-based recovery of config 4)", "bound": "mfma",

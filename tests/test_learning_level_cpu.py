@@ -41,3 +41,19 @@ def test_learning_curves_have_the_reference_shape():
     r = np.array([x["num_constraint_transitions"] for x in ref], dtype=np.float64)
     m = np.array([x["num_constraint_transitions"] for x in mine], dtype=np.float64)
     assert abs(r.mean() - m.mean()) < 0.03 * r.mean()
+
+
+def test_navigation2_run_is_in_the_range_of_the_reference_run():
+    """scripts/navigation2.sh:7 (model-free recovery), seed 1: this stack's run (profiles/round1_learning_other_configs)
+    next to the reference's own run (tests/golden/ref_learning_nav2_seed1.json).  One seed each, so only coarse
+    agreement is asserted: no more violations than the reference + 3, successes within 15 % of the episodes."""
+    import pytest
+    path = os.path.join(HERE, "golden", "ref_learning_nav2_seed1.json")
+    if not os.path.exists(path):
+        pytest.skip("reference navigation2 run not recorded")
+    ref = json.load(open(path))
+    mine = [json.loads(line) for line in open(os.path.join(HERE, "..", "profiles", "round1_learning_other_configs.jsonl"))]
+    mine = [m for m in mine if m["config"] == "nav2_mf"][0]
+    assert mine["episodes"] == ref["episodes"] == 400
+    assert mine["total_violations"] <= ref["total_violations"] + 3
+    assert abs(mine["total_successes"] - ref["total_successes"]) <= 0.15 * 400
