@@ -63,3 +63,13 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f in (), (dirpath, f)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/rrl_hip.h is the C ABI a binding includes: it must compile as C99 on its own."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "rrl_hip.h"\nint main(void) { return rrl_abi_version() < 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"),
+                           str(src)])
