@@ -236,7 +236,8 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
 int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int ldx, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
                      float* h1, float* h2, float* out, float* scratch, int finalize, void* stream);
-/* 1 if rrl_mlp3_forward(M, H, scratch != NULL) takes the split path (so finalize == 0 leaves partials) */
+/* number of partial sums (4) if rrl_mlp3_forward(M, H, scratch != NULL) takes the split path (so finalize == 0
+ * leaves that many partials in scratch), 0 otherwise */
 int rrl_mlp3_is_split(int M, int H);
 
 /* Thin ends of the stack backward (one side 1..4 wide, so no MFMA tile):

@@ -149,8 +149,10 @@ class Stack:
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.h1, self.h2, self.out = z(G, B, H), z(G, B, H), z(G, B, net.dout)
         self.dh1, self.dh2, self.dx = z(G, B, H), z(G, B, H), z(G, B, net.din)
-        self.scratch = z(4, G, B, net.dout)         # partial last-layer sums of the small-batch forward
-        self.split = bool(_lib.load().rrl_mlp3_is_split(B, H)) and mlp3_supported(H, net.din, net.dout)
+        # partial last-layer sums of the small-batch forward: rrl_mlp3_is_split = number of parts (0: not split)
+        self.nsplit = int(_lib.load().rrl_mlp3_is_split(B, H)) if mlp3_supported(H, net.din, net.dout) else 0
+        self.split = self.nsplit > 0
+        self.scratch = z(max(self.nsplit, 1), G, B, net.dout)
         self.finalize = False                       # True: always hand back the summed output tensor
         self.pair_hidden = True                     # dW2 and dh1 of the backward in one launch
 
@@ -166,7 +168,7 @@ class Stack:
                          h1=self.h1 if save else None, h2=self.h2 if save else None, scratch=self.scratch,
                          finalize=self.finalize)
             if self.split and not self.finalize:   # partial last-layer sums: the consumer kernels add them up
-                self.parts = (self.scratch, 4, self.scratch.stride(0))
+                self.parts = (self.scratch, self.nsplit, self.scratch.stride(0))
             return self.parts
         xg = x.unsqueeze(0).expand(G, -1, -1)
         gemm(NT, xg, P["W1"], out=self.h1, bias=P["b1"], relu=True)
