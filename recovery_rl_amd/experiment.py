@@ -546,68 +546,70 @@ class Experiment:
                                               "evals": evals, "episodes": np.concatenate(episodes), "mb_new": mb_new})
         ep_file = open(osp.join(self.logdir, "episode_stats.bin"), "wb")   # append-only, O(new) per log
         ep_file.write(episodes[0].tobytes())
-        captured_gate = None
-        mb = uses_mb_recovery(cfg)
-        # model-based recovery: the ensemble is re-fitted on the transitions gathered since the last
-        # fit every recovery_policy_update_freq * horizon iterations (the reference re-fits every
-        # recovery_policy_update_freq episodes, experiment.py:464-480); the batch size scales with
-        # num_envs so that an epoch keeps the reference's number of optimiser steps per env-step
-        mb_new = mb_resume
-        mb_every = cfg.recovery_policy_update_freq * self.env._max_episode_steps
-        # env_shard: the updates contain RCCL all-reduces, launched eagerly (not captured)
-        graph_ok = (cfg.target_update_interval == 1 and not cfg.nu_schedule and not mb and not self.env_shard)
-        while True:
-            have_batch = len(self.memory) > cfg.batch_size
-            random_actions = cfg.start_steps > loop.total_numsteps
-            gate = self.online_qrisk_enabled() if uses_constraint_buffer(cfg) else False
-            steady = have_batch and not random_actions and graph_ok
-            if steady and (loop.graph is None or captured_gate != gate):
-                it += loop.capture(online_qrisk=gate)
-                captured_gate = gate
-            if steady:
-                loop.replay()
-            else:
-                loop.vector_step(do_update=have_batch, random_actions=random_actions, online_qrisk=gate)
-            it += 1
-            if mb and not cfg.disable_online_updates:
-                info_s, info_a, info_s2 = self.env.prev_obs, self.env.action_clipped, self.env.next_obs
-                mb_new.append((info_s.clone(), info_a.clone(), info_s2.clone()))
-                if it % mb_every == 0:
-                    S, A, S2 = (torch.cat(x) for x in zip(*mb_new))
-                    self.recovery_policy.train(S, A, random=True, next_obs=S2, batch_size=32 * n)
-                    mb_new = []
-            if it // log_every > logged:
-                logged = it // log_every
-                stats = loop.read_stats()
-                self._absorb(stats)
-                new = loop.episode_log.drain()
-                episodes.append(new)
-                ep_file.write(new.tobytes())
-                ep_file.flush()
-                agg = dist_utils.aggregate_stats(stats, self.world_size, self.device)
-                self._global_viols = agg["num_viols"]
-                history.append(dict(stats, iteration=it))
-                if self.rank == 0:
-                    print("Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(
-                        it, agg["env_steps"], agg["episodes"],
-                        round(agg["episode_return_sum"] / max(agg["episodes"], 1), 2)))
-                    print("Num Violations So Far: %d" % agg["num_viols"])
-                    print("Violations with Recovery: %d" % agg["viol_and_recovery"])
-                    print("Violations with No Recovery: %d" % agg["viol_and_no_recovery"])
-                    print("Num Successes So Far: %d" % agg["num_successes"])
-                if cfg.eval and stats["episodes"] >= next_eval:
-                    evals.append(self.get_test_rollout_vectorized(stats["episodes"]))
-                    next_eval += 10 * n
-                with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
-                    pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n}, f)
-                if ckpt_every and logged % ckpt_every == 0:
-                    write_checkpoint()
-                # multi-rank: all ranks leave at the same log point (the next aggregate would hang otherwise);
-                # the thresholds apply to the per-rank mean
-                w = max(self.world_size, 1)
-                if agg["env_steps"] > cfg.num_steps * w or agg["episodes"] > cfg.num_eps * w:
-                    break
-        ep_file.close()
+        try:
+            captured_gate = None
+            mb = uses_mb_recovery(cfg)
+            # model-based recovery: the ensemble is re-fitted on the transitions gathered since the last
+            # fit every recovery_policy_update_freq * horizon iterations (the reference re-fits every
+            # recovery_policy_update_freq episodes, experiment.py:464-480); the batch size scales with
+            # num_envs so that an epoch keeps the reference's number of optimiser steps per env-step
+            mb_new = mb_resume
+            mb_every = cfg.recovery_policy_update_freq * self.env._max_episode_steps
+            # env_shard: the updates contain RCCL all-reduces, launched eagerly (not captured)
+            graph_ok = (cfg.target_update_interval == 1 and not cfg.nu_schedule and not mb and not self.env_shard)
+            while True:
+                have_batch = len(self.memory) > cfg.batch_size
+                random_actions = cfg.start_steps > loop.total_numsteps
+                gate = self.online_qrisk_enabled() if uses_constraint_buffer(cfg) else False
+                steady = have_batch and not random_actions and graph_ok
+                if steady and (loop.graph is None or captured_gate != gate):
+                    it += loop.capture(online_qrisk=gate)
+                    captured_gate = gate
+                if steady:
+                    loop.replay()
+                else:
+                    loop.vector_step(do_update=have_batch, random_actions=random_actions, online_qrisk=gate)
+                it += 1
+                if mb and not cfg.disable_online_updates:
+                    info_s, info_a, info_s2 = self.env.prev_obs, self.env.action_clipped, self.env.next_obs
+                    mb_new.append((info_s.clone(), info_a.clone(), info_s2.clone()))
+                    if it % mb_every == 0:
+                        S, A, S2 = (torch.cat(x) for x in zip(*mb_new))
+                        self.recovery_policy.train(S, A, random=True, next_obs=S2, batch_size=32 * n)
+                        mb_new = []
+                if it // log_every > logged:
+                    logged = it // log_every
+                    stats = loop.read_stats()
+                    self._absorb(stats)
+                    new = loop.episode_log.drain()
+                    episodes.append(new)
+                    ep_file.write(new.tobytes())
+                    ep_file.flush()
+                    agg = dist_utils.aggregate_stats(stats, self.world_size, self.device)
+                    self._global_viols = agg["num_viols"]
+                    history.append(dict(stats, iteration=it))
+                    if self.rank == 0:
+                        print("Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(
+                            it, agg["env_steps"], agg["episodes"],
+                            round(agg["episode_return_sum"] / max(agg["episodes"], 1), 2)))
+                        print("Num Violations So Far: %d" % agg["num_viols"])
+                        print("Violations with Recovery: %d" % agg["viol_and_recovery"])
+                        print("Violations with No Recovery: %d" % agg["viol_and_no_recovery"])
+                        print("Num Successes So Far: %d" % agg["num_successes"])
+                    if cfg.eval and stats["episodes"] >= next_eval:
+                        evals.append(self.get_test_rollout_vectorized(stats["episodes"]))
+                        next_eval += 10 * n
+                    with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
+                        pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n}, f)
+                    if ckpt_every and logged % ckpt_every == 0:
+                        write_checkpoint()
+                    # multi-rank: all ranks leave at the same log point (the next aggregate would hang otherwise);
+                    # the thresholds apply to the per-rank mean
+                    w = max(self.world_size, 1)
+                    if agg["env_steps"] > cfg.num_steps * w or agg["episodes"] > cfg.num_eps * w:
+                        break
+        finally:
+            ep_file.close()
         write_checkpoint()
         with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
             pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n,
