@@ -59,10 +59,10 @@ struct StepPushArgs {
     float* ep_reward;            // [n] running episode return
 };
 
-__device__ __forceinline__ void wave_count_add(unsigned long long* dst, bool flag) {
-    const unsigned long long bal = __ballot(flag);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(dst, (unsigned long long)__popcll(bal));
-}
+// Episode counters: every lane keeps its own tallies over the grid-stride loop; they are added up per wave
+// (ballot-free shuffles), then per workgroup in LDS, and ONE atomic per workgroup and counter reaches memory.
+// (One atomic per wave and iteration serialised 115 k atomics on 7 addresses at 2^20 envs: 719 us.)
+constexpr int kCounters = 7;
 
 template <class ENV>
 __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArgs p) {
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
     int64_t rpos = 0, rsize = 0;
     if (p.use_recovery_memory) { rpos = p.recovery_memory.state[0]; rsize = p.recovery_memory.state[1]; }
     double rsum = 0.0, retsum = 0.0;
+    unsigned cnt[kCounters] = {0, 0, 0, 0, 0, 0, 0};
     const int64_t stride = int64_t(gridDim.x) * kBlock;
     const int64_t n_iter = (a.n + stride - 1) / stride;   // uniform trip count: ballots need whole waves
     for (int64_t it = 0; it < n_iter; ++it) {
@@ -122,21 +123,39 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             a.obs[i] = make_float2(float(nx), float(ny));
         }
         const bool end_viol = epd & cons;
-        wave_count_add(p.stats + 1, epd);
-        wave_count_add(p.stats + 2, end_viol);
-        wave_count_add(p.stats + 3, end_viol & rec);
-        wave_count_add(p.stats + 4, end_viol & !rec);
-        wave_count_add(p.stats + 5, epd & succ);
-        wave_count_add(p.stats + 6, live & rec);
-        wave_count_add(p.stats + 7, cons);
+        cnt[0] += epd;
+        cnt[1] += end_viol;
+        cnt[2] += end_viol & rec;
+        cnt[3] += end_viol & !rec;
+        cnt[4] += epd & succ;
+        cnt[5] += live & rec;
+        cnt[6] += cons;
     }
+    __shared__ unsigned block_cnt[kCounters];
+    __shared__ double block_sum[2][kBlock / 64];
+    if (threadIdx.x < kCounters) block_cnt[threadIdx.x] = 0;
+    __syncthreads();
     for (int off = 32; off > 0; off >>= 1) {
         rsum += __shfl_down(rsum, off);
         retsum += __shfl_down(retsum, off);
+#pragma unroll
+        for (int k = 0; k < kCounters; ++k) cnt[k] += __shfl_down(cnt[k], off);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (rsum != 0.0) atomicAdd(p.reward_sums, rsum);
-        if (retsum != 0.0) atomicAdd(p.reward_sums + 1, retsum);
+        block_sum[0][threadIdx.x >> 6] = rsum;
+        block_sum[1][threadIdx.x >> 6] = retsum;
+#pragma unroll
+        for (int k = 0; k < kCounters; ++k)
+            if (cnt[k]) atomicAdd(&block_cnt[k], cnt[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < kCounters) {
+        if (block_cnt[threadIdx.x]) atomicAdd(p.stats + 1 + threadIdx.x, (unsigned long long)block_cnt[threadIdx.x]);
+    } else if (threadIdx.x < kCounters + 2) {
+        const int w = threadIdx.x - kCounters;
+        double sum = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) sum += block_sum[w][k];       // fixed order inside the workgroup
+        if (sum != 0.0) atomicAdd(p.reward_sums + w, sum);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(p.stats, (unsigned long long)a.n);
     rrl_replay::advance_ring(p.memory, mpos, msize, a.n);
