@@ -17,37 +17,52 @@ __global__ __launch_bounds__(kBlock) void episode_log_kernel(
     int32_t* __restrict__ ep_viol, int32_t* __restrict__ ep_rec, int32_t* __restrict__ rec_i32,
     double* __restrict__ rec_f64, int64_t cap, int64_t* __restrict__ state) {
     const int64_t iteration = state[1];
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const float r = reward[i];
-        const int c = constraint[i] != 0;
-        const int rec = recovery ? (recovery[i] != 0) : 0;
-        const int len = ep_len[i] + 1;
-        const double ret = ep_ret[i] + (double)r;
-        const int viol = ep_viol[i] + c;
-        const int recs = ep_rec[i] + rec;
-        if (ep_done[i]) {
-            const long long slot = (long long)atomicAdd((unsigned long long*)&state[0], 1ULL);
-            if (slot < cap) {
-                int32_t* ri = rec_i32 + slot * RRL_EPLOG_I32;
-                ri[0] = (int32_t)i;
-                ri[1] = (int32_t)iteration;
-                ri[2] = len;
-                ri[3] = viol;
-                ri[4] = recs;
-                ri[5] = (success[i] ? 1 : 0) | (c ? 2 : 0) | (rec ? 4 : 0);
-                rec_f64[slot * 2 + 0] = ret;
-                rec_f64[slot * 2 + 1] = (double)r;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n_iter = (n + stride - 1) / stride;       // uniform trip count: the ballot needs whole waves
+    for (int64_t it = 0; it < n_iter; ++it) {
+        const int64_t i = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+        const bool live = i < n;
+        float r = 0.f;
+        int c = 0, rec = 0, len = 0, viol = 0, recs = 0;
+        double ret = 0.0;
+        bool finished = false;
+        if (live) {
+            r = reward[i];
+            c = constraint[i] != 0;
+            rec = recovery ? (recovery[i] != 0) : 0;
+            len = ep_len[i] + 1;
+            ret = ep_ret[i] + (double)r;
+            viol = ep_viol[i] + c;
+            recs = ep_rec[i] + rec;
+            finished = ep_done[i] != 0;
+        }
+        // one atomic per wave reserves the slots of all its finished episodes (one per lane serialised at large n)
+        const unsigned long long bal = __ballot(finished);
+        long long base = 0;
+        if (bal) {
+            const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
+            if (lane == leader) base = (long long)atomicAdd((unsigned long long*)&state[0], (unsigned long long)__popcll(bal));
+            base = __shfl(base, leader, 64);
+            if (finished) {
+                const long long slot = base + __popcll(bal & ((1ULL << lane) - 1ULL));
+                if (slot < cap) {
+                    int32_t* ri = rec_i32 + slot * RRL_EPLOG_I32;
+                    ri[0] = (int32_t)i;
+                    ri[1] = (int32_t)iteration;
+                    ri[2] = len;
+                    ri[3] = viol;
+                    ri[4] = recs;
+                    ri[5] = (success[i] ? 1 : 0) | (c ? 2 : 0) | (rec ? 4 : 0);
+                    rec_f64[slot * 2 + 0] = ret;
+                    rec_f64[slot * 2 + 1] = (double)r;
+                }
             }
-            ep_len[i] = 0;
-            ep_ret[i] = 0.0;
-            ep_viol[i] = 0;
-            ep_rec[i] = 0;
-        } else {
-            ep_len[i] = len;
-            ep_ret[i] = ret;
-            ep_viol[i] = viol;
-            ep_rec[i] = recs;
+        }
+        if (live) {
+            ep_len[i] = finished ? 0 : len;
+            ep_ret[i] = finished ? 0.0 : ret;
+            ep_viol[i] = finished ? 0 : viol;
+            ep_rec[i] = finished ? 0 : recs;
         }
     }
     // iteration += 1 by the last workgroup to finish (every workgroup read it before its ticket)
