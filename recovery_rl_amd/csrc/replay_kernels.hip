@@ -240,15 +240,33 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
     const int B = n_pos + n_neg;
     unsigned long long* table = (unsigned long long*)smem;      // [table_mask + 1]
     uint32_t* key = (uint32_t*)(table + table_mask + 1);
-    int32_t* prefix = (int32_t*)(key + B);            // [n_chunks + 1] exclusive positive counts
-    int32_t* part = prefix + (n_chunks + 1);          // [blockDim.x]
+    int32_t* prefix = (int32_t*)(key + ((B + 3) & ~3));   // [n_chunks + 1] exclusive positive counts, 16-byte aligned
+    int32_t* part = prefix + (n_chunks + 1) + ((n_chunks + 1) >> 5) + 1;   // [blockDim.x], after the skewed table
     const int64_t size = rb.state[1];
     const int tid = threadIdx.x, nt = blockDim.x;
-    // exclusive scan of pos_cnt into LDS: contiguous segment per thread, then a block scan
+    // exclusive scan of pos_cnt in LDS.  The table is first copied with coalesced, independent 16-byte loads (a
+    // thread walking its own contiguous segment of global memory serialised ~60 round trips twice: 34 us at 1e6
+    // slots), then every thread sums / rewrites its contiguous LDS segment around a block scan.  Entry c lives at
+    // c + c / 32: without the skew the per-thread segments (a power-of-two apart) collide on two LDS banks.
+    auto at = [](int c) { return c + (c >> 5); };
+    {
+        const int n4 = (reinterpret_cast<uintptr_t>(rb.pos_cnt) & 15) == 0 ? n_chunks >> 2 : 0;
+        const int4* src4 = reinterpret_cast<const int4*>(rb.pos_cnt);
+#pragma unroll 8
+        for (int c = tid; c < n4; c += nt) {
+            const int4 v = src4[c];
+            prefix[at(4 * c)] = v.x;
+            prefix[at(4 * c + 1)] = v.y;
+            prefix[at(4 * c + 2)] = v.z;
+            prefix[at(4 * c + 3)] = v.w;
+        }
+        for (int c = 4 * n4 + tid; c < n_chunks; c += nt) prefix[at(c)] = rb.pos_cnt[c];
+    }
+    __syncthreads();
     const int seg = (n_chunks + nt - 1) / nt;
-    const int lo = tid * seg, hi = min(lo + seg, n_chunks);
+    const int lo = min(tid * seg, n_chunks), hi = min(lo + seg, n_chunks);
     int32_t local = 0;
-    for (int c = lo; c < hi; ++c) local += rb.pos_cnt[c];
+    for (int c = lo; c < hi; ++c) local += prefix[at(c)];
     part[tid] = local;
     __syncthreads();
     for (int off = 1; off < nt; off <<= 1) {
@@ -259,11 +277,12 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
     }
     int32_t run = part[tid] - local;
     for (int c = lo; c < hi; ++c) {
-        prefix[c] = run;
-        run += rb.pos_cnt[c];
+        const int32_t cnt = prefix[at(c)];
+        prefix[at(c)] = run;
+        run += cnt;
     }
     const int64_t total_pos = part[nt - 1];
-    if (tid == nt - 1) prefix[n_chunks] = int32_t(total_pos);
+    if (tid == nt - 1) prefix[at(n_chunks)] = int32_t(total_pos);
     __syncthreads();
     const int64_t total_neg = size - total_pos;
     if (int64_t(n_pos) > total_pos || int64_t(n_neg) > total_neg) {
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
     const int64_t k = int64_t(key[tid] & 0x7fffffffu);
     auto before = [&](int c) -> int64_t {  // rows of my class in chunks [0,c)
         const int64_t filled = min(size, int64_t(c) * kChunk);
-        return is_pos ? int64_t(prefix[c]) : filled - int64_t(prefix[c]);
+        return is_pos ? int64_t(prefix[at(c)]) : filled - int64_t(prefix[at(c)]);
     };
     int a = 0, b = n_chunks;  // invariant: before(a) <= k < before(b)
     while (b - a > 1) {
@@ -296,13 +315,32 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
     int64_t rem = k - before(a);
     int64_t slot = -1;
     const int64_t c0 = int64_t(a) * kChunk;
-    for (int j = 0; j < kChunk; ++j) {
-        const int64_t p = c0 + j;
-        if (p >= size) break;
-        const bool pos_row = rb.r[p] != 0.0f;
-        if (pos_row == is_pos) {
-            if (rem == 0) { slot = p; break; }
-            --rem;
+    // the chunk's 64 rewards in 16 independent 16-byte loads (a serial scan chained up to 64 dependent loads);
+    // slots at or beyond `size` never match
+    float4 rv[kChunk / 4];
+    const bool whole = c0 + kChunk <= rb.cap;
+#pragma unroll
+    for (int q = 0; q < kChunk / 4; ++q) {
+        if (whole) {
+            rv[q] = reinterpret_cast<const float4*>(rb.r + c0)[q];
+        } else {
+            float t4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t4[u] = rb.r[min(c0 + 4 * q + u, rb.cap - 1)];
+            rv[q] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kChunk / 4; ++q) {
+        const float e4[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = c0 + 4 * q + u;
+            const bool match = p < size && ((e4[u] != 0.0f) == is_pos);
+            if (match && slot < 0) {
+                if (rem == 0) slot = p;
+                --rem;
+            }
         }
     }
     if (slot < 0) {  // count table out of sync with the rows: flag, never read out of bounds
@@ -367,15 +405,18 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
     const int n_chunks = int((rb->cap + kChunk - 1) / kChunk);
     int threads = ((B + 63) / 64) * 64;
     if (threads < 256) threads = 256;
+    if (n_chunks > 4096) threads = 1024;                 // the count-table scan dominates: spread it
     int table_size = 64;
     while (table_size < 4 * B) table_size <<= 1;
-    const size_t lds = size_t(table_size) * 8 + size_t(B) * 4 + size_t(n_chunks + 1) * 4 + size_t(threads) * 4 + 16;
-    if (lds > 64 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opt in above the 64 KiB default
+    const size_t lds = size_t(table_size) * 8 + size_t((B + 3) & ~3) * 4 + size_t(n_chunks + 2 + ((n_chunks + 1) >> 5)) * 4 + size_t(threads) * 4 + 16;
+    static size_t granted = 64 * 1024;   // gfx950 has 160 KiB of LDS per CU; opt in (once per size) above the default
+    if (lds > granted) {
         if (hipFuncSetAttribute((const void*)creplay_sample_gather_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
             (void)hipGetLastError();
             return RRL_ERANGE;
         }
+        granted = lds;
     }
     const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out, (float4*)xu, (float4*)x2u, (float4*)xpu};
     hipLaunchKernelGGL(creplay_sample_gather_kernel, dim3(1), dim3(threads), lds,
