@@ -30,6 +30,10 @@ def _required(cfg, key, message):
     return cfg[key]
 
 
+def _capturable(opt):
+    return bool(opt.param_groups[0].get("capturable", False))
+
+
 class _GraphedTrainStep:
     """The ensemble training step (forward, NLL loss, backward, Adam) captured once per `MPC.train` call and
     replayed per batch: the batch-32 loop of the reference (MPC.py:266-292) is ~40 tiny launches per step, i.e.
@@ -144,6 +148,7 @@ class MPC:
         num_batch = int(np.ceil(n / batch_size))
         losses = None
         fused = self._fused_trainer(batch_size)
+        self._hand_over_optimiser("fused" if fused is not None else "torch")
         if fused is not None:
             fused.begin(self.train_in, self.train_targs)
         step = None
@@ -166,9 +171,34 @@ class MPC:
                 print("Network training: MSE per net", losses.cpu().numpy())
         return losses
 
+    def _hand_over_optimiser(self, owner):
+        """ONE Adam state per controller (the reference has a single torch.optim.Adam, config/navigation1.py:167):
+        the fused trainer (batch <= 32) and model.optim (any batch) each hold moments and a step count, so when
+        consecutive `train` calls take different paths the state moves with them instead of restarting the bias
+        correction on a fitted model."""
+        prev = getattr(self, "_optim_owner", None)
+        self._optim_owner = owner
+        if prev is None or prev == owner or self._trainer is None:
+            return
+        from .ensemble_train import PARAMS
+        tr, opt = self._trainer, self.model.optim
+        params = [getattr(self.model, n) for n in PARAMS]
+        with torch.no_grad():
+            if owner == "torch":                       # fused -> torch.optim.Adam
+                for p, m, v, st in zip(params, tr.m, tr.v, tr.steps):
+                    opt.state[p] = {"step": st[0].to(torch.float32).cpu() if not _capturable(opt)
+                                    else st[0].to(torch.float32), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+            else:                                      # torch.optim.Adam -> fused
+                for p, m, v, st in zip(params, tr.m, tr.v, tr.steps):
+                    state = opt.state.get(p)
+                    if not state:
+                        m.zero_(), v.zero_(), st.zero_()
+                        continue
+                    m.copy_(state["exp_avg"]), v.copy_(state["exp_avg_sq"])
+                    st[0] = int(float(state["step"]))
+
     def _fused_trainer(self, batch_size):
-        """FusedEnsembleTrainer when the shapes are the kernel's (4-200-200-200-4, batch <= 32), else None.  The
-        fused path owns its Adam state, so once created it serves every later step of this controller."""
+        """FusedEnsembleTrainer when the shapes are the kernel's (4-200-200-200-4, batch <= 32), else None."""
         if not self.fused_train or self.train_in.device.type != "cuda":
             return None
         from .ensemble_train import FusedEnsembleTrainer

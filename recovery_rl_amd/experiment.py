@@ -179,6 +179,12 @@ class VectorLoop:
         if recovery is not None:
             rec_u8 = recovery if recovery.dtype == torch.uint8 else recovery.to(torch.uint8)
         use_rmem = uses_constraint_buffer(cfg)
+        if self.recovery_policy is not None:
+            # the online ensemble re-fit reads (state, clipped action, next state) of this step (experiment.py:464-480
+            # collects them per episode): env.step() writes these buffers, the fused kernel does not
+            env.prev_obs.copy_(env.obs)
+            hi = float(env.action_space.high[0])
+            torch.clamp(real_action, -hi, hi, out=env.action_clipped)
         if env.env_name == "maze":
             entry, head = env.lib.rrl_maze_step_push, ()
         else:
@@ -250,7 +256,11 @@ class VectorLoop:
         return self._graph_obs
 
     def read_stats(self):
-        """One device->host copy of the counter vector."""
+        """One device->host copy of the counter vector (+ the samplers' error flags: a draw the reference would
+        abort with ValueError -- random.sample on too small a population, replay_memory.py:28,61-66 -- leaves the
+        batch unwritten on the device, so the run must stop here instead of training on stale rows)."""
+        self.memory.check_error()
+        self.recovery_memory.check_error()
         vals = self.stats.cpu().tolist()
         vals[8], vals[9] = self.host_updates
         out = dict(zip(STAT_KEYS, vals))
@@ -371,6 +381,7 @@ class Experiment:
                 print("CRITIC SAFE UPDATE STEP: ", i)
             self.agent.safety_critic.update_parameters(memory=self.recovery_memory,
                                                        policy=self.agent.policy, batch_size=batch)
+        self.recovery_memory.check_error()
         if not (cfg.MF_recovery or cfg.Q_sampling_recovery or cfg.DGD_constraints or cfg.RCPO):
             self.train_MB_recovery(s, a, s2, epochs=50)
 
@@ -390,6 +401,7 @@ class Experiment:
             # counters (identical everywhere) and the learner's global batch
             nv = self._global_viols
             return (not cfg.disable_online_updates
+                    and self._global_rmem_len > cfg.global_batch_size                # len(recovery_memory), :408
                     and (nv + self._global_offline_viols) / cfg.global_batch_size > cfg.pos_fraction)
         return (not cfg.disable_online_updates
                 and len(self.recovery_memory) > cfg.batch_size
@@ -517,11 +529,12 @@ class Experiment:
         cfg, loop = self.exp_cfg, self.loop
         n = cfg.num_envs
         self._global_viols = 0
-        self._global_offline_viols = dist_utils.aggregate_stats(
-            {k: (self.num_constraint_violations if k == "num_viols" else 0) for k in dist_utils.METRIC_KEYS},
-            self.world_size, self.device)["num_viols"]
         loop.start()
         log_every = cfg.log_every if getattr(cfg, "log_every", 0) else max(1, 100)
+        if self.world_size > 1 and log_every < 4:
+            # a graph (re)capture adds up to 3 iterations on ONE rank; with a shorter cadence ranks could cross a
+            # different number of log boundaries per pass and issue mismatched metric all-reduces
+            raise ValueError("--log_every must be >= 4 with more than one rank")
         from . import checkpoint
         from .episode_log import EpisodeLog, EPISODE_DTYPE
         loop.episode_log = EpisodeLog(n, n * (log_every + 4), self.device)   # a capture adds <= 3 iterations
@@ -536,14 +549,21 @@ class Experiment:
             it, next_eval = extra["iteration"], extra["next_eval"]
             history, evals, episodes = extra["history"], extra["evals"], [extra["episodes"]]
             mb_resume = [tuple(x.to(self.device) for x in row) for row in extra["mb_new"]]
+            self._global_viols = extra.get("global_viols", 0)
             print("Resumed from %s at iteration %d (%d env-steps)" % (cfg.resume, it, loop.total_numsteps))
+        # after a resume the offline count comes from the checkpoint's counters (pre-training is skipped)
+        start = dist_utils.aggregate_stats(
+            {k: {"num_viols": self.num_constraint_violations, "env_steps": len(self.recovery_memory)}.get(k, 0)
+             for k in dist_utils.METRIC_KEYS}, self.world_size, self.device)
+        self._global_offline_viols, self._global_rmem_len = start["num_viols"], start["env_steps"]
         logged = it // log_every
         ckpt_every = getattr(cfg, "checkpoint_every", 0)
         ckpt_path = osp.join(self.logdir, "checkpoint.pt")
 
         def write_checkpoint():
             checkpoint.save(self, ckpt_path, {"iteration": it, "next_eval": next_eval, "history": history,
-                                              "evals": evals, "episodes": np.concatenate(episodes), "mb_new": mb_new})
+                                              "evals": evals, "episodes": np.concatenate(episodes), "mb_new": mb_new,
+                                              "global_viols": self._global_viols})
         ep_file = open(osp.join(self.logdir, "episode_stats.bin"), "wb")   # append-only, O(new) per log
         ep_file.write(episodes[0].tobytes())
         try:
@@ -587,6 +607,10 @@ class Experiment:
                     ep_file.flush()
                     agg = dist_utils.aggregate_stats(stats, self.world_size, self.device)
                     self._global_viols = agg["num_viols"]
+                    if self.env_shard and self._global_rmem_len <= cfg.global_batch_size:
+                        self._global_rmem_len = dist_utils.aggregate_stats(
+                            {k: (len(self.recovery_memory) if k == "env_steps" else 0)
+                             for k in dist_utils.METRIC_KEYS}, self.world_size, self.device)["env_steps"]
                     history.append(dict(stats, iteration=it))
                     if self.rank == 0:
                         print("Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(

@@ -104,3 +104,91 @@ def test_epoch_loop_in_c_equals_the_per_step_calls():
     for name in PARAMS:
         assert torch.equal(getattr(mpc_a.model, name), getattr(mpc_b.model, name)), name
     assert int(ta.steps[0][0].item()) == 6
+
+
+# ---- pinned to the REFERENCE's MPC.train (tests/golden/mpc_train_golden.npz, gen_mpc_train_golden.py) --------------
+import os  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def reference_controller(rows):
+    """Controller on the GPU with the reference's initial ensemble weights (mpc_golden.npz pt.*)."""
+    G = np.load(os.path.join(GOLDEN, "mpc_golden.npz"))
+    T = np.load(os.path.join(GOLDEN, "mpc_train_golden.npz"))
+    env = make_vec_env("navigation2", 2, device=DEV, seed=1)
+    mpc = MPC(create_config("navigation2", "MPC", {}, [], "/tmp", env=env).ctrl_cfg, seed=1)
+    sd = mpc.model.state_dict()
+    mpc.model.load_state_dict({k: torch.as_tensor(G["pt." + k]).to(DEV) for k in sd})
+    f32 = lambda k: torch.as_tensor(T[k][:rows], dtype=torch.float32, device=DEV)
+    return mpc, T, (f32("data.s"), f32("data.a"), f32("data.s2"))
+
+
+def golden_view(T, name, t):
+    arr = t.detach().cpu().numpy()
+    return arr.reshape(-1)[::int(T["stride"])] if name in ("lin1_w", "lin2_w") else arr
+
+
+def test_fused_gradients_equal_the_reference_step():
+    """rrl_ens_train_grad on the reference's first batch (MPC.py:266-292): loss and every gradient."""
+    mpc, T, (s, a, s2) = reference_controller(32)
+    mpc.train_in = torch.cat([s, a], 1).contiguous()
+    mpc.train_targs = (s2 - s).contiguous()
+    mpc.model.fit_input_stats(mpc.train_in)
+    assert np.allclose(mpc.model.inputs_sigma.cpu().numpy(), T["step.sigma"], rtol=1e-6, atol=1e-6)
+    tr = FusedEnsembleTrainer(mpc.model)
+    tr.begin(mpc.train_in, mpc.train_targs)
+    tr.gradients(torch.as_tensor(T["step.idxs"], device=DEV))
+    m = mpc.model
+    total = 0.01 * (m.max_logvar.sum() - m.min_logvar.sum()) + m.compute_decays() + tr.loss.sum()
+    assert np.isclose(float(total), float(T["step.loss"]), rtol=1e-5)
+    for k, (name, g) in enumerate(zip(PARAMS, tr.grads)):
+        if k < 8:
+            g = g + tr.grads2[k]
+        if name in DECAY:
+            g = g + DECAY[name] * getattr(m, name).data
+        if name in ("max_logvar", "min_logvar"):
+            g = g + (0.01 if name == "max_logvar" else -0.01)       # the 0.01 (sum max - sum min) term (MPC.py:270)
+        want = T["step.grad." + name]
+        got = golden_view(T, name, g)
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max() + 1e-9, name
+
+
+@pytest.mark.parametrize("fused", (True, False))
+def test_training_run_equals_the_reference(fused, monkeypatch):
+    """MPC.train, 2 epochs over 200 rows with the reference's bootstrap table and shuffles injected: the trained
+    parameters of the fused kernel path (and of the PyTorch path) against the reference's."""
+    import recovery_rl_amd.MPC as mod
+    mpc, T, (s, a, s2) = reference_controller(200)
+    mpc.fused_train = fused
+    tables = [torch.as_tensor(t, device=DEV) for t in T["train.shuffled"]]
+    monkeypatch.setattr(torch, "randint", lambda n, size, **k: torch.as_tensor(T["train.idxs"], device=DEV))
+    monkeypatch.setattr(mod, "shuffle_rows", lambda arr: tables.pop(0))
+    mpc.train(s, a, random=True, next_obs=s2, epochs=2)
+    assert (mpc._trainer is not None) == fused
+    if fused:
+        assert int(mpc._trainer.steps[0][0].item()) == 14
+    for name in PARAMS:
+        post, want = golden_view(T, name, getattr(mpc.model, name)), T["train.post." + name]
+        assert np.abs(post - want).max() < 2e-4, (name, np.abs(post - want).max())       # 0.2 lr
+
+
+def test_adam_state_moves_with_the_training_path():
+    """Batch <= 32 runs on the fused trainer, larger batches on torch.optim.Adam: the moments and the step count are
+    handed over, so a re-fit does not restart the bias correction (ONE optimiser in the reference)."""
+    mpc, idxs = build(7)
+    n = mpc.train_in.shape[0]
+    s, a = mpc.train_in[:, :2].contiguous(), mpc.train_in[:, 2:].contiguous()
+    s2 = (s + mpc.train_targs).contiguous()
+    mpc.train_in, mpc.train_targs = mpc.train_in[:0], mpc.train_targs[:0]
+    mpc.train(s, a, random=True, next_obs=s2, epochs=1, batch_size=32)            # fused: ceil(700/32) = 22 steps
+    assert mpc._optim_owner == "fused" and int(mpc._trainer.steps[0][0].item()) == 22
+    m_fused = mpc._trainer.m[0].clone()
+    mpc.train(s[:64], a[:64], random=True, next_obs=s2[:64], epochs=1, batch_size=128)   # torch: ceil(764/128) = 6
+    assert mpc._optim_owner == "torch"
+    st = mpc.model.optim.state[mpc.model.lin0_w]
+    assert int(float(st["step"])) == 28
+    assert not torch.equal(st["exp_avg"], m_fused)
+    mpc.train(s[:32], a[:32], random=True, next_obs=s2[:32], epochs=1, batch_size=32)    # back: ceil(796/32) = 25
+    assert mpc._optim_owner == "fused" and int(mpc._trainer.steps[0][0].item()) == 53
+    assert n == 700

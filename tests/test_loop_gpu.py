@@ -162,6 +162,34 @@ def test_model_based_recovery_runs_single_and_vectorised(tmp_path, capsys):
     assert hist[-1]["env_steps"] > 1700
     assert exp.recovery_policy.train_in.shape[0] > exp.num_unsafe_transitions   # online re-fit happened
     assert exp.loop.graph is None                                    # MB planning is not graph-captured
+    # the online rows are real transitions (state, clipped executed action) -> s' - s, not the zero rows an unwritten
+    # prev_obs / action_clipped would give (the fused step kernel does not write those buffers itself)
+    rp, n_demo = exp.recovery_policy, exp.num_unsafe_transitions
+    online_in, online_targ = rp.train_in[n_demo:], rp.train_targs[n_demo:]
+    assert online_in.shape[0] % 16 == 0 and online_in.shape[0] >= 16 * 100
+    assert float(online_in[:, :2].abs().min(dim=1).values.max()) > 1.0          # states are around (-50 .. 0, .)
+    assert float(online_in[:, 2:].abs().max()) <= 1.0 and float(online_in[:, 2:].abs().mean()) > 0.05
+    free = online_targ.abs().sum(1) > 0                                           # rows that moved (not stuck in the box)
+    resid = (online_targ - online_in[:, 2:])[free]
+    assert float(resid.abs().max()) < 0.5 and 0.02 < float(resid.std()) < 0.08   # s' - s = a + 0.05 N(0, I)
+
+
+def test_fused_step_keeps_state_and_clipped_action_for_the_refit(tmp_path):
+    """One fused lock-step iteration of the model-based configuration: env.prev_obs / env.action_clipped (what the
+    online ensemble re-fit reads, experiment.py:464-480) equal the pre-step observation and the clipped action."""
+    cfg = arg_utils.get_args(["--env-name", "navigation2", "--cuda", "--hidden_size", "32", "--logdir", str(tmp_path),
+                              "--seed", "2", "--num_unsafe_transitions", "600", "--use_recovery", "--gamma_safe",
+                              "0.65", "--eps_safe", "0.2", "--num_envs", "64"])
+    exp = Experiment(cfg)
+    loop = exp.loop
+    assert loop._can_fuse_step() and loop.recovery_policy is not None
+    obs0 = loop.start().clone()
+    act = torch.rand(64, 2, device=DEV) * 4 - 2
+    loop.step_and_store(act, act.clone(), torch.zeros(64, dtype=torch.uint8, device=DEV))
+    assert torch.equal(exp.env.prev_obs, obs0)
+    assert torch.equal(exp.env.action_clipped, act.clamp(-1, 1))
+    moved = exp.env.next_obs - obs0
+    assert float((moved - act.clamp(-1, 1)).abs().max()) < 0.5
 
 
 def test_maze_config3_vectorised_with_stratified_replay(tmp_path, capsys):

@@ -118,3 +118,77 @@ def test_cem_update_rejects_more_elites_than_population():
     with pytest.raises(ValueError):
         co.cem_update(np.zeros((1, 4, 2), np.float32), np.zeros((1, 4), np.float32), np.zeros((1, 2)),
                       np.ones((1, 2)), 5, 0.1)
+
+
+# ---- MPC.train pinned to the reference (tests/golden/mpc_train_golden.npz, gen_mpc_train_golden.py) ----------------
+TRAIN_PARAMS = ("lin0_w", "lin0_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b", "lin3_w", "lin3_b", "max_logvar",
+                "min_logvar")
+
+
+@pytest.fixture(scope="module")
+def T(golden_dir):
+    return np.load(os.path.join(golden_dir, "mpc_train_golden.npz"))
+
+
+def golden_view(T, name, arr):
+    """The fixture stores the two 5x200x200 matrices on a strided subset."""
+    arr = np.asarray(arr)
+    return arr.reshape(-1)[::int(T["stride"])] if name in ("lin1_w", "lin2_w") else arr
+
+
+def cpu_controller(G):
+    """An MPC with only what train() touches, on the CPU (the planner side needs the GPU)."""
+    from recovery_rl_amd.config import NN_TRAIN_CFG, targ_proc
+    mpc = MPC.__new__(MPC)
+    mpc.device = torch.device("cpu")
+    mpc.model = load_ptmodel(G)
+    mpc.model.optim = torch.optim.Adam(mpc.model.parameters(), lr=0.001)
+    mpc.targ_proc, mpc.model_train_cfg = targ_proc, dict(NN_TRAIN_CFG)
+    mpc.train_in, mpc.train_targs = torch.zeros(0, 4), torch.zeros(0, 2)
+    mpc.has_been_trained, mpc.fused_train, mpc.graph_train, mpc._trainer = False, False, False, None
+    return mpc
+
+
+def run_train_with_tables(mpc, monkeypatch, T, case, rows, epochs):
+    """MPC.train with the reference's bootstrap table and shuffles injected (it drew them from np.random)."""
+    import recovery_rl_amd.MPC as mod
+    tables = [torch.as_tensor(t) for t in (T[case + ".shuffled"] if case == "train" else [T["step.idxs"]])]
+    monkeypatch.setattr(torch, "randint", lambda n, size, **k: torch.as_tensor(T[case + ".idxs"]))
+    monkeypatch.setattr(mod, "shuffle_rows", lambda arr: tables.pop(0))
+    f32 = lambda k: torch.as_tensor(T[k][:rows], dtype=torch.float32)
+    mpc.train(f32("data.s"), f32("data.a"), random=True, next_obs=f32("data.s2"), epochs=epochs)
+
+
+def test_one_reference_optimiser_step(G, T, monkeypatch):
+    """MPC.py:250-298: loss, gradients and post-step parameters of the reference's first batch-32 step."""
+    mpc = cpu_controller(G)
+    losses = []
+    real = torch.Tensor.backward
+    monkeypatch.setattr(torch.Tensor, "backward", lambda self, *a, **k: (losses.append(float(self.detach())), real(self, *a, **k))[1])
+    run_train_with_tables(mpc, monkeypatch, T, "step", 32, 1)
+    assert np.allclose(mpc.model.inputs_mu.numpy(), T["step.mu"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(mpc.model.inputs_sigma.numpy(), T["step.sigma"], rtol=1e-6, atol=1e-6)
+    assert len(losses) == 1 and np.isclose(losses[0], float(T["step.loss"]), rtol=1e-5)
+    for name in TRAIN_PARAMS:
+        p = getattr(mpc.model, name)
+        g, want = golden_view(T, name, p.grad.numpy()), T["step.grad." + name]
+        assert np.abs(g - want).max() <= 1e-4 * np.abs(want).max() + 1e-9, name
+        post, want = golden_view(T, name, p.detach().numpy()), T["step.post." + name]
+        # first Adam step = -lr * sign(g): entries whose gradient is ~0 may land on either side
+        assert np.mean(np.abs(post - want) > 1e-6) < 1e-3, name
+
+
+def test_reference_training_run_two_epochs(G, T, monkeypatch):
+    """14 optimiser steps (2 epochs over 200 rows, last batch of an epoch = 8 rows) with the reference's bootstrap
+    table and shuffles: per-step losses and the trained parameters."""
+    mpc = cpu_controller(G)
+    losses = []
+    real = torch.Tensor.backward
+    monkeypatch.setattr(torch.Tensor, "backward", lambda self, *a, **k: (losses.append(float(self.detach())), real(self, *a, **k))[1])
+    run_train_with_tables(mpc, monkeypatch, T, "train", 200, 2)
+    assert np.allclose(mpc.train_in.numpy(), T["train.train_in"]) and np.allclose(mpc.train_targs.numpy(),
+                                                                                T["train.train_targs"], atol=1e-5)
+    assert np.allclose(losses, T["train.losses"], rtol=2e-4, atol=2e-4)
+    for name in TRAIN_PARAMS:
+        post, want = golden_view(T, name, getattr(mpc.model, name).detach().numpy()), T["train.post." + name]
+        assert np.abs(post - want).max() < 2e-4, (name, np.abs(post - want).max())       # 0.2 lr
