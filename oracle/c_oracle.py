@@ -36,6 +36,10 @@ def lib():
         _lib.rrl_oracle_uniform01.argtypes = [C.c_uint64]
         _lib.rrl_oracle_nav_offline.restype = C.c_int64
         _lib.rrl_oracle_maze_offline.restype = C.c_int64
+        _lib.rrl_oracle_nav_offline_explicit.restype = C.c_int64
+        _lib.rrl_oracle_maze_offline_explicit.restype = C.c_int64
+        _lib.rrl_oracle_maze_distance.restype = C.c_double
+        _lib.rrl_oracle_maze_distance.argtypes = [C.c_double, C.c_double]
     return _lib
 
 
@@ -125,6 +129,71 @@ def nav_offline(env_name, num_transitions, seed):
                                      C.c_int64(cap))
     assert w >= 0, w
     return s[:w], a[:w], c[:w], s2[:w], m[:w]
+
+
+class Draws(C.Structure):
+    """rrl_oracle_draws: uniforms / standard normals in the reference's np.random call order."""
+    _fields_ = [("u", C.c_void_p), ("n_u", C.c_int64), ("i_u", C.c_int64), ("z", C.c_void_p), ("n_z", C.c_int64),
+                ("i_z", C.c_int64), ("exhausted", C.c_int)]
+
+    def __init__(self, u=(), z=()):
+        self._u = np.ascontiguousarray(u, dtype=np.float64)
+        self._z = np.ascontiguousarray(z, dtype=np.float64)
+        super().__init__(self._u.ctypes.data, len(self._u), 0, self._z.ctypes.data, len(self._z), 0, 0)
+
+
+def _offline_out(cap):
+    f32 = lambda *sh: np.zeros(sh, np.float32)
+    f64 = lambda *sh: np.zeros(sh, np.float64)
+    return (f32(cap, 2), f32(cap, 2), f32(cap), f32(cap, 2), f32(cap)), (f64(cap, 2), f64(cap, 2), f64(cap, 2))
+
+
+def nav_offline_explicit(env_name, num_transitions, u, z):
+    """The offline-data generator fed explicit draws -> (f32 rows, f64 rows (s, a, s2), draws consumed)."""
+    cap = 10 * (num_transitions // 10 // 3 + 4 * (num_transitions // 10 // 4) + num_transitions // 10) + 16
+    (s, a, c, s2, m), (s64, a64, s2_64) = _offline_out(cap)
+    d = Draws(u, z)
+    w = lib().rrl_oracle_nav_offline_explicit(ENV_KIND[env_name], C.c_int64(num_transitions), C.byref(d), _p(s),
+                                              _p(a), _p(c), _p(s2), _p(m), _p(s64), _p(a64), _p(s2_64),
+                                              C.c_int64(cap))
+    assert w >= 0, w
+    return (s[:w], a[:w], c[:w], s2[:w], m[:w]), (s64[:w], a64[:w], s2_64[:w]), (d.i_u, d.i_z)
+
+
+def maze_offline_explicit(num_transitions, u, rand_actions):
+    cap = max(2 * (num_transitions // 2), 1)
+    (s, a, c, s2, m), (s64, a64, s2_64) = _offline_out(cap)
+    d = Draws(u)
+    ra = np.ascontiguousarray(rand_actions, dtype=np.float32)
+    assert ra.shape == (num_transitions // 2, 2)
+    w = lib().rrl_oracle_maze_offline_explicit(C.c_int64(num_transitions), C.byref(d), _p(ra), _p(s), _p(a), _p(c),
+                                               _p(s2), _p(m), _p(s64), _p(a64), _p(s2_64), C.c_int64(cap))
+    assert w >= 0, w
+    return (s[:w], a[:w], c[:w], s2[:w], m[:w]), (s64[:w], a64[:w], s2_64[:w]), d.i_u
+
+
+def maze_reset_explicit(mode, check_constraint, u):
+    """One reset from explicit uniforms -> (x, y, uniforms consumed)."""
+    d = Draws(u)
+    x, y = C.c_double(), C.c_double()
+    rc = lib().rrl_oracle_maze_reset_explicit(C.c_int(mode), C.c_int(int(check_constraint)), C.byref(d),
+                                              C.byref(x), C.byref(y))
+    assert rc == 0, rc
+    return x.value, y.value, d.i_u
+
+
+def maze_step64(x, y, ax, ay, steps, horizon=100):
+    """One env step with a float64 action -> dict (env/maze.py:139-168)."""
+    cx, cy, st = C.c_double(x), C.c_double(y), C.c_int32(steps)
+    rew, dn, cons, succ = C.c_double(), C.c_int(), C.c_int(), C.c_int()
+    lib().rrl_oracle_maze_step64(C.byref(cx), C.byref(cy), C.c_double(ax), C.c_double(ay), C.byref(st),
+                                 C.c_int32(horizon), C.byref(rew), C.byref(dn), C.byref(cons), C.byref(succ))
+    return dict(x=cx.value, y=cy.value, steps=st.value, reward=rew.value, done=dn.value, constraint=cons.value,
+                success=succ.value)
+
+
+def maze_distance(x, y):
+    return float(lib().rrl_oracle_maze_distance(C.c_double(x), C.c_double(y)))
 
 
 def maze_contact(x, y):

@@ -252,10 +252,31 @@ int rrl_oracle_nav_rollout(int env_kind, int64_t n, int32_t T, double* pos,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Draw sources.  The generators below take their random numbers either from Philox, keyed by
+ * (rollout, slot) so that every rollout is independent (what the HIP kernels do), or -- for the
+ * parity tests -- from two flat arrays holding the uniforms and the standard normals in the
+ * order the REFERENCE calls np.random.uniform / np.random.randn.  With the reference's own
+ * draws injected the same control flow must reproduce the reference's rows bit-for-bit
+ * (tests/golden/nav_offline_golden.npz, maze_ref_golden.npz).
+ * ---------------------------------------------------------------------------------------- */
+static double take_u(rrl_oracle_draws* d)
+{
+    if (d->i_u >= d->n_u) { d->exhausted = 1; return 0.5; }
+    return d->u[d->i_u++];
+}
+
+static double take_z(rrl_oracle_draws* d)
+{
+    if (d->i_z >= d->n_z) { d->exhausted = 1; return 0.0; }
+    return d->z[d->i_z++];
+}
+
+/* ------------------------------------------------------------------------------------------
  * Offline constraint data (env/navigation1.py:133-164, env/navigation2.py:133-243).
- * Rollout i draws from Philox(seed; i, OFFLINE, k, hi): k=0 start uniforms, k=1 second start
- * uniforms, per step j: k=2+3j action normals, 3+3j action uniforms, 4+3j noise normals;
- * hi=1+r is the r-th start re-draw of the nav2 phase-0 rejection loop.
+ * Philox mode: rollout i draws from Philox(seed; i, OFFLINE, k, hi): k=0 start uniforms, k=1
+ * second start uniforms, per step j: k=2+3j action normals, 3+3j action uniforms, 4+3j noise
+ * normals; hi=1+r is the r-th start re-draw of the nav2 phase-0 rejection loop.
+ * np.random.uniform(lo, hi) = lo + (hi - lo) * u; every (hi - lo) below is exact in double.
  * ---------------------------------------------------------------------------------------- */
 static void offline_uniform2(uint64_t seed, uint32_t i, uint64_t k, uint32_t hi, double u[2])
 {
@@ -271,9 +292,9 @@ static int nav2_phase(int64_t i, int64_t n0, int64_t n1)
     return 1 + (int)((i - n0) / (n1 > 0 ? n1 : 1));
 }
 
-int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed,
-                               float* s, float* a, float* c, float* s2, float* m,
-                               int64_t capacity)
+static int64_t nav_offline_core(int env_kind, int64_t num_transitions, uint64_t seed,
+                                rrl_oracle_draws* d, float* s, float* a, float* c, float* s2,
+                                float* m, double* s64, double* a64, double* s2_64, int64_t capacity)
 {
     int64_t n_roll, n0 = 0, n1 = 0;
     if (env_kind == RRL_ENV_NAV1) n_roll = num_transitions / 10;
@@ -286,20 +307,28 @@ int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t s
     for (int64_t i = 0; i < n_roll; ++i) {
         double u[2], v[2], x, y;
         int phase = 0;
-        offline_uniform2(seed, (uint32_t)i, 0, 0, u);
-        offline_uniform2(seed, (uint32_t)i, 1, 0, v);
         if (env_kind == RRL_ENV_NAV1) {                   /* navigation1.py:140-147 */
-            x = -80.0 + 130.0 * u[1];
-            y = (u[0] < 0.5) ? (-5.0 + 3.0 * v[0]) : (2.0 + 3.0 * v[0]);
+            double coin, ux, uy;
+            if (d) { coin = take_u(d); ux = take_u(d); uy = take_u(d); }
+            else {
+                offline_uniform2(seed, (uint32_t)i, 0, 0, u);
+                offline_uniform2(seed, (uint32_t)i, 1, 0, v);
+                coin = u[0]; ux = u[1]; uy = v[0];
+            }
+            x = -80.0 + 130.0 * ux;
+            y = (coin < 0.5) ? (-5.0 + 3.0 * uy) : (2.0 + 3.0 * uy);
         } else {
             phase = nav2_phase(i, n0, n1);
+            if (d) { u[0] = take_u(d); u[1] = take_u(d); }
+            else offline_uniform2(seed, (uint32_t)i, 0, 0, u);
             switch (phase) {
                 case 0: {                                  /* navigation2.py:140-146 */
                     x = -40.0 + 50.0 * u[0]; y = -25.0 + 50.0 * u[1];
                     uint32_t r = 0;
                     while (rrl_oracle_obstacle(env_kind, x, y)) {
                         double q[2];
-                        offline_uniform2(seed, (uint32_t)i, 0, 1 + r, q);
+                        if (d) { q[0] = take_u(d); q[1] = take_u(d); if (d->exhausted) return -3; }
+                        else offline_uniform2(seed, (uint32_t)i, 0, 1 + r, q);
                         x = -40.0 + 50.0 * q[0]; y = -25.0 + 50.0 * q[1];
                         ++r;
                     }
@@ -313,9 +342,19 @@ int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t s
         }
         for (int j = 0; j < 10; ++j) {
             double z[2], q[2], e[2], ax, ay;
-            rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_OFFLINE, (uint64_t)(2 + 3 * j), z);
-            offline_uniform2(seed, (uint32_t)i, (uint64_t)(3 + 3 * j), 0, q);
-            rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_OFFLINE, (uint64_t)(4 + 3 * j), e);
+            if (d) {                                       /* the reference's call order */
+                q[0] = 0.0; e[0] = e[1] = 0.0;
+                switch (phase) {
+                    case 1: case 2: q[0] = take_u(d); z[0] = 0.0; z[1] = take_z(d); break;   /* U(.,.,1), randn(1) */
+                    case 3: case 4: z[0] = take_z(d); z[1] = 0.0; q[0] = take_u(d); break;   /* randn(1), U(.,.,1) */
+                    default: z[0] = take_z(d); z[1] = take_z(d); break;                      /* randn(2) */
+                }
+                if (!rrl_oracle_obstacle(env_kind, x, y)) { e[0] = take_z(d); e[1] = take_z(d); }  /* _next_state :100-104 */
+            } else {
+                rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_OFFLINE, (uint64_t)(2 + 3 * j), z);
+                offline_uniform2(seed, (uint32_t)i, (uint64_t)(3 + 3 * j), 0, q);
+                rrl_oracle_normal2(seed, (uint32_t)i, RRL_STREAM_OFFLINE, (uint64_t)(4 + 3 * j), e);
+            }
             ax = clip1(z[0], -1.0, 1.0); ay = clip1(z[1], -1.0, 1.0);
             switch (phase) {                               /* navigation2.py:166-168,186-188,206-208,226-228 */
                 case 1: ax = 0.5 + 0.5 * q[0]; break;
@@ -324,35 +363,54 @@ int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t s
                 case 4: ay = 0.5 + 0.5 * q[0]; break;
                 default: break;
             }
-            float axf = (float)ax, ayf = (float)ay;        /* replay rows are f32; keep (s,a,s') consistent */
-            double nx, ny, cost;
-            nav_transition(env_kind, x, y, (double)axf, (double)ayf, e[0], e[1], &nx, &ny, &cost);
+            double nx, ny, cost;                           /* the transition uses the float64 action, as the reference */
+            nav_transition(env_kind, x, y, ax, ay, e[0], e[1], &nx, &ny, &cost);
             int cons = rrl_oracle_obstacle(env_kind, nx, ny);
             if (w >= capacity) return -2;
             s[2 * w] = (float)x; s[2 * w + 1] = (float)y;
-            a[2 * w] = axf; a[2 * w + 1] = ayf;
+            a[2 * w] = (float)ax; a[2 * w + 1] = (float)ay;
             c[w] = (float)cons;
             s2[2 * w] = (float)nx; s2[2 * w + 1] = (float)ny;
             m[w] = (float)(!cons);                         /* (state, action, constraint, next_state, not constraint) */
+            if (s64) { s64[2 * w] = x; s64[2 * w + 1] = y; }
+            if (a64) { a64[2 * w] = ax; a64[2 * w + 1] = ay; }
+            if (s2_64) { s2_64[2 * w] = nx; s2_64[2 * w + 1] = ny; }
             ++w;
             x = nx; y = ny;
             if (cons) break;
         }
     }
+    if (d && d->exhausted) return -3;
     return w;
 }
 
+int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed,
+                               float* s, float* a, float* c, float* s2, float* m,
+                               int64_t capacity)
+{
+    return nav_offline_core(env_kind, num_transitions, seed, NULL, s, a, c, s2, m, NULL, NULL, NULL, capacity);
+}
+
+int64_t rrl_oracle_nav_offline_explicit(int env_kind, int64_t num_transitions, rrl_oracle_draws* draws,
+                                        float* s, float* a, float* c, float* s2, float* m,
+                                        double* s64, double* a64, double* s2_64, int64_t capacity)
+{
+    return nav_offline_core(env_kind, num_transitions, 0, draws, s, a, c, s2, m, s64, a64, s2_64, capacity);
+}
+
 /* ------------------------------------------------------------------------------------------
- * Maze (env/maze.py:139-232, env/assets/simple_maze.xml).  PARITY UNPINNED: the reference steps
- * MuJoCo 1.50 (mujoco_py==1.50.1.68, install.sh:13), a third-party binary absent from the
- * reference tree and from this image.  Control flow, reward, termination, reset ranges, wall
- * placement and the expert follow env/maze.py line by line; the physics is replaced by the
- * kinematic surrogate documented in DESIGN.md section 6:
+ * Maze (env/maze.py:34-232, env/assets/simple_maze.xml).  The reference steps MuJoCo 1.50
+ * (mujoco_py==1.50.1.68, install.sh:13), a third-party binary absent from the reference tree
+ * and from this image, so the PHYSICS is a documented kinematic surrogate:
  *   - point cylinder r = 0.025 on two slide joints; motor gear 0.05, joint damping 0.01,
  *     mass 1000 * pi r^2 h = 0.09817 kg, 500 semi-implicit Euler steps of dt = 0.002 from rest
  *     => straight-line displacement MAZE_GAIN * a per env step (a in [-0.1, 0.1]);
  *   - contact (ncon > 3) <=> the disc touches a wall rectangle or an arena plane;
  *   - the disc stops at the first of 64 equal sub-steps that is in contact.
+ * Everything AROUND the physics -- step / reset / expert / distance / offline-data control flow,
+ * reward, termination, reset ranges, wall moves -- is PINNED to env/maze.py itself: the
+ * reference module is imported over a stand-in MjSim implementing exactly this surrogate
+ * (tests/golden/gen_maze_ref_golden.py) and its outputs are the golden vectors.
  * ---------------------------------------------------------------------------------------- */
 #define MAZE_GAIN 0.24667750873451577   /* metres per unit control per env step */
 #define MAZE_R 0.025                    /* toolgeom size, simple_maze.xml:28 */
@@ -366,7 +424,8 @@ int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t s
 /* wall rectangles {cx, cy, half x, half y} after reset() moves them (env/maze.py:199-206):
  * geoms 5..8 = wall1A, wall2A, wall1B, wall2B; y centres 0.5-0.08, 0.4+0.08, -0.25-0.08, -0.25+0.08 */
 static const double MAZE_WALLS[4][4] = {
-    {-0.1, 0.42, 0.005, 0.2}, {0.1, 0.48, 0.005, 0.2}, {-0.1, -0.33, 0.005, 0.2}, {0.1, -0.17, 0.005, 0.2}};
+    {-0.1, 0.5 + -0.08, 0.005, 0.2}, {0.1, 0.4 + 0.08, 0.005, 0.2},
+    {-0.1, -0.25 + -0.08, 0.005, 0.2}, {0.1, -0.25 + 0.08, 0.005, 0.2}};
 
 int rrl_oracle_maze_contact(double x, double y)
 {
@@ -388,6 +447,8 @@ static double maze_dist(double x, double y)
     return sqrt((ex * ex + ey * ey) / 2.0);
 }
 
+double rrl_oracle_maze_distance(double x, double y) { return maze_dist(x, y); }
+
 static void maze_move(double* x, double* y, double ax, double ay)
 {   /* env/maze.py:141-147: no motion when already in contact, else 500 sim steps */
     ax = clip1(ax, -MAZE_MAX_FORCE, MAZE_MAX_FORCE);
@@ -403,21 +464,32 @@ static void maze_move(double* x, double* y, double ax, double ay)
     *x = qx; *y = qy;
 }
 
+/* reset ranges (env/maze.py:188-196), np.random.uniform(lo, hi) = lo + (hi - lo) * u with the
+ * difference taken in double, as numpy does (0.22 - 0.14 is not the double nearest to 0.08) */
+static void maze_reset_xy(int mode, double u0, double u1, double* x, double* y)
+{
+    switch (mode) {
+        case 1: *x = 0.14 + (0.22 - 0.14) * u0; break;       /* 'e' :191 */
+        case 2: *x = -0.04 + (0.04 - -0.04) * u0; break;     /* 'm' :193 */
+        case 3: *x = -0.27 + (0.27 - -0.27) * u0; break;     /* None :189 */
+        default: *x = -0.22 + (-0.13 - -0.22) * u0; break;   /* 'h' :195 */
+    }
+    *y = -0.22 + (0.22 - -0.22) * u1;                        /* :196 */
+}
+
 static void maze_reset_one(uint64_t seed, uint32_t i, uint64_t counter, int mode, int check,
-                           double* x, double* y)
-{   /* env/maze.py:184-213: redraw while in contact (recursion at :209-211) */
+                           rrl_oracle_draws* d, double* x, double* y)
+{   /* env/maze.py:184-213: redraw while in contact (recursion at :209-211, always with the contact check) */
     for (uint32_t r = 0;; ++r) {
-        uint64_t b0, b1;
-        philox_bits(seed, i, RRL_STREAM_RESET, counter | ((uint64_t)r << 48), &b0, &b1);
-        double u0 = rrl_oracle_uniform01(b0), u1 = rrl_oracle_uniform01(b1);
-        switch (mode) {
-            case 1: *x = 0.14 + 0.08 * u0; break;            /* 'e' :191 */
-            case 2: *x = -0.04 + 0.08 * u0; break;           /* 'm' :193 */
-            case 3: *x = -0.27 + 0.54 * u0; break;           /* None :189 */
-            default: *x = -0.22 + 0.09 * u0; break;          /* 'h' :195 */
+        double u0, u1;
+        if (d) { u0 = take_u(d); u1 = take_u(d); }
+        else {
+            uint64_t b0, b1;
+            philox_bits(seed, i, RRL_STREAM_RESET, counter | ((uint64_t)r << 48), &b0, &b1);
+            u0 = rrl_oracle_uniform01(b0); u1 = rrl_oracle_uniform01(b1);
         }
-        *y = -0.22 + 0.44 * u1;                              /* :196 */
-        if (!check || !rrl_oracle_maze_contact(*x, *y) || r >= 1000) return;
+        maze_reset_xy(mode, u0, u1, x, y);
+        if (!check || !rrl_oracle_maze_contact(*x, *y) || r >= 1000 || (d && d->exhausted)) return;
     }
 }
 
@@ -443,7 +515,7 @@ int rrl_oracle_maze_step(int64_t n, double* pos, const float* action, uint64_t s
         done[i] = (uint8_t)dn; constraint[i] = (uint8_t)cons; success[i] = (uint8_t)succ;
         if (ep_done) ep_done[i] = (uint8_t)epd;
         if (auto_reset && epd) {
-            maze_reset_one(seed, (uint32_t)i, counter, 0, 1, &x, &y);
+            maze_reset_one(seed, (uint32_t)i, counter, 0, 1, NULL, &x, &y);
             ti = 0;
         }
         pos[2 * i] = x; pos[2 * i + 1] = y;
@@ -453,17 +525,38 @@ int rrl_oracle_maze_step(int64_t n, double* pos, const float* action, uint64_t s
     return 0;
 }
 
+/* one env step with a float64 action (the reference passes float64 arrays to step(), env/maze.py:139-168) */
+int rrl_oracle_maze_step64(double* x, double* y, double ax, double ay, int32_t* steps, int32_t horizon,
+                           double* reward, int* done, int* constraint, int* success)
+{
+    maze_move(x, y, ax, ay);
+    *steps += 1;
+    *constraint = rrl_oracle_maze_contact(*x, *y);
+    double d = maze_dist(*x, *y);
+    *done = (*steps >= horizon) || *constraint || (d < MAZE_GOAL_THRESH);
+    *reward = -d;
+    *success = *reward > -0.03;
+    return 0;
+}
+
 int rrl_oracle_maze_reset(int64_t n, double* pos, float* obs, int32_t* t, int mode,
                           int check_constraint, uint64_t seed, uint64_t counter)
 {
     for (int64_t i = 0; i < n; ++i) {
         double x, y;
-        maze_reset_one(seed, (uint32_t)i, counter, mode, check_constraint, &x, &y);
+        maze_reset_one(seed, (uint32_t)i, counter, mode, check_constraint, NULL, &x, &y);
         pos[2 * i] = x; pos[2 * i + 1] = y;
         if (t) t[i] = 0;
         if (obs) { obs[2 * i] = (float)x; obs[2 * i + 1] = (float)y; }
     }
     return 0;
+}
+
+/* one reset from explicit uniforms (two per attempt, env/maze.py:188-196 order: x then y) */
+int rrl_oracle_maze_reset_explicit(int mode, int check_constraint, rrl_oracle_draws* draws, double* x, double* y)
+{
+    maze_reset_one(0, 0, 0, mode, check_constraint, draws, x, y);
+    return draws->exhausted ? -3 : 0;
 }
 
 void rrl_oracle_maze_expert_action(double x, double y, double act[2])
@@ -476,10 +569,14 @@ void rrl_oracle_maze_expert_action(double x, double y, double act[2])
     act[1] = 1.05 * (ty - y);
 }
 
-int64_t rrl_oracle_maze_offline(int64_t num_transitions, uint64_t seed, float* s, float* a, float* c,
-                                float* s2, float* m, int64_t capacity)
-{   /* env/maze.py:34-107: half random, half expert actions; reset (no contact check) every 20
-     * steps with mode e/m/h drawn 30/30/40 %; rows (state, raw action, constraint, next, not done) */
+/* env/maze.py:34-107: half random, half expert actions; reset (no contact check) every 20
+ * steps with mode e/m/h drawn 30/30/40 %; rows (state, raw action, constraint, next, not done).
+ * The random actions are env.action_space.sample() (float32, gym's own generator): explicit mode
+ * takes them from `rand_actions` [half, 2]; the expert action stays float64 into step(). */
+static int64_t maze_offline_core(int64_t num_transitions, uint64_t seed, rrl_oracle_draws* d,
+                                 const float* rand_actions, float* s, float* a, float* c, float* s2,
+                                 float* m, double* s64, double* a64, double* s2_64, int64_t capacity)
+{
     int64_t half = num_transitions / 2;
     if (2 * half > capacity) return -2;
     int64_t w = 0;
@@ -488,37 +585,60 @@ int64_t rrl_oracle_maze_offline(int64_t num_transitions, uint64_t seed, float* s
         for (int64_t g = 0; g < n_seg; ++g) {
             uint32_t row = (uint32_t)(part * n_seg + g);
             uint64_t b0, b1;
-            philox_bits(seed, row, RRL_STREAM_OFFLINE, 0, &b0, &b1);
-            double sample = rrl_oracle_uniform01(b0);
+            double sample;
+            if (d) sample = take_u(d);
+            else {
+                philox_bits(seed, row, RRL_STREAM_OFFLINE, 0, &b0, &b1);
+                sample = rrl_oracle_uniform01(b0);
+            }
             int mode = sample < 0.3 ? 1 : (sample < 0.6 ? 2 : 0);      /* :45-51 */
             double x, y;
-            maze_reset_one(seed, row, 1ULL << 40, mode, 0, &x, &y);
+            maze_reset_one(seed, row, 1ULL << 40, mode, 0, d, &x, &y);
             int32_t steps = 0;
             int64_t len = (g == n_seg - 1) ? half - 20 * g : 20;
             for (int64_t j = 0; j < len; ++j) {
                 double act[2];
                 if (part == 0) {                                       /* action_space.sample() :58 */
-                    philox_bits(seed, row, RRL_STREAM_OFFLINE, (uint64_t)(1 + j), &b0, &b1);
-                    act[0] = -0.1 + 0.2 * rrl_oracle_uniform01(b0);
-                    act[1] = -0.1 + 0.2 * rrl_oracle_uniform01(b1);
+                    if (rand_actions) {
+                        act[0] = (double)rand_actions[2 * (20 * g + j)];
+                        act[1] = (double)rand_actions[2 * (20 * g + j) + 1];
+                    } else {
+                        philox_bits(seed, row, RRL_STREAM_OFFLINE, (uint64_t)(1 + j), &b0, &b1);
+                        act[0] = (double)(float)(-0.1 + 0.2 * rrl_oracle_uniform01(b0));
+                        act[1] = (double)(float)(-0.1 + 0.2 * rrl_oracle_uniform01(b1));
+                    }
                 } else rrl_oracle_maze_expert_action(x, y, act);       /* :88 */
-                float axf = (float)act[0], ayf = (float)act[1];
-                double nx = x, ny = y;
-                maze_move(&nx, &ny, (double)axf, (double)ayf);
-                steps += 1;
-                int cons = rrl_oracle_maze_contact(nx, ny);
-                int dn = (steps >= 100) || cons || (maze_dist(nx, ny) < MAZE_GOAL_THRESH);
+                double nx = x, ny = y, rew;
+                int dn, cons, succ;
+                rrl_oracle_maze_step64(&nx, &ny, act[0], act[1], &steps, 100, &rew, &dn, &cons, &succ);
                 s[2 * w] = (float)x; s[2 * w + 1] = (float)y;
-                a[2 * w] = axf; a[2 * w + 1] = ayf;
+                a[2 * w] = (float)act[0]; a[2 * w + 1] = (float)act[1];
                 c[w] = (float)cons;
                 s2[2 * w] = (float)nx; s2[2 * w + 1] = (float)ny;
                 m[w] = (float)(!dn);
+                if (s64) { s64[2 * w] = x; s64[2 * w + 1] = y; }
+                if (a64) { a64[2 * w] = act[0]; a64[2 * w + 1] = act[1]; }
+                if (s2_64) { s2_64[2 * w] = nx; s2_64[2 * w + 1] = ny; }
                 ++w;
                 x = nx; y = ny;
             }
         }
     }
+    if (d && d->exhausted) return -3;
     return w;
+}
+
+int64_t rrl_oracle_maze_offline(int64_t num_transitions, uint64_t seed, float* s, float* a, float* c,
+                                float* s2, float* m, int64_t capacity)
+{
+    return maze_offline_core(num_transitions, seed, NULL, NULL, s, a, c, s2, m, NULL, NULL, NULL, capacity);
+}
+
+int64_t rrl_oracle_maze_offline_explicit(int64_t num_transitions, rrl_oracle_draws* draws, const float* rand_actions,
+                                         float* s, float* a, float* c, float* s2, float* m, double* s64,
+                                         double* a64, double* s2_64, int64_t capacity)
+{
+    return maze_offline_core(num_transitions, 0, draws, rand_actions, s, a, c, s2, m, s64, a64, s2_64, capacity);
 }
 
 /* ------------------------------------------------------------------------------------------

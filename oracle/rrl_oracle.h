@@ -13,8 +13,10 @@
  *   replay push / sample / stratified sample           : PINNED on composition + ring
  *       semantics against tests/golden/replay_golden.npz (index streams cannot match:
  *       the reference uses python `random`).
- *   maze                                                : PARITY UNPINNED (MuJoCo 1.50 is a
- *       third-party dependency absent from the reference tree and this image).
+ *   maze                                                : control flow PINNED to env/maze.py:34-232 (the
+ *       reference module imported over a stand-in MjSim, tests/golden/gen_maze_ref_golden.py ->
+ *       maze_ref_golden.npz); the PHYSICS is a documented surrogate (MuJoCo 1.50 is a third-party
+ *       dependency absent from the reference tree and this image): trajectories are not MuJoCo's.
  *
  * Every function cites the reference file:line it follows.
  */
@@ -47,6 +49,14 @@ void rrl_oracle_normal2(uint64_t seed, uint32_t idx, uint32_t stream, uint64_t c
                         double z[2]);
 double rrl_oracle_uniform01(uint64_t bits);
 
+/* explicit draw source for the parity tests: uniforms in [0,1) and standard normals in the order the reference
+ * calls np.random.uniform / np.random.randn (np.random.uniform(lo, hi) = lo + (hi - lo) * u) */
+typedef struct {
+    const double* u; int64_t n_u; int64_t i_u;
+    const double* z; int64_t n_z; int64_t i_z;
+    int exhausted;
+} rrl_oracle_draws;
+
 /* ---- navigation1 / navigation2 (env/navigation1.py, env/navigation2.py) ---- */
 int rrl_oracle_obstacle(int env_kind, double x, double y);
 
@@ -73,8 +83,21 @@ int64_t rrl_oracle_nav_offline(int env_kind, int64_t num_transitions, uint64_t s
                                float* s, float* a, float* c, float* s2, float* m,
                                int64_t capacity);
 
-/* ---- maze (env/maze.py; kinematic surrogate of the MuJoCo model, PARITY UNPINNED) ---- */
+/* the same generator fed the reference's own draws; also returns the float64 rows the reference holds */
+int64_t rrl_oracle_nav_offline_explicit(int env_kind, int64_t num_transitions, rrl_oracle_draws* draws,
+                                        float* s, float* a, float* c, float* s2, float* m,
+                                        double* s64, double* a64, double* s2_64, int64_t capacity);
+
+/* ---- maze (env/maze.py).  Control flow pinned to env/maze.py:34-232 (reference imported over a stand-in MjSim);
+ * the physics is the documented kinematic surrogate of the MuJoCo model ---- */
 int rrl_oracle_maze_contact(double x, double y);
+double rrl_oracle_maze_distance(double x, double y);
+int rrl_oracle_maze_step64(double* x, double* y, double ax, double ay, int32_t* steps, int32_t horizon,
+                           double* reward, int* done, int* constraint, int* success);
+int rrl_oracle_maze_reset_explicit(int mode, int check_constraint, rrl_oracle_draws* draws, double* x, double* y);
+int64_t rrl_oracle_maze_offline_explicit(int64_t num_transitions, rrl_oracle_draws* draws, const float* rand_actions,
+                                         float* s, float* a, float* c, float* s2, float* m, double* s64,
+                                         double* a64, double* s2_64, int64_t capacity);
 int rrl_oracle_maze_step(int64_t n, double* pos, const float* action, uint64_t seed, uint64_t counter,
                          float* next_obs, float* obs, float* reward, uint8_t* done,
                          uint8_t* constraint, uint8_t* success, uint8_t* ep_done, int32_t* t,

@@ -9,6 +9,10 @@
 
 #pragma clang fp contract(off)
 
+// the geometry below is plain IEEE-double C++: it also compiles for the host, where tests/test_maze_host_geometry.py
+// runs it against the CPU checker's sequential scan (no GPU needed)
+#define RRL_HD __host__ __device__ __forceinline__
+
 namespace rrl_maze {
 
 constexpr double kGain = 0.24667750873451577;  // m per unit control per env step (500 x 2 ms from rest)
@@ -19,72 +23,136 @@ constexpr double kGoalX = 0.25, kGoalY = 0.0;  // env/maze.py:135-137
 constexpr double kGoalThresh = 0.03;           // env/maze.py:19
 constexpr int kSubsteps = 64;
 
-__device__ __forceinline__ bool touches_wall(double x, double y, double cx, double cy) {
-    double dx = fabs(x - cx) - 0.005, dy = fabs(y - cy) - 0.2;  // half sizes, simple_maze.xml:22-25
+// wall rectangles after reset() moved them (env/maze.py:199-206; geoms 5..8 = wall1A, wall2A, wall1B, wall2B):
+// y centres 0.5 + w1, 0.4 + w2, -0.25 + w1, -0.25 + w2 with w1 = -0.08, w2 = 0.08 -- the sums as the reference forms them
+// (0.4 + 0.08 is not the double nearest to 0.48); half sizes 0.005 x 0.2 (simple_maze.xml:22-25)
+constexpr double kWallHX = 0.005, kWallHY = 0.2;
+RRL_HD double wall_x(int j) { return (j & 1) ? 0.1 : -0.1; }
+RRL_HD double wall_y(int j) {
+    return j == 0 ? 0.5 + -0.08 : (j == 1 ? 0.4 + 0.08 : (j == 2 ? -0.25 + -0.08 : -0.25 + 0.08));
+}
+
+RRL_HD bool touches_wall(double x, double y, double cx, double cy) {
+    double dx = fabs(x - cx) - kWallHX, dy = fabs(y - cy) - kWallHY;
     dx = dx < 0.0 ? 0.0 : dx;
     dy = dy < 0.0 ? 0.0 : dy;
     return dx * dx + dy * dy <= kRadius * kRadius;
 }
 
-// ncon > 3  <=>  the disc touches an arena plane or one of the four walls (env/maze.py:199-206)
-__device__ __forceinline__ bool in_contact(double x, double y) {
-    const bool plane = (kLim - x <= kRadius) | (x + kLim <= kRadius) | (kLim - y <= kRadius) |
-                       (y + kLim <= kRadius);
-    return plane | touches_wall(x, y, -0.1, 0.42) | touches_wall(x, y, 0.1, 0.48) |
-           touches_wall(x, y, -0.1, -0.33) | touches_wall(x, y, 0.1, -0.17);
+RRL_HD bool touches_plane(double x, double y) {
+    return (kLim - x <= kRadius) | (x + kLim <= kRadius) | (kLim - y <= kRadius) | (y + kLim <= kRadius);
 }
 
-__device__ __forceinline__ double clampd(double v, double lo, double hi) {
+// ncon > 3  <=>  the disc touches an arena plane or one of the four walls
+RRL_HD bool in_contact(double x, double y) {
+    return touches_plane(x, y) | touches_wall(x, y, wall_x(0), wall_y(0)) | touches_wall(x, y, wall_x(1), wall_y(1)) |
+           touches_wall(x, y, wall_x(2), wall_y(2)) | touches_wall(x, y, wall_x(3), wall_y(3));
+}
+
+RRL_HD double clampd(double v, double lo, double hi) {
     return v < lo ? lo : (v > hi ? hi : v);
 }
 
-__device__ __forceinline__ double goal_distance(double x, double y) {
+RRL_HD double goal_distance(double x, double y) {
     const double ex = kGoalX - x, ey = kGoalY - y;
     return sqrt((ex * ex + ey * ey) / 2.0);  // sqrt(mean(sq)), env/maze.py:219
 }
 
-__device__ __forceinline__ void move(double& x, double& y, double ax, double ay) {
+// Sub-step k of the move (k = 1..64): the position the sequential scan of the specification visits
+RRL_HD void substep_pos(double x, double y, double dx, double dy, int k, double& px, double& py) {
+    const double f = double(k) * (1.0 / kSubsteps);
+    px = clampd(x + dx * f, -kLim, kLim);
+    py = clampd(y + dy * f, -kLim, kLim);
+}
+
+// Entry parameter (in sub-steps, may be < 0 or > 64) of the segment p + t d, t in [0, 64], into the slab |v - c| <= h
+// of one coordinate; lo/hi = the parameter interval inside the slab.
+RRL_HD void slab_interval(double p, double d, double c, double h, double& lo, double& hi) {
+    const double a = (c - h) - p, b = (c + h) - p;
+    if (d == 0.0) {
+        const bool inside = (a <= 0.0) & (b >= 0.0);
+        lo = inside ? -1e300 : 1e300;
+        hi = inside ? 1e300 : -1e300;
+        return;
+    }
+    const double t0 = a / d, t1 = b / d;
+    lo = t0 < t1 ? t0 : t1;
+    hi = t0 < t1 ? t1 : t0;
+}
+
+// The specification scans 64 equal sub-steps one by one and stops
+// at the first that is in contact.  Every obstacle (a wall rectangle inflated by the disc radius, a half plane) is
+// convex, so along the segment its contact set is one interval of sub-steps: the first sub-step in contact with
+// obstacle j is ceil(entry_j) give or take rounding, where entry_j comes from a slab test against the inflated
+// bounding box (a superset of the rounded rectangle: it can only be early, never late).  The kernel evaluates the
+// EXACT predicate of the specification on the few candidates from each entry point onward (until the first hit, at
+// most to the exit of the box) instead of on all 64 positions: same positions, same predicate, same result.
+RRL_HD void move(double& x, double& y, double ax, double ay) {
     ax = clampd(ax, -kMaxForce, kMaxForce);
     ay = clampd(ay, -kMaxForce, kMaxForce);
     if (in_contact(x, y)) return;  // env/maze.py:144-147: no sim steps while in contact
     const double dx = kGain * ax, dy = kGain * ay;
-    double qx = x, qy = y;
-    // four sub-steps per iteration: their positions and contact tests are independent (4x the instruction-level
-    // parallelism of the one-by-one scan), the first one in contact wins -- same values, same result
-    for (int k0 = 1; k0 <= kSubsteps; k0 += 4) {
-        double px[4], py[4];
-        bool hit[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double f = double(k0 + u) * (1.0 / kSubsteps);
-            px[u] = clampd(x + dx * f, -kLim, kLim);
-            py[u] = clampd(y + dy * f, -kLim, kLim);
-            hit[u] = in_contact(px[u], py[u]);
+    const double sx = dx * (1.0 / kSubsteps), sy = dy * (1.0 / kSubsteps);   // per sub-step, for the interval estimate only
+    int first = kSubsteps + 1;                                             // first sub-step in contact with anything
+    // arena planes: contact where |v| >= kLim - kRadius, i.e. outside the slab |v| < 0.275
+    {
+        double lo, hi, t_out = 1e300;
+        slab_interval(x, sx, 0.0, kLim - kRadius, lo, hi);                 // inside the slab for t in [lo, hi]
+        t_out = hi < t_out ? hi : t_out;
+        slab_interval(y, sy, 0.0, kLim - kRadius, lo, hi);
+        t_out = hi < t_out ? hi : t_out;
+        // the move leaves the free square at t_out: candidates from the sub-step before it
+        int k = t_out >= double(kSubsteps + 1) ? kSubsteps + 1 : (t_out <= 1.0 ? 1 : int(t_out) - 1);
+        k = k < 1 ? 1 : k;
+        for (; k <= kSubsteps && k < first; ++k) {
+            double px, py;
+            substep_pos(x, y, dx, dy, k, px, py);
+            if (touches_plane(px, py)) { first = k; break; }
         }
-        const int first = hit[0] ? 0 : (hit[1] ? 1 : (hit[2] ? 2 : 3));
-        qx = px[first];
-        qy = py[first];
-        if (hit[0] | hit[1] | hit[2] | hit[3]) break;
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double lox, hix, loy, hiy;
+        slab_interval(x, sx, wall_x(j), kWallHX + kRadius, lox, hix);
+        slab_interval(y, sy, wall_y(j), kWallHY + kRadius, loy, hiy);
+        const double t_in = lox > loy ? lox : loy, t_out = hix < hiy ? hix : hiy;
+        if (!(t_in <= t_out) || t_out < 0.0 || t_in > double(kSubsteps)) continue;   // the segment misses the box
+        int k = t_in <= 2.0 ? 1 : int(t_in) - 1;
+        int k_end = t_out >= double(kSubsteps) ? kSubsteps : int(t_out) + 2;
+        k_end = k_end > kSubsteps ? kSubsteps : k_end;
+        for (; k <= k_end && k < first; ++k) {
+            double px, py;
+            substep_pos(x, y, dx, dy, k, px, py);
+            if (touches_wall(px, py, wall_x(j), wall_y(j))) { first = k; break; }
+        }
+    }
+    const int k_stop = first <= kSubsteps ? first : kSubsteps;
+    double qx, qy;
+    substep_pos(x, y, dx, dy, k_stop, qx, qy);
     x = qx;
     y = qy;
+}
+
+// reset ranges (env/maze.py:188-196): np.random.uniform(lo, hi) = lo + (hi - lo) * u with the difference taken in
+// double, as numpy does (0.22 - 0.14 is not the double nearest to 0.08)
+RRL_HD void reset_xy(int mode, double u0, double u1, double& x, double& y) {
+    if (mode == 1) x = 0.14 + (0.22 - 0.14) * u0;
+    else if (mode == 2) x = -0.04 + (0.04 - -0.04) * u0;
+    else if (mode == 3) x = -0.27 + (0.27 - -0.27) * u0;
+    else x = -0.22 + (-0.13 - -0.22) * u0;
+    y = -0.22 + (0.22 - -0.22) * u1;
 }
 
 __device__ __forceinline__ void reset_one(uint64_t seed, uint32_t row, uint64_t counter, int mode,
                                           bool check, double& x, double& y) {
     for (uint32_t r = 0;; ++r) {
         const rrl::Bits128 b = rrl::philox_at(seed, row, rrl::kStreamReset, counter | (uint64_t(r) << 48));
-        const double u0 = rrl::unit_open(b.lo), u1 = rrl::unit_open(b.hi);
-        if (mode == 1) x = 0.14 + 0.08 * u0;
-        else if (mode == 2) x = -0.04 + 0.08 * u0;
-        else if (mode == 3) x = -0.27 + 0.54 * u0;
-        else x = -0.22 + 0.09 * u0;
-        y = -0.22 + 0.44 * u1;
+        reset_xy(mode, rrl::unit_open(b.lo), rrl::unit_open(b.hi), x, y);
         if (!check || !in_contact(x, y) || r >= 1000) return;
     }
 }
 
-__device__ __forceinline__ void expert_action(double x, double y, double& ax, double& ay) {
+RRL_HD void expert_action(double x, double y, double& ax, double& ay) {
     double tx, ty;  // env/maze.py:222-232
     if (x <= -0.151) { tx = -0.15; ty = -0.125; }
     else if (x <= 0.149) { tx = 0.15; ty = 0.125; }

@@ -110,14 +110,14 @@ __global__ __launch_bounds__(kBlock) void maze_offline_kernel(int64_t half, int6
         double ax, ay;
         if (part == 0) {
             const rrl::Bits128 u = rrl::philox_at(seed, row, rrl::kStreamOffline, uint64_t(1 + j));
-            ax = -0.1 + 0.2 * rrl::unit_open(u.lo);
-            ay = -0.1 + 0.2 * rrl::unit_open(u.hi);
+            ax = double(float(-0.1 + 0.2 * rrl::unit_open(u.lo)));   // action_space.sample() is float32 (:58)
+            ay = double(float(-0.1 + 0.2 * rrl::unit_open(u.hi)));
         } else {
-            expert_action(x, y, ax, ay);
+            expert_action(x, y, ax, ay);                             // float64 into step() (:88-89)
         }
         const float axf = float(ax), ayf = float(ay);
         double nx = x, ny = y;
-        move(nx, ny, double(axf), double(ayf));
+        move(nx, ny, ax, ay);
         steps += 1;
         const bool cons = in_contact(nx, ny);
         const bool dn = (steps >= 100) | cons | (goal_distance(nx, ny) < kGoalThresh);

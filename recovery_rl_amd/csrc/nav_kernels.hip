@@ -293,8 +293,8 @@ __device__ __forceinline__ int offline_rollout(int64_t i, int64_t n0, int64_t n1
         else if (phase == 3) ay = -1.0 + 0.5 * q0;
         else if (phase == 4) ay = 0.5 + 0.5 * q0;
         const float axf = float(ax), ayf = float(ay);
-        double nx, ny, cost;
-        rrl::nav_transition<KIND>(x, y, double(axf), double(ayf), e0, e1, nx, ny, cost);
+        double nx, ny, cost;   // the transition takes the float64 action, as the reference (navigation1.py:149-150)
+        rrl::nav_transition<KIND>(x, y, ax, ay, e0, e1, nx, ny, cost);
         const bool cons = rrl::in_obstacle<KIND>(nx, ny);
         if constexpr (WRITE) {
             const int64_t w = base + len;

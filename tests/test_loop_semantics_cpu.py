@@ -41,6 +41,9 @@ class StubMem:
     def __len__(self):
         return len(self.rows)
 
+    def check_error(self):
+        pass
+
 
 def run_mine(name, extra, tmp_path, monkeypatch):
     script = sc.Script()

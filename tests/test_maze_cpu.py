@@ -1,5 +1,7 @@
-"""CPU suite for the Maze surrogate oracle (PARITY UNPINNED -- see tests/golden/gen_maze_golden.py):
-control flow / reward / termination follow env/maze.py; geometry follows simple_maze.xml."""
+"""CPU suite for the Maze oracle.  Control flow pinned to the REFERENCE's env/maze.py:34-232: the golden vectors of
+maze_ref_golden.npz were produced by importing env/maze.py over a stand-in MjSim that implements the documented
+kinematic surrogate (tests/golden/gen_maze_ref_golden.py, maze_stub_sim.py).  The physics itself (MuJoCo 1.50) is
+not reproduced.  maze_oracle_golden.npz (the oracle's own output) only guards the Philox-driven paths."""
 import os
 
 import numpy as np
@@ -84,3 +86,91 @@ def test_offline_data_layout():
     assert np.abs(a[5000:]).max() > 0.1                         # expert half stores the raw 1.05*delta
     assert np.array_equal(s[1:20], s2[0:19])                    # 20-step segments are contiguous
     assert not np.array_equal(s[20], s2[19])                    # reset between segments
+
+
+# ---- pinned to env/maze.py (reference imported over the stand-in MjSim) ---------------------------------------------
+import pytest  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def R(golden_dir):
+    return np.load(os.path.join(golden_dir, "maze_ref_golden.npz"))
+
+
+def test_reference_model_constants(R):
+    """What the stand-in read from the reference's simple_maze.xml and what reset() did to the walls."""
+    assert list(R["model.geom_names"][5:9]) == ["wall1A", "wall2A", "wall1B", "wall2B"]
+    assert abs(float(R["model.gain"]) - 0.24667750873451577) < 1e-15          # 500 x 2 ms semi-implicit Euler
+    assert np.array_equal(R["model.wall_pos_after_reset"],
+                          np.array([[-0.1, 0.5 + -0.08], [0.1, 0.4 + 0.08], [-0.1, -0.25 + -0.08], [0.1, -0.25 + 0.08]]))
+
+
+def test_step_equals_env_maze_step(R):
+    """env/maze.py:139-168 row by row: next state and reward bit-for-bit in float64, the three masks, the clipped
+    action and the pre-step state of the info dict."""
+    pos, act, steps = R["step.pos"], R["step.act"], R["step.steps"]
+    for i in range(len(pos)):
+        o = co.maze_step64(pos[i, 0], pos[i, 1], act[i, 0], act[i, 1], int(steps[i]))
+        assert (o["x"], o["y"]) == tuple(R["step.next"][i]), i
+        assert o["reward"] == R["step.reward"][i], i
+        assert (o["done"], o["constraint"], o["success"]) == (R["step.done"][i], R["step.constraint"][i],
+                                                               R["step.success"][i]), i
+    assert np.array_equal(R["step.info_state"], pos)
+    assert np.array_equal(R["step.info_action"], np.clip(act, -0.1, 0.1))
+    assert R["step.constraint"].sum() > 500 and R["step.success"].sum() > 20 and (R["step.done"] > R["step.constraint"]).any()
+
+
+def test_batched_f32_action_step_equals_env_maze_step(R):
+    """The batched entry (float32 actions, what the kernels take) on the rows whose action is float32-valued."""
+    act = R["step.act"]
+    rows = np.where((act == act.astype(np.float32)).all(1))[0]
+    assert len(rows) > 300
+    o = co.maze_step(R["step.pos"][rows], act[rows].astype(np.float32), R["step.steps"][rows].astype(np.int32))
+    assert np.array_equal(o["next_pos64"], R["step.next"][rows])
+    assert np.array_equal(o["reward64"], R["step.reward"][rows])
+    for k in ("done", "constraint", "success"):
+        assert np.array_equal(o[k], R["step." + k][rows]), k
+
+
+def test_expert_episodes_equal_the_reference(R):
+    """40-step closed-loop episodes driven by expert_action (:222-232), incl. over-driven runs that end in a wall
+    and stay stuck there (:144-147), positions bit-for-bit."""
+    for k in range(R["ep.pos"].shape[0]):
+        x, y = R["ep.pos"][k, 0]
+        steps = 0
+        for j in range(R["ep.act"].shape[1]):
+            want = co.maze_expert_action(x, y) * (1.0 if k % 3 else 2.5)
+            assert np.array_equal(want, R["ep.act"][k, j]), (k, j)
+            o = co.maze_step64(x, y, want[0], want[1], steps)
+            x, y, steps = o["x"], o["y"], o["steps"]
+            assert (x, y) == tuple(R["ep.pos"][k, j + 1]) and o["reward"] == R["ep.reward"][k, j]
+            assert (o["done"], o["constraint"]) == (R["ep.done"][k, j], R["ep.constraint"][k, j])
+            assert co.maze_distance(x, y) == R["ep.dist"][k, j]
+    assert R["ep.constraint"].sum() > 0 and (R["ep.reward"] > -0.03).any()
+
+
+def test_expert_and_distance_equal_the_reference(R):
+    for (x, y), a, d in zip(R["expert.pos"], R["expert.act"], R["expert.dist"]):
+        assert np.array_equal(co.maze_expert_action(x, y), a)
+        assert co.maze_distance(x, y) == d
+
+
+def test_reset_equals_env_maze_reset(R):
+    """:184-213 with the reference's own uniforms: ranges per difficulty, y range, re-draw while in contact."""
+    for mode, check, u, pos, used in zip(R["reset.mode"], R["reset.check"], R["reset.u"], R["reset.pos"], R["reset.used"]):
+        x, y, n = co.maze_reset_explicit(int(mode), bool(check), u)
+        assert (x, y) == tuple(pos) and n == used
+    assert (R["reset.used"] > 2).sum() >= 5                           # the re-draw branch is exercised
+
+
+@pytest.mark.parametrize("num", (1000, 90))
+def test_offline_data_equals_env_maze_get_offline_data(R, num):
+    """:34-107 row for row (float64 states and next states, actions, constraint flags, masks) given the reference's
+    uniform stream and its action_space.sample() stream."""
+    pre = "off%d." % num
+    (s, a, c, s2, m), (s64, a64, s2_64), used = co.maze_offline_explicit(num, R[pre + "u"], R[pre + "rand_actions"])
+    assert used == len(R[pre + "u"])
+    assert np.array_equal(s64, R[pre + "s"]) and np.array_equal(s2_64, R[pre + "s2"])
+    assert np.array_equal(a64, R[pre + "a"])
+    assert np.array_equal(c, R[pre + "c"].astype(np.float32)) and np.array_equal(m, R[pre + "m"].astype(np.float32))
+    assert np.array_equal(s, R[pre + "s"].astype(np.float32)) and np.array_equal(a, R[pre + "a"].astype(np.float32))

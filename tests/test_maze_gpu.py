@@ -1,5 +1,6 @@
-"""GPU parity tests for the Maze kernels vs the C oracle (bit-exact).  The oracle itself is
-PARITY UNPINNED w.r.t. MuJoCo."""
+"""GPU parity tests for the Maze kernels: bit-exact against the C oracle, and against the rows recorded from the
+REFERENCE's env/maze.py run over the stand-in MjSim (tests/golden/maze_ref_golden.npz).  The control flow is pinned
+to env/maze.py:34-232; the physics is the documented surrogate, not MuJoCo."""
 import os
 
 import numpy as np
@@ -45,6 +46,37 @@ def test_step_matches_oracle_golden_rows(golden_dir):
     assert np.array_equal(got["reward"], g["out_reward64"].astype(np.float32))
 
 
+def test_step_equals_env_maze_step_rows(golden_dir):
+    """rrl_maze_step against env/maze.py:139-168 itself: the float32-action rows of the reference golden -- next state
+    bit-for-bit in float64, reward, the three masks."""
+    R = np.load(os.path.join(golden_dir, "maze_ref_golden.npz"))
+    act = R["step.act"]
+    rows = np.where((act == act.astype(np.float32)).all(1))[0]
+    assert len(rows) > 1000
+    got = hip_step(R["step.pos"][rows], act[rows].astype(np.float32), R["step.steps"][rows].astype(np.int32))
+    assert np.array_equal(got["pos"], R["step.next"][rows])                       # no auto-reset: pos = s'
+    assert np.array_equal(got["next_obs"], R["step.next"][rows].astype(np.float32))
+    assert np.array_equal(got["reward"], R["step.reward"][rows].astype(np.float32))
+    for k in ("done", "constraint", "success"):
+        assert np.array_equal(got[k], R["step." + k][rows]), k
+    assert R["step.constraint"][rows].sum() > 200
+
+
+def test_expert_episodes_equal_the_reference(golden_dir):
+    """Closed-loop episodes of the reference (expert_action :222-232 + step) replayed through the kernel: the float32
+    rounding of the expert action is the only difference, so positions agree to 1e-6 and every mask is equal."""
+    R = np.load(os.path.join(golden_dir, "maze_ref_golden.npz"))
+    K, T = R["ep.act"].shape[:2]
+    pos = R["ep.pos"][:, 0].copy()
+    t = np.zeros(K, np.int32)
+    for j in range(T):
+        got = hip_step(pos, R["ep.act"][:, j].astype(np.float32), t)
+        assert np.abs(got["pos"] - R["ep.pos"][:, j + 1]).max() < 1e-6, j
+        assert np.array_equal(got["constraint"], R["ep.constraint"][:, j].astype(np.uint8)), j
+        assert np.array_equal(got["done"], R["ep.done"][:, j].astype(np.uint8)), j
+        pos, t = R["ep.pos"][:, j + 1].copy(), got["t"]
+
+
 @pytest.mark.parametrize("n", (1, 65, 4096, 70001))
 def test_step_matches_oracle_random(n):
     rng = np.random.RandomState(n)
@@ -56,6 +88,38 @@ def test_step_matches_oracle_random(n):
         got = hip_step(pos, act, t, seed=77, counter=5, auto_reset=auto)
         for k in ("pos", "t", "next_obs", "obs", "reward", "done", "constraint", "success", "ep_done"):
             assert np.array_equal(got[k], ref[k]), k
+
+
+def test_bracketed_collision_search_equals_the_scan_near_walls():
+    """The kernel finds the first of the 64 sub-steps in contact by a bracketed search; the oracle scans them one by
+    one.  400 000 moves that start within a few sub-steps of a wall face, wall end, corner arc or arena plane."""
+    rng = np.random.RandomState(3)
+    n = 400000
+    wx, wy = np.array([-0.1, 0.1, -0.1, 0.1]), np.array([0.42, 0.48, -0.33, -0.17])
+    j = rng.randint(0, 4, n)
+    d = 0.02501 + 0.01 * rng.uniform(size=n)
+    side = np.where(rng.uniform(size=n) < 0.5, -1.0, 1.0)
+    face = rng.uniform(size=n) < 0.4
+    x = np.where(face, wx[j] + side * (0.005 + d), wx[j] + rng.uniform(-0.04, 0.04, n))
+    y = np.where(face, wy[j] + rng.uniform(-0.24, 0.24, n), wy[j] + side * (0.2 + d))
+    ang, rad = rng.uniform(0, 2 * np.pi, n), 0.025 + rng.uniform(0, 1e-3, n)
+    corner = rng.uniform(size=n) < 0.25
+    x = np.where(corner, wx[j] + side * 0.005 + rad * np.cos(ang), x)
+    y = np.where(corner, wy[j] + np.where(rng.uniform(size=n) < 0.5, -0.2, 0.2) + rad * np.sin(ang), y)
+    plane = rng.uniform(size=n) < 0.1
+    x = np.where(plane, side * rng.uniform(0.27, 0.2749, n), x)
+    y = np.where((y > 0.274) | (y < -0.274), rng.uniform(-0.27, 0.27, n), y)
+    pos = np.c_[x, y]
+    act = rng.uniform(-0.12, 0.12, (n, 2)).astype(np.float32)
+    act[::5] *= 0.02                                             # moves of a few sub-step lengths in total
+    act[1::7, 1] = 0.0
+    t = np.zeros(n, np.int32)
+    ref = co.maze_step(pos, act, t)
+    got = hip_step(pos, act, t)
+    for k in ("pos", "next_obs", "reward", "done", "constraint", "success"):
+        assert np.array_equal(got[k], ref[k]), k
+    started_free = np.array([co.maze_contact(a, b) for a, b in pos[:20000]]) == 0
+    assert (ref["constraint"][:20000][started_free] == 1).sum() > 2000      # many of the moves do run into something
 
 
 def test_vec_env_episode_matches_oracle():

@@ -179,3 +179,22 @@ def test_replay_oracle_stratified_matches_reference_composition(golden_dir):
     assert rb.r[idx[:n_pos]].all() and not rb.r[idx[n_pos:]].any()
     # the reference's own batch has the same composition
     assert g["ref_batch_constraint"][:n_pos].all() and not g["ref_batch_constraint"][n_pos:].any()
+
+
+@pytest.mark.parametrize("env", ENVS)
+@pytest.mark.parametrize("num", (1000, 250))
+def test_c_oracle_offline_data_equals_reference_row_for_row(env, num, golden_dir):
+    """The C generator (the restatement the HIP kernel is compared with bit-for-bit) fed the draws the REFERENCE's
+    get_offline_data consumed (tests/golden/gen_nav_offline_draws_golden.py): same rollouts, same rejection loop,
+    same break-on-constraint, float64 rows equal one for one (navigation1.py:133-164, navigation2.py:133-243)."""
+    g = np.load(os.path.join(golden_dir, "nav_offline_draws_golden.npz"))
+    pre = "%s_n%d_" % (env, num)
+    (s, a, c, s2, m), (s64, a64, s2_64), (nu, nz) = co.nav_offline_explicit(env, num, g[pre + "u"], g[pre + "z"])
+    assert (nu, nz) == (len(g[pre + "u"]), len(g[pre + "z"]))             # every draw consumed, none missing
+    assert len(s64) == len(g[pre + "s"])
+    assert np.array_equal(s64, g[pre + "s"]) and np.array_equal(a64, g[pre + "a"])
+    assert np.array_equal(s2_64, g[pre + "s2"])
+    assert np.array_equal(c, g[pre + "c"].astype(np.float32)) and np.array_equal(m, g[pre + "m"].astype(np.float32))
+    assert np.array_equal(s, g[pre + "s"].astype(np.float32)) and np.array_equal(s2, g[pre + "s2"].astype(np.float32))
+    assert np.array_equal(a, g[pre + "a"].astype(np.float32))
+    assert g[pre + "c"].sum() > 10
