@@ -8,12 +8,21 @@ A "step" is one lock-step iteration of the hot path over all envs: replay sample
 already resident in HBM.  Prints one JSON line (rank 0).
 
     python bench.py --gpus 1 --steps 300 --warmup 30
+    python bench.py --gpus 8                       # spawns 8 ranks itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --env maze                     # config 3 / the Maze leg of config 5 (scripts/maze.sh:7)
+    python bench.py --utd_sweep                    # U = 1, 4, 16, 64 updates per lock-step iteration
+
+Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize; blocks are
+repeated until >= MIN_TIMED_S of timed work exists (a 20-step block is 6 ms -- too short to report on), the
+number of blocks is agreed over ranks, and every figure is over all timed steps (max over ranks of the time).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,25 +30,76 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import arg_utils  # noqa: E402
-from recovery_rl_amd import _lib  # noqa: E402
-from recovery_rl_amd import distributed as dist_utils  # noqa: E402
-
 NUM_ENVS = 4096
+MIN_TIMED_S = 0.5
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 NAV_STEP_ALGO_BYTES = 39         # algorithmic bytes per env-step (f32 contract)
+STEP_PUSH_ALGO_BYTES = 39 + 32 + 32   # + one 32-byte replay row into each of the two buffers (section 8d "replay")
+F32_MFMA_PEAK_TF = 157.3         # MI355X_MICROARCH.md; 155.4 measured on this pool (profiles/mfma_peak.hip)
+PLAN_FLOPS_PER_ROW_STEP = 267264 + 163200      # twin Q_risk (4-256-256-1 x2) + one ensemble member (4-200-200-200-4)
+
+CONFIG_ARGV = {
+    # configs[1]: scripts/navigation1.sh:7
+    "navigation1": ["--env-name", "navigation1", "--cuda", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.8",
+                    "--eps_safe", "0.3", "--num_unsafe_transitions", "20000"],
+    # configs[2] / the Maze leg of configs[4]: scripts/maze.sh:7
+    "maze": ["--env-name", "maze", "--cuda", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.5", "--eps_safe",
+             "0.15", "--pos_fraction", "0.3"],
+}
+
+
+def config_argv(env, seed, num_envs=NUM_ENVS, updates_per_step=1):
+    return CONFIG_ARGV[env] + ["--num_envs", str(num_envs), "--seed", str(seed), "--updates_per_step",
+                               str(updates_per_step)]
 
 
 def config2_argv(seed, num_envs=NUM_ENVS):
-    return ["--env-name", "navigation1", "--cuda", "--use_recovery", "--MF_recovery",
-            "--gamma_safe", "0.8", "--eps_safe", "0.3", "--num_unsafe_transitions", "20000",
-            "--num_envs", str(num_envs), "--seed", str(seed)]
+    return config_argv("navigation1", seed, num_envs)
 
 
-def build_loop(cfg, device, fast=True):
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `--gpus N` with no torchrun environment re-executes this script as N ranks, one per GPU
+# ------------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(argv, n_ranks, port):
+    """The reference's unit of parallelism is the seed loop (scripts/navigation1.sh:4-8): rank g = seed base + g."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def resolve_world(gpus, environ):
+    """(spawn?, world) from --gpus and the torchrun environment; raises when they contradict each other."""
+    if "WORLD_SIZE" in environ:
+        world = int(environ["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit("bench.py: --gpus %d but launched with WORLD_SIZE=%d; start it as `python bench.py --gpus "
+                             "%d` or under torch.distributed.run with --nproc-per-node %d" % (gpus, world, gpus, gpus))
+        return False, world
+    return gpus > 1, gpus
+
+
+def spawn_ranks(argv, n_ranks):
+    import torch
+    backend = os.environ.get("RRL_DIST_BACKEND") or "nccl"
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n_ranks:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one device per rank; set "
+                         "RRL_DIST_BACKEND=gloo to dry-run the multi-rank path on fewer devices)" % (n_ranks, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launch_command(argv, n_ranks, free_port())
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def build_loop(cfg, device, fast=True, pretrain=50):
+    import torch
     from recovery_rl_amd.env import make_vec_env, register_env
     from recovery_rl_amd.experiment import VectorLoop
     from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
@@ -55,7 +115,7 @@ def build_loop(cfg, device, fast=True):
     # offline constraint demonstrations + a short (untimed) Q_risk pre-training
     s, a, c, s2, m = env.transition_function(cfg.num_unsafe_transitions)
     recovery_memory.push(s.contiguous(), a.contiguous(), c.contiguous(), s2.contiguous(), m.contiguous())
-    for _ in range(50):
+    for _ in range(pretrain):
         agent.safety_critic.update_parameters(memory=recovery_memory, policy=agent.policy,
                                               batch_size=cfg.batch_size)
     loop = VectorLoop(cfg, env, agent, memory, recovery_memory)
@@ -66,9 +126,94 @@ def build_loop(cfg, device, fast=True):
     return loop
 
 
+def device_update_counts(loop):
+    """Adam step counters kept ON THE DEVICE by the optimiser kernels (graph replays advance them): the witness that
+    the timed region really ran its optimiser steps.  (SAC critic, Q_risk critic)."""
+    fast = getattr(loop.agent, "fast", None)
+    if fast is None:
+        return None
+    return int(fast.critic.step[0].item()), int(fast.qrisk.step[0].item())
+
+
+def timed_blocks(step, steps, world, device, min_seconds=MIN_TIMED_S, max_blocks=100000):
+    """Blocks of exactly `steps` steps, each bracketed by barrier + synchronize on both sides; repeated until
+    `min_seconds` of timed work (the count is the same on all ranks).  Returns (sum over blocks of the max-over-ranks
+    block time, number of blocks)."""
+    import torch
+    from recovery_rl_amd import distributed as dist_utils
+    total, blocks = 0.0, 0
+    while True:
+        dist_utils.barrier(world)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(device)
+        dist_utils.barrier(world)
+        dt = dist_utils.max_over_ranks(time.perf_counter() - t0, world, device)
+        total += dt
+        blocks += 1
+        if total >= min_seconds or blocks >= max_blocks:       # `total` is all-reduced: every rank stops together
+            return total, blocks
+
+
+def _graph_of(launch, reps, device):
+    import torch
+    for _ in range(10):
+        launch()
+    torch.cuda.synchronize(device)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):          # back-to-back launches from one captured graph: no host launch gaps
+        for _ in range(reps):
+            launch()
+    g.replay()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()                        # events on torch's current stream = the stream the kernels are launched on
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def time_step_push_kernel(device, env_name, n, reps=200):
+    """Average duration of ONE step_push_kernel launch (the env-step + replay-push kernel of the timed iteration)
+    over `reps` back-to-back launches with the bench's own buffers shapes: HIP events on the launch stream."""
+    import ctypes as C
+    import torch
+    from recovery_rl_amd import _lib
+    from recovery_rl_amd.env import make_vec_env
+    from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
+    env = make_vec_env(env_name, n, device=device, seed=1)
+    env.reset()
+    lib = _lib.load()
+    hi = float(env.action_space.high[0])
+    act = (torch.rand(n, 2, device=device) * 2 - 1) * hi
+    real = (torch.rand(n, 2, device=device) * 2 - 1) * hi
+    rec = (torch.rand(n, device=device) < 0.2).to(torch.uint8)
+    cap = max(1000000, 2 * n)
+    mem, rmem = ReplayMemory(cap, 1, device=device), ConstraintReplayMemory(cap, 1, device=device)
+    stats = torch.zeros(10, dtype=torch.int64, device=device)
+    sums = torch.zeros(2, dtype=torch.float64, device=device)
+    ep_reward = torch.zeros(n, device=device)
+    if env_name == "maze":
+        entry, head = lib.rrl_maze_step_push, ()
+    else:
+        entry, head = lib.rrl_nav_step_push, (env.kind,)
+
+    def launch():
+        return entry(*head, n, _lib.ptr(env.pos), _lib.ptr(env.t), _lib.ptr(env.obs), _lib.ptr(act), _lib.ptr(real),
+                     _lib.ptr(rec), env.seed_value, 0, _lib.ptr(env.tick), 1, env.horizon, 1, 0.0, 0,
+                     C.byref(mem._desc), C.byref(rmem._desc), _lib.ptr(env.next_obs), _lib.ptr(env.reward),
+                     _lib.ptr(env.done), _lib.ptr(env.constraint), _lib.ptr(env.success), _lib.ptr(env.ep_done),
+                     _lib.ptr(stats), _lib.ptr(sums), _lib.ptr(ep_reward), _lib.current_stream())
+    return _graph_of(launch, reps, device)
+
+
 def time_nav_step_kernel(device, n, reps=200):
-    """Average duration of ONE rrl_nav_step launch over `reps` launches, bracketed by events on
-    the stream the kernel is launched on (torch's current stream)."""
+    """Average duration of ONE rrl_nav_step launch (the stand-alone env step; the sweep's kernel)."""
+    import torch
+    from recovery_rl_amd import _lib
     from recovery_rl_amd.env import make_vec_env
     env = make_vec_env("navigation1", n, device=device, seed=1)
     env.reset()
@@ -80,27 +225,14 @@ def time_nav_step_kernel(device, n, reps=200):
                                 _lib.ptr(env.next_obs), _lib.ptr(env.obs), _lib.ptr(env.reward),
                                 _lib.ptr(env.done), _lib.ptr(env.constraint), _lib.ptr(env.success),
                                 _lib.ptr(env.ep_done), _lib.ptr(env.t), 100, 1, _lib.current_stream())
-    for _ in range(10):
-        launch()
-    torch.cuda.synchronize(device)
-    # back-to-back launches from one captured graph: removes host launch gaps from the average
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(reps):
-            launch()
-    g.replay()
-    torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    g.replay()
-    e1.record()
-    torch.cuda.synchronize(device)
-    return e0.elapsed_time(e1) * 1e-3 / reps
+    return _graph_of(launch, reps, device)
 
 
 def time_nav_rollout_kernel(device, n=1 << 20, T=100):
     """The fused-rollout variant of SURVEY 8d: T scripted steps per env in ONE launch with the state in registers
     (rrl_nav_rollout); per env-step only the 8-byte action is read and the reward + constraint flag written."""
+    import torch
+    from recovery_rl_amd import _lib
     lib = _lib.load()
     pos = torch.randn(n, 2, dtype=torch.float64, device=device) + torch.tensor([-50.0, 0.0], dtype=torch.float64,
                                                                                 device=device)
@@ -122,39 +254,31 @@ def time_nav_rollout_kernel(device, n=1 << 20, T=100):
     return e0.elapsed_time(e1) * 1e-3 / 3
 
 
-def pmc_traffic(n):
-    """HBM bytes per nav_step launch measured with rocprofv3 PMC counters (committed under profiles/;
-    PMC passes cannot run inside this process).  None when no measurement exists for this size."""
-    path = os.path.join(ROOT, "profiles", "round1_nav_step_pmc.json")
-    try:
-        rec = json.load(open(path)).get(str(n))
-        return None if rec is None else rec["fetch_bytes"] + rec["write_bytes"]
-    except (OSError, ValueError):
-        return None
-
-
-def planner_traffic(n_plans):
-    """HBM bytes per plan_cost_kernel launch from the committed PMC passes (profiles/pmc_plan_traffic.sh)."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "round1_planner_traffic.json"))).get(str(n_plans))
-        return None if rec is None else rec["fetch_bytes"] + rec["write_bytes"]
-    except (OSError, ValueError):
-        return None
+def committed_pmc(name, key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes under profiles/ (PMC passes cannot run inside
+    this process).  None when no measurement exists for this size."""
+    for rnd in ("round2", "round1"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name)))).get(str(key))
+            if rec is not None:
+                return rec["fetch_bytes"] + rec["write_bytes"]
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 # algorithmic FLOPs of one lock-step iteration (SURVEY.md section 8d): SAC update 0.685 GFLOP, Q_risk + recovery
 # update 0.62 GFLOP, acting = per env 2 x (policy 67 072 + twin Q_risk 133 632 + recovery policy 66 560) MAC
-def iteration_flops(num_envs):
-    return 0.685e9 + 0.62e9 + num_envs * 2.0 * (67072 + 133632 + 66560)
-
-
-PLAN_FLOPS_PER_ROW_STEP = 267264 + 163200      # twin Q_risk (4-256-256-1 x2) + one ensemble member (4-200-200-200-4)
-F32_MFMA_PEAK_TF = 157.3                       # MI355X_MICROARCH.md; 155.4 measured on this pool (profiles/mfma_peak.hip)
+def iteration_flops(num_envs, updates_per_step=1):
+    return updates_per_step * (0.685e9 + 0.62e9) + num_envs * 2.0 * (67072 + 133632 + 66560)
 
 
 def time_planner_kernel(device, n_plans=256, reps=3):
     """rrl_plan_cost (MPC._compile_cost of config 4: 400 candidates x 20 particles x 5 steps per planning
     env): seconds per launch from HIP events on the launch stream."""
+    import torch
+    import arg_utils
+    from recovery_rl_amd import _lib
     from recovery_rl_amd.MPC import MPC
     from recovery_rl_amd.config import create_config
     from recovery_rl_amd.env import make_vec_env
@@ -184,74 +308,144 @@ def time_planner_kernel(device, n_plans=256, reps=3):
     return e0.elapsed_time(e1) * 1e-3 / reps, n_plans * pop * mpc.npart * mpc.plan_hor
 
 
-def cpu_baseline(budget_s=15.0):
-    """The reference-style loop (1 env, 1 SAC + 1 Q_risk update per env step; experiment.py:396-452)
-    on the host cores: C oracle env + oracle replay + the same torch modules on the CPU."""
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY.md section 8d "CPU side-by-side"): the reference-order loop on the host cores
+# ------------------------------------------------------------------------------------------------------------------
+def _cpu_loop(cfg, env_name, seconds, with_recovery, mode="full"):
+    """The reference's per-iteration body (experiment.py:396-452) for ONE env on the CPU: C oracle env + oracle
+    replay + the same torch modules.  mode: "full" (update + act + step + push), "update" (updates on a fixed
+    replay, no env), returns (env_steps/s or None, grad_steps/s)."""
+    import numpy as np
+    import torch
     from oracle import c_oracle as co
     from recovery_rl_amd.sac import SAC
     from recovery_rl_amd.spaces import Box
-    cfg = arg_utils.get_args([a for a in config2_argv(1, 1) if a != "--cuda"])
-    # batch-256 MLP updates do not scale past a few threads; oversubscribing a 128-core host is slower
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
     torch.manual_seed(1)
-    act_space = Box(-np.ones(2), np.ones(2))
-    obs_space = Box(-np.ones(2) * np.inf, np.ones(2) * np.inf)
-    agent = SAC(obs_space, act_space, cfg, "/tmp")
+    agent = SAC(Box(-np.ones(2) * np.inf, np.ones(2) * np.inf), Box(-np.ones(2), np.ones(2)), cfg, "/tmp")
     mem, rmem = co.OracleReplay(100000), co.OracleReplay(100000)
-    s, a, c, s2, m = co.nav_offline("navigation1", 20000, 1)
-    rmem.push(s, a, c, s2, m)
     tt = lambda arrs: tuple(torch.from_numpy(x) for x in arrs)
-    pos, obs, t = co.nav_reset("navigation1", 1, seed=1, counter=0)
+    if with_recovery:
+        rmem.push(*co.nav_offline(env_name, 20000, 1))
+    pos, obs, t = co.nav_reset(env_name, 1, seed=1, counter=0)
     steps = updates = 0
     counter = 1
+    t_start, timed_steps, timed_updates = None, 0, 0
     t0 = time.perf_counter()
-    timed_steps = timed_updates = 0
-    t_start = None
+    if mode == "update":                                   # a filled buffer, then only update_parameters calls
+        rng = np.random.RandomState(0)
+        k = 4096
+        mem.push(rng.randn(k, 2).astype(np.float32) + [-50, 0], rng.uniform(-1, 1, (k, 2)).astype(np.float32),
+                 -50 + rng.randn(k).astype(np.float32), rng.randn(k, 2).astype(np.float32) + [-50, 0],
+                 np.ones(k, np.float32))
     while True:
         if len(mem) > cfg.batch_size:
-            if t_start is None:                       # time the steady state only
+            if t_start is None:                            # time the steady state only
                 t_start, timed_steps, timed_updates = time.perf_counter(), 0, 0
             agent.update_parameters(None, cfg.batch_size, updates, safety_critic=agent.safety_critic,
                                     batch=tt(mem.sample(cfg.batch_size, 1, counter)))
-            agent.safety_critic.update_parameters(policy=agent.policy,
-                                                  batch=tt(rmem.sample(cfg.batch_size, 2, counter)))
+            if with_recovery:
+                agent.safety_critic.update_parameters(policy=agent.policy,
+                                                      batch=tt(rmem.sample(cfg.batch_size, 2, counter)))
             updates += 1
             timed_updates += 1
-        st = torch.from_numpy(obs)
-        action = agent.select_action(st) if steps >= cfg.start_steps else torch.rand(1, 2) * 2 - 1
-        risk = agent.safety_critic.get_value(st, action)
-        real = agent.safety_critic.select_action(st) if float(risk) > cfg.eps_safe else action
-        o = co.nav_step("navigation1", pos, real.numpy(), t, seed=1, counter=counter, auto_reset=True)
-        mask = 1.0 - o["done"].astype(np.float32)
-        mem.push(obs, action.numpy(), o["reward"], o["next_obs"], mask)
-        rmem.push(obs, real.numpy(), o["constraint"].astype(np.float32), o["next_obs"], mask)
-        pos, t, obs = o["pos"], o["t"], o["obs"]
-        steps += 1
-        timed_steps += 1
+        if mode == "full":
+            st = torch.from_numpy(obs)
+            action = agent.select_action(st) if steps >= cfg.start_steps else torch.rand(1, 2) * 2 - 1
+            real = action
+            if with_recovery:
+                risk = agent.safety_critic.get_value(st, action)
+                real = agent.safety_critic.select_action(st) if float(risk) > cfg.eps_safe else action
+            o = co.nav_step(env_name, pos, real.numpy(), t, seed=1, counter=counter, auto_reset=True)
+            mask = 1.0 - o["done"].astype(np.float32)
+            mem.push(obs, action.numpy(), o["reward"], o["next_obs"], mask)
+            if with_recovery:
+                rmem.push(obs, real.numpy(), o["constraint"].astype(np.float32), o["next_obs"], mask)
+            pos, t, obs = o["pos"], o["t"], o["obs"]
+            steps += 1
+            timed_steps += 1
         counter += 1
         now = time.perf_counter()
-        if t_start is not None and now - t_start > budget_s:
+        if t_start is not None and now - t_start > seconds:
             break
-        if now - t0 > 4 * budget_s:
+        if now - t0 > 6 * seconds + 20:
             break
     dt = time.perf_counter() - (t_start or t0)
-    # attribution (SURVEY 8d "CPU side-by-side"): the env alone, batched on ONE core of the same host
+    return (timed_steps / dt if mode == "full" else None), timed_updates / dt
+
+
+def cpu_baseline(budget_s=24.0):
+    """Config 1 (Navigation1, 1 env, SAC only: scripts/navigation1.sh:21 without --cuda) and the RRL-MF loop of config 2
+    at one env, on 1 and min(8, cores) host threads, plus the update-only and env-only rates that attribute the
+    time.  `value` = config-1 full-loop env-steps/s at the better thread count."""
+    import numpy as np
+    import torch
+    import arg_utils
+    from oracle import c_oracle as co
+    cores = os.cpu_count() or 1
+    many = min(8, cores)                 # batch-256 MLP updates do not scale past a few threads
+    cfg1 = arg_utils.get_args(["--env-name", "navigation1", "--num_unsafe_transitions", "20000", "--seed", "1"])
+    cfg2 = arg_utils.get_args([a for a in config_argv("navigation1", 1, 1) if a != "--cuda"])
+    slot = budget_s / 6.0
+    out = {"threads": {}}
+    for nt in sorted({1, many}):
+        torch.set_num_threads(nt)
+        env_rate, grad_rate = _cpu_loop(cfg1, "navigation1", slot, with_recovery=False)
+        _, upd_only = _cpu_loop(cfg1, "navigation1", slot / 2, with_recovery=False, mode="update")
+        out["threads"][str(nt)] = {"config1_env_steps_per_s": env_rate, "config1_sac_grad_steps_per_s": grad_rate,
+                                   "config1_update_only_grad_steps_per_s": upd_only}
+    best = max(out["threads"], key=lambda k: out["threads"][k]["config1_env_steps_per_s"])
+    torch.set_num_threads(int(best))
+    mf_env, mf_grad = _cpu_loop(cfg2, "navigation1", slot, with_recovery=True)
+    # the env alone, batched on ONE core of the same host
     n_env = 4096
     p4, _, t4 = co.nav_reset("navigation1", n_env, seed=1, counter=0)
     a4 = np.random.RandomState(0).uniform(-1, 1, (n_env, 2)).astype(np.float32)
-    te = time.perf_counter()
-    reps = 0
+    te, reps = time.perf_counter(), 0
     while time.perf_counter() - te < 1.0:
         o = co.nav_step("navigation1", p4, a4, t4, seed=1, counter=reps + 1, auto_reset=True)
         p4, t4 = o["pos"], o["t"]
         reps += 1
     env_only = reps * n_env / (time.perf_counter() - te)
-    return {"value": timed_steps / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(),
-            "kind": "port", "grad_steps_per_s": timed_updates / dt,
-            "env_only_env_steps_per_s_1core": env_only,
-            "sample": "%d env-steps of the reference-order loop (1 env, 1 SAC + 1 Q_risk/recovery update "
-                      "per env-step, B=256, H=256) in %.1f s: C oracle env + oracle replay + torch CPU nets"
-                      % (timed_steps, dt)}
+    b = out["threads"][best]
+    out.update({
+        "value": b["config1_env_steps_per_s"], "unit": "env-steps/s", "cores": int(best), "kind": "port",
+        "host_cores": cores, "grad_steps_per_s": b["config1_sac_grad_steps_per_s"],
+        "update_only_grad_steps_per_s": b["config1_update_only_grad_steps_per_s"],
+        "env_only_env_steps_per_s_1core": env_only,
+        "rrl_mf_env_steps_per_s": mf_env, "rrl_mf_grad_steps_per_s": mf_grad,
+        "sample": "config 1 = Navigation1, 1 env, SAC only, 1 update per env-step (experiment.py:396-452, B=256, "
+                  "H=256): ~%.0f s per thread count (1 and %d threads) of the full loop + ~%.0f s update-only each; "
+                  "the RRL-MF loop (SAC + Q_risk + recovery policy update per env-step) ~%.0f s at %s thread(s); "
+                  "env-only 1 s on one core.  C oracle env + oracle replay + the same torch modules on the CPU"
+                  % (slot, many, slot / 2, slot, best)})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def run_config(a, cfg, device, world, rank, updates_per_step=1, min_seconds=MIN_TIMED_S):
+    """Build the loop for `cfg`, capture, warm up, time.  Returns (result dict, loop)."""
+    import torch
+    from recovery_rl_amd import distributed as dist_utils
+    loop = build_loop(cfg, device, fast=not a.autograd_updates)
+    step = loop.replay if not a.no_graph else (lambda: loop.vector_step(True, False, True))
+    if not a.no_graph:
+        loop.capture(online_qrisk=True)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    stats0, dev0 = loop.read_stats(), device_update_counts(loop)
+    elapsed, blocks = timed_blocks(step, a.steps, world, device, min_seconds)
+    stats1, dev1 = loop.read_stats(), device_update_counts(loop)
+    n_steps = a.steps * blocks
+    local = {k: stats1[k] - stats0[k] for k in stats1}
+    assert local["env_steps"] == n_steps * cfg.num_envs, (local["env_steps"], n_steps, cfg.num_envs)
+    if dev0 is not None:      # the device-side optimiser step counters, not the host mirrors
+        assert dev1[0] - dev0[0] == n_steps * updates_per_step, (dev0, dev1, n_steps)
+        assert dev1[1] - dev0[1] == n_steps * updates_per_step, (dev0, dev1, n_steps)
+        local["sac_updates"], local["qrisk_updates"] = dev1[0] - dev0[0], dev1[1] - dev0[1]
+    agg = dist_utils.aggregate_stats(local, world, device)
+    return {"elapsed": elapsed, "blocks": blocks, "steps_total": n_steps, "agg": agg,
+            "device_counters": dev0 is not None}, loop
 
 
 def main():
@@ -260,6 +454,11 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--num_envs", type=int, default=NUM_ENVS)
+    ap.add_argument("--env", choices=sorted(CONFIG_ARGV), default="navigation1",
+                    help="navigation1 = configs[1] (the headline); maze = configs[2] and the Maze leg of configs[4]")
+    ap.add_argument("--updates_per_step", type=int, default=1, help="SAC (+ Q_risk) updates per lock-step iteration")
+    ap.add_argument("--utd_sweep", action="store_true",
+                    help="also time U = 4, 16, 64 updates per iteration (update-to-data ratio U / num_envs)")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--planner", action="store_true",
@@ -267,64 +466,78 @@ def main():
                          "on by default for single-GPU runs")
     ap.add_argument("--no_planner", action="store_true")
     ap.add_argument("--sweep", action="store_true",
-                    help="also time rrl_nav_step at N = 2^12..2^24 (the bandwidth regime of the env kernel); off by "
-                         "default so that every nav_step_kernel launch of the default command has the bench size")
-    ap.add_argument("--no_sweep", action="store_true", help=argparse.SUPPRESS)
+                    help="also time rrl_nav_step / step_push at N = 2^12..2^24 (the bandwidth regime of the env kernels)")
     ap.add_argument("--autograd_updates", action="store_true",
                     help="PyTorch autograd + vendor GEMMs for the updates instead of the fused HIP kernels")
     a = ap.parse_args()
 
+    spawn, world_expected = resolve_world(a.gpus, os.environ)
+    if spawn:
+        raise SystemExit(spawn_ranks(sys.argv[1:], a.gpus))
+
+    import torch
+    import arg_utils
+    from recovery_rl_amd import distributed as dist_utils
+
     rank, local_rank, world = dist_utils.init()
+    assert world == world_expected
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = dist_utils.local_device(local_rank)
     torch.cuda.set_device(device)
 
-    cfg = arg_utils.get_args(config2_argv(dist_utils.rank_seed(1, rank), a.num_envs))
-    loop = build_loop(cfg, device, fast=not a.autograd_updates)
-    step = loop.replay if not a.no_graph else (lambda: loop.vector_step(True, False, True))
-    if not a.no_graph:
-        loop.capture(online_qrisk=True)
-    for _ in range(a.warmup):
-        step()
-    stats0 = loop.read_stats()
-
-    dist_utils.barrier(world)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize(device)
-    dist_utils.barrier(world)
-    elapsed = time.perf_counter() - t0
-    elapsed = dist_utils.max_over_ranks(elapsed, world, device)
-
-    stats1 = loop.read_stats()
-    local = {k: stats1[k] - stats0[k] for k in stats1}
-    agg = dist_utils.aggregate_stats(local, world, device)
-    assert local["env_steps"] == a.steps * a.num_envs, (local["env_steps"], a.steps, a.num_envs)
-    assert local["sac_updates"] == a.steps * cfg.updates_per_step
+    U = a.updates_per_step
+    cfg = arg_utils.get_args(config_argv(a.env, dist_utils.rank_seed(1, rank), a.num_envs, U))
+    res, loop = run_config(a, cfg, device, world, rank, U)
+    elapsed, agg, n_steps = res["elapsed"], res["agg"], res["steps_total"]
 
     extra = {}
+    if a.utd_sweep:
+        sweep = []
+        for u in (1, 4, 16, 64):
+            if u == U:
+                r = res
+            else:
+                del loop
+                torch.cuda.empty_cache()
+                cfg_u = arg_utils.get_args(config_argv(a.env, dist_utils.rank_seed(1, rank), a.num_envs, u))
+                r, loop = run_config(a, cfg_u, device, world, rank, u, min_seconds=0.3)
+            sweep.append({"updates_per_step": u, "utd": "%d/%d" % (u, a.num_envs),
+                          "ms_per_step": r["elapsed"] / r["steps_total"] * 1e3,
+                          "env_steps_per_s": r["agg"]["env_steps"] / r["elapsed"],
+                          "sac_grad_steps_per_s": r["agg"]["sac_updates"] / r["elapsed"],
+                          "qrisk_grad_steps_per_s": r["agg"]["qrisk_updates"] / r["elapsed"]})
+        extra["utd_sweep"] = sweep
+
     if rank == 0:
-        t_k = time_nav_step_kernel(device, a.num_envs)
+        t_k = time_step_push_kernel(device, a.env, a.num_envs)
+        gbs = a.num_envs * STEP_PUSH_ALGO_BYTES / t_k / 1e9
         extra["roofline"] = {
-            "kernel": "nav_step_kernel<0,false> (rrl_nav_step)", "bound": "hbm",
-            "achieved": a.num_envs * NAV_STEP_ALGO_BYTES / t_k / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": a.num_envs * NAV_STEP_ALGO_BYTES / t_k / 1e9 / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(a.num_envs), "launch_us": t_k * 1e6,
-            "note": "N=%d moves only %d KB per launch: latency-bound; bandwidth regime (N up to 2^24, "
-                    "`bench.py --sweep`): profiles/round1_roofline_sweep.json"
-                    % (a.num_envs, a.num_envs * NAV_STEP_ALGO_BYTES // 1024)}
-        if a.sweep and not a.no_sweep:
-            sweep = []
+            "kernel": "step_push_kernel<%s> (rrl_%s_step_push): env step + two replay pushes + episode counters, the "
+                      "env kernel of the timed iteration" % ("MazeEnv" if a.env == "maze" else "NavEnv<0>",
+                                                             "maze" if a.env == "maze" else "nav"),
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": committed_pmc("step_push_pmc", a.num_envs) if a.env == "navigation1" else None,
+            "launch_us": t_k * 1e6, "algorithmic_bytes_per_env_step": STEP_PUSH_ALGO_BYTES,
+            "note": "N=%d moves only %d KB per launch: latency-bound by construction; bandwidth regime "
+                    "(N up to 2^24, `bench.py --sweep`): profiles/round2_roofline_sweep.json"
+                    % (a.num_envs, a.num_envs * STEP_PUSH_ALGO_BYTES // 1024)}
+        if a.sweep:
+            sweep, sweep_sp = [], []
             for logn in (12, 16, 20, 24):
                 n = 1 << logn
                 tk = time_nav_step_kernel(device, n, reps=200 if logn <= 16 else 20)
                 sweep.append({"n_envs": n, "launch_us": tk * 1e6, "env_steps_per_s": n / tk,
                               "achieved_GBs": n * NAV_STEP_ALGO_BYTES / tk / 1e9,
                               "frac": n * NAV_STEP_ALGO_BYTES / tk / 1e9 / HBM_PEAK_GBS})
+                if logn <= 22:
+                    ts = time_step_push_kernel(device, "navigation1", n, reps=200 if logn <= 16 else 20)
+                    sweep_sp.append({"n_envs": n, "launch_us": ts * 1e6, "env_steps_per_s": n / ts,
+                                     "achieved_GBs": n * STEP_PUSH_ALGO_BYTES / ts / 1e9,
+                                     "frac": n * STEP_PUSH_ALGO_BYTES / ts / 1e9 / HBM_PEAK_GBS})
+                torch.cuda.empty_cache()
             extra["roofline_sweep"] = sweep
+            extra["roofline_sweep_step_push"] = sweep_sp
             n_r, t_r = 1 << 20, 100
             tr = time_nav_rollout_kernel(device, n_r, t_r)
             extra["roofline_rollout"] = {
@@ -341,7 +554,8 @@ def main():
             extra["roofline_planner"] = {
                 "kernel": "plan_cost_kernel (rrl_plan_cost, model-based recovery of config 4)", "bound": "mfma",
                 "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
-                "traffic": planner_traffic(256), "launch_ms": t_p * 1e3, "row_steps_per_s": row_steps / t_p,
+                "traffic": committed_pmc("planner_traffic", 256), "launch_ms": t_p * 1e3,
+                "row_steps_per_s": row_steps / t_p,
                 "note": "f32-in/f32-acc MFMA (exact f32); algorithmic %d FLOP per particle-step"
                         % PLAN_FLOPS_PER_ROW_STEP}
         if not a.no_cpu_baseline and world == 1:
@@ -349,17 +563,22 @@ def main():
 
     if rank == 0:
         env_rate = agg["env_steps"] / elapsed
+        flops = iteration_flops(a.num_envs, U) * n_steps * world
+        label = {"navigation1": "Navigation1", "maze": "Maze"}[a.env]
         out = {
             "metric": "env-steps/sec + SAC grad-steps/sec, Navigation1 4096 envs, 1/2/4/8 GPU",
             "value": env_rate, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": elapsed / n_steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timed_blocks": res["blocks"], "timed_steps_total": n_steps, "timed_seconds": elapsed,
             "sac_grad_steps_per_s": agg["sac_updates"] / elapsed,
             "qrisk_grad_steps_per_s": agg["qrisk_updates"] / elapsed,
-            "config": {"workload": "Navigation1, %d vectorised envs/GPU, SAC + Q_risk + model-free recovery "
-                                   "(scripts/navigation1.sh:7 + --num_envs %d), batch 256, hidden 256, "
-                                   "updates_per_step 1 (UTD 1/%d), one seed per GPU"
-                                   % (a.num_envs, a.num_envs, a.num_envs),
+            "grad_step_witness": "device-side Adam step counters" if res["device_counters"] else "host counters",
+            "config": {"workload": "%s, %d vectorised envs/GPU, SAC + Q_risk + model-free recovery "
+                                   "(scripts/%s + --num_envs %d), batch 256, hidden 256, "
+                                   "updates_per_step %d (UTD %d/%d), one seed per GPU"
+                                   % (label, a.num_envs, "navigation1.sh:7" if a.env == "navigation1" else "maze.sh:7",
+                                      a.num_envs, U, U, a.num_envs),
                        "num_envs_per_gpu": a.num_envs, "batch_size": cfg.batch_size,
                        "hidden_size": cfg.hidden_size, "updates_per_step": cfg.updates_per_step,
                        "launch": "eager" if a.no_graph else "hipGraph replay",
@@ -368,9 +587,9 @@ def main():
                        "parallelism": "replicas x%d (RCCL metric all-reduce only)" % world},
             "episodes": agg["episodes"], "violations": agg["num_viols"], "successes": agg["num_successes"],
             # the MLP side of the iteration against the f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
-            "roofline_mlp": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
-                             "achieved": iteration_flops(a.num_envs) * a.steps * world / elapsed / 1e12,
-                             "frac": iteration_flops(a.num_envs) * a.steps * world / elapsed / 1e12 / (157.3 * world),
+            "roofline_mlp": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TF,
+                             "achieved": flops / elapsed / 1e12,
+                             "frac": flops / elapsed / 1e12 / (F32_MFMA_PEAK_TF * world),
                              "note": "algorithmic FLOPs of SAC + Q_risk updates (B=256) and acting (N envs) per "
                                      "iteration / iteration time; tiny problems: launch- and latency-bound"},
         }
