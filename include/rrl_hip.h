@@ -136,7 +136,16 @@ typedef struct {
     int64_t cap;
     int64_t* state;
     int32_t* pos_cnt;
+    int32_t flags;       /* RRL_REPLAY_* bits */
 } rrl_replay_t;
+
+/* Stratified draws (rrl_creplay_sample_gather) that ask for more positives (or negatives) than the ring holds: the
+ * reference aborts (random.sample raises ValueError, replay_memory.py:61-66) and so does the default here (error flag
+ * state[3] = 1, outputs untouched).  With this bit the draw takes every row of the short class and fills the batch
+ * from the other one: n_pos' = min(n_pos, positives), n_neg' = B - n_pos' (and the other way round).  The lock-step
+ * loop sets it: thousands of envs overwrite a 1e6-row ring in a few hundred iterations, so a policy that has learned
+ * to avoid violations starves the positive class -- a state the one-env reference cannot reach within its runs. */
+#define RRL_REPLAY_CLAMP_STRATIFIED 1
 
 /* push (replay_memory.py:21-25,47-52) of n rows in row order; `valid` (nullable u8[n]) drops
  * rows with valid == 0 (used for add_both_transitions, experiment.py:446-448).
@@ -156,7 +165,8 @@ int rrl_replay_sample_gather(const rrl_replay_t* rb, int32_t B, uint64_t seed, u
                              float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu, void* stream);
 
 /* stratified sample (replay_memory.py:54-72): first n_pos rows uniform among slots with r != 0,
- * then n_neg rows uniform among filled slots with r == 0.  Needs rb->pos_cnt. cap <= 2^21. */
+ * then n_neg rows uniform among filled slots with r == 0.  Needs rb->pos_cnt. cap <= 2^21.
+ * Too few rows of a class: see RRL_REPLAY_CLAMP_STRATIFIED. */
 int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_neg, uint64_t seed,
                               uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a,
                               float* r, float* s2, float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu,

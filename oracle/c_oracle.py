@@ -321,13 +321,15 @@ class OracleReplay:
             raise ValueError("Sample larger than population or is negative")
         return idx
 
-    def sample_stratified_indices(self, n_pos, n_neg, seed, counter):
+    def sample_stratified_indices(self, n_pos, n_neg, seed, counter, clamp=False, return_split=False):
         idx = np.zeros(n_pos + n_neg, np.int64)
-        rc = lib().rrl_oracle_sample_stratified(C.byref(self._c), C.c_int32(n_pos), C.c_int32(n_neg),
-                                                C.c_uint64(seed), C.c_uint64(counter), _p(idx))
+        used = C.c_int32(n_pos)
+        rc = lib().rrl_oracle_sample_stratified_clamped(C.byref(self._c), C.c_int32(n_pos), C.c_int32(n_neg),
+                                                        C.c_int(int(clamp)), C.c_uint64(seed), C.c_uint64(counter),
+                                                        _p(idx), C.byref(used))
         if rc != 0:
             raise ValueError("Sample larger than population or is negative")
-        return idx
+        return (idx, used.value) if return_split else idx
 
     def gather(self, idx):
         B = len(idx)

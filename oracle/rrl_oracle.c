@@ -713,10 +713,25 @@ static int64_t kth_slot(const rrl_oracle_replay* rb, int64_t k, int want_pos)
 int rrl_oracle_sample_stratified(const rrl_oracle_replay* rb, int32_t n_pos, int32_t n_neg,
                                  uint64_t seed, uint64_t counter, int64_t* idx)
 {
+    return rrl_oracle_sample_stratified_clamped(rb, n_pos, n_neg, 0, seed, counter, idx, NULL);
+}
+
+/* clamp != 0: a class with too few rows gives all it has and the other class fills the batch (the lock-step loop's
+ * rule, include/rrl_hip.h RRL_REPLAY_CLAMP_STRATIFIED); clamp == 0: the reference's ValueError (replay_memory.py:61-66) */
+int rrl_oracle_sample_stratified_clamped(const rrl_oracle_replay* rb, int32_t n_pos, int32_t n_neg, int clamp,
+                                         uint64_t seed, uint64_t counter, int64_t* idx, int32_t* n_pos_used)
+{
     int64_t npos_total = 0;
     for (int64_t p = 0; p < rb->size; ++p) npos_total += rb->r[p] != 0.0f;
     int64_t nneg_total = rb->size - npos_total;
-    if (n_pos > npos_total || n_neg > nneg_total) return -1;
+    if (n_pos > npos_total || n_neg > nneg_total) {
+        int32_t B = n_pos + n_neg;
+        if (!clamp || B > rb->size) return -1;
+        if (n_pos > npos_total) n_pos = (int32_t)npos_total;
+        else n_pos = B - (int32_t)nneg_total;
+        n_neg = B - n_pos;
+    }
+    if (n_pos_used) *n_pos_used = n_pos;
     if (n_pos > 0) {
         if (rrl_oracle_sample_indices(npos_total, n_pos, seed, counter, RRL_STREAM_SAMPLE, idx)) return -2;
         for (int32_t i = 0; i < n_pos; ++i) idx[i] = kth_slot(rb, idx[i], 1);

@@ -132,6 +132,8 @@ int rrl_oracle_sample_indices(int64_t size, int32_t B, uint64_t seed, uint64_t c
  * (replay_memory.py:54-72) */
 int rrl_oracle_sample_stratified(const rrl_oracle_replay* rb, int32_t n_pos, int32_t n_neg,
                                  uint64_t seed, uint64_t counter, int64_t* idx);
+int rrl_oracle_sample_stratified_clamped(const rrl_oracle_replay* rb, int32_t n_pos, int32_t n_neg, int clamp,
+                                         uint64_t seed, uint64_t counter, int64_t* idx, int32_t* n_pos_used);
 int rrl_oracle_gather(const rrl_oracle_replay* rb, int32_t B, const int64_t* idx, float* s,
                       float* a, float* r, float* s2, float* m);
 

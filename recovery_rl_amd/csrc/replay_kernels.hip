@@ -286,8 +286,15 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
     __syncthreads();
     const int64_t total_neg = size - total_pos;
     if (int64_t(n_pos) > total_pos || int64_t(n_neg) > total_neg) {
-        if (tid == 0) rb.state[3] = 1;
-        return;
+        const bool feasible = int64_t(B) <= size && (rb.flags & RRL_REPLAY_CLAMP_STRATIFIED);
+        if (!feasible) {
+            if (tid == 0) rb.state[3] = 1;
+            return;
+        }
+        // every row of the short class, the rest of the batch from the other one (uniform for all threads)
+        if (int64_t(n_pos) > total_pos) n_pos = int(total_pos);
+        else n_pos = B - int(total_neg);
+        n_neg = B - n_pos;
     }
     const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
     rrl::advance_counter(counter_dev, counter_inc);

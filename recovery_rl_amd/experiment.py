@@ -71,6 +71,10 @@ class VectorLoop:
         self._actor = None
         self._one = torch.ones((), dtype=torch.int64, device=dev)
         self.episode_log = None           # optional EpisodeLog (per-episode records for run_stats)
+        if self.n > 1 and hasattr(recovery_memory, "clamp_stratified"):
+            # N envs overwrite the ring in capacity / N iterations: once the policy avoids violations the positive
+            # class can drop below int(B * pos_fraction) rows, where the one-env reference would abort
+            recovery_memory.clamp_stratified = True
 
     # -- pieces --------------------------------------------------------------------------------
     def start(self):

@@ -39,7 +39,7 @@ class ReplayMemory:
         self._desc = _lib.rrl_replay_t(self.s.data_ptr(), self.a.data_ptr(), self.r.data_ptr(),
                                        self.s2.data_ptr(), self.m.data_ptr(), cap,
                                        self.state.data_ptr(),
-                                       self.pos_cnt.data_ptr() if self.pos_cnt is not None else None)
+                                       self.pos_cnt.data_ptr() if self.pos_cnt is not None else None, 0)
         self._len = 0          # host mirror of `size`; exact unless masked pushes were used
         self._len_exact = True
         self._scratch = None
@@ -121,6 +121,18 @@ class ConstraintReplayMemory(ReplayMemory):
 
     _WITH_POS_COUNTS = True
     _SEED_SALT = 0x9E3779B97F4A7C15  # decorrelate its index stream from the task buffer's
+
+    @property
+    def clamp_stratified(self):
+        """False (default): a stratified draw that needs more rows of a class than the ring holds is an error, as
+        random.sample's ValueError in the reference (replay_memory.py:61-66).  True (the lock-step loop): the short
+        class gives every row it has and the other class fills the batch (RRL_REPLAY_CLAMP_STRATIFIED)."""
+        return bool(self._desc.flags & _lib.REPLAY_CLAMP_STRATIFIED)
+
+    @clamp_stratified.setter
+    def clamp_stratified(self, on):
+        self._desc.flags = (self._desc.flags | _lib.REPLAY_CLAMP_STRATIFIED) if on else \
+            (self._desc.flags & ~_lib.REPLAY_CLAMP_STRATIFIED)
 
     def sample(self, batch_size, pos_fraction=None, out=None, rows=None):
         if pos_fraction is None:

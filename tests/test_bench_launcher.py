@@ -1,0 +1,127 @@
+"""bench.py's multi-GPU launcher: `--gpus N` without a torchrun environment re-executes the script as N ranks (one per
+GPU, RCCL); under torchrun the world size must agree with --gpus.  The timed-block loop stops on the same block on every
+rank (its stopping time is all-reduced): world_size-2 gloo run on the CPU.  The real 2-rank run of the whole bench on one
+GPU (gloo dry run) is in the -m gpu part."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_gpus_flag_decides_the_world_size():
+    assert bench.resolve_world(1, {}) == (False, 1)
+    assert bench.resolve_world(8, {}) == (True, 8)                      # no torchrun env: bench spawns the ranks itself
+    assert bench.resolve_world(4, {"WORLD_SIZE": "4"}) == (False, 4)    # the driver's torchrun launch
+    with pytest.raises(SystemExit):
+        bench.resolve_world(8, {"WORLD_SIZE": "1"})                     # a 1-rank run must not report itself as 8 GPUs
+    with pytest.raises(SystemExit):
+        bench.resolve_world(1, {"WORLD_SIZE": "2"})
+
+
+def test_launch_command_is_one_rank_per_gpu_on_localhost():
+    cmd = bench.launch_command(["--gpus", "8", "--steps", "20"], 8, 29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "20"] and cmd[-5].endswith("bench.py")
+
+
+def test_spawn_refuses_more_ranks_than_gpus(monkeypatch):
+    monkeypatch.delenv("RRL_DIST_BACKEND", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(["--gpus", "4"], 4)
+    assert "only 1 GPU" in str(e.value)
+
+
+def test_config_argv_are_the_reference_command_lines():
+    import arg_utils
+    c2 = arg_utils.get_args(bench.config_argv("navigation1", 3, 4096))
+    assert (c2.env_name, c2.use_recovery, c2.MF_recovery, c2.gamma_safe, c2.eps_safe) == ("navigation1", True, True, 0.8, 0.3)
+    assert c2.num_unsafe_transitions == 20000 and c2.num_envs == 4096 and c2.seed == 3       # scripts/navigation1.sh:7
+    c3 = arg_utils.get_args(bench.config_argv("maze", 1, 4096, 16))
+    assert (c3.env_name, c3.gamma_safe, c3.eps_safe, c3.pos_fraction) == ("maze", 0.5, 0.15, 0.3)   # scripts/maze.sh:7
+    assert c3.updates_per_step == 16
+
+
+def _blocks_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from recovery_rl_amd import distributed as du
+    du.init(backend="gloo")
+    import time
+    calls = [0]
+
+    def step():                                   # rank 1 is 3x slower: the slow rank sets the time, both stop together
+        calls[0] += 1
+        time.sleep(0.001 * (1 + 2 * rank))
+    real_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        total, blocks = bench.timed_blocks(step, 10, world, torch.device("cpu"), min_seconds=0.2)
+    finally:
+        torch.cuda.synchronize = real_sync
+    q.put((rank, total, blocks, calls[0]))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_timed_blocks_agree_over_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = bench.free_port()
+    procs = [ctx.Process(target=_blocks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, t0, b0, c0), (_, t1, b1, c1) = res
+    assert b0 == b1 and c0 == c1 == 10 * b0                  # exactly K steps per block, same number of blocks
+    assert t0 == t1 and 0.2 <= t0 < 0.2 + 0.1                # max over ranks, >= the minimum duration
+    assert t0 >= 0.003 * 10 * b0 * 0.9                       # the slow rank's time
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_runs_two_ranks_and_reports_them(tmp_path):
+    """`python bench.py --gpus 2` end to end on the test box's single GPU (gloo for the 96-byte metric all-reduce, both
+    ranks on cuda:0): the line says n_gpus 2, two seeds' worth of env-steps, device-side grad-step counters."""
+    env = dict(os.environ, RRL_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--num_envs", "512", "--no_cpu_baseline", "--no_planner"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:]
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 20 and r["scaling"] == "weak"
+    assert r["timed_steps_total"] == 20 * r["timed_blocks"] and r["timed_seconds"] >= 0.5
+    assert abs(r["value"] - 2 * 512 * r["timed_steps_total"] / r["timed_seconds"]) < 1e-6 * r["value"]
+    assert r["grad_step_witness"] == "device-side Adam step counters"
+    assert abs(r["sac_grad_steps_per_s"] - 2 * r["timed_steps_total"] / r["timed_seconds"]) < 1e-6 * r["sac_grad_steps_per_s"]
+    assert r["roofline"]["kernel"].startswith("step_push_kernel")
+
+
+@pytest.mark.gpu
+def test_bench_maze_leg_and_contradicting_world_size():
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--env", "maze", "--steps", "20", "--warmup",
+                          "5", "--num_envs", "1024", "--no_cpu_baseline", "--no_planner"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["config"]["workload"].startswith("Maze, 1024")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr

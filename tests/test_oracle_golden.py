@@ -198,3 +198,22 @@ def test_c_oracle_offline_data_equals_reference_row_for_row(env, num, golden_dir
     assert np.array_equal(s, g[pre + "s"].astype(np.float32)) and np.array_equal(s2, g[pre + "s2"].astype(np.float32))
     assert np.array_equal(a, g[pre + "a"].astype(np.float32))
     assert g[pre + "c"].sum() > 10
+
+
+def test_stratified_draw_starvation_rule():
+    """Too few positives: the reference's random.sample raises (replay_memory.py:61-66) and so does the oracle; the
+    clamped variant (the lock-step loop's rule) takes all positives and fills the batch with negatives."""
+    rb = co.OracleReplay(512)
+    n = 400
+    r = np.zeros(n, np.float32)
+    r[[3, 77, 200]] = 1.0
+    z = np.zeros((n, 2), np.float32)
+    rb.push(z, z, r, z, np.ones(n, np.float32))
+    with pytest.raises(ValueError):
+        rb.sample_stratified_indices(76, 180, seed=1, counter=0)
+    idx, used = rb.sample_stratified_indices(76, 180, seed=1, counter=0, clamp=True, return_split=True)
+    assert used == 3 and sorted(idx[:3]) == [3, 77, 200] and len(set(idx)) == 256 and not r[idx[3:]].any()
+    with pytest.raises(ValueError):                     # more rows than the ring holds stays an error
+        rb.sample_stratified_indices(200, 300, seed=1, counter=0, clamp=True)
+    ok = rb.sample_stratified_indices(2, 100, seed=1, counter=0)
+    assert np.array_equal(ok, rb.sample_stratified_indices(2, 100, seed=1, counter=0, clamp=True))

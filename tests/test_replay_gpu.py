@@ -145,6 +145,46 @@ def test_stratified_sample_matches_oracle_and_reference_composition(golden_dir):
     mem.check_error()
 
 
+@pytest.mark.parametrize("n_positive,n_rows", ((20, 3000), (0, 500), (2990, 3000), (76, 3000)))
+def test_starved_stratified_draw_flags_by_default_and_clamps_on_request(n_positive, n_rows):
+    """Fewer positives (or negatives) than int(B * pos_fraction) asks for: the reference's random.sample raises
+    ValueError (replay_memory.py:61-66) -> error flag; with clamp_stratified (the lock-step loop's rule) the short class
+    gives all its rows and the other fills the batch, bit-equal to the checker's clamped draw."""
+    rng = np.random.RandomState(n_positive)
+    b = list(rows(rng, n_rows, pos_rate=0.0))
+    b[2][:] = 0.0
+    b[2][rng.permutation(n_rows)[:n_positive]] = 1.0
+    B, n_pos = 256, 76
+    starved = n_positive < n_pos or n_rows - n_positive < B - n_pos
+    mem, ora = ConstraintReplayMemory(4096, 5, device=DEV), co.OracleReplay(4096)
+    mem.push(*dev(b))
+    ora.push(*b)
+    out0 = [t.clone() for t in mem.sample(B, pos_fraction=0.3)]
+    if starved:
+        with pytest.raises(ValueError):
+            mem.check_error()
+        with pytest.raises(ValueError):
+            ora.sample_stratified_indices(n_pos, B - n_pos, seed=mem.seed, counter=0)
+        mem.state[3] = 0
+        mem.tick.zero_()
+    else:
+        mem.check_error()
+    mem2 = ConstraintReplayMemory(4096, 5, device=DEV)
+    mem2.push(*dev(b))
+    mem2.clamp_stratified = True
+    assert mem2.clamp_stratified and not mem.clamp_stratified
+    s, a, r, s2, m = mem2.sample(B, pos_fraction=0.3)
+    mem2.check_error()
+    idx = mem2._batch(B)[5].cpu().numpy()
+    ref, used = ora.sample_stratified_indices(n_pos, B - n_pos, seed=mem2.seed, counter=0, clamp=True, return_split=True)
+    assert np.array_equal(idx, ref) and len(set(idx)) == B
+    assert used == (min(n_pos, n_positive) if n_positive < n_pos else max(n_pos, B - (n_rows - n_positive)))
+    rr = r.cpu().numpy()
+    assert rr[:used].all() and not rr[used:].any()
+    if not starved:                                   # a feasible draw is unchanged by the flag
+        assert all(torch.equal(x, y) for x, y in zip(out0, (s, a, r, s2, m)))
+
+
 def test_stratified_sample_on_wrapped_million_row_buffer():
     """Reference default capacity 1e6, pushed past wrap-around in 4096-row vector steps."""
     cap = 1000000
