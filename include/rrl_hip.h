@@ -172,6 +172,26 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
                               float* r, float* s2, float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu,
                               void* stream);
 
+/* The two draws of one lock-step iteration (task buffer -> SAC update, safety buffer -> Q_risk update,
+ * experiment.py:397-416) and the iteration's policy noise (rrl_normal_fill) in ONE launch: they do not depend on
+ * each other.  A member is a rrl_replay_sample_gather call (stratified = 0, B = n_pos + n_neg) or a
+ * rrl_creplay_sample_gather call (stratified = 1); `second` and the noise part (noise_pairs = 0) are optional.
+ * Rows, indices and normals equal the stand-alone launches'. */
+typedef struct {
+    const rrl_replay_t* rb;
+    int stratified;
+    int32_t n_pos, n_neg;
+    uint64_t seed, counter;
+    uint64_t* counter_dev;
+    uint64_t counter_inc;
+    float *s, *a, *r, *s2, *m;
+    int64_t* idx_out;
+    float *xu, *x2u, *xpu;
+} rrl_draw_t;
+int rrl_sample_multi(const rrl_draw_t* first, const rrl_draw_t* second, long long noise_pairs, uint64_t noise_seed,
+                     uint64_t noise_counter, uint64_t* noise_counter_dev, uint64_t noise_counter_inc, float* noise_out,
+                     void* stream);
+
 /* Fused lock-step iteration tail: env step + reward penalty + bootstrap mask + memory.push +
  * recovery_memory.push + episode counters in ONE launch (the body of recovery_rl/experiment.py:420-461
  * for n navigation envs).  `obs` holds the current observation on entry (it is the stored `state`) and
@@ -195,6 +215,26 @@ int rrl_maze_step_push(int64_t n, double* pos, int32_t* t, float* obs,
                       const rrl_replay_t* memory, const rrl_replay_t* recovery_memory, float* next_obs,
                       float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success, uint8_t* ep_done,
                       uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
+
+/* The same fused tails with the recovery gate of Experiment.get_action (experiment.py:546-577) evaluated inside:
+ * recovery[i] = max(sigmoid(z[i]), sigmoid(z[n + i])) > eps_safe (z = pre-sigmoid twin Q_risk(s, a_task), [2,n]);
+ * executed action = recovery ? rec_action[i] : task_action[i].  real_action [n,2] and recovery [n] are OUTPUTS here
+ * (what rrl_recovery_select would have written); task_action rows are ld_task floats apart (the [s | a] input
+ * of the safety critic, ld_task = 4, can be passed as it is).  One launch less per lock-step iteration. */
+int rrl_nav_step_push_select(int env_kind, int64_t n, double* pos, int32_t* t, float* obs, const float* task_action,
+                             int ld_task, const float* z, float eps_safe, const float* rec_action, float* real_action,
+                             uint8_t* recovery, uint64_t seed, uint64_t counter, uint64_t* counter_dev,
+                             uint64_t counter_inc, int32_t horizon, int auto_reset, float reward_penalty,
+                             int push_real_action, const rrl_replay_t* memory, const rrl_replay_t* recovery_memory,
+                             float* next_obs, float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success,
+                             uint8_t* ep_done, uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
+int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, const float* task_action, int ld_task,
+                              const float* z, float eps_safe, const float* rec_action, float* real_action,
+                              uint8_t* recovery, uint64_t seed, uint64_t counter, uint64_t* counter_dev,
+                              uint64_t counter_inc, int32_t horizon, int auto_reset, float reward_penalty,
+                              int push_real_action, const rrl_replay_t* memory, const rrl_replay_t* recovery_memory,
+                              float* next_obs, float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success,
+                              uint8_t* ep_done, uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * CEM.  Replaces the bookkeeping of CEMOptimizer.obtain_solution (recovery_rl/optimizers.py:73-124)
@@ -297,6 +337,47 @@ int rrl_mlp_head_backward_loss(const rrl_loss_t* loss, int G, int B, int H, int 
                                const float* W3, float* dW3, float* db3, float* dh2, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Grouped launches.  One SAC / Q_risk update is a chain of ~40 tiny DEPENDENT kernels whose cost is the launch
+ * boundary and a few memory round trips each, not their arithmetic; kernels that do not depend on each other
+ * (the three critic forwards of sac.py:192-218 once both actions are sampled; the critic's backward for the
+ * critic loss and for the policy loss; the task policy and the recovery policy of the acting pass) share ONE
+ * launch here, so the chain is as long as its dependency depth.  Every member runs the code of its stand-alone
+ * entry point on its own workgroups: results are bit-identical to the separate launches.  n <= 4.
+ *   rrl_mlp3_forward_multi        members = rrl_mlp3_forward calls; all members must take the same path (all with
+ *                                 scratch on the split path -- partial sums stay in scratch, finalize = 0 -- or all
+ *                                 on the same plain tiling), else RRL_EINVAL
+ *   rrl_mlp_head_backward_multi   members = rrl_mlp_head_backward_loss calls (loss.kind = -1: loss.out is a plain
+ *                                 dOut tensor as in rrl_mlp_head_backward)
+ *   rrl_mlp_hidden_backward_multi members = rrl_mlp_hidden_backward calls; dW2 = db2 = NULL: only dh1
+ *   rrl_mlp_input_backward_multi  members = rrl_mlp_input_backward calls
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int G, M, H, din, dout, ldx;
+    const float *x, *W1, *b1, *W2, *b2, *W3, *b3;
+    float *h1, *h2, *out, *scratch;
+} rrl_stack_t;
+typedef struct {
+    rrl_loss_t loss;
+    int G, B, H, dout;
+    const float *h2, *W3;
+    float *dW3, *db3, *dh2;
+} rrl_head_bwd_t;
+typedef struct {
+    int G, B, H;
+    const float *dh2, *h1, *W2;
+    float *dW2, *db2, *dh1;
+} rrl_hidden_bwd_t;
+typedef struct {
+    int G, B, H, din, ldx;
+    const float *dh1, *x, *W1;
+    float *dW1, *db1, *dx;
+} rrl_input_bwd_t;
+int rrl_mlp3_forward_multi(int n, const rrl_stack_t* stacks, void* stream);
+int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* members, void* stream);
+int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* members, void* stream);
+int rrl_mlp_input_backward_multi(int n, const rrl_input_bwd_t* members, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Fused element-wise pieces of the updates (one launch each instead of a chain of PyTorch ops).
  *   rrl_gauss_head_fwd/bwd   GaussianPolicy.sample and its backward (recovery_rl/model.py:324-340);
  *                            head[b] = (mean0, mean1, log_std0, log_std1) raw linear outputs; the backward
@@ -339,6 +420,26 @@ int rrl_stoch_head_fwd(int B, const float* raw, int n_part, long long part_strid
 int rrl_stoch_head_bwd(int B, const float* raw, int n_part, long long part_stride, const float* eps,
                        const float* log_std, float min_log_std, const float* scale, const float* d_action, int ld,
                        int n_heads, long long head_stride, float* draw, float* dlog_std, void* stream);
+/* rrl_gauss_head_fwd / rrl_stoch_head_fwd calls that do not depend on each other in ONE launch (n <= 4): a' = pi(s')
+ * and pi(s) of one SAC step (sac.py:192-218), the task action and the recovery action of the acting pass
+ * (experiment.py:546-577).  kind RRL_HEAD_GAUSS: fields of rrl_gauss_head_fwd (mean_out = mean_action);
+ * RRL_HEAD_STOCH: fields of rrl_stoch_head_fwd (head = raw).  Results equal the stand-alone launches'. */
+enum { RRL_HEAD_GAUSS = 0, RRL_HEAD_STOCH = 1 };
+typedef struct {
+    int kind, B;
+    const float* head;
+    int n_part;
+    long long part_stride;
+    const float *eps, *scale, *bias;
+    float* action;
+    int ld_action;
+    float *logp, *mean_out;
+    const float* obs_in;
+    float* obs_out;
+    const float* log_std;
+    float min_log_std;
+} rrl_policy_head_t;
+int rrl_policy_heads_fwd_multi(int n, const rrl_policy_head_t* heads, void* stream);
 int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uint64_t* step_dev, float lr,
                   float beta1, float beta2, float eps, float* target, float tau, void* stream);
 /* rrl_adam_step for up to RRL_ADAM_MAX_SEGS flat buffers in one launch (e.g. critic + policy of one update);

@@ -24,10 +24,12 @@ EXPORTS = [
     "rrl_nav_step", "rrl_nav_reset", "rrl_nav_rollout", "rrl_nav_offline_rollouts",
     "rrl_nav_offline",
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
-    "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_nav_step_push", "rrl_maze_step_push",
+    "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_sample_multi",
+    "rrl_nav_step_push", "rrl_maze_step_push", "rrl_nav_step_push_select", "rrl_maze_step_push_select",
     "rrl_cem_sample", "rrl_cem_update",
     "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss", "rrl_mlp_hidden_backward",
-    "rrl_mlp_input_backward",
+    "rrl_mlp_input_backward", "rrl_mlp3_forward_multi", "rrl_mlp_head_backward_multi", "rrl_mlp_hidden_backward_multi",
+    "rrl_mlp_input_backward_multi", "rrl_policy_heads_fwd_multi",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_adam_step_multi", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
@@ -99,6 +101,42 @@ class rrl_loss_t(C.Structure):
                 ("loss", C.c_void_p)]
 
 
+class rrl_stack_t(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("G", "M", "H", "din", "dout", "ldx")] + [
+        (n, C.c_void_p) for n in ("x", "W1", "b1", "W2", "b2", "W3", "b3", "h1", "h2", "out", "scratch")]
+
+
+class rrl_head_bwd_t(C.Structure):
+    _fields_ = [("loss", rrl_loss_t)] + [(n, C.c_int) for n in ("G", "B", "H", "dout")] + [
+        (n, C.c_void_p) for n in ("h2", "W3", "dW3", "db3", "dh2")]
+
+
+class rrl_hidden_bwd_t(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("G", "B", "H")] + [
+        (n, C.c_void_p) for n in ("dh2", "h1", "W2", "dW2", "db2", "dh1")]
+
+
+class rrl_input_bwd_t(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("G", "B", "H", "din", "ldx")] + [
+        (n, C.c_void_p) for n in ("dh1", "x", "W1", "dW1", "db1", "dx")]
+
+
+HEAD_GAUSS, HEAD_STOCH = 0, 1
+
+
+class rrl_policy_head_t(C.Structure):
+    _fields_ = [("kind", C.c_int), ("B", C.c_int), ("head", C.c_void_p), ("n_part", C.c_int),
+                ("part_stride", C.c_longlong), ("eps", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
+                ("action", C.c_void_p), ("ld_action", C.c_int), ("logp", C.c_void_p), ("mean_out", C.c_void_p),
+                ("obs_in", C.c_void_p), ("obs_out", C.c_void_p), ("log_std", C.c_void_p), ("min_log_std", C.c_float)]
+
+
+class rrl_draw_t(C.Structure):
+    _fields_ = [("rb", C.POINTER(rrl_replay_t)), ("stratified", C.c_int), ("n_pos", C.c_int32), ("n_neg", C.c_int32),
+                ("seed", C.c_uint64), ("counter", C.c_uint64), ("counter_dev", C.c_void_p), ("counter_inc", C.c_uint64)] + [
+        (n, C.c_void_p) for n in ("s", "a", "r", "s2", "m", "idx_out", "xu", "x2u", "xpu")]
+
+
 class rrl_adam_seg_t(C.Structure):
     _fields_ = [("n", C.c_longlong), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
                 ("step_dev", C.c_void_p), ("target", C.c_void_p), ("tau", C.c_float), ("weight_decay", C.c_float),
@@ -139,6 +177,16 @@ def _declare(lib):
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_maze_step_push": (ci, [i64, vp, vp, vp, vp, vp, vp, u64, u64, vp, u64, i32, ci, f32, ci, rp, rp,
                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_nav_step_push_select": (ci, [ci, i64, vp, vp, vp, vp, ci, vp, f32, vp, vp, vp, u64, u64, vp, u64, i32, ci,
+                                          f32, ci, rp, rp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_maze_step_push_select": (ci, [i64, vp, vp, vp, vp, ci, vp, f32, vp, vp, vp, u64, u64, vp, u64, i32, ci,
+                                           f32, ci, rp, rp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_sample_multi": (ci, [C.POINTER(rrl_draw_t), C.POINTER(rrl_draw_t), ll, u64, u64, vp, u64, vp, vp]),
+        "rrl_mlp3_forward_multi": (ci, [ci, C.POINTER(rrl_stack_t), vp]),
+        "rrl_mlp_head_backward_multi": (ci, [ci, C.POINTER(rrl_head_bwd_t), vp]),
+        "rrl_mlp_hidden_backward_multi": (ci, [ci, C.POINTER(rrl_hidden_bwd_t), vp]),
+        "rrl_mlp_input_backward_multi": (ci, [ci, C.POINTER(rrl_input_bwd_t), vp]),
+        "rrl_policy_heads_fwd_multi": (ci, [ci, C.POINTER(rrl_policy_head_t), vp]),
         "rrl_cem_sample": (ci, [i64, i32, i32, vp, vp, vp, vp, f64, ci, vp, u64, u64, vp, u64, vp, vp]),
         "rrl_cem_update": (ci, [i64, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]),
         "rrl_gemm_f32": (ci, [ci, ci, ci, ci, ci, vp, ci, C.c_longlong, vp, ci, C.c_longlong, vp, ci,

@@ -203,6 +203,34 @@ __global__ __launch_bounds__(64) void gemm16_pair_kernel(GemmArgs tn, GemmArgs n
     }
 }
 
+// Several independent stack backwards (e.g. the critic's backward for its own loss and its backward for the policy
+// loss, sac.py:233-239) share one launch: a flat grid over (problem, head, tile).  Problems with dW2 == null
+// contribute only their NN tiles (input gradient).
+constexpr int kMaxGroup = 4;
+struct HiddenGroup {
+    GemmArgs tn[kMaxGroup], nn[kMaxGroup];
+    int tn_tiles_x[kMaxGroup], tn_tiles[kMaxGroup], nn_tiles_x[kMaxGroup], per_head[kMaxGroup], fast[kMaxGroup];
+    int first[kMaxGroup + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenGroup hg) {
+    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
+    int k = 0;
+    while (k + 1 < hg.n && (int)blockIdx.x >= hg.first[k + 1]) ++k;
+    const int local = blockIdx.x - hg.first[k];
+    const int g = local / hg.per_head[k], b = local - g * hg.per_head[k];
+    if (b < hg.tn_tiles[k]) {
+        if (hg.fast[k]) gemm16_tile<2, true>(hg.tn[k], As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
+        else gemm16_tile<2, false>(hg.tn[k], As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
+    } else {
+        const int c = b - hg.tn_tiles[k];
+        if (hg.fast[k]) gemm16_tile<1, true>(hg.nn[k], As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
+        else gemm16_tile<1, false>(hg.nn[k], As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
+    }
+}
+
 // ---- fused forward of a whole 2-hidden-layer stack -----------------------------------------------
 //   out[g] = W3[g] relu(W2[g] relu(W1[g] x + b1[g]) + b2[g]) + b3[g]      x [M, din] shared by the heads
 // One workgroup (16 waves) per 16 rows and head: layer 1 on the VALU (din <= 4), layer 2 on MFMA with
@@ -225,12 +253,9 @@ constexpr int kStackMaxH = 256;
 // R = row tiles (of 16 rows) per workgroup: they share the wave's W2 registers, so a big batch re-reads
 // W2 from L2 M / (16 R) times instead of M / 16 (the re-streaming is what bounds M = 4096).
 template <int R>
-__global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
-    // row stride H + 20 floats: the 16 rows of a ds_read_b128 lane group land on distinct 16-byte slots
-    __shared__ __attribute__((aligned(16))) float h1s[R * kStackRows * (kStackMaxH + 20)];
-    __shared__ __attribute__((aligned(16))) float h2s[R * kStackRows * (kStackMaxH + 20)];
+__device__ __forceinline__ void mlp3_fwd_body(const StackArgs& a, int bx, int g, float* h1s, float* h2s) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.y, m0 = blockIdx.x * (R * kStackRows);
+    const int m0 = bx * (R * kStackRows);
     const int H = a.H, ldh = H + 20;
     const float* W1 = a.W1 + (long long)g * H * a.din;
     const float* b1 = a.b1 + (long long)g * H;
@@ -334,6 +359,35 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
     }
 }
 
+template <int R>
+__global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
+    // row stride H + 20 floats: the 16 rows of a ds_read_b128 lane group land on distinct 16-byte slots
+    __shared__ __attribute__((aligned(16))) float h1s[R * kStackRows * (kStackMaxH + 20)];
+    __shared__ __attribute__((aligned(16))) float h2s[R * kStackRows * (kStackMaxH + 20)];
+    mlp3_fwd_body<R>(a, blockIdx.x, blockIdx.y, h1s, h2s);
+}
+
+// Several independent stacks (different networks and / or different inputs) in one launch: flat grid over
+// (stack, head, row tile).  The acting pass evaluates the task policy and the recovery policy on the same
+// observations (experiment.py:546-577): neither depends on the other.
+struct StackGroup {
+    StackArgs a[kMaxGroup];
+    float* partial[kMaxGroup];      // split variant only
+    int G[kMaxGroup], tiles[kMaxGroup];
+    int first[kMaxGroup + 1];
+    int n;
+};
+
+template <int R>
+__global__ __launch_bounds__(1024) void mlp3_fwd_group_kernel(StackGroup sg) {
+    __shared__ __attribute__((aligned(16))) float h1s[R * kStackRows * (kStackMaxH + 20)];
+    __shared__ __attribute__((aligned(16))) float h2s[R * kStackRows * (kStackMaxH + 20)];
+    int k = 0;
+    while (k + 1 < sg.n && (int)blockIdx.x >= sg.first[k + 1]) ++k;
+    const int local = blockIdx.x - sg.first[k];
+    mlp3_fwd_body<R>(sg.a[k], local % sg.tiles[k], local / sg.tiles[k], h1s, h2s);
+}
+
 // ---- small-batch variant of the fused stack forward: hidden-2 columns split over S = 4 workgroups -----
 // With B = 256 rows the kernel above has only 16 workgroups (x heads) and each must pull all of W2
 // (256 KB, ~600 wave-level loads) through ONE compute unit, which is what bounds it (~13 us).  Here each
@@ -342,11 +396,10 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
 // adds the four partials in a fixed order (deterministic).
 constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.320 ms per iteration)
 
-__global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
-    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 20)];
-    __shared__ float h2s[kStackRows * (kStackMaxH / kSplit + 1)];
+__device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* partial, int bx, int g, int z, int G,
+                                                    float* h1s, float* h2s) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.y, m0 = blockIdx.x * kStackRows, z = blockIdx.z;
+    const int m0 = bx * kStackRows;
     const int H = a.H, ldh = H + 20, HS = H / kSplit, ld2 = HS + 1;
     const int colbase = z * HS;
     const float* W1 = a.W1 + (long long)g * H * a.din;
@@ -439,8 +492,25 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float*
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 1);
         if (i == 0 && q < a.dout && m0 + r < a.M)
-            partial[(((long long)z * gridDim.y + g) * a.M + m0 + r) * a.dout + q] = v + bias3;
+            partial[(((long long)z * G + g) * a.M + m0 + r) * a.dout + q] = v + bias3;
     }
+}
+
+__global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
+    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 20)];
+    __shared__ float h2s[kStackRows * (kStackMaxH / kSplit + 1)];
+    mlp3_fwd_split_body(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, h1s, h2s);
+}
+
+// flat grid over (stack, column split, head, row tile)
+__global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg) {
+    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 20)];
+    __shared__ float h2s[kStackRows * (kStackMaxH / kSplit + 1)];
+    int k = 0;
+    while (k + 1 < sg.n && (int)blockIdx.x >= sg.first[k + 1]) ++k;
+    const int local = blockIdx.x - sg.first[k];
+    const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
+    mlp3_fwd_split_body(sg.a[k], sg.partial[k], bx, rest % sg.G[k], rest / sg.G[k], sg.G[k], h1s, h2s);
 }
 
 __global__ void sum_partials_kernel(int n, const float* __restrict__ partial, float* __restrict__ out) {
@@ -538,16 +608,28 @@ __device__ __forceinline__ float dout_at(const rrl_loss_t& a, int B, int g, int 
 
 }  // namespace loss
 
+struct HeadBwdArgs {
+    rrl_loss_t la;
+    int B, H, dout, need_w;
+    const float* h2;
+    const float* W3;
+    float* dW3;
+    float* db3;
+    float* dh2;
+};
+
 template <int KIND>
-__global__ __launch_bounds__(256) void head_bwd_loss_kernel(rrl_loss_t la, int B, int H, int dout,
-                                                            const float* __restrict__ h2,
-                                                            const float* __restrict__ W3, float* __restrict__ dW3,
-                                                            float* __restrict__ db3, float* __restrict__ dh2,
-                                                            int need_w) {
-    __shared__ float red[kSlices][4][kCols];
-    __shared__ float dsh[1024 * 4];
-    const int g = blockIdx.y, hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols;
-    const int h = blockIdx.x * kCols + hc;
+__device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx, int g, float (*red)[4][kCols],
+                                                   float* dsh) {
+    const rrl_loss_t& la = hb.la;
+    const int B = hb.B, H = hb.H, dout = hb.dout, need_w = hb.need_w;
+    const float* __restrict__ h2 = hb.h2;
+    const float* __restrict__ W3 = hb.W3;
+    float* __restrict__ dW3 = hb.dW3;
+    float* __restrict__ db3 = hb.db3;
+    float* __restrict__ dh2 = hb.dh2;
+    const int hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols;
+    const int h = bx * kCols + hc;
     const bool hok = h < H;
     const int hh = hok ? h : H - 1;
     float lsum[2] = {0.f, 0.f};
@@ -610,7 +692,7 @@ __global__ __launch_bounds__(256) void head_bwd_loss_kernel(rrl_loss_t la, int B
             for (int sl = 0; sl < kSlices; ++sl) sum += red[sl][slice][hc];
             dW3[((long long)g * dout + slice) * H + h] = sum;
         }
-        if (blockIdx.x == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + (unsigned)dout) {   // bias gradient
+        if (bx == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + (unsigned)dout) {   // bias gradient
             const int o = threadIdx.x - 128;
             float sum = 0.f;
             for (int b = 0; b < B; ++b) sum += dsh[b * dout + o];
@@ -619,7 +701,7 @@ __global__ __launch_bounds__(256) void head_bwd_loss_kernel(rrl_loss_t la, int B
     }
     // loss scalars / dlog_std: one workgroup per head reduces the per-thread terms in a fixed tree
     constexpr bool per_head = KIND == RRL_LOSS_SAC_CRITIC || KIND == RRL_LOSS_QRISK_CRITIC;
-    if (KIND == kPlainDOut || KIND == RRL_LOSS_GAUSS_HEAD || blockIdx.x != 0 || !la.loss || (!per_head && g != 0))
+    if (KIND == kPlainDOut || KIND == RRL_LOSS_GAUSS_HEAD || bx != 0 || !la.loss || (!per_head && g != 0))
         return;
     __syncthreads();
     float* r0 = &red[0][0][0];          // 1024 floats: two arrays of 256
@@ -643,22 +725,70 @@ __global__ __launch_bounds__(256) void head_bwd_loss_kernel(rrl_loss_t la, int B
     }
 }
 
+template <int KIND>
+__global__ __launch_bounds__(256) void head_bwd_loss_kernel(HeadBwdArgs hb) {
+    __shared__ float red[kSlices][4][kCols];
+    __shared__ float dsh[1024 * 4];
+    head_bwd_loss_body<KIND>(hb, blockIdx.x, blockIdx.y, red, dsh);
+}
+
+__device__ __forceinline__ void head_bwd_dispatch(const HeadBwdArgs& hb, int bx, int g, float (*red)[4][kCols],
+                                                  float* dsh) {
+    switch (hb.la.kind) {
+        case RRL_LOSS_SAC_CRITIC: head_bwd_loss_body<RRL_LOSS_SAC_CRITIC>(hb, bx, g, red, dsh); break;
+        case RRL_LOSS_SAC_POLICY: head_bwd_loss_body<RRL_LOSS_SAC_POLICY>(hb, bx, g, red, dsh); break;
+        case RRL_LOSS_QRISK_CRITIC: head_bwd_loss_body<RRL_LOSS_QRISK_CRITIC>(hb, bx, g, red, dsh); break;
+        case RRL_LOSS_QRISK_POLICY: head_bwd_loss_body<RRL_LOSS_QRISK_POLICY>(hb, bx, g, red, dsh); break;
+        case RRL_LOSS_GAUSS_HEAD: head_bwd_loss_body<RRL_LOSS_GAUSS_HEAD>(hb, bx, g, red, dsh); break;
+        case RRL_LOSS_STOCH_HEAD: head_bwd_loss_body<RRL_LOSS_STOCH_HEAD>(hb, bx, g, red, dsh); break;
+        default: head_bwd_loss_body<kPlainDOut>(hb, bx, g, red, dsh); break;
+    }
+}
+
+// independent head backwards (e.g. critic loss on (s,a) and policy loss on (s,pi)) in one launch: flat grid over
+// (problem, head, column block)
+struct HeadBwdGroup {
+    HeadBwdArgs p[kMaxGroup];
+    int G[kMaxGroup], blocks_x[kMaxGroup];
+    int first[kMaxGroup + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void head_bwd_group_kernel(HeadBwdGroup hg) {
+    __shared__ float red[kSlices][4][kCols];
+    __shared__ float dsh[1024 * 4];
+    int k = 0;
+    while (k + 1 < hg.n && (int)blockIdx.x >= hg.first[k + 1]) ++k;
+    const int local = blockIdx.x - hg.first[k];
+    head_bwd_dispatch(hg.p[k], local % hg.blocks_x[k], local / hg.blocks_x[k], red, dsh);
+}
+
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
 //   dW1[g][h][d] = sum_b dh1[g][b][h] x[b][d]     db1[g][h] = sum_b dh1[g][b][h]          (need_w)
 //   dx[g][b][d]  = sum_h dh1[g][b][h] W1[g][h][d]                                         (need_x)
 // grid (H / 16 + B / 4, G) x 256 threads: the first H/16 blocks do the weight gradients (16 columns x 16
 // batch slices, as above), the remaining ones the input gradients (one wavefront per batch row).
-__global__ __launch_bounds__(256) void input_bwd_kernel(int B, int H, int din,
-                                                        const float* __restrict__ dh1,
-                                                        const float* __restrict__ x, int ldx,
-                                                        const float* __restrict__ W1, float* __restrict__ dW1,
-                                                        float* __restrict__ db1, float* __restrict__ dx,
-                                                        int need_w, int need_x) {
-    __shared__ float red[kSlices][5][kCols];
-    const int g = blockIdx.y;
+struct InputBwdArgs {
+    int B, H, din, ldx, need_w, need_x;
+    const float* dh1;
+    const float* x;
+    const float* W1;
+    float* dW1;
+    float* db1;
+    float* dx;
+};
+
+__device__ __forceinline__ void input_bwd_body(const InputBwdArgs& ib, int bx, int g, float (*red)[5][kCols]) {
+    const int B = ib.B, H = ib.H, din = ib.din, ldx = ib.ldx, need_w = ib.need_w, need_x = ib.need_x;
+    const float* __restrict__ dh1 = ib.dh1;
+    const float* __restrict__ x = ib.x;
+    const float* __restrict__ W1 = ib.W1;
+    float* __restrict__ dW1 = ib.dW1;
+    float* __restrict__ db1 = ib.db1;
+    float* __restrict__ dx = ib.dx;
     const int wblocks = need_w ? (H + kCols - 1) / kCols : 0;
-    if ((int)blockIdx.x < wblocks) {
-        const int hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols, h = blockIdx.x * kCols + hc;
+    if (bx < wblocks) {
+        const int hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols, h = bx * kCols + hc;
         const bool hok = h < H;
         const int hh = hok ? h : H - 1;
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -694,7 +824,7 @@ __global__ __launch_bounds__(256) void input_bwd_kernel(int B, int H, int din,
     }
     if (!need_x) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = ((int)blockIdx.x - wblocks) * 4 + wave;
+    const int b = (bx - wblocks) * 4 + wave;
     if (b >= B) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int h0 = 0; h0 < H; h0 += 256) {
@@ -718,6 +848,26 @@ __global__ __launch_bounds__(256) void input_bwd_kernel(int B, int H, int din,
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if (lane == 0 && k < din) dx[((long long)g * B + b) * din + k] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void input_bwd_kernel(InputBwdArgs ib) {
+    __shared__ float red[kSlices][5][kCols];
+    input_bwd_body(ib, blockIdx.x, blockIdx.y, red);
+}
+
+struct InputBwdGroup {
+    InputBwdArgs p[kMaxGroup];
+    int G[kMaxGroup], blocks_x[kMaxGroup];
+    int first[kMaxGroup + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void input_bwd_group_kernel(InputBwdGroup ig) {
+    __shared__ float red[kSlices][5][kCols];
+    int k = 0;
+    while (k + 1 < ig.n && (int)blockIdx.x >= ig.first[k + 1]) ++k;
+    const int local = blockIdx.x - ig.first[k];
+    input_bwd_body(ig.p[k], local % ig.blocks_x[k], local / ig.blocks_x[k], red);
 }
 
 }  // namespace
@@ -751,33 +901,68 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
     return check_launch();
 }
 
+// GemmArgs of one stack's hidden-layer backward (TN: dW2 + db2; NN: dh1)
+static bool hidden_args(int G, int B, int H, const float* dh2, const float* h1, const float* W2, float* dW2, float* db2,
+                        float* dh1, GemmArgs& tn, GemmArgs& nn) {
+    const long long sAct = (long long)B * H, sW = (long long)H * H;
+    // TN: dW2 [H,H] = dh2^T [H,B] . h1 [B,H], column sums of dh2 -> db2        (A = dh2, K = B)
+    tn = GemmArgs{dh2, h1, dW2, nullptr, nullptr, db2, H, H, B, H, H, H, 0, sAct, sAct, sW, 0, 0, (long long)H, 0, 0};
+    // NN: dh1 [B,H] = dh2 [B,H] . W2 [H,H], masked by h1 > 0                     (K = H)
+    nn = GemmArgs{dh2, W2, dh1, nullptr, h1, nullptr, B, H, H, H, H, H, H, sAct, sW, sAct, 0, sAct, 0, 0, 0};
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return (H % kTile) == 0 && (B % kTile) == 0 && (H % kPanel) == 0 && (B % kPanel) == 0 && al(dh2) && al(h1) && al(W2);
+}
+
 int rrl_mlp_hidden_backward(int G, int B, int H, const float* dh2, const float* h1, const float* W2, float* dW2,
                             float* db2, float* dh1, void* stream) {
     if (!dh2 || !h1 || !W2 || !dW2 || !db2 || !dh1) return RRL_EINVAL;
     if (G <= 0 || G > 65535 || B <= 0 || H <= 0) return RRL_ERANGE;
-    const long long sAct = (long long)B * H, sW = (long long)H * H;
-    // TN: dW2 [H,H] = dh2^T [H,B] . h1 [B,H], column sums of dh2 -> db2        (A = dh2, K = B)
-    GemmArgs tn{dh2, h1, dW2, nullptr, nullptr, db2, H, H, B, H, H, H, 0, sAct, sAct, sW, 0, 0, (long long)H, 0, 0};
-    // NN: dh1 [B,H] = dh2 [B,H] . W2 [H,H], masked by h1 > 0                     (K = H)
-    GemmArgs nn{dh2, W2, dh1, nullptr, h1, nullptr, B, H, H, H, H, H, H, sAct, sW, sAct, 0, sAct, 0, 0, 0};
+    GemmArgs tn, nn;
+    const bool fast = hidden_args(G, B, H, dh2, h1, W2, dW2, db2, dh1, tn, nn);
     const int tx = (H + kTile - 1) / kTile, ty = tx, nx = tx, ny = (B + kTile - 1) / kTile;
-    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    const bool fast = (H % kTile) == 0 && (B % kTile) == 0 && (H % kPanel) == 0 && (B % kPanel) == 0 && al(dh2) &&
-                      al(h1) && al(W2);
     const dim3 grid(tx * ty + nx * ny, G), block(64);
     if (fast) hipLaunchKernelGGL(gemm16_pair_kernel<true>, grid, block, 0, (hipStream_t)stream, tn, nn, tx, tx * ty, nx);
     else hipLaunchKernelGGL(gemm16_pair_kernel<false>, grid, block, 0, (hipStream_t)stream, tn, nn, tx, tx * ty, nx);
     return check_launch();
 }
 
+int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* stream) {
+    if (!ps || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
+    HiddenGroup hg{};
+    hg.n = n;
+    hg.first[0] = 0;
+    for (int k = 0; k < n; ++k) {
+        const rrl_hidden_bwd_t& p = ps[k];
+        if (!p.dh2 || !p.h1 || !p.W2 || !p.dh1 || ((p.dW2 == nullptr) != (p.db2 == nullptr))) return RRL_EINVAL;
+        if (p.G <= 0 || p.G > 65535 || p.B <= 0 || p.H <= 0) return RRL_ERANGE;
+        hg.fast[k] = hidden_args(p.G, p.B, p.H, p.dh2, p.h1, p.W2, p.dW2, p.db2, p.dh1, hg.tn[k], hg.nn[k]);
+        const int tx = (p.H + kTile - 1) / kTile, ny = (p.B + kTile - 1) / kTile;
+        hg.tn_tiles_x[k] = tx;
+        hg.tn_tiles[k] = p.dW2 ? tx * tx : 0;           // no weight gradient wanted: input gradient tiles only
+        hg.nn_tiles_x[k] = tx;
+        hg.per_head[k] = hg.tn_tiles[k] + tx * ny;
+        hg.first[k + 1] = hg.first[k] + hg.per_head[k] * p.G;
+    }
+    for (int k = n; k < kMaxGroup; ++k) hg.first[k + 1] = hg.first[n];
+    hipLaunchKernelGGL(gemm16_group_kernel, dim3(hg.first[n]), dim3(64), 0, (hipStream_t)stream, hg);
+    return check_launch();
+}
+
 int rrl_mlp3_is_split(int M, int H) { return (M <= 1024 && (H % (16 * kSplit)) == 0 && H <= kStackMaxH) ? kSplit : 0; }
+
+static int stack_check(int G, int M, int H, int din, int dout, const float* x, const float* W1, const float* b1,
+                       const float* W2, const float* b2, const float* W3, const float* b3, const float* out) {
+    if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return RRL_EINVAL;
+    if (G <= 0 || G > 65535 || M <= 0 || din <= 0 || din > 4 || dout <= 0 || dout > 4) return RRL_ERANGE;
+    if (H <= 0 || H > kStackMaxH || (H % 16) != 0) return RRL_ERANGE;
+    return RRL_OK;
+}
 
 int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int ldx, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
                      float* h1, float* h2, float* out, float* scratch, int finalize, void* stream) {
-    if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return RRL_EINVAL;
-    if (G <= 0 || G > 65535 || M <= 0 || din <= 0 || din > 4 || dout <= 0 || dout > 4) return RRL_ERANGE;
-    if (H <= 0 || H > kStackMaxH || (H % 16) != 0) return RRL_ERANGE;
+    const int rc = stack_check(G, M, H, din, dout, x, W1, b1, W2, b2, W3, b3, out);
+    if (rc != RRL_OK) return rc;
     StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx};
     if (scratch && rrl_mlp3_is_split(M, H)) {
         // small batch: 4 workgroups per row tile + fixed-order sum of their partial last-layer outputs
@@ -800,32 +985,89 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
     return check_launch();
 }
 
+// Every stack of the group takes the path rrl_mlp3_forward would take for it on its own (so the results are the
+// stand-alone launches', bit for bit); the group must be homogeneous: all split (scratch given, partial sums left in
+// scratch = finalize 0) or all on the same non-split tiling.
+int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
+    if (!st || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
+    StackGroup sg{};
+    sg.n = n;
+    sg.first[0] = 0;
+    int path = -1;   // 0 split, 1 R = 1, 2 R = 2
+    for (int k = 0; k < n; ++k) {
+        const rrl_stack_t& p = st[k];
+        const int rc = stack_check(p.G, p.M, p.H, p.din, p.dout, p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.out);
+        if (rc != RRL_OK) return rc;
+        sg.a[k] = StackArgs{p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.h1, p.h2, p.out, p.M, p.H, p.din, p.dout, p.ldx};
+        sg.partial[k] = p.scratch;
+        sg.G[k] = p.G;
+        int my;
+        const long long tiles16 = (p.M + kStackRows - 1) / kStackRows;
+        if (p.scratch && rrl_mlp3_is_split(p.M, p.H)) {
+            my = 0;
+            sg.tiles[k] = int(tiles16);
+            sg.first[k + 1] = sg.first[k] + int(tiles16) * p.G * kSplit;
+        } else if (tiles16 * p.G > 256) {
+            my = 2;
+            sg.tiles[k] = (p.M + 2 * kStackRows - 1) / (2 * kStackRows);
+            sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G;
+        } else {
+            my = 1;
+            sg.tiles[k] = int(tiles16);
+            sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G;
+        }
+        if (path >= 0 && my != path) return RRL_EINVAL;
+        path = my;
+    }
+    for (int k = n; k < kMaxGroup; ++k) sg.first[k + 1] = sg.first[n];
+    hipStream_t s = (hipStream_t)stream;
+    if (path == 0) hipLaunchKernelGGL(mlp3_fwd_split_group_kernel, dim3(sg.first[n]), dim3(256), 0, s, sg);
+    else if (path == 1) hipLaunchKernelGGL((mlp3_fwd_group_kernel<1>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
+    else hipLaunchKernelGGL((mlp3_fwd_group_kernel<2>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
+    return check_launch();
+}
+
 int rrl_mlp_head_backward(int G, int B, int H, int dout, const float* dOut, const float* h2, const float* W3,
                           float* dW3, float* db3, float* dh2, void* stream) {
     if (!dOut || !h2 || !W3 || !dh2) return RRL_EINVAL;
     if (G <= 0 || B <= 0 || B > 1024 || H <= 0 || dout <= 0 || dout > 4) return RRL_ERANGE;
-    const int need_w = dW3 != nullptr && db3 != nullptr;
-    rrl_loss_t la{};
-    la.out = dOut;
+    HeadBwdArgs hb{};
+    hb.la.kind = kPlainDOut;
+    hb.la.out = dOut;
+    hb.B = B; hb.H = H; hb.dout = dout; hb.need_w = dW3 != nullptr && db3 != nullptr;
+    hb.h2 = h2; hb.W3 = W3; hb.dW3 = dW3; hb.db3 = db3; hb.dh2 = dh2;
     hipLaunchKernelGGL((head_bwd_loss_kernel<kPlainDOut>), dim3((H + kCols - 1) / kCols, G), dim3(256), 0,
-                       (hipStream_t)stream, la, B, H, dout, h2, W3, dW3, db3, dh2, need_w);
+                       (hipStream_t)stream, hb);
     return check_launch();
+}
+
+static int head_loss_args(const rrl_loss_t* la, int G, int B, int H, int dout, const float* h2, const float* W3,
+                          float* dW3, float* db3, float* dh2, HeadBwdArgs& hb) {
+    if (!la || !la->out || !h2 || !W3 || !dh2) return RRL_EINVAL;
+    if (G <= 0 || B <= 0 || B > 1024 || H <= 0 || dout <= 0 || dout > 4) return RRL_ERANGE;
+    if (la->kind != kPlainDOut) {
+        if (la->kind < 0 || la->kind > RRL_LOSS_STOCH_HEAD || la->n_part <= 0) return RRL_ERANGE;
+        const int heads = la->kind <= RRL_LOSS_QRISK_POLICY ? 2 : 1;
+        const int width = la->kind <= RRL_LOSS_QRISK_POLICY ? 1 : (la->kind == RRL_LOSS_GAUSS_HEAD ? 4 : 2);
+        if (G != heads || dout != width) return RRL_EINVAL;
+    }
+    hb.la = *la;
+    hb.B = B; hb.H = H; hb.dout = dout; hb.need_w = dW3 != nullptr && db3 != nullptr;
+    hb.h2 = h2; hb.W3 = W3; hb.dW3 = dW3; hb.db3 = db3; hb.dh2 = dh2;
+    return RRL_OK;
 }
 
 int rrl_mlp_head_backward_loss(const rrl_loss_t* la, int G, int B, int H, int dout, const float* h2,
                                const float* W3, float* dW3, float* db3, float* dh2, void* stream) {
-    if (!la || !la->out || !h2 || !W3 || !dh2) return RRL_EINVAL;
-    if (G <= 0 || B <= 0 || B > 1024 || H <= 0 || dout <= 0 || dout > 4 || la->n_part <= 0) return RRL_ERANGE;
-    const int heads = la->kind <= RRL_LOSS_QRISK_POLICY ? 2 : 1;
-    const int width = la->kind <= RRL_LOSS_QRISK_POLICY ? 1 : (la->kind == RRL_LOSS_GAUSS_HEAD ? 4 : 2);
-    if (G != heads || dout != width) return RRL_EINVAL;
-    const int need_w = dW3 != nullptr && db3 != nullptr;
+    HeadBwdArgs hb{};
+    if (la && la->kind == kPlainDOut) return RRL_EINVAL;
+    const int rc = head_loss_args(la, G, B, H, dout, h2, W3, dW3, db3, dh2, hb);
+    if (rc != RRL_OK) return rc;
     const dim3 grid((H + kCols - 1) / kCols, G), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define RRL_LAUNCH_LOSS(K)                                                                                   \
-    case K:                                                                                                  \
-        hipLaunchKernelGGL((head_bwd_loss_kernel<K>), grid, block, 0, st, *la, B, H, dout, h2, W3, dW3, db3, \
-                           dh2, need_w);                                                                     \
+#define RRL_LAUNCH_LOSS(K)                                                            \
+    case K:                                                                           \
+        hipLaunchKernelGGL((head_bwd_loss_kernel<K>), grid, block, 0, st, hb);        \
         break;
     switch (la->kind) {
         RRL_LAUNCH_LOSS(RRL_LOSS_SAC_CRITIC)
@@ -841,15 +1083,65 @@ int rrl_mlp_head_backward_loss(const rrl_loss_t* la, int G, int B, int H, int do
     return check_launch();
 }
 
-int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const float* x, int ldx,
-                           const float* W1, float* dW1, float* db1, float* dx, void* stream) {
+int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
+    if (!ps || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
+    HeadBwdGroup hg{};
+    hg.n = n;
+    hg.first[0] = 0;
+    for (int k = 0; k < n; ++k) {
+        const rrl_head_bwd_t& p = ps[k];
+        const int rc = head_loss_args(&p.loss, p.G, p.B, p.H, p.dout, p.h2, p.W3, p.dW3, p.db3, p.dh2, hg.p[k]);
+        if (rc != RRL_OK) return rc;
+        hg.G[k] = p.G;
+        hg.blocks_x[k] = (p.H + kCols - 1) / kCols;
+        hg.first[k + 1] = hg.first[k] + hg.blocks_x[k] * p.G;
+    }
+    for (int k = n; k < kMaxGroup; ++k) hg.first[k + 1] = hg.first[n];
+    hipLaunchKernelGGL(head_bwd_group_kernel, dim3(hg.first[n]), dim3(256), 0, (hipStream_t)stream, hg);
+    return check_launch();
+}
+
+static int input_args(int G, int B, int H, int din, const float* dh1, const float* x, int ldx, const float* W1,
+                      float* dW1, float* db1, float* dx, InputBwdArgs& ib, int& blocks) {
     if (!dh1 || !x || !W1) return RRL_EINVAL;
     if (G <= 0 || B <= 0 || H <= 0 || din <= 0 || din > 4) return RRL_ERANGE;
     const int need_w = dW1 != nullptr && db1 != nullptr, need_x = dx != nullptr;
-    if (!need_w && !need_x) return RRL_OK;
-    const int blocks = (need_w ? (H + kCols - 1) / kCols : 0) + (need_x ? (B + 3) / 4 : 0);
-    hipLaunchKernelGGL(input_bwd_kernel, dim3(blocks, G), dim3(256), 0, (hipStream_t)stream, B, H, din, dh1, x, ldx,
-                       W1, dW1, db1, dx, need_w, need_x);
+    ib = InputBwdArgs{B, H, din, ldx, need_w, need_x, dh1, x, W1, dW1, db1, dx};
+    blocks = (need_w ? (H + kCols - 1) / kCols : 0) + (need_x ? (B + 3) / 4 : 0);
+    return RRL_OK;
+}
+
+int rrl_mlp_input_backward(int G, int B, int H, int din, const float* dh1, const float* x, int ldx,
+                           const float* W1, float* dW1, float* db1, float* dx, void* stream) {
+    InputBwdArgs ib;
+    int blocks;
+    const int rc = input_args(G, B, H, din, dh1, x, ldx, W1, dW1, db1, dx, ib, blocks);
+    if (rc != RRL_OK) return rc;
+    if (blocks == 0) return RRL_OK;
+    hipLaunchKernelGGL(input_bwd_kernel, dim3(blocks, G), dim3(256), 0, (hipStream_t)stream, ib);
+    return check_launch();
+}
+
+int rrl_mlp_input_backward_multi(int n, const rrl_input_bwd_t* ps, void* stream) {
+    if (!ps || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
+    InputBwdGroup ig{};
+    ig.first[0] = 0;
+    int m = 0;
+    for (int k = 0; k < n; ++k) {
+        const rrl_input_bwd_t& p = ps[k];
+        int blocks;
+        const int rc = input_args(p.G, p.B, p.H, p.din, p.dh1, p.x, p.ldx, p.W1, p.dW1, p.db1, p.dx, ig.p[m], blocks);
+        if (rc != RRL_OK) return rc;
+        if (blocks == 0) continue;
+        ig.G[m] = p.G;
+        ig.blocks_x[m] = blocks;
+        ig.first[m + 1] = ig.first[m] + blocks * p.G;
+        ++m;
+    }
+    if (m == 0) return RRL_OK;
+    ig.n = m;
+    for (int k = m; k < kMaxGroup; ++k) ig.first[k + 1] = ig.first[m];
+    hipLaunchKernelGGL(input_bwd_group_kernel, dim3(ig.first[m]), dim3(256), 0, (hipStream_t)stream, ig);
     return check_launch();
 }
 

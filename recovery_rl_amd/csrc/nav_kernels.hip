@@ -489,6 +489,15 @@ int rrl_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed, float*
     return check_launch();
 }
 
+static int nav_step_push_launch(int env_kind, const rrl_step::StepPushArgs& p, int64_t n, void* stream) {
+    const dim3 grid(grid_for(n)), block(kBlock);
+    if (env_kind == RRL_ENV_NAV1)
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<0>>), grid, block, 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<1>>), grid, block, 0, (hipStream_t)stream, p);
+    return check_launch();
+}
+
 int rrl_nav_step_push(int env_kind, int64_t n, double* pos, int32_t* t, float* obs,
                       const float* task_action, const float* real_action, const uint8_t* recovery,
                       uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
@@ -497,32 +506,31 @@ int rrl_nav_step_push(int env_kind, int64_t n, double* pos, int32_t* t, float* o
                       float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success, uint8_t* ep_done,
                       uint64_t* stats, double* reward_sums, float* ep_reward, void* stream) {
     if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
-    if (n < 0 || n > 0xffffffffLL) return RRL_ERANGE;
-    if (!pos || !t || !obs || !task_action || !real_action || !memory || !next_obs || !reward || !done ||
-        !constraint || !success || !stats || !reward_sums || !ep_reward)
-        return RRL_EINVAL;
-    if (n > memory->cap || (recovery_memory && n > recovery_memory->cap)) return RRL_ERANGE;
-    if (n == 0) return RRL_OK;
     rrl_step::StepPushArgs p;
-    p.step = StepArgs{n, (double2*)pos, (const float2*)real_action, nullptr, seed, counter, counter_dev,
-                      counter_inc, (float2*)next_obs, (float2*)obs, reward, done, constraint, success, ep_done,
-                      t, horizon, auto_reset};
-    p.task_action = (const float2*)task_action;
-    p.recovery = recovery;
-    p.reward_penalty = reward_penalty;
-    p.push_real_action = push_real_action;
-    p.memory = *memory;
-    p.use_recovery_memory = recovery_memory != nullptr;
-    p.recovery_memory = recovery_memory ? *recovery_memory : *memory;
-    p.stats = (unsigned long long*)stats;
-    p.reward_sums = reward_sums;
-    p.ep_reward = ep_reward;
-    const dim3 grid(grid_for(n)), block(kBlock);
-    if (env_kind == RRL_ENV_NAV1)
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<0>>), grid, block, 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<1>>), grid, block, 0, (hipStream_t)stream, p);
-    return check_launch();
+    const int rc = rrl_step::fill_args(p, n, pos, t, obs, task_action, 2, real_action, recovery, nullptr, seed, counter,
+                                       counter_dev, counter_inc, horizon, auto_reset, reward_penalty, push_real_action,
+                                       memory, recovery_memory, next_obs, reward, done, constraint, success, ep_done,
+                                       stats, reward_sums, ep_reward);
+    if (rc != RRL_OK || n == 0) return rc;
+    return nav_step_push_launch(env_kind, p, n, stream);
+}
+
+int rrl_nav_step_push_select(int env_kind, int64_t n, double* pos, int32_t* t, float* obs, const float* task_action,
+                             int ld_task, const float* z, float eps_safe, const float* rec_action, float* real_action,
+                             uint8_t* recovery, uint64_t seed, uint64_t counter, uint64_t* counter_dev,
+                             uint64_t counter_inc, int32_t horizon, int auto_reset, float reward_penalty,
+                             int push_real_action, const rrl_replay_t* memory, const rrl_replay_t* recovery_memory,
+                             float* next_obs, float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success,
+                             uint8_t* ep_done, uint64_t* stats, double* reward_sums, float* ep_reward, void* stream) {
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
+    rrl_step::StepPushArgs p;
+    const rrl_step::SelectIn sel{z, eps_safe, rec_action, real_action, recovery};
+    const int rc = rrl_step::fill_args(p, n, pos, t, obs, task_action, ld_task, nullptr, nullptr, &sel, seed, counter,
+                                       counter_dev, counter_inc, horizon, auto_reset, reward_penalty, push_real_action,
+                                       memory, recovery_memory, next_obs, reward, done, constraint, success, ep_done,
+                                       stats, reward_sums, ep_reward);
+    if (rc != RRL_OK || n == 0) return rc;
+    return nav_step_push_launch(env_kind, p, n, stream);
 }
 
 }  // extern "C"

@@ -206,12 +206,9 @@ __device__ __forceinline__ void gather_row(const rrl_replay_t& rb, int64_t slot,
     if (out.xpu) ((float2*)out.xpu)[2 * i] = s;
 }
 
-__global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, int B, uint64_t seed,
-                                                             uint64_t counter,
-                                                             uint64_t* counter_dev,
-                                                             uint64_t counter_inc, int table_mask,
-                                                             BatchOut out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void sample_gather_body(const rrl_replay_t& rb, int B, uint64_t seed, uint64_t counter,
+                                                   uint64_t* counter_dev, uint64_t counter_inc, int table_mask,
+                                                   const BatchOut& out, char* smem) {
     unsigned long long* table = (unsigned long long*)smem;      // [table_mask + 1]
     uint32_t* key = (uint32_t*)(table + table_mask + 1);
     const int64_t size = rb.state[1];
@@ -220,7 +217,7 @@ __global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, in
         return;
     }
     const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
-    rrl::advance_counter(counter_dev, counter_inc);
+    rrl::advance_counter_blocks(counter_dev, counter_inc, 1);        // one workgroup per draw
     const int i = threadIdx.x;
     if (!draw_distinct(i, B, 0, uint64_t(size), seed, rrl::kStreamSample, ctr, i, key, table, table_mask)) {
         if (threadIdx.x == 0) rb.state[3] = 2;
@@ -229,14 +226,20 @@ __global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, in
     if (i < B) gather_row(rb, int64_t(key[i] & 0x7fffffffu), i, out);
 }
 
-// Stratified: lanes [0,n_pos) draw ranks among positives, lanes [n_pos,B) among negatives.
-__global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_t rb, int n_pos,
-                                                                     int n_neg, int n_chunks,
-                                                                     uint64_t seed, uint64_t counter,
-                                                                     uint64_t* counter_dev,
-                                                                     uint64_t counter_inc, int table_mask,
-                                                                     BatchOut out) {
+__global__ __launch_bounds__(1024) void sample_gather_kernel(rrl_replay_t rb, int B, uint64_t seed,
+                                                             uint64_t counter,
+                                                             uint64_t* counter_dev,
+                                                             uint64_t counter_inc, int table_mask,
+                                                             BatchOut out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    sample_gather_body(rb, B, seed, counter, counter_dev, counter_inc, table_mask, out, smem);
+}
+
+// Stratified: lanes [0,n_pos) draw ranks among positives, lanes [n_pos,B) among negatives.
+__device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& rb, int n_pos, int n_neg, int n_chunks,
+                                                           uint64_t seed, uint64_t counter, uint64_t* counter_dev,
+                                                           uint64_t counter_inc, int table_mask, const BatchOut& out,
+                                                           char* smem) {
     const int B = n_pos + n_neg;
     unsigned long long* table = (unsigned long long*)smem;      // [table_mask + 1]
     uint32_t* key = (uint32_t*)(table + table_mask + 1);
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
         n_neg = B - n_pos;
     }
     const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
-    rrl::advance_counter(counter_dev, counter_inc);
+    rrl::advance_counter_blocks(counter_dev, counter_inc, 1);
     const bool is_pos = tid < n_pos;
     const uint64_t population = uint64_t(is_pos ? total_pos : total_neg);
     const uint32_t stream = is_pos ? rrl::kStreamSample : rrl::kStreamSampleNeg;
@@ -357,6 +360,61 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
     gather_row(rb, slot, tid, out);
 }
 
+__global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_t rb, int n_pos,
+                                                                     int n_neg, int n_chunks,
+                                                                     uint64_t seed, uint64_t counter,
+                                                                     uint64_t* counter_dev,
+                                                                     uint64_t counter_inc, int table_mask,
+                                                                     BatchOut out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    creplay_sample_gather_body(rb, n_pos, n_neg, n_chunks, seed, counter, counter_dev, counter_inc, table_mask, out,
+                               smem);
+}
+
+// The two draws of one lock-step iteration (task buffer for the SAC update, safety buffer for the Q_risk update:
+// experiment.py:397-416) and the iteration's policy noise do not depend on each other: one launch, workgroup 0 and 1
+// are the samplers (exactly the stand-alone kernels' code), the remaining workgroups fill the noise buffer.
+struct DrawArgs {
+    rrl_replay_t rb;
+    int mode;            // 0: none, 1: uniform (sample_gather), 2: stratified (creplay_sample_gather)
+    int B, n_pos, n_neg, n_chunks, table_mask;
+    uint64_t seed, counter;
+    uint64_t* counter_dev;
+    uint64_t counter_inc;
+    BatchOut out;
+};
+struct NoiseArgs {
+    long long n_pairs;
+    uint64_t seed, counter;
+    uint64_t* counter_dev;
+    uint64_t counter_inc;
+    float* out;
+    int blocks;
+};
+
+__device__ __forceinline__ void draw_body(const DrawArgs& d, char* smem) {
+    if (d.mode == 1)
+        sample_gather_body(d.rb, d.B, d.seed, d.counter, d.counter_dev, d.counter_inc, d.table_mask, d.out, smem);
+    else if (d.mode == 2)
+        creplay_sample_gather_body(d.rb, d.n_pos, d.n_neg, d.n_chunks, d.seed, d.counter, d.counter_dev, d.counter_inc,
+                                   d.table_mask, d.out, smem);
+}
+
+__global__ __launch_bounds__(1024) void sample_group_kernel(DrawArgs a, DrawArgs b, NoiseArgs nz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x == 0) { draw_body(a, smem); return; }
+    if (blockIdx.x == 1) { draw_body(b, smem); return; }
+    // N(0,1) pairs of Philox stream RRL_STREAM_NOISE (rrl_normal_fill)
+    const uint64_t ctr = rrl::effective_counter(nz.counter, nz.counter_dev);
+    const long long stride = (long long)nz.blocks * blockDim.x;
+    for (long long i = (long long)(blockIdx.x - 2) * blockDim.x + threadIdx.x; i < nz.n_pairs; i += stride) {
+        double z0, z1;
+        rrl::normal_at(nz.seed, uint32_t(i), rrl::kStreamNoise, ctr, z0, z1);
+        reinterpret_cast<float2*>(nz.out)[i] = make_float2(float(z0), float(z1));
+    }
+    rrl::advance_counter_blocks(nz.counter_dev, nz.counter_inc, unsigned(nz.blocks));
+}
+
 inline bool valid_rb(const rrl_replay_t* rb) {
     return rb && rb->s && rb->a && rb->r && rb->s2 && rb->m && rb->state && rb->cap > 0;
 }
@@ -383,6 +441,76 @@ int rrl_replay_push(const rrl_replay_t* rb, int64_t n, const float* s, const flo
     hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, st, valid, n, scratch);
     hipLaunchKernelGGL(push_masked_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, st, *rb, n, in,
                        valid, (const int32_t*)scratch);
+    return check_launch();
+}
+
+// launch parameters of one draw (threads, dynamic LDS) shared by the stand-alone and the grouped entry points
+static int draw_setup(const rrl_draw_t& d, DrawArgs& a, int& threads, size_t& lds) {
+    const rrl_replay_t* rb = d.rb;
+    if (!valid_rb(rb) || !d.s || !d.a || !d.r || !d.s2 || !d.m) return RRL_EINVAL;
+    a.rb = *rb;
+    a.seed = d.seed; a.counter = d.counter; a.counter_dev = d.counter_dev; a.counter_inc = d.counter_inc;
+    a.out = BatchOut{(float2*)d.s, (float2*)d.a, d.r, (float2*)d.s2, d.m, d.idx_out, (float4*)d.xu, (float4*)d.x2u,
+                     (float4*)d.xpu};
+    const int B = d.n_pos + d.n_neg;
+    if (d.n_pos < 0 || d.n_neg < 0 || B <= 0 || B > 1024) return RRL_ERANGE;
+    a.B = B; a.n_pos = d.n_pos; a.n_neg = d.n_neg;
+    int table_size = 64;
+    while (table_size < 4 * B) table_size <<= 1;
+    a.table_mask = table_size - 1;
+    threads = ((B + 63) / 64) * 64;
+    if (!d.stratified) {
+        if (rb->cap >= (int64_t(1) << 31)) return RRL_ERANGE;
+        a.mode = 1;
+        a.n_chunks = 0;
+        lds = size_t(table_size) * 8 + size_t(B) * 4 + 16;
+        return RRL_OK;
+    }
+    if (!rb->pos_cnt) return RRL_EINVAL;
+    if (rb->cap > (int64_t(1) << 21)) return RRL_ERANGE;
+    a.mode = 2;
+    a.n_chunks = int((rb->cap + kChunk - 1) / kChunk);
+    if (threads < 256) threads = 256;
+    if (a.n_chunks > 4096) threads = 1024;                 // the count-table scan dominates: spread it
+    lds = size_t(table_size) * 8 + size_t((B + 3) & ~3) * 4 + size_t(a.n_chunks + 2 + ((a.n_chunks + 1) >> 5)) * 4 +
+          size_t(1024) * 4 + 16;
+    return RRL_OK;
+}
+
+int rrl_sample_multi(const rrl_draw_t* first, const rrl_draw_t* second, long long noise_pairs, uint64_t noise_seed,
+                     uint64_t noise_counter, uint64_t* noise_counter_dev, uint64_t noise_counter_inc, float* noise_out,
+                     void* stream) {
+    if (!first) return RRL_EINVAL;
+    if (noise_pairs < 0 || noise_pairs >= (1LL << 32) || (noise_pairs > 0 && !noise_out)) return RRL_EINVAL;
+    DrawArgs a{}, b{};
+    int ta = 0, tb = 0;
+    size_t la = 0, lb = 0;
+    int rc = draw_setup(*first, a, ta, la);
+    if (rc != RRL_OK) return rc;
+    if (second) {
+        rc = draw_setup(*second, b, tb, lb);
+        if (rc != RRL_OK) return rc;
+    }
+    // every member's results are independent of the workgroup size (integer prefix sums, per-index Philox draws), so
+    // the launch takes the largest thread count a member would use on its own
+    int threads = ta > tb ? ta : tb;
+    if (noise_pairs > 0 && threads < 256) threads = 256;
+    const size_t lds = la > lb ? la : lb;
+    static size_t granted = 64 * 1024;
+    if (lds > granted) {
+        if (hipFuncSetAttribute((const void*)sample_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(lds)) != hipSuccess) {
+            (void)hipGetLastError();
+            return RRL_ERANGE;
+        }
+        granted = lds;
+    }
+    NoiseArgs nz{noise_pairs, noise_seed, noise_counter, noise_counter_dev, noise_counter_inc, noise_out, 0};
+    if (noise_pairs > 0) {
+        long long nb = (noise_pairs + threads - 1) / threads;
+        nz.blocks = int(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    }
+    hipLaunchKernelGGL(sample_group_kernel, dim3(2 + nz.blocks), dim3(threads), lds, (hipStream_t)stream, a, b, nz);
     return check_launch();
 }
 

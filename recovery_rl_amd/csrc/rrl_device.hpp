@@ -158,18 +158,24 @@ __device__ __forceinline__ uint64_t effective_counter(uint64_t counter, const ui
 
 // tick += inc by the last workgroup to finish (dev = {tick, ticket}); every workgroup read the
 // tick before taking its ticket, so none can observe the new value.
-__device__ __forceinline__ void advance_counter(uint64_t* dev, uint64_t inc) {
+// `blocks` = number of workgroups that call this for `dev` (the whole grid, or the part of a grouped launch that
+// serves this counter)
+__device__ __forceinline__ void advance_counter_blocks(uint64_t* dev, uint64_t inc, unsigned blocks) {
     if (!dev || !inc) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         // no fence: the ticket only orders this workgroup's READ of dev[0] (already consumed) before the
         // last arriver's write; the write itself is published by the kernel boundary
         const unsigned long long ticket = atomicAdd((unsigned long long*)&dev[1], 1ULL);
-        if (ticket == gridDim.x - 1) {
+        if (ticket == blocks - 1) {
             dev[0] += inc;
             dev[1] = 0;
         }
     }
+}
+
+__device__ __forceinline__ void advance_counter(uint64_t* dev, uint64_t inc) {
+    advance_counter_blocks(dev, inc, gridDim.x);
 }
 
 }  // namespace rrl

@@ -46,8 +46,16 @@ struct Outcome {
 // mask = not done (before the horizon check), memory.push, recovery_memory.push, episode counters.
 struct StepPushArgs {
     StepArgs step;            // obs = observation buffer: read as the pre-step state, then overwritten
-    const float2* task_action;
+    const float* task_action; // row i at task_action + i * ld_task
+    int ld_task;
     const uint8_t* recovery;  // nullable
+    // recovery gate evaluated here instead of in a kernel of its own (experiment.py:546-577, rrl_recovery_select):
+    // recovery = max(sigmoid(z[i]), sigmoid(z[n + i])) > eps_safe; executed action = recovery ? rec : task
+    const float* sel_z;       // nullable: [2, n] pre-sigmoid Q_risk(s, a_task)
+    float sel_eps;
+    const float2* sel_rec_action;
+    float2* sel_real_out;     // the executed action and the flag are written for the consumers downstream
+    uint8_t* sel_recovery_out;
     float reward_penalty;
     int push_real_action;     // disable_action_relabeling (experiment.py:437-441)
     rrl_replay_t memory;
@@ -82,7 +90,18 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
         bool cons = false, succ = false, epd = false, rec = false;
         if (live) {
             const double2 pp = a.pos[i];
-            const float2 act = a.action[i];
+            const float2 task = *reinterpret_cast<const float2*>(p.task_action + i * p.ld_task);
+            float2 act;
+            if (p.sel_z) {
+                const float q0 = 1.f / (1.f + expf(-p.sel_z[i])), q1 = 1.f / (1.f + expf(-p.sel_z[a.n + i]));
+                rec = fmaxf(q0, q1) > p.sel_eps;
+                act = rec ? p.sel_rec_action[i] : task;
+                p.sel_real_out[i] = act;
+                p.sel_recovery_out[i] = uint8_t(rec);
+            } else {
+                act = a.action[i];
+                rec = p.recovery ? p.recovery[i] != 0 : false;
+            }
             const float2 prev = a.obs[i];
             int32_t ti = a.t[i];
             ti += 1;
@@ -92,7 +111,6 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             succ = out.success;
             const bool dn = out.done;
             epd = dn | (ti == a.horizon);
-            rec = p.recovery ? p.recovery[i] != 0 : false;
             const float2 nobs = make_float2(float(nx), float(ny));
             const float rew = out.reward;
             a.next_obs[i] = nobs;
@@ -104,7 +122,7 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             // replay rows (experiment.py:431-448)
             const float mask = dn ? 0.0f : 1.0f;
             const float prew = rew - (cons ? p.reward_penalty : 0.0f);
-            const float2 stored = p.push_real_action ? act : p.task_action[i];
+            const float2 stored = p.push_real_action ? act : task;
             rrl_replay::store_values(p.memory, (mpos + i) % p.memory.cap, msize, prev, stored, prew, nobs, mask);
             if (p.use_recovery_memory)
                 rrl_replay::store_values(p.recovery_memory, (rpos + i) % p.recovery_memory.cap, rsize, prev, act,
@@ -163,5 +181,48 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
     rrl::advance_counter(a.counter_dev, a.counter_inc);
 }
 
+// host side: argument block shared by the navigation and maze entry points
+struct SelectIn {
+    const float* z;
+    float eps_safe;
+    const float* rec_action;
+    float* real_out;
+    uint8_t* recovery_out;
+};
+
+inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float* obs, const float* task_action,
+                     int ld_task, const float* real_action, const uint8_t* recovery, const SelectIn* sel, uint64_t seed,
+                     uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, int32_t horizon, int auto_reset,
+                     float reward_penalty, int push_real_action, const rrl_replay_t* memory,
+                     const rrl_replay_t* recovery_memory, float* next_obs, float* reward, uint8_t* done,
+                     uint8_t* constraint, uint8_t* success, uint8_t* ep_done, uint64_t* stats, double* reward_sums,
+                     float* ep_reward) {
+    if (n < 0 || n > 0xffffffffLL) return RRL_ERANGE;
+    if (!pos || !t || !obs || !task_action || !memory || !next_obs || !reward || !done || !constraint || !success ||
+        !stats || !reward_sums || !ep_reward || ld_task < 2 || (ld_task & 1))
+        return RRL_EINVAL;
+    if (sel ? (!sel->z || !sel->rec_action || !sel->real_out || !sel->recovery_out) : !real_action) return RRL_EINVAL;
+    if (n > memory->cap || (recovery_memory && n > recovery_memory->cap)) return RRL_ERANGE;
+    p.step = StepArgs{n, (double2*)pos, (const float2*)real_action, nullptr, seed, counter, counter_dev,
+                      counter_inc, (float2*)next_obs, (float2*)obs, reward, done, constraint, success, ep_done,
+                      t, horizon, auto_reset};
+    p.task_action = task_action;
+    p.ld_task = ld_task;
+    p.recovery = recovery;
+    p.sel_z = sel ? sel->z : nullptr;
+    p.sel_eps = sel ? sel->eps_safe : 0.f;
+    p.sel_rec_action = sel ? (const float2*)sel->rec_action : nullptr;
+    p.sel_real_out = sel ? (float2*)sel->real_out : nullptr;
+    p.sel_recovery_out = sel ? sel->recovery_out : nullptr;
+    p.reward_penalty = reward_penalty;
+    p.push_real_action = push_real_action;
+    p.memory = *memory;
+    p.use_recovery_memory = recovery_memory != nullptr;
+    p.recovery_memory = recovery_memory ? *recovery_memory : *memory;
+    p.stats = (unsigned long long*)stats;
+    p.reward_sums = reward_sums;
+    p.ep_reward = ep_reward;
+    return RRL_OK;
+}
 
 }  // namespace rrl_step

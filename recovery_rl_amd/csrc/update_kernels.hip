@@ -31,11 +31,10 @@ __device__ __forceinline__ float psum(const float* p, long long idx, int np, lon
 // ---- tanh-Gaussian head (GaussianPolicy.sample, model.py:324-340) -------------------------------
 // head[b] = (mean0, mean1, log_std0, log_std1) raw outputs of the last linear layer
 // obs_in (nullable, [B,2]) is copied to obs_out (row stride ld_action): assembles the [s | a] critic input in place
-__global__ void gauss_head_fwd_kernel(int B, const float* head, int np, long long ps, const float* eps,
-                                      const float* scale, const float* bias, float* action, int ld_action,
-                                      float* logp, float* mean_action, const float* obs_in, float* obs_out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+__device__ __forceinline__ void gauss_head_fwd_row(int b, const float* head, int np, long long ps, const float* eps,
+                                                   const float* scale, const float* bias, float* action,
+                                                   int ld_action, float* logp, float* mean_action,
+                                                   const float* obs_in, float* obs_out) {
     if (obs_in) {
         obs_out[(long long)b * ld_action] = obs_in[2 * b];
         obs_out[(long long)b * ld_action + 1] = obs_in[2 * b + 1];
@@ -52,6 +51,14 @@ __global__ void gauss_head_fwd_kernel(int B, const float* head, int np, long lon
         if (mean_action) mean_action[2 * b + j] = tanhf(mean) * scale[j] + bias[j];
     }
     if (logp) logp[b] = lp;
+}
+
+__global__ void gauss_head_fwd_kernel(int B, const float* head, int np, long long ps, const float* eps,
+                                      const float* scale, const float* bias, float* action, int ld_action,
+                                      float* logp, float* mean_action, const float* obs_in, float* obs_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    gauss_head_fwd_row(b, head, np, ps, eps, scale, bias, action, ld_action, logp, mean_action, obs_in, obs_out);
 }
 
 // backward of the head: given dL/d action[b,j] (d_action, leading dim ld) and dL/d logp[b] = dlogp
@@ -183,12 +190,9 @@ __global__ void qrisk_policy_grad_kernel(int B, const float* zp, int np, long lo
 
 // ---- model-free recovery policy head (StochasticPolicy, model.py:511-525) ------------------------
 // raw[b] = last linear output (2); mean = tanh(raw) scale + bias; action = mean + exp(max(log_std, min)) eps
-__global__ void stoch_head_fwd_kernel(int B, const float* raw, int np, long long ps, const float* eps,
-                                      const float* log_std,
-                                      float min_log_std, const float* scale, const float* bias,
-                                      float* action, int ld_action, float* mean_out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+__device__ __forceinline__ void stoch_head_fwd_row(int b, const float* raw, int np, long long ps, const float* eps,
+                                                   const float* log_std, float min_log_std, const float* scale,
+                                                   const float* bias, float* action, int ld_action, float* mean_out) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const float mean = tanhf(psum(raw, 2 * b + j, np, ps)) * scale[j] + bias[j];
@@ -197,6 +201,38 @@ __global__ void stoch_head_fwd_kernel(int B, const float* raw, int np, long long
         action[(long long)b * ld_action + j] = mean + std * e;
         if (mean_out) mean_out[2 * b + j] = mean;
     }
+}
+
+__global__ void stoch_head_fwd_kernel(int B, const float* raw, int np, long long ps, const float* eps,
+                                      const float* log_std,
+                                      float min_log_std, const float* scale, const float* bias,
+                                      float* action, int ld_action, float* mean_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    stoch_head_fwd_row(b, raw, np, ps, eps, log_std, min_log_std, scale, bias, action, ld_action, mean_out);
+}
+
+// independent policy heads in one launch (e.g. a' = pi(s') and pi(s) of one SAC step; the task action and the
+// recovery action of the acting pass): flat grid over (member, row block)
+constexpr int kMaxHeads = 4;
+struct HeadGroup {
+    rrl_policy_head_t h[kMaxHeads];
+    int first[kMaxHeads + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(kBlock) void policy_heads_group_kernel(HeadGroup hg) {
+    int k = 0;
+    while (k + 1 < hg.n && (int)blockIdx.x >= hg.first[k + 1]) ++k;
+    const rrl_policy_head_t& h = hg.h[k];
+    const int b = (blockIdx.x - hg.first[k]) * kBlock + threadIdx.x;
+    if (b >= h.B) return;
+    if (h.kind == RRL_HEAD_GAUSS)
+        gauss_head_fwd_row(b, h.head, h.n_part, h.part_stride, h.eps, h.scale, h.bias, h.action, h.ld_action, h.logp,
+                           h.mean_out, h.obs_in, h.obs_out);
+    else
+        stoch_head_fwd_row(b, h.head, h.n_part, h.part_stride, h.eps, h.log_std, h.min_log_std, h.scale, h.bias,
+                           h.action, h.ld_action, h.mean_out);
 }
 
 // d_action [B,2] (leading dim ld) -> draw [B,2] and dlog_std[2] (sum over the batch; single workgroup)
@@ -351,6 +387,29 @@ int rrl_gauss_head_fwd(int B, const float* head, int n_part, long long part_stri
         return RRL_EINVAL;
     hipLaunchKernelGGL(gauss_head_fwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, n_part,
                        part_stride, eps, scale, bias, action, ld_action, logp, mean_action, obs_in, obs_out);
+    return check_launch();
+}
+
+int rrl_policy_heads_fwd_multi(int n, const rrl_policy_head_t* heads, void* stream) {
+    if (!heads || n <= 0 || n > kMaxHeads) return RRL_EINVAL;
+    HeadGroup hg{};
+    hg.n = n;
+    hg.first[0] = 0;
+    for (int k = 0; k < n; ++k) {
+        const rrl_policy_head_t& h = heads[k];
+        if (!h.head || !h.scale || !h.bias || !h.action || h.B <= 0 || h.n_part <= 0) return RRL_EINVAL;
+        if (h.kind == RRL_HEAD_GAUSS) {
+            if (!h.eps || (h.obs_in && !h.obs_out)) return RRL_EINVAL;
+        } else if (h.kind == RRL_HEAD_STOCH) {
+            if (!h.log_std) return RRL_EINVAL;
+        } else {
+            return RRL_EINVAL;
+        }
+        hg.h[k] = h;
+        hg.first[k + 1] = hg.first[k] + (h.B + kBlock - 1) / kBlock;
+    }
+    for (int k = n; k < kMaxHeads; ++k) hg.first[k + 1] = hg.first[n];
+    hipLaunchKernelGGL(policy_heads_group_kernel, dim3(hg.first[n]), dim3(kBlock), 0, (hipStream_t)stream, hg);
     return check_launch();
 }
 

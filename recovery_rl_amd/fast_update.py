@@ -176,6 +176,40 @@ class Stack:
         gemm(NT, self.h2, P["W3"], out=self.out, bias=P["b3"])
         return self.parts
 
+    # -- descriptors of the same launches for the grouped entry points (rrl_*_multi) ----------------------------
+    def forward_desc(self, x, params=None, save=True):
+        """rrl_stack_t of forward(x, params, save); the caller launches it with forward_multi()."""
+        assert mlp3_supported(self.net.H, self.net.din, self.net.dout) and not self.finalize
+        P = (params or self.net).p
+        net = self.net
+        self.x = x
+        assert x.stride(1) == 1
+        self.parts = (self.scratch, self.nsplit, self.scratch.stride(0)) if self.split else (self.out, 1, 0)
+        p = _lib.ptr
+        return _lib.rrl_stack_t(net.G, x.shape[0], net.H, net.din, net.dout, x.stride(0), p(x), p(P["W1"]), p(P["b1"]),
+                                p(P["W2"]), p(P["b2"]), p(P["W3"]), p(P["b3"]), p(self.h1) if save else None,
+                                p(self.h2) if save else None, p(self.out), p(self.scratch) if self.split else None)
+
+    def backward_descs(self, dout, weight_grads=True, input_grad=False):
+        """(rrl_head_bwd_t, rrl_hidden_bwd_t, rrl_input_bwd_t) of backward(dout, weight_grads, input_grad)."""
+        P, Gr, net = self.net.p, self.net.g, self.net
+        G, B, H = net.G, self.B, net.H
+        p = _lib.ptr
+        wg = weight_grads
+        if isinstance(dout, _lib.rrl_loss_t):
+            loss = dout
+        else:
+            assert dout.is_contiguous()
+            loss = _lib.rrl_loss_t(-1, 1, 0, p(dout), None, None, None, None, None, None, 0.0, 0, 0, 0, None, None)
+        head = _lib.rrl_head_bwd_t(loss, G, B, H, net.dout, p(self.h2), p(P["W3"]), p(Gr["W3"]) if wg else None,
+                                   p(Gr["b3"]) if wg else None, p(self.dh2))
+        hidden = _lib.rrl_hidden_bwd_t(G, B, H, p(self.dh2), p(self.h1), p(P["W2"]), p(Gr["W2"]) if wg else None,
+                                       p(Gr["b2"]) if wg else None, p(self.dh1))
+        inp = _lib.rrl_input_bwd_t(G, B, H, net.din, self.x.stride(0), p(self.dh1), p(self.x), p(P["W1"]),
+                                   p(Gr["W1"]) if wg else None, p(Gr["b1"]) if wg else None,
+                                   p(self.dx) if input_grad else None)
+        return head, hidden, inp
+
     def backward(self, dout, weight_grads=True, input_grad=False):
         """dout: [G, B, dout] tensor, or an rrl_loss_t describing how the kernel computes it itself
         (rrl_mlp_head_backward_loss).  Writes parameter gradients into net.g (weight_grads) and/or returns
@@ -213,6 +247,29 @@ class Stack:
                                               self.dx.data_ptr() if input_grad else None, st),
                    "rrl_mlp_input_backward")
         return self.dx if input_grad else None
+
+
+def forward_multi(descs):
+    """Independent stack forwards in ONE launch (rrl_mlp3_forward_multi)."""
+    arr = (_lib.rrl_stack_t * len(descs))(*descs)
+    _lib.check(_lib.load().rrl_mlp3_forward_multi(len(descs), arr, _lib.current_stream()), "rrl_mlp3_forward_multi")
+
+
+def backward_multi(triples):
+    """Independent stack backwards, stage by stage: three launches for all of them (head, hidden, input)."""
+    lib, st, n = _lib.load(), _lib.current_stream(), len(triples)
+    heads = (_lib.rrl_head_bwd_t * n)(*[t[0] for t in triples])
+    hidden = (_lib.rrl_hidden_bwd_t * n)(*[t[1] for t in triples])
+    inputs = (_lib.rrl_input_bwd_t * n)(*[t[2] for t in triples])
+    _lib.check(lib.rrl_mlp_head_backward_multi(n, heads, st), "rrl_mlp_head_backward_multi")
+    _lib.check(lib.rrl_mlp_hidden_backward_multi(n, hidden, st), "rrl_mlp_hidden_backward_multi")
+    _lib.check(lib.rrl_mlp_input_backward_multi(n, inputs, st), "rrl_mlp_input_backward_multi")
+
+
+def heads_multi(heads):
+    arr = (_lib.rrl_policy_head_t * len(heads))(*heads)
+    _lib.check(_lib.load().rrl_policy_heads_fwd_multi(len(heads), arr, _lib.current_stream()),
+               "rrl_policy_heads_fwd_multi")
 
 
 class StackRows(Stack):
@@ -266,6 +323,10 @@ class FastUpdater:
         self.cri_a, self.cri_b = Stack(self.critic, B), Stack(self.critic, B)
         self.qr_a, self.qr_b = Stack(self.qrisk, B), Stack(self.qrisk, B)
         self.rec_a = Stack(self.recpolicy, B)
+        # grouped launches evaluate the target networks in the same launch as the online ones: own workspaces
+        self.cri_t, self.qr_t = Stack(self.critic, B), Stack(self.qrisk, B)
+        self.grouped = True        # kernels that do not depend on each other share launches (rrl_*_multi)
+        self.xu_q, self.x2u_q, self.xpu_q = z(B, 4), z(B, 4), z(B, 4)   # the Q_risk batch's rows (drawn up front)
         self.xu = z(B, 4)                                           # [s | a]
         self.x_pol = z(2 * B, 4)                                    # [s' | a'] stacked on [s | pi]
         self.x2u, self.xpu = self.x_pol[:B], self.x_pol[B:]
@@ -380,6 +441,115 @@ class FastUpdater:
                                                 action_view.data_ptr(), action_view.stride(0), logp.data_ptr(),
                                                 None, None, None, _lib.current_stream()), "rrl_gauss_head_fwd")
 
+    # -- grouped path: the same kernels, independent ones sharing a launch ------------------------------------------
+    @property
+    def rows_q(self):
+        return (self.xu_q, self.x2u_q, self.xpu_q)
+
+    def _gauss_desc(self, head, eps, action_view, logp, n=None, obs_in=None, obs_out=None):
+        t, n_part, ps = head
+        p = _lib.ptr
+        return _lib.rrl_policy_head_t(_lib.HEAD_GAUSS, n or self.B, p(t), n_part, ps, p(eps), p(self.scale),
+                                      p(self.bias), p(action_view), action_view.stride(0), p(logp), None, p(obs_in),
+                                      p(obs_out), None, 0.0)
+
+    def _stoch_desc(self, head, eps, action_view, n=None):
+        t, n_part, ps = head
+        p = _lib.ptr
+        return _lib.rrl_policy_head_t(_lib.HEAD_STOCH, n or self.B, p(t), n_part, ps, p(eps), p(self.rscale),
+                                      p(self.rbias), p(action_view), action_view.stride(0), None, None, None, None,
+                                      p(self.recpolicy.p["log_std"]), float(self.qr.policy.min_log_std))
+
+    def update_pair(self, memory, recovery_memory):
+        """One SAC update and (recovery_memory not None) one Q_risk + recovery-policy update of a lock-step iteration
+        (experiment.py:397-416): both replay draws and the iteration's policy noise in ONE launch, then the two
+        updates on the grouped kernels.  Same draws, same arithmetic, same parameters as the separate calls."""
+        B, qr = self.B, self.qr
+        d1, batch = memory.draw_desc(B, rows=self.rows)
+        d2 = batch_q = None
+        if recovery_memory is not None:
+            d2, batch_q = recovery_memory.draw_desc(B, pos_fraction=qr.pos_fraction, rows=self.rows_q)
+        n_act = self.actor_rows
+        need = 4 * B * 2 + 2 * n_act * 2
+        if self._noise_buf is None or self._noise_buf.numel() != need:
+            self._noise_buf = torch.zeros(need, dtype=torch.float32, device=self.dev)
+        self._check(self.lib.rrl_sample_multi(C.byref(d1), C.byref(d2) if d2 is not None else None, need // 2,
+                                              self.noise_seed, 0, _lib.ptr(self.noise_tick), 1,
+                                              _lib.ptr(self._noise_buf), _lib.current_stream()), "rrl_sample_multi")
+        self._noise = self._noise_buf[:4 * B * 2].view(4, B, 2)
+        self._actor_noise = self._noise_buf[4 * B * 2:].view(2, n_act, 2) if n_act else None
+        self._actor_noise_fresh = n_act > 0
+        n = self._noise
+        self.sac_update_grouped(batch, n[0], n[1])
+        if recovery_memory is not None:
+            self.qrisk_update_grouped(batch_q, n[2], n[3])
+        return self.losses
+
+    def sac_update_grouped(self, batch, eps_next, eps_pi):
+        """sac_update with 11 launches instead of 17 (rows already written by the draw)."""
+        ag, B = self.agent, self.B
+        s, a, r, s2, m = batch
+        r, m = r.reshape(-1), m.reshape(-1)
+        self.pol_ab.forward(self.x_pol[:, 0:2])
+        head2, head = self.pol_next.after_forward(), self.pol_b.after_forward()
+        heads_multi([self._gauss_desc(head2, eps_next, self.x2u[:, 2:4], self.logp2),
+                     self._gauss_desc(head, eps_pi, self.xpu[:, 2:4], self.logp)])
+        # critic_target(s', a'), critic(s, a), critic(s, pi): three independent forwards (sac.py:192-218)
+        forward_multi([self.cri_t.forward_desc(self.x2u, params=self.critic_target, save=False),
+                       self.cri_a.forward_desc(self.xu), self.cri_b.forward_desc(self.xpu)])
+        qt, n_part, ps = self.cri_t.parts
+        q, qp = self.cri_a.parts[0], self.cri_b.parts[0]
+        # the critic's backward for its own loss (weight gradients) and for the policy loss (input gradient)
+        backward_multi([
+            self.cri_a.backward_descs(self._loss(_lib.LOSS_SAC_CRITIC, q, n_part, ps, out_t=qt, v0=self.logp2, v1=r,
+                                                 v2=m, alpha=self.alpha, f0=ag.gamma, loss=self.losses)),
+            self.cri_b.backward_descs(self._loss(_lib.LOSS_SAC_POLICY, qp, n_part, ps, v0=self.logp, alpha=self.alpha,
+                                                 loss=self.losses[2:]), weight_grads=False, input_grad=True)])
+        ht, hn, hs = head
+        self.pol_b.backward(self._loss(_lib.LOSS_GAUSS_HEAD, ht, hn, hs, v0=eps_pi, v1=self.scale,
+                                       f0=float(ag.alpha) / B, d_action=self.cri_b.dx))
+        if self.sync_world > 1:
+            self._sync(self.sac_bucket)
+        adam_multi(ag.lr, [(self.critic, self.critic_target, ag.tau), (self.policy, None, 0.0)])
+        return self.losses
+
+    def qrisk_update_grouped(self, batch, eps_next, eps_pi):
+        """qrisk_update with 15 launches instead of 19: the task policy on s' and the recovery policy on s in one
+        forward launch (the recovery policy does not depend on the critic step in between), their heads in one, the
+        target and online critics in one."""
+        qr, B = self.qr, self.B
+        s, a, c, s2, m = batch
+        c, m = c.reshape(-1), m.reshape(-1)
+        xu, x2u, xpu = self.rows_q
+        mf = bool(qr.MF_recovery)
+        fwd = [self.pol_a.forward_desc(x2u[:, 0:2], save=False)]          # a' from the TASK policy (qrisk.py:119-120)
+        if mf:
+            fwd.append(self.rec_a.forward_desc(xpu[:, 0:2]))
+        forward_multi(fwd)
+        hd = [self._gauss_desc(self.pol_a.parts, eps_next, x2u[:, 2:4], self.logp2)]
+        if mf:
+            hd.append(self._stoch_desc(self.rec_a.parts, eps_pi, xpu[:, 2:4]))
+        heads_multi(hd)
+        forward_multi([self.qr_t.forward_desc(x2u, params=self.qrisk_target, save=False), self.qr_a.forward_desc(xu)])
+        zt, n_part, ps = self.qr_t.parts
+        z = self.qr_a.parts[0]
+        self.qr_a.backward(self._loss(_lib.LOSS_QRISK_CRITIC, z, n_part, ps, out_t=zt, v0=c, v1=m,
+                                      f0=qr.gamma_safe, loss=self.losses[4:]))
+        self._sync(self.qrisk.grad)
+        self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau)
+        if mf:                                                             # qrisk.py:150-158, at the UPDATED critic
+            raw, rn, rs = self.rec_a.parts
+            ls = self.recpolicy.p["log_std"]
+            zp, n_part, ps = self.qr_b.forward(xpu)
+            dx = self.qr_b.backward(self._loss(_lib.LOSS_QRISK_POLICY, zp, n_part, ps, loss=self.losses[6:]),
+                                    weight_grads=False, input_grad=True)
+            self.rec_a.backward(self._loss(_lib.LOSS_STOCH_HEAD, raw, rn, rs, v0=eps_pi, v1=ls, v2=self.rscale,
+                                           f0=qr.policy.min_log_std, d_action=dx,
+                                           loss=self.recpolicy.g["log_std"]))
+            self._sync(self.recpolicy.grad)
+            self.recpolicy.adam(qr.lr)
+        return self.losses
+
     # -- SAC -------------------------------------------------------------------------------------
     def sac_update(self, batch, eps_next, eps_pi, rows_loaded=False):
         ag, B, lib, st = self.agent, self.B, self.lib, _lib.current_stream()
@@ -487,11 +657,29 @@ class FastActor:
         self.task_action, self.rec_action, self.real_action = z(n, 2), z(n, 2), z(n, 2)
         self.recovery = torch.zeros(n, dtype=torch.uint8, device=dev)
 
-    def act(self, obs, eps_safe, use_recovery, mf_recovery, noise=None):
-        """-> (task action [n,2], executed action [n,2], recovery u8[n] or None); persistent buffers."""
+    def act(self, obs, eps_safe, use_recovery, mf_recovery, noise=None, defer_select=False):
+        """-> (task action [n,2], executed action [n,2], recovery u8[n] or None); persistent buffers.
+        defer_select: the recovery gate is left to the env-step kernel (rrl_*_step_push_select); `pending_select` then
+        holds its inputs, the task action is the strided view xa[:, 2:4] and the other two are filled by that kernel."""
         f, n, lib, st = self.f, self.n, self.f.lib, _lib.current_stream()
         if noise is None:
             noise = f.actor_noise(n)
+        self.pending_select = None
+        if f.grouped and use_recovery and mf_recovery:
+            # task policy and recovery policy on the same observations: one forward launch, one head launch
+            forward_multi([self.pol.forward_desc(obs, save=False), self.rec.forward_desc(obs, save=False)])
+            heads_multi([f._gauss_desc(self.pol.parts, noise[0], self.xa[:, 2:4], None, n=n, obs_in=obs, obs_out=self.xa),
+                         f._stoch_desc(self.rec.parts, noise[1], self.rec_action, n=n)])
+            self.qr.finalize = True
+            zq, _, _ = self.qr.forward(self.xa, save=False)
+            if defer_select:
+                self.pending_select = (zq, float(eps_safe), self.rec_action)
+                return self.xa[:, 2:4], self.real_action, self.recovery
+            _lib.check(lib.rrl_recovery_select(n, zq.data_ptr(), eps_safe, self.xa[:, 2:4].data_ptr(), 4,
+                                               self.rec_action.data_ptr(), self.real_action.data_ptr(),
+                                               self.recovery.data_ptr(), self.task_action.data_ptr(), st),
+                       "rrl_recovery_select")
+            return self.task_action, self.real_action, self.recovery
         head, hn, hs = self.pol.forward(obs, save=False)
         if not use_recovery:
             _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), hn, hs, noise[0].data_ptr(), f.scale.data_ptr(),

@@ -115,6 +115,25 @@ class ReplayMemory:
         return s, a, r, s2, m
 
 
+    def draw_desc(self, batch_size, pos_fraction=None, out=None, rows=None):
+        """The arguments of sample() as an rrl_draw_t for rrl_sample_multi (several draws in one launch) and the batch
+        tensors it fills.  Same checks, same tick, same rows as sample()."""
+        B = int(batch_size)
+        s, a, r, s2, m, idx = out if out is not None else self._batch(B)
+        xu, x2u, xpu = rows if rows is not None else (None, None, None)
+        if pos_fraction is None:
+            if self._len_exact and B > self._len:
+                raise ValueError("Sample larger than population or is negative")
+            stratified, n_pos, n_neg = 0, 0, B
+        else:
+            stratified, n_pos = 1, int(B * pos_fraction)
+            n_neg = B - n_pos
+        p = _lib.ptr
+        d = _lib.rrl_draw_t(C.pointer(self._desc), stratified, n_pos, n_neg, self.seed, 0, p(self.tick), 1, p(s), p(a),
+                            p(r), p(s2), p(m), p(idx), p(xu), p(x2u), p(xpu))
+        return d, (s, a, r, s2, m)
+
+
 class ConstraintReplayMemory(ReplayMemory):
     """Ring buffer for the safety critic (replay_memory.py:36-75): `reward` holds the constraint
     indicator and `sample(..., pos_fraction)` stratifies on it."""

@@ -263,3 +263,93 @@ def test_loss_fused_head_backward_is_bit_identical_to_the_separate_grad_kernels(
             assert torch.equal(fa.flat, fb.flat), (step, name)
             assert torch.equal(fa.grad, fb.grad), (step, name)
         torch.testing.assert_close(a.fast.losses, b.fast.losses, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("env_name,extra", (
+    ("navigation1", ["--gamma_safe", "0.8", "--eps_safe", "0.3", "--num_unsafe_transitions", "4000"]),
+    ("maze", ["--gamma_safe", "0.5", "--eps_safe", "0.15", "--pos_fraction", "0.3", "--num_unsafe_transitions", "4000"]),
+))
+def test_grouped_launches_equal_the_separate_ones(env_name, extra):
+    """The lock-step iteration with independent kernels sharing launches (rrl_sample_multi, rrl_mlp3_forward_multi,
+    rrl_mlp_*_backward_multi, rrl_policy_heads_fwd_multi, rrl_*_step_push_select: ~30 launches) against the same
+    iteration issued kernel by kernel (~49 launches): after eager iterations AND hipGraph replays every parameter,
+    Adam moment, replay row, env state and counter must be bit-identical."""
+    import bench
+    loops = []
+    for grouped in (True, False):
+        cfg = arg_utils.get_args(["--env-name", env_name, "--cuda", "--use_recovery", "--MF_recovery", "--num_envs", "512",
+                                  "--seed", "4"] + extra)
+        loop = bench.build_loop(cfg, torch.device(DEV), pretrain=5)
+        loop.agent.fast.grouped = grouped
+        loops.append(loop)
+    for phase in range(2):
+        for loop in loops:
+            if phase == 0:
+                for _ in range(4):
+                    loop.vector_step(True, False, True)
+            else:
+                loop.capture(online_qrisk=True)
+                for _ in range(5):
+                    loop.replay()
+        torch.cuda.synchronize()
+        a, b = loops
+        for name in ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy"):
+            fa, fb = getattr(a.agent.fast, name), getattr(b.agent.fast, name)
+            assert torch.equal(fa.flat, fb.flat), (phase, name)
+            assert torch.equal(fa.m, fb.m) and torch.equal(fa.v, fb.v) and torch.equal(fa.step, fb.step), (phase, name)
+        for ma, mb in ((a.memory, b.memory), (a.recovery_memory, b.recovery_memory)):
+            assert torch.equal(ma.state, mb.state) and torch.equal(ma.tick, mb.tick)
+            for fa, fb in ((ma.s, mb.s), (ma.a, mb.a), (ma.r, mb.r), (ma.s2, mb.s2), (ma.m, mb.m)):
+                assert torch.equal(fa, fb), phase
+            ma.check_error()
+        assert torch.equal(a.env.pos, b.env.pos) and torch.equal(a.env.t, b.env.t) and torch.equal(a.env.obs, b.env.obs)
+        assert torch.equal(a.stats, b.stats) and torch.equal(a.reward_sums, b.reward_sums)
+        assert torch.equal(a.agent.fast.noise_tick, b.agent.fast.noise_tick)
+        assert torch.equal(a._actor.recovery, b._actor.recovery) and torch.equal(a._actor.real_action, b._actor.real_action)
+        assert a.read_stats() == b.read_stats()
+    assert int(loops[0].stats[6].item()) > 0                 # the recovery gate fired on some env-steps
+
+
+def test_grouped_entry_points_match_their_members():
+    """rrl_mlp3_forward_multi / rrl_policy_heads_fwd_multi / rrl_sample_multi on their own: outputs equal the
+    stand-alone launches', incl. a mixed group on the non-split path (the acting pass at 4096 rows)."""
+    from recovery_rl_amd.fast_update import Stack, forward_multi, heads_multi
+    from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
+    a, _, _ = make_pair(256)
+    f = a.enable_fast_path(256)
+    for n_rows in (256, 4096):
+        x = torch.randn(n_rows, 4, device=DEV)
+        s1, s2, s3 = Stack(f.critic, n_rows), Stack(f.qrisk, n_rows), Stack(f.critic, n_rows)
+        r1, r2, r3 = Stack(f.critic, n_rows), Stack(f.qrisk, n_rows), Stack(f.critic, n_rows)
+        forward_multi([s1.forward_desc(x), s2.forward_desc(x, save=False), s3.forward_desc(x, params=f.critic_target)])
+        r1.forward(x), r2.forward(x, save=False), r3.forward(x, params=f.critic_target)
+        for g, r in ((s1, r1), (s2, r2), (s3, r3)):
+            tg, tr = g.parts[0], r.parts[0]
+            assert g.parts[1:] == r.parts[1:] and torch.equal(tg, tr)
+        assert torch.equal(s1.h1, r1.h1) and torch.equal(s1.h2, r1.h2) and torch.equal(s3.h2, r3.h2)
+    # draws + noise
+    rng = np.random.RandomState(0)
+    rows = lambda n: [torch.as_tensor(v, device=DEV) for v in (
+        rng.randn(n, 2).astype(np.float32), rng.randn(n, 2).astype(np.float32),
+        (rng.uniform(size=n) < 0.2).astype(np.float32), rng.randn(n, 2).astype(np.float32), np.ones(n, np.float32))]
+    data = rows(5000)
+    mems = [(ReplayMemory(8192, 3, device=DEV), ConstraintReplayMemory(8192, 3, device=DEV)) for _ in range(2)]
+    for m, c in mems:
+        m.push(*data), c.push(*data)
+    (m1, c1), (m2, c2) = mems
+    lib = _lib.load()
+    import ctypes as C
+    noise_a, noise_b = torch.zeros(3000, 2, device=DEV), torch.zeros(3000, 2, device=DEV)
+    tick_a, tick_b = torch.zeros(2, dtype=torch.int64, device=DEV), torch.zeros(2, dtype=torch.int64, device=DEV)
+    for call in range(3):
+        d1, out1 = m1.draw_desc(256)
+        d2, out2 = c1.draw_desc(256, pos_fraction=0.3)
+        _lib.check(lib.rrl_sample_multi(C.byref(d1), C.byref(d2), 3000, 77, 0, _lib.ptr(tick_a), 1, _lib.ptr(noise_a),
+                                        _lib.current_stream()), "rrl_sample_multi")
+        want1 = [t.clone() for t in m2.sample(256)]
+        want2 = [t.clone() for t in c2.sample(256, pos_fraction=0.3)]
+        _lib.check(lib.rrl_normal_fill(3000, 77, 0, _lib.ptr(tick_b), 1, _lib.ptr(noise_b), _lib.current_stream()), "fill")
+        assert all(torch.equal(x, y) for x, y in zip(out1, want1)) and all(torch.equal(x, y) for x, y in zip(out2, want2))
+        assert torch.equal(noise_a, noise_b) and torch.equal(tick_a, tick_b)
+        assert torch.equal(m1._batch(256)[5], m2._batch(256)[5]) and torch.equal(c1._batch(256)[5], c2._batch(256)[5])
+    m1.check_error(), c1.check_error()
