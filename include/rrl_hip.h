@@ -217,19 +217,21 @@ int rrl_maze_step_push(int64_t n, double* pos, int32_t* t, float* obs,
                       uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
 
 /* The same fused tails with the recovery gate of Experiment.get_action (experiment.py:546-577) evaluated inside:
- * recovery[i] = max(sigmoid(z[i]), sigmoid(z[n + i])) > eps_safe (z = pre-sigmoid twin Q_risk(s, a_task), [2,n]);
+ * recovery[i] = max(sigmoid(z[i]), sigmoid(z[n + i])) > eps_safe (z = pre-sigmoid twin Q_risk(s, a_task), [2,n], given
+ * as z_n_part partial sums z_part_stride floats apart like every stack output: rrl_mlp3_forward with scratch);
  * executed action = recovery ? rec_action[i] : task_action[i].  real_action [n,2] and recovery [n] are OUTPUTS here
  * (what rrl_recovery_select would have written); task_action rows are ld_task floats apart (the [s | a] input
  * of the safety critic, ld_task = 4, can be passed as it is).  One launch less per lock-step iteration. */
 int rrl_nav_step_push_select(int env_kind, int64_t n, double* pos, int32_t* t, float* obs, const float* task_action,
-                             int ld_task, const float* z, float eps_safe, const float* rec_action, float* real_action,
+                             int ld_task, const float* z, int z_n_part, long long z_part_stride,
+                             float eps_safe, const float* rec_action, float* real_action,
                              uint8_t* recovery, uint64_t seed, uint64_t counter, uint64_t* counter_dev,
                              uint64_t counter_inc, int32_t horizon, int auto_reset, float reward_penalty,
                              int push_real_action, const rrl_replay_t* memory, const rrl_replay_t* recovery_memory,
                              float* next_obs, float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success,
                              uint8_t* ep_done, uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
 int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, const float* task_action, int ld_task,
-                              const float* z, float eps_safe, const float* rec_action, float* real_action,
+                              const float* z, int z_n_part, long long z_part_stride, float eps_safe, const float* rec_action, float* real_action,
                               uint8_t* recovery, uint64_t seed, uint64_t counter, uint64_t* counter_dev,
                               uint64_t counter_inc, int32_t horizon, int auto_reset, float reward_penalty,
                               int push_real_action, const rrl_replay_t* memory, const rrl_replay_t* recovery_memory,

@@ -177,9 +177,9 @@ def _declare(lib):
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_maze_step_push": (ci, [i64, vp, vp, vp, vp, vp, vp, u64, u64, vp, u64, i32, ci, f32, ci, rp, rp,
                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-        "rrl_nav_step_push_select": (ci, [ci, i64, vp, vp, vp, vp, ci, vp, f32, vp, vp, vp, u64, u64, vp, u64, i32, ci,
+        "rrl_nav_step_push_select": (ci, [ci, i64, vp, vp, vp, vp, ci, vp, ci, ll, f32, vp, vp, vp, u64, u64, vp, u64, i32, ci,
                                           f32, ci, rp, rp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-        "rrl_maze_step_push_select": (ci, [i64, vp, vp, vp, vp, ci, vp, f32, vp, vp, vp, u64, u64, vp, u64, i32, ci,
+        "rrl_maze_step_push_select": (ci, [i64, vp, vp, vp, vp, ci, vp, ci, ll, f32, vp, vp, vp, u64, u64, vp, u64, i32, ci,
                                            f32, ci, rp, rp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_sample_multi": (ci, [C.POINTER(rrl_draw_t), C.POINTER(rrl_draw_t), ll, u64, u64, vp, u64, vp, vp]),
         "rrl_mlp3_forward_multi": (ci, [ci, C.POINTER(rrl_stack_t), vp]),

@@ -17,6 +17,8 @@
 // arbitrary M, N, K (edges are zero-filled / bounds-checked).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rrl_host.hpp"
 
 namespace {
@@ -250,6 +252,36 @@ struct StackArgs {
 constexpr int kStackRows = 16;
 constexpr int kStackMaxH = 256;
 
+// Sum over each 16-lane row of a wave, result in every lane, in the order of the xor butterfly 8, 4, 2, 1 (bit-identical
+// to `v += __shfl_xor(v, 8); ... 4; 2; 1`): after step k the row's values repeat with period 16 / 2^k, so the partner
+// lane^m holds the same value as lane + m (mod 16) and a DPP row rotation delivers it -- one VALU instruction with a DPP
+// operand per step instead of a ds_bpermute round trip through the LDS crossbar (~120 cycles each, four dependent
+// ones per output row: 7 000 of the 25 000 cycles of a 64-row forward tile).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0x128>(v);    // row_ror:8
+    v += dpp_move<0x124>(v);    // row_ror:4
+    v += dpp_move<0x122>(v);    // row_ror:2
+    v += dpp_move<0x121>(v);    // row_ror:1
+    return v;
+}
+
+// -DRRL_FWD_TIMING (profiles/mlp_fwd_timing.sh builds a second library with it): wave 0 of every workgroup of the
+// split forward stamps s_memtime at its phase boundaries
+#ifdef RRL_FWD_TIMING
+__device__ unsigned long long rrl_fwd_stamps[8 * 8192];
+#define RRL_STAMP(k)                                                                              \
+    do {                                                                                          \
+        const unsigned flat_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);    \
+        if (threadIdx.x == 0 && flat_ < 8192) rrl_fwd_stamps[8 * flat_ + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define RRL_STAMP(k)
+#endif
+
 // R = row tiles (of 16 rows) per workgroup: they share the wave's W2 registers, so a big batch re-reads
 // W2 from L2 M / (16 R) times instead of M / 16 (the re-streaming is what bounds M = 4096).
 template <int R>
@@ -351,10 +383,7 @@ __device__ __forceinline__ void mlp3_fwd_body(const StackArgs& a, int bx, int g,
 #pragma unroll
         for (int it = 0; it < kStackMaxH / 16; ++it)
             if (i + 16 * it < H) v = fmaf(h2s[r * ldh + i + 16 * it], w3v[it], v);
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 1);
+        v = row16_sum(v);
         if (i == 0 && q < a.dout && m0 + r < a.M) a.out[((long long)g * a.M + m0 + r) * a.dout + q] = v + bias3;
     }
 }
@@ -396,121 +425,203 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_group_kernel(StackGroup sg) {
 // adds the four partials in a fixed order (deterministic).
 constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.320 ms per iteration)
 
+// R = row tiles (of 16 rows) per workgroup.  R = 1 for the small update batches (latency-bound: as many workgroups as
+// possible).  Large batches (the acting pass, 4096 rows) are bound by re-streaming W2 from L2 once per row tile (64 MB
+// per network and forward at R = 1: 14-15 us); with R = 4 a wave keeps its W2 fragments for four row tiles, the
+// stream drops to 16 MB and the 16-row x 256-column tile of a workgroup becomes 64 x 64.  Per output element the
+// arithmetic (MFMA order, partial-sum order) is the same for every R.
+// HC = the hidden width as a compile-time constant (256, the reference's --hidden_size default) or 0 = read it from
+// the arguments.  With HC fixed every loop below is straight-line code: no per-chunk bounds branches between the LDS
+// reads and the MFMAs (the run-time version waited for each ds_read right before its four MFMAs: 3 500 cycles for the
+// 2 048 cycles of MFMA issue of one 16-row tile), and the row-bounds checks are hoisted into one uniform branch.
+template <int R, int HC>
 __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* partial, int bx, int g, int z, int G,
                                                     float* h1s, float* h2s) {
+    RRL_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = bx * kStackRows;
-    const int H = a.H, ldh = H + 20, HS = H / kSplit, ld2 = HS + 1;
+    const int m0 = bx * (R * kStackRows);
+    const int H = HC ? HC : a.H, ldh = H + 20, HS = H / kSplit, ld2 = HS + 1;
+    constexpr int kJ = HC ? HC / 16 : kStackMaxH / 16;             // K chunks of layer 2
+    constexpr int kU = HC ? HC / 64 : kStackMaxH / 64;             // layer-1 column tiles per wave
+    constexpr int kT3 = HC ? HC / (16 * kSplit) : kStackMaxH / (16 * kSplit);
     const int colbase = z * HS;
-    const float* W1 = a.W1 + (long long)g * H * a.din;
+    const int M = a.M, din = a.din, dout = a.dout;
+    const float* W1 = a.W1 + (long long)g * H * din;
     const float* b1 = a.b1 + (long long)g * H;
     const float* W2 = a.W2 + (long long)g * H * H;
     const float* b2 = a.b2 + (long long)g * H;
-    const float* W3 = a.W3 + (long long)g * a.dout * H;
-    const float* b3 = a.b3 + (long long)g * a.dout;
+    const float* W3 = a.W3 + (long long)g * dout * H;
+    const float* b3 = a.b3 + (long long)g * dout;
+    float* const h1g = (a.h1 && z == 0) ? a.h1 + ((long long)g * M + m0) * H : nullptr;
+    float* const h2g = a.h2 ? a.h2 + ((long long)g * M + m0) * H : nullptr;
     const int i = lane & 15, q = lane >> 4;
     const int ntiles1 = H / 16;                    // layer-1 column tiles, 4 waves take them round-robin
-    const bool has_tile2 = wave * 16 < HS;         // my layer-2 tile inside this group's columns
+    const bool has_tile2 = HC ? true : wave * 16 < HS;   // my layer-2 tile inside this group's columns
     const int n2 = colbase + (has_tile2 ? wave * 16 : 0);
+    const bool full = m0 + R * kStackRows <= M;    // uniform: every row of the workgroup's tiles exists
 
     // ---- all global reads up front, branch-free ---------------------------------------------------------
-    const int xrow = min(m0 + i, a.M - 1);
-    const float xa = (q < a.din) ? a.x[(long long)xrow * a.ldx + q] : 0.f;
-    float w1b[kStackMaxH / 64], bias1[kStackMaxH / 64];
+    float xa[R];
 #pragma unroll
-    for (int u = 0; u < kStackMaxH / 64; ++u) {
+    for (int t = 0; t < R; ++t) {
+        const int xrow = min(m0 + 16 * t + i, M - 1);
+        const float xv = a.x[(long long)xrow * a.ldx + min(q, din - 1)];
+        xa[t] = (q < din) ? xv : 0.f;
+    }
+    float w1b[kU], bias1[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
         const int t = min(wave + 4 * u, ntiles1 - 1);
-        w1b[u] = (q < a.din) ? W1[(t * 16 + i) * a.din + q] : 0.f;
+        const float wv1 = W1[(t * 16 + i) * din + min(q, din - 1)];
+        w1b[u] = (q < din) ? wv1 : 0.f;
         bias1[u] = b1[t * 16 + i];
     }
-    float4 wv[kStackMaxH / 16];
+    float4 wv[kJ];
     {
         const float* wrow = W2 + (long long)(n2 + i) * H + 4 * q;
 #pragma unroll
-        for (int j = 0; j < kStackMaxH / 16; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
+        for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
     }
     const float bias2 = b2[n2 + i];
-    const int o3 = min(q, a.dout - 1);
-    float w3v[kStackMaxH / (16 * kSplit)];
+    const int o3 = min(q, dout - 1);
+    float w3v[kT3];
 #pragma unroll
-    for (int it = 0; it < kStackMaxH / (16 * kSplit); ++it) w3v[it] = W3[o3 * H + colbase + min(i + 16 * it, HS - 1)];
-    const float bias3 = (z == 0) ? b3[o3] : 0.f;
+    for (int it = 0; it < kT3; ++it) w3v[it] = W3[o3 * H + colbase + min(i + 16 * it, HS - 1)];
+    const float b3v = b3[o3];
+    const float bias3 = (z == 0) ? b3v : 0.f;
 
-    // ---- layer 1 (all H columns; one MFMA step per 16-column tile) ---------------------------------------
+    RRL_STAMP(1);
+    // ---- layer 1 (all H columns; one MFMA step per 16-column tile and row tile) ---------------------------
 #pragma unroll
-    for (int u = 0; u < kStackMaxH / 64; ++u) {
+    for (int u = 0; u < kU; ++u) {
         const int t = wave + 4 * u;
-        if (t < ntiles1) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, w1b[u], acc, 0, 0, 0);
+        if (HC || t < ntiles1) {
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[rt], w1b[u], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * rt + 4 * q + r;
+                    float v = acc[r] + bias1[u];
+                    v = v > 0.f ? v : 0.f;
+                    h1s[rr * ldh + t * 16 + i] = v;
+                }
+                if (h1g) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = 16 * rt + 4 * q + r;
+                        float v = acc[r] + bias1[u];
+                        v = v > 0.f ? v : 0.f;
+                        if (full || m0 + rr < M) h1g[(long long)rr * H + t * 16 + i] = v;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    RRL_STAMP(2);
+    // ---- layer 2: my 16 columns, R row tiles sharing the W2 fragments -----------------------------------------
+    if (has_tile2) {
+        f32x4 acc0[R], acc1[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            acc0[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) {
+            if (HC || 16 * j < H) {
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) {
+                    const float4 av = *reinterpret_cast<const float4*>(h1s + (16 * rt + i) * ldh + 4 * q + 16 * j);
+                    acc0[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0[rt], 0, 0, 0);
+                    acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1[rt], 0, 0, 0);
+                    acc0[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0[rt], 0, 0, 0);
+                    acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[j].w, acc1[rt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            const f32x4 acc = acc0[rt] + acc1[rt];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rr = 4 * q + r;
-                float v = acc[r] + bias1[u];
+                const int rr = 16 * rt + 4 * q + r;
+                float v = acc[r] + bias2;
                 v = v > 0.f ? v : 0.f;
-                h1s[rr * ldh + t * 16 + i] = v;
-                if (a.h1 && z == 0 && m0 + rr < a.M) a.h1[((long long)g * a.M + m0 + rr) * H + t * 16 + i] = v;
+                h2s[rr * ld2 + wave * 16 + i] = v;
+            }
+            if (h2g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * rt + 4 * q + r;
+                    float v = acc[r] + bias2;
+                    v = v > 0.f ? v : 0.f;
+                    if (full || m0 + rr < M) h2g[(long long)rr * H + n2 + i] = v;
+                }
             }
         }
     }
+    RRL_STAMP(3);
     __syncthreads();
-    // ---- layer 2: my 16 columns ------------------------------------------------------------------------------
-    if (has_tile2) {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = h1s + i * ldh + 4 * q;
+    RRL_STAMP(4);
+    // ---- layer 3 partial over my HS columns: wave w -> rows 4 w .. 4 w + 3 of every row tile -----------------
+    float res[R][4];
 #pragma unroll
-        for (int j = 0; j < kStackMaxH / 16; ++j) {
-            if (16 * j < H) {
-                const float4 av = *reinterpret_cast<const float4*>(arow + 16 * j);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[j].w, acc1, 0, 0, 0);
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 16 * rt + wave * 4 + rr;
+            float v = 0.f;
+#pragma unroll
+            for (int it = 0; it < kT3; ++it) {
+                const float hv = h2s[r * ld2 + min(i + 16 * it, HS - 1)];
+                if (HC || i + 16 * it < HS) v = fmaf(hv, w3v[it], v);
             }
-        }
-        const f32x4 acc = acc0 + acc1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = 4 * q + r;
-            float v = acc[r] + bias2;
-            v = v > 0.f ? v : 0.f;
-            h2s[rr * ld2 + wave * 16 + i] = v;
-            if (a.h2 && m0 + rr < a.M) a.h2[((long long)g * a.M + m0 + rr) * H + n2 + i] = v;
+            res[rt][rr] = v;
         }
     }
-    __syncthreads();
-    // ---- layer 3 partial over my HS columns: wave w -> rows 4 w .. 4 w + 3 -----------------------------
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = wave * 4 + rr;
-        float v = 0.f;
+    for (int rt = 0; rt < R; ++rt) {
 #pragma unroll
-        for (int it = 0; it < kStackMaxH / (16 * kSplit); ++it)
-            if (i + 16 * it < HS) v = fmaf(h2s[r * ld2 + i + 16 * it], w3v[it], v);
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 1);
-        if (i == 0 && q < a.dout && m0 + r < a.M)
-            partial[(((long long)z * G + g) * a.M + m0 + r) * a.dout + q] = v + bias3;
+        for (int rr = 0; rr < 4; ++rr) {
+            const float v = row16_sum(res[rt][rr]);
+            const int r = 16 * rt + wave * 4 + rr;
+            if (i == 0 && q < dout && (full || m0 + r < M))
+                partial[(((long long)z * G + g) * M + m0 + r) * dout + q] = v + bias3;
+        }
     }
+    RRL_STAMP(5);
 }
 
+constexpr int kBigR = 4;     // row tiles per workgroup for batches above kSplitSmallM rows
+constexpr int kSplitSmallM = 1024;
+constexpr size_t split_lds_floats(int R) {
+    return size_t(R) * kStackRows * (kStackMaxH + 20) + size_t(R) * kStackRows * (kStackMaxH / kSplit + 1);
+}
+
+template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
-    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 20)];
-    __shared__ float h2s[kStackRows * (kStackMaxH / kSplit + 1)];
-    mlp3_fwd_split_body(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, h1s, h2s);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* h2s = lds + R * kStackRows * (kStackMaxH + 20);
+    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
+    else mlp3_fwd_split_body<R, 0>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
 }
 
 // flat grid over (stack, column split, head, row tile)
+template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg) {
-    __shared__ __attribute__((aligned(16))) float h1s[kStackRows * (kStackMaxH + 20)];
-    __shared__ float h2s[kStackRows * (kStackMaxH / kSplit + 1)];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     int k = 0;
     while (k + 1 < sg.n && (int)blockIdx.x >= sg.first[k + 1]) ++k;
     const int local = blockIdx.x - sg.first[k];
     const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
-    mlp3_fwd_split_body(sg.a[k], sg.partial[k], bx, rest % sg.G[k], rest / sg.G[k], sg.G[k], h1s, h2s);
+    float* h2s = lds + R * kStackRows * (kStackMaxH + 20);
+    if (sg.a[k].H == 256)
+        mlp3_fwd_split_body<R, 256>(sg.a[k], sg.partial[k], bx, rest % sg.G[k], rest / sg.G[k], sg.G[k], lds, h2s);
+    else
+        mlp3_fwd_split_body<R, 0>(sg.a[k], sg.partial[k], bx, rest % sg.G[k], rest / sg.G[k], sg.G[k], lds, h2s);
 }
 
 __global__ void sum_partials_kernel(int n, const float* __restrict__ partial, float* __restrict__ out) {
@@ -948,7 +1059,28 @@ int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* strea
     return check_launch();
 }
 
-int rrl_mlp3_is_split(int M, int H) { return (M <= 1024 && (H % (16 * kSplit)) == 0 && H <= kStackMaxH) ? kSplit : 0; }
+static int split_max_rows() {
+    // RRL_SPLIT_MAX_M: tuning knob for profiles/mlp_fwd_probe.py (largest batch that takes the column-split forward)
+    static const int v = [] {
+        const char* e = getenv("RRL_SPLIT_MAX_M");
+        return e ? atoi(e) : (1 << 30);
+    }();
+    return v;
+}
+
+int rrl_mlp3_is_split(int M, int H) {
+    return (M <= split_max_rows() && (H % (16 * kSplit)) == 0 && H <= kStackMaxH) ? kSplit : 0;
+}
+
+// the R = 4 tiles need more than the default 64 KB of LDS per workgroup (gfx950 has 160 KB per CU): opt in once
+static bool grant_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
 
 static int stack_check(int G, int M, int H, int din, int dout, const float* x, const float* W1, const float* b1,
                        const float* W2, const float* b2, const float* W3, const float* b3, const float* out) {
@@ -965,9 +1097,17 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
     if (rc != RRL_OK) return rc;
     StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx};
     if (scratch && rrl_mlp3_is_split(M, H)) {
-        // small batch: 4 workgroups per row tile + fixed-order sum of their partial last-layer outputs
-        hipLaunchKernelGGL(mlp3_fwd_split_kernel, dim3((M + kStackRows - 1) / kStackRows, G, kSplit), dim3(256), 0,
-                           (hipStream_t)stream, a, scratch);
+        // 4 workgroups (column groups) per row tile + fixed-order sum of their partial last-layer outputs
+        if (M <= kSplitSmallM) {
+            hipLaunchKernelGGL(mlp3_fwd_split_kernel<1>, dim3((M + kStackRows - 1) / kStackRows, G, kSplit), dim3(256),
+                               split_lds_floats(1) * 4, (hipStream_t)stream, a, scratch);
+        } else {
+            static const bool ok = grant_lds((const void*)mlp3_fwd_split_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+            if (!ok) return RRL_ERANGE;
+            const int rows = kBigR * kStackRows;
+            hipLaunchKernelGGL(mlp3_fwd_split_kernel<kBigR>, dim3((M + rows - 1) / rows, G, kSplit), dim3(256),
+                               split_lds_floats(kBigR) * 4, (hipStream_t)stream, a, scratch);
+        }
         if (finalize) {
             const int n = G * M * dout;
             hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n,
@@ -988,12 +1128,19 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
 // Every stack of the group takes the path rrl_mlp3_forward would take for it on its own (so the results are the
 // stand-alone launches', bit for bit); the group must be homogeneous: all split (scratch given, partial sums left in
 // scratch = finalize 0) or all on the same non-split tiling.
+#ifdef RRL_FWD_TIMING
+int rrl_debug_fwd_stamps(unsigned long long* host, int n_blocks) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(rrl_fwd_stamps), sizeof(unsigned long long) * 8 * n_blocks) == hipSuccess
+               ? RRL_OK : RRL_ELAUNCH;
+}
+#endif
+
 int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
     if (!st || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
     StackGroup sg{};
     sg.n = n;
     sg.first[0] = 0;
-    int path = -1;   // 0 split, 1 R = 1, 2 R = 2
+    int path = -1;   // 0 split (small batch), 3 split (R = 4 row tiles), 1 plain R = 1, 2 plain R = 2
     for (int k = 0; k < n; ++k) {
         const rrl_stack_t& p = st[k];
         const int rc = stack_check(p.G, p.M, p.H, p.din, p.dout, p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.out);
@@ -1004,9 +1151,10 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
         int my;
         const long long tiles16 = (p.M + kStackRows - 1) / kStackRows;
         if (p.scratch && rrl_mlp3_is_split(p.M, p.H)) {
-            my = 0;
-            sg.tiles[k] = int(tiles16);
-            sg.first[k + 1] = sg.first[k] + int(tiles16) * p.G * kSplit;
+            my = p.M <= kSplitSmallM ? 0 : 3;
+            const int rows = (my == 0 ? 1 : kBigR) * kStackRows;
+            sg.tiles[k] = (p.M + rows - 1) / rows;
+            sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G * kSplit;
         } else if (tiles16 * p.G > 256) {
             my = 2;
             sg.tiles[k] = (p.M + 2 * kStackRows - 1) / (2 * kStackRows);
@@ -1021,8 +1169,14 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
     }
     for (int k = n; k < kMaxGroup; ++k) sg.first[k + 1] = sg.first[n];
     hipStream_t s = (hipStream_t)stream;
-    if (path == 0) hipLaunchKernelGGL(mlp3_fwd_split_group_kernel, dim3(sg.first[n]), dim3(256), 0, s, sg);
-    else if (path == 1) hipLaunchKernelGGL((mlp3_fwd_group_kernel<1>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
+    if (path == 0) {
+        hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<1>, dim3(sg.first[n]), dim3(256), split_lds_floats(1) * 4, s, sg);
+    } else if (path == 3) {
+        static const bool ok = grant_lds((const void*)mlp3_fwd_split_group_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+        if (!ok) return RRL_ERANGE;
+        hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<kBigR>, dim3(sg.first[n]), dim3(256),
+                           split_lds_floats(kBigR) * 4, s, sg);
+    } else if (path == 1) hipLaunchKernelGGL((mlp3_fwd_group_kernel<1>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
     else hipLaunchKernelGGL((mlp3_fwd_group_kernel<2>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
     return check_launch();
 }

@@ -51,7 +51,9 @@ struct StepPushArgs {
     const uint8_t* recovery;  // nullable
     // recovery gate evaluated here instead of in a kernel of its own (experiment.py:546-577, rrl_recovery_select):
     // recovery = max(sigmoid(z[i]), sigmoid(z[n + i])) > eps_safe; executed action = recovery ? rec : task
-    const float* sel_z;       // nullable: [2, n] pre-sigmoid Q_risk(s, a_task)
+    const float* sel_z;       // nullable: [2, n] pre-sigmoid Q_risk(s, a_task), as sel_np partial sums sel_ps apart
+    int sel_np;
+    long long sel_ps;
     float sel_eps;
     const float2* sel_rec_action;
     float2* sel_real_out;     // the executed action and the flag are written for the consumers downstream
@@ -93,7 +95,12 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             const float2 task = *reinterpret_cast<const float2*>(p.task_action + i * p.ld_task);
             float2 act;
             if (p.sel_z) {
-                const float q0 = 1.f / (1.f + expf(-p.sel_z[i])), q1 = 1.f / (1.f + expf(-p.sel_z[a.n + i]));
+                float z0 = p.sel_z[i], z1 = p.sel_z[a.n + i];
+                for (int zz = 1; zz < p.sel_np; ++zz) {      // fixed order, as the stand-alone partial-sum kernel
+                    z0 += p.sel_z[zz * p.sel_ps + i];
+                    z1 += p.sel_z[zz * p.sel_ps + a.n + i];
+                }
+                const float q0 = 1.f / (1.f + expf(-z0)), q1 = 1.f / (1.f + expf(-z1));
                 rec = fmaxf(q0, q1) > p.sel_eps;
                 act = rec ? p.sel_rec_action[i] : task;
                 p.sel_real_out[i] = act;
@@ -184,6 +191,8 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
 // host side: argument block shared by the navigation and maze entry points
 struct SelectIn {
     const float* z;
+    int n_part;
+    long long part_stride;
     float eps_safe;
     const float* rec_action;
     float* real_out;
@@ -201,7 +210,8 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
     if (!pos || !t || !obs || !task_action || !memory || !next_obs || !reward || !done || !constraint || !success ||
         !stats || !reward_sums || !ep_reward || ld_task < 2 || (ld_task & 1))
         return RRL_EINVAL;
-    if (sel ? (!sel->z || !sel->rec_action || !sel->real_out || !sel->recovery_out) : !real_action) return RRL_EINVAL;
+    if (sel ? (!sel->z || !sel->rec_action || !sel->real_out || !sel->recovery_out || sel->n_part <= 0) : !real_action)
+        return RRL_EINVAL;
     if (n > memory->cap || (recovery_memory && n > recovery_memory->cap)) return RRL_ERANGE;
     p.step = StepArgs{n, (double2*)pos, (const float2*)real_action, nullptr, seed, counter, counter_dev,
                       counter_inc, (float2*)next_obs, (float2*)obs, reward, done, constraint, success, ep_done,
@@ -210,6 +220,8 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
     p.ld_task = ld_task;
     p.recovery = recovery;
     p.sel_z = sel ? sel->z : nullptr;
+    p.sel_np = sel ? sel->n_part : 1;
+    p.sel_ps = sel ? sel->part_stride : 0;
     p.sel_eps = sel ? sel->eps_safe : 0.f;
     p.sel_rec_action = sel ? (const float2*)sel->rec_action : nullptr;
     p.sel_real_out = sel ? (float2*)sel->real_out : nullptr;

@@ -670,11 +670,13 @@ class FastActor:
             forward_multi([self.pol.forward_desc(obs, save=False), self.rec.forward_desc(obs, save=False)])
             heads_multi([f._gauss_desc(self.pol.parts, noise[0], self.xa[:, 2:4], None, n=n, obs_in=obs, obs_out=self.xa),
                          f._stoch_desc(self.rec.parts, noise[1], self.rec_action, n=n)])
+            if defer_select:
+                self.qr.finalize = False            # the step kernel adds the partial last-layer sums itself
+                zq, zn, zs = self.qr.forward(self.xa, save=False)
+                self.pending_select = (zq, zn, zs, float(eps_safe), self.rec_action)
+                return self.xa[:, 2:4], self.real_action, self.recovery
             self.qr.finalize = True
             zq, _, _ = self.qr.forward(self.xa, save=False)
-            if defer_select:
-                self.pending_select = (zq, float(eps_safe), self.rec_action)
-                return self.xa[:, 2:4], self.real_action, self.recovery
             _lib.check(lib.rrl_recovery_select(n, zq.data_ptr(), eps_safe, self.xa[:, 2:4].data_ptr(), 4,
                                                self.rec_action.data_ptr(), self.real_action.data_ptr(),
                                                self.recovery.data_ptr(), self.task_action.data_ptr(), st),
