@@ -8,5 +8,12 @@ mkdir -p $OUT
 rm -rf /tmp/bench_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bench_prof -o p -- python $R/bench.py --no_cpu_baseline "$@" > $OUT/bench_under_rocprof.json 2>/tmp/bench_prof.err
 cp $(find /tmp/bench_prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-python $R/profiles/kernel_breakdown.py $OUT/kernel_stats.csv 333 > $OUT/breakdown.txt
-head -32 $OUT/breakdown.txt
+# iterations the run executed = launches of the step kernel
+STEPS=$(python - <<PY
+import csv
+rows = list(csv.DictReader(open("$OUT/kernel_stats.csv")))
+print(max([int(r["Calls"]) for r in rows if "step_push_kernel" in r["Name"]] or [1]))
+PY
+)
+python $R/profiles/kernel_breakdown.py $OUT/kernel_stats.csv $STEPS > $OUT/breakdown.txt
+head -40 $OUT/breakdown.txt

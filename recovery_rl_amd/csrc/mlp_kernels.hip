@@ -655,9 +655,18 @@ constexpr float kLogSigMax = 2.f, kLogSigMin = -20.f, kEps = 1e-6f;   // model.p
 
 __device__ __forceinline__ float sigm(float z) { return 1.f / (1.f + expf(-z)); }
 
+// value of a stack output given as np <= 4 partial sums ps floats apart: ((p0 + p1) + p2) + p3, the order of the
+// stand-alone sum kernel.  All loads are issued together (a run-time loop over np chained one memory round trip per
+// part: twelve of them in a row set the 11 us of the critic-loss head backward).
 __device__ __forceinline__ float psum(const float* p, long long idx, int np, long long ps) {
-    float v = p[idx];
-    for (int z = 1; z < np; ++z) v += p[z * ps + idx];
+    const float v0 = p[idx];
+    const float v1 = p[(np > 1 ? ps : 0) + idx];
+    const float v2 = p[(np > 2 ? 2 * ps : 0) + idx];
+    const float v3 = p[(np > 3 ? 3 * ps : 0) + idx];
+    float v = v0;
+    v = np > 1 ? v + v1 : v;
+    v = np > 2 ? v + v2 : v;
+    v = np > 3 ? v + v3 : v;
     return v;
 }
 
@@ -730,19 +739,33 @@ struct HeadBwdArgs {
 };
 
 template <int KIND>
+constexpr int kind_dout() {
+    return (KIND >= RRL_LOSS_SAC_CRITIC && KIND <= RRL_LOSS_QRISK_POLICY) ? 1
+           : KIND == RRL_LOSS_GAUSS_HEAD ? 4 : KIND == RRL_LOSS_STOCH_HEAD ? 2 : 0;   // 0: run-time (plain dOut)
+}
+
+template <int KIND>
 __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx, int g, float (*red)[4][kCols],
                                                    float* dsh) {
     const rrl_loss_t& la = hb.la;
-    const int B = hb.B, H = hb.H, dout = hb.dout, need_w = hb.need_w;
-    const float* __restrict__ h2 = hb.h2;
-    const float* __restrict__ W3 = hb.W3;
+    constexpr int DOUT = kind_dout<KIND>();
+    const int B = hb.B, H = hb.H, dout = DOUT ? DOUT : hb.dout, need_w = hb.need_w;
+    const float* __restrict__ h2 = hb.h2 + (long long)g * B * H;
+    const float* __restrict__ W3 = hb.W3 + (long long)g * dout * H;
     float* __restrict__ dW3 = hb.dW3;
     float* __restrict__ db3 = hb.db3;
-    float* __restrict__ dh2 = hb.dh2;
+    float* __restrict__ dh2 = hb.dh2 + (long long)g * B * H;
     const int hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols;
     const int h = bx * kCols + hc;
     const bool hok = h < H;
     const int hh = hok ? h : H - 1;
+    // operands of the batch loop that do not depend on dOut: requested before the loss formulas are evaluated
+    float w[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) w[o] = o < dout ? W3[(long long)(o < dout ? o : 0) * H + hh] : 0.f;
+    float a0[kUnroll];
+#pragma unroll
+    for (int it = 0; it < kUnroll; ++it) a0[it] = h2[(long long)min(slice + kSlices * it, B - 1) * H + hh];
     float lsum[2] = {0.f, 0.f};
     if constexpr (KIND == kPlainDOut) {
         const float* dO = la.out + (long long)g * B * dout;
@@ -767,29 +790,47 @@ __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx
             if (KIND == RRL_LOSS_STOCH_HEAD && o == 1) lsum[1] += term; else lsum[0] += term;
         }
     }
-    float w[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int o = 0; o < 4; ++o) w[o] = o < dout ? W3[((long long)g * dout + o) * H + hh] : 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     for (int b0 = 0; b0 < B; b0 += kSlices * kUnroll) {
         float a[kUnroll];
+        if (b0 == 0) {
 #pragma unroll
-        for (int it = 0; it < kUnroll; ++it) {
-            const int b = min(b0 + slice + kSlices * it, B - 1);
-            a[it] = h2[((long long)g * B + b) * H + hh];
+            for (int it = 0; it < kUnroll; ++it) a[it] = a0[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < kUnroll; ++it) a[it] = h2[(long long)min(b0 + slice + kSlices * it, B - 1) * H + hh];
         }
+        const bool whole = (b0 + kSlices * kUnroll <= B) & hok;     // uniform for hok-uniform column blocks
+        if (whole) {                                                  // no per-row bounds checks, no store predicates
 #pragma unroll
-        for (int it = 0; it < kUnroll; ++it) {
-            const int b = b0 + slice + kSlices * it;
-            if (b < B) {
+            for (int it = 0; it < kUnroll; ++it) {
+                const int b = b0 + slice + kSlices * it;
                 float d = 0.f;
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
-                    const float go = o < dout ? dsh[b * dout + o] : 0.f;
-                    d = fmaf(go, w[o], d);
-                    acc[o] = fmaf(go, a[it], acc[o]);
+                    if (o < (DOUT ? DOUT : 4)) {
+                        const float go = (DOUT || o < dout) ? dsh[b * dout + (o < dout ? o : 0)] : 0.f;
+                        d = fmaf(go, w[o], d);
+                        acc[o] = fmaf(go, a[it], acc[o]);
+                    }
                 }
-                if (hok) dh2[((long long)g * B + b) * H + h] = a[it] > 0.f ? d : 0.f;
+                dh2[(long long)b * H + h] = a[it] > 0.f ? d : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < kUnroll; ++it) {
+                const int b = b0 + slice + kSlices * it;
+                if (b < B) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const float go = o < dout ? dsh[b * dout + o] : 0.f;
+                        d = fmaf(go, w[o], d);
+                        acc[o] = fmaf(go, a[it], acc[o]);
+                    }
+                    if (hok) dh2[(long long)b * H + h] = a[it] > 0.f ? d : 0.f;
+                }
             }
         }
     }
@@ -1200,7 +1241,7 @@ static int head_loss_args(const rrl_loss_t* la, int G, int B, int H, int dout, c
     if (!la || !la->out || !h2 || !W3 || !dh2) return RRL_EINVAL;
     if (G <= 0 || B <= 0 || B > 1024 || H <= 0 || dout <= 0 || dout > 4) return RRL_ERANGE;
     if (la->kind != kPlainDOut) {
-        if (la->kind < 0 || la->kind > RRL_LOSS_STOCH_HEAD || la->n_part <= 0) return RRL_ERANGE;
+        if (la->kind < 0 || la->kind > RRL_LOSS_STOCH_HEAD || la->n_part <= 0 || la->n_part > 4) return RRL_ERANGE;
         const int heads = la->kind <= RRL_LOSS_QRISK_POLICY ? 2 : 1;
         const int width = la->kind <= RRL_LOSS_QRISK_POLICY ? 1 : (la->kind == RRL_LOSS_GAUSS_HEAD ? 4 : 2);
         if (G != heads || dout != width) return RRL_EINVAL;

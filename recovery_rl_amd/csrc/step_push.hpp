@@ -95,11 +95,17 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             const float2 task = *reinterpret_cast<const float2*>(p.task_action + i * p.ld_task);
             float2 act;
             if (p.sel_z) {
-                float z0 = p.sel_z[i], z1 = p.sel_z[a.n + i];
-                for (int zz = 1; zz < p.sel_np; ++zz) {      // fixed order, as the stand-alone partial-sum kernel
-                    z0 += p.sel_z[zz * p.sel_ps + i];
-                    z1 += p.sel_z[zz * p.sel_ps + a.n + i];
-                }
+                // up to four partial sums, all loads issued together, added in the fixed order of the sum kernel
+                const int np = p.sel_np;
+                const long long ps = p.sel_ps;
+                const float* zp = p.sel_z + i;
+                const float u0 = zp[0], u1 = zp[np > 1 ? ps : 0], u2 = zp[np > 2 ? 2 * ps : 0], u3 = zp[np > 3 ? 3 * ps : 0];
+                const float w0 = zp[a.n], w1 = zp[(np > 1 ? ps : 0) + a.n], w2 = zp[(np > 2 ? 2 * ps : 0) + a.n],
+                            w3 = zp[(np > 3 ? 3 * ps : 0) + a.n];
+                float z0 = u0, z1 = w0;
+                z0 = np > 1 ? z0 + u1 : z0; z1 = np > 1 ? z1 + w1 : z1;
+                z0 = np > 2 ? z0 + u2 : z0; z1 = np > 2 ? z1 + w2 : z1;
+                z0 = np > 3 ? z0 + u3 : z0; z1 = np > 3 ? z1 + w3 : z1;
                 const float q0 = 1.f / (1.f + expf(-z0)), q1 = 1.f / (1.f + expf(-z1));
                 rec = fmaxf(q0, q1) > p.sel_eps;
                 act = rec ? p.sel_rec_action[i] : task;
@@ -210,7 +216,7 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
     if (!pos || !t || !obs || !task_action || !memory || !next_obs || !reward || !done || !constraint || !success ||
         !stats || !reward_sums || !ep_reward || ld_task < 2 || (ld_task & 1))
         return RRL_EINVAL;
-    if (sel ? (!sel->z || !sel->rec_action || !sel->real_out || !sel->recovery_out || sel->n_part <= 0) : !real_action)
+    if (sel ? (!sel->z || !sel->rec_action || !sel->real_out || !sel->recovery_out || sel->n_part <= 0 || sel->n_part > 4) : !real_action)
         return RRL_EINVAL;
     if (n > memory->cap || (recovery_memory && n > recovery_memory->cap)) return RRL_ERANGE;
     p.step = StepArgs{n, (double2*)pos, (const float2*)real_action, nullptr, seed, counter, counter_dev,

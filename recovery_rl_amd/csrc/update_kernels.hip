@@ -23,8 +23,15 @@ __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z
 // A stack output may arrive as `np` partial sums (rrl_mlp3_forward with scratch and no final sum): element
 // idx = p[idx] + p[ps + idx] + ... in that fixed order (the order of the stand-alone sum kernel).
 __device__ __forceinline__ float psum(const float* p, long long idx, int np, long long ps) {
-    float v = p[idx];
-    for (int z = 1; z < np; ++z) v += p[z * ps + idx];
+    // np <= 4; every load issued before the first add, sum in the fixed order ((p0 + p1) + p2) + p3
+    const float v0 = p[idx];
+    const float v1 = p[(np > 1 ? ps : 0) + idx];
+    const float v2 = p[(np > 2 ? 2 * ps : 0) + idx];
+    const float v3 = p[(np > 3 ? 3 * ps : 0) + idx];
+    float v = v0;
+    v = np > 1 ? v + v1 : v;
+    v = np > 2 ? v + v2 : v;
+    v = np > 3 ? v + v3 : v;
     return v;
 }
 
@@ -397,7 +404,7 @@ int rrl_policy_heads_fwd_multi(int n, const rrl_policy_head_t* heads, void* stre
     hg.first[0] = 0;
     for (int k = 0; k < n; ++k) {
         const rrl_policy_head_t& h = heads[k];
-        if (!h.head || !h.scale || !h.bias || !h.action || h.B <= 0 || h.n_part <= 0) return RRL_EINVAL;
+        if (!h.head || !h.scale || !h.bias || !h.action || h.B <= 0 || h.n_part <= 0 || h.n_part > 4) return RRL_EINVAL;
         if (h.kind == RRL_HEAD_GAUSS) {
             if (!h.eps || (h.obs_in && !h.obs_out)) return RRL_EINVAL;
         } else if (h.kind == RRL_HEAD_STOCH) {
@@ -416,7 +423,7 @@ int rrl_policy_heads_fwd_multi(int n, const rrl_policy_head_t* heads, void* stre
 int rrl_gauss_head_bwd(int B, const float* head, int n_part, long long part_stride, const float* eps,
                        const float* scale, const float* d_action, int ld, int n_heads, long long head_stride,
                        float dlogp, float* dhead, void* stream) {
-    if (!head || !eps || !scale || !d_action || !dhead || B <= 0 || n_heads <= 0 || n_part <= 0) return RRL_EINVAL;
+    if (!head || !eps || !scale || !d_action || !dhead || B <= 0 || n_heads <= 0 || n_part <= 0 || n_part > 4) return RRL_EINVAL;
     hipLaunchKernelGGL(gauss_head_bwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, head, n_part,
                        part_stride, eps, scale, d_action, ld, n_heads, head_stride, dlogp, dhead);
     return check_launch();
@@ -425,7 +432,7 @@ int rrl_gauss_head_bwd(int B, const float* head, int n_part, long long part_stri
 int rrl_sac_critic_grad(int B, const float* q, const float* qt, int n_part, long long part_stride,
                         const float* logp2, const float* r, const float* m, float gamma, const float* alpha,
                         const float* penalty, float* dq, float* loss, void* stream) {
-    if (!q || !qt || !logp2 || !r || !m || !alpha || !dq || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    if (!q || !qt || !logp2 || !r || !m || !alpha || !dq || B <= 0 || n_part <= 0 || n_part > 4) return RRL_EINVAL;
     hipLaunchKernelGGL(sac_critic_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, q, qt, n_part,
                        part_stride, logp2, r, m, gamma, alpha, penalty, dq, loss);
     return check_launch();
@@ -433,7 +440,7 @@ int rrl_sac_critic_grad(int B, const float* q, const float* qt, int n_part, long
 
 int rrl_sac_policy_grad(int B, const float* qp, int n_part, long long part_stride, const float* logp,
                         const float* alpha, float* dqp, float* loss, void* stream) {
-    if (!qp || !logp || !alpha || !dqp || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    if (!qp || !logp || !alpha || !dqp || B <= 0 || n_part <= 0 || n_part > 4) return RRL_EINVAL;
     hipLaunchKernelGGL(sac_policy_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, qp, n_part,
                        part_stride, logp, alpha, dqp, loss);
     return check_launch();
@@ -441,7 +448,7 @@ int rrl_sac_policy_grad(int B, const float* qp, int n_part, long long part_strid
 
 int rrl_qrisk_critic_grad(int B, const float* z, const float* zt, int n_part, long long part_stride,
                           const float* c, const float* m, float gamma_safe, float* dz, float* loss, void* stream) {
-    if (!z || !zt || !c || !m || !dz || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    if (!z || !zt || !c || !m || !dz || B <= 0 || n_part <= 0 || n_part > 4) return RRL_EINVAL;
     hipLaunchKernelGGL(qrisk_critic_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, z, zt, n_part,
                        part_stride, c, m, gamma_safe, dz, loss);
     return check_launch();
@@ -449,7 +456,7 @@ int rrl_qrisk_critic_grad(int B, const float* z, const float* zt, int n_part, lo
 
 int rrl_qrisk_policy_grad(int B, const float* zp, int n_part, long long part_stride, float* dzp, float* loss,
                           void* stream) {
-    if (!zp || !dzp || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    if (!zp || !dzp || B <= 0 || n_part <= 0 || n_part > 4) return RRL_EINVAL;
     hipLaunchKernelGGL(qrisk_policy_grad_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, zp, n_part,
                        part_stride, dzp, loss);
     return check_launch();
@@ -458,7 +465,7 @@ int rrl_qrisk_policy_grad(int B, const float* zp, int n_part, long long part_str
 int rrl_stoch_head_fwd(int B, const float* raw, int n_part, long long part_stride, const float* eps,
                        const float* log_std, float min_log_std, const float* scale, const float* bias,
                        float* action, int ld_action, float* mean_out, void* stream) {
-    if (!raw || !log_std || !scale || !bias || !action || B <= 0 || n_part <= 0) return RRL_EINVAL;
+    if (!raw || !log_std || !scale || !bias || !action || B <= 0 || n_part <= 0 || n_part > 4) return RRL_EINVAL;
     hipLaunchKernelGGL(stoch_head_fwd_kernel, rows_grid(B), dim3(kBlock), 0, (hipStream_t)stream, B, raw, n_part,
                        part_stride, eps, log_std, min_log_std, scale, bias, action, ld_action, mean_out);
     return check_launch();
@@ -468,7 +475,7 @@ int rrl_stoch_head_bwd(int B, const float* raw, int n_part, long long part_strid
                        const float* log_std, float min_log_std, const float* scale, const float* d_action, int ld,
                        int n_heads, long long head_stride, float* draw, float* dlog_std, void* stream) {
     if (!raw || !eps || !log_std || !scale || !d_action || !draw || !dlog_std || B <= 0 || n_heads <= 0 ||
-        n_part <= 0)
+        n_part <= 0 || n_part > 4)
         return RRL_EINVAL;
     hipLaunchKernelGGL(stoch_head_bwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, B, raw, n_part,
                        part_stride, eps, log_std, min_log_std, scale, d_action, ld, n_heads, head_stride, draw,
