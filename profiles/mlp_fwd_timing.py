@@ -34,7 +34,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = _lib.load()
 lib.rrl_debug_fwd_stamps.argtypes = [C.c_void_p, C.c_int]
-rows = 64 if M > 1024 else 16
+rows = 32 if M > 1024 else 16
 n_blocks = min(8192, ((M + rows - 1) // rows) * G * 4)
 buf = np.zeros((n_blocks, 8), np.uint64)
 assert lib.rrl_debug_fwd_stamps(buf.ctypes.data, n_blocks) == 0

@@ -427,8 +427,9 @@ constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.
 
 // R = row tiles (of 16 rows) per workgroup.  R = 1 for the small update batches (latency-bound: as many workgroups as
 // possible).  Large batches (the acting pass, 4096 rows) are bound by re-streaming W2 from L2 once per row tile (64 MB
-// per network and forward at R = 1: 14-15 us); with R = 4 a wave keeps its W2 fragments for four row tiles, the
-// stream drops to 16 MB and the 16-row x 256-column tile of a workgroup becomes 64 x 64.  Per output element the
+// per network and forward at R = 1: 14-15 us); with R > 1 a wave keeps its W2 fragments for R row tiles and the stream
+// drops R-fold.  Measured at 4096 rows (profiles/mlp_fwd_probe.py; one head / two heads): plain tiling 15.4 / 20.7 us,
+// R = 1 split 13.9 / 24.2, R = 4 10.4 / 16.0, R = 2 9.6 / 15.4 (more workgroups in flight per CU).  Per output element the
 // arithmetic (MFMA order, partial-sum order) is the same for every R.
 // HC = the hidden width as a compile-time constant (256, the reference's --hidden_size default) or 0 = read it from
 // the arguments.  With HC fixed every loop below is straight-line code: no per-chunk bounds branches between the LDS
@@ -542,6 +543,9 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
                 }
             }
         }
+        // R > 1: the h2 tile reuses the h1 tile's LDS (one 70 KB tile per workgroup instead of 87 KB: two workgroups per
+        // CU), so every wave must be done reading h1 first.  (All four waves own a layer-2 tile here: HC fixes H = 256.)
+        if (R > 1) __syncthreads();
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
             const f32x4 acc = acc0[rt] + acc1[rt];
@@ -595,16 +599,20 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     RRL_STAMP(5);
 }
 
-constexpr int kBigR = 4;     // row tiles per workgroup for batches above kSplitSmallM rows
+#ifndef RRL_BIG_R
+#define RRL_BIG_R 2
+#endif
+constexpr int kBigR = RRL_BIG_R;     // row tiles per workgroup for batches above kSplitSmallM rows
 constexpr int kSplitSmallM = 1024;
 constexpr size_t split_lds_floats(int R) {
-    return size_t(R) * kStackRows * (kStackMaxH + 20) + size_t(R) * kStackRows * (kStackMaxH / kSplit + 1);
+    return size_t(R) * kStackRows * (kStackMaxH + 20) +
+           (R > 1 ? 0 : size_t(R) * kStackRows * (kStackMaxH / kSplit + 1));      // R > 1: h2 aliases h1
 }
 
 template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* h2s = lds + R * kStackRows * (kStackMaxH + 20);
+    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + 20);
     if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
     else mlp3_fwd_split_body<R, 0>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
 }
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg
     while (k + 1 < sg.n && (int)blockIdx.x >= sg.first[k + 1]) ++k;
     const int local = blockIdx.x - sg.first[k];
     const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
-    float* h2s = lds + R * kStackRows * (kStackMaxH + 20);
+    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + 20);
     if (sg.a[k].H == 256)
         mlp3_fwd_split_body<R, 256>(sg.a[k], sg.partial[k], bx, rest % sg.G[k], rest / sg.G[k], sg.G[k], lds, h2s);
     else
@@ -1113,7 +1121,7 @@ int rrl_mlp3_is_split(int M, int H) {
     return (M <= split_max_rows() && (H % (16 * kSplit)) == 0 && H <= kStackMaxH) ? kSplit : 0;
 }
 
-// the R = 4 tiles need more than the default 64 KB of LDS per workgroup (gfx950 has 160 KB per CU): opt in once
+// tiles of R >= 4 need more than the default 64 KB of LDS per workgroup (gfx950 has 160 KB per CU): opt in once
 static bool grant_lds(const void* kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return true;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)) != hipSuccess) {
@@ -1139,7 +1147,7 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
     StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx};
     if (scratch && rrl_mlp3_is_split(M, H)) {
         // 4 workgroups (column groups) per row tile + fixed-order sum of their partial last-layer outputs
-        if (M <= kSplitSmallM) {
+        if (M <= kSplitSmallM || H != 256) {
             hipLaunchKernelGGL(mlp3_fwd_split_kernel<1>, dim3((M + kStackRows - 1) / kStackRows, G, kSplit), dim3(256),
                                split_lds_floats(1) * 4, (hipStream_t)stream, a, scratch);
         } else {
@@ -1181,7 +1189,7 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
     StackGroup sg{};
     sg.n = n;
     sg.first[0] = 0;
-    int path = -1;   // 0 split (small batch), 3 split (R = 4 row tiles), 1 plain R = 1, 2 plain R = 2
+    int path = -1;   // 0 split (small batch), 3 split (R = kBigR row tiles), 1 plain R = 1, 2 plain R = 2
     for (int k = 0; k < n; ++k) {
         const rrl_stack_t& p = st[k];
         const int rc = stack_check(p.G, p.M, p.H, p.din, p.dout, p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.out);
@@ -1192,7 +1200,7 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
         int my;
         const long long tiles16 = (p.M + kStackRows - 1) / kStackRows;
         if (p.scratch && rrl_mlp3_is_split(p.M, p.H)) {
-            my = p.M <= kSplitSmallM ? 0 : 3;
+            my = (p.M <= kSplitSmallM || p.H != 256) ? 0 : 3;      // the multi-row tiles are built for H = 256
             const int rows = (my == 0 ? 1 : kBigR) * kStackRows;
             sg.tiles[k] = (p.M + rows - 1) / rows;
             sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G * kSplit;

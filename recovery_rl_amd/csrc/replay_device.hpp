@@ -26,6 +26,13 @@ __device__ __forceinline__ void store_values(const rrl_replay_t& rb, int64_t slo
     rb.m[slot] = m;
 }
 
+// {position, size} after `pushed` more rows (called by the one thread that won the launch's ticket)
+__device__ __forceinline__ void set_ring(const rrl_replay_t& rb, int64_t pos, int64_t size, int64_t pushed) {
+    rb.state[0] = (pos + pushed) % rb.cap;
+    const int64_t ns = size + pushed;
+    rb.state[1] = ns > rb.cap ? rb.cap : ns;
+}
+
 // Last workgroup to finish advances {position, size}; every workgroup has read them before it takes
 // its ticket, so no workgroup can observe the new values.  Call with all threads of the block.
 __device__ __forceinline__ void advance_ring(const rrl_replay_t& rb, int64_t pos, int64_t size,

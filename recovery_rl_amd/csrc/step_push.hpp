@@ -74,6 +74,21 @@ struct StepPushArgs {
 // (One atomic per wave and iteration serialised 115 k atomics on 7 addresses at 2^20 envs: 719 us.)
 constexpr int kCounters = 7;
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// sum over each 16-lane row, every lane gets the row's total (xor-butterfly order 8, 4, 2, 1 by row rotations)
+__device__ __forceinline__ double row16_sum_f64(double v) {
+    v += dpp_move_f64<0x128>(v);
+    v += dpp_move_f64<0x124>(v);
+    v += dpp_move_f64<0x122>(v);
+    v += dpp_move_f64<0x121>(v);
+    return v;
+}
+
 template <class ENV>
 __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArgs p) {
     constexpr int kBlock = rrl_host::kBlock;
@@ -153,28 +168,29 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             a.t[i] = ti;
             a.obs[i] = make_float2(float(nx), float(ny));
         }
+        // episode counters: one ballot + popcount per counter and wave (wave-uniform scalars, no cross-lane shuffles)
         const bool end_viol = epd & cons;
-        cnt[0] += epd;
-        cnt[1] += end_viol;
-        cnt[2] += end_viol & rec;
-        cnt[3] += end_viol & !rec;
-        cnt[4] += epd & succ;
-        cnt[5] += live & rec;
-        cnt[6] += cons;
+        cnt[0] += __popcll(__ballot(epd));
+        cnt[1] += __popcll(__ballot(end_viol));
+        cnt[2] += __popcll(__ballot(end_viol & rec));
+        cnt[3] += __popcll(__ballot(end_viol & !rec));
+        cnt[4] += __popcll(__ballot(epd & succ));
+        cnt[5] += __popcll(__ballot(live & rec));
+        cnt[6] += __popcll(__ballot(cons));
     }
     __shared__ unsigned block_cnt[kCounters];
-    __shared__ double block_sum[2][kBlock / 64];
+    __shared__ double block_sum[2][kBlock / 16];
     if (threadIdx.x < kCounters) block_cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (int off = 32; off > 0; off >>= 1) {
-        rsum += __shfl_down(rsum, off);
-        retsum += __shfl_down(retsum, off);
-#pragma unroll
-        for (int k = 0; k < kCounters; ++k) cnt[k] += __shfl_down(cnt[k], off);
+    // reward sums: DPP row rotations inside each 16-lane row (no LDS crossbar round trips), then the 16 row sums of the
+    // workgroup in a fixed order
+    rsum = row16_sum_f64(rsum);
+    retsum = row16_sum_f64(retsum);
+    if ((threadIdx.x & 15) == 0) {
+        block_sum[0][threadIdx.x >> 4] = rsum;
+        block_sum[1][threadIdx.x >> 4] = retsum;
     }
     if ((threadIdx.x & 63) == 0) {
-        block_sum[0][threadIdx.x >> 6] = rsum;
-        block_sum[1][threadIdx.x >> 6] = retsum;
 #pragma unroll
         for (int k = 0; k < kCounters; ++k)
             if (cnt[k]) atomicAdd(&block_cnt[k], cnt[k]);
@@ -185,13 +201,23 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
     } else if (threadIdx.x < kCounters + 2) {
         const int w = threadIdx.x - kCounters;
         double sum = 0.0;
-        for (int k = 0; k < kBlock / 64; ++k) sum += block_sum[w][k];       // fixed order inside the workgroup
+        for (int k = 0; k < kBlock / 16; ++k) sum += block_sum[w][k];       // fixed order inside the workgroup
         if (sum != 0.0) atomicAdd(p.reward_sums + w, sum);
+    } else if (blockIdx.x == 0 && threadIdx.x == 64) {
+        atomicAdd(p.stats, (unsigned long long)a.n);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(p.stats, (unsigned long long)a.n);
-    rrl_replay::advance_ring(p.memory, mpos, msize, a.n);
-    if (p.use_recovery_memory) rrl_replay::advance_ring(p.recovery_memory, rpos, rsize, a.n);
-    rrl::advance_counter(a.counter_dev, a.counter_inc);
+    // ONE ticket for the three device-side cursors (both replay rings and the RNG tick): a returning device-scope atomic
+    // is a ~0.7 us round trip, three in a row were a sixth of this kernel.  Every workgroup has read all of them before
+    // it takes the ticket; the last arriver advances them.
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket = atomicAdd((unsigned long long*)&p.memory.state[2], 1ULL);
+        if (ticket == gridDim.x - 1) {
+            p.memory.state[2] = 0;
+            rrl_replay::set_ring(p.memory, mpos, msize, a.n);
+            if (p.use_recovery_memory) rrl_replay::set_ring(p.recovery_memory, rpos, rsize, a.n);
+            if (a.counter_dev && a.counter_inc) a.counter_dev[0] += a.counter_inc;
+        }
+    }
 }
 
 // host side: argument block shared by the navigation and maze entry points
