@@ -237,3 +237,26 @@ def test_learning_level_parity_with_the_reference_run(tmp_path, golden_dir, caps
     # the offline constraint data is distributed like the reference's (14 664 transitions, 903 violations)
     assert abs(exp.num_unsafe_transitions - ref["num_constraint_transitions"]) < 0.04 * ref["num_constraint_transitions"]
     assert abs(exp.num_constraint_violations - ref["num_constraint_violations_offline"]) < 0.15 * ref["num_constraint_violations_offline"]
+
+
+def test_learning_at_the_headline_size_4096_envs(tmp_path, capsys):
+    """BASELINE config 2 (scripts/navigation1.sh:7 + --num_envs 4096) with 16 updates per lock-step iteration: within
+    250 iterations (1 M env-steps, 4 k grad steps, ~1 s) most episodes reach the goal and violations are rare -- the
+    success / violation definitions of plotting/plot_runs.py:214-235 on the device-side counters."""
+    cfg = arg_utils.get_args(["--cuda", "--env-name", "navigation1", "--use_recovery", "--MF_recovery", "--gamma_safe",
+                              "0.8", "--eps_safe", "0.3", "--logdir", str(tmp_path), "--num_unsafe_transitions", "20000",
+                              "--seed", "1", "--num_envs", "4096", "--updates_per_step", "16", "--num_steps",
+                              str(4096 * 250), "--num_eps", "100000000", "--log_every", "25"])
+    exp = Experiment(cfg)
+    hist = exp.run()
+    capsys.readouterr()
+    assert exp.loop.graph is not None and exp.agent.fast.grouped
+    last, mid = hist[-1], hist[len(hist) // 2]
+    assert last["sac_updates"] >= 16 * 200 and last["qrisk_updates"] >= 16 * 200
+    ep = last["episodes"] - mid["episodes"]
+    succ = last["num_successes"] - mid["num_successes"]
+    viol = last["num_viols"] - mid["num_viols"]
+    assert ep > 5000 and succ / ep > 0.8, (ep, succ, viol)
+    assert viol / ep < 0.1, (ep, succ, viol)
+    exp.memory.check_error()
+    exp.recovery_memory.check_error()
