@@ -1,7 +1,10 @@
 """Rates of SURVEY 8d configs 3 (Maze, MF recovery) and 4 (Navigation2, model-based recovery) at 4096 envs on
 one MI355X; config 2 is bench.py's line.  Prints one JSON object per config.
 
-    python profiles/config_rates.py [3|4] [num_envs]
+    python profiles/config_rates.py [3|4] [num_envs] [Q_risk pre-training steps = 10000, the reference's default]
+
+Config 4 is reported twice: with the safety critic as pre-trained on the offline data (the regime the reference runs
+in: only the envs whose Q_risk exceeds eps_safe plan) and -- `untrained` -- with every env planning (worst case).
 """
 import json
 import os
@@ -22,7 +25,7 @@ ARGV = {
 }
 
 
-def run(config, n, pretrain=300):
+def run(config, n, pretrain=10000):
     cfg = arg_utils.get_args(ARGV[config] + ["--cuda", "--num_envs", str(n), "--seed", "1", "--logdir", "/tmp/rrl_rates",
                                              "--critic_safe_pretraining_steps", str(pretrain)])
     exp = Experiment(cfg)
@@ -34,7 +37,7 @@ def run(config, n, pretrain=300):
     loop.start()
     while not (len(exp.memory) > cfg.batch_size and loop.total_numsteps >= cfg.start_steps):
         loop.vector_step(do_update=False, random_actions=True)
-    out = {"config": config, "num_envs": n, "pretrain_s": round(pre_s, 2)}
+    out = {"config": config, "num_envs": n, "qrisk_pretraining_steps": pretrain, "pretrain_s": round(pre_s, 2)}
     if config == 3:
         loop.capture(online_qrisk=True)
         for _ in range(20):
@@ -49,7 +52,7 @@ def run(config, n, pretrain=300):
         out.update(ms_per_iteration=dt * 1e3, env_steps_per_s=n / dt, grad_steps_per_s=1 / dt, graph=True)
     else:
         mpc = exp.recovery_policy
-        sizes, k = [], 6
+        sizes, k = [], 6 if pretrain < 1000 else 30
         for _ in range(2):
             loop.vector_step(do_update=True, online_qrisk=True)
         torch.cuda.synchronize()
@@ -72,5 +75,6 @@ def run(config, n, pretrain=300):
 if __name__ == "__main__":
     which = [int(sys.argv[1])] if len(sys.argv) > 1 else [3, 4]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    pre = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
     for c in which:
-        run(c, n)
+        run(c, n, pre)

@@ -249,7 +249,9 @@ class MPC:
         if self.fused is not None:
             self.fused.pack()              # weights moved since the last call (Q_risk update / re-fit)
         rows = idx if self.prev_sol.shape[0] == n else torch.zeros_like(idx)
-        soln = self.optimizer.obtain_solution(self.prev_sol[rows], self.init_var.expand(idx.numel(), -1))
+        from .utils import trace_range
+        with trace_range("cem"):
+            soln = self.optimizer.obtain_solution(self.prev_sol[rows], self.init_var.expand(idx.numel(), -1))
         shifted = torch.cat([soln[:, self.per * self.dU:],
                              torch.zeros(idx.numel(), self.per * self.dU, dtype=soln.dtype,
                                          device=self.device)], dim=1)          # :342-344

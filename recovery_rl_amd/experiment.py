@@ -30,7 +30,7 @@ from . import distributed as dist_utils
 from .env import make_env, make_vec_env, register_env
 from .replay_memory import ConstraintReplayMemory, ReplayMemory
 from .sac import SAC
-from .utils import linear_schedule
+from .utils import linear_schedule, trace_range
 
 # order of the device-side counter vector (also the RCCL-aggregated metric vector)
 STAT_KEYS = ("env_steps", "episodes", "num_viols", "viol_and_recovery", "viol_and_no_recovery",
@@ -93,7 +93,8 @@ class VectorLoop:
             if grouped:
                 # both replay draws + the policy noise in one launch, independent kernels of the two updates grouped
                 # (fast_update.FastUpdater.update_pair): same results as the two calls below, ~30 % fewer launches
-                fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None)
+                with trace_range("sample+sac_update+qrisk_update"):
+                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None)
                 self.host_updates[0] += 1
                 if online_qrisk:
                     qr.updates += 1
@@ -101,14 +102,16 @@ class VectorLoop:
                     self.host_updates[1] += 1
                 self.updates += 1
                 continue
-            self.agent.update_parameters(self.memory, cfg.batch_size, self.updates,
-                                         safety_critic=self.agent.safety_critic,
-                                         nu=self.nu_schedule(i_episode))
+            with trace_range("sample+sac_update"):
+                self.agent.update_parameters(self.memory, cfg.batch_size, self.updates,
+                                             safety_critic=self.agent.safety_critic,
+                                             nu=self.nu_schedule(i_episode))
             self.host_updates[0] += 1
             if online_qrisk:
-                self.agent.safety_critic.update_parameters(memory=self.recovery_memory,
-                                                           policy=self.agent.policy,
-                                                           batch_size=cfg.batch_size, plot=0)
+                with trace_range("sample+qrisk_update"):
+                    self.agent.safety_critic.update_parameters(memory=self.recovery_memory,
+                                                               policy=self.agent.policy,
+                                                               batch_size=cfg.batch_size, plot=0)
                 self.host_updates[1] += 1
             self.updates += 1
 
@@ -260,9 +263,11 @@ class VectorLoop:
     def vector_step(self, do_update=True, random_actions=False, online_qrisk=True, i_episode=1):
         if do_update:
             self.do_updates(i_episode, online_qrisk)
-        action, real_action, recovery = self.act(self.obs, random_actions)
+        with trace_range("act"):
+            action, real_action, recovery = self.act(self.obs, random_actions)
         self._last_recovery = recovery
-        return self.step_and_store(action, real_action, recovery)
+        with trace_range("env_step+push"):
+            return self.step_and_store(action, real_action, recovery)
 
     def capture(self, online_qrisk=True, warmup=3):
         """Capture the steady-state iteration (updates + act + step + push + counters) into one

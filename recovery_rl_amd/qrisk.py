@@ -117,9 +117,10 @@ class QRiskWrapper:
         return self.safety_critic(states, actions)                        # :303-307
 
     @torch.no_grad()
-    def select_action(self, state, eval=False):
+    def select_action(self, state, eval=False, candidates=None):
         """Recovery action (qrisk.py:198-227).  Accepts a [N,2] CUDA tensor (returns a tensor) or a
-        single numpy state (returns numpy, like the reference)."""
+        single numpy state (returns numpy, like the reference).  `candidates` [N,1000,dU] injects the
+        action_space.sample() draws of the Q-sampling branch (KAT tests)."""
         single = not torch.is_tensor(state)
         if single:
             state = torch.as_tensor(np.asarray(state, dtype=np.float32), device=self.device).unsqueeze(0)
@@ -131,7 +132,8 @@ class QRiskWrapper:
             n, k = state.shape[0], 1000
             lo = torch.as_tensor(self.ac_space.low, dtype=torch.float32, device=self.device)
             hi = torch.as_tensor(self.ac_space.high, dtype=torch.float32, device=self.device)
-            cand = lo + (hi - lo) * torch.rand(n, k, lo.numel(), device=self.device)
+            cand = lo + (hi - lo) * torch.rand(n, k, lo.numel(), device=self.device) if candidates is None else \
+                torch.as_tensor(candidates, dtype=torch.float32, device=self.device).reshape(n, k, -1)
             q = self.get_value(state.unsqueeze(1).expand(n, k, -1).reshape(n * k, -1),
                                cand.reshape(n * k, -1)).reshape(n, k)
             out = cand[torch.arange(n, device=self.device), q.argmin(dim=1)]

@@ -108,19 +108,32 @@ class SAC(object):
             action = mean if eval else sampled
         return action[0].cpu().numpy() if single else action
 
-    def _sqrl_action(self, state, safe_samples=100):
-        """SQRL rejection sampling (sac.py:139-161) for every env of the batch at once: draw 100
-        actions, keep those with Q_risk <= eps_safe and pick one with probability proportional to
-        exp(log pi); if none is safe take the argmin of Q_risk."""
+    @torch.no_grad()
+    def _sqrl_action(self, state, safe_samples=100, eps=None, draw=None):
+        """SQRL constraint sampling (sac.py:139-161) for every env of the batch at once: draw 100 candidate actions,
+        keep those with Q_risk <= eps_safe and draw ONE with probability proportional to pi(a|s) = exp(log pi) over the
+        safe ones; no safe candidate -> the argmin of Q_risk.
+
+        Bug-compatible with the reference on purpose (results parity): its Categorical runs over the safe candidates
+        only, and the drawn position j -- an index into that SAFE list -- is then used on the FULL candidate list
+        (`pi[sampled_idx]`, sac.py:157-158), so the executed action is candidate j, safe or not.  `eps` [n,k,dU]
+        injects the candidate noise and `draw` [n] the categorical's result (a position in the safe list) -- KAT tests."""
         n, k = state.shape[0], safe_samples
         sb = state.unsqueeze(1).expand(n, k, state.shape[1]).reshape(n * k, -1)
-        pi, log_pi, _ = self.policy.sample(sb)
+        pi, log_pi, _ = self.policy.sample(sb, None if eps is None else eps.reshape(n * k, -1))
         q = self.safety_critic.get_value(sb, pi).reshape(n, k)
-        w = torch.exp(log_pi.reshape(n, k)) * (q <= self.eps_safe)
-        none_safe = w.sum(1) <= 0
-        fallback = F.one_hot(q.argmin(1), k).to(w.dtype)
-        w = torch.where(none_safe.unsqueeze(1), fallback, w)
-        pick = torch.multinomial(w, 1).squeeze(1)
+        safe = q <= self.eps_safe
+        n_safe = safe.sum(1)
+        if draw is None:
+            # Categorical over the safe candidates = multinomial over all candidates with the unsafe weights zeroed;
+            # its position within the compacted safe list is the number of safe candidates up to it
+            w = torch.exp(log_pi.reshape(n, k)) * safe
+            w = torch.where((n_safe > 0).unsqueeze(1), w, torch.ones_like(w))
+            cand = torch.multinomial(w, 1)
+            j = (safe.to(torch.int64).cumsum(1).gather(1, cand).squeeze(1) - 1).clamp(min=0)
+        else:
+            j = torch.as_tensor(draw, dtype=torch.int64, device=state.device).clamp(min=0)
+        pick = torch.where(n_safe > 0, j, q.argmin(1))                 # sac.py:153-158
         return pi.reshape(n, k, -1)[torch.arange(n, device=state.device), pick]
 
     # -- learning ----------------------------------------------------------------------------

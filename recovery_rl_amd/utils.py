@@ -1,5 +1,31 @@
 """Small helpers of the hot path (reference: recovery_rl/utils.py:46-64)."""
+import os
+
 import torch
+
+# RRL_ROCTX=1: roctx ranges (torch.cuda.nvtx maps to roctx on ROCm) around the stages of the lock-step iteration, so a
+# `rocprofv3 --marker-trace --kernel-trace` run of the EAGER loop (bench.py --no_graph) attributes kernels to
+# sample / sac_update / qrisk_update / act / env_step / cem without name matching.  Off by default: a range is two host
+# calls per stage, and ranges inside a captured hipGraph mean nothing (the graph is one launch).
+TRACE = os.environ.get("RRL_ROCTX", "") not in ("", "0")
+
+
+class trace_range:
+    """with trace_range("env_step"): ...  -- a roctx range when RRL_ROCTX=1, nothing otherwise."""
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TRACE:
+            torch.cuda.nvtx.range_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if TRACE:
+            torch.cuda.nvtx.range_pop()
+        return False
 
 
 @torch.no_grad()

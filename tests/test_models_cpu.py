@@ -32,7 +32,7 @@ def load(module, G, prefix):
 
 
 def close(a, b):
-    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     return np.allclose(a, b, rtol=RTOL, atol=ATOL)
 
 
@@ -41,7 +41,7 @@ def assert_params(module, G, prefix):
     for k, v in module.state_dict().items():
         key = prefix + "." + k
         if key in G.files and "num_batches_tracked" not in k:
-            assert np.allclose(v.numpy(), G[key], rtol=RTOL, atol=ATOL), key
+            assert np.allclose(v.cpu().numpy(), G[key], rtol=RTOL, atol=ATOL), key
             n += 1
     assert n >= 4
 
@@ -75,8 +75,10 @@ def test_parameter_counts_match_survey():
     assert count(StochasticPolicy(2, 2, 256, ACT)) == 67076
 
 
-def make_agent(G, name):
+def make_agent(G, name, device="cpu"):
     argv = ["--env-name", "navigation1", "--hidden_size", "16"] + str(G[name + ".argv"]).split()
+    if device != "cpu" and "--cuda" not in argv:
+        argv.append("--cuda")
     args = arg_utils.get_args(argv)
     agent = SAC(OBS, ACT, args, "/tmp")
     pre = name + ".pre"
@@ -166,3 +168,91 @@ def test_select_action_shapes_and_eval():
     agent = SAC(OBS, ACT, args, "/tmp")
     a = agent.select_action(s)
     assert a.shape == (32, 2) and (a.abs() <= 1).all()
+
+
+# ---- sampling-based selectors pinned to the reference (tests/golden/select_golden.npz, gen_select_golden.py) --------
+@pytest.fixture(scope="module")
+def S(golden_dir):
+    return np.load(os.path.join(golden_dir, "select_golden.npz"))
+
+
+def _load_prefixed(module, S, prefix):
+    sd = {k[len(prefix) + 1:]: torch.as_tensor(S[k]) for k in S.files if k.startswith(prefix + ".")}
+    module.load_state_dict(sd, strict=True)
+
+
+def sqrl_agent(S, device="cpu"):
+    args = arg_utils.get_args(["--env-name", "navigation1", "--hidden_size", "16", "--DGD_constraints",
+                               "--use_constraint_sampling"] + (["--cuda"] if device != "cpu" else []))
+    agent = SAC(OBS, ACT, args, "/tmp")
+    _load_prefixed(agent.policy, S, "sqrl.policy")
+    _load_prefixed(agent.safety_critic.safety_critic, S, "sqrl.qrisk")
+    return agent
+
+
+def check_sqrl(S, device):
+    agent = sqrl_agent(S, device)
+    n = len(S["sqrl.u"])
+    seen = set()
+    for c in range(n):
+        agent.eps_safe = float(S["sqrl.eps_safe"][c])
+        st = torch.as_tensor(S["sqrl.state"][c], dtype=torch.float32, device=device).unsqueeze(0)
+        eps = torch.as_tensor(S["sqrl.noise"][c], device=device).unsqueeze(0)
+        a = agent._sqrl_action(st, eps=eps, draw=S["sqrl.idx"][c:c + 1])[0].detach().cpu().numpy()
+        assert np.allclose(a, S["sqrl.action"][c], rtol=1e-5, atol=1e-6), (c, a, S["sqrl.action"][c], S["sqrl.n_safe"][c])
+        seen.add(int(S["sqrl.n_safe"][c]))
+    assert 0 in seen and 100 in seen and any(0 < k < 100 for k in seen)       # argmin branch, all safe, mixed
+    # batched call == the per-state calls (the vectorised loop evaluates all envs at once)
+    agent.eps_safe = float(S["sqrl.eps_safe"][4])
+    rows = [c for c in range(n) if S["sqrl.eps_safe"][c] == S["sqrl.eps_safe"][4]] or [4]
+    st = torch.as_tensor(S["sqrl.state"][rows], dtype=torch.float32, device=device)
+    out = agent._sqrl_action(st, eps=torch.as_tensor(S["sqrl.noise"][rows], device=device),
+                             draw=S["sqrl.idx"][rows])
+    assert np.allclose(out.detach().cpu().numpy(), S["sqrl.action"][rows], rtol=1e-5, atol=1e-6)
+
+
+def check_q_sampling(S, device):
+    args = arg_utils.get_args(["--env-name", "navigation1", "--hidden_size", "16", "--use_recovery",
+                               "--Q_sampling_recovery"] + (["--cuda"] if device != "cpu" else []))
+    agent = SAC(OBS, ACT, args, "/tmp")
+    _load_prefixed(agent.safety_critic.safety_critic, S, "qs.qrisk")
+    st = torch.as_tensor(S["qs.state"], dtype=torch.float32, device=device)
+    out = agent.safety_critic.select_action(st, candidates=S["qs.candidates"])
+    assert np.array_equal(out.cpu().numpy(), S["qs.action"])               # the reference's argmin candidate, row by row
+    one = agent.safety_critic.select_action(S["qs.state"][1], candidates=S["qs.candidates"][1:2])
+    assert isinstance(one, np.ndarray) and np.array_equal(one, S["qs.action"][1])
+
+
+def test_sqrl_constraint_sampling_matches_reference(S):
+    """sac.py:139-161 incl. the reference's indexing of the full candidate list with the safe-list position."""
+    check_sqrl(S, "cpu")
+
+
+def test_q_sampling_recovery_matches_reference(S):
+    """qrisk.py:214-225: argmin of Q_risk over 1000 injected uniform candidates."""
+    check_q_sampling(S, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ("sac", "sac_autoent", "sac_dgd", "sac_rcpo"))
+def test_one_sac_update_matches_reference_on_the_gpu(G, name):
+    """The LR / RCPO / auto-entropy KATs of G4 through the modules on cuda (autograd path of the comparison algorithms)."""
+    agent, args = make_agent(G, name, device="cuda")
+    dev = agent.device
+    eps_next, eps_pi = torch.as_tensor(G["g4.eps_next"], device=dev), torch.as_tensor(G["g4.eps_pi"], device=dev)
+    res = agent.update_parameters(None, 8, 0, nu=args.nu, safety_critic=agent.safety_critic,
+                                  batch=tuple(t.to(dev) for t in batch_of(G)), eps_next=eps_next, eps_pi=eps_pi,
+                                  as_floats=True)
+    assert np.allclose(res, G[name + ".returns"], rtol=RTOL, atol=ATOL), (res, G[name + ".returns"])
+    post = name + ".post"
+    assert_params(agent.critic, G, post + ".critic")
+    assert_params(agent.critic_target, G, post + ".critic_target")
+    assert_params(agent.policy, G, post + ".policy")
+    assert np.isclose(agent.log_nu.item(), G[post + ".log_nu"], rtol=RTOL)
+    assert np.isclose(agent.log_lambda_RCPO.item(), G[post + ".log_lambda"], rtol=RTOL)
+
+
+@pytest.mark.gpu
+def test_sampling_selectors_match_reference_on_the_gpu(S):
+    check_sqrl(S, "cuda")
+    check_q_sampling(S, "cuda")

@@ -98,3 +98,29 @@ def test_planner_acts_through_the_fused_kernel_and_repacks_after_updates():
         agent.safety_critic.safety_critic.linear2.weight.add_(0.01)
     mpc.act(obs, 0)
     assert not torch.equal(before, mpc.fused.packed)
+
+
+def test_fused_cost_at_config4_scale_4096_planning_envs():
+    """BASELINE config 4's worst case: all 4096 envs plan at once (M = 4096, pop = 400, 20 particles, 5 steps = 164 M
+    particle-steps per CEM iteration, through the ragged-tail / chunking / finish path of the kernel).  The PyTorch path
+    (pinned to the reference by KAT G7c) evaluates a strided subset of the envs with the same noise rows."""
+    env, mpc, _ = build(seed=3)
+    M, pop = 4096, 400
+    g = torch.Generator(device=DEV).manual_seed(77)
+    acs = torch.rand(M, pop, mpc.plan_hor * 2, device=DEV, generator=g) * 2 - 1
+    obs = torch.randn(M, 2, device=DEV, generator=g) * torch.tensor([1.5, 1.0], device=DEV) + \
+        torch.tensor([-0.5, 0.3], device=DEV)
+    per_env = pop * mpc.npart
+    noise = torch.randn(mpc.plan_hor, M * per_env, 2, device=DEV, generator=g)        # 1.3 GB
+    got = mpc._compile_cost(acs, obs, noise=noise, fused=True)
+    assert got.shape == (M, pop) and torch.isfinite(got).all()
+    rows = torch.tensor([0, 1, 255, 256, 1023, 2048, 3000, 4094, 4095], device=DEV)   # first / last groups, interior
+    sub_noise = torch.cat([noise[:, int(m) * per_env:(int(m) + 1) * per_env] for m in rows], dim=1)
+    want = mpc._compile_cost(acs[rows], obs[rows], noise=sub_noise, fused=False)
+    assert float(want.std()) > 0.05
+    torch.testing.assert_close(got[rows], want, rtol=RTOL, atol=ATOL)
+    # in-kernel Philox noise at the same size: finite, different draws per env, tick advanced once
+    t0 = int(mpc.fused.tick[0].item())
+    free = mpc._compile_cost(acs, obs, fused=True)
+    assert torch.isfinite(free).all() and int(mpc.fused.tick[0].item()) == t0 + 1
+    assert float((free - got).abs().mean()) > 1e-4
