@@ -23,7 +23,8 @@ def _launch(tmp_path, mode, port):
            "--dp_mode", mode]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    dirs = sorted(glob.glob(os.path.join(str(tmp_path), "*_seed*")))
+    # one directory per rank; the names start with a wall-clock stamp, so order them by the seed suffix
+    dirs = sorted(glob.glob(os.path.join(str(tmp_path), "*_seed*")), key=lambda d: d.rsplit("_seed", 1)[1])
     assert len(dirs) == 2 and dirs[0].endswith("_seed4") and dirs[1].endswith("_seed5")
     return [torch.load(os.path.join(d, "checkpoint.pt"), map_location="cpu", weights_only=False) for d in dirs], out
 
