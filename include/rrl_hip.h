@@ -334,6 +334,8 @@ typedef struct {
     long long head_stride;
     const float* d_action;
     float* loss;
+    int da_parts;                /* 0/1: d_action is a plain tensor; k: the sum of k partials da_part_stride apart */
+    long long da_part_stride;    /* (the dx_part of rrl_first_layer_t: k = H/16 <= 16) */
 } rrl_loss_t;
 int rrl_mlp_head_backward_loss(const rrl_loss_t* loss, int G, int B, int H, int dout, const float* h2,
                                const float* W3, float* dW3, float* db3, float* dh2, void* stream);
@@ -364,10 +366,26 @@ typedef struct {
     const float *h2, *W3;
     float *dW3, *db3, *dh2;
 } rrl_head_bwd_t;
+/* First layer of the stack backward done by the hidden-layer launch itself (instead of rrl_mlp_input_backward as a
+ * dependent launch): every 16 x 16 tile of dh1 = (dh2 W2) * [h1 > 0] also emits its share of
+ *   dW1 = dh1^T x, db1 = column sums of dh1   -> first_part [B/16][first_stride]: row-tile t's partial of dW1[g][h][d] at
+ *                                                 t*first_stride + (g*H + h)*din + d, of db1[g][h] at ... + G*H*din + g*H + h
+ *                                                 (the layout of the head of a flat [W1 | b1 | ...] gradient buffer);
+ *   dx  = dh1 W1                              -> dx_part [H/16][G][B][din]: column-tile partials.
+ * Consumers add the partials in a fixed order: rrl_adam_step_multi (g_part fields of the segment) and the policy-head
+ * backward (da_parts of rrl_loss_t).  x = NULL: no first-layer work (then dh1 must be given).  Needs B, H % 128 == 0. */
+typedef struct {
+    const float *x, *W1;
+    int ldx, din;
+    float* first_part;
+    long long first_stride;
+    float* dx_part;
+} rrl_first_layer_t;
 typedef struct {
     int G, B, H;
     const float *dh2, *h1, *W2;
-    float *dW2, *db2, *dh1;
+    float *dW2, *db2, *dh1;       /* dh1 nullable when `first` consumes it */
+    rrl_first_layer_t first;
 } rrl_hidden_bwd_t;
 typedef struct {
     int G, B, H, din, ldx;
@@ -458,6 +476,9 @@ typedef struct {
     float tau;
     float weight_decay;   /* g <- g + weight_decay * p before the moment updates (torch.optim.Adam weight_decay) */
     const float* g2;      /* nullable: second partial gradient, g <- g + g2 (rrl_ens_train_grad) */
+    const float* g_part;  /* nullable: the first part_elems gradients are the sum of n_part partials part_stride apart */
+    int n_part;           /* (first_part of rrl_first_layer_t; added in a fixed order; n_part <= 64, part_elems % 4 == 0) */
+    long long part_stride, part_elems;
 } rrl_adam_seg_t;
 int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2, float eps,
                         void* stream);

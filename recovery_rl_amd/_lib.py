@@ -98,7 +98,7 @@ class rrl_loss_t(C.Structure):
                 ("out_t", C.c_void_p), ("v0", C.c_void_p), ("v1", C.c_void_p), ("v2", C.c_void_p),
                 ("v3", C.c_void_p), ("alpha", C.c_void_p), ("f0", C.c_float), ("ld", C.c_int),
                 ("n_heads", C.c_int), ("head_stride", C.c_longlong), ("d_action", C.c_void_p),
-                ("loss", C.c_void_p)]
+                ("loss", C.c_void_p), ("da_parts", C.c_int), ("da_part_stride", C.c_longlong)]
 
 
 class rrl_stack_t(C.Structure):
@@ -111,9 +111,14 @@ class rrl_head_bwd_t(C.Structure):
         (n, C.c_void_p) for n in ("h2", "W3", "dW3", "db3", "dh2")]
 
 
+class rrl_first_layer_t(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("W1", C.c_void_p), ("ldx", C.c_int), ("din", C.c_int), ("first_part", C.c_void_p),
+                ("first_stride", C.c_longlong), ("dx_part", C.c_void_p)]
+
+
 class rrl_hidden_bwd_t(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("G", "B", "H")] + [
-        (n, C.c_void_p) for n in ("dh2", "h1", "W2", "dW2", "db2", "dh1")]
+        (n, C.c_void_p) for n in ("dh2", "h1", "W2", "dW2", "db2", "dh1")] + [("first", rrl_first_layer_t)]
 
 
 class rrl_input_bwd_t(C.Structure):
@@ -140,7 +145,8 @@ class rrl_draw_t(C.Structure):
 class rrl_adam_seg_t(C.Structure):
     _fields_ = [("n", C.c_longlong), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
                 ("step_dev", C.c_void_p), ("target", C.c_void_p), ("tau", C.c_float), ("weight_decay", C.c_float),
-                ("g2", C.c_void_p)]
+                ("g2", C.c_void_p), ("g_part", C.c_void_p), ("n_part", C.c_int), ("part_stride", C.c_longlong),
+                ("part_elems", C.c_longlong)]
 
 
 class rrl_plan_weights_t(C.Structure):

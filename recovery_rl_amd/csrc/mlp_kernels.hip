@@ -44,6 +44,19 @@ struct GemmArgs {
     long long sA, sB, sC, sBias, sMask, sColsum;  // per-head strides (elements)
     int relu;
     int accumulate;       // C += result
+    // NN tiles of a stack backward can finish the FIRST layer's backward as well (rrl_mlp_input_backward), from the
+    // 16 x 16 tile of dh1 they hold, instead of a dependent launch that re-reads dh1:
+    //   first_part[by][g*H*din + col*din + d] = sum over the tile's 16 rows of dh1[row][col] x[row][d]   (dW1 partial)
+    //   first_part[by][G*H*din + g*H + col]   = sum over the tile's 16 rows of dh1[row][col]             (db1 partial)
+    //   dx_part[bx][g][row][d]                = sum over the tile's 16 cols of dh1[row][col] W1[col][d]   (dx partial)
+    // The consumers (Adam; the policy-head backward) add the 16 row-tile / column-tile partials in a fixed order.
+    const float* x;       // [M, din] rows ldx apart, shared by the heads; null = no first-layer work
+    const float* W1;      // [G, N, din]
+    float* first_part;    // nullable
+    float* dx_part;       // nullable
+    long long first_stride;
+    int ldx, din, G;
+    int skip_c;           // do not write the C tile itself (dh1): nothing reads it once the first layer is done here
 };
 
 struct Frag {
@@ -157,6 +170,8 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
     // epilogue: lane holds C[row][col], col = lane & 15, row = 4 (lane >> 4) + r
     const int col = n0 + (lane & 15);
     const float bias = (MODE == 0 && a.bias && col < a.N) ? a.bias[g * a.sBias + col] : 0.f;
+    float vout[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool store_c = MODE != 1 || !a.skip_c;
     if (col < a.N) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -168,9 +183,41 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
                     const float s = a.mask[g * a.sMask + (long long)row * a.ldmask + col];
                     v = s > 0.f ? v : 0.f;
                 }
-                float* dst = C + (long long)row * a.ldc + col;
-                *dst = a.accumulate ? (*dst + v) : v;
+                vout[r] = v;
+                if (store_c) {
+                    float* dst = C + (long long)row * a.ldc + col;
+                    *dst = a.accumulate ? (*dst + v) : v;
+                }
             }
+        }
+    }
+    if constexpr (MODE == 1) {
+        if (a.x) {      // first-layer backward from this tile (FAST geometry: full tiles); a WG is one wavefront
+            // the tile and the 16 rows of x / W1 it meets, through LDS (the K loop is done with Bs)
+            float* T = Bs;                    // [16][17] tile, then xs [16][4] at 272, ws [16][4] at 336
+            const int rr = lane & 15, dd = lane >> 4;
+            const float xv = dd < a.din ? a.x[(long long)(m0 + rr) * a.ldx + dd] : 0.f;
+            const float wv = dd < a.din ? a.W1[((long long)g * a.N + n0 + rr) * a.din + dd] : 0.f;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = vout[r];
+            T[272 + rr * 4 + dd] = xv;
+            T[336 + rr * 4 + dd] = wv;
+            __syncthreads();
+            float sw = 0.f, sb = 0.f, sx = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float tc = T[k * 17 + rr];                     // dh1[row k][col rr]
+                sw = fmaf(tc, T[272 + k * 4 + dd], sw);              // x[row k][d]
+                sb += tc;
+                sx = fmaf(T[rr * 17 + k], T[336 + k * 4 + dd], sx);  // dh1[row rr][col k] W1[col k][d]
+            }
+            if (a.first_part && dd < a.din)
+                a.first_part[by * a.first_stride + ((long long)g * a.N + n0 + rr) * a.din + dd] = sw;
+            if (a.first_part && dd == 0)
+                a.first_part[by * a.first_stride + (long long)a.G * a.N * a.din + (long long)g * a.N + n0 + rr] = sb;
+            if (a.dx_part && dd < a.din)
+                a.dx_part[(((long long)bx * a.G + g) * a.M + m0 + rr) * a.din + dd] = sx;
         }
     }
     if (MODE == 2 && a.colsum && bx == 0) {
@@ -678,6 +725,23 @@ __device__ __forceinline__ float psum(const float* p, long long idx, int np, lon
     return v;
 }
 
+// dL/d action[b][j]: over the critic heads that consumed the action and, when the critic's first-layer backward came out
+// of the hidden-layer tiles (rrl_first_layer_t), over their column-tile partials -- up to 2 x 16 loads, all issued
+// before the first add, summed head by head, tile by tile.
+__device__ __forceinline__ float d_action_sum(const rrl_loss_t& a, int b, int j) {
+    const float* p = a.d_action + (long long)b * a.ld + j;
+    const int parts = a.da_parts > 1 ? a.da_parts : 1;
+    float da = 0.f;
+    for (int hd = 0; hd < a.n_heads; ++hd) {
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = p[hd * a.head_stride + (t < parts ? t : 0) * a.da_part_stride];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) da = t < parts ? da + v[t] : da;
+    }
+    return da;
+}
+
 // dOut[g][b][o]; `term` = this element's contribution to loss[g] (critics), loss[0] (policies, g == 0 only)
 // or dlog_std[o] (stochastic head)
 template <int KIND>
@@ -712,7 +776,7 @@ __device__ __forceinline__ float dout_at(const rrl_loss_t& a, int B, int g, int 
     } else if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
         const int j = o & 1;
         float da = 0.f;
-        for (int hd = 0; hd < a.n_heads; ++hd) da += a.d_action[hd * a.head_stride + (long long)b * a.ld + j];
+        da = d_action_sum(a, b, j);
         const float mean = psum(a.out, 4 * b + j, np, ps);
         const float raw = psum(a.out, 4 * b + 2 + j, np, ps);
         const float ls = fminf(fmaxf(raw, kLogSigMin), kLogSigMax);
@@ -727,7 +791,7 @@ __device__ __forceinline__ float dout_at(const rrl_loss_t& a, int B, int g, int 
         const int j = o;
         const float t = tanhf(psum(a.out, 2 * b + j, np, ps));
         float da = 0.f;
-        for (int hd = 0; hd < a.n_heads; ++hd) da += a.d_action[hd * a.head_stride + (long long)b * a.ld + j];
+        da = d_action_sum(a, b, j);
         const float sd = expf(fmaxf(a.v1[j], a.f0));
         term = (a.v1[j] >= a.f0) ? da * sd * a.v0[2 * b + j] : 0.f;
         return da * a.v2[j] * (1.f - t * t);
@@ -1063,12 +1127,17 @@ int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, 
 
 // GemmArgs of one stack's hidden-layer backward (TN: dW2 + db2; NN: dh1)
 static bool hidden_args(int G, int B, int H, const float* dh2, const float* h1, const float* W2, float* dW2, float* db2,
-                        float* dh1, GemmArgs& tn, GemmArgs& nn) {
+                        float* dh1, GemmArgs& tn, GemmArgs& nn, const rrl_first_layer_t* fl = nullptr) {
     const long long sAct = (long long)B * H, sW = (long long)H * H;
     // TN: dW2 [H,H] = dh2^T [H,B] . h1 [B,H], column sums of dh2 -> db2        (A = dh2, K = B)
     tn = GemmArgs{dh2, h1, dW2, nullptr, nullptr, db2, H, H, B, H, H, H, 0, sAct, sAct, sW, 0, 0, (long long)H, 0, 0};
     // NN: dh1 [B,H] = dh2 [B,H] . W2 [H,H], masked by h1 > 0                     (K = H)
     nn = GemmArgs{dh2, W2, dh1, nullptr, h1, nullptr, B, H, H, H, H, H, H, sAct, sW, sAct, 0, sAct, 0, 0, 0};
+    if (fl && fl->x) {
+        nn.x = fl->x; nn.W1 = fl->W1; nn.first_part = fl->first_part; nn.dx_part = fl->dx_part;
+        nn.first_stride = fl->first_stride; nn.ldx = fl->ldx; nn.din = fl->din; nn.G = G;
+        nn.skip_c = dh1 == nullptr;
+    }
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return (H % kTile) == 0 && (B % kTile) == 0 && (H % kPanel) == 0 && (B % kPanel) == 0 && al(dh2) && al(h1) && al(W2);
 }
@@ -1093,9 +1162,14 @@ int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* strea
     hg.first[0] = 0;
     for (int k = 0; k < n; ++k) {
         const rrl_hidden_bwd_t& p = ps[k];
-        if (!p.dh2 || !p.h1 || !p.W2 || !p.dh1 || ((p.dW2 == nullptr) != (p.db2 == nullptr))) return RRL_EINVAL;
+        if (!p.dh2 || !p.h1 || !p.W2 || ((p.dW2 == nullptr) != (p.db2 == nullptr))) return RRL_EINVAL;
         if (p.G <= 0 || p.G > 65535 || p.B <= 0 || p.H <= 0) return RRL_ERANGE;
-        hg.fast[k] = hidden_args(p.G, p.B, p.H, p.dh2, p.h1, p.W2, p.dW2, p.db2, p.dh1, hg.tn[k], hg.nn[k]);
+        const bool first = p.first.x != nullptr;
+        if (first && (!p.first.W1 || p.first.din <= 0 || p.first.din > 4 || (!p.first.first_part && !p.first.dx_part)))
+            return RRL_EINVAL;
+        if (!p.dh1 && !first) return RRL_EINVAL;
+        hg.fast[k] = hidden_args(p.G, p.B, p.H, p.dh2, p.h1, p.W2, p.dW2, p.db2, p.dh1, hg.tn[k], hg.nn[k], &p.first);
+        if (first && !hg.fast[k]) return RRL_ERANGE;          // the fused first layer needs full, aligned tiles
         const int tx = (p.H + kTile - 1) / kTile, ny = (p.B + kTile - 1) / kTile;
         hg.tn_tiles_x[k] = tx;
         hg.tn_tiles[k] = p.dW2 ? tx * tx : 0;           // no weight gradient wanted: input gradient tiles only
@@ -1253,6 +1327,7 @@ static int head_loss_args(const rrl_loss_t* la, int G, int B, int H, int dout, c
         const int heads = la->kind <= RRL_LOSS_QRISK_POLICY ? 2 : 1;
         const int width = la->kind <= RRL_LOSS_QRISK_POLICY ? 1 : (la->kind == RRL_LOSS_GAUSS_HEAD ? 4 : 2);
         if (G != heads || dout != width) return RRL_EINVAL;
+        if (la->da_parts < 0 || la->da_parts > 16) return RRL_ERANGE;
     }
     hb.la = *la;
     hb.B = B; hb.H = H; hb.dout = dout; hb.need_w = dW3 != nullptr && db3 != nullptr;

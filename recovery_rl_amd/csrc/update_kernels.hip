@@ -299,12 +299,35 @@ __device__ __forceinline__ float adam_elem(float& p, float g, float& m, float& v
 // `vec` (host-checked: every pointer 16-byte aligned): the body runs on float4 with the loads of two strided slots
 // in flight per thread (135 K parameters over 64 workgroups are 2 float4 per thread; the scalar loop chained
 // one memory round trip per element: 7.5 us); the arithmetic per element is the scalar one.
+// the first `pe` gradients of a segment may arrive as np partial sums ps floats apart (rrl_first_layer_t): loads of up
+// to kMaxGradParts parts issued together, added in the order 0, 1, 2, ...
+constexpr int kMaxGradParts = 64;
+__device__ __forceinline__ float4 part_sum4(const float* gp, int np, long long ps, long long i4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t0 = 0; t0 < np; t0 += 16) {
+        float4 v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = reinterpret_cast<const float4*>(gp + (long long)min(t0 + t, np - 1) * ps)[i4];
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t0 + t < np) { acc.x += v[t].x; acc.y += v[t].y; acc.z += v[t].z; acc.w += v[t].w; }
+    }
+    return acc;
+}
+__device__ __forceinline__ float part_sum1(const float* gp, int np, long long ps, long long i) {
+    float acc = 0.f;
+    for (int t = 0; t < np; ++t) acc += gp[t * ps + i];
+    return acc;
+}
+
 __device__ __forceinline__ void adam_range(long long n, float* p, const float* g, float* m, float* v,
                                            float step_size, float bc2_sqrt, float b1, float b2, float eps,
                                            float* target, float tau, float wd, const float* g2, int block,
-                                           int blocks, bool vec) {
+                                           int blocks, bool vec, const float* gp = nullptr, int np = 0,
+                                           long long ps = 0, long long pe = 0) {
     const long long stride = (long long)blocks * kBlock;
     long long done = 0;
+    if (!gp) pe = 0;
     if (vec) {
         const long long n4 = n >> 2;
         float4* p4 = reinterpret_cast<float4*>(p);
@@ -318,6 +341,8 @@ __device__ __forceinline__ void adam_range(long long n, float* p, const float* g
             const bool two = i1 < n4;
             const long long j1 = two ? i1 : i0;
             float4 P[2] = {p4[i0], p4[j1]}, G[2] = {g4[i0], g4[j1]}, M[2] = {m4[i0], m4[j1]}, V[2] = {v4[i0], v4[j1]};
+            if (4 * i0 < pe) G[0] = part_sum4(gp, np, ps, i0);          // pe % 4 == 0: a float4 is inside or outside
+            if (4 * j1 < pe) G[1] = part_sum4(gp, np, ps, j1);
             float4 T[2] = {P[0], P[1]}, Hh[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
             if (target) { T[0] = t4[i0]; T[1] = t4[j1]; }
             if (g2) { Hh[0] = h4[i0]; Hh[1] = h4[j1]; }
@@ -347,7 +372,8 @@ __device__ __forceinline__ void adam_range(long long n, float* p, const float* g
     }
     for (long long i = done + (long long)block * kBlock + threadIdx.x; i < n; i += stride) {
         float pi = p[i], mi = m[i], vi = v[i];
-        const float gi = g2 ? g[i] + g2[i] : g[i];
+        const float g0 = i < pe ? part_sum1(gp, np, ps, i) : g[i];
+        const float gi = g2 ? g0 + g2[i] : g0;
         adam_elem(pi, gi, mi, vi, step_size, bc2_sqrt, b1, b2, eps, wd);
         p[i] = pi; m[i] = mi; v[i] = vi;
         if (target) target[i] = target[i] * (1.f - tau) + pi * tau;
@@ -370,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_se
     }
     __syncthreads();
     adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, sg.weight_decay, sg.g2,
-               block, blocks, a.vec[k] != 0);
+               block, blocks, a.vec[k] != 0, sg.g_part, sg.n_part, sg.part_stride, sg.part_elems);
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long ticket = atomicAdd((unsigned long long*)&sg.step_dev[1], 1ULL);
@@ -545,6 +571,9 @@ int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float b
     for (int k = 0; k < n_seg; ++k) {
         const rrl_adam_seg_t& sg = segs[k];
         if (!sg.p || !sg.g || !sg.m || !sg.v || !sg.step_dev || sg.n <= 0) return RRL_EINVAL;
+        if (sg.g_part && (sg.n_part <= 0 || sg.n_part > kMaxGradParts || sg.part_elems <= 0 || sg.part_elems > sg.n ||
+                          (sg.part_elems & 3) || (sg.part_stride & 3) || !aligned16(sg.g_part)))
+            return RRL_EINVAL;
         a.seg[k] = sg;
         a.vec[k] = aligned16(sg.p) && aligned16(sg.g) && aligned16(sg.m) && aligned16(sg.v) && aligned16(sg.target) &&
                    aligned16(sg.g2);

@@ -65,7 +65,11 @@ class FlatNet:
                     dst[i].copy_(prm.data.reshape(dst[i].shape))
                     prm.data = dst[i].view(prm.shape)
 
-    def adam(self, lr, target=None, tau=0.0, betas=(0.9, 0.999), eps=1e-8):
+    def adam(self, lr, target=None, tau=0.0, betas=(0.9, 0.999), eps=1e-8, part=None):
+        """`part` = (first_part tensor [T, stride], n_first): the gradients of the leading n_first parameters
+        (W1, b1) arrive as T row-tile partials (Stack.backward with fuse_first)."""
+        if part is not None:
+            return adam_multi(lr, [(self, target, tau, part)], betas, eps)
         lib = _lib.load()
         rc = lib.rrl_adam_step(self.flat.numel(), self.flat.data_ptr(), self.grad.data_ptr(),
                                self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(), lr, betas[0],
@@ -75,13 +79,19 @@ class FlatNet:
 
 
 def adam_multi(lr, nets, betas=(0.9, 0.999), eps=1e-8):
-    """One rrl_adam_step_multi launch over several FlatNets: nets = [(net, target or None, tau), ...]."""
+    """One rrl_adam_step_multi launch over several FlatNets: nets = [(net, target or None, tau[, part]), ...];
+    part = (first_part [T, stride], n_first) or None, see FlatNet.adam."""
     lib = _lib.load()
     segs = (_lib.rrl_adam_seg_t * len(nets))()
-    for k, (net, target, tau) in enumerate(nets):
+    for k, item in enumerate(nets):
+        net, target, tau = item[:3]
+        part = item[3] if len(item) > 3 else None
+        gp, n_part, stride, n_first = (None, 0, 0, 0) if part is None else \
+            (part[0].data_ptr(), part[0].shape[0], part[0].stride(0), part[1])
         segs[k] = _lib.rrl_adam_seg_t(net.flat.numel(), net.flat.data_ptr(), net.grad.data_ptr(), net.m.data_ptr(),
                                       net.v.data_ptr(), net.step.data_ptr(),
-                                      None if target is None else target.flat.data_ptr(), tau, 0.0, None)
+                                      None if target is None else target.flat.data_ptr(), tau, 0.0, None,
+                                      gp, n_part, stride, n_first)
     _lib.check(lib.rrl_adam_step_multi(len(nets), segs, lr, betas[0], betas[1], eps, _lib.current_stream()),
                "rrl_adam_step_multi")
 
@@ -155,6 +165,30 @@ class Stack:
         self.scratch = z(max(self.nsplit, 1), G, B, net.dout)
         self.finalize = False                       # True: always hand back the summed output tensor
         self.pair_hidden = True                     # dW2 and dh1 of the backward in one launch
+        self._init_first(dev, G, B, H, net.din)
+
+    def _init_first(self, dev, G, B, H, din):
+        """First layer of the backward inside the hidden-layer launch (rrl_first_layer_t): the 16 x 16 tiles of dh1 emit
+        row-tile partials of (dW1, db1) -- laid out like the head [W1 | b1] of the flat gradient buffer, summed by
+        Adam -- and column-tile partials of dx, summed by the policy-head backward.  One launch per stack backward less;
+        dh1 never goes to memory."""
+        self.fuse_first = B % 128 == 0 and H % 128 == 0 and B // 16 <= 64 and H // 16 <= 16
+        self.n_first = G * H * (din + 1)
+        self.first_part = self.dx_part = None
+        if self.fuse_first:
+            self.first_part = torch.zeros(B // 16, self.n_first, dtype=torch.float32, device=dev)
+            self.dx_part = torch.zeros(H // 16, G, B, din, dtype=torch.float32, device=dev)
+
+    @property
+    def grad_part(self):
+        """What FlatNet.adam / adam_multi need to read this stack's (dW1, db1): (partials, count) or None."""
+        return (self.first_part, self.n_first) if self.fuse_first else None
+
+    def dx_parts(self):
+        """(tensor [G, B, din] view of partial 0, number of partials, partial stride) of dL/dx after backward(input_grad)."""
+        if self.fuse_first:
+            return self.dx_part[0], self.dx_part.shape[0], self.dx_part.stride(0)
+        return self.dx, 1, 0
 
     def forward(self, x, params=None, save=True):
         """x [B, din] shared by all heads.  `params` lets a target network reuse this workspace;
@@ -203,8 +237,15 @@ class Stack:
             loss = _lib.rrl_loss_t(-1, 1, 0, p(dout), None, None, None, None, None, None, 0.0, 0, 0, 0, None, None)
         head = _lib.rrl_head_bwd_t(loss, G, B, H, net.dout, p(self.h2), p(P["W3"]), p(Gr["W3"]) if wg else None,
                                    p(Gr["b3"]) if wg else None, p(self.dh2))
+        if self.fuse_first:
+            first = _lib.rrl_first_layer_t(p(self.x), p(P["W1"]), self.x.stride(0), net.din,
+                                           p(self.first_part) if wg else None, self.first_part.stride(0),
+                                           p(self.dx_part) if input_grad else None)
+            hidden = _lib.rrl_hidden_bwd_t(G, B, H, p(self.dh2), p(self.h1), p(P["W2"]), p(Gr["W2"]) if wg else None,
+                                           p(Gr["b2"]) if wg else None, None, first)
+            return head, hidden, None
         hidden = _lib.rrl_hidden_bwd_t(G, B, H, p(self.dh2), p(self.h1), p(P["W2"]), p(Gr["W2"]) if wg else None,
-                                       p(Gr["b2"]) if wg else None, p(self.dh1))
+                                       p(Gr["b2"]) if wg else None, p(self.dh1), _lib.rrl_first_layer_t())
         inp = _lib.rrl_input_bwd_t(G, B, H, net.din, self.x.stride(0), p(self.dh1), p(self.x), p(P["W1"]),
                                    p(Gr["W1"]) if wg else None, p(Gr["b1"]) if wg else None,
                                    p(self.dx) if input_grad else None)
@@ -214,6 +255,9 @@ class Stack:
         """dout: [G, B, dout] tensor, or an rrl_loss_t describing how the kernel computes it itself
         (rrl_mlp_head_backward_loss).  Writes parameter gradients into net.g (weight_grads) and/or returns
         dL/dx per head [G, B, din] (input_grad)."""
+        if self.fuse_first:             # head backward, then hidden + first layer in one launch (rrl_first_layer_t)
+            backward_multi([self.backward_descs(dout, weight_grads, input_grad)])
+            return self.dx_part if input_grad else None
         P, Gr = self.net.p, self.net.g
         net, lib, st = self.net, _lib.load(), _lib.current_stream()
         G, B, H = net.G, self.B, net.H
@@ -260,10 +304,12 @@ def backward_multi(triples):
     lib, st, n = _lib.load(), _lib.current_stream(), len(triples)
     heads = (_lib.rrl_head_bwd_t * n)(*[t[0] for t in triples])
     hidden = (_lib.rrl_hidden_bwd_t * n)(*[t[1] for t in triples])
-    inputs = (_lib.rrl_input_bwd_t * n)(*[t[2] for t in triples])
+    rest = [t[2] for t in triples if t[2] is not None]          # stacks whose first layer is not fused into `hidden`
+    inputs = (_lib.rrl_input_bwd_t * len(rest))(*rest) if rest else None
     _lib.check(lib.rrl_mlp_head_backward_multi(n, heads, st), "rrl_mlp_head_backward_multi")
     _lib.check(lib.rrl_mlp_hidden_backward_multi(n, hidden, st), "rrl_mlp_hidden_backward_multi")
-    _lib.check(lib.rrl_mlp_input_backward_multi(n, inputs, st), "rrl_mlp_input_backward_multi")
+    if inputs is not None:
+        _lib.check(lib.rrl_mlp_input_backward_multi(len(inputs), inputs, st), "rrl_mlp_input_backward_multi")
 
 
 def heads_multi(heads):
@@ -286,6 +332,7 @@ class StackRows(Stack):
         self.h1, self.h2 = parent.h1[:, lo:hi], parent.h2[:, lo:hi]
         self.dh1, self.dh2, self.dx = z(1, self.B, H), z(1, self.B, H), z(1, self.B, parent.net.din)
         self.pair_hidden = True
+        self._init_first(dev, 1, self.B, H, parent.net.din)
 
     def forward(self, *a, **k):
         raise RuntimeError("run the parent's forward, then use .after_forward()")
@@ -348,6 +395,25 @@ class FastUpdater:
         self.rbias = self.qr.policy.action_bias.to(dev).float().contiguous()
 
     # -- helpers ---------------------------------------------------------------------------------
+    def stacks(self):
+        return [self.pol_a, self.pol_ab, self.pol_next, self.pol_b, self.cri_a, self.cri_b, self.cri_t, self.qr_a,
+                self.qr_b, self.qr_t, self.rec_a]
+
+    def set_fuse_first(self, on):
+        """First layer of every stack backward inside the hidden-layer launch (partial sums read by Adam and by the
+        policy-head backward) or as its own launch writing the flat gradient buffer (needed when the gradient buffers
+        are all-reduced, and by the stand-alone loss-gradient kernels of fuse_loss = False)."""
+        for st in self.stacks():
+            st.fuse_first = bool(on) and st.first_part is not None
+
+    def gather_first_grads(self):
+        """Write the summed (dW1, db1) partials of the last backward into the flat gradient buffers (inspection and
+        tests; the optimiser reads the partials directly)."""
+        for net, st in ((self.critic, self.cri_a), (self.policy, self.pol_b), (self.qrisk, self.qr_a),
+                        (self.recpolicy, self.rec_a)):
+            if st.fuse_first:
+                net.grad[:st.n_first] = st.first_part.sum(0)
+
     # -- env-shard data parallelism (one learner, envs and replay split over ranks) ---------------------------
     def enable_grad_sync(self, world):
         """Every rank holds the same weights and averages gradients before each optimiser step: three
@@ -362,6 +428,7 @@ class FastUpdater:
         for net in (self.critic, self.critic_target, self.policy, self.qrisk, self.qrisk_target, self.recpolicy):
             dist.broadcast(net.flat, 0)
         self.sync_world = world
+        self.set_fuse_first(False)              # the all-reduce works on the flat gradient buffers
         self._avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else None
 
     def _sync(self, grad):
@@ -379,12 +446,14 @@ class FastUpdater:
         """rrl_loss_t for Stack.backward: the head-backward kernel evaluates the loss gradient itself.
         d_action = the critic's input gradient dx [2, B, 4] whose action columns feed a policy head."""
         p = _lib.ptr
-        ld = n_heads = hs = 0
+        ld = n_heads = hs = parts = ps = 0
         da = None
         if d_action is not None:
+            if isinstance(d_action, tuple):           # Stack.dx_parts(): column-tile partials of the critic's dx
+                d_action, parts, ps = d_action
             da, ld, n_heads, hs = d_action[0, :, 2:4].data_ptr(), d_action.stride(1), 2, d_action.stride(0)
         return _lib.rrl_loss_t(kind, n_part, part_stride, p(out), p(out_t), p(v0), p(v1), p(v2), p(v3), p(alpha),
-                               float(f0), ld, n_heads, hs, da, p(loss))
+                               float(f0), ld, n_heads, hs, da, p(loss), parts, ps)
 
     def _check(self, rc, what):
         _lib.check(rc, what)
@@ -507,10 +576,11 @@ class FastUpdater:
                                                  loss=self.losses[2:]), weight_grads=False, input_grad=True)])
         ht, hn, hs = head
         self.pol_b.backward(self._loss(_lib.LOSS_GAUSS_HEAD, ht, hn, hs, v0=eps_pi, v1=self.scale,
-                                       f0=float(ag.alpha) / B, d_action=self.cri_b.dx))
+                                       f0=float(ag.alpha) / B, d_action=self.cri_b.dx_parts()))
         if self.sync_world > 1:
             self._sync(self.sac_bucket)
-        adam_multi(ag.lr, [(self.critic, self.critic_target, ag.tau), (self.policy, None, 0.0)])
+        adam_multi(ag.lr, [(self.critic, self.critic_target, ag.tau, self.cri_a.grad_part),
+                           (self.policy, None, 0.0, self.pol_b.grad_part)])
         return self.losses
 
     def qrisk_update_grouped(self, batch, eps_next, eps_pi):
@@ -536,18 +606,18 @@ class FastUpdater:
         self.qr_a.backward(self._loss(_lib.LOSS_QRISK_CRITIC, z, n_part, ps, out_t=zt, v0=c, v1=m,
                                       f0=qr.gamma_safe, loss=self.losses[4:]))
         self._sync(self.qrisk.grad)
-        self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau)
+        self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau, part=self.qr_a.grad_part)
         if mf:                                                             # qrisk.py:150-158, at the UPDATED critic
             raw, rn, rs = self.rec_a.parts
             ls = self.recpolicy.p["log_std"]
             zp, n_part, ps = self.qr_b.forward(xpu)
-            dx = self.qr_b.backward(self._loss(_lib.LOSS_QRISK_POLICY, zp, n_part, ps, loss=self.losses[6:]),
-                                    weight_grads=False, input_grad=True)
+            self.qr_b.backward(self._loss(_lib.LOSS_QRISK_POLICY, zp, n_part, ps, loss=self.losses[6:]),
+                               weight_grads=False, input_grad=True)
             self.rec_a.backward(self._loss(_lib.LOSS_STOCH_HEAD, raw, rn, rs, v0=eps_pi, v1=ls, v2=self.rscale,
-                                           f0=qr.policy.min_log_std, d_action=dx,
+                                           f0=qr.policy.min_log_std, d_action=self.qr_b.dx_parts(),
                                            loss=self.recpolicy.g["log_std"]))
             self._sync(self.recpolicy.grad)
-            self.recpolicy.adam(qr.lr)
+            self.recpolicy.adam(qr.lr, part=self.rec_a.grad_part)
         return self.losses
 
     # -- SAC -------------------------------------------------------------------------------------
@@ -576,12 +646,13 @@ class FastUpdater:
         qp, n_part, ps = self.cri_b.forward(self.xpu)
         ht, hn, hs = head
         if self.fuse_loss:
-            dx = self.cri_b.backward(self._loss(_lib.LOSS_SAC_POLICY, qp, n_part, ps, v0=self.logp, alpha=self.alpha,
-                                                loss=self.losses[2:]), weight_grads=False, input_grad=True)
+            self.cri_b.backward(self._loss(_lib.LOSS_SAC_POLICY, qp, n_part, ps, v0=self.logp, alpha=self.alpha,
+                                           loss=self.losses[2:]), weight_grads=False, input_grad=True)
             # d pi = action columns of dx [2,B,4], summed over the two critic heads inside the policy's head backward
             self.pol_b.backward(self._loss(_lib.LOSS_GAUSS_HEAD, ht, hn, hs, v0=eps_pi, v1=self.scale,
-                                           f0=float(ag.alpha) / B, d_action=dx))
+                                           f0=float(ag.alpha) / B, d_action=self.cri_b.dx_parts()))
         else:
+            assert not self.cri_b.fuse_first, "fuse_loss = False needs set_fuse_first(False)"
             self._check(lib.rrl_sac_policy_grad(B, qp.data_ptr(), n_part, ps, self.logp.data_ptr(),
                                                 self.alpha.data_ptr(), self.dq.data_ptr(),
                                                 self.losses[2:].data_ptr(), st), "rrl_sac_policy_grad")
@@ -594,7 +665,8 @@ class FastUpdater:
         if self.sync_world > 1:
             self._sync(self.sac_bucket)
         # both optimiser steps + the soft target update (:273-274) in one launch
-        adam_multi(ag.lr, [(self.critic, self.critic_target, ag.tau), (self.policy, None, 0.0)])
+        adam_multi(ag.lr, [(self.critic, self.critic_target, ag.tau, self.cri_a.grad_part),
+                           (self.policy, None, 0.0, self.pol_b.grad_part)])
         return self.losses
 
     # -- Q_risk ------------------------------------------------------------------------------------
@@ -614,7 +686,7 @@ class FastUpdater:
                                                   self.losses[4:].data_ptr(), st), "rrl_qrisk_critic_grad")
             self.qr_a.backward(self.dq)
         self._sync(self.qrisk.grad)
-        self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau)
+        self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau, part=self.qr_a.grad_part)
         if qr.MF_recovery:                                              # qrisk.py:150-158, at the UPDATED critic
             raw, rn, rs = self.rec_a.forward(s)
             ls = self.recpolicy.p["log_std"]
@@ -623,10 +695,10 @@ class FastUpdater:
                                                self.xpu[:, 2:4].data_ptr(), 4, None, st), "rrl_stoch_head_fwd")
             zp, n_part, ps = self.qr_b.forward(self.xpu)
             if self.fuse_loss:
-                dx = self.qr_b.backward(self._loss(_lib.LOSS_QRISK_POLICY, zp, n_part, ps, loss=self.losses[6:]),
-                                        weight_grads=False, input_grad=True)
+                self.qr_b.backward(self._loss(_lib.LOSS_QRISK_POLICY, zp, n_part, ps, loss=self.losses[6:]),
+                                   weight_grads=False, input_grad=True)
                 self.rec_a.backward(self._loss(_lib.LOSS_STOCH_HEAD, raw, rn, rs, v0=eps_pi, v1=ls, v2=self.rscale,
-                                               f0=qr.policy.min_log_std, d_action=dx,
+                                               f0=qr.policy.min_log_std, d_action=self.qr_b.dx_parts(),
                                                loss=self.recpolicy.g["log_std"]))
             else:
                 self._check(lib.rrl_qrisk_policy_grad(B, zp.data_ptr(), n_part, ps, self.dq.data_ptr(),
@@ -639,7 +711,7 @@ class FastUpdater:
                                                    st), "rrl_stoch_head_bwd")
                 self.rec_a.backward(self.draw)
             self._sync(self.recpolicy.grad)
-            self.recpolicy.adam(qr.lr)
+            self.recpolicy.adam(qr.lr, part=self.rec_a.grad_part)
         return self.losses
 
 

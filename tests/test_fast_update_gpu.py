@@ -92,6 +92,7 @@ def test_fast_path_equals_autograd_path(hidden, B):
         fast.safety_critic.update_parameters(policy=fast.policy, batch=b_qr, eps_next=e1, eps_pi=e2)
         for x, y in zip(slow.safety_critic.last_losses, fast.safety_critic.last_losses):
             assert torch.allclose(x, y, rtol=1e-4, atol=1e-6), (step, float(x), float(y))
+        fast.fast.gather_first_grads()      # (dW1, db1) live as row-tile partials when the first layer is fused
         twin = {"linear1.weight": ("W1", 0), "linear4.weight": ("W1", 1), "linear2.weight": ("W2", 0),
                 "linear5.weight": ("W2", 1), "linear3.weight": ("W3", 0), "linear6.bias": ("b3", 1),
                 "linear2.bias": ("b2", 0), "linear4.bias": ("b1", 1)}
@@ -251,6 +252,8 @@ def test_loss_fused_head_backward_is_bit_identical_to_the_separate_grad_kernels(
     a.enable_fast_path(B)
     b.enable_fast_path(B)
     a.fast.fuse_loss, b.fast.fuse_loss = True, False
+    a.fast.set_fuse_first(False)       # this test isolates the loss fusion and the paired hidden-layer launch: the
+    b.fast.set_fuse_first(False)       # first layer of the backward stays its own launch on both sides
     for name in ("pol_a", "pol_b", "cri_a", "cri_b", "qr_a", "qr_b", "rec_a"):
         getattr(b.fast, name).pair_hidden = False          # ... and the two hidden-layer GEMMs as separate launches
     for step in range(3):
@@ -353,3 +356,40 @@ def test_grouped_entry_points_match_their_members():
         assert torch.equal(noise_a, noise_b) and torch.equal(tick_a, tick_b)
         assert torch.equal(m1._batch(256)[5], m2._batch(256)[5]) and torch.equal(c1._batch(256)[5], c2._batch(256)[5])
     m1.check_error(), c1.check_error()
+
+
+@pytest.mark.parametrize("B", (256,))
+def test_first_layer_backward_inside_the_hidden_launch(B):
+    """rrl_first_layer_t: (dW1, db1) as row-tile partials summed by Adam and dx as column-tile partials summed by the
+    policy-head backward, against the stand-alone rrl_mlp_input_backward launch: the partial sums add up to its outputs
+    (summation order differs: float tolerance), and three updates give the same parameters within Adam's noise floor."""
+    _, a, _ = make_pair(256)
+    _, b, _ = make_pair(256)
+    for dst, src in ((b.critic, a.critic), (b.critic_target, a.critic_target), (b.policy, a.policy),
+                     (b.safety_critic.safety_critic, a.safety_critic.safety_critic),
+                     (b.safety_critic.safety_critic_target, a.safety_critic.safety_critic_target),
+                     (b.safety_critic.policy, a.safety_critic.policy)):
+        dst.load_state_dict(copy.deepcopy(src.state_dict()))
+    a.enable_fast_path(B)
+    b.enable_fast_path(B)
+    assert a.fast.cri_a.fuse_first and a.fast.pol_b.fuse_first
+    b.fast.set_fuse_first(False)
+    for step in range(3):
+        b_sac, b_qr, e1, e2 = batch(B, 70 + step)
+        for ag in (a, b):
+            ag.update_parameters(None, B, step, safety_critic=ag.safety_critic, batch=b_sac, eps_next=e1, eps_pi=e2)
+            ag.safety_critic.update_parameters(policy=ag.policy, batch=b_qr, eps_next=e1, eps_pi=e2)
+        if step == 0:
+            fa, fb = a.fast, b.fast
+            for sa, sb, net in ((fa.cri_a, fb.cri_a, "critic"), (fa.pol_b, fb.pol_b, "policy"), (fa.qr_a, fb.qr_a, "qrisk"),
+                                (fa.rec_a, fb.rec_a, "recpolicy")):
+                summed = sa.first_part.sum(0)
+                want = getattr(fb, net).grad[:sa.n_first]
+                scale = float(want.abs().max())
+                assert float((summed - want).abs().max()) <= 2e-6 * scale + 1e-9, net
+            dxa = fa.cri_b.dx_part.sum(0)
+            assert float((dxa - fb.cri_b.dx).abs().max()) <= 2e-6 * float(fb.cri_b.dx.abs().max()) + 1e-12
+        for name in ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy"):
+            pa, pb = getattr(a.fast, name).flat, getattr(b.fast, name).flat
+            assert float((pa - pb).abs().max()) < 3e-5, (step, name, float((pa - pb).abs().max()))      # 0.1 lr
+    assert int(a.fast.critic.step[0].item()) == 3
