@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 
+#include "rrl_device.hpp"
 #include "rrl_host.hpp"
 
 namespace {
@@ -304,17 +305,7 @@ constexpr int kStackMaxH = 256;
 // lane^m holds the same value as lane + m (mod 16) and a DPP row rotation delivers it -- one VALU instruction with a DPP
 // operand per step instead of a ds_bpermute round trip through the LDS crossbar (~120 cycles each, four dependent
 // ones per output row: 7 000 of the 25 000 cycles of a 64-row forward tile).
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_move<0x128>(v);    // row_ror:8
-    v += dpp_move<0x124>(v);    // row_ror:4
-    v += dpp_move<0x122>(v);    // row_ror:2
-    v += dpp_move<0x121>(v);    // row_ror:1
-    return v;
-}
+using rrl::row16_sum;
 
 // -DRRL_FWD_TIMING (profiles/mlp_fwd_timing.sh builds a second library with it): wave 0 of every workgroup of the
 // split forward stamps s_memtime at its phase boundaries
@@ -855,11 +846,15 @@ __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx
             dsh[4 * b + 2 + j] = inside ? (dx * sd * la.v0[2 * b + j] - la.f0) : 0.f;
         }
     } else {
-        for (int e = threadIdx.x; e < B * dout; e += 256) {
-            const int b = e / dout, o = e - b * dout;
-            float term;
-            dsh[e] = loss::dout_at<KIND>(la, B, g, b, o, term);
-            if (KIND == RRL_LOSS_STOCH_HEAD && o == 1) lsum[1] += term; else lsum[0] += term;
+        // one thread per batch row (all its outputs): the per-thread partial sums of the loss terms are then the ones of
+        // the stand-alone kernels (update_kernels.hip), and so is every bit of the reduced value
+        for (int b = threadIdx.x; b < B; b += 256) {
+#pragma unroll
+            for (int o = 0; o < (DOUT ? DOUT : 1); ++o) {
+                float term;
+                dsh[b * dout + o] = loss::dout_at<KIND>(la, B, g, b, o, term);
+                if (KIND == RRL_LOSS_STOCH_HEAD && o == 1) lsum[1] += term; else lsum[0] += term;
+            }
         }
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -909,24 +904,59 @@ __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx
     if (need_w) {
 #pragma unroll
         for (int o = 0; o < 4; ++o) red[slice][o][hc] = acc[o];
-        __syncthreads();
-        if (slice < dout && hok) {
-            float sum = 0.f;
+    }
+    // bias gradient (column sums of dOut) and the loss scalars / dlog_std: workgroup bx == 0 reduces up to 4 + 2 values
+    // over its 256 threads -- DPP sums inside the 16-lane rows, the 16 row sums through LDS, ONE barrier (the serial
+    // 256-term bias loop and the 8-step barrier tree of the loss were ~1.5 us of this kernel's critical path)
+    constexpr bool per_head = KIND == RRL_LOSS_SAC_CRITIC || KIND == RRL_LOSS_QRISK_CRITIC;
+    const bool want_loss = KIND != kPlainDOut && KIND != RRL_LOSS_GAUSS_HEAD && la.loss && (per_head || g == 0);
+    float* tail = dsh + 1024 * 4 - 6 * 16;            // dsh holds B * dout <= 4096 floats only when B = 1024, dout = 4:
+    const bool tail_free = B * dout <= 1024 * 4 - 6 * 16;   // then the scalars take the slow path below
+    float part[6] = {0.f, 0.f, 0.f, 0.f, lsum[0], lsum[1]};
+    if (bx == 0 && tail_free) {
+        for (int e = threadIdx.x; e < B; e += 256) {
 #pragma unroll
-            for (int sl = 0; sl < kSlices; ++sl) sum += red[sl][slice][hc];
-            dW3[((long long)g * dout + slice) * H + h] = sum;
-        }
-        if (bx == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + (unsigned)dout) {   // bias gradient
-            const int o = threadIdx.x - 128;
-            float sum = 0.f;
-            for (int b = 0; b < B; ++b) sum += dsh[b * dout + o];
-            db3[g * dout + o] = sum;
+            for (int o = 0; o < 4; ++o)
+                if (o < dout) part[o] += dsh[e * dout + o];
         }
     }
-    // loss scalars / dlog_std: one workgroup per head reduces the per-thread terms in a fixed tree
-    constexpr bool per_head = KIND == RRL_LOSS_SAC_CRITIC || KIND == RRL_LOSS_QRISK_CRITIC;
-    if (KIND == kPlainDOut || KIND == RRL_LOSS_GAUSS_HEAD || bx != 0 || !la.loss || (!per_head && g != 0))
+    __syncthreads();                                   // red[] complete (need_w); dsh reads above done before tail writes
+    if (need_w && slice < dout && hok) {
+        float sum = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < kSlices; ++sl) sum += red[sl][slice][hc];
+        dW3[((long long)g * dout + slice) * H + h] = sum;
+    }
+    if (bx != 0 || (!need_w && !want_loss)) return;
+    if (tail_free) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float rsum = row16_sum(part[k]);
+            if ((threadIdx.x & 15) == 0) tail[k * 16 + (threadIdx.x >> 4)] = rsum;
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            float tot = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot += tail[threadIdx.x * 16 + r];
+            const int k = threadIdx.x;
+            if (k < 4) {
+                if (need_w && k < dout) db3[g * dout + k] = tot;
+            } else if (want_loss) {
+                if constexpr (KIND == RRL_LOSS_STOCH_HEAD) la.loss[k - 4] = tot;
+                else if (k == 4) la.loss[per_head ? g : 0] = tot / B;
+            }
+        }
         return;
+    }
+    // B * dout too large for the LDS tail (B = 1024 with four outputs): serial sums by single threads
+    if (need_w && threadIdx.x >= 128 && threadIdx.x < 128 + (unsigned)dout) {
+        const int o = threadIdx.x - 128;
+        float sum = 0.f;
+        for (int b = 0; b < B; ++b) sum += dsh[b * dout + o];
+        db3[g * dout + o] = sum;
+    }
+    if (!want_loss) return;
     __syncthreads();
     float* r0 = &red[0][0][0];          // 1024 floats: two arrays of 256
     r0[threadIdx.x] = lsum[0];

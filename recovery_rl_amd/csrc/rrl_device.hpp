@@ -152,6 +152,18 @@ __device__ __forceinline__ void nav_transition(double x, double y, double ax, do
     cost = -sqrt(fma(y, y, x * x));
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0x128>(v);    // row_ror:8
+    v += dpp_move<0x124>(v);    // row_ror:4
+    v += dpp_move<0x122>(v);    // row_ror:2
+    v += dpp_move<0x121>(v);    // row_ror:1
+    return v;
+}
+
 __device__ __forceinline__ uint64_t effective_counter(uint64_t counter, const uint64_t* dev) {
     return dev ? counter + *dev : counter;
 }

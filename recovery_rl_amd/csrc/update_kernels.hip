@@ -261,17 +261,21 @@ __global__ void stoch_head_bwd_kernel(int B, const float* raw, int np, long long
             if (j == 0) s0 += g; else s1 += g;
         }
     }
-    red[0][threadIdx.x] = s0;
-    red[1][threadIdx.x] = s1;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + off];
-            red[1][threadIdx.x] += red[1][threadIdx.x + off];
-        }
-        __syncthreads();
+    // the order of the loss-fused head backward (mlp_kernels.hip): DPP sums inside the 16-lane rows, then the 16 row
+    // sums one after the other -- the two paths give the same bits
+    s0 = rrl::row16_sum(s0);
+    s1 = rrl::row16_sum(s1);
+    if ((threadIdx.x & 15) == 0) {
+        red[0][threadIdx.x >> 4] = s0;
+        red[1][threadIdx.x >> 4] = s1;
     }
-    if (threadIdx.x == 0) { dlog_std[0] = red[0][0]; dlog_std[1] = red[1][0]; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        float tot = 0.f;
+#pragma unroll
+        for (int r = 0; r < kBlock / 16; ++r) tot += red[threadIdx.x][r];
+        dlog_std[threadIdx.x] = tot;
+    }
 }
 
 // ---- Adam (+ Polyak target update) over one flat parameter buffer -------------------------------
@@ -390,21 +394,22 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_se
     const rrl_adam_seg_t sg = a.seg[k];
     const int block = blockIdx.x - a.first_block[k], blocks = a.first_block[k + 1] - a.first_block[k];
     if (threadIdx.x == 0) {
-        const double t = double(sg.step_dev[0] + 1);
+        const uint64_t step = sg.step_dev[0];
+        const double t = double(step + 1);
+        // the ticket is taken as soon as this workgroup has READ the step count: the last of the segment's workgroups
+        // to do so knows every other one has read it too and may store t + 1 right away -- the returning atomic's round
+        // trip (~0.7 us) runs under the parameter loads instead of after the last store
+        const unsigned long long ticket = atomicAdd((unsigned long long*)&sg.step_dev[1], 1ULL);
         sh[0] = lr / float(1.0 - pow(double(b1), t));
         sh[1] = float(sqrt(1.0 - pow(double(b2), t)));
+        if (ticket == (unsigned long long)blocks - 1) {
+            sg.step_dev[0] = step + 1;
+            sg.step_dev[1] = 0;
+        }
     }
     __syncthreads();
     adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, sg.weight_decay, sg.g2,
                block, blocks, a.vec[k] != 0, sg.g_part, sg.n_part, sg.part_stride, sg.part_elems);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long ticket = atomicAdd((unsigned long long*)&sg.step_dev[1], 1ULL);
-        if (ticket == (unsigned long long)blocks - 1) {
-            sg.step_dev[0] += 1;
-            sg.step_dev[1] = 0;
-        }
-    }
 }
 
 // ---- N(0,1) fill: out[2i], out[2i+1] = the Philox normal pair of index i (stream RRL_STREAM_NOISE) ----
