@@ -172,6 +172,28 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
                               float* r, float* s2, float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu,
                               void* stream);
 
+/* Description of one policy-head evaluation (used by rrl_policy_heads_fwd_multi, by the input head of rrl_stack_t and
+ * by the recovery action of rrl_*_step_push_select). */
+/* rrl_gauss_head_fwd / rrl_stoch_head_fwd calls that do not depend on each other in ONE launch (n <= 4): a' = pi(s')
+ * and pi(s) of one SAC step (sac.py:192-218), the task action and the recovery action of the acting pass
+ * (experiment.py:546-577).  kind RRL_HEAD_GAUSS: fields of rrl_gauss_head_fwd (mean_out = mean_action);
+ * RRL_HEAD_STOCH: fields of rrl_stoch_head_fwd (head = raw).  Results equal the stand-alone launches'. */
+enum { RRL_HEAD_GAUSS = 0, RRL_HEAD_STOCH = 1 };
+typedef struct {
+    int kind, B;
+    const float* head;
+    int n_part;
+    long long part_stride;
+    const float *eps, *scale, *bias;
+    float* action;
+    int ld_action;
+    float *logp, *mean_out;
+    const float* obs_in;
+    float* obs_out;
+    const float* log_std;
+    float min_log_std;
+} rrl_policy_head_t;
+
 /* The two draws of one lock-step iteration (task buffer -> SAC update, safety buffer -> Q_risk update,
  * experiment.py:397-416) and the iteration's policy noise (rrl_normal_fill) in ONE launch: they do not depend on
  * each other.  A member is a rrl_replay_sample_gather call (stratified = 0, B = n_pos + n_neg) or a
@@ -219,19 +241,23 @@ int rrl_maze_step_push(int64_t n, double* pos, int32_t* t, float* obs,
 /* The same fused tails with the recovery gate of Experiment.get_action (experiment.py:546-577) evaluated inside:
  * recovery[i] = max(sigmoid(z[i]), sigmoid(z[n + i])) > eps_safe (z = pre-sigmoid twin Q_risk(s, a_task), [2,n], given
  * as z_n_part partial sums z_part_stride floats apart like every stack output: rrl_mlp3_forward with scratch);
- * executed action = recovery ? rec_action[i] : task_action[i].  real_action [n,2] and recovery [n] are OUTPUTS here
+ * executed action = recovery ? rec_action[i] : task_action[i]; with rec_action = NULL the recovery action is evaluated in
+ * the kernel from rec_head (an RRL_HEAD_STOCH description, rrl_stoch_head_fwd's formula on the recovery policy's stack
+ * output).  real_action [n,2] and recovery [n] are OUTPUTS here
  * (what rrl_recovery_select would have written); task_action rows are ld_task floats apart (the [s | a] input
  * of the safety critic, ld_task = 4, can be passed as it is).  One launch less per lock-step iteration. */
 int rrl_nav_step_push_select(int env_kind, int64_t n, double* pos, int32_t* t, float* obs, const float* task_action,
                              int ld_task, const float* z, int z_n_part, long long z_part_stride,
-                             float eps_safe, const float* rec_action, float* real_action,
+                             float eps_safe, const float* rec_action, const rrl_policy_head_t* rec_head,
+                             float* real_action,
                              uint8_t* recovery, uint64_t seed, uint64_t counter, uint64_t* counter_dev,
                              uint64_t counter_inc, int32_t horizon, int auto_reset, float reward_penalty,
                              int push_real_action, const rrl_replay_t* memory, const rrl_replay_t* recovery_memory,
                              float* next_obs, float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success,
                              uint8_t* ep_done, uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
 int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, const float* task_action, int ld_task,
-                              const float* z, int z_n_part, long long z_part_stride, float eps_safe, const float* rec_action, float* real_action,
+                              const float* z, int z_n_part, long long z_part_stride, float eps_safe, const float* rec_action, const rrl_policy_head_t* rec_head,
+                             float* real_action,
                               uint8_t* recovery, uint64_t seed, uint64_t counter, uint64_t* counter_dev,
                               uint64_t counter_inc, int32_t horizon, int auto_reset, float reward_penalty,
                               int push_real_action, const rrl_replay_t* memory, const rrl_replay_t* recovery_memory,
@@ -355,10 +381,17 @@ int rrl_mlp_head_backward_loss(const rrl_loss_t* loss, int G, int B, int H, int 
  *   rrl_mlp_hidden_backward_multi members = rrl_mlp_hidden_backward calls; dW2 = db2 = NULL: only dh1
  *   rrl_mlp_input_backward_multi  members = rrl_mlp_input_backward calls
  * ------------------------------------------------------------------------------------------ */
+/* use_in_head != 0 (din = 4, column-split path only): columns 2..3 of the stack's input are not read from x but computed
+ * -- the action in_head yields for the same row (in_head.B is ignored: the stack's M rows) -- so the policy head needs no
+ * launch of its own between the policy stack and the critic stack that consumes its action.  Columns 0..1 come from
+ * in_head.obs_in (rows 2 floats apart) when given, else from x.  in_head.action / logp / obs_out, when non-null,
+ * receive what the stand-alone head kernel would have written (same formulas, same bits). */
 typedef struct {
     int G, M, H, din, dout, ldx;
     const float *x, *W1, *b1, *W2, *b2, *W3, *b3;
     float *h1, *h2, *out, *scratch;
+    rrl_policy_head_t in_head;
+    int use_in_head;
 } rrl_stack_t;
 typedef struct {
     rrl_loss_t loss;
@@ -440,25 +473,6 @@ int rrl_stoch_head_fwd(int B, const float* raw, int n_part, long long part_strid
 int rrl_stoch_head_bwd(int B, const float* raw, int n_part, long long part_stride, const float* eps,
                        const float* log_std, float min_log_std, const float* scale, const float* d_action, int ld,
                        int n_heads, long long head_stride, float* draw, float* dlog_std, void* stream);
-/* rrl_gauss_head_fwd / rrl_stoch_head_fwd calls that do not depend on each other in ONE launch (n <= 4): a' = pi(s')
- * and pi(s) of one SAC step (sac.py:192-218), the task action and the recovery action of the acting pass
- * (experiment.py:546-577).  kind RRL_HEAD_GAUSS: fields of rrl_gauss_head_fwd (mean_out = mean_action);
- * RRL_HEAD_STOCH: fields of rrl_stoch_head_fwd (head = raw).  Results equal the stand-alone launches'. */
-enum { RRL_HEAD_GAUSS = 0, RRL_HEAD_STOCH = 1 };
-typedef struct {
-    int kind, B;
-    const float* head;
-    int n_part;
-    long long part_stride;
-    const float *eps, *scale, *bias;
-    float* action;
-    int ld_action;
-    float *logp, *mean_out;
-    const float* obs_in;
-    float* obs_out;
-    const float* log_std;
-    float min_log_std;
-} rrl_policy_head_t;
 int rrl_policy_heads_fwd_multi(int n, const rrl_policy_head_t* heads, void* stream);
 int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uint64_t* step_dev, float lr,
                   float beta1, float beta2, float eps, float* target, float tau, void* stream);

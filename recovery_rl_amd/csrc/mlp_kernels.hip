@@ -287,6 +287,27 @@ __global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenGroup hg) {
 // the 16 x H activation tile in LDS shared by all waves (wave w owns output columns 16w..16w+15 and
 // streams its 16 rows of W2 straight from L2 into MFMA operands), layer 3 by 16-lane dot products.
 // No intermediate activation touches HBM unless the caller asks for h1 / h2 (needed by backward).
+namespace loss {
+
+constexpr float kLogSigMax = 2.f, kLogSigMin = -20.f, kEps = 1e-6f;   // model.py:14-16
+
+// value of a stack output given as np <= 4 partial sums ps floats apart: ((p0 + p1) + p2) + p3, the order of the
+// stand-alone sum kernel.  All loads are issued together (a run-time loop over np chained one memory round trip per
+// part: twelve of them in a row set the 11 us of the critic-loss head backward).
+__device__ __forceinline__ float psum(const float* p, long long idx, int np, long long ps) {
+    const float v0 = p[idx];
+    const float v1 = p[(np > 1 ? ps : 0) + idx];
+    const float v2 = p[(np > 2 ? 2 * ps : 0) + idx];
+    const float v3 = p[(np > 3 ? 3 * ps : 0) + idx];
+    float v = v0;
+    v = np > 1 ? v + v1 : v;
+    v = np > 2 ? v + v2 : v;
+    v = np > 3 ? v + v3 : v;
+    return v;
+}
+
+}  // namespace loss
+
 struct StackArgs {
     const float* x;       // [M, din]
     const float* W1; const float* b1;   // [G,H,din], [G,H]
@@ -295,6 +316,11 @@ struct StackArgs {
     float* h1; float* h2;               // [G,M,H] or null
     float* out;                          // [G,M,dout]
     int M, H, din, dout, ldx;
+    // optional: columns 2..3 of x are not read but computed -- the action a policy head (rrl_gauss_head_fwd /
+    // rrl_stoch_head_fwd) yields for the same row -- so the head needs no launch of its own between the policy stack and
+    // the critic stack that consumes its action (sac.py:192-218, qrisk.py:119-152, experiment.py:546-577)
+    rrl_policy_head_t in_head;
+    int use_in_head;
 };
 
 constexpr int kStackRows = 16;
@@ -507,6 +533,45 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         const float xv = a.x[(long long)xrow * a.ldx + min(q, din - 1)];
         xa[t] = (q < din) ? xv : 0.f;
     }
+    if (a.use_in_head) {
+        // lanes q = 0, 1 carry the observation, lanes q = 2, 3 the action dimension j = q - 2 of the policy head for
+        // their row; every wave of every workgroup recomputes it (a few transcendental ops), workgroup (z, g) = (0, 0)
+        // stores action and log-probability for the consumers downstream.  Same formulas, same bits as the kernels of
+        // update_kernels.hip.
+        const rrl_policy_head_t& hd = a.in_head;
+        const int j = q & 1;
+        const bool writer = z == 0 && g == 0 && wave == 0;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int row = min(m0 + 16 * t + i, M - 1);
+            const bool row_ok = m0 + 16 * t + i < M;
+            float val, lp_term = 0.f;
+            const float e = hd.eps ? hd.eps[2 * row + j] : 0.f;
+            const float sc = hd.scale[j], bi = hd.bias[j];
+            if (hd.kind == RRL_HEAD_GAUSS) {
+                const float mean = loss::psum(hd.head, 4 * row + j, hd.n_part, hd.part_stride);
+                const float ls = fminf(fmaxf(loss::psum(hd.head, 4 * row + 2 + j, hd.n_part, hd.part_stride),
+                                             loss::kLogSigMin), loss::kLogSigMax);
+                const float y = tanhf(mean + expf(ls) * e);
+                val = y * sc + bi;
+                lp_term = -0.5f * e * e - ls - 0.918938533204672742f - logf(sc * (1.f - y * y) + loss::kEps);
+            } else {
+                const float mean = tanhf(loss::psum(hd.head, 2 * row + j, hd.n_part, hd.part_stride)) * sc + bi;
+                val = mean + expf(fmaxf(hd.log_std[j], hd.min_log_std)) * e;
+            }
+            const float other = __shfl_xor(lp_term, 16);           // lane (i, 2) <-> lane (i, 3)
+            if (q >= 2) {
+                xa[t] = val;
+                if (writer && row_ok) {
+                    if (hd.action) hd.action[(long long)row * hd.ld_action + j] = val;
+                    if (hd.logp && q == 2) hd.logp[row] = lp_term + other;
+                }
+            } else if (hd.obs_in) {
+                xa[t] = hd.obs_in[2 * row + q];
+                if (writer && row_ok && hd.obs_out) hd.obs_out[(long long)row * hd.ld_action + q] = xa[t];
+            }
+        }
+    }
     float w1b[kU], bias1[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -697,24 +762,9 @@ constexpr int kCols = 16, kSlices = 16, kUnroll = 16;
 constexpr int kPlainDOut = -1;
 namespace loss {
 
-constexpr float kLogSigMax = 2.f, kLogSigMin = -20.f, kEps = 1e-6f;   // model.py:14-16
 
 __device__ __forceinline__ float sigm(float z) { return 1.f / (1.f + expf(-z)); }
 
-// value of a stack output given as np <= 4 partial sums ps floats apart: ((p0 + p1) + p2) + p3, the order of the
-// stand-alone sum kernel.  All loads are issued together (a run-time loop over np chained one memory round trip per
-// part: twelve of them in a row set the 11 us of the critic-loss head backward).
-__device__ __forceinline__ float psum(const float* p, long long idx, int np, long long ps) {
-    const float v0 = p[idx];
-    const float v1 = p[(np > 1 ? ps : 0) + idx];
-    const float v2 = p[(np > 2 ? 2 * ps : 0) + idx];
-    const float v3 = p[(np > 3 ? 3 * ps : 0) + idx];
-    float v = v0;
-    v = np > 1 ? v + v1 : v;
-    v = np > 2 ? v + v2 : v;
-    v = np > 3 ? v + v3 : v;
-    return v;
-}
 
 // dL/d action[b][j]: over the critic heads that consumed the action and, when the critic's first-layer backward came out
 // of the hidden-layer tiles (rrl_first_layer_t), over their column-tile partials -- up to 2 x 16 loads, all issued
@@ -1248,7 +1298,7 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
                      float* h1, float* h2, float* out, float* scratch, int finalize, void* stream) {
     const int rc = stack_check(G, M, H, din, dout, x, W1, b1, W2, b2, W3, b3, out);
     if (rc != RRL_OK) return rc;
-    StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx};
+    StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx, rrl_policy_head_t{}, 0};
     if (scratch && rrl_mlp3_is_split(M, H)) {
         // 4 workgroups (column groups) per row tile + fixed-order sum of their partial last-layer outputs
         if (M <= kSplitSmallM || H != 256) {
@@ -1298,7 +1348,15 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
         const rrl_stack_t& p = st[k];
         const int rc = stack_check(p.G, p.M, p.H, p.din, p.dout, p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.out);
         if (rc != RRL_OK) return rc;
-        sg.a[k] = StackArgs{p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.h1, p.h2, p.out, p.M, p.H, p.din, p.dout, p.ldx};
+        sg.a[k] = StackArgs{p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.h1, p.h2, p.out, p.M, p.H, p.din, p.dout, p.ldx,
+                            p.in_head, p.use_in_head};
+        if (p.use_in_head) {
+            const rrl_policy_head_t& h = p.in_head;
+            if (p.din != 4 || !h.head || !h.scale || !h.bias || h.n_part <= 0 || h.n_part > 4 ||
+                (h.kind == RRL_HEAD_GAUSS ? !h.eps : (h.kind != RRL_HEAD_STOCH || !h.log_std)) || (h.obs_out && !h.action))
+                return RRL_EINVAL;
+            if (!(p.scratch && rrl_mlp3_is_split(p.M, p.H))) return RRL_EINVAL;   // the column-split kernels only
+        }
         sg.partial[k] = p.scratch;
         sg.G[k] = p.G;
         int my;

@@ -517,7 +517,8 @@ int rrl_nav_step_push(int env_kind, int64_t n, double* pos, int32_t* t, float* o
 
 int rrl_nav_step_push_select(int env_kind, int64_t n, double* pos, int32_t* t, float* obs, const float* task_action,
                              int ld_task, const float* z, int z_n_part, long long z_part_stride,
-                             float eps_safe, const float* rec_action, float* real_action,
+                             float eps_safe, const float* rec_action, const rrl_policy_head_t* rec_head,
+                             float* real_action,
                              uint8_t* recovery, uint64_t seed, uint64_t counter, uint64_t* counter_dev,
                              uint64_t counter_inc, int32_t horizon, int auto_reset, float reward_penalty,
                              int push_real_action, const rrl_replay_t* memory, const rrl_replay_t* recovery_memory,
@@ -525,7 +526,7 @@ int rrl_nav_step_push_select(int env_kind, int64_t n, double* pos, int32_t* t, f
                              uint8_t* ep_done, uint64_t* stats, double* reward_sums, float* ep_reward, void* stream) {
     if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
     rrl_step::StepPushArgs p;
-    const rrl_step::SelectIn sel{z, z_n_part, z_part_stride, eps_safe, rec_action, real_action, recovery};
+    const rrl_step::SelectIn sel{z, z_n_part, z_part_stride, eps_safe, rec_action, rec_head, real_action, recovery};
     const int rc = rrl_step::fill_args(p, n, pos, t, obs, task_action, ld_task, nullptr, nullptr, &sel, seed, counter,
                                        counter_dev, counter_inc, horizon, auto_reset, reward_penalty, push_real_action,
                                        memory, recovery_memory, next_obs, reward, done, constraint, success, ep_done,

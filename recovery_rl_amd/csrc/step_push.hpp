@@ -55,7 +55,8 @@ struct StepPushArgs {
     int sel_np;
     long long sel_ps;
     float sel_eps;
-    const float2* sel_rec_action;
+    const float2* sel_rec_action;   // the recovery action, or (null) computed here from the recovery policy's head:
+    rrl_policy_head_t sel_rec_head; // rrl_stoch_head_fwd evaluated per env (same formulas, same bits)
     float2* sel_real_out;     // the executed action and the flag are written for the consumers downstream
     uint8_t* sel_recovery_out;
     float reward_penalty;
@@ -123,7 +124,29 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
                 z0 = np > 3 ? z0 + u3 : z0; z1 = np > 3 ? z1 + w3 : z1;
                 const float q0 = 1.f / (1.f + expf(-z0)), q1 = 1.f / (1.f + expf(-z1));
                 rec = fmaxf(q0, q1) > p.sel_eps;
-                act = rec ? p.sel_rec_action[i] : task;
+                float2 ra;
+                if (p.sel_rec_action) {
+                    ra = p.sel_rec_action[i];
+                } else {
+                    const rrl_policy_head_t& hd = p.sel_rec_head;
+                    float v[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float* hp = hd.head + 2 * i + j;
+                        const int hn = hd.n_part;
+                        const float h0 = hp[0], h1 = hp[hn > 1 ? hd.part_stride : 0], h2 = hp[hn > 2 ? 2 * hd.part_stride : 0],
+                                    h3 = hp[hn > 3 ? 3 * hd.part_stride : 0];
+                        float raw = h0;
+                        raw = hn > 1 ? raw + h1 : raw;
+                        raw = hn > 2 ? raw + h2 : raw;
+                        raw = hn > 3 ? raw + h3 : raw;
+                        const float mean = tanhf(raw) * hd.scale[j] + hd.bias[j];
+                        const float e = hd.eps ? hd.eps[2 * i + j] : 0.f;
+                        v[j] = mean + expf(fmaxf(hd.log_std[j], hd.min_log_std)) * e;
+                    }
+                    ra = make_float2(v[0], v[1]);
+                }
+                act = rec ? ra : task;
                 p.sel_real_out[i] = act;
                 p.sel_recovery_out[i] = uint8_t(rec);
             } else {
@@ -227,6 +250,7 @@ struct SelectIn {
     long long part_stride;
     float eps_safe;
     const float* rec_action;
+    const rrl_policy_head_t* rec_head;
     float* real_out;
     uint8_t* recovery_out;
 };
@@ -242,8 +266,14 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
     if (!pos || !t || !obs || !task_action || !memory || !next_obs || !reward || !done || !constraint || !success ||
         !stats || !reward_sums || !ep_reward || ld_task < 2 || (ld_task & 1))
         return RRL_EINVAL;
-    if (sel ? (!sel->z || !sel->rec_action || !sel->real_out || !sel->recovery_out || sel->n_part <= 0 || sel->n_part > 4) : !real_action)
+    if (sel ? (!sel->z || (!sel->rec_action && !sel->rec_head) || !sel->real_out || !sel->recovery_out ||
+               sel->n_part <= 0 || sel->n_part > 4) : !real_action)
         return RRL_EINVAL;
+    if (sel && !sel->rec_action) {
+        const rrl_policy_head_t& h = *sel->rec_head;
+        if (h.kind != RRL_HEAD_STOCH || !h.head || !h.scale || !h.bias || !h.log_std || h.n_part <= 0 || h.n_part > 4)
+            return RRL_EINVAL;
+    }
     if (n > memory->cap || (recovery_memory && n > recovery_memory->cap)) return RRL_ERANGE;
     p.step = StepArgs{n, (double2*)pos, (const float2*)real_action, nullptr, seed, counter, counter_dev,
                       counter_inc, (float2*)next_obs, (float2*)obs, reward, done, constraint, success, ep_done,
@@ -256,6 +286,7 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
     p.sel_ps = sel ? sel->part_stride : 0;
     p.sel_eps = sel ? sel->eps_safe : 0.f;
     p.sel_rec_action = sel ? (const float2*)sel->rec_action : nullptr;
+    p.sel_rec_head = (sel && !sel->rec_action) ? *sel->rec_head : rrl_policy_head_t{};
     p.sel_real_out = sel ? (float2*)sel->real_out : nullptr;
     p.sel_recovery_out = sel ? sel->recovery_out : nullptr;
     p.reward_penalty = reward_penalty;
