@@ -101,9 +101,20 @@ class rrl_loss_t(C.Structure):
                 ("loss", C.c_void_p), ("da_parts", C.c_int), ("da_part_stride", C.c_longlong)]
 
 
+HEAD_GAUSS, HEAD_STOCH = 0, 1
+
+
+class rrl_policy_head_t(C.Structure):
+    _fields_ = [("kind", C.c_int), ("B", C.c_int), ("head", C.c_void_p), ("n_part", C.c_int),
+                ("part_stride", C.c_longlong), ("eps", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
+                ("action", C.c_void_p), ("ld_action", C.c_int), ("logp", C.c_void_p), ("mean_out", C.c_void_p),
+                ("obs_in", C.c_void_p), ("obs_out", C.c_void_p), ("log_std", C.c_void_p), ("min_log_std", C.c_float)]
+
+
 class rrl_stack_t(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("G", "M", "H", "din", "dout", "ldx")] + [
-        (n, C.c_void_p) for n in ("x", "W1", "b1", "W2", "b2", "W3", "b3", "h1", "h2", "out", "scratch")]
+        (n, C.c_void_p) for n in ("x", "W1", "b1", "W2", "b2", "W3", "b3", "h1", "h2", "out", "scratch")] + [
+        ("in_head", rrl_policy_head_t), ("use_in_head", C.c_int)]
 
 
 class rrl_head_bwd_t(C.Structure):
@@ -124,16 +135,6 @@ class rrl_hidden_bwd_t(C.Structure):
 class rrl_input_bwd_t(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("G", "B", "H", "din", "ldx")] + [
         (n, C.c_void_p) for n in ("dh1", "x", "W1", "dW1", "db1", "dx")]
-
-
-HEAD_GAUSS, HEAD_STOCH = 0, 1
-
-
-class rrl_policy_head_t(C.Structure):
-    _fields_ = [("kind", C.c_int), ("B", C.c_int), ("head", C.c_void_p), ("n_part", C.c_int),
-                ("part_stride", C.c_longlong), ("eps", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
-                ("action", C.c_void_p), ("ld_action", C.c_int), ("logp", C.c_void_p), ("mean_out", C.c_void_p),
-                ("obs_in", C.c_void_p), ("obs_out", C.c_void_p), ("log_std", C.c_void_p), ("min_log_std", C.c_float)]
 
 
 class rrl_draw_t(C.Structure):
@@ -183,9 +184,11 @@ def _declare(lib):
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_maze_step_push": (ci, [i64, vp, vp, vp, vp, vp, vp, u64, u64, vp, u64, i32, ci, f32, ci, rp, rp,
                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-        "rrl_nav_step_push_select": (ci, [ci, i64, vp, vp, vp, vp, ci, vp, ci, ll, f32, vp, vp, vp, u64, u64, vp, u64, i32, ci,
+        "rrl_nav_step_push_select": (ci, [ci, i64, vp, vp, vp, vp, ci, vp, ci, ll, f32, vp, C.POINTER(rrl_policy_head_t), vp, vp,
+                                          u64, u64, vp, u64, i32, ci,
                                           f32, ci, rp, rp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-        "rrl_maze_step_push_select": (ci, [i64, vp, vp, vp, vp, ci, vp, ci, ll, f32, vp, vp, vp, u64, u64, vp, u64, i32, ci,
+        "rrl_maze_step_push_select": (ci, [i64, vp, vp, vp, vp, ci, vp, ci, ll, f32, vp, C.POINTER(rrl_policy_head_t), vp, vp,
+                                           u64, u64, vp, u64, i32, ci,
                                            f32, ci, rp, rp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_sample_multi": (ci, [C.POINTER(rrl_draw_t), C.POINTER(rrl_draw_t), ll, u64, u64, vp, u64, vp, vp]),
         "rrl_mlp3_forward_multi": (ci, [ci, C.POINTER(rrl_stack_t), vp]),

@@ -535,42 +535,53 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     }
     if (a.use_in_head) {
         // lanes q = 0, 1 carry the observation, lanes q = 2, 3 the action dimension j = q - 2 of the policy head for
-        // their row; every wave of every workgroup recomputes it (a few transcendental ops), workgroup (z, g) = (0, 0)
+        // their row.  Wave 0 evaluates it for the workgroup's rows (the transcendental chain costs ~1 000 cycles per row
+        // tile: done by every wave of four workgroups per CU it was +3.7 us on the 4096-row forward) and hands the
+        // values to the other waves through LDS (the h2 tile's space: nothing lives there yet); workgroup (z, g) = (0, 0)
         // stores action and log-probability for the consumers downstream.  Same formulas, same bits as the kernels of
         // update_kernels.hip.
         const rrl_policy_head_t& hd = a.in_head;
         const int j = q & 1;
-        const bool writer = z == 0 && g == 0 && wave == 0;
+        const bool writer = z == 0 && g == 0;
+        float* xs = h2s;                                 // [R * 16][4]
+        if (wave == 0) {
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const int row = min(m0 + 16 * t + i, M - 1);
-            const bool row_ok = m0 + 16 * t + i < M;
-            float val, lp_term = 0.f;
-            const float e = hd.eps ? hd.eps[2 * row + j] : 0.f;
-            const float sc = hd.scale[j], bi = hd.bias[j];
-            if (hd.kind == RRL_HEAD_GAUSS) {
-                const float mean = loss::psum(hd.head, 4 * row + j, hd.n_part, hd.part_stride);
-                const float ls = fminf(fmaxf(loss::psum(hd.head, 4 * row + 2 + j, hd.n_part, hd.part_stride),
-                                             loss::kLogSigMin), loss::kLogSigMax);
-                const float y = tanhf(mean + expf(ls) * e);
-                val = y * sc + bi;
-                lp_term = -0.5f * e * e - ls - 0.918938533204672742f - logf(sc * (1.f - y * y) + loss::kEps);
-            } else {
-                const float mean = tanhf(loss::psum(hd.head, 2 * row + j, hd.n_part, hd.part_stride)) * sc + bi;
-                val = mean + expf(fmaxf(hd.log_std[j], hd.min_log_std)) * e;
-            }
-            const float other = __shfl_xor(lp_term, 16);           // lane (i, 2) <-> lane (i, 3)
-            if (q >= 2) {
-                xa[t] = val;
-                if (writer && row_ok) {
-                    if (hd.action) hd.action[(long long)row * hd.ld_action + j] = val;
-                    if (hd.logp && q == 2) hd.logp[row] = lp_term + other;
+            for (int t = 0; t < R; ++t) {
+                const int row = min(m0 + 16 * t + i, M - 1);
+                const bool row_ok = m0 + 16 * t + i < M;
+                float val, lp_term = 0.f;
+                const float e = hd.eps ? hd.eps[2 * row + j] : 0.f;
+                const float sc = hd.scale[j], bi = hd.bias[j];
+                if (hd.kind == RRL_HEAD_GAUSS) {
+                    const float mean = loss::psum(hd.head, 4 * row + j, hd.n_part, hd.part_stride);
+                    const float ls = fminf(fmaxf(loss::psum(hd.head, 4 * row + 2 + j, hd.n_part, hd.part_stride),
+                                                 loss::kLogSigMin), loss::kLogSigMax);
+                    const float y = tanhf(mean + expf(ls) * e);
+                    val = y * sc + bi;
+                    lp_term = -0.5f * e * e - ls - 0.918938533204672742f - logf(sc * (1.f - y * y) + loss::kEps);
+                } else {
+                    const float mean = tanhf(loss::psum(hd.head, 2 * row + j, hd.n_part, hd.part_stride)) * sc + bi;
+                    val = mean + expf(fmaxf(hd.log_std[j], hd.min_log_std)) * e;
                 }
-            } else if (hd.obs_in) {
-                xa[t] = hd.obs_in[2 * row + q];
-                if (writer && row_ok && hd.obs_out) hd.obs_out[(long long)row * hd.ld_action + q] = xa[t];
+                const float other = __shfl_xor(lp_term, 16);           // lane (i, 2) <-> lane (i, 3)
+                float xv = xa[t];
+                if (q >= 2) {
+                    xv = val;
+                    if (writer && row_ok) {
+                        if (hd.action) hd.action[(long long)row * hd.ld_action + j] = val;
+                        if (hd.logp && q == 2) hd.logp[row] = lp_term + other;
+                    }
+                } else if (hd.obs_in) {
+                    xv = hd.obs_in[2 * row + q];
+                    if (writer && row_ok && hd.obs_out) hd.obs_out[(long long)row * hd.ld_action + q] = xv;
+                }
+                xs[(16 * t + i) * 4 + q] = xv;
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < R; ++t) xa[t] = xs[(16 * t + i) * 4 + q];
+        __syncthreads();                                 // h2s is reused by layer 2 (and aliases h1s for R > 1)
     }
     float w1b[kU], bias1[kU];
 #pragma unroll

@@ -209,13 +209,14 @@ class VectorLoop:
             # the recovery gate runs inside the step kernel: `action` is the strided task action, `real_action` and
             # `rec_u8` are written by this launch
             self._actor.pending_select = None
-            zq, z_parts, z_stride, eps_safe, rec_action = select
+            zq, z_parts, z_stride, eps_safe, rec_action, rec_head = select
             assert action.stride(1) == 1 and rec_u8 is not None and rec_u8.dtype == torch.uint8
             entry = env.lib.rrl_maze_step_push_select if env.env_name == "maze" else env.lib.rrl_nav_step_push_select
             head = () if env.env_name == "maze" else (env.kind,)
             rc = entry(
                 *head, self.n, _lib.ptr(env.pos), _lib.ptr(env.t), _lib.ptr(env.obs), _lib.ptr(action), action.stride(0),
-                _lib.ptr(zq), z_parts, z_stride, eps_safe, _lib.ptr(rec_action), _lib.ptr(real_action), _lib.ptr(rec_u8),
+                _lib.ptr(zq), z_parts, z_stride, eps_safe, _lib.ptr(rec_action),
+                C.byref(rec_head) if rec_head is not None else None, _lib.ptr(real_action), _lib.ptr(rec_u8),
                 env.seed_value, 0,
                 _lib.ptr(env.tick), 1, env.horizon, 1, float(cfg.constraint_reward_penalty),
                 int(bool(cfg.disable_action_relabeling)), C.byref(mem._desc), C.byref(rmem._desc) if use_rmem else None,

@@ -211,8 +211,9 @@ class Stack:
         return self.parts
 
     # -- descriptors of the same launches for the grouped entry points (rrl_*_multi) ----------------------------
-    def forward_desc(self, x, params=None, save=True):
-        """rrl_stack_t of forward(x, params, save); the caller launches it with forward_multi()."""
+    def forward_desc(self, x, params=None, save=True, in_head=None):
+        """rrl_stack_t of forward(x, params, save); the caller launches it with forward_multi().  `in_head`
+        (rrl_policy_head_t): columns 2..3 of x are computed by the stack kernel itself from that policy head."""
         assert mlp3_supported(self.net.H, self.net.din, self.net.dout) and not self.finalize
         P = (params or self.net).p
         net = self.net
@@ -220,9 +221,12 @@ class Stack:
         assert x.stride(1) == 1
         self.parts = (self.scratch, self.nsplit, self.scratch.stride(0)) if self.split else (self.out, 1, 0)
         p = _lib.ptr
+        if in_head is not None:
+            assert self.split and net.din == 4, "the input head lives in the column-split kernels"
         return _lib.rrl_stack_t(net.G, x.shape[0], net.H, net.din, net.dout, x.stride(0), p(x), p(P["W1"]), p(P["b1"]),
                                 p(P["W2"]), p(P["b2"]), p(P["W3"]), p(P["b3"]), p(self.h1) if save else None,
-                                p(self.h2) if save else None, p(self.out), p(self.scratch) if self.split else None)
+                                p(self.h2) if save else None, p(self.out), p(self.scratch) if self.split else None,
+                                in_head if in_head is not None else _lib.rrl_policy_head_t(), int(in_head is not None))
 
     def backward_descs(self, dout, weight_grads=True, input_grad=False):
         """(rrl_head_bwd_t, rrl_hidden_bwd_t, rrl_input_bwd_t) of backward(dout, weight_grads, input_grad)."""
@@ -373,6 +377,7 @@ class FastUpdater:
         # grouped launches evaluate the target networks in the same launch as the online ones: own workspaces
         self.cri_t, self.qr_t = Stack(self.critic, B), Stack(self.qrisk, B)
         self.grouped = True        # kernels that do not depend on each other share launches (rrl_*_multi)
+        self.fuse_heads = True     # policy heads evaluated by the consuming critic stack (rrl_stack_t.in_head)
         self.xu_q, self.x2u_q, self.xpu_q = z(B, 4), z(B, 4), z(B, 4)   # the Q_risk batch's rows (drawn up front)
         self.xu = z(B, 4)                                           # [s | a]
         self.x_pol = z(2 * B, 4)                                    # [s' | a'] stacked on [s | pi]
@@ -561,11 +566,16 @@ class FastUpdater:
         r, m = r.reshape(-1), m.reshape(-1)
         self.pol_ab.forward(self.x_pol[:, 0:2])
         head2, head = self.pol_next.after_forward(), self.pol_b.after_forward()
-        heads_multi([self._gauss_desc(head2, eps_next, self.x2u[:, 2:4], self.logp2),
-                     self._gauss_desc(head, eps_pi, self.xpu[:, 2:4], self.logp)])
-        # critic_target(s', a'), critic(s, a), critic(s, pi): three independent forwards (sac.py:192-218)
-        forward_multi([self.cri_t.forward_desc(self.x2u, params=self.critic_target, save=False),
-                       self.cri_a.forward_desc(self.xu), self.cri_b.forward_desc(self.xpu)])
+        hd2 = self._gauss_desc(head2, eps_next, self.x2u[:, 2:4], self.logp2)
+        hd1 = self._gauss_desc(head, eps_pi, self.xpu[:, 2:4], self.logp)
+        fuse = self.fuse_heads and self.cri_t.split
+        if not fuse:
+            heads_multi([hd2, hd1])
+            hd2 = hd1 = None
+        # critic_target(s', a'), critic(s, a), critic(s, pi): three independent forwards (sac.py:192-218); a' and pi are
+        # evaluated by the stacks that consume them
+        forward_multi([self.cri_t.forward_desc(self.x2u, params=self.critic_target, save=False, in_head=hd2),
+                       self.cri_a.forward_desc(self.xu), self.cri_b.forward_desc(self.xpu, in_head=hd1)])
         qt, n_part, ps = self.cri_t.parts
         q, qp = self.cri_a.parts[0], self.cri_b.parts[0]
         # the critic's backward for its own loss (weight gradients) and for the policy loss (input gradient)
@@ -596,11 +606,14 @@ class FastUpdater:
         if mf:
             fwd.append(self.rec_a.forward_desc(xpu[:, 0:2]))
         forward_multi(fwd)
-        hd = [self._gauss_desc(self.pol_a.parts, eps_next, x2u[:, 2:4], self.logp2)]
-        if mf:
-            hd.append(self._stoch_desc(self.rec_a.parts, eps_pi, xpu[:, 2:4]))
-        heads_multi(hd)
-        forward_multi([self.qr_t.forward_desc(x2u, params=self.qrisk_target, save=False), self.qr_a.forward_desc(xu)])
+        hd_next = self._gauss_desc(self.pol_a.parts, eps_next, x2u[:, 2:4], self.logp2)
+        hd_rec = self._stoch_desc(self.rec_a.parts, eps_pi, xpu[:, 2:4]) if mf else None
+        fuse = self.fuse_heads and self.qr_t.split
+        if not fuse:
+            heads_multi([hd_next] + ([hd_rec] if mf else []))
+            hd_next = hd_rec = None
+        forward_multi([self.qr_t.forward_desc(x2u, params=self.qrisk_target, save=False, in_head=hd_next),
+                       self.qr_a.forward_desc(xu)])
         zt, n_part, ps = self.qr_t.parts
         z = self.qr_a.parts[0]
         self.qr_a.backward(self._loss(_lib.LOSS_QRISK_CRITIC, z, n_part, ps, out_t=zt, v0=c, v1=m,
@@ -610,7 +623,11 @@ class FastUpdater:
         if mf:                                                             # qrisk.py:150-158, at the UPDATED critic
             raw, rn, rs = self.rec_a.parts
             ls = self.recpolicy.p["log_std"]
-            zp, n_part, ps = self.qr_b.forward(xpu)
+            if hd_rec is not None:         # the recovery action is evaluated by the critic stack that consumes it
+                forward_multi([self.qr_b.forward_desc(xpu, in_head=hd_rec)])
+                zp, n_part, ps = self.qr_b.parts
+            else:
+                zp, n_part, ps = self.qr_b.forward(xpu)
             self.qr_b.backward(self._loss(_lib.LOSS_QRISK_POLICY, zp, n_part, ps, loss=self.losses[6:]),
                                weight_grads=False, input_grad=True)
             self.rec_a.backward(self._loss(_lib.LOSS_STOCH_HEAD, raw, rn, rs, v0=eps_pi, v1=ls, v2=self.rscale,
@@ -740,12 +757,21 @@ class FastActor:
         if f.grouped and use_recovery and mf_recovery:
             # task policy and recovery policy on the same observations: one forward launch, one head launch
             forward_multi([self.pol.forward_desc(obs, save=False), self.rec.forward_desc(obs, save=False)])
-            heads_multi([f._gauss_desc(self.pol.parts, noise[0], self.xa[:, 2:4], None, n=n, obs_in=obs, obs_out=self.xa),
-                         f._stoch_desc(self.rec.parts, noise[1], self.rec_action, n=n)])
+            task_head = f._gauss_desc(self.pol.parts, noise[0], self.xa[:, 2:4], None, n=n, obs_in=obs, obs_out=self.xa)
+            rec_head = f._stoch_desc(self.rec.parts, noise[1], self.rec_action, n=n)
+            if defer_select and f.fuse_heads and self.qr.split:
+                # no head launch: the task action is evaluated by the Q_risk stack that consumes it (and stored in xa
+                # for the step kernel), the recovery action by the step kernel itself
+                self.qr.finalize = False
+                forward_multi([self.qr.forward_desc(self.xa, save=False, in_head=task_head)])
+                zq, zn, zs = self.qr.parts
+                self.pending_select = (zq, zn, zs, float(eps_safe), None, rec_head)
+                return self.xa[:, 2:4], self.real_action, self.recovery
+            heads_multi([task_head, rec_head])
             if defer_select:
                 self.qr.finalize = False            # the step kernel adds the partial last-layer sums itself
                 zq, zn, zs = self.qr.forward(self.xa, save=False)
-                self.pending_select = (zq, zn, zs, float(eps_safe), self.rec_action)
+                self.pending_select = (zq, zn, zs, float(eps_safe), self.rec_action, None)
                 return self.xa[:, 2:4], self.real_action, self.recovery
             self.qr.finalize = True
             zq, _, _ = self.qr.forward(self.xa, save=False)
