@@ -228,6 +228,26 @@ def time_nav_step_kernel(device, n, reps=200):
     return _graph_of(launch, reps, device)
 
 
+def time_nav_step_compact_kernel(device, n, reps=200):
+    """Average duration of ONE rrl_nav_step_compact launch: the same env step in the 56 B/env-step layout (u16 status
+    words instead of four u8 masks + an i32 count; no second observation array: the post-reset observation of the ~1 %
+    finished rows is float(pos))."""
+    import torch
+    from recovery_rl_amd import _lib
+    from recovery_rl_amd.env import make_vec_env
+    env = make_vec_env("navigation1", n, device=device, seed=1)
+    env.reset()
+    lib = _lib.load()
+    act = torch.rand(n, 2, device=device) * 2 - 1
+    status = torch.zeros(n, dtype=torch.int16, device=device)
+
+    def launch():
+        return lib.rrl_nav_step_compact(0, n, _lib.ptr(env.pos), _lib.ptr(act), None, 1, 0, _lib.ptr(env.tick), 1,
+                                        _lib.ptr(env.next_obs), None, _lib.ptr(env.reward),
+                                        _lib.ptr(status), 100, 1, _lib.current_stream())
+    return _graph_of(launch, reps, device)
+
+
 def time_nav_rollout_kernel(device, n=1 << 20, T=100):
     """The fused-rollout variant of SURVEY 8d: T scripted steps per env in ONE launch with the state in registers
     (rrl_nav_rollout); per env-step only the 8-byte action is read and the reward + constraint flag written."""
@@ -523,13 +543,17 @@ def main():
                     "(N up to 2^24, `bench.py --sweep`): profiles/round2_roofline_sweep.json"
                     % (a.num_envs, a.num_envs * STEP_PUSH_ALGO_BYTES // 1024)}
         if a.sweep:
-            sweep, sweep_sp = [], []
+            sweep, sweep_sp, sweep_c = [], [], []
             for logn in (12, 16, 20, 24):
                 n = 1 << logn
                 tk = time_nav_step_kernel(device, n, reps=200 if logn <= 16 else 20)
                 sweep.append({"n_envs": n, "launch_us": tk * 1e6, "env_steps_per_s": n / tk,
                               "achieved_GBs": n * NAV_STEP_ALGO_BYTES / tk / 1e9,
                               "frac": n * NAV_STEP_ALGO_BYTES / tk / 1e9 / HBM_PEAK_GBS})
+                tc = time_nav_step_compact_kernel(device, n, reps=200 if logn <= 16 else 20)
+                sweep_c.append({"n_envs": n, "launch_us": tc * 1e6, "env_steps_per_s": n / tc,
+                                "achieved_GBs": n * NAV_STEP_ALGO_BYTES / tc / 1e9,
+                                "frac": n * NAV_STEP_ALGO_BYTES / tc / 1e9 / HBM_PEAK_GBS})
                 if logn <= 22:
                     ts = time_step_push_kernel(device, "navigation1", n, reps=200 if logn <= 16 else 20)
                     sweep_sp.append({"n_envs": n, "launch_us": ts * 1e6, "env_steps_per_s": n / ts,
@@ -538,6 +562,9 @@ def main():
                 torch.cuda.empty_cache()
             extra["roofline_sweep"] = sweep
             extra["roofline_sweep_step_push"] = sweep_sp
+            extra["roofline_sweep_compact"] = {
+                "kernel": "nav_step_compact_kernel<0,false> (rrl_nav_step_compact): the env step in the 56 B/env-step "
+                          "layout", "moved_bytes_per_env_step": 56, "rows": sweep_c}
             n_r, t_r = 1 << 20, 100
             tr = time_nav_rollout_kernel(device, n_r, t_r)
             extra["roofline_rollout"] = {

@@ -78,6 +78,26 @@ int rrl_nav_step(int env_kind, int64_t n, double* pos, const float* action, cons
                  uint8_t* success, uint8_t* ep_done, int32_t* t, int32_t horizon, int auto_reset,
                  void* stream);
 
+/* The same step in the compact layout of the bandwidth regime (56 B moved per env-step instead of 72; same
+ * arithmetic, same bits).  The step count and the four flags of rrl_nav_step share ONE u16 status word per env:
+ *   status     [n]   u16  in/out  bits 0-11 steps taken in the running episode (in: before, out: after; 0 after an
+ *                                 auto-reset), bit 12 done, 13 constraint, 14 success, 15 ep_done (out; ignored on input)
+ *   reset_obs  [n,2] f32  out     written ONLY at rows with ep_done when auto_reset != 0: the observation after the
+ *                                 reset (= float(pos) of that row).  Everywhere else the next policy input is next_obs
+ *                                 itself.  Nullable, and NULL is the fast form in the bandwidth regime: ~200 k
+ *                                 scattered 8-byte stores cost as much as a dense 8 B/env array (+45 us at 2^24 envs).
+ * horizon <= 4095 (RRL_ERANGE otherwise).  pos / action / noise / next_obs / reward 16-byte aligned, status and
+ * reset_obs 8-byte aligned (RRL_EINVAL otherwise). */
+#define RRL_STATUS_STEPS 0x0fffu
+#define RRL_STATUS_DONE 0x1000u
+#define RRL_STATUS_CONSTRAINT 0x2000u
+#define RRL_STATUS_SUCCESS 0x4000u
+#define RRL_STATUS_EP_DONE 0x8000u
+int rrl_nav_step_compact(int env_kind, int64_t n, double* pos, const float* action, const double* noise,
+                         uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                         float* next_obs, float* reset_obs, float* reward, uint16_t* status, int32_t horizon,
+                         int auto_reset, void* stream);
+
 /* Replaces Navigation*.reset (env/navigation1.py:91-97) for n envs. `mask` (nullable, u8[n])
  * restricts the reset to rows with mask != 0.  obs / t nullable. */
 int rrl_nav_reset(int env_kind, int64_t n, double* pos, float* obs, int32_t* t,

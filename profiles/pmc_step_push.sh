@@ -9,8 +9,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc
 mkdir -p $OUT
 : > $OUT/raw_counters.txt
-for PROG in run_step_push run_nav_step; do
- for N in 4096 1048576 ${BIGN:-2097152}; do
+for PROG in ${PROGS:-run_step_push run_nav_step run_nav_step_compact}; do
+ for N in ${SIZES:-4096 1048576 ${BIGN:-2097152}}; do
   for C in FETCH_SIZE WRITE_SIZE; do
     D=/tmp/pmc_${PROG}_${N}_$C
     rm -rf $D
@@ -39,7 +39,8 @@ for line in open(sys.argv[1]):
     if len(p) == 5 and p[2] in ('FETCH_SIZE', 'WRITE_SIZE') and float(p[4]) >= 0:
         kb = float(p[4])
         d[p[0]][p[1]]['fetch_bytes' if p[2] == 'FETCH_SIZE' else 'write_bytes'] = int(kb * 1024 * (2 if p[2] == 'FETCH_SIZE' else 1))
-for prog, name in (('run_step_push', 'round2_step_push_pmc.json'), ('run_nav_step', 'round2_nav_step_pmc.json')):
+for prog, name in (('run_step_push', 'round2_step_push_pmc.json'), ('run_nav_step', 'round2_nav_step_pmc.json'),
+                   ('run_nav_step_compact', 'round2_nav_step_compact_pmc.json')):
     rec = {n: v for n, v in d[prog].items() if len(v) == 2}
     json.dump(rec, open(sys.argv[2] + '/' + name, 'w'), indent=1)
     print(name, rec)

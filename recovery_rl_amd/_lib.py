@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 EXPORTS = [
     "rrl_abi_version", "rrl_last_hip_error", "rrl_counter_add",
-    "rrl_nav_step", "rrl_nav_reset", "rrl_nav_rollout", "rrl_nav_offline_rollouts",
+    "rrl_nav_step", "rrl_nav_step_compact", "rrl_nav_reset", "rrl_nav_rollout", "rrl_nav_offline_rollouts",
     "rrl_nav_offline",
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_sample_multi",
@@ -169,6 +169,7 @@ def _declare(lib):
         "rrl_counter_add": (ci, [vp, u64, vp]),
         "rrl_nav_step": (ci, [ci, i64, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, vp, vp, vp,
                               vp, i32, ci, vp]),
+        "rrl_nav_step_compact": (ci, [ci, i64, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, i32, ci, vp]),
         "rrl_nav_reset": (ci, [ci, i64, vp, vp, vp, vp, vp, u64, u64, vp, vp]),
         "rrl_nav_rollout": (ci, [ci, i64, i32, vp, vp, u64, u64, vp, vp, vp, vp, vp, vp]),
         "rrl_nav_offline_rollouts": (i64, [ci, i64]),

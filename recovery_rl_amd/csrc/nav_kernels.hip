@@ -7,6 +7,9 @@
 // grid-stride, so a launch covers the 256 CUs (8 XCDs) with 8 workgroups per CU.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <type_traits>
+
 #include "replay_device.hpp"
 #include "rrl_device.hpp"
 #include "rrl_host.hpp"
@@ -63,6 +66,61 @@ __global__ __launch_bounds__(kBlock) void nav_step_kernel(StepArgs a) {
     rrl::advance_counter(a.counter_dev, a.counter_inc);
 }
 
+// Resets of the bandwidth-regime kernels.  With a ~1.2 % termination rate per step, one to three of the 256 envs a wave
+// steps per pass finish, and an inline reset sends the whole wave through the Philox + Box-Muller chain again for each k
+// that has a finished lane (2.2 extra trips per pass).  Measured at 2^24 envs, all variants interleaved in one process
+// (profiles/nav_step_probe.py; compact layout without reset_obs / general layout; no resets at all: 233 / 261 us):
+//   inline per lane                                            268 / 276 us
+//   once per wave and pass, handed back through LDS (below)     243 / 262 us   <- kept
+//   deferred to the end of the wave, pos patched by scattered stores       267 / 353 us
+//   once per workgroup and pass (two barriers)                  ~340 / 357 us
+// Scattered small stores are what the deferred variant pays for: ~200 k of them per launch cost 35-50 us next to the
+// streaming traffic (profiles/sparse_write_probe.hip: anything below a whole 64-byte granule is a read-modify-write).
+// The reset draws of the rows a wave finished in this pass, evaluated once per wave and pass.  The finished
+// rows of the wave's V x 64 envs are listed in LDS (slots from ballots), the first `total` lanes evaluate normal_at() for
+// them in ONE trip (instead of one trip per k with any finished lane: 2.2 trips per pass at a 1.2 % termination rate), and
+// the owners read the pair back and store it with their dense stores -- no scattered store anywhere.
+template <int V>
+__device__ __forceinline__ void wave_reset_draws(uint64_t seed, uint64_t ctr, int64_t i0, const bool (&fin)[V],
+                                                 double (&z0)[V], double (&z1)[V], uint32_t* rows, double2* draws) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t below = (1ULL << lane) - 1ULL;
+    int slot[V], total = 0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const uint64_t bal = __ballot(fin[k]);
+        slot[k] = total + __popcll(bal & below);
+        total += __popcll(bal);
+    }
+    if (total == 0) return;
+    if (total > 64) {
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (fin[k]) rrl::normal_at(seed, uint32_t(i0 + k), rrl::kStreamReset, ctr, z0[k], z1[k]);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+        if (fin[k]) rows[slot[k]] = uint32_t(i0 + k);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < total) {
+        double x, y;
+        rrl::normal_at(seed, rows[lane], rrl::kStreamReset, ctr, x, y);
+        draws[lane] = make_double2(x, y);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+        if (fin[k]) {
+            const double2 d = draws[slot[k]];
+            z0[k] = d.x;
+            z1[k] = d.y;
+        }
+    __builtin_amdgcn_wave_barrier();   // the lists are reused by the wave's next pass
+}
+
 // Bandwidth-regime variant (n >= 2^19, n % 4 == 0; measured: 34.9 -> 27.1 us at 2^20, slower below 2^18): one thread steps FOUR consecutive envs.  All loads of the
 // four envs are issued before the first dependent f64 operation (4x the bytes in flight per thread), every
 // access is a 16-byte vector (the four u8 masks of the four envs become one 32-bit store per array), and a wave
@@ -70,9 +128,15 @@ __global__ __launch_bounds__(kBlock) void nav_step_kernel(StepArgs a) {
 // results are bit-identical.
 template <int KIND, bool EXT_NOISE>
 __global__ __launch_bounds__(kBlock) void nav_step4_kernel(StepArgs a) {
+    __shared__ uint32_t wave_rows[kBlock / 64][64];
+    __shared__ double2 wave_draws[kBlock / 64][64];
     const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
     const int64_t n4 = a.n >> 2, stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t q = int64_t(blockIdx.x) * kBlock + threadIdx.x; q < n4; q += stride) {
+    const int64_t n_pass = (n4 + stride - 1) / stride;     // uniform trip count: the reset lists need whole waves
+    for (int64_t pass = 0; pass < n_pass; ++pass) {
+        int64_t q = pass * stride + int64_t(blockIdx.x) * kBlock + threadIdx.x;
+        const bool live = q < n4;
+        if (!live) q = n4 - 1;                             // idle lanes shadow the last quad and store nothing
         const int64_t i0 = q << 2;
         double2 p[4], e[4];
 #pragma unroll
@@ -89,6 +153,7 @@ __global__ __launch_bounds__(kBlock) void nav_step4_kernel(StepArgs a) {
         float2 nobs[4], obs[4];
         float rew[4];
         uint32_t dn4 = 0, cons4 = 0, succ4 = 0, epd4 = 0;
+        bool fin[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             double ex, ey;
@@ -111,16 +176,20 @@ __global__ __launch_bounds__(kBlock) void nav_step4_kernel(StepArgs a) {
             cons4 |= uint32_t(cons) << (8 * k);
             succ4 |= uint32_t(succ) << (8 * k);
             epd4 |= uint32_t(epd) << (8 * k);
-            if (a.auto_reset && epd) {
-                double z0, z1;
-                rrl::normal_at(a.seed, uint32_t(i0 + k), rrl::kStreamReset, ctr, z0, z1);
-                nx = -50.0 + z0;
-                ny = 0.0 + z1;
-                ti[k] = 0;
-            }
+            fin[k] = live & epd & (a.auto_reset != 0);
             p[k] = make_double2(nx, ny);
-            obs[k] = make_float2(float(nx), float(ny));
         }
+        double w0[4], w1[4];
+        wave_reset_draws<4>(a.seed, ctr, i0, fin, w0, w1, wave_rows[threadIdx.x >> 6], wave_draws[threadIdx.x >> 6]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (fin[k]) {
+                ti[k] = 0;
+                p[k] = make_double2(-50.0 + w0[k], 0.0 + w1[k]);     // START_STATE + randn(2), navigation1.py:92
+            }
+            obs[k] = make_float2(float(p[k].x), float(p[k].y));
+        }
+        if (!live) continue;
 #pragma unroll
         for (int k = 0; k < 4; ++k) a.pos[i0 + k] = p[k];
         reinterpret_cast<float4*>(a.next_obs)[2 * q] = make_float4(nobs[0].x, nobs[0].y, nobs[1].x, nobs[1].y);
@@ -135,6 +204,156 @@ __global__ __launch_bounds__(kBlock) void nav_step4_kernel(StepArgs a) {
         reinterpret_cast<uint32_t*>(a.success)[q] = succ4;
         if (a.ep_done) reinterpret_cast<uint32_t*>(a.ep_done)[q] = epd4;
         reinterpret_cast<int4*>(a.t)[q] = make_int4(ti[0], ti[1], ti[2], ti[3]);
+    }
+    rrl::advance_counter(a.counter_dev, a.counter_inc);
+}
+
+// ---- compact form (rrl_nav_step_compact): 56 B moved per env-step instead of 72 ----
+// The general entry keeps the reference's separate arrays (four u8 masks, an i32 step count, two f32 observations).
+// Here the step count and the four flags share one u16 status word per env (read for the count, rewritten), and the
+// post-reset observation -- equal to next_obs wherever the episode goes on -- is written only for the rows whose
+// episode ended.  Four envs per thread, every access a 16-byte vector (8 bytes for the status words); a last partial
+// quad goes through scalar accesses.  Per-env arithmetic = the general kernel's, call for call.
+struct CompactArgs {
+    int64_t n;
+    double2* pos;
+    const float2* action;
+    const double2* noise;
+    uint64_t seed, counter;
+    uint64_t* counter_dev;
+    uint64_t counter_inc;
+    float2* next_obs;
+    float2* reset_obs;
+    float* reward;
+    uint16_t* status;
+    int32_t horizon, auto_reset;
+};
+
+template <int V, bool EXT_NOISE>
+struct CompactIn {
+    double2 p[V], e[V];
+    float ax[V], ay[V];
+    uint32_t st[V];
+};
+
+// inputs of group q (V consecutive envs from q * V; `have` of them exist): 16-byte vectors when V == 4 and the group is whole
+template <int V, bool EXT_NOISE>
+__device__ __forceinline__ void compact_load(const CompactArgs& a, int64_t q, int have, CompactIn<V, EXT_NOISE>& in) {
+    const int64_t i0 = q * V;
+    if (V == 4 && have == 4) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) in.p[k] = a.pos[i0 + k];
+        const float4 a01 = reinterpret_cast<const float4*>(a.action)[2 * q];
+        const float4 a23 = reinterpret_cast<const float4*>(a.action)[2 * q + 1];
+        const uint2 sv = reinterpret_cast<const uint2*>(a.status)[q];
+        if constexpr (EXT_NOISE) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) in.e[k] = a.noise[i0 + k];
+        }
+        const float fx[4] = {a01.x, a01.z, a23.x, a23.z}, fy[4] = {a01.y, a01.w, a23.y, a23.w};
+        const uint32_t sw[4] = {sv.x & 0xffffu, sv.x >> 16, sv.y & 0xffffu, sv.y >> 16};
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            in.ax[k] = fx[k];
+            in.ay[k] = fy[k];
+            in.st[k] = sw[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int64_t i = i0 + (k < have ? k : 0);
+            in.p[k] = a.pos[i];
+            const float2 ak = a.action[i];
+            in.ax[k] = ak.x;
+            in.ay[k] = ak.y;
+            in.st[k] = a.status[i];
+            if constexpr (EXT_NOISE) in.e[k] = a.noise[i];
+        }
+    }
+}
+
+// V envs per thread: 4 in the bandwidth regime, 1 when the launch is latency-bound (a short dependent chain per thread
+// matters more than wide accesses).  (Requesting the next pass's inputs before the f64 chain of the current one --
+// software pipelining at 125 VGPRs -- measured 257.5 vs 258.0 us at 2^24 envs: not kept.)
+template <int KIND, bool EXT_NOISE, int V>
+__global__ __launch_bounds__(kBlock) void nav_step_compact_kernel(CompactArgs a) {
+    __shared__ uint32_t wave_rows[V > 1 ? kBlock / 64 : 1][64];
+    __shared__ double2 wave_draws[V > 1 ? kBlock / 64 : 1][64];
+    const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
+    const int64_t nq = (a.n + V - 1) / V, stride = int64_t(gridDim.x) * kBlock;
+    const int64_t n_pass = (nq + stride - 1) / stride;     // uniform trip count: the reset lists need whole waves
+    const int64_t q_first = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const auto group_of = [&](int64_t pass) {              // idle lanes shadow the last group and store nothing
+        const int64_t q = pass * stride + q_first;
+        return q < nq ? q : nq - 1;
+    };
+    const auto have_of = [&](int64_t q) { return int(a.n - q * V < V ? a.n - q * V : V); };
+    for (int64_t pass = 0; pass < n_pass; ++pass) {
+        const bool live = pass * stride + q_first < nq;
+        const int64_t q = group_of(pass);
+        const int64_t i0 = q * V;
+        const int have = have_of(q);
+        CompactIn<V, EXT_NOISE> in;
+        compact_load<V, EXT_NOISE>(a, q, have, in);
+        double2 p[V];
+        float2 nobs[V];
+        float rew[V];
+        uint32_t st[V];
+        bool fin[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            double ex, ey;
+            if constexpr (EXT_NOISE) {
+                ex = in.e[k].x;
+                ey = in.e[k].y;
+            } else {
+                rrl::normal_at(a.seed, uint32_t(i0 + k), rrl::kStreamStep, ctr, ex, ey);
+            }
+            double nx, ny, cost;
+            rrl::nav_transition<KIND>(in.p[k].x, in.p[k].y, double(in.ax[k]), double(in.ay[k]), ex, ey, nx, ny, cost);
+            const bool cons = rrl::in_obstacle<KIND>(nx, ny);
+            const bool succ = cost > -4.0;
+            const bool dn = succ | cons;
+            uint32_t ti = (in.st[k] & RRL_STATUS_STEPS) + 1u;
+            const bool epd = dn | (int32_t(ti) == a.horizon);
+            if (ti > RRL_STATUS_STEPS) ti = RRL_STATUS_STEPS;
+            nobs[k] = make_float2(float(nx), float(ny));
+            rew[k] = float(cost);
+            fin[k] = live & (k < have) & epd & (a.auto_reset != 0);
+            st[k] = (fin[k] ? 0u : ti) | (dn ? RRL_STATUS_DONE : 0u) | (cons ? RRL_STATUS_CONSTRAINT : 0u) |
+                    (succ ? RRL_STATUS_SUCCESS : 0u) | (epd ? RRL_STATUS_EP_DONE : 0u);
+            p[k] = make_double2(nx, ny);
+        }
+        double w0[V], w1[V];
+        if constexpr (V > 1) {
+            wave_reset_draws<V>(a.seed, ctr, i0, fin, w0, w1, wave_rows[threadIdx.x >> 6], wave_draws[threadIdx.x >> 6]);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (fin[k]) {
+                if constexpr (V == 1) rrl::normal_at(a.seed, uint32_t(i0 + k), rrl::kStreamReset, ctr, w0[k], w1[k]);
+                p[k] = make_double2(-50.0 + w0[k], 0.0 + w1[k]);     // START_STATE + randn(2), navigation1.py:92
+                if (a.reset_obs) a.reset_obs[i0 + k] = make_float2(float(p[k].x), float(p[k].y));
+            }
+        if (!live) continue;
+        if (V == 4 && have == 4) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) a.pos[i0 + k] = p[k];
+            reinterpret_cast<float4*>(a.next_obs)[2 * q] = make_float4(nobs[0].x, nobs[0].y, nobs[1 % V].x, nobs[1 % V].y);
+            reinterpret_cast<float4*>(a.next_obs)[2 * q + 1] =
+                make_float4(nobs[2 % V].x, nobs[2 % V].y, nobs[3 % V].x, nobs[3 % V].y);
+            reinterpret_cast<float4*>(a.reward)[q] = make_float4(rew[0], rew[1 % V], rew[2 % V], rew[3 % V]);
+            reinterpret_cast<uint2*>(a.status)[q] = make_uint2(st[0] | (st[1 % V] << 16), st[2 % V] | (st[3 % V] << 16));
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                if (k < have) {
+                    a.pos[i0 + k] = p[k];
+                    a.next_obs[i0 + k] = nobs[k];
+                    a.reward[i0 + k] = rew[k];
+                    a.status[i0 + k] = uint16_t(st[k]);
+                }
+        }
     }
     rrl::advance_counter(a.counter_dev, a.counter_inc);
 }
@@ -405,6 +624,7 @@ int rrl_nav_step(int env_kind, int64_t n, double* pos, const float* action, cons
                       al(reward, 16) && al(t, 16) && al(done, 4) && al(constraint, 4) && al(success, 4) &&
                       al(ep_done, 4);
     if (vec4) {
+        // 2048 workgroups (8 per CU) although only 5 are resident at ~90 VGPRs: measured 262 vs 272 us for one full round
         const dim3 grid(grid_for(n >> 2));
         if (env_kind == RRL_ENV_NAV1) {
             if (noise) hipLaunchKernelGGL((nav_step4_kernel<0, true>), grid, block, 0, st, a);
@@ -422,6 +642,42 @@ int rrl_nav_step(int env_kind, int64_t n, double* pos, const float* action, cons
     } else {
         if (noise) hipLaunchKernelGGL((nav_step_kernel<1, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((nav_step_kernel<1, false>), grid, block, 0, st, a);
+    }
+    return check_launch();
+}
+
+int rrl_nav_step_compact(int env_kind, int64_t n, double* pos, const float* action, const double* noise,
+                         uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                         float* next_obs, float* reset_obs, float* reward, uint16_t* status, int32_t horizon,
+                         int auto_reset, void* stream) {
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
+    if (n < 0 || n > 0xffffffffLL || horizon < 1 || horizon > int32_t(RRL_STATUS_STEPS)) return RRL_ERANGE;
+    if (!pos || !action || !next_obs || !reward || !status) return RRL_EINVAL;
+    auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & (m - 1)) == 0; };
+    if (!al(pos, 16) || !al(action, 16) || !al(noise, 16) || !al(next_obs, 16) || !al(reset_obs, 8) ||
+        !al(reward, 16) || !al(status, 8))
+        return RRL_EINVAL;
+    if (n == 0) return RRL_OK;
+    CompactArgs a{n, (double2*)pos, (const float2*)action, (const double2*)noise, seed, counter, counter_dev,
+                  counter_inc, (float2*)next_obs, (float2*)reset_obs, reward, status, horizon, auto_reset};
+    const dim3 block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    const auto go = [&](auto kind, auto ext) {
+        constexpr int K = decltype(kind)::value;
+        constexpr bool E = decltype(ext)::value;
+        if (n < (1 << 18)) {          // latency regime: one env per thread, resets inline
+            hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 1>), dim3(grid_for(n)), block, 0, st, a);
+        } else {
+            hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 4>), dim3(grid_for((n + 3) >> 2)), block, 0, st, a);
+        }
+    };
+    using std::integral_constant;
+    if (env_kind == RRL_ENV_NAV1) {
+        if (noise) go(integral_constant<int, 0>{}, integral_constant<bool, true>{});
+        else go(integral_constant<int, 0>{}, integral_constant<bool, false>{});
+    } else {
+        if (noise) go(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+        else go(integral_constant<int, 1>{}, integral_constant<bool, false>{});
     }
     return check_launch();
 }

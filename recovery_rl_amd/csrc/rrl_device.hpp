@@ -25,8 +25,11 @@ __device__ __forceinline__ Bits128 philox(uint32_t c0, uint32_t c1, uint32_t c2,
                                           uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of a mul_hi + mul_lo pair: 20 quarter-rate
+        // multiplies per call instead of 40, same bits
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c0, p1 = uint64_t(0xCD9E8D57u) * c2;
+        const uint32_t h0 = uint32_t(p0 >> 32), l0 = uint32_t(p0);
+        const uint32_t h1 = uint32_t(p1 >> 32), l1 = uint32_t(p1);
         c0 = h1 ^ c1 ^ k0;
         c1 = l1;
         c2 = h0 ^ c3 ^ k1;

@@ -71,6 +71,96 @@ def test_step_matches_oracle_with_philox_noise(env, n):
         assert_same(got, ref)
 
 
+def hip_step_compact(env_name, pos, action, t, noise=None, seed=0, counter=0, horizon=100, auto_reset=False,
+                     stale_flags=0):
+    """rrl_nav_step_compact; returns the same dict as hip_step (flags and count unpacked from the status words,
+    obs = reset_obs where ep_done and auto_reset, next_obs elsewhere) plus the raw outputs."""
+    lib = _lib.load()
+    n = len(pos)
+    d = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=DEV)
+    pos_t, act_t = d(pos, np.float64), d(action, np.float32)
+    status = torch.as_tensor((np.asarray(t).astype(np.int64) | stale_flags).astype(np.int16), device=DEV)
+    noise_t = None if noise is None else d(noise, np.float64)
+    next_obs = torch.zeros(n, 2, device=DEV)
+    reset_obs = torch.full((n, 2), -7.0, device=DEV)
+    reward = torch.zeros(n, device=DEV)
+    rc = lib.rrl_nav_step_compact(co.ENV_KIND[env_name], n, _lib.ptr(pos_t), _lib.ptr(act_t), _lib.ptr(noise_t), seed,
+                                  counter, None, 0, _lib.ptr(next_obs), _lib.ptr(reset_obs), _lib.ptr(reward),
+                                  _lib.ptr(status), horizon, int(auto_reset), _lib.current_stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    st = status.cpu().numpy().astype(np.uint16).astype(np.int64)
+    out = dict(pos=pos_t.cpu().numpy(), next_obs=next_obs.cpu().numpy(), reward=reward.cpu().numpy(),
+               t=(st & 0x0fff).astype(np.int32), reset_obs=reset_obs.cpu().numpy())
+    for bit, k in ((12, "done"), (13, "constraint"), (14, "success"), (15, "ep_done")):
+        out[k] = ((st >> bit) & 1).astype(np.uint8)
+    fin = (out["ep_done"] != 0) & bool(auto_reset)
+    out["obs"] = np.where(fin[:, None], out["reset_obs"], out["next_obs"])
+    return out
+
+
+@pytest.mark.parametrize("env", ENVS)
+@pytest.mark.parametrize("n", (1, 2, 3, 4, 5, 63, 64, 257, 4096, 100003, 1 << 19, 600001))
+def test_compact_step_matches_oracle_with_philox_noise(env, n):
+    """rrl_nav_step_compact (u16 status words, sparse post-reset observation, finished episodes of a wave re-drawn
+    once per workgroup and pass) against the C oracle: every field bit-exact; reset_obs rows of continuing episodes are
+    untouched or repeat next_obs."""
+    rng = np.random.RandomState(n + 5)
+    pos = np.c_[rng.uniform(-60, 10, n), rng.uniform(-12, 12, n)]
+    act = rng.uniform(-1.5, 1.5, (n, 2)).astype(np.float32)
+    t = rng.randint(0, 100, n).astype(np.int32)
+    for auto in (False, True):
+        ref = co.nav_step(env, pos, act, t, seed=0xDEADBEEF12345, counter=17, auto_reset=auto)
+        got = hip_step_compact(env, pos, act, t, seed=0xDEADBEEF12345, counter=17, auto_reset=auto,
+                               stale_flags=0xF000)            # flag bits of the previous step are ignored on input
+        assert_same(got, ref)
+        fin = (ref["ep_done"] != 0) & auto
+        rest = got["reset_obs"][~fin]                      # untouched, or a copy of next_obs (whole 32-byte groups)
+        assert np.all((rest == -7.0) | (rest == got["next_obs"][~fin]))
+        assert np.any(rest == -7.0) or fin.mean() > 0.2 or n < 8
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_compact_step_every_episode_ending_at_once(env):
+    """All envs reach the horizon on the same step (what a synchronously started sweep does): more finished episodes
+    per wave than its reset list holds -> the per-lane path; and a mixed case around the 64-entry limit."""
+    n = 8192
+    rng = np.random.RandomState(3)
+    pos = np.c_[rng.uniform(-60, -40, n), rng.uniform(-3, 3, n)]
+    act = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    for t in (np.full(n, 99, np.int32), np.where(np.arange(n) % 4 == 0, 99, 5).astype(np.int32),
+              np.where(np.arange(n) % 5 == 0, 99, 5).astype(np.int32)):
+        ref = co.nav_step(env, pos, act, t, seed=11, counter=3, auto_reset=True)
+        assert_same(hip_step_compact(env, pos, act, t, seed=11, counter=3, auto_reset=True), ref)
+        assert_same(hip_step(env, pos, act, t, seed=11, counter=3, auto_reset=True), ref)
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_compact_step_matches_reference_golden_bit_exact(env, golden_dir):
+    """G1 rows (explicit noise) through the compact entry."""
+    g = np.load(os.path.join(golden_dir, "nav_step_golden.npz"))
+    S, A, E = g[env + "_s"], g[env + "_a"], g[env + "_eps"]
+    o = hip_step_compact(env, S, A, np.zeros(len(S), np.int32), noise=E)
+    assert np.array_equal(o["pos"], g[env + "_s2"])
+    assert np.array_equal(o["next_obs"], g[env + "_s2"].astype(np.float32))
+    assert np.array_equal(o["reward"], g[env + "_reward"].astype(np.float32))
+    for k in ("done", "constraint", "success"):
+        assert np.array_equal(o[k], g[env + "_" + k]), k
+
+
+def test_compact_step_rejects_what_the_status_word_cannot_hold():
+    lib = _lib.load()
+    z = torch.zeros(8, 2, dtype=torch.float64, device=DEV)
+    f = torch.zeros(8, 2, device=DEV)
+    st = torch.zeros(8, dtype=torch.int16, device=DEV)
+    args = lambda horizon, pos=z: (0, 8, _lib.ptr(pos), _lib.ptr(f), None, 0, 0, None, 0, _lib.ptr(f), None,
+                                   _lib.ptr(f[:, 0].contiguous()), _lib.ptr(st), horizon, 0, _lib.current_stream())
+    assert lib.rrl_nav_step_compact(*args(4096)) == -3
+    assert lib.rrl_nav_step_compact(*args(4095)) == 0
+    assert lib.rrl_nav_step_compact(*args(100, pos=z.view(-1)[1:9].view(4, 2))) == -1   # 8-byte aligned pos
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("env", ENVS)
 def test_vector_path_with_explicit_noise_and_device_tick(env):
     """The 4-envs-per-thread kernel (n >= 2^19) with caller-supplied noise, and its device-side tick."""
