@@ -10,7 +10,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librrl_oracle.so")
+# RRL_ORACLE_SANITIZE=1: load the ASan + UBSan build instead (oracle/Makefile target `sanitize`; run the tests with
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0, see tests/sanitize_oracle.sh)
+_SANITIZE = os.environ.get("RRL_ORACLE_SANITIZE", "") not in ("", "0")
+_SO = os.path.join(_HERE, "librrl_oracle_san.so" if _SANITIZE else "librrl_oracle.so")
 
 ENV_KIND = {"navigation1": 0, "navigation2": 1, "maze": 2}
 STREAM_STEP, STREAM_RESET, STREAM_OFFLINE, STREAM_SAMPLE, STREAM_SAMPLE_NEG, STREAM_CEM, STREAM_ACTION = range(7)
@@ -20,7 +23,7 @@ def build(force=False):
     src = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     if force or not os.path.exists(_SO) or any(
             os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"] + (["sanitize"] if _SANITIZE else []))
     return _SO
 
 
