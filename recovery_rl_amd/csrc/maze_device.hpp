@@ -110,8 +110,18 @@ RRL_HD void move(double& x, double& y, double ax, double ay) {
             if (touches_plane(px, py)) { first = k; break; }
         }
     }
+    // every sub-step position lies in the box spanned by the start and the end of the move (rounding is monotone in k, and
+    // the start is inside the arena, so clamping keeps it there): a wall whose inflated rectangle misses that box in x or
+    // in y cannot be touched at any sub-step (tested with a slack of 1e-9).  A move is at most 0.025 long, so this settles three or four of the four
+    // walls with comparisons alone -- no divisions, no candidate loop.
+    const double ex = clampd(x + dx, -kLim, kLim), ey = clampd(y + dy, -kLim, kLim);
+    const double bx0 = x < ex ? x : ex, bx1 = x < ex ? ex : x, by0 = y < ey ? y : ey, by1 = y < ey ? ey : y;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        constexpr double kSlack = 1e-9;     // far above any rounding of the predicate, far below the geometry
+        if (wall_x(j) + (kWallHX + kRadius + kSlack) < bx0 || wall_x(j) - (kWallHX + kRadius + kSlack) > bx1 ||
+            wall_y(j) + (kWallHY + kRadius + kSlack) < by0 || wall_y(j) - (kWallHY + kRadius + kSlack) > by1)
+            continue;
         double lox, hix, loy, hiy;
         slab_interval(x, sx, wall_x(j), kWallHX + kRadius, lox, hix);
         slab_interval(y, sy, wall_y(j), kWallHY + kRadius, loy, hiy);

@@ -747,10 +747,14 @@ int rrl_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed, float*
 
 static int nav_step_push_launch(int env_kind, const rrl_step::StepPushArgs& p, int64_t n, void* stream) {
     const dim3 grid(grid_for(n)), block(kBlock);
-    if (env_kind == RRL_ENV_NAV1)
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<0>>), grid, block, 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<1>>), grid, block, 0, (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 65536) {      // at most one wave per SIMD: latency-bound, the reset draw runs beside the step draw
+        if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<0>, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<1>, true>), grid, block, 0, st, p);
+    } else {
+        if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<0>>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<1>>), grid, block, 0, st, p);
+    }
     return check_launch();
 }
 

@@ -90,7 +90,11 @@ __device__ __forceinline__ double row16_sum_f64(double v) {
     return v;
 }
 
-template <class ENV>
+// SPECULATE (latency regime, one pass per thread and one wave per SIMD): the reset draw does not depend on the step, so it
+// is evaluated next to the step's own draw -- two independent Philox + Box-Muller chains interleaved by the scheduler --
+// instead of after it for the lanes whose episode ended (at the bench's termination rate that is every wave: a second
+// ~1 us dependent chain).  Same function, same arguments, same bits; in the bandwidth regime it would be +70 % VALU work.
+template <class ENV, bool SPECULATE = false>
 __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArgs p) {
     constexpr int kBlock = rrl_host::kBlock;
     const StepArgs& a = p.step;
@@ -156,6 +160,10 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             const float2 prev = a.obs[i];
             int32_t ti = a.t[i];
             ti += 1;
+            double rx = 0.0, ry = 0.0;
+            if constexpr (SPECULATE) {
+                if (a.auto_reset) ENV::reset(a, i, ctr, rx, ry);
+            }
             const Outcome out = ENV::step(a, i, ctr, pp, act, ti);
             double nx = out.x, ny = out.y;
             cons = out.constraint;
@@ -184,7 +192,12 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             if (epd) retsum += double(er);
             p.ep_reward[i] = epd ? 0.0f : er;
             if (a.auto_reset && epd) {
-                ENV::reset(a, i, ctr, nx, ny);
+                if constexpr (SPECULATE) {
+                    nx = rx;
+                    ny = ry;
+                } else {
+                    ENV::reset(a, i, ctr, nx, ny);
+                }
                 ti = 0;
             }
             a.pos[i] = make_double2(nx, ny);
