@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md);
 NAV_STEP_ALGO_BYTES = 39         # algorithmic bytes per env-step (f32 contract)
 STEP_PUSH_ALGO_BYTES = 39 + 32 + 32   # + one 32-byte replay row into each of the two buffers (section 8d "replay")
 F32_MFMA_PEAK_TF = 157.3         # MI355X_MICROARCH.md; 155.4 measured on this pool (profiles/mfma_peak.hip)
+F16_MFMA_PEAK_TF = 2500.0                       # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PLAN_FLOPS_PER_ROW_STEP = 267264 + 163200      # twin Q_risk (4-256-256-1 x2) + one ensemble member (4-200-200-200-4)
 
 CONFIG_ARGV = {
@@ -293,9 +294,9 @@ def iteration_flops(num_envs, updates_per_step=1):
     return updates_per_step * (0.685e9 + 0.62e9) + num_envs * 2.0 * (67072 + 133632 + 66560)
 
 
-def time_planner_kernel(device, n_plans=256, reps=3):
-    """rrl_plan_cost (MPC._compile_cost of config 4: 400 candidates x 20 particles x 5 steps per planning
-    env): seconds per launch from HIP events on the launch stream."""
+def time_planner_kernel(device, n_plans=256, reps=3, precision="f32"):
+    """rrl_plan_cost / rrl_plan_cost_f16x3 (MPC._compile_cost of config 4: 400 candidates x 20 particles x 5 steps per
+    planning env): seconds per launch from HIP events on the launch stream."""
     import torch
     import arg_utils
     from recovery_rl_amd import _lib
@@ -304,7 +305,7 @@ def time_planner_kernel(device, n_plans=256, reps=3):
     from recovery_rl_amd.env import make_vec_env
     from recovery_rl_amd.sac import SAC
     env = make_vec_env("navigation2", 4, device=device, seed=1)
-    mpc = MPC(create_config("navigation2", "MPC", {}, [], "/tmp", env=env).ctrl_cfg, seed=1)
+    mpc = MPC(create_config("navigation2", "MPC", {}, [], "/tmp", env=env).ctrl_cfg, seed=1, plan_precision=precision)
     args = arg_utils.get_args(["--env-name", "navigation2", "--cuda", "--use_recovery", "--gamma_safe", "0.65",
                                "--eps_safe", "0.2"])
     agent = SAC(env.observation_space, env.action_space, args, "/tmp")
@@ -585,6 +586,22 @@ def main():
                 "row_steps_per_s": row_steps / t_p,
                 "note": "f32-in/f32-acc MFMA (exact f32); algorithmic %d FLOP per particle-step"
                         % PLAN_FLOPS_PER_ROW_STEP}
+            with contextlib.redirect_stdout(sys.stderr):
+                t_h, row_steps = time_planner_kernel(device, precision="f16x3")
+            tf_h = row_steps * PLAN_FLOPS_PER_ROW_STEP / t_h / 1e12
+            # three f16 products per algorithmic product: the matrix pipe executes 3x the algorithmic flops of the hidden
+            # layers, priced against the dense f16 MFMA peak
+            hidden = 2 * 2 * 256 * 256 + 2 * 2 * 200 * 200
+            extra["roofline_planner_f16x3"] = {
+                "kernel": "plan_cost_kernel<f16x3> (rrl_plan_cost_f16x3, opt-in --plan_precision f16x3): hidden layers as "
+                          "three v_mfma_f32_16x16x16_f16 products of hi/lo splits",
+                "bound": "mfma", "achieved": tf_h, "unit": "TFLOP/s (algorithmic f32-equivalent)",
+                "vs_f32_mfma_peak": tf_h / F32_MFMA_PEAK_TF, "launch_ms": t_h * 1e3, "row_steps_per_s": row_steps / t_h,
+                "speedup_vs_f32_kernel": t_p / t_h,
+                "executed_f16_TFLOPs": row_steps * (3 * hidden) / t_h / 1e12, "peak": F16_MFMA_PEAK_TF,
+                "frac": row_steps * (3 * hidden) / t_h / 1e12 / F16_MFMA_PEAK_TF,
+                "note": "costs agree with the f32 kernel to < 2e-5 (tests/test_plan_gpu.py); the v_mfma_f32_16x16x16_f16 "
+                        "shape sustains 1233 TF on this pool (profiles/mfma_f16_rate.hip), the K=32 shape 2460"}
         if not a.no_cpu_baseline and world == 1:
             extra["cpu_baseline"] = cpu_baseline()
 

@@ -582,6 +582,18 @@ int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, lo
                   const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
                   uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream);
 
+/* The same evaluation with the three hidden-layer products (Q_risk 256 x 256, ensemble 200 x 200 twice) on the f16 matrix
+ * pipe: every f32 activation and weight is split as hi + lo (two f16 carrying 22 bits of the value) and the product is
+ * hi*hi + hi*lo + lo*hi with f32 accumulation -- one v_mfma_f32_16x16x16_f16 (16 cycles) three times instead of four
+ * v_mfma_f32_16x16x4_f32 (32 cycles each) per 16-wide k chunk.  Input layers, biases, activations, epilogues and the
+ * rollout state stay f32.  Same interface; the packed buffer has the same size but is NOT interchangeable (pack with
+ * rrl_plan_pack_f16x3).  Opt-in: results agree with rrl_plan_cost to ~1e-6 relative (tests: the same 2e-4 bound as the
+ * f32 kernel against the PyTorch path); values beyond +-65504 in a hidden layer saturate. */
+int rrl_plan_pack_f16x3(const rrl_plan_weights_t* w, float* packed, void* stream);
+int rrl_plan_cost_f16x3(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
+                        const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
+                        uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Ensemble fitting.  One optimiser step of MPC.train (recovery_rl/MPC.py:266-292) for the PETS ensemble
  * (PtModel, config/navigation1.py:23-96): gather of the bootstrap rows idx[e, 0..batch), forward, loss

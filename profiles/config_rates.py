@@ -1,7 +1,7 @@
 """Rates of SURVEY 8d configs 3 (Maze, MF recovery) and 4 (Navigation2, model-based recovery) at 4096 envs on
 one MI355X; config 2 is bench.py's line.  Prints one JSON object per config.
 
-    python profiles/config_rates.py [3|4] [num_envs] [Q_risk pre-training steps = 10000, the reference's default]
+    python profiles/config_rates.py [3|4] [num_envs] [Q_risk pre-training steps = 10000, the reference's default] [f16x3]
 
 Config 4 is reported twice: with the safety critic as pre-trained on the offline data (the regime the reference runs
 in: only the envs whose Q_risk exceeds eps_safe plan) and -- `untrained` -- with every env planning (worst case).
@@ -25,9 +25,10 @@ ARGV = {
 }
 
 
-def run(config, n, pretrain=10000):
+def run(config, n, pretrain=10000, precision=""):
     cfg = arg_utils.get_args(ARGV[config] + ["--cuda", "--num_envs", str(n), "--seed", "1", "--logdir", "/tmp/rrl_rates",
-                                             "--critic_safe_pretraining_steps", str(pretrain)])
+                                             "--critic_safe_pretraining_steps", str(pretrain)] +
+                             (["--plan_precision", precision] if precision else []))
     exp = Experiment(cfg)
     t0 = time.time()
     exp.pretrain_critic_recovery()
@@ -38,6 +39,8 @@ def run(config, n, pretrain=10000):
     while not (len(exp.memory) > cfg.batch_size and loop.total_numsteps >= cfg.start_steps):
         loop.vector_step(do_update=False, random_actions=True)
     out = {"config": config, "num_envs": n, "qrisk_pretraining_steps": pretrain, "pretrain_s": round(pre_s, 2)}
+    if config == 4:
+        out["plan_precision"] = "f16x3" if exp.recovery_policy.fused.f16x3 else "f32"
     if config == 3:
         loop.capture(online_qrisk=True)
         for _ in range(20):
@@ -76,5 +79,6 @@ if __name__ == "__main__":
     which = [int(sys.argv[1])] if len(sys.argv) > 1 else [3, 4]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     pre = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
+    prec = sys.argv[4] if len(sys.argv) > 4 else ""
     for c in which:
-        run(c, n, pre)
+        run(c, n, pre, prec)

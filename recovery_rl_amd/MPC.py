@@ -69,7 +69,7 @@ class MPC:
     optimizers = {"CEM": CEMOptimizer}
     MAX_ROWS = 1 << 21       # rows per rollout chunk (activations: rows x 200 x 4 B x few)
 
-    def __init__(self, params, mb_dynamics="model", seed=0):
+    def __init__(self, params, mb_dynamics="model", seed=0, plan_precision=None):
         env = params.env
         self.env = env
         self.device = env.device
@@ -119,6 +119,9 @@ class MPC:
         self._trainer = None
         self.fused = None                  # FusedPlanner (rrl_plan_cost) when the shapes allow it
         self.use_fused_planner = True
+        if plan_precision not in (None, "f32", "f16x3"):
+            raise ValueError("--plan_precision must be 'f32' or 'f16x3'")
+        self.plan_f16x3 = None if plan_precision is None else plan_precision == "f16x3"   # None: RRL_PLAN_F16X3
         self._lb = torch.as_tensor(self.ac_lb, dtype=torch.float32, device=self.device)
         self._ub = torch.as_tensor(self.ac_ub, dtype=torch.float32, device=self.device)
 
@@ -229,7 +232,7 @@ class MPC:
         if self.use_fused_planner:
             from .planner import FusedPlanner
             if FusedPlanner.supported(self):
-                self.fused = FusedPlanner(self)
+                self.fused = FusedPlanner(self, f16x3=self.plan_f16x3)
 
     # -- acting (MPC.py:322-347) ---------------------------------------------------------------
     @torch.no_grad()

@@ -23,6 +23,9 @@ using namespace rrl_plan;
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // waves per SIMD the register allocator targets: 2 = one workgroup per CU (<= 256 VGPRs), 4 = two (<= 128)
 // timing ablations for profiles/ (wrong results!): 1 = no weight-fragment loads, 2 = no LDS fragment reads,
@@ -38,11 +41,29 @@ constexpr int kRows = 64;                 // rows per workgroup
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kActStride = kHQ + 4;       // +4 floats: row r starts at bank 4r, ds_read_b128 conflict-free
-constexpr int kLdsFloats = kRows * kActStride + 3 * kRows * 4 + 2 * kWaves * kRows + 4 * kRows * 4;
-constexpr int kLdsBytes = kLdsFloats * 4;  // 77.5 KB: two workgroups per CU
+// F16X3 mode keeps the activations as two f16 planes (hi, lo) of [64][kHalfStride] instead: 132 words per row, so row r
+// starts at bank 4r again and the 8-byte fragment reads of a half-wave (16 rows x 2 k-groups) hit 64 different banks
+constexpr int kHalfStride = kHQ + 8;
+constexpr int kActFloats = kRows * kHalfStride;       // 2 planes x 64 x 264 x 2 B = 66 KB (f32 layout: 65 KB)
+static_assert(kActFloats >= kRows * kActStride, "the f32 activation tile must fit the same region");
+constexpr int kLdsFloats = kActFloats + 3 * kRows * 4 + 2 * kWaves * kRows + 4 * kRows * 4;
+constexpr int kLdsBytes = kLdsFloats * 4;  // 78.5 KB: two workgroups per CU
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// F16X3: one v_mfma_f32_16x16x16_f16 covers the 16 k of a chunk (lane l: k = 4 (l / 16) + 0..3 on both operands -- the
+// fragment order of the four 16x16x4 steps it replaces) in 16 cycles instead of 4 x 32
+__device__ __forceinline__ f32x4 mfma16(f16x4 a, f16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+// v = hi + lo with hi = f16(v) and lo = f16(v - hi): v - hi is exact in f32 (13 significant bits at most), so hi + lo
+// carries 22 bits of v; three products hi*hi + hi*lo + lo*hi then carry ~2^-21 of the f32 product (the lo*lo term, 2^-22
+// of it, is dropped).  Values beyond the f16 range saturate (NaN stays NaN and becomes the reference's 1e6 cost).
+__device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
+    v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
 }
 
 // Identity the optimiser cannot see through: address arithmetic derived from opaque(lane) is redone per phase
@@ -80,9 +101,37 @@ __device__ __forceinline__ void load_b(f32x4 (&b)[NC], const float* __restrict__
     }
 }
 
-template <int NCV, int XR, int MR, int NC>
+template <bool F16X3, int NCV, int XR, int MR, int NC>
 __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
                                           const f32x4 (&b)[NC], int j, int lane) {
+    if constexpr (F16X3) {
+        // A: 4 hi + 4 lo f16 of this lane's row and k group; B: the packed float4 slot holds {hi[4], lo[4]}
+        const _Float16* ah = reinterpret_cast<const _Float16*>(act);
+        const _Float16* al = ah + kRows * kHalfStride;
+        f16x4 ahi[MR], alo[MR];
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const int off = (rt[r] * 16 + (lane & 15)) * kHalfStride + 16 * j + (lane >> 4) * 4;
+            ahi[r] = *reinterpret_cast<const f16x4*>(ah + off);
+            alo[r] = *reinterpret_cast<const f16x4*>(al + off);
+        }
+        f16x4 bhi[NC], blo[NC];
+#pragma unroll
+        for (int c = 0; c < NCV; ++c) {
+            bhi[c] = __builtin_bit_cast(f16x4, f32x2{b[c][0], b[c][1]});
+            blo[c] = __builtin_bit_cast(f16x4, f32x2{b[c][2], b[c][3]});
+        }
+        // product by product over all tiles: consecutive MFMAs never share an accumulator
+#pragma unroll
+        for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+            for (int r = 0; r < MR; ++r)
+#pragma unroll
+                for (int c = 0; c < NCV; ++c)
+                    if (tile_on<XR>(r, c))
+                        acc[r][c] = mfma16(prod == 2 ? alo[r] : ahi[r], prod == 1 ? blo[c] : bhi[c], acc[r][c]);
+        return;
+    }
     f32x4 a[MR];
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -102,9 +151,62 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MR][NC], const float* act
                 if (tile_on<XR>(r, c)) acc[r][c] = mfma(a[r][t], b[c][t], acc[r][c]);
 }
 
+// F16X3 with the K = 32 shape (v_mfma_f32_16x16x32_f16: lane l holds k = 8 (l / 16) + 0..7 of a 32-wide block on both
+// operands; the same 16 cycles as the K = 16 shape for twice the k).  A: one 16-byte read per plane; B: the two float4
+// slots of block jp hold {hi[8]} and {lo[8]} of this lane's row (pack_layer_f16x3_k32_kernel).
+template <int NCV, int XR, int MR, int NC>
+__device__ __forceinline__ void mma_pair(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
+                                         const f32x4 (&bh)[NC], const f32x4 (&bl)[NC], int jp, int lane) {
+    const _Float16* ah = reinterpret_cast<const _Float16*>(act);
+    const _Float16* al = ah + kRows * kHalfStride;
+    f16x8 ahi[MR], alo[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const int off = (rt[r] * 16 + (lane & 15)) * kHalfStride + 32 * jp + (lane >> 4) * 8;
+        ahi[r] = *reinterpret_cast<const f16x8*>(ah + off);
+        alo[r] = *reinterpret_cast<const f16x8*>(al + off);
+    }
+#pragma unroll
+    for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+        for (int r = 0; r < MR; ++r)
+#pragma unroll
+            for (int c = 0; c < NCV; ++c)
+                if (tile_on<XR>(r, c))
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                        prod == 2 ? alo[r] : ahi[r], __builtin_bit_cast(f16x8, prod == 1 ? bl[c] : bh[c]), acc[r][c], 0, 0, 0);
+}
+
+// 32-wide blocks (slots 2 jp = hi, 2 jp + 1 = lo) with the fragments of the NEXT block in flight (four float4 sets live:
+// affordable for two column tiles per wave, i.e. the Q_risk layers; J = number of 16-wide chunks, a multiple of 4).
+template <int NCV, int J, int XR = -1, int MR, int NC>
+__device__ __forceinline__ void layer_mma_pairs(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
+                                                const float* __restrict__ wpk, const int (&ct)[NC], int lane) {
+    static_assert(J % 4 == 0 && J >= 4, "pairs are consumed two at a time");
+    f32x4 p0[NC], p1[NC], q0[NC], q1[NC];
+    load_b<NCV>(p0, wpk, ct, J, 0, lane);
+    load_b<NCV>(p1, wpk, ct, J, 1, lane);
+    int j = 0;
+#pragma unroll 1
+    for (; j + 4 < J; j += 4) {
+        load_b<NCV>(q0, wpk, ct, J, j + 2, lane);
+        load_b<NCV>(q1, wpk, ct, J, j + 3, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_pair<NCV, XR>(acc, act, rt, p0, p1, j >> 1, lane);
+        load_b<NCV>(p0, wpk, ct, J, j + 4, lane);
+        load_b<NCV>(p1, wpk, ct, J, j + 5, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_pair<NCV, XR>(acc, act, rt, q0, q1, (j >> 1) + 1, lane);
+    }
+    load_b<NCV>(q0, wpk, ct, J, J - 2, lane);
+    load_b<NCV>(q1, wpk, ct, J, J - 1, lane);
+    mma_pair<NCV, XR>(acc, act, rt, p0, p1, J / 2 - 2, lane);
+    mma_pair<NCV, XR>(acc, act, rt, q0, q1, J / 2 - 1, lane);
+}
+
 // The weight fragments of chunk j + 1 are requested before the 4 MR NC MFMAs of chunk j (register double
 // buffer): their L2 latency hides behind ~1000 cycles of matrix work.  LDS fragments are read per chunk.
-template <int NCV, int J, int XR = -1, int MR, int NC>
+template <bool F16X3, int NCV, int J, int XR = -1, int MR, int NC>
 __device__ __forceinline__ void layer_mma(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
                                           const float* __restrict__ wpk, const int (&ct)[NC], int lane) {
     f32x4 b0[NC], b1[NC];
@@ -116,17 +218,17 @@ __device__ __forceinline__ void layer_mma(f32x4 (&acc)[MR][NC], const float* act
     for (; j + 2 < J; j += 2) {
         load_b<NCV>(b1, wpk, ct, J, j + 1, lane);
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs it hides behind
-        mma_chunk<NCV, XR>(acc, act, rt, b0, j, lane);
+        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b0, j, lane);
         load_b<NCV>(b0, wpk, ct, J, j + 2, lane);
         __builtin_amdgcn_sched_barrier(0);
-        mma_chunk<NCV, XR>(acc, act, rt, b1, j + 1, lane);
+        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b1, j + 1, lane);
     }
     if constexpr (J % 2 == 0) {
         load_b<NCV>(b1, wpk, ct, J, J - 1, lane);
-        mma_chunk<NCV, XR>(acc, act, rt, b0, J - 2, lane);
-        mma_chunk<NCV, XR>(acc, act, rt, b1, J - 1, lane);
+        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b0, J - 2, lane);
+        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b1, J - 1, lane);
     } else {
-        mma_chunk<NCV, XR>(acc, act, rt, b0, J - 1, lane);
+        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b0, J - 1, lane);
     }
 }
 
@@ -152,12 +254,14 @@ __device__ __forceinline__ void zero(f32x4 (&acc)[MR][NC]) {
 }
 
 // act[row][col] = f(acc + bias[col]); C layout: row = 16 rt + 4 (lane / 16) + i, col = 16 ct + lane % 16
-template <bool SWISH, int NCV, int XR = -1, int MR, int NC>
+template <bool F16X3, bool SWISH, int NCV, int XR = -1, int MR, int NC>
 __device__ __forceinline__ void store_act(const f32x4 (&acc)[MR][NC], float* act, const int (&rt)[MR],
                                           const float (&bias)[NC], const int (&ct)[NC], int lane) {
 #if RRL_PLAN_ABLATE & 4
     if (bias[0] != 12345.f) return;
 #endif
+    _Float16* ah = reinterpret_cast<_Float16*>(act);
+    _Float16* al = ah + kRows * kHalfStride;
 #pragma unroll
     for (int c = 0; c < NCV; ++c) {
         const int col = ct[c] * 16 + (lane & 15);
@@ -168,7 +272,16 @@ __device__ __forceinline__ void store_act(const f32x4 (&acc)[MR][NC], float* act
             for (int i = 0; i < 4; ++i) {
                 if (!tile_on<XR>(r, c)) continue;
                 const float v = acc[r][c][i] + bv;
-                act[(rt[r] * 16 + 4 * (lane >> 4) + i) * kActStride + col] = SWISH ? swishf(v) : reluf(v);
+                const float f = SWISH ? swishf(v) : reluf(v);
+                const int row = rt[r] * 16 + 4 * (lane >> 4) + i;
+                if constexpr (F16X3) {
+                    _Float16 hi, lo;
+                    split16(f, hi, lo);
+                    ah[row * kHalfStride + col] = hi;
+                    al[row * kHalfStride + col] = lo;
+                } else {
+                    act[row * kActStride + col] = f;
+                }
             }
     }
 }
@@ -181,14 +294,15 @@ __device__ __forceinline__ float reduce16(float v) {   // sum over the 16 lanes 
     return v;
 }
 
+template <bool F16X3>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(RRL_PLAN_WAVES_PER_EU, RRL_PLAN_WAVES_PER_EU)))
 void plan_cost_kernel(
     const float* __restrict__ pk, int n_nets, int npart, long long n_groups, int pop, int plan_hor,
     const float* __restrict__ cur_obs, const float* __restrict__ ac_seqs, const float* __restrict__ noise,
     uint64_t seed, uint64_t counter, const uint64_t* __restrict__ counter_dev, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* act = lds;                                               // [64][260] activations
-    float* xs = act + kRows * kActStride;                           // [64][4] raw (obs, ac)
+    float* act = lds;                                               // [64][260] f32 activations, or two f16 planes
+    float* xs = act + kActFloats;                                   // [64][4] raw (obs, ac)
     float* xn = xs + kRows * 4;                                     // [64][4] standardised ensemble input
     float(*qpart)[kWaves][kRows] = reinterpret_cast<float(*)[kWaves][kRows]>(xn + kRows * 4);
     float(*epart)[kRows][4] = reinterpret_cast<float(*)[kRows][4]>(xn + kRows * 4 + 2 * kWaves * kRows);
@@ -270,10 +384,11 @@ void plan_cost_kernel(
                     f32x4 acc[4][2];
                     zero(acc);
                     input_mma<2>(acc, xs, q_rt, w + kQW1, q_ct, opaque(lane));
-                    store_act<false, 2>(acc, act, q_rt, b1v, q_ct, opaque(lane));
+                    store_act<F16X3, false, 2>(acc, act, q_rt, b1v, q_ct, opaque(lane));
                     __syncthreads();
                     zero(acc);
-                    layer_mma<2, kQTiles>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
+                    if constexpr (F16X3) layer_mma_pairs<2, kQTiles>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
+                    else layer_mma<F16X3, 2, kQTiles>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
                     // last layer folded in: q[row] = sum_col relu(h2 + b2) w3[col]
                     float s[4][4];
 #pragma unroll
@@ -320,29 +435,29 @@ void plan_cost_kernel(
                 f32x4 acc[2][4];
                 zero(acc);
                 E_STAGE((input_mma<4, 0>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
-                         store_act<true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+                         store_act<F16X3, true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
                         (input_mma<4, 1>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
-                         store_act<true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+                         store_act<F16X3, true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
                         (input_mma<3>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
-                         store_act<true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
+                         store_act<F16X3, true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
 #pragma unroll
                 for (int c = 0; c < 4; ++c) eb[c] = epk[kEB1 + ecol(c)];
                 __syncthreads();
                 zero(acc);
-                E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
-                        (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
-                        (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
+                E_STAGE((layer_mma<F16X3, 4, kETiles, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                        (layer_mma<F16X3, 4, kETiles, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                        (layer_mma<F16X3, 3, kETiles>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
                 __syncthreads();       // every wave has finished reading layer-1 input
-                E_STAGE((store_act<true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
-                        (store_act<true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
-                        (store_act<true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
+                E_STAGE((store_act<F16X3, true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+                        (store_act<F16X3, true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+                        (store_act<F16X3, true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
 #pragma unroll
                 for (int c = 0; c < 4; ++c) eb[c] = epk[kEB2 + ecol(c)];
                 __syncthreads();
                 zero(acc);
-                E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
-                        (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
-                        (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
+                E_STAGE((layer_mma<F16X3, 4, kETiles, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                        (layer_mma<F16X3, 4, kETiles, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                        (layer_mma<F16X3, 3, kETiles>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
 #undef E_STAGE
                 // last layer (200 -> 4) folded in: out[row][o] = sum_col swish(h3 + b2) W3[col][o]
                 f32x4 ew3[4];
@@ -466,6 +581,62 @@ __global__ __launch_bounds__(kBlock) void pack_layer_kernel(const float* __restr
     }
 }
 
+// the same fragment stream for the F16X3 kernel: the float4 slot of (ct, j, lane) holds the four weights of that lane as
+// {hi[0..3], lo[0..3]} f16 (hi = f16(w), lo = f16(w - hi))
+__global__ __launch_bounds__(kBlock) void pack_layer_f16x3_kernel(const float* __restrict__ src, long long sn,
+                                                                  long long sk, int N, int K, int tiles, int J,
+                                                                  float* __restrict__ dst) {
+    const long long total = (long long)tiles * J * 64;
+    for (long long f = blockIdx.x * (long long)blockDim.x + threadIdx.x; f < total;
+         f += (long long)gridDim.x * blockDim.x) {
+        const int lane = int(f & 63);
+        const long long frag = f >> 6;
+        const int j = int(frag % J), ct = int(frag / J);
+        const int n = 16 * ct + (lane & 15);
+        _Float16 hi[4], lo[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = 16 * j + 4 * (lane >> 4) + t;
+            float w = (n < N && k < K) ? src[n * sn + k * sk] : 0.f;
+            w = w > 65504.f ? 65504.f : (w < -65504.f ? -65504.f : w);
+            hi[t] = (_Float16)w;
+            lo[t] = (_Float16)(w - (float)hi[t]);
+        }
+        _Float16* out = reinterpret_cast<_Float16*>(dst + f * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            out[t] = hi[t];
+            out[4 + t] = lo[t];
+        }
+    }
+}
+
+// F16X3 with the K = 32 MFMA shape (the Q_risk layers): slot (ct, 2 jp, lane) = hi[8], slot (ct, 2 jp + 1, lane) = lo[8]
+// of W[n = 16 ct + lane % 16][k = 32 jp + 8 (lane / 16) + 0..7].  J (16-wide chunks) must be even.
+__global__ __launch_bounds__(kBlock) void pack_layer_f16x3_k32_kernel(const float* __restrict__ src, long long sn,
+                                                                      long long sk, int N, int K, int tiles, int J,
+                                                                      float* __restrict__ dst) {
+    const long long total = (long long)tiles * (J / 2) * 64;
+    for (long long f = blockIdx.x * (long long)blockDim.x + threadIdx.x; f < total;
+         f += (long long)gridDim.x * blockDim.x) {
+        const int lane = int(f & 63);
+        const long long blk = f >> 6;
+        const int jp = int(blk % (J / 2)), ct = int(blk / (J / 2));
+        const int n = 16 * ct + (lane & 15);
+        _Float16* hi = reinterpret_cast<_Float16*>(dst + (((long long)ct * J + 2 * jp) * 64 + lane) * 4);
+        _Float16* lo = reinterpret_cast<_Float16*>(dst + (((long long)ct * J + 2 * jp + 1) * 64 + lane) * 4);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int k = 32 * jp + 8 * (lane >> 4) + t;
+            float w = (n < N && k < K) ? src[n * sn + k * sk] : 0.f;
+            w = w > 65504.f ? 65504.f : (w < -65504.f ? -65504.f : w);
+            const _Float16 h = (_Float16)w;
+            hi[t] = h;
+            lo[t] = (_Float16)(w - (float)h);
+        }
+    }
+}
+
 // first layers (K = 4): out[ct * 64 + lane] = W[n = 16 ct + lane % 16][k = lane / 16]
 __global__ __launch_bounds__(kBlock) void pack_input_kernel(const float* __restrict__ src, long long sn, long long sk,
                                                             int N, int tiles, float* __restrict__ dst) {
@@ -505,17 +676,24 @@ int rrl_plan_supported(int hq, int he, int n_nets, int npart, int d_obs, int d_a
            d_act == 2;
 }
 
-int rrl_plan_pack(const rrl_plan_weights_t* w, float* packed, void* stream_) {
+static int plan_pack_impl(const rrl_plan_weights_t* w, float* packed, void* stream_, bool f16x3) {
     if (!w || !packed || !rrl_plan_supported(w->hq, w->he, w->n_nets, 4 * w->n_nets, 2, 2)) return RRL_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     const dim3 b(kBlock);
+    const auto pack_layer = [&](const float* src, long long sn, long long sk, int N, int K, int tiles, int J, float* dst) {
+        if (f16x3) hipLaunchKernelGGL(pack_layer_f16x3_kernel, dim3(64), b, 0, st, src, sn, sk, N, K, tiles, J, dst);
+        else hipLaunchKernelGGL(pack_layer_kernel, dim3(64), b, 0, st, src, sn, sk, N, K, tiles, J, dst);
+    };
     for (int h = 0; h < 2; ++h) {
         float* d = packed + q_off(h);
         hipLaunchKernelGGL(pack_input_kernel, dim3(4), b, 0, st, w->q_w1 + (size_t)h * kHQ * 4, 4LL, 1LL, kHQ,
                            kQTiles, d + kQW1);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_b1 + h * kHQ, 1LL, kHQ, kHQ, d + kQB1);
-        hipLaunchKernelGGL(pack_layer_kernel, dim3(64), b, 0, st, w->q_w2 + (size_t)h * kHQ * kHQ, (long long)kHQ,
-                           1LL, kHQ, kHQ, kQTiles, kQTiles, d + kQW2);
+        if (f16x3)
+            hipLaunchKernelGGL(pack_layer_f16x3_k32_kernel, dim3(64), b, 0, st, w->q_w2 + (size_t)h * kHQ * kHQ,
+                               (long long)kHQ, 1LL, kHQ, kHQ, kQTiles, kQTiles, d + kQW2);
+        else
+            pack_layer(w->q_w2 + (size_t)h * kHQ * kHQ, (long long)kHQ, 1LL, kHQ, kHQ, kQTiles, kQTiles, d + kQW2);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_b2 + h * kHQ, 1LL, kHQ, kHQ, d + kQB2);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_w3 + h * kHQ, 1LL, kHQ, kHQ, d + kQW3);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_b3 + h, 1LL, 1, 4, d + kQB3);
@@ -526,11 +704,9 @@ int rrl_plan_pack(const rrl_plan_weights_t* w, float* packed, void* stream_) {
         hipLaunchKernelGGL(pack_input_kernel, dim3(4), b, 0, st, w->e_w0 + (size_t)e * 4 * kHE, 1LL, (long long)kHE,
                            kHE, kETiles, d + kEW0);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b0 + e * kHE, 1LL, kHE, kHEPad, d + kEB0);
-        hipLaunchKernelGGL(pack_layer_kernel, dim3(64), b, 0, st, w->e_w1 + (size_t)e * kHE * kHE, 1LL,
-                           (long long)kHE, kHE, kHE, kETiles, kETiles, d + kEW1);
+        pack_layer(w->e_w1 + (size_t)e * kHE * kHE, 1LL, (long long)kHE, kHE, kHE, kETiles, kETiles, d + kEW1);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b1 + e * kHE, 1LL, kHE, kHEPad, d + kEB1);
-        hipLaunchKernelGGL(pack_layer_kernel, dim3(64), b, 0, st, w->e_w2 + (size_t)e * kHE * kHE, 1LL,
-                           (long long)kHE, kHE, kHE, kETiles, kETiles, d + kEW2);
+        pack_layer(w->e_w2 + (size_t)e * kHE * kHE, 1LL, (long long)kHE, kHE, kHE, kETiles, kETiles, d + kEW2);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b2 + e * kHE, 1LL, kHE, kHEPad, d + kEB2);
         hipLaunchKernelGGL(pack_head_kernel, dim3(4), b, 0, st, w->e_w3 + (size_t)e * kHE * 4, kHE, d + kEW3);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b3 + e * 4, 1LL, 4, 4, d + kEB3);
@@ -543,9 +719,18 @@ int rrl_plan_pack(const rrl_plan_weights_t* w, float* packed, void* stream_) {
     return check_launch();
 }
 
-int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
-                  const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
-                  uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream_) {
+int rrl_plan_pack(const rrl_plan_weights_t* w, float* packed, void* stream) {
+    return plan_pack_impl(w, packed, stream, false);
+}
+
+int rrl_plan_pack_f16x3(const rrl_plan_weights_t* w, float* packed, void* stream) {
+    return plan_pack_impl(w, packed, stream, true);
+}
+
+static int plan_cost_impl(bool f16x3, const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop,
+                          int plan_hor, const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed,
+                          uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs,
+                          void* stream_) {
     if (!packed || !cur_obs || !ac_seqs || !partial || !costs || M <= 0 || pop <= 0 || plan_hor <= 0 ||
         plan_hor > 16 || !rrl_plan_supported(hq, he, n_nets, npart, 2, 2))
         return RRL_EINVAL;
@@ -556,18 +741,38 @@ int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, lo
     hipStream_t st = (hipStream_t)stream_;
     static bool lds_set = false;
     if (!lds_set) {       // > 64 KB of LDS has to be granted explicitly
-        if (hipFuncSetAttribute((const void*)plan_cost_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)plan_cost_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLdsBytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)plan_cost_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kLdsBytes) != hipSuccess) {
             last_hip_error = int(hipGetLastError());
             return RRL_ELAUNCH;
         }
         lds_set = true;
     }
-    hipLaunchKernelGGL(plan_cost_kernel, dim3((unsigned)tiles), dim3(kThreads), kLdsBytes, st, packed, n_nets, npart,
-                       n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial);
+    if (f16x3)
+        hipLaunchKernelGGL(plan_cost_kernel<true>, dim3((unsigned)tiles), dim3(kThreads), kLdsBytes, st, packed, n_nets,
+                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial);
+    else
+        hipLaunchKernelGGL(plan_cost_kernel<false>, dim3((unsigned)tiles), dim3(kThreads), kLdsBytes, st, packed, n_nets,
+                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial);
     hipLaunchKernelGGL(plan_finish_kernel, dim3(grid_for(n_groups)), dim3(kBlock), 0, st, n_groups, n_nets, npart,
                        partial, costs, counter_dev, counter_inc);
     return check_launch();
+}
+
+int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
+                  const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
+                  uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream) {
+    return plan_cost_impl(false, packed, hq, he, n_nets, npart, M, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter,
+                          counter_dev, counter_inc, partial, costs, stream);
+}
+
+int rrl_plan_cost_f16x3(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
+                        const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
+                        uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream) {
+    return plan_cost_impl(true, packed, hq, he, n_nets, npart, M, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter,
+                          counter_dev, counter_inc, partial, costs, stream);
 }
 
 }  // extern "C"

@@ -2,6 +2,7 @@
 `MPC._compile_cost` (recovery_rl/MPC.py:374-416).  The PyTorch path in MPC.py stays as the general
 path (other widths) and as the cross-check (tests/test_plan_gpu.py)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -11,9 +12,12 @@ from . import _lib
 class FusedPlanner:
     """Packs the live Q_risk and ensemble weights into MFMA fragment order and evaluates CEM candidates."""
 
-    def __init__(self, mpc):
+    def __init__(self, mpc, f16x3=None):
+        """f16x3: evaluate the hidden layers as three f16 MFMA products of hi/lo splits (rrl_plan_cost_f16x3) instead of
+        f32 MFMA; default from RRL_PLAN_F16X3 (off)."""
         self.mpc = mpc
         self.lib = _lib.load()
+        self.f16x3 = (os.environ.get("RRL_PLAN_F16X3", "") not in ("", "0")) if f16x3 is None else bool(f16x3)
         self.device = mpc.device
         model = mpc.model
         self.hq = int(mpc.value_func.safety_critic.linear1.weight.shape[0])
@@ -48,8 +52,8 @@ class FusedPlanner:
                model.lin3_b, model.inputs_mu, model.inputs_sigma, model.max_logvar, model.min_logvar]
         ens = [t.detach().to(torch.float32).contiguous() for t in ens]
         w = _lib.rrl_plan_weights_t(self.hq, self.he, self.n_nets, *[t.data_ptr() for t in keep + ens])
-        _lib.check(self.lib.rrl_plan_pack(C.byref(w), _lib.ptr(self.packed), _lib.current_stream()),
-                   "rrl_plan_pack")
+        pack = self.lib.rrl_plan_pack_f16x3 if self.f16x3 else self.lib.rrl_plan_pack
+        _lib.check(pack(C.byref(w), _lib.ptr(self.packed), _lib.current_stream()), "rrl_plan_pack")
         self._keep = keep + ens        # the pack kernels read them asynchronously
 
     def cost(self, ac_seqs, cur_obs, noise=None):
@@ -65,7 +69,8 @@ class FusedPlanner:
         if self._partial is None or self._partial.numel() < need:
             self._partial = torch.empty(need, dtype=torch.float32, device=self.device)
         costs = torch.empty(M, pop, dtype=torch.float32, device=self.device)
-        rc = self.lib.rrl_plan_cost(_lib.ptr(self.packed), self.hq, self.he, self.n_nets, mpc.npart, M, pop,
+        entry = self.lib.rrl_plan_cost_f16x3 if self.f16x3 else self.lib.rrl_plan_cost
+        rc = entry(_lib.ptr(self.packed), self.hq, self.he, self.n_nets, mpc.npart, M, pop,
                                     mpc.plan_hor, _lib.ptr(cur_obs), _lib.ptr(ac_seqs), _lib.ptr(noise), self.seed, 0,
                                     _lib.ptr(self.tick), 1, _lib.ptr(self._partial), _lib.ptr(costs),
                                     _lib.current_stream())

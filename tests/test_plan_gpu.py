@@ -17,7 +17,7 @@ DEV = "cuda:0"
 RTOL, ATOL = 2e-4, 2e-4          # costs are sums of plan_hor sigmoids, O(1)
 
 
-def build(seed=0, weight_scale=2.5):
+def build(seed=0, weight_scale=2.5, f16x3=False):
     torch.manual_seed(seed)
     env = make_vec_env("navigation2", 4, device=DEV, seed=1)
     cfg = create_config("navigation2", "MPC", {}, [], "/tmp", env=env)
@@ -37,6 +37,10 @@ def build(seed=0, weight_scale=2.5):
     mpc.has_been_trained = True
     mpc.update_value_func(agent.safety_critic)
     assert mpc.fused is not None
+    if f16x3:                  # the hidden layers as three f16 MFMA products of hi / lo splits (rrl_plan_cost_f16x3)
+        from recovery_rl_amd.planner import FusedPlanner
+        mpc.fused = FusedPlanner(mpc, f16x3=True)
+    assert mpc.fused.f16x3 == f16x3
     mpc.fused.pack()
     return env, mpc, agent
 
@@ -50,9 +54,10 @@ def inputs(mpc, M, pop, seed):
     return acs, obs, noise
 
 
+@pytest.mark.parametrize("f16x3", [False, True])
 @pytest.mark.parametrize("M,pop", [(1, 400), (3, 400), (2, 30), (5, 7)])
-def test_fused_cost_equals_the_pytorch_path(M, pop):
-    env, mpc, _ = build()
+def test_fused_cost_equals_the_pytorch_path(M, pop, f16x3):
+    env, mpc, _ = build(f16x3=f16x3)
     acs, obs, noise = inputs(mpc, M, pop, seed=M * 1000 + pop)
     want = mpc._compile_cost(acs, obs, noise=noise, fused=False)
     got = mpc._compile_cost(acs, obs, noise=noise, fused=True)
@@ -61,8 +66,22 @@ def test_fused_cost_equals_the_pytorch_path(M, pop):
     torch.testing.assert_close(got, want, rtol=RTOL, atol=ATOL)
 
 
-def test_fused_cost_nan_particles_count_as_1e6():
-    env, mpc, _ = build()
+def test_f16x3_kernel_agrees_with_the_f32_kernel_far_inside_the_tolerance():
+    """hi + lo carries 22 bits: the two fused kernels differ by rounding noise, not by f16 precision.  Also with weights
+    and activations large enough that a single f16 product (11 bits) would be off by ~1e-3."""
+    for scale in (2.5, 6.0):
+        env, mpc32, _ = build(weight_scale=scale)
+        _, mpc16, _ = build(weight_scale=scale, f16x3=True)
+        acs, obs, noise = inputs(mpc32, 4, 400, seed=77)
+        a = mpc32._compile_cost(acs, obs, noise=noise, fused=True)
+        b = mpc16._compile_cost(acs, obs, noise=noise, fused=True)
+        assert float(a.std()) > 0.05
+        assert float((a - b).abs().max()) < 2e-5, float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("f16x3", [False, True])
+def test_fused_cost_nan_particles_count_as_1e6(f16x3):
+    env, mpc, _ = build(f16x3=f16x3)
     acs, obs, noise = inputs(mpc, 2, 32, seed=5)
     obs[1, 0] = float("nan")
     want = mpc._compile_cost(acs, obs, noise=noise, fused=False)
@@ -100,11 +119,12 @@ def test_planner_acts_through_the_fused_kernel_and_repacks_after_updates():
     assert not torch.equal(before, mpc.fused.packed)
 
 
-def test_fused_cost_at_config4_scale_4096_planning_envs():
+@pytest.mark.parametrize("f16x3", [False, True])
+def test_fused_cost_at_config4_scale_4096_planning_envs(f16x3):
     """BASELINE config 4's worst case: all 4096 envs plan at once (M = 4096, pop = 400, 20 particles, 5 steps = 164 M
     particle-steps per CEM iteration, through the ragged-tail / chunking / finish path of the kernel).  The PyTorch path
     (pinned to the reference by KAT G7c) evaluates a strided subset of the envs with the same noise rows."""
-    env, mpc, _ = build(seed=3)
+    env, mpc, _ = build(seed=3, f16x3=f16x3)
     M, pop = 4096, 400
     g = torch.Generator(device=DEV).manual_seed(77)
     acs = torch.rand(M, pop, mpc.plan_hor * 2, device=DEV, generator=g) * 2 - 1
