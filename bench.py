@@ -594,14 +594,14 @@ def main():
             hidden = 2 * 2 * 256 * 256 + 2 * 2 * 200 * 200
             extra["roofline_planner_f16x3"] = {
                 "kernel": "plan_cost_kernel<f16x3> (rrl_plan_cost_f16x3, opt-in --plan_precision f16x3): hidden layers as "
-                          "three v_mfma_f32_16x16x16_f16 products of hi/lo splits",
+                          "three v_mfma_f32_16x16x32_f16 products of hi/lo splits",
                 "bound": "mfma", "achieved": tf_h, "unit": "TFLOP/s (algorithmic f32-equivalent)",
                 "vs_f32_mfma_peak": tf_h / F32_MFMA_PEAK_TF, "launch_ms": t_h * 1e3, "row_steps_per_s": row_steps / t_h,
                 "speedup_vs_f32_kernel": t_p / t_h,
                 "executed_f16_TFLOPs": row_steps * (3 * hidden) / t_h / 1e12, "peak": F16_MFMA_PEAK_TF,
                 "frac": row_steps * (3 * hidden) / t_h / 1e12 / F16_MFMA_PEAK_TF,
-                "note": "costs agree with the f32 kernel to < 2e-5 (tests/test_plan_gpu.py); the v_mfma_f32_16x16x16_f16 "
-                        "shape sustains 1233 TF on this pool (profiles/mfma_f16_rate.hip), the K=32 shape 2460"}
+                "note": "costs agree with the f32 kernel to < 2e-5 (tests/test_plan_gpu.py); the K=32 f16 MFMA shape sustains 2460 TF on "
+                        "this pool (profiles/mfma_f16_rate.hip)"}
         if not a.no_cpu_baseline and world == 1:
             extra["cpu_baseline"] = cpu_baseline()
 

@@ -23,13 +23,11 @@ using namespace rrl_plan;
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // waves per SIMD the register allocator targets: 2 = one workgroup per CU (<= 256 VGPRs), 4 = two (<= 128)
 // timing ablations for profiles/ (wrong results!): 1 = no weight-fragment loads, 2 = no LDS fragment reads,
-// 4 = no activation stores / reductions
+// 4 = no activation stores / reductions, 8 = (f16x3) one matrix product instead of three, 16 = no per-row tail
 #ifndef RRL_PLAN_ABLATE
 #define RRL_PLAN_ABLATE 0
 #endif
@@ -52,16 +50,11 @@ constexpr int kLdsBytes = kLdsFloats * 4;  // 78.5 KB: two workgroups per CU
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-// F16X3: one v_mfma_f32_16x16x16_f16 covers the 16 k of a chunk (lane l: k = 4 (l / 16) + 0..3 on both operands -- the
-// fragment order of the four 16x16x4 steps it replaces) in 16 cycles instead of 4 x 32
-__device__ __forceinline__ f32x4 mfma16(f16x4 a, f16x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
-}
 // v = hi + lo with hi = f16(v) and lo = f16(v - hi): v - hi is exact in f32 (13 significant bits at most), so hi + lo
 // carries 22 bits of v; three products hi*hi + hi*lo + lo*hi then carry ~2^-21 of the f32 product (the lo*lo term, 2^-22
-// of it, is dropped).  Values beyond the f16 range saturate (NaN stays NaN and becomes the reference's 1e6 cost).
+// of it, is dropped).  Activations beyond the f16 range saturate (NaN stays NaN and becomes the reference's 1e6 cost).
 __device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
-    v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+    v = v > 65504.f ? 65504.f : v;      // activations are relu / swish outputs: bounded below (NaN compares false: kept)
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
 }
@@ -74,8 +67,10 @@ __device__ __forceinline__ int opaque(int x) {
 }
 
 __device__ __forceinline__ float reluf(float x) { return x < 0.f ? 0.f : x; }   // NaN stays NaN (F.relu)
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float swishf(float x) { return x / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): swish runs once per hidden activation of
+// the ensemble, 40 k times per workgroup and rollout step
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
 // acc[r][c] += act[rt[r] tile, :K] * W[:, ct[c] tile] over J chunks of 16 k.  A fragments come from LDS
@@ -101,37 +96,9 @@ __device__ __forceinline__ void load_b(f32x4 (&b)[NC], const float* __restrict__
     }
 }
 
-template <bool F16X3, int NCV, int XR, int MR, int NC>
+template <int NCV, int XR, int MR, int NC>
 __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
                                           const f32x4 (&b)[NC], int j, int lane) {
-    if constexpr (F16X3) {
-        // A: 4 hi + 4 lo f16 of this lane's row and k group; B: the packed float4 slot holds {hi[4], lo[4]}
-        const _Float16* ah = reinterpret_cast<const _Float16*>(act);
-        const _Float16* al = ah + kRows * kHalfStride;
-        f16x4 ahi[MR], alo[MR];
-#pragma unroll
-        for (int r = 0; r < MR; ++r) {
-            const int off = (rt[r] * 16 + (lane & 15)) * kHalfStride + 16 * j + (lane >> 4) * 4;
-            ahi[r] = *reinterpret_cast<const f16x4*>(ah + off);
-            alo[r] = *reinterpret_cast<const f16x4*>(al + off);
-        }
-        f16x4 bhi[NC], blo[NC];
-#pragma unroll
-        for (int c = 0; c < NCV; ++c) {
-            bhi[c] = __builtin_bit_cast(f16x4, f32x2{b[c][0], b[c][1]});
-            blo[c] = __builtin_bit_cast(f16x4, f32x2{b[c][2], b[c][3]});
-        }
-        // product by product over all tiles: consecutive MFMAs never share an accumulator
-#pragma unroll
-        for (int prod = 0; prod < 3; ++prod)
-#pragma unroll
-            for (int r = 0; r < MR; ++r)
-#pragma unroll
-                for (int c = 0; c < NCV; ++c)
-                    if (tile_on<XR>(r, c))
-                        acc[r][c] = mfma16(prod == 2 ? alo[r] : ahi[r], prod == 1 ? blo[c] : bhi[c], acc[r][c]);
-        return;
-    }
     f32x4 a[MR];
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -153,60 +120,73 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MR][NC], const float* act
 
 // F16X3 with the K = 32 shape (v_mfma_f32_16x16x32_f16: lane l holds k = 8 (l / 16) + 0..7 of a 32-wide block on both
 // operands; the same 16 cycles as the K = 16 shape for twice the k).  A: one 16-byte read per plane; B: the two float4
-// slots of block jp hold {hi[8]} and {lo[8]} of this lane's row (pack_layer_f16x3_k32_kernel).
-template <int NCV, int XR, int MR, int NC>
-__device__ __forceinline__ void mma_pair(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
-                                         const f32x4 (&bh)[NC], const f32x4 (&bl)[NC], int jp, int lane) {
+// slots of block jp hold {hi[8]} and {lo[8]} of this lane's column (pack_layer_f16x3_k32_kernel).
+// Fragment sets in flight: the next block's hi set is requested before this block's MFMAs; the lo set has ONE buffer --
+// the hi*lo products go first, and the next block's lo set is requested into the same registers as soon as they are
+// issued (3 float4 sets live instead of 4: what fits next to 32 accumulator registers when a wave owns four column tiles).
+template <int NCV, int NB, int XR = -1, int MR, int NC>
+__device__ __forceinline__ void layer_mma_k32(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
+                                              const float* __restrict__ wpk, const int (&ct)[NC], int lane) {
+    constexpr int J = 2 * NB;          // float4 slots per column tile
     const _Float16* ah = reinterpret_cast<const _Float16*>(act);
     const _Float16* al = ah + kRows * kHalfStride;
-    f16x8 ahi[MR], alo[MR];
+    f32x4 h0[NC], h1[NC], l[NC];
+    const auto block = [&](const f32x4 (&bh)[NC], int jp, bool more) {
+        f16x8 ahi[MR], alo[MR];
 #pragma unroll
-    for (int r = 0; r < MR; ++r) {
-        const int off = (rt[r] * 16 + (lane & 15)) * kHalfStride + 32 * jp + (lane >> 4) * 8;
-        ahi[r] = *reinterpret_cast<const f16x8*>(ah + off);
-        alo[r] = *reinterpret_cast<const f16x8*>(al + off);
-    }
-#pragma unroll
-    for (int prod = 0; prod < 3; ++prod)
+        for (int r = 0; r < MR; ++r) {
+            const int off = (rt[r] * 16 + (lane & 15)) * kHalfStride + 32 * jp + (lane >> 4) * 8;
+#if RRL_PLAN_ABLATE & 2
+            ahi[r] = __builtin_bit_cast(f16x8, f32x4{float(jp), float(lane), 1.f, float(r + off)});
+            alo[r] = ahi[r];
+#else
+            ahi[r] = *reinterpret_cast<const f16x8*>(ah + off);
+            alo[r] = *reinterpret_cast<const f16x8*>(al + off);
+#endif
+        }
+#if !(RRL_PLAN_ABLATE & 8)
 #pragma unroll
         for (int r = 0; r < MR; ++r)
 #pragma unroll
             for (int c = 0; c < NCV; ++c)
                 if (tile_on<XR>(r, c))
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                        prod == 2 ? alo[r] : ahi[r], __builtin_bit_cast(f16x8, prod == 1 ? bl[c] : bh[c]), acc[r][c], 0, 0, 0);
-}
-
-// 32-wide blocks (slots 2 jp = hi, 2 jp + 1 = lo) with the fragments of the NEXT block in flight (four float4 sets live:
-// affordable for two column tiles per wave, i.e. the Q_risk layers; J = number of 16-wide chunks, a multiple of 4).
-template <int NCV, int J, int XR = -1, int MR, int NC>
-__device__ __forceinline__ void layer_mma_pairs(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
-                                                const float* __restrict__ wpk, const int (&ct)[NC], int lane) {
-    static_assert(J % 4 == 0 && J >= 4, "pairs are consumed two at a time");
-    f32x4 p0[NC], p1[NC], q0[NC], q1[NC];
-    load_b<NCV>(p0, wpk, ct, J, 0, lane);
-    load_b<NCV>(p1, wpk, ct, J, 1, lane);
-    int j = 0;
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[r], __builtin_bit_cast(f16x8, l[c]), acc[r][c], 0, 0, 0);
+#endif
+        if (more) load_b<NCV>(l, wpk, ct, J, 2 * jp + 3, lane);
+#pragma unroll
+        for (int prod = 0; prod < ((RRL_PLAN_ABLATE & 8) ? 1 : 2); ++prod)      // ablation 8: one product instead of three
+#pragma unroll
+            for (int r = 0; r < MR; ++r)
+#pragma unroll
+                for (int c = 0; c < NCV; ++c)
+                    if (tile_on<XR>(r, c))
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(prod ? alo[r] : ahi[r],
+                                                                           __builtin_bit_cast(f16x8, bh[c]), acc[r][c], 0, 0, 0);
+    };
+    load_b<NCV>(h0, wpk, ct, J, 0, lane);
+    load_b<NCV>(l, wpk, ct, J, 1, lane);
+    int jp = 0;
 #pragma unroll 1
-    for (; j + 4 < J; j += 4) {
-        load_b<NCV>(q0, wpk, ct, J, j + 2, lane);
-        load_b<NCV>(q1, wpk, ct, J, j + 3, lane);
+    for (; jp + 2 < NB; jp += 2) {
+        load_b<NCV>(h1, wpk, ct, J, 2 * jp + 2, lane);
         __builtin_amdgcn_sched_barrier(0);
-        mma_pair<NCV, XR>(acc, act, rt, p0, p1, j >> 1, lane);
-        load_b<NCV>(p0, wpk, ct, J, j + 4, lane);
-        load_b<NCV>(p1, wpk, ct, J, j + 5, lane);
+        block(h0, jp, true);
+        load_b<NCV>(h0, wpk, ct, J, 2 * jp + 4, lane);
         __builtin_amdgcn_sched_barrier(0);
-        mma_pair<NCV, XR>(acc, act, rt, q0, q1, (j >> 1) + 1, lane);
+        block(h1, jp + 1, true);
     }
-    load_b<NCV>(q0, wpk, ct, J, J - 2, lane);
-    load_b<NCV>(q1, wpk, ct, J, J - 1, lane);
-    mma_pair<NCV, XR>(acc, act, rt, p0, p1, J / 2 - 2, lane);
-    mma_pair<NCV, XR>(acc, act, rt, q0, q1, J / 2 - 1, lane);
+    if constexpr (NB % 2 == 1) {
+        block(h0, NB - 1, false);
+    } else {
+        load_b<NCV>(h1, wpk, ct, J, 2 * NB - 2, lane);
+        block(h0, NB - 2, true);
+        block(h1, NB - 1, false);
+    }
 }
 
 // The weight fragments of chunk j + 1 are requested before the 4 MR NC MFMAs of chunk j (register double
 // buffer): their L2 latency hides behind ~1000 cycles of matrix work.  LDS fragments are read per chunk.
-template <bool F16X3, int NCV, int J, int XR = -1, int MR, int NC>
+template <int NCV, int J, int XR = -1, int MR, int NC>
 __device__ __forceinline__ void layer_mma(f32x4 (&acc)[MR][NC], const float* act, const int (&rt)[MR],
                                           const float* __restrict__ wpk, const int (&ct)[NC], int lane) {
     f32x4 b0[NC], b1[NC];
@@ -218,17 +198,17 @@ __device__ __forceinline__ void layer_mma(f32x4 (&acc)[MR][NC], const float* act
     for (; j + 2 < J; j += 2) {
         load_b<NCV>(b1, wpk, ct, J, j + 1, lane);
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs it hides behind
-        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b0, j, lane);
+        mma_chunk<NCV, XR>(acc, act, rt, b0, j, lane);
         load_b<NCV>(b0, wpk, ct, J, j + 2, lane);
         __builtin_amdgcn_sched_barrier(0);
-        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b1, j + 1, lane);
+        mma_chunk<NCV, XR>(acc, act, rt, b1, j + 1, lane);
     }
     if constexpr (J % 2 == 0) {
         load_b<NCV>(b1, wpk, ct, J, J - 1, lane);
-        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b0, J - 2, lane);
-        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b1, J - 1, lane);
+        mma_chunk<NCV, XR>(acc, act, rt, b0, J - 2, lane);
+        mma_chunk<NCV, XR>(acc, act, rt, b1, J - 1, lane);
     } else {
-        mma_chunk<F16X3, NCV, XR>(acc, act, rt, b0, J - 1, lane);
+        mma_chunk<NCV, XR>(acc, act, rt, b0, J - 1, lane);
     }
 }
 
@@ -329,6 +309,13 @@ void plan_cost_kernel(
         }
         *reinterpret_cast<f32x4*>(rowstate + tid * 4) = st;
     }
+    if constexpr (F16X3) {
+        // the ensemble's last 32-wide k block covers columns 192..223, its stores only 0..207: the rest multiplies zero
+        // weights, which needs them finite (later steps find the Q_risk phase's finite activations there)
+        _Float16* planes = reinterpret_cast<_Float16*>(act);
+        for (int i = tid; i < 2 * kRows * 16; i += kThreads)
+            planes[(i >> 10) * (kRows * kHalfStride) + ((i >> 4) & (kRows - 1)) * kHalfStride + kHEPad + (i & 15)] = (_Float16)0.f;
+    }
     const float* epk = pk + e_off(e);
     const float* g = pk + glob_off(n_nets);                // mu[4], sigma[4], max_logvar[2], min_logvar[2]
 
@@ -387,8 +374,8 @@ void plan_cost_kernel(
                     store_act<F16X3, false, 2>(acc, act, q_rt, b1v, q_ct, opaque(lane));
                     __syncthreads();
                     zero(acc);
-                    if constexpr (F16X3) layer_mma_pairs<2, kQTiles>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
-                    else layer_mma<F16X3, 2, kQTiles>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
+                    if constexpr (F16X3) layer_mma_k32<2, kQTiles / 2>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
+                    else layer_mma<2, kQTiles>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
                     // last layer folded in: q[row] = sum_col relu(h2 + b2) w3[col]
                     float s[4][4];
 #pragma unroll
@@ -444,9 +431,15 @@ void plan_cost_kernel(
                 for (int c = 0; c < 4; ++c) eb[c] = epk[kEB1 + ecol(c)];
                 __syncthreads();
                 zero(acc);
-                E_STAGE((layer_mma<F16X3, 4, kETiles, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
-                        (layer_mma<F16X3, 4, kETiles, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
-                        (layer_mma<F16X3, 3, kETiles>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
+                if constexpr (F16X3) {
+                    E_STAGE((layer_mma_k32<4, kEBlocks32, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                            (layer_mma_k32<4, kEBlocks32, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                            (layer_mma_k32<3, kEBlocks32>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
+                } else {
+                    E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                            (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                            (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
+                }
                 __syncthreads();       // every wave has finished reading layer-1 input
                 E_STAGE((store_act<F16X3, true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
                         (store_act<F16X3, true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
@@ -455,9 +448,15 @@ void plan_cost_kernel(
                 for (int c = 0; c < 4; ++c) eb[c] = epk[kEB2 + ecol(c)];
                 __syncthreads();
                 zero(acc);
-                E_STAGE((layer_mma<F16X3, 4, kETiles, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
-                        (layer_mma<F16X3, 4, kETiles, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
-                        (layer_mma<F16X3, 3, kETiles>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
+                if constexpr (F16X3) {
+                    E_STAGE((layer_mma_k32<4, kEBlocks32, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                            (layer_mma_k32<4, kEBlocks32, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                            (layer_mma_k32<3, kEBlocks32>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
+                } else {
+                    E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                            (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                            (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
+                }
 #undef E_STAGE
                 // last layer (200 -> 4) folded in: out[row][o] = sum_col swish(h3 + b2) W3[col][o]
                 f32x4 ew3[4];
@@ -493,7 +492,7 @@ void plan_cost_kernel(
         }
 
         // ---- per-row tail: cost, predictive distribution, next observation ----
-        if (owner) {
+        if (owner && !(RRL_PLAN_ABLATE & 16)) {
             float q[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -581,37 +580,7 @@ __global__ __launch_bounds__(kBlock) void pack_layer_kernel(const float* __restr
     }
 }
 
-// the same fragment stream for the F16X3 kernel: the float4 slot of (ct, j, lane) holds the four weights of that lane as
-// {hi[0..3], lo[0..3]} f16 (hi = f16(w), lo = f16(w - hi))
-__global__ __launch_bounds__(kBlock) void pack_layer_f16x3_kernel(const float* __restrict__ src, long long sn,
-                                                                  long long sk, int N, int K, int tiles, int J,
-                                                                  float* __restrict__ dst) {
-    const long long total = (long long)tiles * J * 64;
-    for (long long f = blockIdx.x * (long long)blockDim.x + threadIdx.x; f < total;
-         f += (long long)gridDim.x * blockDim.x) {
-        const int lane = int(f & 63);
-        const long long frag = f >> 6;
-        const int j = int(frag % J), ct = int(frag / J);
-        const int n = 16 * ct + (lane & 15);
-        _Float16 hi[4], lo[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k = 16 * j + 4 * (lane >> 4) + t;
-            float w = (n < N && k < K) ? src[n * sn + k * sk] : 0.f;
-            w = w > 65504.f ? 65504.f : (w < -65504.f ? -65504.f : w);
-            hi[t] = (_Float16)w;
-            lo[t] = (_Float16)(w - (float)hi[t]);
-        }
-        _Float16* out = reinterpret_cast<_Float16*>(dst + f * 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            out[t] = hi[t];
-            out[4 + t] = lo[t];
-        }
-    }
-}
-
-// F16X3 with the K = 32 MFMA shape (the Q_risk layers): slot (ct, 2 jp, lane) = hi[8], slot (ct, 2 jp + 1, lane) = lo[8]
+// fragment stream of the F16X3 kernel (K = 32 MFMA shape): slot (ct, 2 jp, lane) = hi[8], slot (ct, 2 jp + 1, lane) = lo[8]
 // of W[n = 16 ct + lane % 16][k = 32 jp + 8 (lane / 16) + 0..7].  J (16-wide chunks) must be even.
 __global__ __launch_bounds__(kBlock) void pack_layer_f16x3_k32_kernel(const float* __restrict__ src, long long sn,
                                                                       long long sk, int N, int K, int tiles, int J,
@@ -680,20 +649,20 @@ static int plan_pack_impl(const rrl_plan_weights_t* w, float* packed, void* stre
     if (!w || !packed || !rrl_plan_supported(w->hq, w->he, w->n_nets, 4 * w->n_nets, 2, 2)) return RRL_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     const dim3 b(kBlock);
-    const auto pack_layer = [&](const float* src, long long sn, long long sk, int N, int K, int tiles, int J, float* dst) {
-        if (f16x3) hipLaunchKernelGGL(pack_layer_f16x3_kernel, dim3(64), b, 0, st, src, sn, sk, N, K, tiles, J, dst);
-        else hipLaunchKernelGGL(pack_layer_kernel, dim3(64), b, 0, st, src, sn, sk, N, K, tiles, J, dst);
+    // hidden layers: f32 fragments of J 16-wide chunks, or (f16x3) {hi, lo} fragments of J32 32-wide blocks
+    const auto pack_layer = [&](const float* src, long long sn, long long sk, int N, int K, int tiles, int J, int J32,
+                                float* dst) {
+        if (f16x3)
+            hipLaunchKernelGGL(pack_layer_f16x3_k32_kernel, dim3(64), b, 0, st, src, sn, sk, N, K, tiles, 2 * J32, dst);
+        else
+            hipLaunchKernelGGL(pack_layer_kernel, dim3(64), b, 0, st, src, sn, sk, N, K, tiles, J, dst);
     };
     for (int h = 0; h < 2; ++h) {
         float* d = packed + q_off(h);
         hipLaunchKernelGGL(pack_input_kernel, dim3(4), b, 0, st, w->q_w1 + (size_t)h * kHQ * 4, 4LL, 1LL, kHQ,
                            kQTiles, d + kQW1);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_b1 + h * kHQ, 1LL, kHQ, kHQ, d + kQB1);
-        if (f16x3)
-            hipLaunchKernelGGL(pack_layer_f16x3_k32_kernel, dim3(64), b, 0, st, w->q_w2 + (size_t)h * kHQ * kHQ,
-                               (long long)kHQ, 1LL, kHQ, kHQ, kQTiles, kQTiles, d + kQW2);
-        else
-            pack_layer(w->q_w2 + (size_t)h * kHQ * kHQ, (long long)kHQ, 1LL, kHQ, kHQ, kQTiles, kQTiles, d + kQW2);
+        pack_layer(w->q_w2 + (size_t)h * kHQ * kHQ, (long long)kHQ, 1LL, kHQ, kHQ, kQTiles, kQTiles, kQTiles / 2, d + kQW2);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_b2 + h * kHQ, 1LL, kHQ, kHQ, d + kQB2);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_w3 + h * kHQ, 1LL, kHQ, kHQ, d + kQW3);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->q_b3 + h, 1LL, 1, 4, d + kQB3);
@@ -704,9 +673,9 @@ static int plan_pack_impl(const rrl_plan_weights_t* w, float* packed, void* stre
         hipLaunchKernelGGL(pack_input_kernel, dim3(4), b, 0, st, w->e_w0 + (size_t)e * 4 * kHE, 1LL, (long long)kHE,
                            kHE, kETiles, d + kEW0);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b0 + e * kHE, 1LL, kHE, kHEPad, d + kEB0);
-        pack_layer(w->e_w1 + (size_t)e * kHE * kHE, 1LL, (long long)kHE, kHE, kHE, kETiles, kETiles, d + kEW1);
+        pack_layer(w->e_w1 + (size_t)e * kHE * kHE, 1LL, (long long)kHE, kHE, kHE, kETiles, kETiles, kEBlocks32, d + kEW1);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b1 + e * kHE, 1LL, kHE, kHEPad, d + kEB1);
-        pack_layer(w->e_w2 + (size_t)e * kHE * kHE, 1LL, (long long)kHE, kHE, kHE, kETiles, kETiles, d + kEW2);
+        pack_layer(w->e_w2 + (size_t)e * kHE * kHE, 1LL, (long long)kHE, kHE, kHE, kETiles, kETiles, kEBlocks32, d + kEW2);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b2 + e * kHE, 1LL, kHE, kHEPad, d + kEB2);
         hipLaunchKernelGGL(pack_head_kernel, dim3(4), b, 0, st, w->e_w3 + (size_t)e * kHE * 4, kHE, d + kEW3);
         hipLaunchKernelGGL(pack_vector_kernel, dim3(1), b, 0, st, w->e_b3 + e * 4, 1LL, 4, 4, d + kEB3);
