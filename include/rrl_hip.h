@@ -144,9 +144,12 @@ int rrl_maze_offline(int64_t num_transitions, uint64_t seed, float* s, float* a,
  * Replay.  Replaces ReplayMemory / ConstraintReplayMemory (recovery_rl/replay_memory.py).
  * Layout: structure-of-arrays ring, f32: s[cap,2] a[cap,2] r[cap] s2[cap,2] m[cap] = 32 B/row.
  *   state   device int64[4]: {position, size, ticket(internal, keep 0), error flag}
- *   pos_cnt device int32[ceil(cap/64)] or NULL: number of rows with r != 0 per 64-slot chunk,
- *           maintained by push, consumed by the stratified sampler (replay_memory.py:50,58-66).
+ *   pos_cnt device int32[RRL_POS_CNT_LEN(cap)] (zero-initialised) or NULL: number of rows with r != 0 per 64-slot chunk,
+ *           then (from the next multiple of 4) per 4096-slot super-chunk; maintained by push, consumed by the
+ *           stratified sampler (replay_memory.py:50,58-66), which scans the second level only (cap / 4096 entries)
+ *           and one super-chunk's 64 first-level counts per drawn row.
  * ------------------------------------------------------------------------------------------ */
+#define RRL_POS_CNT_LEN(cap) (((((cap) + 63) / 64 + 3) / 4) * 4 + ((cap) + 4095) / 4096)
 typedef struct {
     float* s;
     float* a;

@@ -732,12 +732,15 @@ int rrl_oracle_sample_stratified_clamped(const rrl_oracle_replay* rb, int32_t n_
         n_neg = B - n_pos;
     }
     if (n_pos_used) *n_pos_used = n_pos;
+    /* a class taken whole is listed in slot order (rank i for its i-th batch row): no draw */
     if (n_pos > 0) {
-        if (rrl_oracle_sample_indices(npos_total, n_pos, seed, counter, RRL_STREAM_SAMPLE, idx)) return -2;
+        if (n_pos == npos_total) { for (int32_t i = 0; i < n_pos; ++i) idx[i] = i; }
+        else if (rrl_oracle_sample_indices(npos_total, n_pos, seed, counter, RRL_STREAM_SAMPLE, idx)) return -2;
         for (int32_t i = 0; i < n_pos; ++i) idx[i] = kth_slot(rb, idx[i], 1);
     }
     if (n_neg > 0) {
-        if (rrl_oracle_sample_indices(nneg_total, n_neg, seed, counter, RRL_STREAM_SAMPLE_NEG, idx + n_pos)) return -2;
+        if (n_neg == nneg_total) { for (int32_t i = 0; i < n_neg; ++i) idx[n_pos + i] = i; }
+        else if (rrl_oracle_sample_indices(nneg_total, n_neg, seed, counter, RRL_STREAM_SAMPLE_NEG, idx + n_pos)) return -2;
         for (int32_t i = 0; i < n_neg; ++i) idx[n_pos + i] = kth_slot(rb, idx[n_pos + i], 0);
     }
     return 0;

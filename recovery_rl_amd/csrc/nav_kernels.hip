@@ -593,7 +593,7 @@ thread_local int rrl_host::last_hip_error = 0;
 
 extern "C" {
 
-int rrl_abi_version(void) { return 1; }
+int rrl_abi_version(void) { return 2; }   // 2: pos_cnt carries a second count level (RRL_POS_CNT_LEN)
 
 int rrl_last_hip_error(void) { return rrl_host::last_hip_error; }
 

@@ -10,6 +10,12 @@
 namespace rrl_replay {
 
 constexpr int kChunk = 64;    // slots per positive-count chunk
+constexpr int kSuper = 4096;  // slots per second-level count (64 chunks)
+
+// pos_cnt layout: [n_chunks] per-chunk counts, padded to a multiple of 4, then [n_super] per-4096-slot counts
+__host__ __device__ __forceinline__ int64_t count_chunks(int64_t cap) { return (cap + kChunk - 1) / kChunk; }
+__host__ __device__ __forceinline__ int64_t count_supers(int64_t cap) { return (cap + kSuper - 1) / kSuper; }
+__host__ __device__ __forceinline__ int64_t super_base(int64_t cap) { return (count_chunks(cap) + 3) & ~int64_t(3); }
 
 // write one row into `slot`; keeps the per-chunk positive counts exact (pos_idx, replay_memory.py:50)
 __device__ __forceinline__ void store_values(const rrl_replay_t& rb, int64_t slot, int64_t size, float2 s,
@@ -17,7 +23,10 @@ __device__ __forceinline__ void store_values(const rrl_replay_t& rb, int64_t slo
     if (rb.pos_cnt) {
         const int was = (slot < size) ? int(rb.r[slot] != 0.0f) : 0;
         const int delta = int(r != 0.0f) - was;
-        if (delta) atomicAdd(&rb.pos_cnt[slot / kChunk], delta);
+        if (delta) {
+            atomicAdd(&rb.pos_cnt[slot / kChunk], delta);
+            atomicAdd(&rb.pos_cnt[super_base(rb.cap) + slot / kSuper], delta);
+        }
     }
     ((float2*)rb.s)[slot] = s;
     ((float2*)rb.a)[slot] = a;

@@ -25,6 +25,12 @@ constexpr int kTile = 1024;   // rows per workgroup in the masked push
 using rrl_replay::advance_ring;
 using rrl_replay::kChunk;
 
+// timing ablations for profiles/creplay_probe.py (wrong results!): stop the stratified sampler after 1 = the count scan,
+// 2 = the distinct draws, 3 = the rank -> chunk walk, 4 = the reward scan
+#ifndef RRL_CREPLAY_ABLATE
+#define RRL_CREPLAY_ABLATE 0
+#endif
+
 struct Rows {
     const float2* s;
     const float2* a;
@@ -146,13 +152,21 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     return x;
 }
 
+// `whole`: this lane's class is taken whole (as many rows requested as it has -- what the clamped stratified draw does to
+// a starved class): its lanes get the ranks 0, 1, ... in lane order instead of drawing.  (Drawing n distinct values out
+// of n by rejection needs O(n) rounds: 50 us for 69 positives in the Maze loop.)
 __device__ __forceinline__ bool draw_distinct(int i, int B, int group, uint64_t population, uint64_t seed,
                                               uint32_t stream, uint64_t ctr, int row, uint32_t* key,
-                                              unsigned long long* table, int table_mask) {
+                                              unsigned long long* table, int table_mask, bool whole = false) {
     const unsigned long long kEmpty = ~0ULL;
     const bool active = i < B;
     bool mine = !active;  // inactive lanes count as settled
     uint32_t v = 0;
+    if (active && whole) {
+        mine = true;
+        v = uint32_t(row);
+        key[i] = v | 0x80000000u;
+    }
     for (uint32_t round = 0; round <= 4096; ++round) {
         for (int e = threadIdx.x; e <= table_mask; e += blockDim.x) table[e] = kEmpty;
         if (active && !mine) {
@@ -243,51 +257,43 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
     const int B = n_pos + n_neg;
     unsigned long long* table = (unsigned long long*)smem;      // [table_mask + 1]
     uint32_t* key = (uint32_t*)(table + table_mask + 1);
-    int32_t* prefix = (int32_t*)(key + ((B + 3) & ~3));   // [n_chunks + 1] exclusive positive counts, 16-byte aligned
-    int32_t* part = prefix + (n_chunks + 1) + ((n_chunks + 1) >> 5) + 1;   // [blockDim.x], after the skewed table
+    int32_t* sup = (int32_t*)(key + ((B + 3) & ~3));      // [n_super + 1] exclusive positive counts per super-chunk
     const int64_t size = rb.state[1];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    // exclusive scan of pos_cnt in LDS.  The table is first copied with coalesced, independent 16-byte loads (a
-    // thread walking its own contiguous segment of global memory serialised ~60 round trips twice: 34 us at 1e6
-    // slots), then every thread sums / rewrites its contiguous LDS segment around a block scan.  Entry c lives at
-    // c + c / 32: without the skew the per-thread segments (a power-of-two apart) collide on two LDS banks.
-    auto at = [](int c) { return c + (c >> 5); };
-    {
-        const int n4 = (reinterpret_cast<uintptr_t>(rb.pos_cnt) & 15) == 0 ? n_chunks >> 2 : 0;
-        const int4* src4 = reinterpret_cast<const int4*>(rb.pos_cnt);
-#pragma unroll 8
-        for (int c = tid; c < n4; c += nt) {
-            const int4 v = src4[c];
-            prefix[at(4 * c)] = v.x;
-            prefix[at(4 * c + 1)] = v.y;
-            prefix[at(4 * c + 2)] = v.z;
-            prefix[at(4 * c + 3)] = v.w;
+    const int tid = threadIdx.x;
+    // Second count level (one entry per 4096 slots, <= 512 of them) -> exclusive scan in LDS.  (The first version
+    // copied and scanned the whole first level -- 15 625 entries at 1e6 slots, 62 KB -- in this one workgroup: 27 us.)
+    const int n_super = int(rrl_replay::count_supers(rb.cap));
+    const int32_t* sup_cnt = rb.pos_cnt + rrl_replay::super_base(rb.cap);
+    // wave 0: lane l owns entries 8 l .. 8 l + 7 (cap <= 2^21: at most 512 entries), wave prefix by shuffles
+    if (tid < 64) {
+        int32_t v[8], run = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = 8 * tid + u;
+            v[u] = c < n_super ? sup_cnt[c] : 0;
+            run += v[u];
         }
-        for (int c = 4 * n4 + tid; c < n_chunks; c += nt) prefix[at(c)] = rb.pos_cnt[c];
+        int32_t incl = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t up = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += up;
+        }
+        int32_t acc = incl - run;                      // exclusive prefix of this lane's first entry
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = 8 * tid + u;
+            if (c <= n_super) sup[c] = acc;
+            acc += v[u];
+        }
+        if (8 * tid + 8 == n_super) sup[n_super] = acc;     // total, when n_super is a multiple of 8
     }
     __syncthreads();
-    const int seg = (n_chunks + nt - 1) / nt;
-    const int lo = min(tid * seg, n_chunks), hi = min(lo + seg, n_chunks);
-    int32_t local = 0;
-    for (int c = lo; c < hi; ++c) local += prefix[at(c)];
-    part[tid] = local;
-    __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {
-        const int32_t add = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += add;
-        __syncthreads();
-    }
-    int32_t run = part[tid] - local;
-    for (int c = lo; c < hi; ++c) {
-        const int32_t cnt = prefix[at(c)];
-        prefix[at(c)] = run;
-        run += cnt;
-    }
-    const int64_t total_pos = part[nt - 1];
-    if (tid == nt - 1) prefix[at(n_chunks)] = int32_t(total_pos);
-    __syncthreads();
+    const int64_t total_pos = sup[n_super];
     const int64_t total_neg = size - total_pos;
+#if RRL_CREPLAY_ABLATE == 1
+    return;
+#endif
     if (int64_t(n_pos) > total_pos || int64_t(n_neg) > total_neg) {
         const bool feasible = int64_t(B) <= size && (rb.flags & RRL_REPLAY_CLAMP_STRATIFIED);
         if (!feasible) {
@@ -306,24 +312,72 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
     const uint32_t stream = is_pos ? rrl::kStreamSample : rrl::kStreamSampleNeg;
     // lanes of the negative group are numbered from 0 within their group, like a separate call
     const int gi = is_pos ? tid : tid - n_pos;
-    if (!draw_distinct(tid, B, is_pos ? 0 : 1, population, seed, stream, ctr, gi, key, table, table_mask)) {
+    const bool class_whole = population == uint64_t(is_pos ? n_pos : n_neg);
+    if (!draw_distinct(tid, B, is_pos ? 0 : 1, population, seed, stream, ctr, gi, key, table, table_mask, class_whole)) {
         if (tid == 0) rb.state[3] = 2;
         return;
     }
+#if RRL_CREPLAY_ABLATE == 2
+    return;
+#endif
     if (tid >= B) return;
-    // rank -> slot: binary search the chunk, then scan its 64 rewards
+    // rank -> slot: binary search the super-chunk in LDS, walk its 64 first-level counts (16 independent 16-byte loads),
+    // then scan the chunk's 64 rewards
     const int64_t k = int64_t(key[tid] & 0x7fffffffu);
-    auto before = [&](int c) -> int64_t {  // rows of my class in chunks [0,c)
-        const int64_t filled = min(size, int64_t(c) * kChunk);
-        return is_pos ? int64_t(prefix[at(c)]) : filled - int64_t(prefix[at(c)]);
+    auto before_super = [&](int sc) -> int64_t {  // rows of my class in super-chunks [0, sc)
+        const int64_t filled = min(size, int64_t(sc) * rrl_replay::kSuper);
+        return is_pos ? int64_t(sup[sc]) : filled - int64_t(sup[sc]);
     };
-    int a = 0, b = n_chunks;  // invariant: before(a) <= k < before(b)
-    while (b - a > 1) {
-        const int mid = (a + b) >> 1;
-        if (before(mid) <= k) a = mid; else b = mid;
+    int sa = 0, sb = n_super;  // invariant: before_super(sa) <= k < before_super(sb)
+    while (sb - sa > 1) {
+        const int mid = (sa + sb) >> 1;
+        if (before_super(mid) <= k) sa = mid; else sb = mid;
     }
-    int64_t rem = k - before(a);
-    int64_t slot = -1;
+    constexpr int kPer = rrl_replay::kSuper / kChunk;     // 64 chunks per super-chunk
+    const int c_first = sa * kPer;
+    int4 cv[kPer / 4];
+    {
+        const int4* src = reinterpret_cast<const int4*>(rb.pos_cnt + c_first);   // c_first % 4 == 0, table 16-byte aligned
+        const bool all = c_first + kPer <= n_chunks && (reinterpret_cast<uintptr_t>(rb.pos_cnt) & 15) == 0;
+#pragma unroll
+        for (int q = 0; q < kPer / 4; ++q) {
+            if (all) {
+                cv[q] = src[q];
+            } else {
+                int t4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t4[u] = c_first + 4 * q + u < n_chunks ? rb.pos_cnt[c_first + 4 * q + u] : 0;
+                cv[q] = make_int4(t4[0], t4[1], t4[2], t4[3]);
+            }
+        }
+    }
+    // From here on everything is relative to the super-chunk / chunk and fits 32 bits (the 64-bit version of these two
+    // 64-step walks was 20 of the kernel's 26 us: ~1300 emulated-int64 instructions per lane on a single CU).
+    int32_t rem = int32_t(k - before_super(sa));                          // rank inside the super-chunk, < 4096
+    const int64_t sup_lo = int64_t(c_first) * kChunk;
+    const int32_t filled_sup = int32_t(min(int64_t(rrl_replay::kSuper), max(int64_t(0), size - sup_lo)));
+    int32_t a_rel = -1;
+#pragma unroll
+    for (int q = 0; q < kPer / 4; ++q) {
+        const int e4[4] = {cv[q].x, cv[q].y, cv[q].z, cv[q].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cu = 4 * q + u;
+            const int32_t filled = min(max(filled_sup - cu * kChunk, 0), kChunk);      // filled slots of this chunk
+            const int32_t mine = is_pos ? e4[u] : filled - e4[u];
+            const bool take = (a_rel < 0) & (rem < mine);
+            a_rel = take ? cu : a_rel;
+            rem = a_rel < 0 ? rem - mine : rem;
+        }
+    }
+    if (a_rel < 0) {          // the two count levels disagree
+        rb.state[3] = 3;
+        return;
+    }
+    const int a = c_first + a_rel;
+#if RRL_CREPLAY_ABLATE == 3
+    if (rem >= 0) return;
+#endif
     const int64_t c0 = int64_t(a) * kChunk;
     // the chunk's 64 rewards in 16 independent 16-byte loads (a serial scan chained up to 64 dependent loads);
     // slots at or beyond `size` never match
@@ -340,23 +394,27 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
             rv[q] = make_float4(t4[0], t4[1], t4[2], t4[3]);
         }
     }
+    const int32_t filled_c = int32_t(min(int64_t(kChunk), max(int64_t(0), size - c0)));
+    int32_t slot_rel = -1;
 #pragma unroll
     for (int q = 0; q < kChunk / 4; ++q) {
         const float e4[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int64_t p = c0 + 4 * q + u;
-            const bool match = p < size && ((e4[u] != 0.0f) == is_pos);
-            if (match && slot < 0) {
-                if (rem == 0) slot = p;
-                --rem;
-            }
+            const int pu = 4 * q + u;
+            const bool match = (pu < filled_c) & ((e4[u] != 0.0f) == is_pos);
+            slot_rel = (match & (rem == 0) & (slot_rel < 0)) ? pu : slot_rel;
+            rem -= int32_t(match);
         }
     }
+    const int64_t slot = slot_rel < 0 ? int64_t(-1) : c0 + slot_rel;
     if (slot < 0) {  // count table out of sync with the rows: flag, never read out of bounds
         rb.state[3] = 3;
         return;
     }
+#if RRL_CREPLAY_ABLATE == 4
+    if (slot >= 0) return;
+#endif
     gather_row(rb, slot, tid, out);
 }
 
@@ -470,10 +528,8 @@ static int draw_setup(const rrl_draw_t& d, DrawArgs& a, int& threads, size_t& ld
     if (rb->cap > (int64_t(1) << 21)) return RRL_ERANGE;
     a.mode = 2;
     a.n_chunks = int((rb->cap + kChunk - 1) / kChunk);
-    if (threads < 256) threads = 256;
-    if (a.n_chunks > 4096) threads = 1024;                 // the count-table scan dominates: spread it
-    lds = size_t(table_size) * 8 + size_t((B + 3) & ~3) * 4 + size_t(a.n_chunks + 2 + ((a.n_chunks + 1) >> 5)) * 4 +
-          size_t(1024) * 4 + 16;
+    if (threads < 64) threads = 64;
+    lds = size_t(table_size) * 8 + size_t((B + 3) & ~3) * 4 + size_t(rrl_replay::count_supers(rb->cap) + 2) * 4 + 16;
     return RRL_OK;
 }
 
@@ -538,12 +594,10 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
     if (n_pos < 0 || n_neg < 0 || B <= 0 || B > 1024) return RRL_ERANGE;
     if (rb->cap > (int64_t(1) << 21)) return RRL_ERANGE;
     const int n_chunks = int((rb->cap + kChunk - 1) / kChunk);
-    int threads = ((B + 63) / 64) * 64;
-    if (threads < 256) threads = 256;
-    if (n_chunks > 4096) threads = 1024;                 // the count-table scan dominates: spread it
+    const int threads = ((B + 63) / 64) * 64;
     int table_size = 64;
     while (table_size < 4 * B) table_size <<= 1;
-    const size_t lds = size_t(table_size) * 8 + size_t((B + 3) & ~3) * 4 + size_t(n_chunks + 2 + ((n_chunks + 1) >> 5)) * 4 + size_t(threads) * 4 + 16;
+    const size_t lds = size_t(table_size) * 8 + size_t((B + 3) & ~3) * 4 + size_t(rrl_replay::count_supers(rb->cap) + 2) * 4 + 16;
     static size_t granted = 64 * 1024;   // gfx950 has 160 KiB of LDS per CU; opt in (once per size) above the default
     if (lds > granted) {
         if (hipFuncSetAttribute((const void*)creplay_sample_gather_kernel,

@@ -64,7 +64,12 @@ def test_push_matches_oracle_including_wraparound(cap, chunks):
         ref_cnt = np.add.reduceat(np.r_[filled, np.zeros((-len(filled)) % 64, bool)].astype(np.int32),
                                   np.arange(0, len(filled), 64)) if len(filled) else np.zeros(0)
         got = mem.pos_cnt.cpu().numpy()
-        assert np.array_equal(got[:len(ref_cnt)], ref_cnt) and not got[len(ref_cnt):].any()
+        n_chunks = (cap + 63) // 64
+        base = (n_chunks + 3) // 4 * 4                     # second level: per-4096-slot counts (RRL_POS_CNT_LEN)
+        assert len(got) == base + (cap + 4095) // 4096
+        assert np.array_equal(got[:len(ref_cnt)], ref_cnt) and not got[len(ref_cnt):base].any()
+        first = np.r_[got[:n_chunks], np.zeros((-n_chunks) % 64, np.int32)]
+        assert np.array_equal(got[base:], first.reshape(-1, 64).sum(1))
 
 
 def test_masked_push_matches_oracle():
