@@ -17,16 +17,51 @@ __host__ __device__ __forceinline__ int64_t count_chunks(int64_t cap) { return (
 __host__ __device__ __forceinline__ int64_t count_supers(int64_t cap) { return (cap + kSuper - 1) / kSuper; }
 __host__ __device__ __forceinline__ int64_t super_base(int64_t cap) { return (count_chunks(cap) + 3) & ~int64_t(3); }
 
-// write one row into `slot`; keeps the per-chunk positive counts exact (pos_idx, replay_memory.py:50)
+// Both count levels += delta (delta in {-1, 0, +1}) for the active lanes of a wave: ONE pair of atomics per distinct
+// chunk for the first two distinct chunks (a wave pushes 64 consecutive slots: at most two chunks), lane by lane for
+// anything beyond that (a ring wrap).  4096 envs pushing into one super-chunk would otherwise queue hundreds of atomics
+// on one address (+4 us on the 11 us step kernel).  Call from converged code: every active lane of the wave.
+// `block_acc` (optional, LDS int[2]): the caller sums the second level per workgroup and pass instead -- the wave's net
+// goes to block_acc[super-chunk != s0], s0 = the super-chunk of the workgroup's first slot of the pass (256 consecutive
+// slots touch at most two), and the caller adds the two sums to memory after a barrier.
+__device__ __forceinline__ void wave_count_add(int32_t* chunk_cnt, int32_t* super_cnt, int chunk, int delta,
+                                               int* block_acc = nullptr, int s0 = 0) {
+    bool pending = delta != 0;
+    unsigned long long act = __ballot(pending);
+    if (!act) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int kPer = kSuper / kChunk;
+#pragma unroll
+    for (int round = 0; round < 2 && act; ++round) {
+        const int leader = __ffsll(act) - 1;
+        const int c0 = __shfl(chunk, leader, 64);
+        const bool same = pending & (chunk == c0);
+        const unsigned long long up = __ballot(same & (delta > 0)), down = __ballot(same & (delta < 0));
+        const int net = __popcll(up) - __popcll(down);
+        if (lane == leader && net != 0) {
+            atomicAdd(&chunk_cnt[c0], net);
+            if (block_acc) atomicAdd(&block_acc[(c0 / kPer) != s0], net);
+            else atomicAdd(&super_cnt[c0 / kPer], net);
+        }
+        pending = pending & !same;
+        act &= ~(up | down);
+    }
+    if (pending) {
+        atomicAdd(&chunk_cnt[chunk], delta);
+        if (block_acc) atomicAdd(&block_acc[(chunk / kPer) != s0], delta);
+        else atomicAdd(&super_cnt[chunk / kPer], delta);
+    }
+}
+
+// write one row into `slot`; keeps both levels of positive counts exact (pos_idx, replay_memory.py:50).
+// Call from converged code (all active lanes of the wave reach it together).
 __device__ __forceinline__ void store_values(const rrl_replay_t& rb, int64_t slot, int64_t size, float2 s,
-                                             float2 a, float r, float2 s2, float m) {
+                                             float2 a, float r, float2 s2, float m, int* block_acc = nullptr,
+                                             int s0 = 0) {
     if (rb.pos_cnt) {
         const int was = (slot < size) ? int(rb.r[slot] != 0.0f) : 0;
         const int delta = int(r != 0.0f) - was;
-        if (delta) {
-            atomicAdd(&rb.pos_cnt[slot / kChunk], delta);
-            atomicAdd(&rb.pos_cnt[super_base(rb.cap) + slot / kSuper], delta);
-        }
+        wave_count_add(rb.pos_cnt, rb.pos_cnt + super_base(rb.cap), int(slot / kChunk), delta, block_acc, s0);
     }
     ((float2*)rb.s)[slot] = s;
     ((float2*)rb.a)[slot] = a;

@@ -94,9 +94,18 @@ __device__ __forceinline__ double row16_sum_f64(double v) {
 // is evaluated next to the step's own draw -- two independent Philox + Box-Muller chains interleaved by the scheduler --
 // instead of after it for the lanes whose episode ended (at the bench's termination rate that is every wave: a second
 // ~1 us dependent chain).  Same function, same arguments, same bits; in the bandwidth regime it would be +70 % VALU work.
+// !SPECULATE (bandwidth regime): the second level of the safety buffer's positive counts is summed per workgroup and pass
+// in LDS (one atomic per workgroup and super-chunk instead of one per wave: 64 waves share a super-chunk's counter).
 template <class ENV, bool SPECULATE = false>
 __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArgs p) {
     constexpr int kBlock = rrl_host::kBlock;
+    constexpr bool kBlockSuper = !SPECULATE;
+    __shared__ int super_acc[2];
+    const bool counts = p.use_recovery_memory && p.recovery_memory.pos_cnt != nullptr;
+    if (kBlockSuper) {
+        if (threadIdx.x < 2) super_acc[threadIdx.x] = 0;
+        __syncthreads();
+    }
     const StepArgs& a = p.step;
     const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
     const int64_t mpos = p.memory.state[0], msize = p.memory.state[1];
@@ -109,6 +118,12 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
     for (int64_t it = 0; it < n_iter; ++it) {
         const int64_t i = it * stride + int64_t(blockIdx.x) * kBlock + threadIdx.x;
         const bool live = i < a.n;
+        int s0 = 0, s1 = 0;       // super-chunks of the workgroup's first and last safety-buffer slot of this pass
+        if (kBlockSuper && counts) {
+            const int64_t first = (rpos + it * stride + int64_t(blockIdx.x) * kBlock) % p.recovery_memory.cap;
+            s0 = int(first / rrl_replay::kSuper);
+            s1 = int(((first + kBlock - 1) % p.recovery_memory.cap) / rrl_replay::kSuper);
+        }
         bool cons = false, succ = false, epd = false, rec = false;
         if (live) {
             const double2 pp = a.pos[i];
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             rrl_replay::store_values(p.memory, (mpos + i) % p.memory.cap, msize, prev, stored, prew, nobs, mask);
             if (p.use_recovery_memory)
                 rrl_replay::store_values(p.recovery_memory, (rpos + i) % p.recovery_memory.cap, rsize, prev, act,
-                                         cons ? 1.0f : 0.0f, nobs, mask);
+                                         cons ? 1.0f : 0.0f, nobs, mask, kBlockSuper ? super_acc : nullptr, s0);
             // episode accounting
             const float er = p.ep_reward[i] + rew;
             rsum += double(rew);
@@ -203,6 +218,15 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             a.pos[i] = make_double2(nx, ny);
             a.t[i] = ti;
             a.obs[i] = make_float2(float(nx), float(ny));
+        }
+        if (kBlockSuper && counts) {
+            __syncthreads();
+            if (threadIdx.x < 2 && super_acc[threadIdx.x] != 0) {
+                int32_t* super_cnt = p.recovery_memory.pos_cnt + rrl_replay::super_base(p.recovery_memory.cap);
+                atomicAdd(&super_cnt[threadIdx.x ? s1 : s0], super_acc[threadIdx.x]);
+                super_acc[threadIdx.x] = 0;
+            }
+            __syncthreads();
         }
         // episode counters: one ballot + popcount per counter and wave (wave-uniform scalars, no cross-lane shuffles)
         const bool end_viol = epd & cons;
