@@ -4,7 +4,10 @@ ended in a constraint violation (definitions of plotting/plot_runs.py:214-235: s
 any constraint in the episode -- an episode ends at its first violation, so the per-episode flag of the last step);
 plus the env-steps and grad-steps spent until the first window with >= 90 % successes.
 
-    python profiles/learning_vec4096.py [updates_per_step=16] [iterations=1500] [first_seed=1] [last_seed=4]
+    python profiles/learning_vec4096.py [updates_per_step=16] [iterations=1500] [first_seed=1] [last_seed=4] [config=2]
+                                        [plan_precision]
+config 2 = Navigation1 model-free recovery (scripts/navigation1.sh:7), 3 = Maze model-free recovery (scripts/maze.sh:7),
+4 = Navigation2 model-based recovery (scripts/navigation2.sh:14; plan_precision f32 | f16x3).
 """
 import contextlib
 import io
@@ -22,13 +25,22 @@ from recovery_rl_amd.experiment import Experiment  # noqa: E402
 N = 4096
 
 
-def run(seed, U, iterations, log_every=25):
+CONFIGS = {
+    2: ["--env-name", "navigation1", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe", "0.3",
+        "--logdir_suffix", "RRL_MF", "--num_unsafe_transitions", "20000"],
+    3: ["--env-name", "maze", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.5", "--eps_safe", "0.15",
+        "--pos_fraction=0.3", "--logdir_suffix", "RRL_MF"],
+    4: ["--env-name", "navigation2", "--use_recovery", "--gamma_safe", "0.65", "--eps_safe", "0.2",
+        "--logdir_suffix", "RRL_MB", "--num_unsafe_transitions", "20000"],
+}
+
+
+def run(seed, U, iterations, log_every=25, config=2, precision=""):
     tmp = tempfile.mkdtemp()
-    cfg = arg_utils.get_args(["--cuda", "--env-name", "navigation1", "--use_recovery", "--MF_recovery", "--gamma_safe",
-                              "0.8", "--eps_safe", "0.3", "--logdir", tmp, "--logdir_suffix", "RRL_MF",
-                              "--num_unsafe_transitions", "20000", "--seed", str(seed), "--num_envs", str(N),
+    cfg = arg_utils.get_args(["--cuda"] + CONFIGS[config] +
+                             ["--logdir", tmp, "--seed", str(seed), "--num_envs", str(N),
                               "--updates_per_step", str(U), "--num_steps", str(N * iterations), "--num_eps", "100000000",
-                              "--log_every", str(log_every)])
+                              "--log_every", str(log_every)] + (["--plan_precision", precision] if precision else []))
     t0 = time.time()
     with contextlib.redirect_stdout(io.StringIO()):
         exp = Experiment(cfg)
@@ -49,7 +61,8 @@ def run(seed, U, iterations, log_every=25):
             first90 = {"env_steps": h["env_steps"], "grad_steps": h["sac_updates"], "iteration": h["iteration"]}
     last = hist[-1]
     tail = windows[-max(1, len(windows) // 5):]
-    return {"seed": seed, "num_envs": N, "updates_per_step": U, "iterations": last["iteration"],
+    return {"config": config, "plan_precision": precision or None,
+            "seed": seed, "num_envs": N, "updates_per_step": U, "iterations": last["iteration"],
             "env_steps": last["env_steps"], "sac_grad_steps": last["sac_updates"], "episodes": last["episodes"],
             "successes": last["num_successes"], "violations": last["num_viols"],
             "viol_and_recovery": last["viol_and_recovery"], "viol_and_no_recovery": last["viol_and_no_recovery"],
@@ -66,7 +79,9 @@ if __name__ == "__main__":
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
     lo = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     hi = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-    out = [run(s, U, iters) for s in range(lo, hi + 1)]
+    config = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+    precision = sys.argv[6] if len(sys.argv) > 6 else ""
+    out = [run(s, U, iters, config=config, precision=precision) for s in range(lo, hi + 1)]
     for r in out:
         print({k: v for k, v in r.items() if k != "windows"}, file=sys.stderr)
     print(json.dumps(out))
