@@ -748,7 +748,7 @@ int rrl_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed, float*
 static int nav_step_push_launch(int env_kind, const rrl_step::StepPushArgs& p, int64_t n, void* stream) {
     const dim3 grid(grid_for(n)), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
-    if (n <= 65536) {      // at most one wave per SIMD: latency-bound, the reset draw runs beside the step draw
+    if (n <= 16384) {      // a quarter of the SIMDs busy at most: latency-bound, the reset draw runs beside the step draw (at 65536 envs it costs 13 -> 17 us)
         if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<0>, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<1>, true>), grid, block, 0, st, p);
     } else {
