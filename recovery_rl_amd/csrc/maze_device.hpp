@@ -65,6 +65,29 @@ RRL_HD void substep_pos(double x, double y, double dx, double dy, int k, double&
     py = clampd(y + dy * f, -kLim, kLim);
 }
 
+// The bracket [t_in, t_out] and the jump lengths are ESTIMATES that only have to err on the safe side by less than the
+// one or two sub-steps of margin the scan keeps (the exact f64 predicate decides every visited sub-step), so they are
+// computed in f32 with v_rcp_f32 / v_sqrt_f32 (a handful of instructions instead of the ~25-instruction f64 division and
+// square-root sequences: with one wave per SIMD the step kernel's time IS this dependent chain).  The slabs are widened by
+// 1e-6 (f32 rounding of 0.3-sized coordinates is 3e-8) and a slightly negative discriminant counts as a grazing root.
+RRL_HD void slab_interval_f32(float p, float d, float c, float h, float& lo, float& hi) {
+    const float a = (c - h) - p, b = (c + h) - p;
+    if (d == 0.0f) {
+        const bool inside = (a <= 0.0f) & (b >= 0.0f);
+        lo = inside ? -1e30f : 1e30f;
+        hi = inside ? 1e30f : -1e30f;
+        return;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float inv = __builtin_amdgcn_rcpf(d);
+#else
+    const float inv = 1.0f / d;
+#endif
+    const float t0 = a * inv, t1 = b * inv;
+    lo = t0 < t1 ? t0 : t1;
+    hi = t0 < t1 ? t1 : t0;
+}
+
 // Entry parameter (in sub-steps, may be < 0 or > 64) of the segment p + t d, t in [0, 64], into the slab |v - c| <= h
 // of one coordinate; lo/hi = the parameter interval inside the slab.
 RRL_HD void slab_interval(double p, double d, double c, double h, double& lo, double& hi) {
@@ -96,13 +119,14 @@ RRL_HD void move(double& x, double& y, double ax, double ay) {
     int first = kSubsteps + 1;                                             // first sub-step in contact with anything
     // arena planes: contact where |v| >= kLim - kRadius, i.e. outside the slab |v| < 0.275
     {
-        double lo, hi, t_out = 1e300;
-        slab_interval(x, sx, 0.0, kLim - kRadius, lo, hi);                 // inside the slab for t in [lo, hi]
+        float lo, hi, t_out = 1e30f;
+        constexpr float kNarrow = 1e-6f;        // the slab shrunk: the estimated exit can only be early
+        slab_interval_f32(float(x), float(sx), 0.0f, float(kLim - kRadius) - kNarrow, lo, hi);   // inside for t in [lo, hi]
         t_out = hi < t_out ? hi : t_out;
-        slab_interval(y, sy, 0.0, kLim - kRadius, lo, hi);
+        slab_interval_f32(float(y), float(sy), 0.0f, float(kLim - kRadius) - kNarrow, lo, hi);
         t_out = hi < t_out ? hi : t_out;
-        // the move leaves the free square at t_out: candidates from the sub-step before it
-        int k = t_out >= double(kSubsteps + 1) ? kSubsteps + 1 : (t_out <= 1.0 ? 1 : int(t_out) - 1);
+        // the move leaves the free square at t_out: candidates from two sub-steps before it
+        int k = t_out >= float(kSubsteps + 2) ? kSubsteps + 1 : (t_out <= 2.0f ? 1 : int(t_out) - 2);
         k = k < 1 ? 1 : k;
         for (; k <= kSubsteps && k < first; ++k) {
             double px, py;
@@ -116,19 +140,30 @@ RRL_HD void move(double& x, double& y, double ax, double ay) {
     // walls with comparisons alone -- no divisions, no candidate loop.
     const double ex = clampd(x + dx, -kLim, kLim), ey = clampd(y + dy, -kLim, kLim);
     const double bx0 = x < ex ? x : ex, bx1 = x < ex ? ex : x, by0 = y < ey ? y : ey, by1 = y < ey ? ey : y;
+    // The walls are 0.2 apart in x and 0.3 apart in y, a move is 0.025 long: at most ONE wall survives the box test, so
+    // the search below exists once, with that wall's centre as data, instead of four times behind four branches (with one
+    // wave per SIMD the kernel's time is the number of instructions the wave walks through: every copy any lane needs).
+    // The loop form keeps it correct for any geometry: it simply runs once per surviving wall.
+    unsigned survivors = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         constexpr double kSlack = 1e-9;     // far above any rounding of the predicate, far below the geometry
-        if (wall_x(j) + (kWallHX + kRadius + kSlack) < bx0 || wall_x(j) - (kWallHX + kRadius + kSlack) > bx1 ||
-            wall_y(j) + (kWallHY + kRadius + kSlack) < by0 || wall_y(j) - (kWallHY + kRadius + kSlack) > by1)
-            continue;
-        double lox, hix, loy, hiy;
-        slab_interval(x, sx, wall_x(j), kWallHX + kRadius, lox, hix);
-        slab_interval(y, sy, wall_y(j), kWallHY + kRadius, loy, hiy);
-        const double t_in = lox > loy ? lox : loy, t_out = hix < hiy ? hix : hiy;
-        if (!(t_in <= t_out) || t_out < 0.0 || t_in > double(kSubsteps)) continue;   // the segment misses the box
-        int k = t_in <= 2.0 ? 1 : int(t_in) - 1;
-        int k_end = t_out >= double(kSubsteps) ? kSubsteps : int(t_out) + 2;
+        const bool out = wall_x(j) + (kWallHX + kRadius + kSlack) < bx0 || wall_x(j) - (kWallHX + kRadius + kSlack) > bx1 ||
+                         wall_y(j) + (kWallHY + kRadius + kSlack) < by0 || wall_y(j) - (kWallHY + kRadius + kSlack) > by1;
+        survivors |= out ? 0u : (1u << j);
+    }
+    while (survivors) {
+        const int j = __builtin_ctz(survivors);
+        survivors &= survivors - 1;
+        const double wcx = wall_x(j), wcy = wall_y(j);
+        float lox, hix, loy, hiy;
+        constexpr float kWide = 1e-6f;
+        slab_interval_f32(float(x), float(sx), float(wcx), float(kWallHX + kRadius) + kWide, lox, hix);
+        slab_interval_f32(float(y), float(sy), float(wcy), float(kWallHY + kRadius) + kWide, loy, hiy);
+        const float t_in = lox > loy ? lox : loy, t_out = hix < hiy ? hix : hiy;
+        if (!(t_in <= t_out) || t_out < -1.0f || t_in > float(kSubsteps + 1)) continue;   // the segment misses the box
+        int k = t_in <= 3.0f ? 1 : int(t_in) - 2;
+        int k_end = t_out >= float(kSubsteps - 1) ? kSubsteps : int(t_out) + 3;
         k_end = k_end > kSubsteps ? kSubsteps : k_end;
         // A candidate inside the inflated box that does not touch is in one of its four corner zones (beside the
         // rectangle in x AND in y): from there contact starts either where the path enters the circle around that
@@ -140,21 +175,24 @@ RRL_HD void move(double& x, double& y, double ax, double ay) {
         while (k <= k_end && k < first) {
             double px, py;
             substep_pos(x, y, dx, dy, k, px, py);
-            if (touches_wall(px, py, wall_x(j), wall_y(j))) { first = k; break; }
+            if (touches_wall(px, py, wcx, wcy)) { first = k; break; }
             int skip = 1;
-            const double ox = px - wall_x(j), oy = py - wall_y(j);
+            const double ox = px - wcx, oy = py - wcy;
             const double ax_ = fabs(ox) - kWallHX, ay_ = fabs(oy) - kWallHY;
             if (ax_ > 0.0 && ay_ > 0.0) {                      // corner zone (or still outside the box)
-                const double rx = ox > 0.0 ? ax_ : -ax_, ry = oy > 0.0 ? ay_ : -ay_;   // position relative to the corner
-                double tau = 1e300;                             // sub-steps until contact can begin
+                // position relative to the corner and motion per sub-step, f32 (estimates, see slab_interval_f32)
+                const float rx = float(ox > 0.0 ? ax_ : -ax_), ry = float(oy > 0.0 ? ay_ : -ay_);
+                const float fx = float(sx), fy = float(sy);
+                float tau = 1e30f;                              // sub-steps until contact can begin
                 // circle of radius r around the corner: |rel + tau s|^2 = r^2
-                const double qa = sx * sx + sy * sy, qb = rx * sx + ry * sy, qc = rx * rx + ry * ry - kRadius * kRadius;
-                const double disc = qb * qb - qa * qc;
-                if (qb < 0.0 && disc >= 0.0) tau = (-qb - sqrt(disc)) / qa;
+                const float qa = fx * fx + fy * fy, qb = rx * fx + ry * fy;
+                const float qc = rx * rx + ry * ry - float(kRadius * kRadius);
+                const float disc = qb * qb - qa * qc;
+                if (qb < 0.0f && disc >= -1e-4f * qb * qb) tau = (-qb - sqrtf(disc > 0.0f ? disc : 0.0f)) / qa;
                 // leaving the corner zone across the rectangle's edge lines (into a face zone of the box)
-                if (rx * sx < 0.0) { const double tx = -rx / sx; tau = tx < tau ? tx : tau; }
-                if (ry * sy < 0.0) { const double ty = -ry / sy; tau = ty < tau ? ty : tau; }
-                skip = tau >= double(kSubsteps) ? kSubsteps : int(tau) - 1;
+                if (rx * fx < 0.0f) { const float tx = -rx / fx; tau = tx < tau ? tx : tau; }
+                if (ry * fy < 0.0f) { const float ty = -ry / fy; tau = ty < tau ? ty : tau; }
+                skip = tau >= float(kSubsteps) ? kSubsteps : int(tau) - 2;
                 skip = skip < 1 ? 1 : skip;
             }
             k += skip;
