@@ -258,6 +258,18 @@ __device__ __forceinline__ void compact_load(const CompactArgs& a, int64_t q, in
             in.ay[k] = fy[k];
             in.st[k] = sw[k];
         }
+    } else if (V == 2 && have == 2) {
+        // two envs per thread: one 16-byte action load, one 4-byte status load
+#pragma unroll
+        for (int k = 0; k < V; ++k) in.p[k] = a.pos[i0 + k];
+        const float4 a01 = reinterpret_cast<const float4*>(a.action)[q];
+        const uint32_t sv = reinterpret_cast<const uint32_t*>(a.status)[q];
+        if constexpr (EXT_NOISE) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) in.e[k] = a.noise[i0 + k];
+        }
+        in.ax[0] = a01.x; in.ay[0] = a01.y; in.ax[1 % V] = a01.z; in.ay[1 % V] = a01.w;
+        in.st[0] = sv & 0xffffu; in.st[1 % V] = sv >> 16;
     } else {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -344,6 +356,12 @@ __global__ __launch_bounds__(kBlock) void nav_step_compact_kernel(CompactArgs a)
                 make_float4(nobs[2 % V].x, nobs[2 % V].y, nobs[3 % V].x, nobs[3 % V].y);
             reinterpret_cast<float4*>(a.reward)[q] = make_float4(rew[0], rew[1 % V], rew[2 % V], rew[3 % V]);
             reinterpret_cast<uint2*>(a.status)[q] = make_uint2(st[0] | (st[1 % V] << 16), st[2 % V] | (st[3 % V] << 16));
+        } else if (V == 2 && have == 2) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) a.pos[i0 + k] = p[k];
+            reinterpret_cast<float4*>(a.next_obs)[q] = make_float4(nobs[0].x, nobs[0].y, nobs[1 % V].x, nobs[1 % V].y);
+            reinterpret_cast<float2*>(a.reward)[q] = make_float2(rew[0], rew[1 % V]);
+            reinterpret_cast<uint32_t*>(a.status)[q] = st[0] | (st[1 % V] << 16);
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k)
@@ -665,8 +683,15 @@ int rrl_nav_step_compact(int env_kind, int64_t n, double* pos, const float* acti
     const auto go = [&](auto kind, auto ext) {
         constexpr int K = decltype(kind)::value;
         constexpr bool E = decltype(ext)::value;
-        if (n < (1 << 18)) {          // latency regime: one env per thread, resets inline
+        // envs per thread, measured at 2^24 envs in one process (profiles/nav_step_probe.py, RRL_NAV_V): without resets
+        // 1 and 2 run at 192 us, 4 at 220 us (115 VGPRs, 236 SGPR-spill reads per pass); with resets 241 / 231 / 236 us --
+        // the once-per-wave reset draw batches 64 V envs, and at V = 1 every finished lane costs its wave a second chain.
+        static const int v_env = [] { const char* e = getenv("RRL_NAV_V"); return e ? atoi(e) : 0; }();
+        const int v = v_env ? v_env : (n < (1 << 18) ? 1 : 2);
+        if (v == 1) {                 // also the latency regime: a short dependent chain per thread, resets inline
             hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 1>), dim3(grid_for(n)), block, 0, st, a);
+        } else if (v == 2) {
+            hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 2>), dim3(grid_for((n + 1) >> 1)), block, 0, st, a);
         } else {
             hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 4>), dim3(grid_for((n + 3) >> 2)), block, 0, st, a);
         }
