@@ -59,7 +59,7 @@ def test_step_matches_reference_golden_bit_exact(env, golden_dir):
 
 
 @pytest.mark.parametrize("env", ENVS)
-@pytest.mark.parametrize("n", (1, 63, 64, 257, 4096, 100003, 1 << 19, 600000))   # >= 2^19, n % 4 == 0: 4 envs/thread
+@pytest.mark.parametrize("n", (1, 63, 64, 257, 4096, 100003, 1 << 19, 600000, (1 << 22) + 2))   # >= 2^19, n % 4 == 0: 4 envs/thread; >= 2^22, even: 2
 def test_step_matches_oracle_with_philox_noise(env, n):
     rng = np.random.RandomState(n)
     pos = np.c_[rng.uniform(-60, 10, n), rng.uniform(-12, 12, n)]
@@ -100,7 +100,7 @@ def hip_step_compact(env_name, pos, action, t, noise=None, seed=0, counter=0, ho
 
 
 @pytest.mark.parametrize("env", ENVS)
-@pytest.mark.parametrize("n", (1, 2, 3, 4, 5, 63, 64, 257, 4096, 100003, 1 << 19, 600001))
+@pytest.mark.parametrize("n", (1, 2, 3, 4, 5, 63, 64, 257, 4096, 100003, 1 << 19, 600001, (1 << 22) + 3))
 def test_compact_step_matches_oracle_with_philox_noise(env, n):
     """rrl_nav_step_compact (u16 status words, sparse post-reset observation, finished episodes of a wave re-drawn
     once per workgroup and pass) against the C oracle: every field bit-exact; reset_obs rows of continuing episodes are
