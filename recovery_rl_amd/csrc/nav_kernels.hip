@@ -784,7 +784,8 @@ int rrl_nav_step_compact(int env_kind, int64_t n, double* pos, const float* acti
         // envs per thread, measured at 2^24 envs in one process (profiles/nav_step_probe.py, RRL_NAV_V): without resets
         // 1 and 2 run at 192 us, 4 at 220 us (115 VGPRs, 236 SGPR-spill reads per pass); with resets 241 / 231 / 236 us --
         // the once-per-wave reset draw batches 64 V envs, and at V = 1 every finished lane costs its wave a second chain.
-        // Below 2^22 envs four per thread: 2^20 envs are then ONE round of 4 waves per SIMD (24.5 us; two per thread 34 us).
+        // (Two passes of two envs sharing one reset draw -- positions held in registers across the passes -- came out at
+        // 118 VGPRs and the same 237 us.)  Below 2^22 envs four per thread: 2^20 envs are then ONE round of 4 waves per SIMD (24.5 us; two per thread 34 us).
         static const int v_env = [] { const char* e = getenv("RRL_NAV_V"); return e ? atoi(e) : 0; }();
         const int v = v_env ? v_env : (n < (1 << 18) ? 1 : (n < (1 << 22) ? 4 : 2));
         if (v == 1) {                 // also the latency regime: a short dependent chain per thread, resets inline
