@@ -244,7 +244,9 @@ int rrl_sample_multi(const rrl_draw_t* first, const rrl_draw_t* second, long lon
  * push_real_action, reward - penalty*constraint, next_obs, 1-done); recovery_memory (nullable) <- (obs,
  * real_action, constraint, next_obs, 1-done).  stats = uint64[8] {env_steps, episodes, num_viols,
  * viol_and_recovery, viol_and_no_recovery, num_successes, recovery_steps, constraint_steps};
- * reward_sums = double[2] {sum of rewards, sum of finished-episode returns}; ep_reward = float[n]. */
+ * reward_sums = double[2] {sum of rewards, sum of finished-episode returns}; ep_reward = float[n].
+ * next_obs, reward, done, constraint, success, ep_done are per-env outputs of the step for callers that read them
+ * (episode log, online model re-fit): each may be NULL (17 of the 171 B the kernel moves per env-step are theirs). */
 int rrl_nav_step_push(int env_kind, int64_t n, double* pos, int32_t* t, float* obs,
                       const float* task_action, const float* real_action, const uint8_t* recovery,
                       uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,

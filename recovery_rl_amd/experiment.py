@@ -71,6 +71,7 @@ class VectorLoop:
         self._actor = None
         self._one = torch.ones((), dtype=torch.int64, device=dev)
         self.episode_log = None           # optional EpisodeLog (per-episode records for run_stats)
+        self.step_outputs = True          # the fused step also writes env.next_obs / reward / done / constraint / success
         if self.n > 1 and hasattr(recovery_memory, "clamp_stratified"):
             # N envs overwrite the ring in capacity / N iterations: once the policy avoids violations the positive
             # class can drop below int(B * pos_fraction) rows, where the one-env reference would abort
@@ -204,6 +205,10 @@ class VectorLoop:
         if recovery is not None:
             rec_u8 = recovery if recovery.dtype == torch.uint8 else recovery.to(torch.uint8)
         use_rmem = uses_constraint_buffer(cfg)
+        # per-env outputs of the step (env.next_obs, env.reward, the flags): the kernel skips the ones it gets no pointer for;
+        # `step_outputs = False` is for callers that read nothing but the replay rows and the counters
+        keep = self.step_outputs or self.episode_log is not None or self.recovery_policy is not None
+        out_ptr = (lambda t: _lib.ptr(t)) if keep else (lambda t: None)
         select = getattr(self._actor, "pending_select", None) if self._actor is not None else None
         if select is not None:
             # the recovery gate runs inside the step kernel: `action` is the strided task action, `real_action` and
@@ -220,8 +225,8 @@ class VectorLoop:
                 env.seed_value, 0,
                 _lib.ptr(env.tick), 1, env.horizon, 1, float(cfg.constraint_reward_penalty),
                 int(bool(cfg.disable_action_relabeling)), C.byref(mem._desc), C.byref(rmem._desc) if use_rmem else None,
-                _lib.ptr(env.next_obs), _lib.ptr(env.reward), _lib.ptr(env.done), _lib.ptr(env.constraint),
-                _lib.ptr(env.success), _lib.ptr(env.ep_done), _lib.ptr(self.stats), _lib.ptr(self.reward_sums),
+                out_ptr(env.next_obs), out_ptr(env.reward), out_ptr(env.done), out_ptr(env.constraint),
+                out_ptr(env.success), out_ptr(env.ep_done), _lib.ptr(self.stats), _lib.ptr(self.reward_sums),
                 _lib.ptr(self.ep_reward), _lib.current_stream())
             _lib.check(rc, "rrl_step_push_select")
             mem._len = min(mem._len + self.n, mem.capacity)
@@ -246,9 +251,9 @@ class VectorLoop:
             *head, self.n, _lib.ptr(env.pos), _lib.ptr(env.t), _lib.ptr(env.obs), _lib.ptr(action),
             _lib.ptr(real_action), _lib.ptr(rec_u8), env.seed_value, 0, _lib.ptr(env.tick), 1, env.horizon, 1,
             float(cfg.constraint_reward_penalty), int(bool(cfg.disable_action_relabeling)),
-            C.byref(mem._desc), C.byref(rmem._desc) if use_rmem else None, _lib.ptr(env.next_obs),
-            _lib.ptr(env.reward), _lib.ptr(env.done), _lib.ptr(env.constraint), _lib.ptr(env.success),
-            _lib.ptr(env.ep_done), _lib.ptr(self.stats), _lib.ptr(self.reward_sums), _lib.ptr(self.ep_reward),
+            C.byref(mem._desc), C.byref(rmem._desc) if use_rmem else None, out_ptr(env.next_obs),
+            out_ptr(env.reward), out_ptr(env.done), out_ptr(env.constraint), out_ptr(env.success),
+            out_ptr(env.ep_done), _lib.ptr(self.stats), _lib.ptr(self.reward_sums), _lib.ptr(self.ep_reward),
             _lib.current_stream())
         _lib.check(rc, "rrl_step_push")
         mem._len = min(mem._len + self.n, mem.capacity)

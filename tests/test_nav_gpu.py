@@ -309,8 +309,10 @@ def test_full_size_properties_4096x100():
 
 
 @pytest.mark.parametrize("env", ENVS)
-def test_fused_step_push_matches_oracle_step_plus_pushes(env):
-    """rrl_nav_step_push == oracle nav_step + two oracle replay pushes + counters, over a wrap-around."""
+@pytest.mark.parametrize("with_outputs", [True, False])
+def test_fused_step_push_matches_oracle_step_plus_pushes(env, with_outputs):
+    """rrl_nav_step_push == oracle nav_step + two oracle replay pushes + counters, over a wrap-around; with and without
+    the optional per-env output arrays (next_obs, reward, flags: NULL = not written, everything else unchanged)."""
     import ctypes as C
     from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
     lib = _lib.load()
@@ -334,11 +336,19 @@ def test_fused_step_push_matches_oracle_step_plus_pushes(env):
         rc = lib.rrl_nav_step_push(
             co.ENV_KIND[env], n, _lib.ptr(venv.pos), _lib.ptr(venv.t), _lib.ptr(venv.obs), _lib.ptr(task),
             _lib.ptr(real), _lib.ptr(rec), 31, 0, _lib.ptr(venv.tick), 1, 100, 1, 2.5, 0, C.byref(mem._desc),
-            C.byref(rmem._desc), _lib.ptr(venv.next_obs), _lib.ptr(venv.reward), _lib.ptr(venv.done),
-            _lib.ptr(venv.constraint), _lib.ptr(venv.success), _lib.ptr(venv.ep_done), _lib.ptr(stats),
+            C.byref(rmem._desc), *([_lib.ptr(venv.next_obs), _lib.ptr(venv.reward), _lib.ptr(venv.done),
+                                    _lib.ptr(venv.constraint), _lib.ptr(venv.success), _lib.ptr(venv.ep_done)]
+                                   if with_outputs else [None] * 6), _lib.ptr(stats),
             _lib.ptr(sums), _lib.ptr(ep_reward), _lib.current_stream())
         assert rc == 0
         ref = co.nav_step(env, pos, real.cpu().numpy(), t, seed=31, counter=1 + k, auto_reset=True)
+        if with_outputs:
+            assert np.array_equal(venv.next_obs.cpu().numpy(), ref["next_obs"])
+            assert np.array_equal(venv.reward.cpu().numpy(), ref["reward"])
+            for key in ("done", "constraint", "success", "ep_done"):
+                assert np.array_equal(getattr(venv, key).cpu().numpy(), ref[key]), key
+        else:
+            assert not venv.next_obs.any() and not venv.reward.any() and not venv.done.any()
         pos, t = ref["pos"], ref["t"]
         mask = 1.0 - ref["done"].astype(np.float32)
         cons = ref["constraint"].astype(np.float32)
