@@ -12,20 +12,27 @@ namespace rrl_replay {
 constexpr int kChunk = 64;    // slots per positive-count chunk
 constexpr int kSuper = 4096;  // slots per second-level count (64 chunks)
 
-// pos_cnt layout: [n_chunks] per-chunk counts, padded to a multiple of 4, then [n_super] per-4096-slot counts
+// pos_cnt layout: [n_chunks] per-chunk counts, padded to a multiple of 4, then [n_super] per-4096-slot counts, padded to
+// a multiple of 2, then [n_chunks] 64-bit masks (bit b of mask c = slot 64 c + b holds a positive row)
 __host__ __device__ __forceinline__ int64_t count_chunks(int64_t cap) { return (cap + kChunk - 1) / kChunk; }
 __host__ __device__ __forceinline__ int64_t count_supers(int64_t cap) { return (cap + kSuper - 1) / kSuper; }
 __host__ __device__ __forceinline__ int64_t super_base(int64_t cap) { return (count_chunks(cap) + 3) & ~int64_t(3); }
+__host__ __device__ __forceinline__ int64_t mask_base(int64_t cap) {
+    return (super_base(cap) + count_supers(cap) + 1) & ~int64_t(1);
+}
+__device__ __forceinline__ unsigned long long* chunk_masks(const rrl_replay_t& rb) {
+    return reinterpret_cast<unsigned long long*>(rb.pos_cnt + mask_base(rb.cap));
+}
 
-// Both count levels += delta (delta in {-1, 0, +1}) for the active lanes of a wave: ONE pair of atomics per distinct
+// Both count levels += delta (delta in {-1, 0, +1}) and the chunk masks for the active lanes of a wave: ONE set of atomics per distinct
 // chunk for the first two distinct chunks (a wave pushes 64 consecutive slots: at most two chunks), lane by lane for
 // anything beyond that (a ring wrap).  4096 envs pushing into one super-chunk would otherwise queue hundreds of atomics
 // on one address (+4 us on the 11 us step kernel).  Call from converged code: every active lane of the wave.
 // `block_acc` (optional, LDS int[2]): the caller sums the second level per workgroup and pass instead -- the wave's net
 // goes to block_acc[super-chunk != s0], s0 = the super-chunk of the workgroup's first slot of the pass (256 consecutive
 // slots touch at most two), and the caller adds the two sums to memory after a barrier.
-__device__ __forceinline__ void wave_count_add(int32_t* chunk_cnt, int32_t* super_cnt, int chunk, int delta,
-                                               int* block_acc = nullptr, int s0 = 0) {
+__device__ __forceinline__ void wave_count_add(int32_t* chunk_cnt, int32_t* super_cnt, unsigned long long* masks,
+                                               int chunk, int bit, int delta, int* block_acc = nullptr, int s0 = 0) {
     bool pending = delta != 0;
     unsigned long long act = __ballot(pending);
     if (!act) return;
@@ -34,14 +41,27 @@ __device__ __forceinline__ void wave_count_add(int32_t* chunk_cnt, int32_t* supe
 #pragma unroll
     for (int round = 0; round < 2 && act; ++round) {
         const int leader = __ffsll(act) - 1;
-        const int c0 = __shfl(chunk, leader, 64);
+        const int c0 = __shfl(chunk, leader, 64), bit0 = __shfl(bit, leader, 64);
         const bool same = pending & (chunk == c0);
         const unsigned long long up = __ballot(same & (delta > 0)), down = __ballot(same & (delta < 0));
         const int net = __popcll(up) - __popcll(down);
-        if (lane == leader && net != 0) {
-            atomicAdd(&chunk_cnt[c0], net);
-            if (block_acc) atomicAdd(&block_acc[(c0 / kPer) != s0], net);
-            else atomicAdd(&super_cnt[c0 / kPer], net);
+        // the chunk's mask: when the group's lanes hold consecutive slots (they do unless the push was masked) the two
+        // ballots ARE the bits to set and to clear, shifted from lane numbers to slot numbers
+        const bool in_line = __ballot(same & (bit - bit0 != lane - leader)) == 0;
+        if (lane == leader) {
+            if (net != 0) {
+                atomicAdd(&chunk_cnt[c0], net);
+                if (block_acc) atomicAdd(&block_acc[(c0 / kPer) != s0], net);
+                else atomicAdd(&super_cnt[c0 / kPer], net);
+            }
+            if (in_line) {
+                if (up) atomicOr(&masks[c0], (up >> leader) << bit0);
+                if (down) atomicAnd(&masks[c0], ~((down >> leader) << bit0));
+            }
+        }
+        if (!in_line && same) {
+            if (delta > 0) atomicOr(&masks[chunk], 1ULL << bit);
+            else atomicAnd(&masks[chunk], ~(1ULL << bit));
         }
         pending = pending & !same;
         act &= ~(up | down);
@@ -50,6 +70,8 @@ __device__ __forceinline__ void wave_count_add(int32_t* chunk_cnt, int32_t* supe
         atomicAdd(&chunk_cnt[chunk], delta);
         if (block_acc) atomicAdd(&block_acc[(chunk / kPer) != s0], delta);
         else atomicAdd(&super_cnt[chunk / kPer], delta);
+        if (delta > 0) atomicOr(&masks[chunk], 1ULL << bit);
+        else atomicAnd(&masks[chunk], ~(1ULL << bit));
     }
 }
 
@@ -61,7 +83,8 @@ __device__ __forceinline__ void store_values(const rrl_replay_t& rb, int64_t slo
     if (rb.pos_cnt) {
         const int was = (slot < size) ? int(rb.r[slot] != 0.0f) : 0;
         const int delta = int(r != 0.0f) - was;
-        wave_count_add(rb.pos_cnt, rb.pos_cnt + super_base(rb.cap), int(slot / kChunk), delta, block_acc, s0);
+        wave_count_add(rb.pos_cnt, rb.pos_cnt + super_base(rb.cap), chunk_masks(rb), int(slot / kChunk),
+                       int(slot % kChunk), delta, block_acc, s0);
     }
     ((float2*)rb.s)[slot] = s;
     ((float2*)rb.a)[slot] = a;

@@ -379,33 +379,25 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
     if (rem >= 0) return;
 #endif
     const int64_t c0 = int64_t(a) * kChunk;
-    // the chunk's 64 rewards in 16 independent 16-byte loads (a serial scan chained up to 64 dependent loads);
-    // slots at or beyond `size` never match
-    float4 rv[kChunk / 4];
-    const bool whole = c0 + kChunk <= rb.cap;
-#pragma unroll
-    for (int q = 0; q < kChunk / 4; ++q) {
-        if (whole) {
-            rv[q] = reinterpret_cast<const float4*>(rb.r + c0)[q];
-        } else {
-            float t4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t4[u] = rb.r[min(c0 + 4 * q + u, rb.cap - 1)];
-            rv[q] = make_float4(t4[0], t4[1], t4[2], t4[3]);
-        }
-    }
+    // the chunk's bit mask instead of its 64 rewards (256 B and a 64-step compare chain per row: 6 of the kernel's 19 us):
+    // the rem-th set bit of the class's candidates, by popcounts of halves
     const int32_t filled_c = int32_t(min(int64_t(kChunk), max(int64_t(0), size - c0)));
+    const unsigned long long pos_bits = rrl_replay::chunk_masks(rb)[a];
+    const unsigned long long filled_bits = filled_c >= kChunk ? ~0ULL : ((1ULL << filled_c) - 1ULL);
+    unsigned long long cand = is_pos ? (pos_bits & filled_bits) : (filled_bits & ~pos_bits);
     int32_t slot_rel = -1;
+    if (rem < __popcll(cand)) {
+        int32_t at = 0;
 #pragma unroll
-    for (int q = 0; q < kChunk / 4; ++q) {
-        const float e4[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int pu = 4 * q + u;
-            const bool match = (pu < filled_c) & ((e4[u] != 0.0f) == is_pos);
-            slot_rel = (match & (rem == 0) & (slot_rel < 0)) ? pu : slot_rel;
-            rem -= int32_t(match);
+        for (int w = 32; w >= 1; w >>= 1) {
+            const unsigned long long low = cand & ((1ULL << w) - 1ULL);
+            const int32_t c = __popcll(low);
+            const bool upper = rem >= c;
+            rem -= upper ? c : 0;
+            cand = upper ? (cand >> w) : low;
+            at += upper ? w : 0;
         }
+        slot_rel = at;
     }
     const int64_t slot = slot_rel < 0 ? int64_t(-1) : c0 + slot_rel;
     if (slot < 0) {  // count table out of sync with the rows: flag, never read out of bounds

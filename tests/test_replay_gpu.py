@@ -66,10 +66,16 @@ def test_push_matches_oracle_including_wraparound(cap, chunks):
         got = mem.pos_cnt.cpu().numpy()
         n_chunks = (cap + 63) // 64
         base = (n_chunks + 3) // 4 * 4                     # second level: per-4096-slot counts (RRL_POS_CNT_LEN)
-        assert len(got) == base + (cap + 4095) // 4096
+        n_super = (cap + 4095) // 4096
+        mbase = (base + n_super + 1) // 2 * 2              # third region: one 64-bit mask per chunk
+        assert len(got) == mbase + 2 * n_chunks
         assert np.array_equal(got[:len(ref_cnt)], ref_cnt) and not got[len(ref_cnt):base].any()
         first = np.r_[got[:n_chunks], np.zeros((-n_chunks) % 64, np.int32)]
-        assert np.array_equal(got[base:], first.reshape(-1, 64).sum(1))
+        assert np.array_equal(got[base:base + n_super], first.reshape(-1, 64).sum(1))
+        masks = got[mbase:].view(np.uint64)
+        want = np.zeros(n_chunks * 64, bool)
+        want[:len(filled)] = filled
+        assert np.array_equal(masks, np.packbits(want.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).ravel())
 
 
 def test_masked_push_matches_oracle():
