@@ -145,14 +145,14 @@ int rrl_maze_offline(int64_t num_transitions, uint64_t seed, float* s, float* a,
  * Layout: structure-of-arrays ring, f32: s[cap,2] a[cap,2] r[cap] s2[cap,2] m[cap] = 32 B/row.
  *   state   device int64[4]: {position, size, ticket(internal, keep 0), error flag}
  *   pos_cnt device int32[RRL_POS_CNT_LEN(cap)] (zero-initialised) or NULL: number of rows with r != 0 per 64-slot chunk,
- *           then (from the next multiple of 4) per 4096-slot super-chunk, then (from the next multiple of 2) one
+ *           then (from the next multiple of 4) per 1024-slot super-chunk, then (from the next multiple of 2) one
  *           64-bit mask per chunk (bit b = slot 64 c + b holds such a row; 8-byte aligned: keep pos_cnt 8-byte
  *           aligned); maintained by push, consumed by the stratified sampler (replay_memory.py:50,58-66), which scans
- *           the second level only (cap / 4096 entries), one super-chunk's 64 first-level counts and one mask per
+ *           the second level only (cap / 1024 entries), one super-chunk's 16 first-level counts and one mask per
  *           drawn row.
  * ------------------------------------------------------------------------------------------ */
 #define RRL_POS_CNT_LEN(cap) \
-    ((((((((cap) + 63) / 64 + 3) / 4) * 4 + ((cap) + 4095) / 4096) + 1) / 2) * 2 + 2 * (((cap) + 63) / 64))
+    ((((((((cap) + 63) / 64 + 3) / 4) * 4 + ((cap) + 1023) / 1024) + 1) / 2) * 2 + 2 * (((cap) + 63) / 64))
 typedef struct {
     float* s;
     float* a;

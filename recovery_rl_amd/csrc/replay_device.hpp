@@ -10,9 +10,9 @@
 namespace rrl_replay {
 
 constexpr int kChunk = 64;    // slots per positive-count chunk
-constexpr int kSuper = 4096;  // slots per second-level count (64 chunks)
+constexpr int kSuper = 1024;  // slots per second-level count (16 chunks)
 
-// pos_cnt layout: [n_chunks] per-chunk counts, padded to a multiple of 4, then [n_super] per-4096-slot counts, padded to
+// pos_cnt layout: [n_chunks] per-chunk counts, padded to a multiple of 4, then [n_super] per-1024-slot counts, padded to
 // a multiple of 2, then [n_chunks] 64-bit masks (bit b of mask c = slot 64 c + b holds a positive row)
 __host__ __device__ __forceinline__ int64_t count_chunks(int64_t cap) { return (cap + kChunk - 1) / kChunk; }
 __host__ __device__ __forceinline__ int64_t count_supers(int64_t cap) { return (cap + kSuper - 1) / kSuper; }

@@ -260,19 +260,28 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
     int32_t* sup = (int32_t*)(key + ((B + 3) & ~3));      // [n_super + 1] exclusive positive counts per super-chunk
     const int64_t size = rb.state[1];
     const int tid = threadIdx.x;
-    // Second count level (one entry per 4096 slots, <= 512 of them) -> exclusive scan in LDS.  (The first version
+    // Second count level (one entry per 1024 slots, <= 2048 of them) -> exclusive scan in LDS.  (The first version
     // copied and scanned the whole first level -- 15 625 entries at 1e6 slots, 62 KB -- in this one workgroup: 27 us.)
     const int n_super = int(rrl_replay::count_supers(rb.cap));
     const int32_t* sup_cnt = rb.pos_cnt + rrl_replay::super_base(rb.cap);
-    // wave 0: lane l owns entries 8 l .. 8 l + 7 (cap <= 2^21: at most 512 entries), wave prefix by shuffles
+    // wave 0: lane l owns entries 32 l .. 32 l + 31 (cap <= 2^21: at most 2048 entries), wave prefix by shuffles
     if (tid < 64) {
-        int32_t v[8], run = 0;
+        constexpr int kOwn = 32;
+        int32_t v[kOwn], run = 0;
+        const bool vec = (reinterpret_cast<uintptr_t>(sup_cnt) & 15) == 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = 8 * tid + u;
-            v[u] = c < n_super ? sup_cnt[c] : 0;
-            run += v[u];
+        for (int q = 0; q < kOwn / 4; ++q) {             // eight independent 16-byte loads per lane, in flight together
+            const int c = kOwn * tid + 4 * q;
+            if (vec && c + 3 < n_super) {
+                const int4 t4 = *reinterpret_cast<const int4*>(sup_cnt + c);
+                v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * q + u] = c + u < n_super ? sup_cnt[c + u] : 0;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < kOwn; ++u) run += v[u];
         int32_t incl = run;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -281,12 +290,12 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
         }
         int32_t acc = incl - run;                      // exclusive prefix of this lane's first entry
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = 8 * tid + u;
+        for (int u = 0; u < kOwn; ++u) {
+            const int c = kOwn * tid + u;
             if (c <= n_super) sup[c] = acc;
             acc += v[u];
         }
-        if (8 * tid + 8 == n_super) sup[n_super] = acc;     // total, when n_super is a multiple of 8
+        if (kOwn * tid + kOwn == n_super) sup[n_super] = acc;     // total, when n_super is a multiple of kOwn
     }
     __syncthreads();
     const int64_t total_pos = sup[n_super];
@@ -333,7 +342,7 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
         const int mid = (sa + sb) >> 1;
         if (before_super(mid) <= k) sa = mid; else sb = mid;
     }
-    constexpr int kPer = rrl_replay::kSuper / kChunk;     // 64 chunks per super-chunk
+    constexpr int kPer = rrl_replay::kSuper / kChunk;     // 16 chunks per super-chunk
     const int c_first = sa * kPer;
     int4 cv[kPer / 4];
     {
@@ -353,7 +362,7 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
     }
     // From here on everything is relative to the super-chunk / chunk and fits 32 bits (the 64-bit version of these two
     // 64-step walks was 20 of the kernel's 26 us: ~1300 emulated-int64 instructions per lane on a single CU).
-    int32_t rem = int32_t(k - before_super(sa));                          // rank inside the super-chunk, < 4096
+    int32_t rem = int32_t(k - before_super(sa));                          // rank inside the super-chunk, < 1024
     const int64_t sup_lo = int64_t(c_first) * kChunk;
     const int32_t filled_sup = int32_t(min(int64_t(rrl_replay::kSuper), max(int64_t(0), size - sup_lo)));
     int32_t a_rel = -1;

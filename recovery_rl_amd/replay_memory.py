@@ -34,10 +34,10 @@ class ReplayMemory:
         self.m = torch.zeros(cap, dtype=torch.float32, device=dev)
         self.state = torch.zeros(4, dtype=torch.int64, device=dev)   # position, size, ticket, error
         self.tick = torch.zeros(2, dtype=torch.int64, device=dev)    # sampling RNG tick
-        # per-64-slot positive counts, then (from the next multiple of 4) per-4096-slot counts, then (from the next
+        # per-64-slot positive counts, then (from the next multiple of 4) per-1024-slot counts, then (from the next
         # multiple of 2) one 64-bit mask per chunk: RRL_POS_CNT_LEN(cap)
         n_chunks = (cap + 63) // 64
-        n_cnt = (((n_chunks + 3) // 4) * 4 + (cap + 4095) // 4096 + 1) // 2 * 2 + 2 * n_chunks
+        n_cnt = (((n_chunks + 3) // 4) * 4 + (cap + 1023) // 1024 + 1) // 2 * 2 + 2 * n_chunks
         self.pos_cnt = torch.zeros(n_cnt, dtype=torch.int32, device=dev) if self._WITH_POS_COUNTS else None
         self._desc = _lib.rrl_replay_t(self.s.data_ptr(), self.a.data_ptr(), self.r.data_ptr(),
                                        self.s2.data_ptr(), self.m.data_ptr(), cap,

@@ -65,13 +65,13 @@ def test_push_matches_oracle_including_wraparound(cap, chunks):
                                   np.arange(0, len(filled), 64)) if len(filled) else np.zeros(0)
         got = mem.pos_cnt.cpu().numpy()
         n_chunks = (cap + 63) // 64
-        base = (n_chunks + 3) // 4 * 4                     # second level: per-4096-slot counts (RRL_POS_CNT_LEN)
-        n_super = (cap + 4095) // 4096
+        base = (n_chunks + 3) // 4 * 4                     # second level: per-1024-slot counts (RRL_POS_CNT_LEN)
+        n_super = (cap + 1023) // 1024
         mbase = (base + n_super + 1) // 2 * 2              # third region: one 64-bit mask per chunk
         assert len(got) == mbase + 2 * n_chunks
         assert np.array_equal(got[:len(ref_cnt)], ref_cnt) and not got[len(ref_cnt):base].any()
-        first = np.r_[got[:n_chunks], np.zeros((-n_chunks) % 64, np.int32)]
-        assert np.array_equal(got[base:base + n_super], first.reshape(-1, 64).sum(1))
+        first = np.r_[got[:n_chunks], np.zeros((-n_chunks) % 16, np.int32)]
+        assert np.array_equal(got[base:base + n_super], first.reshape(-1, 16).sum(1))
         masks = got[mbase:].view(np.uint64)
         want = np.zeros(n_chunks * 64, bool)
         want[:len(filled)] = filled
