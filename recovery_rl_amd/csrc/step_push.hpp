@@ -112,18 +112,25 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
     int64_t rpos = 0, rsize = 0;
     if (p.use_recovery_memory) { rpos = p.recovery_memory.state[0]; rsize = p.recovery_memory.state[1]; }
     // ONE ticket for the three device-side cursors (both replay rings and the RNG tick): a returning device-scope atomic
-    // is a ~0.7 us round trip, three in a row were a sixth of this kernel.  It is taken HERE, right after this workgroup
-    // has read the cursors: the workgroup that draws the last ticket knows that every workgroup has read them, which is
-    // all the update has to wait for -- and the round trip runs under the env step instead of after it.
-    __syncthreads();            // every thread of this workgroup holds its copies of the cursors
-    if (threadIdx.x == 0) {
-        const unsigned long long ticket = atomicAdd((unsigned long long*)&p.memory.state[2], 1ULL);
-        if (ticket == gridDim.x - 1) {
-            p.memory.state[2] = 0;
-            rrl_replay::set_ring(p.memory, mpos, msize, a.n);
-            if (p.use_recovery_memory) rrl_replay::set_ring(p.recovery_memory, rpos, rsize, a.n);
-            if (a.counter_dev && a.counter_inc) a.counter_dev[0] += a.counter_inc;
+    // is a ~0.7 us round trip, three in a row were a sixth of this kernel.  The workgroup that draws the last ticket knows
+    // that every workgroup has read the cursors, which is all their update has to wait for.  In the latency regime (a few
+    // workgroups) it is drawn right after the cursors are read, so the round trip runs under the env step; with thousands
+    // of workgroups that would be a burst of atomics on one address at launch (+8 us at 2^20 envs) -- there it stays at
+    // the end, where the workgroups arrive spread out.
+    const auto draw_ticket = [&]() {
+        if (threadIdx.x == 0) {
+            const unsigned long long ticket = atomicAdd((unsigned long long*)&p.memory.state[2], 1ULL);
+            if (ticket == gridDim.x - 1) {
+                p.memory.state[2] = 0;
+                rrl_replay::set_ring(p.memory, mpos, msize, a.n);
+                if (p.use_recovery_memory) rrl_replay::set_ring(p.recovery_memory, rpos, rsize, a.n);
+                if (a.counter_dev && a.counter_inc) a.counter_dev[0] += a.counter_inc;
+            }
         }
+    };
+    if constexpr (SPECULATE) {
+        __syncthreads();            // every thread of this workgroup holds its copies of the cursors
+        draw_ticket();
     }
     double rsum = 0.0, retsum = 0.0;
     unsigned cnt[kCounters] = {0, 0, 0, 0, 0, 0, 0};
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
     } else if (blockIdx.x == 0 && threadIdx.x == 64) {
         atomicAdd(p.stats, (unsigned long long)a.n);
     }
+    if constexpr (!SPECULATE) draw_ticket();
 }
 
 // host side: argument block shared by the navigation and maze entry points
