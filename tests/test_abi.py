@@ -73,3 +73,25 @@ def test_header_is_plain_c(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"),
                            str(src)])
+
+
+def test_pos_cnt_length_macro_matches_the_python_allocation(tmp_path):
+    """RRL_POS_CNT_LEN(cap) of the header (what a binding allocates for rrl_replay_t.pos_cnt: chunk counts, super-chunk
+    counts, chunk masks) equals the length replay_memory.py allocates, for aligned and ragged capacities."""
+    import subprocess
+    caps = [1, 63, 64, 65, 1000, 1023, 1024, 1025, 4096, 5000, 70000, 1000000, 1 << 21]
+    src = tmp_path / "len.c"
+    src.write_text('#include <stdio.h>\n#include "rrl_hip.h"\nint main(void) {\n' +
+                   "".join('  printf("%%lld\\n", (long long)RRL_POS_CNT_LEN(%dLL));\n' % c for c in caps) +
+                   "  return 0;\n}\n")
+    exe = tmp_path / "len"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+                           str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = []
+    for cap in caps:
+        n_chunks = (cap + 63) // 64
+        want.append((((n_chunks + 3) // 4) * 4 + (cap + 1023) // 1024 + 1) // 2 * 2 + 2 * n_chunks)
+    assert got == want
+    src_py = open(os.path.join(ROOT, "recovery_rl_amd", "replay_memory.py")).read()
+    assert "(((n_chunks + 3) // 4) * 4 + (cap + 1023) // 1024 + 1) // 2 * 2 + 2 * n_chunks" in src_py
