@@ -1,10 +1,11 @@
 // nav_kernels.hip -- batched Navigation1 / Navigation2 env kernels for gfx950 (MI355X).
 //
-// One lane per env, structure-of-arrays state in HBM, every access unit-stride across the
-// 64-lane wavefront.  The kernels are HBM-bound streaming kernels (DESIGN.md "nav_step"):
-// 28 B read + 43 B written per env-step; all arithmetic in registers (Philox + Box-Muller +
-// two fp64 adds), no LDS, no inter-lane traffic.  Grid: <=2048 workgroups of 256 threads,
-// grid-stride, so a launch covers the 256 CUs (8 XCDs) with 8 workgroups per CU.
+// Structure-of-arrays state in HBM, every access unit-stride across the 64-lane wavefront; one, two or four
+// consecutive envs per lane depending on the launch size (latency regime / one resident round / streaming).
+// General layout (rrl_nav_step: the reference's arrays): 28 B read + 44 B written per env-step; compact layout
+// (rrl_nav_step_compact: u16 status words, one observation array): 26 B + 30 B.  All arithmetic in registers
+// (Philox + Box-Muller in f64); LDS only for the per-wave list of finished rows whose start states are drawn
+// once per wave and pass.  Grid: <= 2048 workgroups of 256 threads, grid-stride.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
