@@ -29,6 +29,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import recovery_rl_amd  # noqa: E402,F401  (sets the HIP runtime's graph-replay mode before the runtime starts)
 
 NUM_ENVS = 4096
 MIN_TIMED_S = 0.5
