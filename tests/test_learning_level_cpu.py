@@ -1,5 +1,5 @@
 """Learning-level parity (SURVEY 8d "parity gates"): cumulative task successes / constraint violations over 400
-episodes of scripts/navigation1.sh:7, this stack (profiles/round1_learning_seeds.json, 8 seeds on one MI355X) against
+episodes of scripts/navigation1.sh:7, this stack (profiles/round2_learning_seeds.json = the round-2 build, and round 1's file; 8 seeds on one MI355X) against
 the REFERENCE's own runs of the same command line (tests/golden/ref_learning_nav1_seed*.json, produced by
 tests/golden/run_reference_training.py on the CPU of the build container).  RNG streams differ, so the comparison
 is between the seed-to-seed distributions, with the definitions of plotting/plot_runs.py:214-235."""
@@ -12,14 +12,20 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _load():
+import pytest
+
+RUNS = ("round2_learning_seeds.json", "round1_learning_seeds.json")
+
+
+def _load(name=RUNS[0]):
     ref = [json.load(open(p)) for p in sorted(glob.glob(os.path.join(HERE, "golden", "ref_learning_nav1_seed*.json")))]
-    mine = json.load(open(os.path.join(HERE, "..", "profiles", "round1_learning_seeds.json")))["runs"]
+    mine = json.load(open(os.path.join(HERE, "..", "profiles", name)))["runs"]
     return ref, mine
 
 
-def test_success_and_violation_counts_lie_in_the_reference_spread():
-    ref, mine = _load()
+@pytest.mark.parametrize("name", RUNS)
+def test_success_and_violation_counts_lie_in_the_reference_spread(name):
+    ref, mine = _load(name)
     assert len(ref) >= 3 and len(mine) == 8
     for key, slack in (("total_successes", 6), ("total_violations", 2), ("env_steps", 800)):
         r = np.array([x[key] for x in ref], dtype=np.float64)
@@ -30,9 +36,10 @@ def test_success_and_violation_counts_lie_in_the_reference_spread():
         assert m.min() >= r.min() - 3 * spread - slack and m.max() <= r.max() + 3 * spread + slack, (key, r, m)
 
 
-def test_learning_curves_have_the_reference_shape():
+@pytest.mark.parametrize("name", RUNS)
+def test_learning_curves_have_the_reference_shape(name):
     """Cumulative successes after 100 / 200 / 400 episodes (the y axis of plot_runs.py PLOT_TYPE 'success')."""
-    ref, mine = _load()
+    ref, mine = _load(name)
     for upto in (100, 200, 400):
         r = np.array([sum(x["successes"][:upto]) for x in ref], dtype=np.float64)
         m = np.array([sum(x["successes"][:upto]) for x in mine], dtype=np.float64)
