@@ -209,8 +209,14 @@ int rrl_maze_step_push(int64_t n, double* pos, int32_t* t, float* obs, const flo
                                        memory, recovery_memory, next_obs, reward, done, constraint, success, ep_done,
                                        stats, reward_sums, ep_reward);
     if (rc != RRL_OK || n == 0) return rc;
-    hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv>), dim3(grid_for(n)), dim3(kBlock), 0,
-                       (hipStream_t)stream, p);
+    // latency regime: the reset draw (one Philox call + the contact test of the candidate; the start region is clear of
+    // the walls, so the rejection loop runs once) beside the move instead of after it, and the early cursor ticket
+    if (n <= 16384)
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv, true>), dim3(grid_for(n)), dim3(kBlock), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv>), dim3(grid_for(n)), dim3(kBlock), 0,
+                           (hipStream_t)stream, p);
     return check_launch();
 }
 
@@ -229,8 +235,14 @@ int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, co
                                        memory, recovery_memory, next_obs, reward, done, constraint, success, ep_done,
                                        stats, reward_sums, ep_reward);
     if (rc != RRL_OK || n == 0) return rc;
-    hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv>), dim3(grid_for(n)), dim3(kBlock), 0,
-                       (hipStream_t)stream, p);
+    // latency regime: the reset draw (one Philox call + the contact test of the candidate; the start region is clear of
+    // the walls, so the rejection loop runs once) beside the move instead of after it, and the early cursor ticket
+    if (n <= 16384)
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv, true>), dim3(grid_for(n)), dim3(kBlock), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv>), dim3(grid_for(n)), dim3(kBlock), 0,
+                           (hipStream_t)stream, p);
     return check_launch();
 }
 
