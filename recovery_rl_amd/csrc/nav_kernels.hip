@@ -82,8 +82,9 @@ __global__ __launch_bounds__(kBlock) void nav_step_kernel(StepArgs a) {
 // them in ONE trip (instead of one trip per k with any finished lane: 2.2 trips per pass at a 1.2 % termination rate), and
 // the owners read the pair back and store it with their dense stores -- no scattered store anywhere.
 template <int V>
-__device__ __forceinline__ void wave_reset_draws(uint64_t seed, uint64_t ctr, int64_t i0, const bool (&fin)[V],
-                                                 double (&z0)[V], double (&z1)[V], uint32_t* rows, double2* draws) {
+__device__ __forceinline__ void wave_reset_draws(uint64_t seed, uint64_t ctr, const uint32_t (&row)[V],
+                                                 const bool (&fin)[V], double (&z0)[V], double (&z1)[V], uint32_t* rows,
+                                                 double2* draws) {
     const int lane = threadIdx.x & 63;
     const uint64_t below = (1ULL << lane) - 1ULL;
     int slot[V], total = 0;
@@ -97,12 +98,12 @@ __device__ __forceinline__ void wave_reset_draws(uint64_t seed, uint64_t ctr, in
     if (total > 64) {
 #pragma unroll
         for (int k = 0; k < V; ++k)
-            if (fin[k]) rrl::normal_at(seed, uint32_t(i0 + k), rrl::kStreamReset, ctr, z0[k], z1[k]);
+            if (fin[k]) rrl::normal_at(seed, row[k], rrl::kStreamReset, ctr, z0[k], z1[k]);
         return;
     }
 #pragma unroll
     for (int k = 0; k < V; ++k)
-        if (fin[k]) rows[slot[k]] = uint32_t(i0 + k);
+        if (fin[k]) rows[slot[k]] = row[k];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < total) {
@@ -120,6 +121,16 @@ __device__ __forceinline__ void wave_reset_draws(uint64_t seed, uint64_t ctr, in
             z1[k] = d.y;
         }
     __builtin_amdgcn_wave_barrier();   // the lists are reused by the wave's next pass
+}
+
+// the same for V consecutive rows from i0
+template <int V>
+__device__ __forceinline__ void wave_reset_draws(uint64_t seed, uint64_t ctr, int64_t i0, const bool (&fin)[V],
+                                                 double (&z0)[V], double (&z1)[V], uint32_t* rows, double2* draws) {
+    uint32_t row[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) row[k] = uint32_t(i0 + k);
+    wave_reset_draws<V>(seed, ctr, row, fin, z0, z1, rows, draws);
 }
 
 // Mid-range variant (2^19 <= n < 2^22, n % 4 == 0; measured: 34.9 -> 27.1 us at 2^20, slower below 2^18): one thread steps FOUR consecutive envs
@@ -461,6 +472,131 @@ __global__ __launch_bounds__(kBlock) void nav_step_compact_kernel(CompactArgs a)
     rrl::advance_counter(a.counter_dev, a.counter_inc);
 }
 
+// Streaming variant of the compact step (n >= 2^22): two envs per thread, and HOLD passes share ONE reset draw.  A pass
+// stores what a reset does not touch (next_obs, reward) at once and parks its positions, status words and finished flags
+// in LDS (40 B per thread and pass); after HOLD passes the wave draws the start states of all the rows it finished in
+// them in one trip through normal_at(), applies them to the parked positions and stores positions and status words
+// densely.  At a 1.2 % termination rate that is ~1 trip per 64 x 2 x HOLD envs instead of 0.79 per 128.  The passes of a
+// group run in a loop that is NOT unrolled: the register footprint stays that of one pass (holding them in registers
+// let the compiler interleave them: 118 VGPRs, no gain).
+struct HeldPass {
+    double2 p[2][kBlock];
+    uint32_t st[kBlock];       // both status words
+    uint32_t fin[kBlock];      // bit k: row k finished and takes a reset
+};
+
+template <int KIND, bool EXT_NOISE, int HOLD>
+__global__ __launch_bounds__(kBlock) void nav_step_compact_hold_kernel(CompactArgs a) {
+    constexpr int V = 2;
+    __shared__ HeldPass held[HOLD];
+    __shared__ uint32_t wave_rows[kBlock / 64][64];
+    __shared__ double2 wave_draws[kBlock / 64][64];
+    const int tid = threadIdx.x;
+    const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
+    const int64_t nq = (a.n + V - 1) / V, stride = int64_t(gridDim.x) * kBlock;
+    const int64_t n_pass = (nq + stride - 1) / stride;     // uniform trip count: the reset lists need whole waves
+    const int64_t q_first = int64_t(blockIdx.x) * kBlock + tid;
+    const auto group_of = [&](int64_t pass) {              // idle lanes shadow the last group and store nothing
+        const int64_t q = pass * stride + q_first;
+        return q < nq ? q : nq - 1;
+    };
+    const auto have_of = [&](int64_t q) { return int(a.n - q * V < V ? a.n - q * V : V); };
+    for (int64_t pass0 = 0; pass0 < n_pass; pass0 += HOLD) {
+        const int n_here = int(n_pass - pass0 < HOLD ? n_pass - pass0 : HOLD);      // wave-uniform
+#pragma unroll 1
+        for (int h = 0; h < n_here; ++h) {
+            const int64_t pass = pass0 + h;
+            const bool live = pass * stride + q_first < nq;
+            const int64_t q = group_of(pass);
+            const int64_t i0 = q * V;
+            const int have = have_of(q);
+            CompactIn<V, EXT_NOISE> in;
+            compact_load<V, EXT_NOISE>(a, q, have, in);
+            float2 nobs[V];
+            float rew[V];
+            uint32_t st[V], finbits = 0;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                double ex, ey;
+                if constexpr (EXT_NOISE) {
+                    ex = in.e[k].x;
+                    ey = in.e[k].y;
+                } else {
+                    rrl::normal_at(a.seed, uint32_t(i0 + k), rrl::kStreamStep, ctr, ex, ey);
+                }
+                double nx, ny, cost;
+                rrl::nav_transition<KIND>(in.p[k].x, in.p[k].y, double(in.ax[k]), double(in.ay[k]), ex, ey, nx, ny, cost);
+                const bool cons = rrl::in_obstacle<KIND>(nx, ny);
+                const bool succ = cost > -4.0;
+                const bool dn = succ | cons;
+                uint32_t ti = (in.st[k] & RRL_STATUS_STEPS) + 1u;
+                const bool epd = dn | (int32_t(ti) == a.horizon);
+                if (ti > RRL_STATUS_STEPS) ti = RRL_STATUS_STEPS;
+                nobs[k] = make_float2(float(nx), float(ny));
+                rew[k] = float(cost);
+                const bool f = live & (k < have) & epd & (a.auto_reset != 0);
+                finbits |= uint32_t(f) << k;
+                st[k] = (f ? 0u : ti) | (dn ? RRL_STATUS_DONE : 0u) | (cons ? RRL_STATUS_CONSTRAINT : 0u) |
+                        (succ ? RRL_STATUS_SUCCESS : 0u) | (epd ? RRL_STATUS_EP_DONE : 0u);
+                held[h].p[k][tid] = make_double2(nx, ny);
+            }
+            held[h].st[tid] = st[0] | (st[1] << 16);
+            held[h].fin[tid] = finbits;
+            if (live) {
+                if (have == 2) {
+                    reinterpret_cast<float4*>(a.next_obs)[q] = make_float4(nobs[0].x, nobs[0].y, nobs[1].x, nobs[1].y);
+                    reinterpret_cast<float2*>(a.reward)[q] = make_float2(rew[0], rew[1]);
+                } else {
+                    a.next_obs[i0] = nobs[0];
+                    a.reward[i0] = rew[0];
+                }
+            }
+        }
+        // one reset draw for the rows this wave finished in the group's passes (own LDS slots: no barrier needed)
+        bool fin[HOLD * V];
+        uint32_t row[HOLD * V];
+#pragma unroll
+        for (int h = 0; h < HOLD; ++h) {
+            const uint32_t fb = h < n_here ? held[h].fin[tid] : 0u;
+            const int64_t q = group_of(h < n_here ? pass0 + h : pass0);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                fin[h * V + k] = (fb >> k) & 1u;
+                row[h * V + k] = uint32_t(q * V + k);
+            }
+        }
+        double w0[HOLD * V], w1[HOLD * V];
+        wave_reset_draws<HOLD * V>(a.seed, ctr, row, fin, w0, w1, wave_rows[tid >> 6], wave_draws[tid >> 6]);
+#pragma unroll
+        for (int h = 0; h < HOLD; ++h) {
+            if (h >= n_here) continue;
+            const int64_t pass = pass0 + h;
+            if (!(pass * stride + q_first < nq)) continue;
+            const int64_t q = group_of(pass), i0 = q * V;
+            const int have = have_of(q);
+            double2 p[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                p[k] = held[h].p[k][tid];
+                if (fin[h * V + k]) {
+                    p[k] = make_double2(-50.0 + w0[h * V + k], 0.0 + w1[h * V + k]);     // START_STATE + randn(2), navigation1.py:92
+                    if (a.reset_obs) a.reset_obs[i0 + k] = make_float2(float(p[k].x), float(p[k].y));
+                }
+            }
+            const uint32_t stw = held[h].st[tid];
+            if (have == 2) {
+                a.pos[i0] = p[0];
+                a.pos[i0 + 1] = p[1];
+                reinterpret_cast<uint32_t*>(a.status)[q] = stw;
+            } else {
+                a.pos[i0] = p[0];
+                a.status[i0] = uint16_t(stw & 0xffffu);
+            }
+        }
+    }
+    rrl::advance_counter(a.counter_dev, a.counter_inc);
+}
+
 __global__ __launch_bounds__(kBlock) void nav_reset_kernel(int64_t n, double2* pos, float2* obs,
                                                            int32_t* t, const uint8_t* mask,
                                                            const double2* noise, uint64_t seed,
@@ -785,14 +921,18 @@ int rrl_nav_step_compact(int env_kind, int64_t n, double* pos, const float* acti
         // envs per thread, measured at 2^24 envs in one process (profiles/nav_step_probe.py, RRL_NAV_V): without resets
         // 1 and 2 run at 192 us, 4 at 220 us (115 VGPRs, 236 SGPR-spill reads per pass); with resets 241 / 231 / 236 us --
         // the once-per-wave reset draw batches 64 V envs, and at V = 1 every finished lane costs its wave a second chain.
-        // (Two passes of two envs sharing one reset draw -- positions held in registers across the passes -- came out at
-        // 118 VGPRs and the same 237 us.)  Below 2^22 envs four per thread: 2^20 envs are then ONE round of 4 waves per SIMD (24.5 us; two per thread 34 us).
+        // Below 2^22 envs four per thread: 2^20 envs are then ONE round of 4 waves per SIMD (24.5 us; two per thread 34 us).
         static const int v_env = [] { const char* e = getenv("RRL_NAV_V"); return e ? atoi(e) : 0; }();
         const int v = v_env ? v_env : (n < (1 << 18) ? 1 : (n < (1 << 22) ? 4 : 2));
         if (v == 1) {                 // also the latency regime: a short dependent chain per thread, resets inline
             hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 1>), dim3(grid_for(n)), block, 0, st, a);
         } else if (v == 2) {
-            hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 2>), dim3(grid_for((n + 1) >> 1)), block, 0, st, a);
+            // passes that share one reset draw (parked in LDS): 1 -> 236 us, 2 -> 225 us, 3 -> 228 us, 4 -> 240 us at 2^24
+            // envs (the larger groups cost registers in the apply phase); RRL_NAV_HOLD=1 selects the plain kernel
+            static const int hold = [] { const char* e = getenv("RRL_NAV_HOLD"); return e ? atoi(e) : 2; }();
+            const dim3 grid2(grid_for((n + 1) >> 1));
+            if (hold == 2) hipLaunchKernelGGL((nav_step_compact_hold_kernel<K, E, 2>), grid2, block, 0, st, a);
+            else hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 2>), grid2, block, 0, st, a);
         } else {
             hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 4>), dim3(grid_for((n + 3) >> 2)), block, 0, st, a);
         }
