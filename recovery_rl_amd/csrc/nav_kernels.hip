@@ -304,6 +304,120 @@ __global__ __launch_bounds__(kBlock) void nav_step2_kernel(StepArgs a) {
     rrl::advance_counter(a.counter_dev, a.counter_inc);
 }
 
+// The two-env kernel with HOLD passes sharing one reset draw (see nav_step_compact_hold_kernel below for the scheme): a
+// pass stores next_obs, reward and the four flags at once and parks positions, step counts and finished flags in LDS;
+// after HOLD passes one trip through normal_at() serves every row the wave finished in them, and pos / t / obs go out.
+struct HeldStep {
+    double2 p[2][kBlock];
+    int32_t t[2][kBlock];
+    uint32_t fin[kBlock];
+};
+
+template <int KIND, bool EXT_NOISE, int HOLD>
+__global__ __launch_bounds__(kBlock) void nav_step2_hold_kernel(StepArgs a) {
+    __shared__ HeldStep held[HOLD];
+    __shared__ uint32_t wave_rows[kBlock / 64][64];
+    __shared__ double2 wave_draws[kBlock / 64][64];
+    const int tid = threadIdx.x;
+    const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
+    const int64_t n2 = a.n >> 1, stride = int64_t(gridDim.x) * kBlock;
+    const int64_t n_pass = (n2 + stride - 1) / stride;     // uniform trip count: the reset lists need whole waves
+    const int64_t q_first = int64_t(blockIdx.x) * kBlock + tid;
+    for (int64_t pass0 = 0; pass0 < n_pass; pass0 += HOLD) {
+        const int n_here = int(n_pass - pass0 < HOLD ? n_pass - pass0 : HOLD);      // wave-uniform
+#pragma unroll 1
+        for (int h = 0; h < n_here; ++h) {
+            int64_t q = (pass0 + h) * stride + q_first;
+            const bool live = q < n2;
+            if (!live) q = n2 - 1;                         // idle lanes shadow the last pair and store nothing
+            const int64_t i0 = q << 1;
+            double2 p[2], e[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) p[k] = a.pos[i0 + k];
+            const float4 a01 = reinterpret_cast<const float4*>(a.action)[q];
+            const int2 tv = reinterpret_cast<const int2*>(a.t)[q];
+            if constexpr (EXT_NOISE) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) e[k] = a.noise[i0 + k];
+            }
+            const float ax[2] = {a01.x, a01.z}, ay[2] = {a01.y, a01.w};
+            int32_t ti[2] = {tv.x, tv.y};
+            float2 nobs[2];
+            float rew[2];
+            uint32_t dn2 = 0, cons2 = 0, succ2 = 0, epd2 = 0, finbits = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                double ex, ey;
+                if constexpr (EXT_NOISE) {
+                    ex = e[k].x;
+                    ey = e[k].y;
+                } else {
+                    rrl::normal_at(a.seed, uint32_t(i0 + k), rrl::kStreamStep, ctr, ex, ey);
+                }
+                double nx, ny, cost;
+                rrl::nav_transition<KIND>(p[k].x, p[k].y, double(ax[k]), double(ay[k]), ex, ey, nx, ny, cost);
+                const bool cons = rrl::in_obstacle<KIND>(nx, ny);
+                const bool succ = cost > -4.0;
+                const bool dn = succ | cons;
+                ti[k] += 1;
+                const bool epd = dn | (ti[k] == a.horizon);
+                nobs[k] = make_float2(float(nx), float(ny));
+                rew[k] = float(cost);
+                dn2 |= uint32_t(dn) << (8 * k);
+                cons2 |= uint32_t(cons) << (8 * k);
+                succ2 |= uint32_t(succ) << (8 * k);
+                epd2 |= uint32_t(epd) << (8 * k);
+                const bool f = live & epd & (a.auto_reset != 0);
+                finbits |= uint32_t(f) << k;
+                held[h].p[k][tid] = make_double2(nx, ny);
+                held[h].t[k][tid] = f ? 0 : ti[k];
+            }
+            held[h].fin[tid] = finbits;
+            if (live) {
+                reinterpret_cast<float4*>(a.next_obs)[q] = make_float4(nobs[0].x, nobs[0].y, nobs[1].x, nobs[1].y);
+                reinterpret_cast<float2*>(a.reward)[q] = make_float2(rew[0], rew[1]);
+                reinterpret_cast<uint16_t*>(a.done)[q] = uint16_t(dn2);
+                reinterpret_cast<uint16_t*>(a.constraint)[q] = uint16_t(cons2);
+                reinterpret_cast<uint16_t*>(a.success)[q] = uint16_t(succ2);
+                if (a.ep_done) reinterpret_cast<uint16_t*>(a.ep_done)[q] = uint16_t(epd2);
+            }
+        }
+        bool fin[HOLD * 2];
+        uint32_t row[HOLD * 2];
+#pragma unroll
+        for (int h = 0; h < HOLD; ++h) {
+            const uint32_t fb = h < n_here ? held[h].fin[tid] : 0u;
+            int64_t q = (pass0 + (h < n_here ? h : 0)) * stride + q_first;
+            if (q >= n2) q = n2 - 1;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                fin[h * 2 + k] = (fb >> k) & 1u;
+                row[h * 2 + k] = uint32_t(2 * q + k);
+            }
+        }
+        double w0[HOLD * 2], w1[HOLD * 2];
+        wave_reset_draws<HOLD * 2>(a.seed, ctr, row, fin, w0, w1, wave_rows[tid >> 6], wave_draws[tid >> 6]);
+#pragma unroll
+        for (int h = 0; h < HOLD; ++h) {
+            if (h >= n_here) continue;
+            const int64_t q = (pass0 + h) * stride + q_first;
+            if (q >= n2) continue;
+            const int64_t i0 = q << 1;
+            double2 p[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                p[k] = held[h].p[k][tid];
+                if (fin[h * 2 + k]) p[k] = make_double2(-50.0 + w0[h * 2 + k], 0.0 + w1[h * 2 + k]);   // navigation1.py:92
+                a.pos[i0 + k] = p[k];
+            }
+            if (a.obs)
+                reinterpret_cast<float4*>(a.obs)[q] = make_float4(float(p[0].x), float(p[0].y), float(p[1].x), float(p[1].y));
+            reinterpret_cast<int2*>(a.t)[q] = make_int2(held[h].t[0][tid], held[h].t[1][tid]);
+        }
+    }
+    rrl::advance_counter(a.counter_dev, a.counter_inc);
+}
+
 // ---- compact form (rrl_nav_step_compact): 56 B moved per env-step instead of 72 ----
 // The general entry keeps the reference's separate arrays (four u8 masks, an i32 step count, two f32 observations).
 // Here the step count and the four flags share one u16 status word per env (read for the count, rewritten), and the
@@ -863,6 +977,17 @@ int rrl_nav_step(int env_kind, int64_t n, double* pos, const float* action, cons
                       al(reward, 8) && al(t, 8) && al(done, 2) && al(constraint, 2) && al(success, 2) && al(ep_done, 2);
     if (vec2) {
         const dim3 grid(grid_for(n >> 1));
+        static const int hold = [] { const char* e = getenv("RRL_NAV_HOLD"); return e ? atoi(e) : 2; }();
+        if (hold == 2) {            // two passes share one reset draw (same scheme as the compact kernel)
+            if (env_kind == RRL_ENV_NAV1) {
+                if (noise) hipLaunchKernelGGL((nav_step2_hold_kernel<0, true, 2>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((nav_step2_hold_kernel<0, false, 2>), grid, block, 0, st, a);
+            } else {
+                if (noise) hipLaunchKernelGGL((nav_step2_hold_kernel<1, true, 2>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((nav_step2_hold_kernel<1, false, 2>), grid, block, 0, st, a);
+            }
+            return check_launch();
+        }
         if (env_kind == RRL_ENV_NAV1) {
             if (noise) hipLaunchKernelGGL((nav_step2_kernel<0, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((nav_step2_kernel<0, false>), grid, block, 0, st, a);
