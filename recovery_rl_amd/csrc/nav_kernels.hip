@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kBlock) void nav_step_kernel(StepArgs a) {
 //   once per wave and pass, handed back through LDS (below)     243 / 262 us   <- kept
 //   deferred to the end of the wave, pos patched by scattered stores       267 / 353 us
 //   once per workgroup and pass (two barriers)                  ~340 / 357 us
+//   once per wave and TWO passes, the first parked in LDS (nav_step_compact_hold_kernel, two envs per thread)   222 / 249 us
 // Scattered small stores are what the deferred variant pays for: ~200 k of them per launch cost 35-50 us next to the
 // streaming traffic (profiles/sparse_write_probe.hip: anything below a whole 64-byte granule is a read-modify-write).
 // The reset draws of the rows a wave finished in this pass, evaluated once per wave and pass.  The finished
