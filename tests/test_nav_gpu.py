@@ -370,6 +370,8 @@ def test_fused_step_push_matches_oracle_step_plus_pushes(env, with_outputs):
     assert np.array_equal(rmem.pos_cnt.cpu().numpy()[:cap // 64 + 1][: (cap + 63) // 64],
                           np.add.reduceat(np.r_[filled, np.zeros((-cap) % 64, bool)].astype(np.int32),
                                           np.arange(0, cap, 64)))
+    from test_replay_gpu import assert_count_tables       # chunk counts, super-chunk counts, slot masks (wrapped ring)
+    assert_count_tables(rmem, ormem, cap)
     assert np.array_equal(stats.cpu().numpy()[:8], ref_stats)
     assert np.allclose(sums.cpu().numpy(), ref_sums, rtol=1e-9)
     assert np.allclose(ep_reward.cpu().numpy(), ref_ep, rtol=1e-6, atol=1e-4)

@@ -78,6 +78,22 @@ def test_push_matches_oracle_including_wraparound(cap, chunks):
         assert np.array_equal(masks, np.packbits(want.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).ravel())
 
 
+def assert_count_tables(mem, ora, cap):
+    """chunk counts, super-chunk counts and slot masks of `mem.pos_cnt` against the oracle's rows"""
+    filled = ora.r[:len(ora)] != 0
+    n_chunks, n_super = (cap + 63) // 64, (cap + 1023) // 1024
+    base = (n_chunks + 3) // 4 * 4
+    mbase = (base + n_super + 1) // 2 * 2
+    got = mem.pos_cnt.cpu().numpy()
+    want = np.zeros(n_chunks * 64, bool)
+    want[:len(filled)] = filled
+    assert np.array_equal(got[:n_chunks], want.reshape(-1, 64).sum(1))
+    first = np.r_[got[:n_chunks], np.zeros((-n_chunks) % 16, np.int32)]
+    assert np.array_equal(got[base:base + n_super], first.reshape(-1, 16).sum(1))
+    assert np.array_equal(got[mbase:].view(np.uint64),
+                          np.packbits(want.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).ravel())
+
+
 def test_masked_push_matches_oracle():
     rng = np.random.RandomState(5)
     mem, ora = ConstraintReplayMemory(9000, 1, device=DEV), co.OracleReplay(9000)
@@ -87,6 +103,7 @@ def test_masked_push_matches_oracle():
         mem.push(*dev(b), valid=torch.as_tensor(valid, device=DEV))
         ora.push(*b, valid=valid)
         assert_buffers_equal(mem, ora)
+        assert_count_tables(mem, ora, 9000)        # masked rows land in non-consecutive lanes: the per-lane mask path
     b = rows(rng, 64, pos_rate=0.2)
     mem.push(*dev(b), valid=torch.zeros(64, dtype=torch.uint8, device=DEV))   # nothing valid
     assert_buffers_equal(mem, ora)
