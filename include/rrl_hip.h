@@ -315,6 +315,29 @@ int rrl_cem_update(int64_t M, int32_t pop, int32_t dim, int32_t num_elites, doub
                    const float* samples, const float* costs, double* mean, double* var,
                    const uint8_t* active, void* stream);
 
+/* The same two steps for a planning set whose size is decided ON THE DEVICE (no host round trip in MPC.act,
+ * recovery_rl/MPC.py:322-347; the reference plans for its one env only when Q_risk > eps_safe, experiment.py:568-571):
+ *   rrl_cem_begin   ONE launch: idx[0..count) = rows with mask != 0 in ascending order, count[0] = their number, and the
+ *                   planner's inputs of the compacted problems: mean[j] = prev_sol[idx[j]] (prev_sol [n,dim] f64),
+ *                   var[j] = init_var [dim], cur_obs[j] = obs[idx[j]] (f32 [n,2]), active[j] = 1      (MPC.py:336-341)
+ *   rrl_cem_sample_n / rrl_cem_update_n
+ *                   rrl_cem_sample / rrl_cem_update with M = m_dev[0] read by the kernel; m_max >= m_dev[0] bounds the
+ *                   launch (buffers are sized for m_max); same Philox rows, same bits as the host-count entries
+ *   rrl_cem_finish  action[i, 0..du) = float(mean[j, 0..du)) for i = idx[j], 0 for rows that did not plan;
+ *                   prev_sol[i] = mean[j] shifted left by du, zero-filled                              (MPC.py:342-344) */
+int rrl_cem_begin(int64_t n, const uint8_t* mask, int32_t dim, const double* prev_sol, const double* init_var,
+                  const float* obs, int32_t* idx, int32_t* count, double* mean, double* var, float* cur_obs,
+                  uint8_t* active, void* stream);
+int rrl_cem_sample_n(const int32_t* m_dev, int64_t m_max, int32_t pop, int32_t dim, const double* mean,
+                     const double* var, const double* lb, const double* ub, double epsilon, int sticky, uint8_t* active,
+                     uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* samples,
+                     void* stream);
+int rrl_cem_update_n(const int32_t* m_dev, int64_t m_max, int32_t pop, int32_t dim, int32_t num_elites, double alpha,
+                     const float* samples, const float* costs, double* mean, double* var, const uint8_t* active,
+                     void* stream);
+int rrl_cem_finish(int64_t n, const uint8_t* mask, int32_t dim, int32_t du, const int32_t* idx, const int32_t* count,
+                   const double* mean, double* prev_sol, float* action, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * MLP building block.  Replaces the nn.Linear forward/backward of the SAC / Q_risk networks
  * (recovery_rl/model.py:49-76,172-199,295-343,489-530) for G heads in one launch; exact f32
@@ -601,6 +624,14 @@ int rrl_plan_pack_f16x3(const rrl_plan_weights_t* w, float* packed, void* stream
 int rrl_plan_cost_f16x3(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
                         const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
                         uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream);
+
+/* rrl_plan_cost / rrl_plan_cost_f16x3 (f16x3 != 0) for M = m_dev[0] planning problems, M read by the kernel (see
+ * rrl_cem_begin); the grid covers m_max problems and workgroups past the live ones exit at once.  cur_obs, ac_seqs,
+ * partial and costs are sized for m_max.  Results for the live problems equal the host-count entries' bit for bit. */
+int rrl_plan_cost_n(int f16x3, const float* packed, int hq, int he, int n_nets, int npart, const int32_t* m_dev,
+                    long long m_max, int pop, int plan_hor, const float* cur_obs, const float* ac_seqs, const float* noise,
+                    uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* partial,
+                    float* costs, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Ensemble fitting.  One optimiser step of MPC.train (recovery_rl/MPC.py:266-292) for the PETS ensemble

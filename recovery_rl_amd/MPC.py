@@ -118,6 +118,8 @@ class MPC:
         self.fused_train = True            # ... or, for the reference's shapes, run it as one fused kernel
         self._trainer = None
         self.fused = None                  # FusedPlanner (rrl_plan_cost) when the shapes allow it
+        self.device_count = True           # act(obs, t, mask): planning-set size stays on the device (no host sync)
+        self._plan_ws = self._plan_out = self.last_count = None
         self.use_fused_planner = True
         if plan_precision not in (None, "f32", "f16x3"):
             raise ValueError("--plan_precision must be 'f32' or 'f16x3'")
@@ -244,6 +246,9 @@ class MPC:
         if not self.has_been_trained:                                         # :333-334
             out = self._lb + (self._ub - self._lb) * torch.rand(n, self.dU, device=self.device)
             return out[0].cpu().numpy() if single else out
+        if (mask is not None and self.fused is not None and self.device_count and self.prev_sol.shape[0] == n
+                and self.mb_dynamics == "model"):
+            return self._act_device_count(obs, mask)
         out = torch.zeros(n, self.dU, dtype=torch.float32, device=self.device)
         idx = torch.arange(n, device=self.device) if mask is None else mask.nonzero().squeeze(1)
         if idx.numel() == 0:
@@ -262,12 +267,41 @@ class MPC:
         out[idx] = soln[:, :self.dU].to(torch.float32)
         return out[0].cpu().numpy() if single else out
 
+    def _act_device_count(self, obs, mask):
+        """act() for a recovery mask without reading the number of planning envs on the host: the mask is compacted on
+        the device (rrl_cem_begin), every kernel of the CEM reads the count from device memory and is launched for the
+        upper bound n (workgroups past the live problems exit at once), rrl_cem_finish scatters the actions and the
+        shifted solutions.  Same index order, Philox rows and arithmetic as the host-count path."""
+        from .optimizers import PlanWorkspace
+        from .utils import trace_range
+        n, dim = obs.shape[0], self.plan_hor * self.dU
+        ws = self._plan_ws
+        if ws is None or ws.m_max != n:
+            ws = self._plan_ws = PlanWorkspace(n, self.optimizer.popsize, dim, self.device)
+            self._plan_out = torch.zeros(n, self.dU, dtype=torch.float32, device=self.device)
+        mask_u8 = mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
+        obs = obs.to(torch.float32).contiguous()
+        lib, st = _lib.load(), _lib.current_stream()
+        p = _lib.ptr
+        _lib.check(lib.rrl_cem_begin(n, p(mask_u8), dim, p(self.prev_sol), p(self.init_var), p(obs), p(ws.idx),
+                                     p(ws.count), p(ws.mean), p(ws.var), p(ws.cur_obs), p(ws.active), st),
+                   "rrl_cem_begin")
+        self.fused.pack()                  # weights moved since the last call (Q_risk update / re-fit)
+        with trace_range("cem"):
+            self.optimizer.obtain_solution_n(ws, ws.count)
+        _lib.check(lib.rrl_cem_finish(n, p(mask_u8), dim, self.per * self.dU, p(ws.idx), p(ws.count), p(ws.mean),
+                                      p(self.prev_sol), p(self._plan_out), st), "rrl_cem_finish")
+        self.last_count = ws.count         # device-side size of the planning set of this call (int32[1])
+        return self._plan_out
+
     # -- candidate evaluation (MPC.py:374-416) -------------------------------------------------
     @torch.no_grad()
-    def _compile_cost(self, ac_seqs, cur_obs=None, noise=None, fused=None):
+    def _compile_cost(self, ac_seqs, cur_obs=None, noise=None, fused=None, count=None):
         """ac_seqs [M, pop, plan_hor*dU] -> mean over particles of sum_t Q_risk(obs_t, ac_t): [M, pop].
         `noise` (optional, [plan_hor, M*pop*npart, dO], row = (m*pop + c)*npart + p) replaces the particle
         noise draws; `fused` forces (True) or forbids (False) the rrl_plan_cost kernel."""
+        if count is not None:              # device-count planning set (obtain_solution_n): the workspace holds the inputs
+            return self.fused.cost_n(self._plan_ws, count, self._plan_ws.costs)
         single = not torch.is_tensor(ac_seqs)
         if single:
             ac_seqs = torch.as_tensor(ac_seqs, dtype=torch.float32, device=self.device)[None]

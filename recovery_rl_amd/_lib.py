@@ -26,7 +26,7 @@ EXPORTS = [
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_sample_multi",
     "rrl_nav_step_push", "rrl_maze_step_push", "rrl_nav_step_push_select", "rrl_maze_step_push_select",
-    "rrl_cem_sample", "rrl_cem_update",
+    "rrl_cem_sample", "rrl_cem_update", "rrl_cem_begin", "rrl_cem_sample_n", "rrl_cem_update_n", "rrl_cem_finish",
     "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss", "rrl_mlp_hidden_backward",
     "rrl_mlp_input_backward", "rrl_mlp3_forward_multi", "rrl_mlp_head_backward_multi", "rrl_mlp_hidden_backward_multi",
     "rrl_mlp_input_backward_multi", "rrl_policy_heads_fwd_multi",
@@ -34,7 +34,7 @@ EXPORTS = [
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_adam_step_multi", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
     "rrl_plan_supported", "rrl_plan_pack_floats", "rrl_plan_pack", "rrl_plan_cost", "rrl_plan_pack_f16x3",
-    "rrl_plan_cost_f16x3",
+    "rrl_plan_cost_f16x3", "rrl_plan_cost_n",
     "rrl_ens_train_supported", "rrl_ens_scratch_floats", "rrl_ens_train_grad", "rrl_ens_train_epoch",
 ]
 
@@ -56,12 +56,32 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/*.hip into csrc/librrl_hip.so for gfx950."""
+def build(force=False, verbose=False, jobs=None):
+    """Compile csrc/*.hip into csrc/librrl_hip.so for gfx950: one object per source (compiled in parallel, re-used
+    while neither the source nor any header changed), then one link."""
     if not force and not _stale():
         return SO_PATH
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", SO_PATH] + _sources()
+    objdir = os.path.join(CSRC, "_build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(INCLUDE, "rrl_hip.h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            return obj
+        cmd = [hipcc] + compile_flags + ["-I", INCLUDE, "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs or min(4, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, _sources()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", SO_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -200,6 +220,10 @@ def _declare(lib):
         "rrl_policy_heads_fwd_multi": (ci, [ci, C.POINTER(rrl_policy_head_t), vp]),
         "rrl_cem_sample": (ci, [i64, i32, i32, vp, vp, vp, vp, f64, ci, vp, u64, u64, vp, u64, vp, vp]),
         "rrl_cem_update": (ci, [i64, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]),
+        "rrl_cem_begin": (ci, [i64, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "rrl_cem_sample_n": (ci, [vp, i64, i32, i32, vp, vp, vp, vp, f64, ci, vp, u64, u64, vp, u64, vp, vp]),
+        "rrl_cem_update_n": (ci, [vp, i64, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]),
+        "rrl_cem_finish": (ci, [i64, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
         "rrl_gemm_f32": (ci, [ci, ci, ci, ci, ci, vp, ci, C.c_longlong, vp, ci, C.c_longlong, vp, ci,
                               C.c_longlong, vp, C.c_longlong, ci, vp, ci, C.c_longlong, vp, C.c_longlong,
                               ci, vp]),
@@ -227,6 +251,7 @@ def _declare(lib):
         "rrl_plan_cost": (ci, [vp, ci, ci, ci, ci, ll, ci, ci, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp]),
         "rrl_plan_pack_f16x3": (ci, [C.POINTER(rrl_plan_weights_t), vp, vp]),
         "rrl_plan_cost_f16x3": (ci, [vp, ci, ci, ci, ci, ll, ci, ci, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp]),
+        "rrl_plan_cost_n": (ci, [ci, vp, ci, ci, ci, ci, vp, ll, ci, ci, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp]),
         "rrl_ens_train_supported": (ci, [ci, ci, ci, ci]),
         "rrl_ens_scratch_floats": (ll, [ci]),
         "rrl_ens_train_epoch": (ci, [C.POINTER(rrl_ens_t), ci, C.POINTER(rrl_adam_seg_t), f32, f32, f32, f32, vp, vp,

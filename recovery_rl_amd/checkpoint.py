@@ -33,6 +33,7 @@ def replay_state(mem):
         out[name] = _cpu(getattr(mem, name)[:size])
     if mem.pos_cnt is not None:
         out["pos_cnt"] = _cpu(mem.pos_cnt)
+        out["abi"] = int(mem.lib.rrl_abi_version())      # the count-table layout belongs to the library version
     return out
 
 
@@ -45,7 +46,11 @@ def load_replay_state(mem, sd):
     mem.state.copy_(sd["state"])
     mem.tick.copy_(sd["tick"])
     if mem.pos_cnt is not None:
-        mem.pos_cnt.copy_(sd["pos_cnt"])
+        same = sd.get("abi") == int(mem.lib.rrl_abi_version()) and sd["pos_cnt"].shape == mem.pos_cnt.shape
+        if same:
+            mem.pos_cnt.copy_(sd["pos_cnt"])
+        else:       # written by a library with another table layout: the table is a function of the rows
+            mem.rebuild_pos_cnt()
     mem._len, mem._len_exact = sd["len"], sd["len_exact"]
 
 

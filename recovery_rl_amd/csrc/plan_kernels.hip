@@ -279,7 +279,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(RRL_PL
 void plan_cost_kernel(
     const float* __restrict__ pk, int n_nets, int npart, long long n_groups, int pop, int plan_hor,
     const float* __restrict__ cur_obs, const float* __restrict__ ac_seqs, const float* __restrict__ noise,
-    uint64_t seed, uint64_t counter, const uint64_t* __restrict__ counter_dev, float* __restrict__ partial) {
+    uint64_t seed, uint64_t counter, const uint64_t* __restrict__ counter_dev, float* __restrict__ partial,
+    const int32_t* __restrict__ m_dev) {
+    if (m_dev) {
+        // the number of planning problems was decided on the device (rrl_cem_begin): the grid covers the launch bound,
+        // workgroups past the live tiles leave before they touch anything
+        n_groups = (long long)m_dev[0] * pop;
+        if ((long long)blockIdx.x >= ((n_groups + 15) / 16) * n_nets) return;
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* act = lds;                                               // [64][260] f32 activations, or two f16 planes
     float* xs = act + kActFloats;                                   // [64][4] raw (obs, ac)
@@ -554,7 +561,9 @@ void plan_cost_kernel(
 __global__ __launch_bounds__(kBlock) void plan_finish_kernel(long long n_groups, int n_nets, int npart,
                                                              const float* __restrict__ partial,
                                                              float* __restrict__ costs, uint64_t* counter_dev,
-                                                             uint64_t counter_inc) {
+                                                             uint64_t counter_inc, const int32_t* __restrict__ m_dev,
+                                                             int pop) {
+    if (m_dev) n_groups = (long long)m_dev[0] * pop;
     for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < n_groups;
          g += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -699,7 +708,7 @@ int rrl_plan_pack_f16x3(const rrl_plan_weights_t* w, float* packed, void* stream
 static int plan_cost_impl(bool f16x3, const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop,
                           int plan_hor, const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed,
                           uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs,
-                          void* stream_) {
+                          void* stream_, const int32_t* m_dev = nullptr) {
     if (!packed || !cur_obs || !ac_seqs || !partial || !costs || M <= 0 || pop <= 0 || plan_hor <= 0 ||
         plan_hor > 16 || !rrl_plan_supported(hq, he, n_nets, npart, 2, 2))
         return RRL_EINVAL;
@@ -721,12 +730,12 @@ static int plan_cost_impl(bool f16x3, const float* packed, int hq, int he, int n
     }
     if (f16x3)
         hipLaunchKernelGGL(plan_cost_kernel<true>, dim3((unsigned)tiles), dim3(kThreads), kLdsBytes, st, packed, n_nets,
-                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial);
+                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial, m_dev);
     else
         hipLaunchKernelGGL(plan_cost_kernel<false>, dim3((unsigned)tiles), dim3(kThreads), kLdsBytes, st, packed, n_nets,
-                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial);
+                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial, m_dev);
     hipLaunchKernelGGL(plan_finish_kernel, dim3(grid_for(n_groups)), dim3(kBlock), 0, st, n_groups, n_nets, npart,
-                       partial, costs, counter_dev, counter_inc);
+                       partial, costs, counter_dev, counter_inc, m_dev, pop);
     return check_launch();
 }
 
@@ -742,6 +751,15 @@ int rrl_plan_cost_f16x3(const float* packed, int hq, int he, int n_nets, int npa
                         uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream) {
     return plan_cost_impl(true, packed, hq, he, n_nets, npart, M, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter,
                           counter_dev, counter_inc, partial, costs, stream);
+}
+
+int rrl_plan_cost_n(int f16x3, const float* packed, int hq, int he, int n_nets, int npart, const int32_t* m_dev,
+                    long long m_max, int pop, int plan_hor, const float* cur_obs, const float* ac_seqs, const float* noise,
+                    uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* partial,
+                    float* costs, void* stream) {
+    if (!m_dev) return RRL_EINVAL;
+    return plan_cost_impl(f16x3 != 0, packed, hq, he, n_nets, npart, m_max, pop, plan_hor, cur_obs, ac_seqs, noise, seed,
+                          counter, counter_dev, counter_inc, partial, costs, stream, m_dev);
 }
 
 }  // extern "C"

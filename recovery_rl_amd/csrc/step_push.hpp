@@ -107,25 +107,31 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
         __syncthreads();
     }
     const StepArgs& a = p.step;
-    const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
-    const int64_t mpos = p.memory.state[0], msize = p.memory.state[1];
+    const uint64_t ctr = a.counter_dev ? a.counter + __atomic_load_n(a.counter_dev, __ATOMIC_RELAXED) : a.counter;
+    // the cursors are read with (relaxed) atomic loads and the ticket below is a RELEASE operation, so neither the
+    // compiler nor the memory system may let a workgroup's read of a cursor slip behind its ticket
+    const auto ld = [](const int64_t* q) { return (int64_t)__atomic_load_n((const long long*)q, __ATOMIC_RELAXED); };
+    const int64_t mpos = ld(&p.memory.state[0]), msize = ld(&p.memory.state[1]);
     int64_t rpos = 0, rsize = 0;
-    if (p.use_recovery_memory) { rpos = p.recovery_memory.state[0]; rsize = p.recovery_memory.state[1]; }
+    if (p.use_recovery_memory) { rpos = ld(&p.recovery_memory.state[0]); rsize = ld(&p.recovery_memory.state[1]); }
     // ONE ticket for the three device-side cursors (both replay rings and the RNG tick): a returning device-scope atomic
     // is a ~0.7 us round trip, three in a row were a sixth of this kernel.  The workgroup that draws the last ticket knows
     // that every workgroup has read the cursors, which is all their update has to wait for.  In the latency regime (a few
-    // workgroups) it is drawn right after the cursors are read, so the round trip runs under the env step; with thousands
-    // of workgroups that would be a burst of atomics on one address at launch (+8 us at 2^20 envs) -- there it stays at
-    // the end, where the workgroups arrive spread out.
+    // workgroups) it is drawn right after the cursors are read and its value is looked at when the workgroup is done, so
+    // the round trip runs under the env step; with thousands of workgroups that would be a burst of atomics on one
+    // address at launch (+8 us at 2^20 envs) -- there it is drawn at the end, where the workgroups arrive spread out.
+    unsigned long long ticket = ~0ULL;
     const auto draw_ticket = [&]() {
-        if (threadIdx.x == 0) {
-            const unsigned long long ticket = atomicAdd((unsigned long long*)&p.memory.state[2], 1ULL);
-            if (ticket == gridDim.x - 1) {
-                p.memory.state[2] = 0;
-                rrl_replay::set_ring(p.memory, mpos, msize, a.n);
-                if (p.use_recovery_memory) rrl_replay::set_ring(p.recovery_memory, rpos, rsize, a.n);
-                if (a.counter_dev && a.counter_inc) a.counter_dev[0] += a.counter_inc;
-            }
+        if (threadIdx.x == 0)
+            ticket = __hip_atomic_fetch_add((unsigned long long*)&p.memory.state[2], 1ULL, __ATOMIC_RELEASE,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const auto advance_cursors = [&]() {
+        if (threadIdx.x == 0 && ticket == gridDim.x - 1) {
+            p.memory.state[2] = 0;
+            rrl_replay::set_ring(p.memory, mpos, msize, a.n);
+            if (p.use_recovery_memory) rrl_replay::set_ring(p.recovery_memory, rpos, rsize, a.n);
+            if (a.counter_dev && a.counter_inc) a.counter_dev[0] = ctr - a.counter + a.counter_inc;
         }
     };
     if constexpr (SPECULATE) {
@@ -140,10 +146,16 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
         const int64_t i = it * stride + int64_t(blockIdx.x) * kBlock + threadIdx.x;
         const bool live = i < a.n;
         int s0 = 0, s1 = 0;       // super-chunks of the workgroup's first and last safety-buffer slot of this pass
+        // the two workgroup sums cover a pass whose 256 consecutive slots touch at most two super-chunks: always, unless
+        // the pass wraps around a ring whose capacity is not a multiple of the super-chunk (then it can touch the last
+        // two super-chunks AND super-chunk 0): that pass sends its waves' nets straight to memory instead
+        bool block_sums = false;
         if (kBlockSuper && counts) {
-            const int64_t first = (rpos + it * stride + int64_t(blockIdx.x) * kBlock) % p.recovery_memory.cap;
+            const int64_t cap = p.recovery_memory.cap;
+            const int64_t first = (rpos + it * stride + int64_t(blockIdx.x) * kBlock) % cap;
             s0 = int(first / rrl_replay::kSuper);
-            s1 = int(((first + kBlock - 1) % p.recovery_memory.cap) / rrl_replay::kSuper);
+            s1 = int(((first + kBlock - 1) % cap) / rrl_replay::kSuper);
+            block_sums = first + kBlock <= cap || cap % rrl_replay::kSuper == 0;
         }
         bool cons = false, succ = false, epd = false, rec = false;
         if (live) {
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             rrl_replay::store_values(p.memory, (mpos + i) % p.memory.cap, msize, prev, stored, prew, nobs, mask);
             if (p.use_recovery_memory)
                 rrl_replay::store_values(p.recovery_memory, (rpos + i) % p.recovery_memory.cap, rsize, prev, act,
-                                         cons ? 1.0f : 0.0f, nobs, mask, kBlockSuper ? super_acc : nullptr, s0);
+                                         cons ? 1.0f : 0.0f, nobs, mask, block_sums ? super_acc : nullptr, s0);
             // episode accounting
             const float er = p.ep_reward[i] + rew;
             rsum += double(rew);
@@ -290,6 +302,7 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
         atomicAdd(p.stats, (unsigned long long)a.n);
     }
     if constexpr (!SPECULATE) draw_ticket();
+    advance_cursors();
 }
 
 // host side: argument block shared by the navigation and maze entry points

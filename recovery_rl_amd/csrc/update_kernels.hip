@@ -393,23 +393,27 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_se
     while (k + 1 < n_seg && (int)blockIdx.x >= a.first_block[k + 1]) ++k;
     const rrl_adam_seg_t sg = a.seg[k];
     const int block = blockIdx.x - a.first_block[k], blocks = a.first_block[k + 1] - a.first_block[k];
+    uint64_t step = 0;
+    unsigned long long ticket = ~0ULL;
     if (threadIdx.x == 0) {
-        const uint64_t step = sg.step_dev[0];
+        // (relaxed) atomic load + RELEASE ticket: the read of the step count cannot slip behind the ticket
+        step = __atomic_load_n(&sg.step_dev[0], __ATOMIC_RELAXED);
         const double t = double(step + 1);
         // the ticket is taken as soon as this workgroup has READ the step count: the last of the segment's workgroups
-        // to do so knows every other one has read it too and may store t + 1 right away -- the returning atomic's round
-        // trip (~0.7 us) runs under the parameter loads instead of after the last store
-        const unsigned long long ticket = atomicAdd((unsigned long long*)&sg.step_dev[1], 1ULL);
+        // to do so knows every other one has read it too and may store t + 1 -- the returning atomic's round trip
+        // (~0.7 us) runs under the parameter loads: its value is looked at after them
+        ticket = __hip_atomic_fetch_add((unsigned long long*)&sg.step_dev[1], 1ULL, __ATOMIC_RELEASE,
+                                        __HIP_MEMORY_SCOPE_AGENT);
         sh[0] = lr / float(1.0 - pow(double(b1), t));
         sh[1] = float(sqrt(1.0 - pow(double(b2), t)));
-        if (ticket == (unsigned long long)blocks - 1) {
-            sg.step_dev[0] = step + 1;
-            sg.step_dev[1] = 0;
-        }
     }
     __syncthreads();
     adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, sg.weight_decay, sg.g2,
                block, blocks, a.vec[k] != 0, sg.g_part, sg.n_part, sg.part_stride, sg.part_elems);
+    if (threadIdx.x == 0 && ticket == (unsigned long long)blocks - 1) {
+        sg.step_dev[0] = step + 1;
+        sg.step_dev[1] = 0;
+    }
 }
 
 // ---- N(0,1) fill: out[2i], out[2i+1] = the Philox normal pair of index i (stream RRL_STREAM_NOISE) ----

@@ -376,7 +376,11 @@ class FastUpdater:
         self.rec_a = Stack(self.recpolicy, B)
         # grouped launches evaluate the target networks in the same launch as the online ones: own workspaces
         self.cri_t, self.qr_t = Stack(self.critic, B), Stack(self.qrisk, B)
-        self.grouped = True        # kernels that do not depend on each other share launches (rrl_*_multi)
+        # kernels that do not depend on each other share launches (rrl_*_multi): the grouped entry points exist for the
+        # one-launch stack forward only (H % 16 == 0, H <= 256, <= 4 inputs / outputs); other widths (--hidden_size 512)
+        # take the separate calls, whose Stack.forward falls back to the per-layer GEMM kernel
+        self.grouped = all(mlp3_supported(net.H, net.din, net.dout)
+                           for net in (self.critic, self.policy, self.qrisk, self.recpolicy))
         self.fuse_heads = True     # policy heads evaluated by the consuming critic stack (rrl_stack_t.in_head)
         self.xu_q, self.x2u_q, self.xpu_q = z(B, 4), z(B, 4), z(B, 4)   # the Q_risk batch's rows (drawn up front)
         self.xu = z(B, 4)                                           # [s | a]

@@ -62,3 +62,37 @@ class CEMOptimizer(Optimizer):
                                          _lib.ptr(active), stream)
             _lib.check(rc, "rrl_cem_update")
         return mean[0].cpu().numpy() if single else mean
+
+    def obtain_solution_n(self, ws, count, iters=None):
+        """obtain_solution for a planning set whose size lives on the device (`count`, int32[1], <= ws.m_max problems;
+        MPC.act with a recovery mask): mean / var / samples are the caller's persistent workspace `ws`, the cost function
+        is called as cost_function(samples, count=count) and must not synchronise.  Same Philox rows, same arithmetic as
+        obtain_solution on the compacted problems."""
+        stream = _lib.current_stream()
+        dim = self.sol_dim
+        for _ in range(self.max_iters if iters is None else iters):
+            rc = self.lib.rrl_cem_sample_n(_lib.ptr(count), ws.m_max, self.popsize, dim, _lib.ptr(ws.mean),
+                                           _lib.ptr(ws.var), _lib.ptr(self.lb), _lib.ptr(self.ub), self.epsilon, 1,
+                                           _lib.ptr(ws.active), self.seed, 0, _lib.ptr(self.tick), 1,
+                                           _lib.ptr(ws.samples), stream)
+            _lib.check(rc, "rrl_cem_sample_n")
+            costs = self.cost_function(ws.samples, count=count)
+            rc = self.lib.rrl_cem_update_n(_lib.ptr(count), ws.m_max, self.popsize, dim, self.num_elites, self.alpha,
+                                           _lib.ptr(ws.samples), _lib.ptr(costs), _lib.ptr(ws.mean), _lib.ptr(ws.var),
+                                           _lib.ptr(ws.active), stream)
+            _lib.check(rc, "rrl_cem_update_n")
+        return ws.mean
+
+
+class PlanWorkspace:
+    """Persistent buffers of the device-count planning path, sized for m_max problems."""
+
+    def __init__(self, m_max, popsize, sol_dim, device):
+        self.m_max = int(m_max)
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)
+        self.idx, self.count = z(m_max, dt=torch.int32), z(1, dt=torch.int32)
+        self.mean, self.var = z(m_max, sol_dim, dt=torch.float64), z(m_max, sol_dim, dt=torch.float64)
+        self.samples = z(m_max, popsize, sol_dim)
+        self.cur_obs = z(m_max, 2)
+        self.active = z(m_max, dt=torch.uint8)
+        self.costs = z(m_max, popsize)

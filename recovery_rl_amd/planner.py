@@ -76,3 +76,18 @@ class FusedPlanner:
                                     _lib.current_stream())
         _lib.check(rc, "rrl_plan_cost")
         return costs
+
+    def cost_n(self, ws, count, costs):
+        """cost() for the first count[0] problems of the workspace (count on the device; rrl_plan_cost_n): no host
+        synchronisation, the launch covers ws.m_max problems and the workgroups past the live ones exit at once."""
+        mpc = self.mpc
+        pop = int(ws.samples.shape[1])
+        need = ws.m_max * pop * self.n_nets
+        if self._partial is None or self._partial.numel() < need:
+            self._partial = torch.empty(need, dtype=torch.float32, device=self.device)
+        rc = self.lib.rrl_plan_cost_n(int(self.f16x3), _lib.ptr(self.packed), self.hq, self.he, self.n_nets, mpc.npart,
+                                      _lib.ptr(count), ws.m_max, pop, mpc.plan_hor, _lib.ptr(ws.cur_obs),
+                                      _lib.ptr(ws.samples), None, self.seed, 0, _lib.ptr(self.tick), 1,
+                                      _lib.ptr(self._partial), _lib.ptr(costs), _lib.current_stream())
+        _lib.check(rc, "rrl_plan_cost_n")
+        return costs

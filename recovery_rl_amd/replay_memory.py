@@ -48,6 +48,25 @@ class ReplayMemory:
         self._scratch = None
         self._out = {}
 
+    def rebuild_pos_cnt(self):
+        """Recompute the three regions of `pos_cnt` (per-chunk counts, per-super-chunk counts, per-chunk slot masks;
+        RRL_POS_CNT_LEN) from the filled rows' r != 0 -- for checkpoints written with another table layout."""
+        if self.pos_cnt is None:
+            return
+        cap, dev = self.capacity, self.device
+        size = int(self.state[1].item())
+        n_chunks, n_super = (cap + 63) // 64, (cap + 1023) // 1024
+        pos = torch.zeros(n_super * 1024, dtype=torch.int64, device=dev)
+        pos[:size] = (self.r[:size] != 0).to(torch.int64)
+        per_chunk = pos.view(-1, 64)
+        self.pos_cnt.zero_()
+        self.pos_cnt[:n_chunks] = per_chunk.sum(1)[:n_chunks].to(torch.int32)
+        sb = (n_chunks + 3) // 4 * 4
+        self.pos_cnt[sb:sb + n_super] = pos.view(n_super, 1024).sum(1).to(torch.int32)
+        mb = (sb + n_super + 1) // 2 * 2
+        masks = (per_chunk << torch.arange(64, device=dev)).sum(1)[:n_chunks]     # bit 63 wraps into the sign: intended
+        self.pos_cnt[mb:mb + 2 * n_chunks] = masks.contiguous().view(torch.int32)
+
     # -- push ---------------------------------------------------------------------------------
     def push(self, state, action, reward, next_state, done, valid=None):
         """Append N rows (row i = env i). `done` is the reference's 5th tuple field: the

@@ -1,0 +1,40 @@
+"""HIP runtime settings a LAUNCHER may opt into (bench.py, rrl_main.py) -- never applied by importing the package.
+
+`graph_packet_capture`: ROCm's hipGraph replay either re-submits pre-captured AQL packets (runtime default) or walks
+the regular command path (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, a debug variable of the ROCm 7.x runtime).  For the
+lock-step iteration -- one graph of ~20 dependent tiny kernels -- the regular path measured 2.8 % faster on ROCm 7.2 /
+MI355X.  That is a finding about ONE runtime release, so it is opt-in (`RRL_GRAPH_PACKET_CAPTURE=0`
+in the environment or `configure(graph_packet_capture=0)` from the launcher), it is logged, it never overrides an
+explicit DEBUG_CLR_GRAPH_PACKET_CAPTURE, and `settings()` reports what is in force so that a bench line says how it ran.
+The variable is read by the runtime at its first call: `configure` must run before anything touches the GPU.
+"""
+import os
+import sys
+
+_VAR = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+_applied = {}
+
+
+def configure(graph_packet_capture=None, log=True):
+    """graph_packet_capture: None = leave the runtime default unless RRL_GRAPH_PACKET_CAPTURE is set; 0 / 1 = ask for
+    that mode.  Returns settings()."""
+    want = os.environ.get("RRL_GRAPH_PACKET_CAPTURE")
+    if want is None and graph_packet_capture is not None:
+        want = str(int(graph_packet_capture))
+    if want is not None and _VAR not in os.environ:
+        hip_started = "torch" in sys.modules and sys.modules["torch"].cuda.is_initialized()
+        if hip_started:
+            if log:
+                print("recovery_rl_amd.runtime: HIP is already initialised, %s left at the runtime default" % _VAR,
+                      file=sys.stderr)
+        else:
+            os.environ[_VAR] = want
+            _applied[_VAR] = want
+            if log:
+                print("recovery_rl_amd.runtime: %s=%s (hipGraph replay through the %s path)"
+                      % (_VAR, want, "regular command" if want == "0" else "pre-captured packet"), file=sys.stderr)
+    return settings()
+
+
+def settings():
+    return {_VAR: os.environ.get(_VAR, "runtime default"), "set_by_launcher": _VAR in _applied}

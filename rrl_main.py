@@ -1,6 +1,8 @@
 """`python -m rrl_main --env-name navigation1 --cuda ...` -- same entry point as the reference
 (rrl_main.py:1-9).  Under torchrun each rank runs seed + rank on its own GPU."""
 from arg_utils import get_args
+from recovery_rl_amd import runtime
+runtime.configure()        # opt-in runtime settings (RRL_GRAPH_PACKET_CAPTURE); none by default
 from recovery_rl_amd import distributed as dist_utils
 from recovery_rl_amd.experiment import Experiment
 

@@ -260,3 +260,27 @@ def test_learning_at_the_headline_size_4096_envs(tmp_path, capsys):
     assert viol / ep < 0.1, (ep, succ, viol)
     exp.memory.check_error()
     exp.recovery_memory.check_error()
+
+
+@pytest.mark.parametrize("hidden", (512, 40))
+def test_loop_at_hidden_widths_outside_the_one_launch_stack_kernel(tmp_path, hidden):
+    """--hidden_size 512 (> 256) and 40 (not a multiple of 16): the grouped launches and the fused stack forward do not
+    cover these widths; the fused update path must fall back to its per-layer kernels (not assert), eagerly and from a graph,
+    and stay equal to the autograd path."""
+    argv = ["--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe", "0.3", "--num_envs", "64",
+            "--hidden_size", str(hidden), "--batch_size", "64"]
+    cfg = make_cfg(tmp_path, argv)
+    exp = Experiment(cfg)
+    assert exp.agent.fast is not None and not exp.agent.fast.grouped
+    exp.pretrain_critic_recovery()
+    loop = exp.loop
+    loop.start()
+    for k in range(4):
+        loop.vector_step(do_update=len(exp.memory) > cfg.batch_size, random_actions=k < 2)
+    loop.capture(online_qrisk=True)
+    for _ in range(5):
+        loop.replay()
+    st = loop.read_stats()
+    assert st["env_steps"] == loop.total_numsteps and st["sac_updates"] == st["qrisk_updates"] >= 5
+    for net in (exp.agent.critic, exp.agent.policy, exp.agent.safety_critic.safety_critic, exp.agent.safety_critic.policy):
+        assert all(torch.isfinite(p).all() for p in net.parameters())

@@ -375,3 +375,47 @@ def test_fused_step_push_matches_oracle_step_plus_pushes(env, with_outputs, n, c
     assert np.allclose(sums.cpu().numpy(), ref_sums, rtol=1e-9)
     assert np.allclose(ep_reward.cpu().numpy(), ref_ep, rtol=1e-6, atol=1e-4)
     assert int(venv.tick[0].item()) == 6
+
+
+def test_fused_step_push_counts_when_a_workgroup_wraps_over_three_super_chunks():
+    """Bandwidth-regime instance (n > 16384: second-level positive counts summed per workgroup) on a ring whose capacity
+    is NOT a multiple of the 1024-slot super-chunk: the workgroup that straddles the wrap touches the last two super-chunks
+    and super-chunk 0.  cap = 100424 = 98 * 1024 + 72; the third push starts at slot 80000, its workgroup 79 covers slots
+    100224 .. 100423 (super-chunks 97 and 98) and 0 .. 55 (super-chunk 0).  Rows start next to the walls so that ~40 % of
+    them are constraint positives.  Tables (chunk counts, super-chunk counts, slot masks) = a function of the stored rows."""
+    import ctypes as C
+    from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
+    from test_replay_gpu import assert_count_tables
+    lib = _lib.load()
+    n, cap = 40000, 100424
+    assert 0 < cap % 1024 < 255 and (cap - 80000) % 256 > cap % 1024
+    rng = np.random.RandomState(11)
+    venv = make_vec_env("navigation1", n, device=DEV, seed=5)
+    venv.reset()
+    start = np.stack([rng.uniform(-70, 40, n), rng.uniform(3.5, 6.5, n) * rng.choice([-1, 1], n)], 1)
+    venv.pos.copy_(torch.as_tensor(start, device=DEV))
+    venv.obs.copy_(torch.as_tensor(start.astype(np.float32), device=DEV))
+    mem, rmem = ReplayMemory(cap, 1, device=DEV), ConstraintReplayMemory(cap, 1, device=DEV)
+    ormem = co.OracleReplay(cap)
+    stats = torch.zeros(10, dtype=torch.int64, device=DEV)
+    sums = torch.zeros(2, dtype=torch.float64, device=DEV)
+    ep_reward = torch.zeros(n, device=DEV)
+    pos, t = start.copy(), np.zeros(n, np.int32)
+    for k in range(6):
+        obs_prev = venv.obs.cpu().numpy().copy()
+        real = torch.as_tensor(rng.uniform(-1, 1, (n, 2)).astype(np.float32), device=DEV)
+        rec = torch.zeros(n, dtype=torch.uint8, device=DEV)
+        rc = lib.rrl_nav_step_push(0, n, _lib.ptr(venv.pos), _lib.ptr(venv.t), _lib.ptr(venv.obs), _lib.ptr(real),
+                                   _lib.ptr(real), _lib.ptr(rec), 5, 0, _lib.ptr(venv.tick), 1, 100, 1, 0.0, 0,
+                                   C.byref(mem._desc), C.byref(rmem._desc), None, None, None, None, None, None,
+                                   _lib.ptr(stats), _lib.ptr(sums), _lib.ptr(ep_reward), _lib.current_stream())
+        assert rc == 0
+        ref = co.nav_step("navigation1", pos, real.cpu().numpy(), t, seed=5, counter=1 + k, auto_reset=True)
+        pos, t = ref["pos"], ref["t"]
+        ormem.push(obs_prev, real.cpu().numpy(), ref["constraint"].astype(np.float32), ref["next_obs"],
+                   1.0 - ref["done"].astype(np.float32))
+        assert np.array_equal(rmem.r.cpu().numpy(), ormem.r)
+        assert_count_tables(rmem, ormem, cap)
+    assert 0.1 < float((ormem.r != 0).mean()) < 0.9
+    rmem.rebuild_pos_cnt()                  # the torch re-computation used when a checkpoint carries another layout
+    assert_count_tables(rmem, ormem, cap)

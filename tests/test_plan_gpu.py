@@ -144,3 +144,39 @@ def test_fused_cost_at_config4_scale_4096_planning_envs(f16x3):
     free = mpc._compile_cost(acs, obs, fused=True)
     assert torch.isfinite(free).all() and int(mpc.fused.tick[0].item()) == t0 + 1
     assert float((free - got).abs().mean()) > 1e-4
+
+
+@pytest.mark.parametrize("f16x3", [False, True])
+@pytest.mark.parametrize("n,frac", [(64, 0.3), (64, 0.0), (64, 1.0), (700, 0.05)])
+def test_act_with_the_planning_set_counted_on_the_device_equals_the_host_count_path(n, frac, f16x3):
+    """MPC.act(obs, t, mask): the device-count path (rrl_cem_begin -> rrl_cem_sample_n / rrl_plan_cost_n /
+    rrl_cem_update_n -> rrl_cem_finish; no host synchronisation) against the path that compacts with mask.nonzero() on the
+    host: same actions, same shifted solutions, same RNG ticks, bit for bit -- incl. an empty and a full planning set, over
+    two consecutive calls (prev_sol carried between them)."""
+    _, mpc, agent = build(seed=5, f16x3=f16x3)
+    g = torch.Generator(device=DEV).manual_seed(n)
+    results = []
+    for device_count in (False, True):
+        mpc.device_count = device_count
+        mpc.prev_sol = torch.zeros(n, mpc.plan_hor * 2, dtype=torch.float64, device=DEV)
+        mpc.optimizer.tick.zero_()
+        mpc.fused.tick.zero_()
+        g.manual_seed(n)
+        outs = []
+        for call in range(2):
+            obs = torch.randn(n, 2, device=DEV, generator=g) * torch.tensor([1.5, 1.0], device=DEV)
+            mask = torch.rand(n, device=DEV, generator=g) < frac
+            outs.append(mpc.act(obs, 0, mask=mask).clone())
+            if frac not in (0.0, 1.0):
+                assert 0 < int(mask.sum()) < n
+            if device_count:
+                assert int(mpc.last_count.item()) == int(mask.sum())
+                assert (outs[-1][~mask] == 0).all()
+        results.append((outs, mpc.prev_sol.clone(), mpc.optimizer.tick.clone(), mpc.fused.tick.clone()))
+    (o0, p0, t0, f0), (o1, p1, t1, f1) = results
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    assert torch.equal(p0, p1)
+    if frac > 0:           # the host path skips the CEM for an empty set; the device path launches it for zero problems
+        assert torch.equal(t0, t1) and torch.equal(f0, f1)
+        assert float(o0[0].abs().max()) > 0
