@@ -37,7 +37,8 @@ from recovery_rl_amd import runtime as rrl_runtime  # noqa: E402
 RUNTIME = rrl_runtime.configure(graph_packet_capture=0, log=False)
 
 NUM_ENVS = 4096
-MIN_TIMED_S = 0.5
+MIN_TIMED_S = 3.0                # timed region of the headline leg (an external SMI sampler must be able to see it)
+MIN_TIMED_LEG_S = 1.0            # ... of the secondary legs (U = 16, config 4)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 NAV_STEP_ALGO_BYTES = 39         # algorithmic bytes per env-step (f32 contract)
 STEP_PUSH_ALGO_BYTES = 39 + 32 + 32   # + one 32-byte replay row into each of the two buffers (section 8d "replay")
@@ -282,16 +283,18 @@ def time_nav_rollout_kernel(device, n=1 << 20, T=100):
 
 
 def committed_pmc(name, key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes under profiles/ (PMC passes cannot run inside
-    this process).  None when no measurement exists for this size."""
-    for rnd in ("round2", "round1"):
+    """(HBM bytes per launch, source file) from the committed rocprofv3 PMC passes under profiles/ (PMC passes cannot run
+    inside this process: the figure is NOT measured by this run, `traffic_source` in the JSON line says where it comes
+    from).  (None, None) when no measurement exists for this size."""
+    for rnd in ("round3", "round2", "round1"):
+        rel = os.path.join("profiles", "%s_%s.json" % (rnd, name))
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name)))).get(str(key))
+            rec = json.load(open(os.path.join(ROOT, rel))).get(str(key))
             if rec is not None:
-                return rec["fetch_bytes"] + rec["write_bytes"]
+                return rec["fetch_bytes"] + rec["write_bytes"], rel
         except (OSError, ValueError):
             pass
-    return None
+    return None, None
 
 
 # algorithmic FLOPs of one lock-step iteration (SURVEY.md section 8d): SAC update 0.685 GFLOP, Q_risk + recovery
@@ -475,6 +478,58 @@ def run_config(a, cfg, device, world, rank, updates_per_step=1, min_seconds=MIN_
             "device_counters": dev0 is not None}, loop
 
 
+CONFIG4_ARGV = ["--env-name", "navigation2", "--cuda", "--use_recovery", "--gamma_safe", "0.65", "--eps_safe", "0.2",
+                "--num_unsafe_transitions", "20000"]                       # configs[3]: scripts/navigation2.sh:14
+
+
+def run_config4_leg(device, precision, num_envs=NUM_ENVS, iters=30):
+    """BASELINE configs[3] (Navigation2, 4096 envs, model-based recovery: PETS/CEM through rrl_plan_cost) with the gate
+    the reference runs with -- Q_risk pre-trained for the default 10 000 steps on 20 000 offline transitions, ensemble
+    pre-trained for 50 epochs (experiment.py:261-305) -- so that only the envs whose Q_risk exceeds eps_safe plan.
+    `iters` lock-step iterations (SAC + Q_risk update, act, plan for the recovery set, step, push) are timed; the size of
+    the recovery set of every iteration is recorded ON THE DEVICE (MPC.act does not synchronise)."""
+    import torch
+    import arg_utils
+    from recovery_rl_amd.experiment import Experiment
+    cfg = arg_utils.get_args(CONFIG4_ARGV + ["--num_envs", str(num_envs), "--seed", "1", "--logdir", "/tmp/rrl_bench_c4",
+                                             "--plan_precision", precision])
+    exp = Experiment(cfg)
+    t0 = time.perf_counter()
+    exp.pretrain_critic_recovery()
+    torch.cuda.synchronize(device)
+    pre_s = time.perf_counter() - t0
+    loop, mpc = exp.loop, exp.recovery_policy
+    loop.start()
+    while not (len(exp.memory) > cfg.batch_size and loop.total_numsteps >= cfg.start_steps):
+        loop.vector_step(do_update=False, random_actions=True)
+    for _ in range(2):
+        loop.vector_step(do_update=True, online_qrisk=True)
+    sizes = torch.zeros(iters, dtype=torch.int32, device=device)
+    stats0 = loop.read_stats()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(iters):
+        loop.vector_step(do_update=True, online_qrisk=True)
+        if mpc.last_count is not None:
+            sizes[k:k + 1].copy_(mpc.last_count)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    stats1 = loop.read_stats()
+    sizes = sizes.cpu().tolist()
+    assert stats1["env_steps"] - stats0["env_steps"] == iters * num_envs
+    assert stats1["recovery_steps"] - stats0["recovery_steps"] == sum(sizes), (stats1["recovery_steps"], sum(sizes))
+    row_steps = sum(sizes) * mpc.optimizer.popsize * mpc.npart * mpc.plan_hor * mpc.optimizer.max_iters
+    return {"workload": "Navigation2, %d envs, model-based recovery (scripts/navigation2.sh:14 + --num_envs %d), "
+                        "pre-trained gate, planner kernel %s" % (num_envs, num_envs, precision),
+            "iterations": iters, "timed_seconds": dt, "ms_per_step": dt / iters * 1e3,
+            "env_steps_per_s": iters * num_envs / dt, "grad_steps_per_s": iters / dt,
+            "recovery_set_sizes": sizes, "planned_actions": sum(sizes),
+            "planner_row_steps_per_s": row_steps / dt,
+            "planner_TFLOPs_over_whole_iteration": row_steps * PLAN_FLOPS_PER_ROW_STEP / dt / 1e12,
+            "pretrain_seconds": pre_s, "graph": False,
+            "host_syncs_per_iteration": 0 if mpc.device_count else 1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -494,6 +549,11 @@ def main():
     ap.add_argument("--no_planner", action="store_true")
     ap.add_argument("--sweep", action="store_true",
                     help="also time rrl_nav_step / step_push at N = 2^12..2^24 (the bandwidth regime of the env kernels)")
+    ap.add_argument("--min_seconds", type=float, default=MIN_TIMED_S,
+                    help="timed blocks of --steps steps are repeated until this much timed work exists")
+    ap.add_argument("--no_legs", action="store_true",
+                    help="skip the secondary legs of a single-GPU run: U = 16 updates per iteration (UTD 1/256, the "
+                         "learning regime) and config 4 (Navigation2, model-based recovery, trained gate)")
     ap.add_argument("--autograd_updates", action="store_true",
                     help="PyTorch autograd + vendor GEMMs for the updates instead of the fused HIP kernels")
     a = ap.parse_args()
@@ -515,7 +575,7 @@ def main():
 
     U = a.updates_per_step
     cfg = arg_utils.get_args(config_argv(a.env, dist_utils.rank_seed(1, rank), a.num_envs, U))
-    res, loop = run_config(a, cfg, device, world, rank, U)
+    res, loop = run_config(a, cfg, device, world, rank, U, min_seconds=a.min_seconds)
     elapsed, agg, n_steps = res["elapsed"], res["agg"], res["steps_total"]
 
     extra = {}
@@ -536,15 +596,40 @@ def main():
                           "qrisk_grad_steps_per_s": r["agg"]["qrisk_updates"] / r["elapsed"]})
         extra["utd_sweep"] = sweep
 
+    if world == 1 and not a.no_legs and not a.no_graph:
+        import contextlib
+        # the learning regime: 16 updates per lock-step iteration (UTD 1/256), same graph mechanism
+        if U != 16:
+            del loop
+            torch.cuda.empty_cache()
+            cfg_u = arg_utils.get_args(config_argv(a.env, dist_utils.rank_seed(1, rank), a.num_envs, 16))
+            r16, loop = run_config(a, cfg_u, device, world, rank, 16, min_seconds=min(a.min_seconds, MIN_TIMED_LEG_S))
+            extra["utd_1_256"] = {
+                "updates_per_step": 16, "utd": "16/%d" % a.num_envs, "ms_per_step": r16["elapsed"] / r16["steps_total"] * 1e3,
+                "env_steps_per_s": r16["agg"]["env_steps"] / r16["elapsed"],
+                "sac_grad_steps_per_s": r16["agg"]["sac_updates"] / r16["elapsed"],
+                "qrisk_grad_steps_per_s": r16["agg"]["qrisk_updates"] / r16["elapsed"],
+                "timed_seconds": r16["elapsed"], "timed_steps_total": r16["steps_total"],
+                "grad_step_witness": "device-side Adam step counters" if r16["device_counters"] else "host counters"}
+        del loop
+        torch.cuda.empty_cache()
+        loop = None
+        if a.env == "navigation1" and a.num_envs == NUM_ENVS:
+            with contextlib.redirect_stdout(sys.stderr):       # the driver announces itself: stdout carries the JSON line only
+                extra["config4"] = {prec: run_config4_leg(device, prec) for prec in ("f32", "f16x3")}
+
     if rank == 0:
         t_k = time_step_push_kernel(device, a.env, a.num_envs)
         gbs = a.num_envs * STEP_PUSH_ALGO_BYTES / t_k / 1e9
+        traffic, traffic_src = committed_pmc("step_push_pmc", a.num_envs) if a.env == "navigation1" else (None, None)
         extra["roofline"] = {
             "kernel": "step_push_kernel<%s> (rrl_%s_step_push): env step + two replay pushes + episode counters, the "
                       "env kernel of the timed iteration" % ("MazeEnv" if a.env == "maze" else "NavEnv<0>",
                                                              "maze" if a.env == "maze" else "nav"),
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": committed_pmc("step_push_pmc", a.num_envs) if a.env == "navigation1" else None,
+            "traffic": traffic, "traffic_source": (
+                "committed rocprofv3 PMC passes (TCC fetch / write bytes, separate passes), %s entry '%d'; not "
+                "re-measured by this run" % (traffic_src, a.num_envs)) if traffic is not None else None,
             "launch_us": t_k * 1e6, "algorithmic_bytes_per_env_step": STEP_PUSH_ALGO_BYTES,
             "note": "N=%d moves only %d KB per launch: latency-bound by construction; bandwidth regime "
                     "(N up to 2^24, `bench.py --sweep`): profiles/round2_roofline_sweep.json"
@@ -588,7 +673,8 @@ def main():
             extra["roofline_planner"] = {
                 "kernel": "plan_cost_kernel (rrl_plan_cost, model-based recovery of config 4)", "bound": "mfma",
                 "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
-                "traffic": committed_pmc("planner_traffic", 256), "launch_ms": t_p * 1e3,
+                "traffic": committed_pmc("planner_traffic", 256)[0],
+                "traffic_source": committed_pmc("planner_traffic", 256)[1], "launch_ms": t_p * 1e3,
                 "row_steps_per_s": row_steps / t_p,
                 "note": "f32-in/f32-acc MFMA (exact f32); algorithmic %d FLOP per particle-step"
                         % PLAN_FLOPS_PER_ROW_STEP}
@@ -624,6 +710,7 @@ def main():
             "sac_grad_steps_per_s": agg["sac_updates"] / elapsed,
             "qrisk_grad_steps_per_s": agg["qrisk_updates"] / elapsed,
             "grad_step_witness": "device-side Adam step counters" if res["device_counters"] else "host counters",
+            "runtime": RUNTIME, "collective_backend": dist_utils.backend_name(world),
             "config": {"workload": "%s, %d vectorised envs/GPU, SAC + Q_risk + model-free recovery "
                                    "(scripts/%s + --num_envs %d), batch 256, hidden 256, "
                                    "updates_per_step %d (UTD %d/%d), one seed per GPU"

@@ -16,11 +16,21 @@ def env_rank():
         int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for one process)."""
+_FORCED = False       # a 1-rank process group was asked for: the collectives below then really run
+
+
+def init(backend=None, force=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for one process, unless `force` or
+    RRL_DIST_FORCE_INIT=1 asks for a 1-rank process group: then every collective of this module goes through the
+    backend -- RCCL on the GPU box -- exactly as it does with 8 ranks; used to prove the RCCL path on a 1-GPU box)."""
+    global _FORCED
     import torch.distributed as dist
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("RRL_DIST_FORCE_INIT", "") not in ("", "0")
+    if world == 1 and force:
+        _FORCED = True
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -48,7 +58,7 @@ def aggregate_stats(stats, world_size, device):
     """Sum the metric vector over ranks: one 96-byte all-reduce (latency-bound; xGMI bandwidth is
     irrelevant at this size, so it runs at logging cadence, never per step)."""
     import torch.distributed as dist
-    if world_size <= 1 or not dist.is_initialized():
+    if not _active(world_size):
         return dict(stats)
     vec = torch.tensor([float(stats[k]) for k in METRIC_KEYS], dtype=torch.float64, device=device)
     dist.all_reduce(vec, op=dist.ReduceOp.SUM)
@@ -60,7 +70,7 @@ def aggregate_stats(stats, world_size, device):
 
 def max_over_ranks(value, world_size, device):
     import torch.distributed as dist
-    if world_size <= 1 or not dist.is_initialized():
+    if not _active(world_size):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -69,5 +79,16 @@ def max_over_ranks(value, world_size, device):
 
 def barrier(world_size):
     import torch.distributed as dist
-    if world_size > 1 and dist.is_initialized():
+    if _active(world_size):
         dist.barrier()
+
+
+def _active(world_size):
+    import torch.distributed as dist
+    return (world_size > 1 or _FORCED) and dist.is_initialized()
+
+
+def backend_name(world_size=1):
+    """'nccl' (= RCCL on ROCm) / 'gloo' when collectives run, None for a plain single process."""
+    import torch.distributed as dist
+    return dist.get_backend() if _active(world_size) else None

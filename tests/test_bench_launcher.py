@@ -98,8 +98,8 @@ def test_bench_gpus_2_runs_two_ranks_and_reports_them(tmp_path):
     env = dict(os.environ, RRL_DIST_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-                          "--num_envs", "512", "--no_cpu_baseline", "--no_planner"], env=env, capture_output=True,
-                         text=True, timeout=600)
+                          "--num_envs", "512", "--no_cpu_baseline", "--no_planner", "--no_legs", "--min_seconds", "0.5"],
+                         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, out.stdout[-2000:]
@@ -117,11 +117,90 @@ def test_bench_maze_leg_and_contradicting_world_size():
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--env", "maze", "--steps", "20", "--warmup",
-                          "5", "--num_envs", "1024", "--no_cpu_baseline", "--no_planner"], env=env, capture_output=True,
-                         text=True, timeout=600)
+                          "5", "--num_envs", "1024", "--no_cpu_baseline", "--no_planner", "--no_legs", "--min_seconds", "0.5"],
+                         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert r["n_gpus"] == 1 and r["config"]["workload"].startswith("Maze, 1024")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+RCCL_PROBE = """
+import os, sys, json
+sys.path.insert(0, %r)
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
+import torch
+import torch.distributed as dist
+from recovery_rl_amd import distributed as du
+rank, local_rank, world = du.init(backend="nccl", force=True)        # backend "nccl" IS RCCL on ROCm
+dev = du.local_device(local_rank)
+torch.cuda.set_device(dev)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and du.backend_name(world) == "nccl"
+stats = {k: i + 1 for i, k in enumerate(du.METRIC_KEYS)}
+stats["reward_sum"], stats["episode_return_sum"] = -12.5, 3.25
+agg = du.aggregate_stats(stats, world, dev)                          # all_reduce(SUM) of the 12-element f64 vector
+mx = du.max_over_ranks(0.125, world, dev)                            # all_reduce(MAX)
+du.barrier(world)
+big = torch.arange(1 << 20, dtype=torch.float32, device=dev)         # and one bandwidth-sized reduction through RCCL
+dist.all_reduce(big)
+torch.cuda.synchronize()
+print(json.dumps({"agg": agg, "max": mx, "backend": dist.get_backend(), "big_ok": bool(big[12345].item() == 12345.0),
+                  "nccl_version": list(torch.cuda.nccl.version())}))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_backend_runs_the_metric_collectives_on_the_box():
+    """the only collectives of the path (metric all-reduce at logging cadence, max-over-ranks of the bench
+    time, barrier) through backend `nccl` = RCCL on cuda:0 -- a 1-rank process group, i.e. the code path the 8-GPU run
+    takes, minus the peers."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, "-c", RCCL_PROBE % (ROOT, str(bench.free_port()))], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["backend"] == "nccl" and r["big_ok"] and r["max"] == 0.125
+    from recovery_rl_amd import distributed as du
+    for i, k in enumerate(du.METRIC_KEYS[:10]):
+        assert r["agg"][k] == i + 1
+    assert r["agg"]["reward_sum"] == -12.5 and r["agg"]["episode_return_sum"] == 3.25
+
+
+@pytest.mark.gpu
+def test_bench_through_rccl_on_one_rank():
+    """The whole bench with its barrier / max-over-ranks / metric all-reduce going through RCCL (RRL_DIST_FORCE_INIT=1:
+    a 1-rank `nccl` process group): the line reports the backend."""
+    env = dict(os.environ, RRL_DIST_FORCE_INIT="1", RRL_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(bench.free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--num_envs",
+                          "512", "--no_cpu_baseline", "--no_planner", "--no_legs", "--min_seconds", "0.3"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["collective_backend"] == "nccl" and r["n_gpus"] == 1
+    assert r["runtime"]["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0" and r["runtime"]["set_by_launcher"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_8_dry_run_aggregates_eight_ranks():
+    """`python bench.py --gpus 8` as the driver's SCALE run issues it, dry-run on the box's single GPU (gloo for the
+    96-byte all-reduces, 8 ranks sharing cuda:0): one JSON line, n_gpus 8, the value is eight seeds' worth of env-steps
+    over the max-over-ranks time, eight ranks' device-side grad-step counters."""
+    env = dict(os.environ, RRL_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "10", "--warmup", "3",
+                          "--num_envs", "256", "--no_cpu_baseline", "--min_seconds", "0.2"], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:]
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 8 and r["collective_backend"] == "gloo" and "utd_1_256" not in r and "config4" not in r
+    assert abs(r["value"] - 8 * 256 * r["timed_steps_total"] / r["timed_seconds"]) < 1e-6 * r["value"]
+    assert abs(r["sac_grad_steps_per_s"] - 8 * r["timed_steps_total"] / r["timed_seconds"]) < 1e-6 * r["sac_grad_steps_per_s"]
+    assert r["config"]["parallelism"].startswith("replicas x8")

@@ -1,0 +1,73 @@
+"""Full-size lock-step loops of BASELINE configs 3 and 4 through the driver (`Experiment.run`, 4096 envs, the reference's
+command lines scripts/maze.sh:7 and scripts/navigation2.sh:14 + --num_envs 4096), ~100 iterations each: sampler error flags,
+composition of the stratified draw, size of the recovery set, counters, the online ensemble re-fit of config 4."""
+import numpy as np
+import pytest
+import torch
+
+import arg_utils
+from recovery_rl_amd.experiment import Experiment
+
+pytestmark = pytest.mark.gpu
+N = 4096
+
+
+def run(argv, tmp_path, iters=100, log_every=25):
+    cfg = arg_utils.get_args(argv + ["--cuda", "--num_envs", str(N), "--seed", "1", "--logdir", str(tmp_path), "--eval", "",
+                                     "--log_every", str(log_every), "--num_steps", str(iters * N - 1)])
+    exp = Experiment(cfg)
+    hist = exp.run()                      # read_stats() at every log point raises if a sampler set its error flag
+    assert hist[-1]["iteration"] >= iters and hist[-1]["env_steps"] == hist[-1]["iteration"] * N
+    return exp, hist
+
+
+def test_config3_maze_model_free_recovery_at_4096_envs(tmp_path):
+    exp, hist = run(["--env-name", "maze", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.5", "--eps_safe", "0.15",
+                     "--pos_fraction", "0.3"], tmp_path)
+    last, cfg = hist[-1], exp.exp_cfg
+    assert exp.loop.graph is not None                                   # steady state replayed from one hipGraph
+    assert int(exp.memory.state[3].item()) == 0 and int(exp.recovery_memory.state[3].item()) == 0    # error flags
+    assert last["sac_updates"] >= 95 and last["qrisk_updates"] >= 95
+    assert int(exp.agent.fast.critic.step[0].item()) == last["sac_updates"]          # device-side optimiser counters
+    assert 0 < last["recovery_steps"] < last["env_steps"] and last["episodes"] > 0
+    assert last["num_viols"] == last["viol_and_recovery"] + last["viol_and_no_recovery"]
+    # the stratified draw of the Q_risk update (replay_memory.py:54-72): int(B * 0.3) = 76 positives first, then 180 negatives
+    rm = exp.recovery_memory
+    size = int(rm.state[1].item())
+    assert size == len(rm) == exp.num_unsafe_transitions + last["iteration"] * N
+    n_pos = int((rm.r[:size] != 0).sum().item())
+    assert n_pos >= 76, "the positive class is not starved after 100 iterations"
+    s, a, c, s2, m = rm.sample(cfg.batch_size, pos_fraction=cfg.pos_fraction)
+    c = c.reshape(-1).cpu().numpy()
+    assert c.shape == (256,) and (c[:76] == 1).all() and (c[76:] == 0).all()
+    rm.check_error()
+    # pos_cnt (three count levels) is consistent with the rows after 100 fused pushes
+    n_chunks = (rm.capacity + 63) // 64
+    filled = torch.zeros(n_chunks * 64, dtype=torch.int32, device=rm.r.device)
+    filled[:size] = (rm.r[:size] != 0).to(torch.int32)
+    assert torch.equal(rm.pos_cnt[:n_chunks], filled.view(-1, 64).sum(1).to(torch.int32))
+
+
+@pytest.mark.parametrize("precision", ("f32", "f16x3"))
+def test_config4_navigation2_model_based_recovery_at_4096_envs(tmp_path, precision):
+    exp, hist = run(["--env-name", "navigation2", "--use_recovery", "--gamma_safe", "0.65", "--eps_safe", "0.2",
+                     "--num_unsafe_transitions", "20000", "--plan_precision", precision], tmp_path)
+    last, mpc = hist[-1], exp.recovery_policy
+    assert int(exp.memory.state[3].item()) == 0 and int(exp.recovery_memory.state[3].item()) == 0
+    assert mpc.fused is not None and mpc.fused.f16x3 == (precision == "f16x3") and mpc.has_been_trained
+    assert mpc.device_count and mpc.last_count is not None              # planning set counted on the device
+    # the gate is the pre-trained Q_risk: some, not all, env-steps are under the recovery controller
+    assert 0 < last["recovery_steps"] < 0.6 * last["env_steps"], last
+    per_log = np.diff([0] + [h["recovery_steps"] for h in hist])
+    assert (per_log >= 0).all() and per_log.sum() == last["recovery_steps"]
+    assert last["sac_updates"] >= 95 and last["qrisk_updates"] >= 95 and last["episodes"] > 0
+    # the online re-fit (experiment.py:464-480): every recovery_policy_update_freq * horizon iterations on ALL data
+    rows = exp.num_unsafe_transitions + 100 * N
+    assert mpc.train_in.shape[0] == rows and mpc.train_targs.shape[0] == rows
+    for name in ("lin0_w", "lin1_w", "lin2_w", "lin3_w", "max_logvar", "min_logvar"):
+        assert torch.isfinite(getattr(mpc.model, name)).all()
+    with torch.no_grad():                  # the re-fitted ensemble predicts the nav2 dynamics s' = s + a (navigation2.py:98-103)
+        s = torch.tensor([[-45.0, 1.0], [-10.0, -12.0]], device=exp.device)
+        a = torch.tensor([[1.0, 0.0], [0.0, 1.0]], device=exp.device)
+        mean, _ = mpc.model(torch.cat([s, a], 1).unsqueeze(0).expand(mpc.model.num_nets, -1, -1))
+        assert (mean.mean(0) - a).abs().max() < 0.2
