@@ -183,7 +183,7 @@ def test_bench_through_rccl_on_one_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert r["collective_backend"] == "nccl" and r["n_gpus"] == 1
-    assert r["runtime"]["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0" and r["runtime"]["set_by_launcher"]
+    assert r["runtime"]["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0"        # the graph replay mode in force is part of the line
 
 
 @pytest.mark.gpu

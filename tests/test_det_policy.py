@@ -106,7 +106,7 @@ def test_deterministic_policy_script_line_runs_on_the_gpu(tmp_path, extra):
     data = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))
     assert len(data["train_stats"]) == 2 and exp.updates > 0 and isinstance(exp.agent.policy, DeterministicPolicy)
     w0 = exp.agent.policy.mean.weight.clone()
-    vec = Experiment(arg_utils.get_args(base + ["--num_envs", "64", "--num_eps", "100", "--log_every", "20", "--logdir",
+    vec = Experiment(arg_utils.get_args(base + ["--num_envs", "64", "--num_eps", "1000", "--log_every", "20", "--logdir",
                                                  str(tmp_path / "vec")]))
     hist = vec.run()
     assert hist and hist[-1]["sac_updates"] > 20 and vec.loop.graph is not None

@@ -381,8 +381,8 @@ def test_fused_step_push_counts_when_a_workgroup_wraps_over_three_super_chunks()
     """Bandwidth-regime instance (n > 16384: second-level positive counts summed per workgroup) on a ring whose capacity
     is NOT a multiple of the 1024-slot super-chunk: the workgroup that straddles the wrap touches the last two super-chunks
     and super-chunk 0.  cap = 100424 = 98 * 1024 + 72; the third push starts at slot 80000, its workgroup 79 covers slots
-    100224 .. 100423 (super-chunks 97 and 98) and 0 .. 55 (super-chunk 0).  Rows start next to the walls so that ~40 % of
-    them are constraint positives.  Tables (chunk counts, super-chunk counts, slot masks) = a function of the stored rows."""
+    100224 .. 100423 (super-chunks 97 and 98) and 0 .. 55 (super-chunk 0).  Half of the envs start inside a wall and stay
+    there (no auto-reset: `_next_state` returns the state unchanged), so about half of all rows are constraint positives.  Tables (chunk counts, super-chunk counts, slot masks) = a function of the stored rows."""
     import ctypes as C
     from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
     from test_replay_gpu import assert_count_tables
@@ -406,11 +406,11 @@ def test_fused_step_push_counts_when_a_workgroup_wraps_over_three_super_chunks()
         real = torch.as_tensor(rng.uniform(-1, 1, (n, 2)).astype(np.float32), device=DEV)
         rec = torch.zeros(n, dtype=torch.uint8, device=DEV)
         rc = lib.rrl_nav_step_push(0, n, _lib.ptr(venv.pos), _lib.ptr(venv.t), _lib.ptr(venv.obs), _lib.ptr(real),
-                                   _lib.ptr(real), _lib.ptr(rec), 5, 0, _lib.ptr(venv.tick), 1, 100, 1, 0.0, 0,
+                                   _lib.ptr(real), _lib.ptr(rec), 5, 0, _lib.ptr(venv.tick), 1, 100, 0, 0.0, 0,
                                    C.byref(mem._desc), C.byref(rmem._desc), None, None, None, None, None, None,
                                    _lib.ptr(stats), _lib.ptr(sums), _lib.ptr(ep_reward), _lib.current_stream())
         assert rc == 0
-        ref = co.nav_step("navigation1", pos, real.cpu().numpy(), t, seed=5, counter=1 + k, auto_reset=True)
+        ref = co.nav_step("navigation1", pos, real.cpu().numpy(), t, seed=5, counter=1 + k, auto_reset=False)
         pos, t = ref["pos"], ref["t"]
         ormem.push(obs_prev, real.cpu().numpy(), ref["constraint"].astype(np.float32), ref["next_obs"],
                    1.0 - ref["done"].astype(np.float32))
