@@ -669,6 +669,22 @@ int rrl_ens_train_epoch(const rrl_ens_t* m, int n_seg, const rrl_adam_seg_t* seg
 int rrl_ens_train_grad(const rrl_ens_t* m, int batch, const float* train_in, const float* train_targ,
                        const int64_t* idx, long long idx_stride, float* scratch, float* loss_out, void* stream);
 
+/* The same optimiser step at LARGE batch (the lock-step loop's online re-fit trains on 32 x num_envs rows per member per
+ * step, experiment.py:464-480 scaled by the number of envs; any batch >= 1 is accepted): same loss, same gradients
+ * (to f32 summation order), same rrl_ens_t, gradients land in g_* only (g2_*, g_logvar_part, loss_part are not used: pass
+ * Adam segments without g2).  Three launches: forward + backward per 64-row tile with the activations in LDS (f32 MFMA),
+ * split-K weight-gradient products, fixed-order reduction of the partials (deterministic).
+ *   scratch     float [rrl_ens_big_scratch_floats(E, batch)]  (6 activation-sized buffers [E][ceil64(batch)][200] + partials)
+ *   idx         int64, member e's rows at idx[e * idx_stride + 0 .. batch) */
+int rrl_ens_train_big_supported(int d_in, int hidden, int d_out);
+long long rrl_ens_big_scratch_floats(int n_nets, long long batch);
+int rrl_ens_train_grad_big(const rrl_ens_t* m, long long batch, const float* train_in, const float* train_targ,
+                           const int64_t* idx, long long idx_stride, float* scratch, float* loss_out, void* stream);
+int rrl_ens_train_epoch_big(const rrl_ens_t* m, int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2,
+                            float eps, const float* train_in, const float* train_targ, const int64_t* idx,
+                            long long idx_stride, long long n_rows, long long batch, float* scratch, float* loss_out,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -203,13 +203,16 @@ class MPC:
                     st[0] = int(float(state["step"]))
 
     def _fused_trainer(self, batch_size):
-        """FusedEnsembleTrainer when the shapes are the kernel's (4-200-200-200-4, batch <= 32), else None."""
+        """FusedEnsembleTrainer when the shapes are the kernels' (4-200-200-200-4; batch <= 32: the one-launch kernel,
+        larger: the large-batch MFMA kernels of the lock-step loop's re-fit), else None."""
         if not self.fused_train or self.train_in.device.type != "cuda":
             return None
         from .ensemble_train import FusedEnsembleTrainer
-        if self._trainer is None and FusedEnsembleTrainer.supported(self.model, batch_size):
+        if not FusedEnsembleTrainer.supported(self.model, batch_size):
+            return None
+        if self._trainer is None:
             self._trainer = FusedEnsembleTrainer(self.model, lr=self.model.optim.param_groups[0]["lr"])
-        return self._trainer if (self._trainer is not None and batch_size <= 32) else None
+        return self._trainer
 
     def _train_step(self, bi):
         """One optimiser step on the bootstrap rows bi [num_nets, batch] (MPC.py:270-292)."""

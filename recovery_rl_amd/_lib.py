@@ -14,7 +14,8 @@ SO_PATH = os.environ.get("RRL_HIP_LIB") or os.path.join(CSRC, "librrl_hip.so")  
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["nav_kernels.hip", "replay_kernels.hip", "maze_kernels.hip", "cem_kernels.hip",
-               "mlp_kernels.hip", "update_kernels.hip", "log_kernels.hip", "plan_kernels.hip", "ens_train_kernels.hip"]
+               "mlp_kernels.hip", "update_kernels.hip", "log_kernels.hip", "plan_kernels.hip", "ens_train_kernels.hip",
+               "ens_train_big_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                "-Wno-bitwise-instead-of-logical"]
@@ -36,6 +37,7 @@ EXPORTS = [
     "rrl_plan_supported", "rrl_plan_pack_floats", "rrl_plan_pack", "rrl_plan_cost", "rrl_plan_pack_f16x3",
     "rrl_plan_cost_f16x3", "rrl_plan_cost_n",
     "rrl_ens_train_supported", "rrl_ens_scratch_floats", "rrl_ens_train_grad", "rrl_ens_train_epoch",
+    "rrl_ens_train_big_supported", "rrl_ens_big_scratch_floats", "rrl_ens_train_grad_big", "rrl_ens_train_epoch_big",
 ]
 
 
@@ -257,6 +259,11 @@ def _declare(lib):
         "rrl_ens_train_epoch": (ci, [C.POINTER(rrl_ens_t), ci, C.POINTER(rrl_adam_seg_t), f32, f32, f32, f32, vp, vp,
                                      vp, ll, ll, ci, vp, vp, vp]),
         "rrl_ens_train_grad": (ci, [C.POINTER(rrl_ens_t), ci, vp, vp, vp, ll, vp, vp, vp]),
+        "rrl_ens_train_big_supported": (ci, [ci, ci, ci]),
+        "rrl_ens_big_scratch_floats": (ll, [ci, ll]),
+        "rrl_ens_train_grad_big": (ci, [C.POINTER(rrl_ens_t), ll, vp, vp, vp, ll, vp, vp, vp]),
+        "rrl_ens_train_epoch_big": (ci, [C.POINTER(rrl_ens_t), ci, C.POINTER(rrl_adam_seg_t), f32, f32, f32, f32, vp, vp,
+                                         vp, ll, ll, ll, vp, vp, vp]),
         "rrl_episode_log_append": (ci, [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(rrl_episode_log_t), vp]),
     }
     for name, (res, args) in sig.items():

@@ -42,12 +42,27 @@ class FusedEnsembleTrainer:
                                                 DECAY.get(PARAMS[k], 0.0),
                                                 self.grads2[k].data_ptr() if k < 8 else None)
 
+        # large-batch path (rrl_ens_train_grad_big): gradients land in self.grads only
+        self._segs_big = (_lib.rrl_adam_seg_t * len(self.params))()
+        for k, p in enumerate(self.params):
+            self._segs_big[k] = _lib.rrl_adam_seg_t(p.numel(), p.data_ptr(), self.grads[k].data_ptr(),
+                                                    self.m[k].data_ptr(), self.v[k].data_ptr(), self.steps[k].data_ptr(),
+                                                    None, 0.0, DECAY.get(PARAMS[k], 0.0), None)
+        self._scratch_big = None
+
+    SMALL_BATCH = 32
+
     @staticmethod
     def supported(model, batch_size):
+        """The kernels cover the reference's ensemble shape (4-200-200-200-4): batch <= 32 on the one-launch kernel,
+        anything larger on the large-batch kernels."""
         lib = _lib.load()
-        return (model.lin0_w.is_cuda and
-                bool(lib.rrl_ens_train_supported(int(model.in_features), int(model.lin1_w.shape[1]),
-                                                 int(model.out_features), int(batch_size))))
+        if not model.lin0_w.is_cuda:
+            return False
+        shape = (int(model.in_features), int(model.lin1_w.shape[1]), int(model.out_features))
+        if batch_size <= FusedEnsembleTrainer.SMALL_BATCH:
+            return bool(lib.rrl_ens_train_supported(shape[0], shape[1], shape[2], int(batch_size)))
+        return bool(lib.rrl_ens_train_big_supported(*shape))
 
     def _desc(self):
         m = self.model
@@ -80,9 +95,41 @@ class FusedEnsembleTrainer:
                                           self.eps, _lib.current_stream())
         _lib.check(rc, "rrl_adam_step_multi")
 
+    def _big_scratch(self, batch):
+        need = int(self.lib.rrl_ens_big_scratch_floats(self.E, int(batch)))
+        if self._scratch_big is None or self._scratch_big.numel() < need:
+            self._scratch_big = None        # release first: 3.1 GB at batch 131 072
+            self._scratch_big = torch.empty(need, device=self.device)
+        return self._scratch_big
+
+    def gradients_big(self, idx):
+        """idx: int64 [E, batch], any batch >= 1: the large-batch kernels (rrl_ens_train_grad_big).  Fills self.grads
+        (without the weight-decay terms) and self.loss."""
+        assert idx.dtype == torch.int64 and idx.stride(1) == 1 and idx.shape[0] == self.E
+        rc = self.lib.rrl_ens_train_grad_big(C.byref(self._d), int(idx.shape[1]), _lib.ptr(self._data[0]),
+                                             _lib.ptr(self._data[1]), _lib.ptr(idx), idx.stride(0),
+                                             _lib.ptr(self._big_scratch(idx.shape[1])), _lib.ptr(self.loss),
+                                             _lib.current_stream())
+        _lib.check(rc, "rrl_ens_train_grad_big")
+
+    def step_big(self, idx):
+        self.gradients_big(idx)
+        rc = self.lib.rrl_adam_step_multi(len(self.params), self._segs_big, self.lr, self.betas[0], self.betas[1],
+                                          self.eps, _lib.current_stream())
+        _lib.check(rc, "rrl_adam_step_multi")
+
     def epoch(self, idxs, batch_size):
         """All ceil(n / batch_size) steps over the columns of idxs [E, n], launched from one C loop."""
         assert idxs.dtype == torch.int64 and idxs.stride(1) == 1 and idxs.shape[0] == self.E
+        if batch_size > self.SMALL_BATCH:
+            rc = self.lib.rrl_ens_train_epoch_big(C.byref(self._d), len(self.params), self._segs_big, self.lr,
+                                                  self.betas[0], self.betas[1], self.eps, _lib.ptr(self._data[0]),
+                                                  _lib.ptr(self._data[1]), _lib.ptr(idxs), idxs.stride(0),
+                                                  int(idxs.shape[1]), int(batch_size),
+                                                  _lib.ptr(self._big_scratch(min(batch_size, idxs.shape[1]))),
+                                                  _lib.ptr(self.loss), _lib.current_stream())
+            _lib.check(rc, "rrl_ens_train_epoch_big")
+            return
         rc = self.lib.rrl_ens_train_epoch(C.byref(self._d), len(self.params), self._segs, self.lr, self.betas[0],
                                           self.betas[1], self.eps, _lib.ptr(self._data[0]), _lib.ptr(self._data[1]),
                                           _lib.ptr(idxs), idxs.stride(0), int(idxs.shape[1]), int(batch_size),

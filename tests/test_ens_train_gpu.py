@@ -173,8 +173,9 @@ def test_training_run_equals_the_reference(fused, monkeypatch):
 
 
 def test_adam_state_moves_with_the_training_path():
-    """Batch <= 32 runs on the fused trainer, larger batches on torch.optim.Adam: the moments and the step count are
-    handed over, so a re-fit does not restart the bias correction (ONE optimiser in the reference)."""
+    """The fused trainer and torch.optim.Adam (the general path: other shapes, `fused_train = False`) each hold moments
+    and a step count: they are handed over, so a re-fit on the other path does not restart the bias correction (ONE
+    optimiser in the reference)."""
     mpc, idxs = build(7)
     n = mpc.train_in.shape[0]
     s, a = mpc.train_in[:, :2].contiguous(), mpc.train_in[:, 2:].contiguous()
@@ -183,7 +184,9 @@ def test_adam_state_moves_with_the_training_path():
     mpc.train(s, a, random=True, next_obs=s2, epochs=1, batch_size=32)            # fused: ceil(700/32) = 22 steps
     assert mpc._optim_owner == "fused" and int(mpc._trainer.steps[0][0].item()) == 22
     m_fused = mpc._trainer.m[0].clone()
+    mpc.fused_train = False
     mpc.train(s[:64], a[:64], random=True, next_obs=s2[:64], epochs=1, batch_size=128)   # torch: ceil(764/128) = 6
+    mpc.fused_train = True
     assert mpc._optim_owner == "torch"
     st = mpc.model.optim.state[mpc.model.lin0_w]
     assert int(float(st["step"])) == 28
@@ -191,3 +194,109 @@ def test_adam_state_moves_with_the_training_path():
     mpc.train(s[:32], a[:32], random=True, next_obs=s2[:32], epochs=1, batch_size=32)    # back: ceil(796/32) = 25
     assert mpc._optim_owner == "fused" and int(mpc._trainer.steps[0][0].item()) == 53
     assert n == 700
+
+
+# ---- large-batch kernels (rrl_ens_train_grad_big): the lock-step loop's online re-fit -------------------------------
+def big_grads_vs(want, tr, mpc, rel):
+    for name, g in zip(PARAMS, tr.grads):
+        if name in DECAY:
+            g = g + DECAY[name] * getattr(mpc.model, name).data
+        scale = float(want[name].abs().max()) + 1e-12
+        err = float((g - want[name]).abs().max())
+        assert err <= rel * scale + 1e-9, (name, err, scale)
+
+
+@pytest.mark.parametrize("batch", (1, 31, 64, 65, 200, 1000, 4096 + 17))
+def test_large_batch_gradients_equal_autograd(batch):
+    """Ragged sizes: one row, less than a 64-row tile, exactly one, one more, several workgroups per member, a size
+    whose last tile is short and whose chunks of the weight-gradient pass are uneven."""
+    mpc, _ = build(11)
+    g = torch.Generator(device=DEV).manual_seed(batch)
+    bi = torch.randint(mpc.train_in.shape[0], (mpc.model.num_nets, batch), device=DEV, generator=g)
+    tr = FusedEnsembleTrainer(mpc.model)
+    assert FusedEnsembleTrainer.supported(mpc.model, batch if batch > 32 else 33)
+    tr.begin(mpc.train_in, mpc.train_targs)
+    want, nll = torch_grads(mpc, bi)
+    tr.gradients_big(bi)
+    torch.testing.assert_close(tr.loss, nll, rtol=2e-5, atol=1e-6)
+    big_grads_vs(want, tr, mpc, 5e-5)
+    tr.gradients_big(bi)                                       # deterministic: fixed-order reductions everywhere
+    again = [t.clone() for t in tr.grads]
+    tr.gradients_big(bi)
+    for x, y in zip(again, tr.grads):
+        assert torch.equal(x, y)
+
+
+def test_large_batch_kernels_equal_the_batch_32_kernel():
+    mpc, idxs = build(13)
+    tr = FusedEnsembleTrainer(mpc.model)
+    tr.begin(mpc.train_in, mpc.train_targs)
+    bi = idxs[:, :32]
+    tr.gradients(bi)
+    small = [g.clone() + (tr.grads2[k] if k < 8 else 0) for k, g in enumerate(tr.grads)]
+    loss = tr.loss.clone()
+    tr.gradients_big(bi)
+    torch.testing.assert_close(tr.loss, loss, rtol=1e-5, atol=1e-6)
+    for name, a, b in zip(PARAMS, small, tr.grads):
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, name
+
+
+def test_large_batch_gradients_at_the_config4_refit_size():
+    """Batch 131 072 = 32 x 4096 envs (experiment.py:659 at BASELINE config 4) against autograd, f32 on both sides:
+    sums over 131 072 rows in different orders agree to ~1e-4 of scale."""
+    torch.manual_seed(17)
+    env = make_vec_env("navigation2", 2, device=DEV, seed=1)
+    mpc = MPC(create_config("navigation2", "MPC", {}, [], "/tmp", env=env).ctrl_cfg, seed=1)
+    g = torch.Generator(device=DEV).manual_seed(17)
+    n, batch = 424000, 131072
+    s = torch.rand(n, 2, device=DEV, generator=g) * torch.tensor([40.0, 30.0], device=DEV) - \
+        torch.tensor([45.0, 15.0], device=DEV)
+    ac = torch.rand(n, 2, device=DEV, generator=g) * 2 - 1
+    d = ac + 0.05 * torch.randn(n, 2, device=DEV, generator=g)
+    mpc.train_in, mpc.train_targs = torch.cat([s, ac], 1).contiguous(), d.contiguous()
+    mpc.model.fit_input_stats(mpc.train_in)
+    with torch.no_grad():
+        for name in ("lin0_b", "lin1_b", "lin2_b", "lin3_b"):
+            getattr(mpc.model, name).normal_(0, 0.05)
+    idxs = torch.randint(n, (mpc.model.num_nets, n), device=DEV, generator=g)
+    bi = idxs[:, batch:2 * batch]                              # a strided view of the bootstrap table
+    tr = FusedEnsembleTrainer(mpc.model)
+    tr.begin(mpc.train_in, mpc.train_targs)
+    want, nll = torch_grads(mpc, bi)
+    tr.gradients_big(bi)
+    torch.testing.assert_close(tr.loss, nll, rtol=1e-4, atol=1e-6)
+    big_grads_vs(want, tr, mpc, 3e-4)
+
+
+def test_large_batch_epoch_tracks_the_pytorch_optimiser_and_the_training_golden():
+    """(a) MPC.train with batch 128 on 700 rows, 3 epochs: fused large-batch path vs the PyTorch path, same bootstrap
+    table and shuffles; (b) the reference's 2-epoch run (mpc_train_golden.npz, batch 32) driven through step_big."""
+    mpc_a, idxs = build(19)
+    mpc_b, _ = build(19)
+    ta = FusedEnsembleTrainer(mpc_a.model)
+    ta.begin(mpc_a.train_in, mpc_a.train_targs)
+    table = idxs[:, :96].repeat(1, 4)[:, :300].contiguous()    # 300 columns: batches of 128, 128, 44
+    for _ in range(3):
+        ta.epoch(table, 128)
+        for lo in range(0, 300, 128):
+            mpc_b._train_step(table[:, lo:lo + 128])
+    assert int(ta.steps[0][0].item()) == 9
+    for name in PARAMS:
+        pa, pb = getattr(mpc_a.model, name), getattr(mpc_b.model, name)
+        assert torch.allclose(pa, pb, rtol=1e-3, atol=2e-4), (name, float((pa - pb).abs().max()))   # 0.2 lr
+    # (b) reference run
+    mpc, T, (s, a, s2) = reference_controller(200)
+    mpc.train_in = torch.cat([s, a], 1).contiguous()
+    mpc.train_targs = (s2 - s).contiguous()
+    mpc.model.fit_input_stats(mpc.train_in)
+    tr = FusedEnsembleTrainer(mpc.model)
+    tr.begin(mpc.train_in, mpc.train_targs)
+    tables = [torch.as_tensor(T["train.idxs"], device=DEV)] + [torch.as_tensor(t, device=DEV) for t in T["train.shuffled"]]
+    for ep in range(2):
+        tab = tables[ep]
+        for lo in range(0, tab.shape[1], 32):
+            tr.step_big(tab[:, lo:lo + 32])
+    for name in PARAMS:
+        post, want = golden_view(T, name, getattr(mpc.model, name)), T["train.post." + name]
+        assert np.abs(post - want).max() < 2e-4, (name, np.abs(post - want).max())
