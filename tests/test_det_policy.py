@@ -98,8 +98,8 @@ def test_deterministic_policy_script_line_runs_on_the_gpu(tmp_path, extra):
     """`python -m rrl_main --cuda --env-name navigation1 --policy Deterministic ...` (the reference's CLI, sac.py:115-123):
     one env in the reference-order loop, then the same flags in the lock-step loop (autograd update path, hipGraph replay)."""
     from recovery_rl_amd.experiment import Experiment
-    base = ["--env-name", "navigation1", "--cuda", "--policy", "Deterministic", "--hidden_size", "32", "--batch_size", "16",
-            "--start_steps", "10", "--critic_safe_pretraining_steps", "10", "--num_unsafe_transitions", "600",
+    base = ["--env-name", "navigation1", "--cuda", "--policy", "Deterministic", "--hidden_size", "32", "--batch_size", "4",
+            "--start_steps", "3", "--critic_safe_pretraining_steps", "10", "--num_unsafe_transitions", "600",
             "--eval", "", "--seed", "2"] + extra
     exp = Experiment(arg_utils.get_args(base + ["--num_eps", "2", "--logdir", str(tmp_path / "one")]))
     exp.run()
