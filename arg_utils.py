@@ -87,6 +87,9 @@ ADDITIVE = [
                                    "'f16x3' = three f16 MFMA products of hi/lo splits (22-bit operands, 2.2x faster); "
                                    "default: f32 unless RRL_PLAN_F16X3=1"),
     (("--resume",), S, "", "checkpoint.pt to continue from (lock-step loop; skips pre-training)"),
+    (("--no_pin_demos",), "store_true", None, "lock-step loop: let the safety buffer's ring overwrite the offline constraint "
+                                              "demonstrations (default: they are pinned, as the one-env reference never "
+                                              "wraps its 1e6-row ring within a run)"),
 ]
 
 

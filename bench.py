@@ -123,6 +123,7 @@ def build_loop(cfg, device, fast=True, pretrain=50):
     # offline constraint demonstrations + a short (untimed) Q_risk pre-training
     s, a, c, s2, m = env.transition_function(cfg.num_unsafe_transitions)
     recovery_memory.push(s.contiguous(), a.contiguous(), c.contiguous(), s2.contiguous(), m.contiguous())
+    recovery_memory.pin()                 # as Experiment.pretrain_critic_recovery does for the lock-step loop
     for _ in range(pretrain):
         agent.safety_critic.update_parameters(memory=recovery_memory, policy=agent.policy,
                                               batch_size=cfg.batch_size)

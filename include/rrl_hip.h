@@ -163,6 +163,10 @@ typedef struct {
     int64_t* state;
     int32_t* pos_cnt;
     int32_t flags;       /* RRL_REPLAY_* bits */
+    int64_t pinned;      /* rows [0, pinned) are never overwritten: after slot cap - 1 the ring continues at slot `pinned`
+                          * (0 = the reference's plain ring, replay_memory.py:21-25).  The lock-step loop pins the offline
+                          * constraint demonstrations: N envs fill a 1e6-row ring in 1e6 / N iterations, whereas the one-env
+                          * reference never wraps within a run (4e4 env-steps), i.e. never loses them. */
 } rrl_replay_t;
 
 /* Stratified draws (rrl_creplay_sample_gather) that ask for more positives (or negatives) than the ring holds: the

@@ -280,7 +280,7 @@ def cem_update(samples, costs, mean, var, num_elites, alpha, active=None):
 
 class _Replay(C.Structure):
     _fields_ = [("s", C.c_void_p), ("a", C.c_void_p), ("r", C.c_void_p), ("s2", C.c_void_p),
-                ("m", C.c_void_p), ("cap", C.c_int64), ("pos", C.c_int64), ("size", C.c_int64)]
+                ("m", C.c_void_p), ("cap", C.c_int64), ("pos", C.c_int64), ("size", C.c_int64), ("pinned", C.c_int64)]
 
 
 class OracleReplay:
@@ -294,7 +294,11 @@ class OracleReplay:
         self.s2 = np.zeros((capacity, 2), np.float32)
         self.m = np.zeros(capacity, np.float32)
         self._c = _Replay(self.s.ctypes.data, self.a.ctypes.data, self.r.ctypes.data,
-                          self.s2.ctypes.data, self.m.ctypes.data, capacity, 0, 0)
+                          self.s2.ctypes.data, self.m.ctypes.data, capacity, 0, 0, 0)
+
+    def pin(self, rows=None):
+        """rows [0, rows) are never overwritten (default: everything stored so far)"""
+        self._c.pinned = self.size if rows is None else int(rows)
 
     @property
     def pos(self):

@@ -656,7 +656,7 @@ int rrl_oracle_replay_push(rrl_oracle_replay* rb, int64_t n, const float* s, con
         rb->r[p] = r[i];
         rb->s2[2 * p] = s2[2 * i]; rb->s2[2 * p + 1] = s2[2 * i + 1];
         rb->m[p] = m[i];
-        rb->pos = (p + 1) % rb->cap;
+        rb->pos = p + 1 < rb->cap ? p + 1 : rb->pinned;   /* pinned = 0: (p + 1) % capacity, replay_memory.py:25 */
         if (rb->size < rb->cap) rb->size += 1;
     }
     return 0;

@@ -120,6 +120,7 @@ typedef struct {
     int64_t cap;
     int64_t pos;    /* next write slot */
     int64_t size;   /* filled rows */
+    int64_t pinned; /* rows [0, pinned) are never overwritten (0: the reference's ring); the build's vectorisation rule */
 } rrl_oracle_replay;
 
 int rrl_oracle_replay_push(rrl_oracle_replay* rb, int64_t n, const float* s, const float* a,

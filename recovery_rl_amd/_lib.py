@@ -93,7 +93,7 @@ def build(force=False, verbose=False, jobs=None):
 class rrl_replay_t(C.Structure):
     _fields_ = [("s", C.c_void_p), ("a", C.c_void_p), ("r", C.c_void_p), ("s2", C.c_void_p),
                 ("m", C.c_void_p), ("cap", C.c_int64), ("state", C.c_void_p),
-                ("pos_cnt", C.c_void_p), ("flags", C.c_int32)]
+                ("pos_cnt", C.c_void_p), ("flags", C.c_int32), ("pinned", C.c_int64)]
 
 
 REPLAY_CLAMP_STRATIFIED = 1

@@ -28,7 +28,7 @@ def _cpu(t):
 def replay_state(mem):
     size = int(mem.state[1].item())
     out = {"capacity": mem.capacity, "size": size, "state": _cpu(mem.state), "tick": _cpu(mem.tick),
-           "len": mem._len, "len_exact": mem._len_exact}
+           "len": mem._len, "len_exact": mem._len_exact, "pinned": mem.pinned}
     for name in ("s", "a", "r", "s2", "m"):
         out[name] = _cpu(getattr(mem, name)[:size])
     if mem.pos_cnt is not None:
@@ -45,6 +45,7 @@ def load_replay_state(mem, sd):
         getattr(mem, name)[:size].copy_(sd[name])
     mem.state.copy_(sd["state"])
     mem.tick.copy_(sd["tick"])
+    mem.pin(sd.get("pinned", 0))
     if mem.pos_cnt is not None:
         same = sd.get("abi") == int(mem.lib.rrl_abi_version()) and sd["pos_cnt"].shape == mem.pos_cnt.shape
         if same:

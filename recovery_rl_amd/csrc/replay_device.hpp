@@ -93,9 +93,16 @@ __device__ __forceinline__ void store_values(const rrl_replay_t& rb, int64_t slo
     rb.m[slot] = m;
 }
 
+// slot of the i-th row pushed when the ring's cursor is at `pos` (i <= cap - pinned): past the last slot the ring continues
+// at slot `pinned` (rows [0, pinned) are never overwritten; pinned = 0: (pos + i) % cap)
+__device__ __forceinline__ int64_t ring_slot(const rrl_replay_t& rb, int64_t pos, int64_t i) {
+    const int64_t s = pos + i;
+    return s < rb.cap ? s : s - rb.cap + rb.pinned;
+}
+
 // {position, size} after `pushed` more rows (called by the one thread that won the launch's ticket)
 __device__ __forceinline__ void set_ring(const rrl_replay_t& rb, int64_t pos, int64_t size, int64_t pushed) {
-    rb.state[0] = (pos + pushed) % rb.cap;
+    rb.state[0] = ring_slot(rb, pos, pushed);
     const int64_t ns = size + pushed;
     rb.state[1] = ns > rb.cap ? rb.cap : ns;
 }
@@ -110,7 +117,7 @@ __device__ __forceinline__ void advance_ring(const rrl_replay_t& rb, int64_t pos
         // before the last arriver's write; the write itself is published by the kernel boundary
         const unsigned long long ticket = atomicAdd((unsigned long long*)&rb.state[2], 1ULL);
         if (ticket == gridDim.x - 1) {
-            rb.state[0] = (pos + pushed) % rb.cap;
+            rb.state[0] = ring_slot(rb, pos, pushed);
             const int64_t ns = size + pushed;
             rb.state[1] = ns > rb.cap ? rb.cap : ns;
             rb.state[2] = 0;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void push_kernel(rrl_replay_t rb, int64_t n
     const int64_t pos = rb.state[0], size = rb.state[1];
     const int64_t stride = int64_t(gridDim.x) * kBlock;
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
-        store_row(rb, (pos + i) % rb.cap, size, in, i);
+        store_row(rb, rrl_replay::ring_slot(rb, pos, i), size, in, i);
     advance_ring(rb, pos, size, n);
 }
 
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void push_masked_kernel(rrl_replay_t rb, in
             if (w < wave) woff += c;
             tile_tot += c;
         }
-        if (v) store_row(rb, (pos + run + woff + rank_in_wave) % rb.cap, size, in, i);
+        if (v) store_row(rb, rrl_replay::ring_slot(rb, pos, run + woff + rank_in_wave), size, in, i);
         run += tile_tot;
         __syncthreads();
     }
@@ -486,7 +486,7 @@ int rrl_replay_push(const rrl_replay_t* rb, int64_t n, const float* s, const flo
                     const float* r, const float* s2, const float* m, const uint8_t* valid,
                     int32_t* scratch, void* stream) {
     if (!valid_rb(rb) || !s || !a || !r || !s2 || !m || n < 0) return RRL_EINVAL;
-    if (n > rb->cap) return RRL_ERANGE;
+    if (rb->pinned < 0 || rb->pinned >= rb->cap || n > rb->cap - rb->pinned) return RRL_ERANGE;
     if (n == 0) return RRL_OK;
     const Rows in{(const float2*)s, (const float2*)a, r, (const float2*)s2, m};
     hipStream_t st = (hipStream_t)stream;

@@ -152,10 +152,12 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
         bool block_sums = false;
         if (kBlockSuper && counts) {
             const int64_t cap = p.recovery_memory.cap;
-            const int64_t first = (rpos + it * stride + int64_t(blockIdx.x) * kBlock) % cap;
+            const int64_t off = it * stride + int64_t(blockIdx.x) * kBlock;
+            const int64_t first = rrl_replay::ring_slot(p.recovery_memory, rpos, off);
             s0 = int(first / rrl_replay::kSuper);
-            s1 = int(((first + kBlock - 1) % cap) / rrl_replay::kSuper);
-            block_sums = first + kBlock <= cap || cap % rrl_replay::kSuper == 0;
+            s1 = int(rrl_replay::ring_slot(p.recovery_memory, rpos, off + kBlock - 1) / rrl_replay::kSuper);
+            block_sums = first + kBlock <= cap ||
+                         (cap % rrl_replay::kSuper == 0 && p.recovery_memory.pinned % rrl_replay::kSuper == 0);
         }
         bool cons = false, succ = false, epd = false, rec = false;
         if (live) {
@@ -232,9 +234,9 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
             const float mask = dn ? 0.0f : 1.0f;
             const float prew = rew - (cons ? p.reward_penalty : 0.0f);
             const float2 stored = p.push_real_action ? act : task;
-            rrl_replay::store_values(p.memory, (mpos + i) % p.memory.cap, msize, prev, stored, prew, nobs, mask);
+            rrl_replay::store_values(p.memory, rrl_replay::ring_slot(p.memory, mpos, i), msize, prev, stored, prew, nobs, mask);
             if (p.use_recovery_memory)
-                rrl_replay::store_values(p.recovery_memory, (rpos + i) % p.recovery_memory.cap, rsize, prev, act,
+                rrl_replay::store_values(p.recovery_memory, rrl_replay::ring_slot(p.recovery_memory, rpos, i), rsize, prev, act,
                                          cons ? 1.0f : 0.0f, nobs, mask, block_sums ? super_acc : nullptr, s0);
             // episode accounting
             const float er = p.ep_reward[i] + rew;
@@ -336,7 +338,9 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
         if (h.kind != RRL_HEAD_STOCH || !h.head || !h.scale || !h.bias || !h.log_std || h.n_part <= 0 || h.n_part > 4)
             return RRL_EINVAL;
     }
-    if (n > memory->cap || (recovery_memory && n > recovery_memory->cap)) return RRL_ERANGE;
+    if (memory->pinned < 0 || n > memory->cap - memory->pinned ||
+        (recovery_memory && (recovery_memory->pinned < 0 || n > recovery_memory->cap - recovery_memory->pinned)))
+        return RRL_ERANGE;
     p.step = StepArgs{n, (double2*)pos, (const float2*)real_action, nullptr, seed, counter, counter_dev,
                       counter_inc, (float2*)next_obs, (float2*)obs, reward, done, constraint, success, ep_done,
                       t, horizon, auto_reset};

@@ -431,6 +431,11 @@ class Experiment:
         n_demo = int(c.shape[0])
         if n_demo:
             self.recovery_memory.push(s, a, c, s2, m)
+            if cfg.num_envs > 1 and not getattr(cfg, "no_pin_demos", False):
+                # vectorisation rule: N envs fill the 1e6-row ring in 1e6 / N iterations and would overwrite the
+                # demonstrations -- the only violations a safe policy ever shows the safety critic; the one-env reference
+                # (4e4 env-steps per run) never wraps its ring, i.e. keeps them for the whole run
+                self.recovery_memory.pin()
         self.num_unsafe_transitions = n_demo
         self.num_constraint_violations += int(c.sum().item())
         self.loop.num_constraint_violations = self.num_constraint_violations

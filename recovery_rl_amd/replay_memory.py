@@ -42,11 +42,23 @@ class ReplayMemory:
         self._desc = _lib.rrl_replay_t(self.s.data_ptr(), self.a.data_ptr(), self.r.data_ptr(),
                                        self.s2.data_ptr(), self.m.data_ptr(), cap,
                                        self.state.data_ptr(),
-                                       self.pos_cnt.data_ptr() if self.pos_cnt is not None else None, 0)
+                                       self.pos_cnt.data_ptr() if self.pos_cnt is not None else None, 0, 0)
+        self.pinned = 0
         self._len = 0          # host mirror of `size`; exact unless masked pushes were used
         self._len_exact = True
         self._scratch = None
         self._out = {}
+
+    def pin(self, rows=None):
+        """Never overwrite rows [0, rows) (default: everything stored so far): past the last slot the ring continues at
+        slot `rows`.  The lock-step loop pins the offline constraint demonstrations (experiment.py:280-286): thousands of
+        envs fill the ring in capacity / num_envs iterations, while the one-env reference never wraps within a run and so
+        never loses them.  Must be called while the ring has not wrapped."""
+        rows = int(self.state[1].item()) if rows is None else int(rows)
+        if not 0 <= rows < self.capacity:
+            raise ValueError("cannot pin %d of %d rows" % (rows, self.capacity))
+        self.pinned = rows
+        self._desc.pinned = rows
 
     def rebuild_pos_cnt(self):
         """Recompute the three regions of `pos_cnt` (per-chunk counts, per-super-chunk counts, per-chunk slot masks;

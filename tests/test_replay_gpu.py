@@ -240,3 +240,39 @@ def test_sampling_is_uniform():
         hits[mem._batch(256)[5]] += 1
     h = hits.cpu().numpy()
     assert abs(h.mean() - 25.0) < 1e-6 and 3.5 < h.std() < 6.5    # binomial(400, 1/16): std 4.84
+
+
+@pytest.mark.parametrize("cap,pinned,n", [(5000, 1200, 900), (4096, 1024, 1024), (100424, 20000, 40000)])
+def test_pinned_rows_are_never_overwritten(cap, pinned, n):
+    """rrl_replay_t.pinned (the lock-step loop pins the offline demonstrations): past the last slot the ring continues at
+    slot `pinned`.  Rows, cursor, size and the three count tables equal the oracle's over several wraps; plain and masked
+    pushes; the stratified draw still finds the pinned positives."""
+    rng = np.random.RandomState(cap)
+    mem, ora = ConstraintReplayMemory(cap, 1, device=DEV), co.OracleReplay(cap)
+
+    def rows(k, pos_rate):
+        s, a, s2 = (rng.randn(k, 2).astype(np.float32) for _ in range(3))
+        return s, a, (rng.uniform(size=k) < pos_rate).astype(np.float32), s2, rng.randint(0, 2, k).astype(np.float32)
+
+    first = rows(pinned, 0.5)
+    mem.push(*dev(first))
+    ora.push(*first)
+    mem.pin()
+    ora.pin()
+    assert mem.pinned == pinned == int(ora._c.pinned)
+    for k in range(2 * (cap - pinned) // n + 3):
+        batch = rows(n, 0.0)                       # the online rows carry no violation at all
+        valid = (rng.uniform(size=n) < 0.7).astype(np.uint8) if k % 3 == 2 else None
+        mem.push(*dev(batch), valid=None if valid is None else dev([valid])[0])
+        ora.push(*batch, valid=valid)
+        assert int(mem.state[0].item()) == ora.pos and int(mem.state[1].item()) == ora.size
+    assert ora.size == cap and ora.pos >= pinned
+    for a_, b_ in ((mem.s, ora.s), (mem.a, ora.a), (mem.r, ora.r), (mem.s2, ora.s2), (mem.m, ora.m)):
+        assert np.array_equal(a_.cpu().numpy(), b_)
+    assert np.array_equal(mem.r.cpu().numpy()[:pinned], first[2]) and not mem.r.cpu().numpy()[pinned:].any()
+    assert_count_tables(mem, ora, cap)
+    n_pos = int(first[2].sum())
+    s, a, c, s2, m = mem.sample(64, pos_fraction=0.25)
+    c = c.reshape(-1).cpu().numpy()
+    assert n_pos >= 16 and (c[:16] == 1).all() and (c[16:] == 0).all()
+    mem.check_error()
