@@ -84,7 +84,8 @@ ADDITIVE = [
                                     "the GPUs, gradients averaged with RCCL before every optimiser step"),
     (("--no_fast_path",), "store_true", None, "SAC / Q_risk updates through autograd instead of the fused kernels"),
     (("--plan_precision",), S, "", "hidden layers of the fused planner kernel: 'f32' = f32 MFMA (exact f32 products), "
-                                   "'f16x3' = three f16 MFMA products of hi/lo splits (22-bit operands, 2.2x faster); "
+                                   "'f16x3' = three f16 MFMA products of hi/lo splits (operands to 2^-22 relative, 3e-8 absolute for "
+                                   "values below 0.06; 2.7x faster); "
                                    "default: f32 unless RRL_PLAN_F16X3=1"),
     (("--resume",), S, "", "checkpoint.pt to continue from (lock-step loop; skips pre-training)"),
     (("--no_pin_demos",), "store_true", None, "lock-step loop: let the safety buffer's ring overwrite the offline constraint "

@@ -185,9 +185,10 @@ def _graph_of(launch, reps, device):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def time_step_push_kernel(device, env_name, n, reps=200):
-    """Average duration of ONE step_push_kernel launch (the env-step + replay-push kernel of the timed iteration)
-    over `reps` back-to-back launches with the bench's own buffers shapes: HIP events on the launch stream."""
+def step_push_launcher(device, env_name, n, compact=True):
+    """A closure launching ONE step_push_kernel with the bench's buffer shapes.  compact (what the timed graph launches):
+    u16 status word instead of step count + four flag arrays, stored state from pos, no per-env output arrays; otherwise the
+    reference-shaped arrays with every optional output."""
     import ctypes as C
     import torch
     from recovery_rl_amd import _lib
@@ -205,18 +206,34 @@ def time_step_push_kernel(device, env_name, n, reps=200):
     stats = torch.zeros(10, dtype=torch.int64, device=device)
     sums = torch.zeros(2, dtype=torch.float64, device=device)
     ep_reward = torch.zeros(n, device=device)
-    if env_name == "maze":
-        entry, head = lib.rrl_maze_step_push, ()
+    p = _lib.ptr
+    a = _lib.rrl_step_push_t()
+    a.n, a.pos, a.obs = n, p(env.pos), p(env.obs)
+    if compact:
+        a.status = p(env.use_status())
     else:
-        entry, head = lib.rrl_nav_step_push, (env.kind,)
+        a.t = p(env.t)
+        a.next_obs, a.reward = p(env.next_obs), p(env.reward)
+        a.done, a.constraint, a.success, a.ep_done = p(env.done), p(env.constraint), p(env.success), p(env.ep_done)
+    a.task_action, a.ld_task, a.real_action, a.recovery = p(act), 2, p(real), p(rec)
+    a.seed, a.counter, a.counter_dev, a.counter_inc = env.seed_value, 0, p(env.tick), 1
+    a.horizon, a.auto_reset, a.reward_penalty, a.push_real_action = env.horizon, 1, 0.0, 0
+    a.memory, a.recovery_memory = C.pointer(mem._desc), C.pointer(rmem._desc)
+    a.stats, a.reward_sums, a.ep_reward = p(stats), p(sums), p(ep_reward)
+    keep = (env, act, real, rec, mem, rmem, stats, sums, ep_reward, a)
 
     def launch():
-        return entry(*head, n, _lib.ptr(env.pos), _lib.ptr(env.t), _lib.ptr(env.obs), _lib.ptr(act), _lib.ptr(real),
-                     _lib.ptr(rec), env.seed_value, 0, _lib.ptr(env.tick), 1, env.horizon, 1, 0.0, 0,
-                     C.byref(mem._desc), C.byref(rmem._desc), _lib.ptr(env.next_obs), _lib.ptr(env.reward),
-                     _lib.ptr(env.done), _lib.ptr(env.constraint), _lib.ptr(env.success), _lib.ptr(env.ep_done),
-                     _lib.ptr(stats), _lib.ptr(sums), _lib.ptr(ep_reward), _lib.current_stream())
-    return _graph_of(launch, reps, device)
+        keep[0].num_envs        # (the closure owns the buffers)
+        if env_name == "maze":
+            return lib.rrl_maze_step_push_x(C.byref(a), _lib.current_stream())
+        return lib.rrl_nav_step_push_x(env.kind, C.byref(a), _lib.current_stream())
+    return launch
+
+
+def time_step_push_kernel(device, env_name, n, reps=200, compact=True):
+    """Average duration of ONE step_push_kernel launch (the env-step + replay-push kernel of the timed iteration)
+    over `reps` back-to-back launches with the bench's own buffers shapes: HIP events on the launch stream."""
+    return _graph_of(step_push_launcher(device, env_name, n, compact), reps, device)
 
 
 def time_nav_step_kernel(device, n, reps=200):
@@ -632,6 +649,7 @@ def main():
                 "committed rocprofv3 PMC passes (TCC fetch / write bytes, separate passes), %s entry '%d'; not "
                 "re-measured by this run" % (traffic_src, a.num_envs)) if traffic is not None else None,
             "launch_us": t_k * 1e6, "algorithmic_bytes_per_env_step": STEP_PUSH_ALGO_BYTES,
+            "layout": "compact env state (u16 status word, state from pos, no per-env output arrays): what the timed graph launches",
             "note": "N=%d moves only %d KB per launch: latency-bound by construction; bandwidth regime "
                     "(N up to 2^24, `bench.py --sweep`): profiles/round2_roofline_sweep.json"
                     % (a.num_envs, a.num_envs * STEP_PUSH_ALGO_BYTES // 1024)}
@@ -649,9 +667,12 @@ def main():
                                 "frac": n * NAV_STEP_ALGO_BYTES / tc / 1e9 / HBM_PEAK_GBS})
                 if logn <= 22:
                     ts = time_step_push_kernel(device, "navigation1", n, reps=200 if logn <= 16 else 20)
+                    ta = time_step_push_kernel(device, "navigation1", n, reps=200 if logn <= 16 else 20, compact=False)
                     sweep_sp.append({"n_envs": n, "launch_us": ts * 1e6, "env_steps_per_s": n / ts,
                                      "achieved_GBs": n * STEP_PUSH_ALGO_BYTES / ts / 1e9,
-                                     "frac": n * STEP_PUSH_ALGO_BYTES / ts / 1e9 / HBM_PEAK_GBS})
+                                     "frac": n * STEP_PUSH_ALGO_BYTES / ts / 1e9 / HBM_PEAK_GBS,
+                                     "array_layout_launch_us": ta * 1e6,
+                                     "array_layout_frac": n * STEP_PUSH_ALGO_BYTES / ta / 1e9 / HBM_PEAK_GBS})
                 torch.cuda.empty_cache()
             extra["roofline_sweep"] = sweep
             extra["roofline_sweep_step_push"] = sweep_sp

@@ -296,6 +296,47 @@ int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, co
                               float* next_obs, float* reward, uint8_t* done, uint8_t* constraint, uint8_t* success,
                               uint8_t* ep_done, uint64_t* stats, double* reward_sums, float* ep_reward, void* stream);
 
+/* The same kernel through ONE argument struct, which also carries the COMPACT per-env state: `status` (nullable) is
+ * one u16 word per env -- step count in bits 0-11 (horizon <= 4095), done / constraint / success / ep_done of the last
+ * step in bits 12-15 -- and replaces `t` (then nullable) and the four u8 flag arrays; with it the stored `state` of the
+ * replay rows is float(pos), so `obs` is written only (8 B less read, 8 + 4 B less written per env-step than t + flags).
+ * next_obs / reward / done / constraint / success / ep_done stay optional outputs (NULL: not written).  The recovery gate
+ * (rrl_*_step_push_select) is selected by sel_z != NULL; otherwise real_action (+ recovery, nullable) are read.
+ * Replay rows, counters and env state equal the entries above bit for bit. */
+typedef struct {
+    int64_t n;
+    double* pos;
+    int32_t* t;
+    uint16_t* status;
+    float* obs;
+    const float* task_action;
+    int32_t ld_task;
+    const float* real_action;
+    const uint8_t* recovery;
+    const float* sel_z;
+    int32_t sel_n_part;
+    long long sel_part_stride;
+    float sel_eps_safe;
+    const float* sel_rec_action;
+    const rrl_policy_head_t* sel_rec_head;
+    float* real_action_out;
+    uint8_t* recovery_out;
+    uint64_t seed, counter;
+    uint64_t* counter_dev;
+    uint64_t counter_inc;
+    int32_t horizon, auto_reset;
+    float reward_penalty;
+    int32_t push_real_action;
+    const rrl_replay_t *memory, *recovery_memory;
+    float *next_obs, *reward;
+    uint8_t *done, *constraint, *success, *ep_done;
+    uint64_t* stats;
+    double* reward_sums;
+    float* ep_reward;
+} rrl_step_push_t;
+int rrl_nav_step_push_x(int env_kind, const rrl_step_push_t* a, void* stream);
+int rrl_maze_step_push_x(const rrl_step_push_t* a, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * CEM.  Replaces the bookkeeping of CEMOptimizer.obtain_solution (recovery_rl/optimizers.py:73-124)
  * for M independent planning problems (one per env that needs a recovery action); the cost

@@ -27,6 +27,7 @@ EXPORTS = [
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_sample_multi",
     "rrl_nav_step_push", "rrl_maze_step_push", "rrl_nav_step_push_select", "rrl_maze_step_push_select",
+    "rrl_nav_step_push_x", "rrl_maze_step_push_x",
     "rrl_cem_sample", "rrl_cem_update", "rrl_cem_begin", "rrl_cem_sample_n", "rrl_cem_update_n", "rrl_cem_finish",
     "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss", "rrl_mlp_hidden_backward",
     "rrl_mlp_input_backward", "rrl_mlp3_forward_multi", "rrl_mlp_head_backward_multi", "rrl_mlp_hidden_backward_multi",
@@ -134,6 +135,20 @@ class rrl_policy_head_t(C.Structure):
                 ("obs_in", C.c_void_p), ("obs_out", C.c_void_p), ("log_std", C.c_void_p), ("min_log_std", C.c_float)]
 
 
+class rrl_step_push_t(C.Structure):
+    _fields_ = [("n", C.c_int64), ("pos", C.c_void_p), ("t", C.c_void_p), ("status", C.c_void_p), ("obs", C.c_void_p),
+                ("task_action", C.c_void_p), ("ld_task", C.c_int32), ("real_action", C.c_void_p), ("recovery", C.c_void_p),
+                ("sel_z", C.c_void_p), ("sel_n_part", C.c_int32), ("sel_part_stride", C.c_longlong),
+                ("sel_eps_safe", C.c_float), ("sel_rec_action", C.c_void_p),
+                ("sel_rec_head", C.POINTER(rrl_policy_head_t)), ("real_action_out", C.c_void_p),
+                ("recovery_out", C.c_void_p), ("seed", C.c_uint64), ("counter", C.c_uint64), ("counter_dev", C.c_void_p),
+                ("counter_inc", C.c_uint64), ("horizon", C.c_int32), ("auto_reset", C.c_int32),
+                ("reward_penalty", C.c_float), ("push_real_action", C.c_int32), ("memory", C.POINTER(rrl_replay_t)),
+                ("recovery_memory", C.POINTER(rrl_replay_t)), ("next_obs", C.c_void_p), ("reward", C.c_void_p),
+                ("done", C.c_void_p), ("constraint", C.c_void_p), ("success", C.c_void_p), ("ep_done", C.c_void_p),
+                ("stats", C.c_void_p), ("reward_sums", C.c_void_p), ("ep_reward", C.c_void_p)]
+
+
 class rrl_stack_t(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("G", "M", "H", "din", "dout", "ldx")] + [
         (n, C.c_void_p) for n in ("x", "W1", "b1", "W2", "b2", "W3", "b3", "h1", "h2", "out", "scratch")] + [
@@ -220,6 +235,8 @@ def _declare(lib):
         "rrl_mlp_hidden_backward_multi": (ci, [ci, C.POINTER(rrl_hidden_bwd_t), vp]),
         "rrl_mlp_input_backward_multi": (ci, [ci, C.POINTER(rrl_input_bwd_t), vp]),
         "rrl_policy_heads_fwd_multi": (ci, [ci, C.POINTER(rrl_policy_head_t), vp]),
+        "rrl_nav_step_push_x": (ci, [ci, C.POINTER(rrl_step_push_t), vp]),
+        "rrl_maze_step_push_x": (ci, [C.POINTER(rrl_step_push_t), vp]),
         "rrl_cem_sample": (ci, [i64, i32, i32, vp, vp, vp, vp, f64, ci, vp, u64, u64, vp, u64, vp, vp]),
         "rrl_cem_update": (ci, [i64, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]),
         "rrl_cem_begin": (ci, [i64, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

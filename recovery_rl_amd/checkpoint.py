@@ -56,6 +56,8 @@ def load_replay_state(mem, sd):
 
 
 def env_state(env):
+    if hasattr(env, "refresh_arrays"):
+        env.refresh_arrays()             # the loop may be running on the compact status word: decode it for the record
     return {"num_envs": env.num_envs, "seed": env.seed_value,
             **{f: _cpu(getattr(env, f)) for f in _ENV_FIELDS}}
 
@@ -66,6 +68,8 @@ def load_env_state(env, sd):
     env.seed_value = sd["seed"]
     for f in _ENV_FIELDS:
         getattr(env, f).copy_(sd[f])
+    if hasattr(env, "_status_live"):
+        env._status_live = False         # the arrays are the record; the loop re-encodes the status word when it needs it
 
 
 def agent_state(agent):

@@ -246,4 +246,17 @@ int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, co
     return check_launch();
 }
 
+int rrl_maze_step_push_x(const rrl_step_push_t* a, void* stream) {
+    rrl_step::StepPushArgs p;
+    const int rc = rrl_step::fill_args(p, a);
+    if (rc != RRL_OK || a->n == 0) return rc;
+    if (a->n <= 16384)
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv, true>), dim3(grid_for(a->n)), dim3(kBlock), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv>), dim3(grid_for(a->n)), dim3(kBlock), 0,
+                           (hipStream_t)stream, p);
+    return check_launch();
+}
+
 }  // extern "C"

@@ -1187,4 +1187,12 @@ int rrl_nav_step_push_select(int env_kind, int64_t n, double* pos, int32_t* t, f
     return nav_step_push_launch(env_kind, p, n, stream);
 }
 
+int rrl_nav_step_push_x(int env_kind, const rrl_step_push_t* a, void* stream) {
+    if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
+    rrl_step::StepPushArgs p;
+    const int rc = rrl_step::fill_args(p, a);
+    if (rc != RRL_OK || a->n == 0) return rc;
+    return nav_step_push_launch(env_kind, p, a->n, stream);
+}
+
 }  // extern "C"

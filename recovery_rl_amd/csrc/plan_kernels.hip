@@ -50,9 +50,13 @@ constexpr int kLdsBytes = kLdsFloats * 4;  // 78.5 KB: two workgroups per CU
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-// v = hi + lo with hi = f16(v) and lo = f16(v - hi): v - hi is exact in f32 (13 significant bits at most), so hi + lo
-// carries 22 bits of v; three products hi*hi + hi*lo + lo*hi then carry ~2^-21 of the f32 product (the lo*lo term, 2^-22
-// of it, is dropped).  Activations beyond the f16 range saturate (NaN stays NaN and becomes the reference's 1e6 cost).
+// v = hi + lo with hi = f16(v) and lo = f16(v - hi): v - hi is exact in f32 (13 significant bits at most), so for
+// |v| >= 2^-3 hi + lo carries 22 bits of v and three products hi*hi + hi*lo + lo*hi carry ~2^-21 of the f32 product (the
+// lo*lo term, 2^-22 of it, is dropped).  lo is stored UNSCALED: for |v| below ~0.06 it falls into the f16 subnormal range
+// (spacing 2^-24), where hi + lo keeps an ABSOLUTE error <= 2^-25 = 3e-8 instead of a relative 2^-22 (14-17 bits of a
+// small value) -- an absolute bound that is below the f32 rounding of the O(1) sums these values enter, and what the
+// 2e-5 agreement with the f32 kernel (tests/test_plan_gpu.py) rests on; the CDNA4 f16 MFMA does not flush subnormal
+// inputs.  Activations beyond the f16 range saturate (NaN stays NaN and becomes the reference's 1e6 cost).
 __device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
     v = v > 65504.f ? 65504.f : v;      // activations are relu / swish outputs: bounded below (NaN compares false: kept)
     hi = (_Float16)v;
@@ -316,13 +320,6 @@ void plan_cost_kernel(
         }
         *reinterpret_cast<f32x4*>(rowstate + tid * 4) = st;
     }
-    if constexpr (F16X3) {
-        // the ensemble's last 32-wide k block covers columns 192..223, its stores only 0..207: the rest multiplies zero
-        // weights, which needs them finite (later steps find the Q_risk phase's finite activations there)
-        _Float16* planes = reinterpret_cast<_Float16*>(act);
-        for (int i = tid; i < 2 * kRows * 16; i += kThreads)
-            planes[(i >> 10) * (kRows * kHalfStride) + ((i >> 4) & (kRows - 1)) * kHalfStride + kHEPad + (i & 15)] = (_Float16)0.f;
-    }
     const float* epk = pk + e_off(e);
     const float* g = pk + glob_off(n_nets);                // mu[4], sigma[4], max_logvar[2], min_logvar[2]
 
@@ -426,6 +423,17 @@ void plan_cost_kernel(
                 float eb[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) eb[c] = epk[kEB0 + ecol(c)];
+                if constexpr (F16X3) {
+                    // the ensemble's last 32-wide k block covers columns 192..223, its stores only 0..207: the rest
+                    // multiplies zero weights, which needs them FINITE -- the Q_risk phase leaves its own activations
+                    // there, and a NaN / inf among them (a diverged safety critic) would leak into this member's
+                    // prediction as NaN x 0; re-zeroed before every ensemble phase (nobody reads `act` right now: the
+                    // previous phase ended with a barrier, the layer-0 stores below touch columns < 208 only)
+                    _Float16* planes = reinterpret_cast<_Float16*>(act);
+                    for (int i = opaque(tid); i < 2 * kRows * 16; i += kThreads)
+                        planes[(i >> 10) * (kRows * kHalfStride) + ((i >> 4) & (kRows - 1)) * kHalfStride + kHEPad + (i & 15)] =
+                            (_Float16)0.f;
+                }
                 f32x4 acc[2][4];
                 zero(acc);
                 E_STAGE((input_mma<4, 0>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),

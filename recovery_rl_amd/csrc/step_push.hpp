@@ -31,6 +31,10 @@ struct StepArgs {
     int32_t* t;
     int32_t horizon;
     int32_t auto_reset;
+    // compact per-env state (step_push only; nullable): ONE u16 word instead of the i32 step count + four u8 flags --
+    // count in bits 0-11, done / constraint / success / ep_done of the LAST step in bits 12-15; with it the stored state is
+    // float(pos) (the observation array is written, never read)
+    uint16_t* status;
 };
 
 
@@ -207,8 +211,10 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
                 act = a.action[i];
                 rec = p.recovery ? p.recovery[i] != 0 : false;
             }
-            const float2 prev = a.obs[i];
-            int32_t ti = a.t[i];
+            // compact layout: the observation IS float(pos) (that is what this kernel and the resets store), so the 8-byte
+            // read is dropped, and the step count comes out of the status word
+            const float2 prev = a.status ? make_float2(float(pp.x), float(pp.y)) : a.obs[i];
+            int32_t ti = a.status ? int32_t(a.status[i] & 0xfffu) : a.t[i];
             ti += 1;
             double rx = 0.0, ry = 0.0;
             if constexpr (SPECULATE) {
@@ -253,7 +259,9 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
                 ti = 0;
             }
             a.pos[i] = make_double2(nx, ny);
-            a.t[i] = ti;
+            if (a.status) a.status[i] = uint16_t(unsigned(ti) | (unsigned(dn) << 12) | (unsigned(cons) << 13) |
+                                                 (unsigned(succ) << 14) | (unsigned(epd) << 15));
+            else a.t[i] = ti;
             a.obs[i] = make_float2(float(nx), float(ny));
         }
         if (kBlockSuper && counts) {
@@ -325,9 +333,10 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
                      float reward_penalty, int push_real_action, const rrl_replay_t* memory,
                      const rrl_replay_t* recovery_memory, float* next_obs, float* reward, uint8_t* done,
                      uint8_t* constraint, uint8_t* success, uint8_t* ep_done, uint64_t* stats, double* reward_sums,
-                     float* ep_reward) {
+                     float* ep_reward, uint16_t* status = nullptr) {
     if (n < 0 || n > 0xffffffffLL) return RRL_ERANGE;
-    if (!pos || !t || !obs || !task_action || !memory || !stats || !reward_sums || !ep_reward || ld_task < 2 ||
+    if (status && (horizon < 1 || horizon > 4095)) return RRL_ERANGE;      // 12 bits of step count
+    if (!pos || !(t || status) || !obs || !task_action || !memory || !stats || !reward_sums || !ep_reward || ld_task < 2 ||
         (ld_task & 1))
         return RRL_EINVAL;
     if (sel ? (!sel->z || (!sel->rec_action && !sel->rec_head) || !sel->real_out || !sel->recovery_out ||
@@ -343,7 +352,7 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
         return RRL_ERANGE;
     p.step = StepArgs{n, (double2*)pos, (const float2*)real_action, nullptr, seed, counter, counter_dev,
                       counter_inc, (float2*)next_obs, (float2*)obs, reward, done, constraint, success, ep_done,
-                      t, horizon, auto_reset};
+                      t, horizon, auto_reset, status};
     p.task_action = task_action;
     p.ld_task = ld_task;
     p.recovery = recovery;
@@ -364,6 +373,23 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
     p.reward_sums = reward_sums;
     p.ep_reward = ep_reward;
     return RRL_OK;
+}
+
+// rrl_step_push_t (the struct entry points rrl_nav_step_push_x / rrl_maze_step_push_x) -> kernel arguments
+inline int fill_args(StepPushArgs& p, const rrl_step_push_t* a) {
+    if (!a) return RRL_EINVAL;
+    if (a->sel_z) {
+        const SelectIn sel{a->sel_z, a->sel_n_part, a->sel_part_stride, a->sel_eps_safe, a->sel_rec_action, a->sel_rec_head,
+                           a->real_action_out, a->recovery_out};
+        return fill_args(p, a->n, a->pos, a->t, a->obs, a->task_action, a->ld_task, nullptr, nullptr, &sel, a->seed,
+                         a->counter, a->counter_dev, a->counter_inc, a->horizon, a->auto_reset, a->reward_penalty,
+                         a->push_real_action, a->memory, a->recovery_memory, a->next_obs, a->reward, a->done, a->constraint,
+                         a->success, a->ep_done, a->stats, a->reward_sums, a->ep_reward, a->status);
+    }
+    return fill_args(p, a->n, a->pos, a->t, a->obs, a->task_action, a->ld_task, a->real_action, a->recovery, nullptr, a->seed,
+                     a->counter, a->counter_dev, a->counter_inc, a->horizon, a->auto_reset, a->reward_penalty,
+                     a->push_real_action, a->memory, a->recovery_memory, a->next_obs, a->reward, a->done, a->constraint,
+                     a->success, a->ep_done, a->stats, a->reward_sums, a->ep_reward, a->status);
 }
 
 }  // namespace rrl_step

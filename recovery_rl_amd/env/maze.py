@@ -11,6 +11,7 @@ import torch
 
 from .. import _lib
 from ..spaces import Box
+from .status import StatusWordMixin
 
 HORIZON = 100          # env/maze.py:16
 MAX_FORCE = 0.1        # env/maze.py:17
@@ -19,7 +20,7 @@ GOAL = (0.25, 0.0)     # env/maze.py:135-137
 RESET_MODES = {'h': 0, 'e': 1, 'm': 2, None: 3}
 
 
-class MazeVecEnv:
+class MazeVecEnv(StatusWordMixin):
     """Batched MazeNavigation; same step contract as NavigationVecEnv.  `done` already includes
     the env's own horizon (env/maze.py:153), so the bootstrap mask is 0 on time-outs, as in the
     reference."""
@@ -48,6 +49,7 @@ class MazeVecEnv:
         self.action_clipped = torch.zeros(n, 2, dtype=torch.float32, device=dev)
         self._flags = torch.zeros(4, n, dtype=torch.uint8, device=dev)
         self.done, self.constraint, self.success, self.ep_done = self._flags.unbind(0)
+        self._init_status()
         self.tick = torch.zeros(2, dtype=torch.int64, device=dev)
 
     def seed(self, seed=None):
@@ -60,6 +62,7 @@ class MazeVecEnv:
 
     def reset(self, difficulty='h', check_constraint=True, pos=(), mask=None):
         """env/maze.py:184-213."""
+        self.use_arrays()
         if len(pos):
             self.pos[:] = torch.as_tensor(pos, dtype=torch.float64, device=self.device)
             self.t.zero_()
@@ -75,6 +78,7 @@ class MazeVecEnv:
     def step(self, action):
         assert action.dtype == torch.float32 and action.is_contiguous()
         assert action.shape == (self.num_envs, 2)
+        self.use_arrays()
         self.prev_obs.copy_(self.obs)
         rc = self.lib.rrl_maze_step(
             self.num_envs, _lib.ptr(self.pos), _lib.ptr(action), self.seed_value, 0, _lib.ptr(self.tick), 1,

@@ -11,6 +11,7 @@ import torch
 
 from .. import _lib
 from ..spaces import Box
+from .status import StatusWordMixin
 
 ENV_KIND = {"navigation1": 0, "navigation2": 1}
 
@@ -22,7 +23,7 @@ HORIZON = 100
 NOISE_SCALE = 0.05
 
 
-class NavigationVecEnv:
+class NavigationVecEnv(StatusWordMixin):
     """Batched Navigation1/2.
 
     step(action[N,2] f32) -> (obs[N,2], reward[N], done[N] bool, info) where `info` holds
@@ -57,6 +58,7 @@ class NavigationVecEnv:
         self.action_clipped = torch.zeros(n, 2, dtype=torch.float32, device=dev)
         self._flags = torch.zeros(4, n, dtype=torch.uint8, device=dev)
         self.done, self.constraint, self.success, self.ep_done = self._flags.unbind(0)
+        self._init_status()
         # RNG tick {tick, ticket}: lives on the device so that captured graphs advance it
         self.tick = torch.zeros(2, dtype=torch.int64, device=dev)
 
@@ -73,6 +75,7 @@ class NavigationVecEnv:
     # -- protocol ---------------------------------------------------------------------------
     def reset(self, mask=None, noise=None):
         """All envs (or those with mask != 0) restart at START_STATE + N(0, I)."""
+        self.use_arrays()
         rc = self.lib.rrl_nav_reset(self.kind, self.num_envs, _lib.ptr(self.pos), _lib.ptr(self.obs),
                                     _lib.ptr(self.t), _lib.ptr(mask), _lib.ptr(noise),
                                     self.seed_value, 0, _lib.ptr(self.tick), _lib.current_stream())
@@ -85,6 +88,7 @@ class NavigationVecEnv:
     def step(self, action, noise=None):
         assert action.dtype == torch.float32 and action.is_contiguous()
         assert action.shape == (self.num_envs, 2)
+        self.use_arrays()
         self.prev_obs.copy_(self.obs)
         rc = self.lib.rrl_nav_step(
             self.kind, self.num_envs, _lib.ptr(self.pos), _lib.ptr(action), _lib.ptr(noise),

@@ -71,7 +71,9 @@ class VectorLoop:
         self._actor = None
         self._one = torch.ones((), dtype=torch.int64, device=dev)
         self.episode_log = None           # optional EpisodeLog (per-episode records for run_stats)
-        self.step_outputs = True          # the fused step also writes env.next_obs / reward / done / constraint / success
+        # the fused step also writes env.next_obs / reward / done / constraint / success / ep_done (off: nobody reads them
+        # in the steady-state graph; the episode log and the online ensemble re-fit switch them on by themselves)
+        self.step_outputs = False
         if self.n > 1 and hasattr(recovery_memory, "clamp_stratified"):
             # N envs overwrite the ring in capacity / N iterations: once the policy avoids violations the positive
             # class can drop below int(B * pos_fraction) rows, where the one-env reference would abort
@@ -197,7 +199,12 @@ class VectorLoop:
                 and not self.cfg.add_both_transitions and not getattr(self.cfg, "no_fused_step", False))
 
     def _fused_step(self, action, real_action, recovery):
-        """env step + both replay pushes + counters in ONE launch (rrl_nav_step_push / rrl_maze_step_push)."""
+        """env step + both replay pushes + counters in ONE launch (rrl_nav_step_push_x / rrl_maze_step_push_x).
+
+        Per-env outputs of the step (env.next_obs, env.reward, the four flags) are written only when something reads them:
+        `step_outputs` (callers that look at the env's arrays after a step), the episode log, the online ensemble re-fit.
+        Without a reader the loop runs on the COMPACT env state: one u16 status word per env instead of the i32 step count
+        and four u8 flags, and the stored state taken from `pos` instead of the observation array."""
         import ctypes as C
         from . import _lib
         cfg, env, mem, rmem = self.cfg, self.env, self.memory, self.recovery_memory
@@ -205,10 +212,25 @@ class VectorLoop:
         if recovery is not None:
             rec_u8 = recovery if recovery.dtype == torch.uint8 else recovery.to(torch.uint8)
         use_rmem = uses_constraint_buffer(cfg)
-        # per-env outputs of the step (env.next_obs, env.reward, the flags): the kernel skips the ones it gets no pointer for;
-        # `step_outputs = False` is for callers that read nothing but the replay rows and the counters
         keep = self.step_outputs or self.episode_log is not None or self.recovery_policy is not None
-        out_ptr = (lambda t: _lib.ptr(t)) if keep else (lambda t: None)
+        p = _lib.ptr
+        out = (lambda t: p(t)) if keep else (lambda t: None)
+        a = _lib.rrl_step_push_t()
+        a.n, a.pos, a.obs = self.n, p(env.pos), p(env.obs)
+        if keep:
+            env.use_arrays()
+            a.t, a.status = p(env.t), None
+        else:
+            a.t, a.status = None, p(env.use_status())
+        a.seed, a.counter, a.counter_dev, a.counter_inc = env.seed_value, 0, p(env.tick), 1
+        a.horizon, a.auto_reset = env.horizon, 1
+        a.reward_penalty = float(cfg.constraint_reward_penalty)
+        a.push_real_action = int(bool(cfg.disable_action_relabeling))
+        a.memory = C.pointer(mem._desc)
+        a.recovery_memory = C.pointer(rmem._desc) if use_rmem else None
+        a.next_obs, a.reward = out(env.next_obs), out(env.reward)
+        a.done, a.constraint, a.success, a.ep_done = out(env.done), out(env.constraint), out(env.success), out(env.ep_done)
+        a.stats, a.reward_sums, a.ep_reward = p(self.stats), p(self.reward_sums), p(self.ep_reward)
         select = getattr(self._actor, "pending_select", None) if self._actor is not None else None
         if select is not None:
             # the recovery gate runs inside the step kernel: `action` is the strided task action, `real_action` and
@@ -216,46 +238,26 @@ class VectorLoop:
             self._actor.pending_select = None
             zq, z_parts, z_stride, eps_safe, rec_action, rec_head = select
             assert action.stride(1) == 1 and rec_u8 is not None and rec_u8.dtype == torch.uint8
-            entry = env.lib.rrl_maze_step_push_select if env.env_name == "maze" else env.lib.rrl_nav_step_push_select
-            head = () if env.env_name == "maze" else (env.kind,)
-            rc = entry(
-                *head, self.n, _lib.ptr(env.pos), _lib.ptr(env.t), _lib.ptr(env.obs), _lib.ptr(action), action.stride(0),
-                _lib.ptr(zq), z_parts, z_stride, eps_safe, _lib.ptr(rec_action),
-                C.byref(rec_head) if rec_head is not None else None, _lib.ptr(real_action), _lib.ptr(rec_u8),
-                env.seed_value, 0,
-                _lib.ptr(env.tick), 1, env.horizon, 1, float(cfg.constraint_reward_penalty),
-                int(bool(cfg.disable_action_relabeling)), C.byref(mem._desc), C.byref(rmem._desc) if use_rmem else None,
-                out_ptr(env.next_obs), out_ptr(env.reward), out_ptr(env.done), out_ptr(env.constraint),
-                out_ptr(env.success), out_ptr(env.ep_done), _lib.ptr(self.stats), _lib.ptr(self.reward_sums),
-                _lib.ptr(self.ep_reward), _lib.current_stream())
-            _lib.check(rc, "rrl_step_push_select")
-            mem._len = min(mem._len + self.n, mem.capacity)
-            if use_rmem:
-                rmem._len = min(rmem._len + self.n, rmem.capacity)
-            if self.episode_log is not None:
-                self.episode_log.append(env.reward, env.constraint, env.success, env.ep_done, rec_u8)
-            self.obs = env.obs
-            self.total_numsteps += self.n
-            return env.obs
-        if self.recovery_policy is not None:
-            # the online ensemble re-fit reads (state, clipped action, next state) of this step (experiment.py:464-480
-            # collects them per episode): env.step() writes these buffers, the fused kernel does not
-            env.prev_obs.copy_(env.obs)
-            hi = float(env.action_space.high[0])
-            torch.clamp(real_action, -hi, hi, out=env.action_clipped)
-        if env.env_name == "maze":
-            entry, head = env.lib.rrl_maze_step_push, ()
+            a.task_action, a.ld_task = p(action), action.stride(0)
+            a.sel_z, a.sel_n_part, a.sel_part_stride, a.sel_eps_safe = p(zq), z_parts, z_stride, eps_safe
+            a.sel_rec_action = p(rec_action)
+            a.sel_rec_head = C.pointer(rec_head) if rec_head is not None else None
+            a.real_action_out, a.recovery_out = p(real_action), p(rec_u8)
         else:
-            entry, head = env.lib.rrl_nav_step_push, (env.kind,)
-        rc = entry(
-            *head, self.n, _lib.ptr(env.pos), _lib.ptr(env.t), _lib.ptr(env.obs), _lib.ptr(action),
-            _lib.ptr(real_action), _lib.ptr(rec_u8), env.seed_value, 0, _lib.ptr(env.tick), 1, env.horizon, 1,
-            float(cfg.constraint_reward_penalty), int(bool(cfg.disable_action_relabeling)),
-            C.byref(mem._desc), C.byref(rmem._desc) if use_rmem else None, out_ptr(env.next_obs),
-            out_ptr(env.reward), out_ptr(env.done), out_ptr(env.constraint), out_ptr(env.success),
-            out_ptr(env.ep_done), _lib.ptr(self.stats), _lib.ptr(self.reward_sums), _lib.ptr(self.ep_reward),
-            _lib.current_stream())
-        _lib.check(rc, "rrl_step_push")
+            if self.recovery_policy is not None:
+                # the online ensemble re-fit reads (state, clipped action, next state) of this step (experiment.py:464-480
+                # collects them per episode): env.step() writes these buffers, the fused kernel does not
+                env.prev_obs.copy_(env.obs)
+                hi = float(env.action_space.high[0])
+                torch.clamp(real_action, -hi, hi, out=env.action_clipped)
+            a.task_action, a.ld_task = p(action), 2
+            a.real_action, a.recovery = p(real_action), p(rec_u8)
+        self._step_args = a          # keeps the ctypes pointers alive until the launch has been issued
+        if env.env_name == "maze":
+            rc = env.lib.rrl_maze_step_push_x(C.byref(a), _lib.current_stream())
+        else:
+            rc = env.lib.rrl_nav_step_push_x(env.kind, C.byref(a), _lib.current_stream())
+        _lib.check(rc, "rrl_step_push_x")
         mem._len = min(mem._len + self.n, mem.capacity)
         if use_rmem:
             rmem._len = min(rmem._len + self.n, rmem.capacity)

@@ -306,6 +306,7 @@ def test_grouped_launches_equal_the_separate_ones(env_name, extra):
                 assert torch.equal(fa, fb), phase
             ma.check_error()
         assert torch.equal(a.env.pos, b.env.pos) and torch.equal(a.env.t, b.env.t) and torch.equal(a.env.obs, b.env.obs)
+        assert torch.equal(a.env.status, b.env.status) and a.env._status_live == b.env._status_live
         assert torch.equal(a.stats, b.stats) and torch.equal(a.reward_sums, b.reward_sums)
         assert torch.equal(a.agent.fast.noise_tick, b.agent.fast.noise_tick)
         assert torch.equal(a._actor.recovery, b._actor.recovery) and torch.equal(a._actor.real_action, b._actor.real_action)

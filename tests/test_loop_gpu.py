@@ -28,6 +28,7 @@ def test_vector_loop_bookkeeping_eager(tmp_path, capsys):
     assert len(exp.recovery_memory) == exp.num_unsafe_transitions > 1000
     assert exp.num_constraint_violations == int(exp.constraint_demo_data[2].sum().item())
     loop = exp.loop
+    loop.step_outputs = True        # this test reads the env's per-step arrays after every step
     loop.start()
     ep_done_total = 0
     for k in range(30):
@@ -284,3 +285,51 @@ def test_loop_at_hidden_widths_outside_the_one_launch_stack_kernel(tmp_path, hid
     assert st["env_steps"] == loop.total_numsteps and st["sac_updates"] == st["qrisk_updates"] >= 5
     for net in (exp.agent.critic, exp.agent.policy, exp.agent.safety_critic.safety_critic, exp.agent.safety_critic.policy):
         assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+@pytest.mark.parametrize("env_name,extra", [("navigation1", ["--gamma_safe", "0.8", "--eps_safe", "0.3"]),
+                                            ("maze", ["--gamma_safe", "0.5", "--eps_safe", "0.15", "--pos_fraction", "0.3"])])
+def test_compact_env_state_loop_equals_the_array_state_loop(tmp_path, env_name, extra):
+    """The steady-state loop runs on the compact env state (u16 status word instead of step count + four flags, stored
+    state taken from pos, no per-env outputs; rrl_*_step_push_x with `status`); with `step_outputs` it runs on the arrays.
+    Same replay rows, env state, counters and networks, eagerly and from the graph; the decoded status word equals the
+    arrays; switching representation in mid-run (as env.step / a checkpoint does) loses nothing."""
+    loops = []
+    for outputs in (False, True):
+        cfg = arg_utils.get_args(["--env-name", env_name, "--cuda", "--hidden_size", "32", "--logdir", str(tmp_path),
+                                  "--seed", "5", "--num_unsafe_transitions", "2000", "--critic_safe_pretraining_steps", "20",
+                                  "--use_recovery", "--MF_recovery", "--num_envs", "192", "--batch_size", "64"] + extra)
+        exp = Experiment(cfg)
+        exp.pretrain_critic_recovery()
+        loop = exp.loop
+        loop.step_outputs = outputs
+        loop.start()
+        for k in range(40):           # > horizon / 3: episodes end by violation, success and (maze) the step limit
+            loop.vector_step(do_update=len(exp.memory) > cfg.batch_size, random_actions=k < 3)
+        if not outputs:               # a representation switch in mid-run: arrays, then back to the word
+            assert exp.env._status_live
+            exp.env.use_arrays()
+            assert not exp.env._status_live
+        loop.capture(online_qrisk=True)
+        for _ in range(30):
+            loop.replay()
+        torch.cuda.synchronize()
+        loops.append((exp, loop))
+    (ea, la), (eb, lb) = loops
+    assert ea.env._status_live and not eb.env._status_live
+    ea.env.refresh_arrays()
+    assert ea.env._status_live                                   # decoding does not switch the live representation
+    assert torch.equal(ea.env.pos, eb.env.pos) and torch.equal(ea.env.obs, eb.env.obs)
+    assert torch.equal(ea.env.t, eb.env.t) and int(ea.env.t.max()) > 3
+    assert torch.equal(ea.env._flags, eb.env._flags) and int(eb.env.ep_done.sum()) >= 0
+    assert torch.equal(la.stats, lb.stats) and torch.equal(la.reward_sums, lb.reward_sums)
+    assert torch.equal(la.ep_reward, lb.ep_reward)
+    for ma, mb in ((ea.memory, eb.memory), (ea.recovery_memory, eb.recovery_memory)):
+        assert torch.equal(ma.state, mb.state)
+        for x, y in ((ma.s, mb.s), (ma.a, mb.a), (ma.r, mb.r), (ma.s2, mb.s2), (ma.m, mb.m)):
+            assert torch.equal(x, y)
+    assert torch.equal(ea.recovery_memory.pos_cnt, eb.recovery_memory.pos_cnt)
+    for name in ("critic", "policy", "qrisk", "recpolicy"):
+        assert torch.equal(getattr(ea.agent.fast, name).flat, getattr(eb.agent.fast, name).flat), name
+    st = la.read_stats()
+    assert st["episodes"] > 0 and st["env_steps"] == 73 * 192     # 40 eager + 3 capture warm-up + 30 replays
