@@ -730,6 +730,36 @@ int rrl_ens_train_epoch_big(const rrl_ens_t* m, int n_seg, const rrl_adam_seg_t*
                             long long idx_stride, long long n_rows, long long batch, float* scratch, float* loss_out,
                             void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Packed launches: S independent learners ("seeds" -- own envs, replay rings, networks, Philox keys; the reference's unit
+ * of parallelism is the seed loop, scripts/navigation1.sh:4-8) share every launch of the lock-step iteration.  Each entry is
+ * its stand-alone counterpart for S argument sets at once: seed s runs exactly the stand-alone code on its own workgroups,
+ * so every seed's results equal its solo run bit for bit.  The S argument blocks live in device memory (content-addressed
+ * cache inside the library: blocks that do not change from call to call are uploaded once).  S <= 16.
+ *   rrl_sample_multi_packed                rrl_sample_multi            (args[s])
+ *   rrl_mlp3_forward_multi_packed          rrl_mlp3_forward_multi      (n[s] stacks members[s][0..n[s]); column-split path)
+ *   rrl_mlp_head_backward_multi_packed     rrl_mlp_head_backward_multi
+ *   rrl_mlp_hidden_backward_multi_packed   rrl_mlp_hidden_backward_multi
+ *   rrl_adam_step_multi_packed             rrl_adam_step_multi         (lr[s])
+ *   rrl_nav_step_push_packed / rrl_maze_step_push_packed    rrl_*_step_push_x (a[s]; one env kind, sizes on one side of 16384)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const rrl_draw_t *first, *second;
+    long long noise_pairs;
+    uint64_t noise_seed, noise_counter;
+    uint64_t* noise_counter_dev;
+    uint64_t noise_counter_inc;
+    float* noise_out;
+} rrl_sample_args_t;
+int rrl_sample_multi_packed(int S, const rrl_sample_args_t* args, void* stream);
+int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const* members, void* stream);
+int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t* const* members, void* stream);
+int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_bwd_t* const* members, void* stream);
+int rrl_adam_step_multi_packed(int S, const int* n_seg, const rrl_adam_seg_t* const* segs, const float* lr, float beta1,
+                               float beta2, float eps, void* stream);
+int rrl_nav_step_push_packed(int S, int env_kind, const rrl_step_push_t* a, void* stream);
+int rrl_maze_step_push_packed(int S, const rrl_step_push_t* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

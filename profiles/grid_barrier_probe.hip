@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void rounds_xcd_local_kernel(float* buf, unsig
         if (tid == 0) {
             const unsigned target = (unsigned)n_wg * (r + 1);
             __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while (__hip_atomic_fetch_add(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {}
+            // polled with an L1-bypassing load (agent scope = served by the XCD's L2); a workgroup-scope `fetch_add(bar, 0)`
+            // is folded into a plain workgroup-scope load by the compiler, which the CU's L1 answers forever (it hung)
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
         }
         __syncthreads();
     }
@@ -73,6 +75,7 @@ __global__ void step_kernel(const float* src, float* dst, int n_wg) {
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int n_wg = argc > 1 ? atoi(argv[1]) : 32, rounds = 2000;
     float* buf;
     unsigned* bar;

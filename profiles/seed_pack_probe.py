@@ -22,7 +22,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 U = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda:0")
 out = []
-for S in (1, 2, 4, 8):
+for S in [int(x) for x in os.environ.get("PACK_S", "1,2,4,8").split(",")]:
     loops, streams = [], []
     for k in range(S):
         cfg = arg_utils.get_args(bench.config_argv("navigation1", 1 + k, 4096, U))
@@ -36,6 +36,19 @@ for S in (1, 2, 4, 8):
     torch.cuda.synchronize()
 
     def run(n):
+        if os.environ.get("PACK_THREADS", "0") == "1":          # one host thread per learner
+            import threading
+
+            def work(loop, st):
+                with torch.cuda.stream(st):
+                    for _ in range(n):
+                        loop.replay()
+            ts = [threading.Thread(target=work, args=(l, s)) for l, s in zip(loops, streams)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            return
         for _ in range(n):
             for loop, st in zip(loops, streams):
                 with torch.cuda.stream(st):
@@ -47,7 +60,8 @@ for S in (1, 2, 4, 8):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     upd = [int(l.agent.fast.critic.step[0].item()) for l in loops]
-    rec = {"seeds_per_gpu": S, "updates_per_step": U, "ms_per_round": dt / steps * 1e3,
+    rec = {"packet_capture": os.environ.get("PACK_PACKET_CAPTURE", "0"), "threads": os.environ.get("PACK_THREADS", "0"),
+           "seeds_per_gpu": S, "updates_per_step": U, "ms_per_round": dt / steps * 1e3,
            "aggregate_env_steps_per_s": S * 4096 * steps / dt, "aggregate_sac_grad_steps_per_s": S * U * steps / dt,
            "device_update_counters": upd}
     out.append(rec)

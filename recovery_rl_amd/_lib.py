@@ -28,6 +28,9 @@ EXPORTS = [
     "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_sample_multi",
     "rrl_nav_step_push", "rrl_maze_step_push", "rrl_nav_step_push_select", "rrl_maze_step_push_select",
     "rrl_nav_step_push_x", "rrl_maze_step_push_x",
+    "rrl_sample_multi_packed", "rrl_mlp3_forward_multi_packed", "rrl_mlp_head_backward_multi_packed",
+    "rrl_mlp_hidden_backward_multi_packed", "rrl_adam_step_multi_packed", "rrl_nav_step_push_packed",
+    "rrl_maze_step_push_packed",
     "rrl_cem_sample", "rrl_cem_update", "rrl_cem_begin", "rrl_cem_sample_n", "rrl_cem_update_n", "rrl_cem_finish",
     "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss", "rrl_mlp_hidden_backward",
     "rrl_mlp_input_backward", "rrl_mlp3_forward_multi", "rrl_mlp_head_backward_multi", "rrl_mlp_hidden_backward_multi",
@@ -181,6 +184,12 @@ class rrl_draw_t(C.Structure):
         (n, C.c_void_p) for n in ("s", "a", "r", "s2", "m", "idx_out", "xu", "x2u", "xpu")]
 
 
+class rrl_sample_args_t(C.Structure):
+    _fields_ = [("first", C.POINTER(rrl_draw_t)), ("second", C.POINTER(rrl_draw_t)), ("noise_pairs", C.c_longlong),
+                ("noise_seed", C.c_uint64), ("noise_counter", C.c_uint64), ("noise_counter_dev", C.c_void_p),
+                ("noise_counter_inc", C.c_uint64), ("noise_out", C.c_void_p)]
+
+
 class rrl_adam_seg_t(C.Structure):
     _fields_ = [("n", C.c_longlong), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
                 ("step_dev", C.c_void_p), ("target", C.c_void_p), ("tau", C.c_float), ("weight_decay", C.c_float),
@@ -235,6 +244,14 @@ def _declare(lib):
         "rrl_mlp_hidden_backward_multi": (ci, [ci, C.POINTER(rrl_hidden_bwd_t), vp]),
         "rrl_mlp_input_backward_multi": (ci, [ci, C.POINTER(rrl_input_bwd_t), vp]),
         "rrl_policy_heads_fwd_multi": (ci, [ci, C.POINTER(rrl_policy_head_t), vp]),
+        "rrl_sample_multi_packed": (ci, [ci, C.POINTER(rrl_sample_args_t), vp]),
+        "rrl_mlp3_forward_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_stack_t)), vp]),
+        "rrl_mlp_head_backward_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_head_bwd_t)), vp]),
+        "rrl_mlp_hidden_backward_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_hidden_bwd_t)), vp]),
+        "rrl_adam_step_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_adam_seg_t)), C.POINTER(f32), f32,
+                                            f32, f32, vp]),
+        "rrl_nav_step_push_packed": (ci, [ci, ci, C.POINTER(rrl_step_push_t), vp]),
+        "rrl_maze_step_push_packed": (ci, [ci, C.POINTER(rrl_step_push_t), vp]),
         "rrl_nav_step_push_x": (ci, [ci, C.POINTER(rrl_step_push_t), vp]),
         "rrl_maze_step_push_x": (ci, [C.POINTER(rrl_step_push_t), vp]),
         "rrl_cem_sample": (ci, [i64, i32, i32, vp, vp, vp, vp, f64, ci, vp, u64, u64, vp, u64, vp, vp]),

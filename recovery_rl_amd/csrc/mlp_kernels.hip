@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "rrl_device.hpp"
+#include "pack.hpp"
 #include "rrl_host.hpp"
 
 namespace {
@@ -264,20 +265,38 @@ struct HiddenGroup {
     int n;
 };
 
+__device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int block, float* As, float* Bs);
+
 __global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenGroup hg) {
     __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
     __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
+    gemm16_group_body(hg, blockIdx.x, As, Bs);
+}
+
+__global__ __launch_bounds__(64) void gemm16_pack_kernel(const HiddenGroup* __restrict__ groups, rrl_pack::Idx ix) {
+    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
+    const int s = rrl_pack::seed_of(ix, blockIdx.x);
+    // the one member this workgroup serves, not the whole 1.8 KB group, is what it copies out of device memory
+    gemm16_group_body(groups[s], blockIdx.x - ix.first[s], As, Bs);
+}
+
+__device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int block, float* As, float* Bs) {
     int k = 0;
-    while (k + 1 < hg.n && (int)blockIdx.x >= hg.first[k + 1]) ++k;
-    const int local = blockIdx.x - hg.first[k];
+    while (k + 1 < hg.n && block >= hg.first[k + 1]) ++k;
+    const int local = block - hg.first[k];
     const int g = local / hg.per_head[k], b = local - g * hg.per_head[k];
+    // the one problem this workgroup serves is copied out of the group (kernel arguments, or device memory for the packed
+    // launch): its fields are then wave-uniform registers whatever the group's home
     if (b < hg.tn_tiles[k]) {
-        if (hg.fast[k]) gemm16_tile<2, true>(hg.tn[k], As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
-        else gemm16_tile<2, false>(hg.tn[k], As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
+        const GemmArgs ga = hg.tn[k];
+        if (hg.fast[k]) gemm16_tile<2, true>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
+        else gemm16_tile<2, false>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
     } else {
         const int c = b - hg.tn_tiles[k];
-        if (hg.fast[k]) gemm16_tile<1, true>(hg.nn[k], As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
-        else gemm16_tile<1, false>(hg.nn[k], As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
+        const GemmArgs ga = hg.nn[k];
+        if (hg.fast[k]) gemm16_tile<1, true>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
+        else gemm16_tile<1, false>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
     }
 }
 
@@ -733,17 +752,30 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float*
 
 // flat grid over (stack, column split, head, row tile)
 template <int R>
-__global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void mlp3_fwd_split_group_body(const StackGroup& sg, int block, float* lds) {
     int k = 0;
-    while (k + 1 < sg.n && (int)blockIdx.x >= sg.first[k + 1]) ++k;
-    const int local = blockIdx.x - sg.first[k];
+    while (k + 1 < sg.n && block >= sg.first[k + 1]) ++k;
+    const int local = block - sg.first[k];
     const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
     float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + 20);
-    if (sg.a[k].H == 256)
-        mlp3_fwd_split_body<R, 256>(sg.a[k], sg.partial[k], bx, rest % sg.G[k], rest / sg.G[k], sg.G[k], lds, h2s);
-    else
-        mlp3_fwd_split_body<R, 0>(sg.a[k], sg.partial[k], bx, rest % sg.G[k], rest / sg.G[k], sg.G[k], lds, h2s);
+    const StackArgs a = sg.a[k];             // this workgroup's member, copied out of the group (see gemm16_group_body)
+    const int G = sg.G[k];
+    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, h2s);
+    else mlp3_fwd_split_body<R, 0>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, h2s);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    mlp3_fwd_split_group_body<R>(sg, blockIdx.x, lds);
+}
+
+// the same launch for S seeds (pack.hpp): seed s runs its group on workgroups [first[s], first[s + 1])
+template <int R>
+__global__ __launch_bounds__(256) void mlp3_fwd_split_pack_kernel(const StackGroup* __restrict__ groups, rrl_pack::Idx ix) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = rrl_pack::seed_of(ix, blockIdx.x);
+    mlp3_fwd_split_group_body<R>(groups[s], blockIdx.x - ix.first[s], lds);
 }
 
 __global__ void sum_partials_kernel(int n, const float* __restrict__ partial, float* __restrict__ out) {
@@ -1069,13 +1101,25 @@ struct HeadBwdGroup {
     int n;
 };
 
+__device__ __forceinline__ void head_bwd_group_body(const HeadBwdGroup& hg, int block, float (*red)[4][kCols], float* dsh) {
+    int k = 0;
+    while (k + 1 < hg.n && block >= hg.first[k + 1]) ++k;
+    const int local = block - hg.first[k];
+    const HeadBwdArgs hb = hg.p[k];          // this workgroup's member, copied out of the group (see gemm16_group_body)
+    head_bwd_dispatch(hb, local % hg.blocks_x[k], local / hg.blocks_x[k], red, dsh);
+}
+
 __global__ __launch_bounds__(256) void head_bwd_group_kernel(HeadBwdGroup hg) {
     __shared__ float red[kSlices][4][kCols];
     __shared__ float dsh[1024 * 4];
-    int k = 0;
-    while (k + 1 < hg.n && (int)blockIdx.x >= hg.first[k + 1]) ++k;
-    const int local = blockIdx.x - hg.first[k];
-    head_bwd_dispatch(hg.p[k], local % hg.blocks_x[k], local / hg.blocks_x[k], red, dsh);
+    head_bwd_group_body(hg, blockIdx.x, red, dsh);
+}
+
+__global__ __launch_bounds__(256) void head_bwd_pack_kernel(const HeadBwdGroup* __restrict__ groups, rrl_pack::Idx ix) {
+    __shared__ float red[kSlices][4][kCols];
+    __shared__ float dsh[1024 * 4];
+    const int s = rrl_pack::seed_of(ix, blockIdx.x);
+    head_bwd_group_body(groups[s], blockIdx.x - ix.first[s], red, dsh);
 }
 
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
@@ -1187,6 +1231,24 @@ __global__ __launch_bounds__(256) void input_bwd_group_kernel(InputBwdGroup ig) 
 
 }  // namespace
 
+// ---- packed launches: the same group launch for S seeds side by side (pack.hpp) ----
+template <class Group, class Member, class Build>
+static int build_pack(int S, const int* n, const Member* const* members, std::vector<Group>& groups, rrl_pack::Idx& ix,
+                      Build build) {
+    if (S <= 0 || S > rrl_pack::kMaxSeeds || !n || !members) return RRL_EINVAL;
+    groups.resize(S);
+    ix.S = S;
+    ix.first[0] = 0;
+    for (int s = 0; s < S; ++s) {
+        const int rc = build(n[s], members[s], groups[s]);
+        if (rc != RRL_OK) return rc;
+        ix.first[s + 1] = ix.first[s] + groups[s].first[n[s]];
+    }
+    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+    return RRL_OK;
+}
+
+
 extern "C" {
 
 int rrl_gemm_f32(int mode, int G, int M, int N, int K, const float* A, int lda, long long sA,
@@ -1246,9 +1308,9 @@ int rrl_mlp_hidden_backward(int G, int B, int H, const float* dh2, const float* 
     return check_launch();
 }
 
-int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* stream) {
+static int build_hidden_group(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg) {
     if (!ps || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
-    HiddenGroup hg{};
+    hg = HiddenGroup{};
     hg.n = n;
     hg.first[0] = 0;
     for (int k = 0; k < n; ++k) {
@@ -1269,7 +1331,26 @@ int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* strea
         hg.first[k + 1] = hg.first[k] + hg.per_head[k] * p.G;
     }
     for (int k = n; k < kMaxGroup; ++k) hg.first[k + 1] = hg.first[n];
+    return RRL_OK;
+}
+
+int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* stream) {
+    HiddenGroup hg;
+    const int rc = build_hidden_group(n, ps, hg);
+    if (rc != RRL_OK) return rc;
     hipLaunchKernelGGL(gemm16_group_kernel, dim3(hg.first[n]), dim3(64), 0, (hipStream_t)stream, hg);
+    return check_launch();
+}
+
+int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_bwd_t* const* members, void* stream) {
+    std::vector<HiddenGroup> groups;
+    rrl_pack::Idx ix;
+    const int rc = build_pack<HiddenGroup>(S, n, members, groups, ix, build_hidden_group);
+    if (rc != RRL_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const void* dev = rrl_pack::upload(groups.data(), sizeof(HiddenGroup) * S, st);
+    if (!dev) return RRL_ELAUNCH;
+    hipLaunchKernelGGL(gemm16_pack_kernel, dim3(ix.first[S]), dim3(64), 0, st, (const HiddenGroup*)dev, ix);
     return check_launch();
 }
 
@@ -1349,12 +1430,12 @@ int rrl_debug_fwd_stamps(unsigned long long* host, int n_blocks) {
 }
 #endif
 
-int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
+static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& path) {
     if (!st || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
-    StackGroup sg{};
+    sg = StackGroup{};
     sg.n = n;
     sg.first[0] = 0;
-    int path = -1;   // 0 split (small batch), 3 split (R = kBigR row tiles), 1 plain R = 1, 2 plain R = 2
+    path = -1;   // 0 split (small batch), 3 split (R = kBigR row tiles), 1 plain R = 1, 2 plain R = 2
     for (int k = 0; k < n; ++k) {
         const rrl_stack_t& p = st[k];
         const int rc = stack_check(p.G, p.M, p.H, p.din, p.dout, p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.out);
@@ -1390,6 +1471,14 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
         path = my;
     }
     for (int k = n; k < kMaxGroup; ++k) sg.first[k + 1] = sg.first[n];
+    return RRL_OK;
+}
+
+int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
+    StackGroup sg;
+    int path;
+    const int rc = build_stack_group(n, st, sg, path);
+    if (rc != RRL_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (path == 0) {
         hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<1>, dim3(sg.first[n]), dim3(256), split_lds_floats(1) * 4, s, sg);
@@ -1400,6 +1489,35 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
                            split_lds_floats(kBigR) * 4, s, sg);
     } else if (path == 1) hipLaunchKernelGGL((mlp3_fwd_group_kernel<1>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
     else hipLaunchKernelGGL((mlp3_fwd_group_kernel<2>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
+    return check_launch();
+}
+
+// the column-split kernels only (what the steady-state iteration launches at H = 256); every seed on the same path
+int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const* members, void* stream) {
+    std::vector<StackGroup> groups;
+    rrl_pack::Idx ix;
+    int path = -1;
+    const int rc = build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
+        int my;
+        const int r = build_stack_group(nk, m, g, my);
+        if (r != RRL_OK) return r;
+        if ((my != 0 && my != 3) || (path >= 0 && my != path)) return int(RRL_EINVAL);
+        path = my;
+        return int(RRL_OK);
+    });
+    if (rc != RRL_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const void* dev = rrl_pack::upload(groups.data(), sizeof(StackGroup) * S, st);
+    if (!dev) return RRL_ELAUNCH;
+    if (path == 0) {
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(ix.first[S]), dim3(256), split_lds_floats(1) * 4, st,
+                           (const StackGroup*)dev, ix);
+    } else {
+        static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+        if (!ok) return RRL_ERANGE;
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(ix.first[S]), dim3(256), split_lds_floats(kBigR) * 4, st,
+                           (const StackGroup*)dev, ix);
+    }
     return check_launch();
 }
 
@@ -1460,9 +1578,9 @@ int rrl_mlp_head_backward_loss(const rrl_loss_t* la, int G, int B, int H, int do
     return check_launch();
 }
 
-int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
+static int build_head_group(int n, const rrl_head_bwd_t* ps, HeadBwdGroup& hg) {
     if (!ps || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
-    HeadBwdGroup hg{};
+    hg = HeadBwdGroup{};
     hg.n = n;
     hg.first[0] = 0;
     for (int k = 0; k < n; ++k) {
@@ -1474,7 +1592,26 @@ int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
         hg.first[k + 1] = hg.first[k] + hg.blocks_x[k] * p.G;
     }
     for (int k = n; k < kMaxGroup; ++k) hg.first[k + 1] = hg.first[n];
+    return RRL_OK;
+}
+
+int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
+    HeadBwdGroup hg;
+    const int rc = build_head_group(n, ps, hg);
+    if (rc != RRL_OK) return rc;
     hipLaunchKernelGGL(head_bwd_group_kernel, dim3(hg.first[n]), dim3(256), 0, (hipStream_t)stream, hg);
+    return check_launch();
+}
+
+int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t* const* members, void* stream) {
+    std::vector<HeadBwdGroup> groups;
+    rrl_pack::Idx ix;
+    const int rc = build_pack<HeadBwdGroup>(S, n, members, groups, ix, build_head_group);
+    if (rc != RRL_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const void* dev = rrl_pack::upload(groups.data(), sizeof(HeadBwdGroup) * S, st);
+    if (!dev) return RRL_ELAUNCH;
+    hipLaunchKernelGGL(head_bwd_pack_kernel, dim3(ix.first[S]), dim3(256), 0, st, (const HeadBwdGroup*)dev, ix);
     return check_launch();
 }
 

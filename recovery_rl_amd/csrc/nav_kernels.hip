@@ -1187,6 +1187,35 @@ int rrl_nav_step_push_select(int env_kind, int64_t n, double* pos, int32_t* t, f
     return nav_step_push_launch(env_kind, p, n, stream);
 }
 
+int rrl_nav_step_push_packed(int S, int env_kind, const rrl_step_push_t* a, void* stream) {
+    if ((env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) || S <= 0 || S > rrl_pack::kMaxSeeds || !a) return RRL_EINVAL;
+    std::vector<rrl_step::StepPushArgs> ps(S);
+    memset(ps.data(), 0, sizeof(rrl_step::StepPushArgs) * S);
+    rrl_pack::Idx ix;
+    ix.S = S;
+    ix.first[0] = 0;
+    const bool small = a[0].n <= 16384;
+    for (int s = 0; s < S; ++s) {
+        const int rc = rrl_step::fill_args(ps[s], &a[s]);
+        if (rc != RRL_OK) return rc;
+        if (a[s].n <= 0 || (a[s].n <= 16384) != small) return RRL_EINVAL;
+        ix.first[s + 1] = ix.first[s] + grid_for(a[s].n);
+    }
+    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+    hipStream_t st = (hipStream_t)stream;
+    const auto* dev = (const rrl_step::StepPushArgs*)rrl_pack::upload(ps.data(), sizeof(rrl_step::StepPushArgs) * S, st);
+    if (!dev) return RRL_ELAUNCH;
+    const dim3 grid(ix.first[S]), block(kBlock);
+    if (small) {
+        if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<0>, true>), grid, block, 0, st, dev, ix);
+        else hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<1>, true>), grid, block, 0, st, dev, ix);
+    } else {
+        if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<0>>), grid, block, 0, st, dev, ix);
+        else hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<1>>), grid, block, 0, st, dev, ix);
+    }
+    return check_launch();
+}
+
 int rrl_nav_step_push_x(int env_kind, const rrl_step_push_t* a, void* stream) {
     if (env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) return RRL_EINVAL;
     rrl_step::StepPushArgs p;

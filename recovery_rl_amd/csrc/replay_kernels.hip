@@ -13,6 +13,7 @@
 
 #include "replay_device.hpp"
 #include "rrl_device.hpp"
+#include "pack.hpp"
 #include "rrl_host.hpp"
 
 namespace {
@@ -459,14 +460,14 @@ __device__ __forceinline__ void draw_body(const DrawArgs& d, char* smem) {
                                    d.table_mask, d.out, smem);
 }
 
-__global__ __launch_bounds__(1024) void sample_group_kernel(DrawArgs a, DrawArgs b, NoiseArgs nz) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (blockIdx.x == 0) { draw_body(a, smem); return; }
-    if (blockIdx.x == 1) { draw_body(b, smem); return; }
+__device__ __forceinline__ void sample_group_body(const DrawArgs& a, const DrawArgs& b, const NoiseArgs& nz, int block,
+                                                  char* smem) {
+    if (block == 0) { draw_body(a, smem); return; }
+    if (block == 1) { draw_body(b, smem); return; }
     // N(0,1) pairs of Philox stream RRL_STREAM_NOISE (rrl_normal_fill)
     const uint64_t ctr = rrl::effective_counter(nz.counter, nz.counter_dev);
     const long long stride = (long long)nz.blocks * blockDim.x;
-    for (long long i = (long long)(blockIdx.x - 2) * blockDim.x + threadIdx.x; i < nz.n_pairs; i += stride) {
+    for (long long i = (long long)(block - 2) * blockDim.x + threadIdx.x; i < nz.n_pairs; i += stride) {
         double z0, z1;
         rrl::normal_at(nz.seed, uint32_t(i), rrl::kStreamNoise, ctr, z0, z1);
         reinterpret_cast<float2*>(nz.out)[i] = make_float2(float(z0), float(z1));
@@ -474,11 +475,44 @@ __global__ __launch_bounds__(1024) void sample_group_kernel(DrawArgs a, DrawArgs
     rrl::advance_counter_blocks(nz.counter_dev, nz.counter_inc, unsigned(nz.blocks));
 }
 
+__global__ __launch_bounds__(1024) void sample_group_kernel(DrawArgs a, DrawArgs b, NoiseArgs nz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sample_group_body(a, b, nz, blockIdx.x, smem);
+}
+
+// the same launch for S seeds (pack.hpp)
+struct SamplePack {
+    DrawArgs a, b;
+    NoiseArgs nz;
+};
+__global__ __launch_bounds__(1024) void sample_pack_kernel(const SamplePack* __restrict__ packs, rrl_pack::Idx ix) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int s = rrl_pack::seed_of(ix, blockIdx.x);
+    const int block = blockIdx.x - ix.first[s];
+    // a sampler workgroup copies its own draw, a noise workgroup the noise block, out of device memory
+    if (block == 0) { const DrawArgs d = packs[s].a; draw_body(d, smem); return; }
+    if (block == 1) { const DrawArgs d = packs[s].b; draw_body(d, smem); return; }
+    const NoiseArgs nz = packs[s].nz;
+    sample_group_body(packs[s].a, packs[s].b, nz, block, smem);
+}
+
 inline bool valid_rb(const rrl_replay_t* rb) {
     return rb && rb->s && rb->a && rb->r && rb->s2 && rb->m && rb->state && rb->cap > 0;
 }
 
 }  // namespace
+
+template <class K>
+static bool grant_sample_lds(K kernel, size_t lds, size_t& granted) {
+    if (lds > granted) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        granted = lds;
+    }
+    return true;
+}
 
 extern "C" {
 
@@ -534,12 +568,13 @@ static int draw_setup(const rrl_draw_t& d, DrawArgs& a, int& threads, size_t& ld
     return RRL_OK;
 }
 
-int rrl_sample_multi(const rrl_draw_t* first, const rrl_draw_t* second, long long noise_pairs, uint64_t noise_seed,
-                     uint64_t noise_counter, uint64_t* noise_counter_dev, uint64_t noise_counter_inc, float* noise_out,
-                     void* stream) {
+static int build_sample(const rrl_draw_t* first, const rrl_draw_t* second, long long noise_pairs, uint64_t noise_seed,
+                        uint64_t noise_counter, uint64_t* noise_counter_dev, uint64_t noise_counter_inc, float* noise_out,
+                        DrawArgs& a, DrawArgs& b, NoiseArgs& nz, int& threads, size_t& lds) {
     if (!first) return RRL_EINVAL;
     if (noise_pairs < 0 || noise_pairs >= (1LL << 32) || (noise_pairs > 0 && !noise_out)) return RRL_EINVAL;
-    DrawArgs a{}, b{};
+    a = DrawArgs{};
+    b = DrawArgs{};
     int ta = 0, tb = 0;
     size_t la = 0, lb = 0;
     int rc = draw_setup(*first, a, ta, la);
@@ -550,24 +585,67 @@ int rrl_sample_multi(const rrl_draw_t* first, const rrl_draw_t* second, long lon
     }
     // every member's results are independent of the workgroup size (integer prefix sums, per-index Philox draws), so
     // the launch takes the largest thread count a member would use on its own
-    int threads = ta > tb ? ta : tb;
+    threads = ta > tb ? ta : tb;
     if (noise_pairs > 0 && threads < 256) threads = 256;
-    const size_t lds = la > lb ? la : lb;
-    static size_t granted = 64 * 1024;
-    if (lds > granted) {
-        if (hipFuncSetAttribute((const void*)sample_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                int(lds)) != hipSuccess) {
-            (void)hipGetLastError();
-            return RRL_ERANGE;
-        }
-        granted = lds;
-    }
-    NoiseArgs nz{noise_pairs, noise_seed, noise_counter, noise_counter_dev, noise_counter_inc, noise_out, 0};
-    if (noise_pairs > 0) {
-        long long nb = (noise_pairs + threads - 1) / threads;
+    lds = la > lb ? la : lb;
+    nz = NoiseArgs{noise_pairs, noise_seed, noise_counter, noise_counter_dev, noise_counter_inc, noise_out, 0};
+    return RRL_OK;
+}
+
+static void noise_blocks(NoiseArgs& nz, int threads) {
+    if (nz.n_pairs > 0) {
+        long long nb = (nz.n_pairs + threads - 1) / threads;
         nz.blocks = int(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
     }
+}
+
+int rrl_sample_multi(const rrl_draw_t* first, const rrl_draw_t* second, long long noise_pairs, uint64_t noise_seed,
+                     uint64_t noise_counter, uint64_t* noise_counter_dev, uint64_t noise_counter_inc, float* noise_out,
+                     void* stream) {
+    DrawArgs a, b;
+    NoiseArgs nz;
+    int threads;
+    size_t lds;
+    const int rc = build_sample(first, second, noise_pairs, noise_seed, noise_counter, noise_counter_dev, noise_counter_inc,
+                                noise_out, a, b, nz, threads, lds);
+    if (rc != RRL_OK) return rc;
+    static size_t granted = 64 * 1024;
+    if (!grant_sample_lds(sample_group_kernel, lds, granted)) return RRL_ERANGE;
+    noise_blocks(nz, threads);
     hipLaunchKernelGGL(sample_group_kernel, dim3(2 + nz.blocks), dim3(threads), lds, (hipStream_t)stream, a, b, nz);
+    return check_launch();
+}
+
+int rrl_sample_multi_packed(int S, const rrl_sample_args_t* args, void* stream) {
+    if (S <= 0 || S > rrl_pack::kMaxSeeds || !args) return RRL_EINVAL;
+    std::vector<SamplePack> packs(S);
+    memset(packs.data(), 0, sizeof(SamplePack) * S);
+    int threads = 0;
+    size_t lds = 0;
+    for (int s = 0; s < S; ++s) {
+        const rrl_sample_args_t& g = args[s];
+        int t;
+        size_t l;
+        const int rc = build_sample(g.first, g.second, g.noise_pairs, g.noise_seed, g.noise_counter, g.noise_counter_dev,
+                                    g.noise_counter_inc, g.noise_out, packs[s].a, packs[s].b, packs[s].nz, t, l);
+        if (rc != RRL_OK) return rc;
+        threads = t > threads ? t : threads;
+        lds = l > lds ? l : lds;
+    }
+    rrl_pack::Idx ix;
+    ix.S = S;
+    ix.first[0] = 0;
+    for (int s = 0; s < S; ++s) {
+        noise_blocks(packs[s].nz, threads);
+        ix.first[s + 1] = ix.first[s] + 2 + packs[s].nz.blocks;
+    }
+    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+    static size_t granted = 64 * 1024;
+    if (!grant_sample_lds(sample_pack_kernel, lds, granted)) return RRL_ERANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const void* dev = rrl_pack::upload(packs.data(), sizeof(SamplePack) * S, st);
+    if (!dev) return RRL_ELAUNCH;
+    hipLaunchKernelGGL(sample_pack_kernel, dim3(ix.first[S]), dim3(threads), lds, st, (const SamplePack*)dev, ix);
     return check_launch();
 }
 

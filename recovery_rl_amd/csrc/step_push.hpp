@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pack.hpp"
 #include "replay_device.hpp"
 #include "rrl_device.hpp"
 #include "rrl_host.hpp"
@@ -100,8 +101,8 @@ __device__ __forceinline__ double row16_sum_f64(double v) {
 // ~1 us dependent chain).  Same function, same arguments, same bits; in the bandwidth regime it would be +70 % VALU work.
 // !SPECULATE (bandwidth regime): the second level of the safety buffer's positive counts is summed per workgroup and pass
 // in LDS (one atomic per workgroup and super-chunk instead of one per wave: 64 waves share a super-chunk's counter).
-template <class ENV, bool SPECULATE = false>
-__global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArgs p) {
+template <class ENV, bool SPECULATE>
+__device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsigned blk, const unsigned n_blk) {
     constexpr int kBlock = rrl_host::kBlock;
     constexpr bool kBlockSuper = !SPECULATE;
     __shared__ int super_acc[2];
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
                                             __HIP_MEMORY_SCOPE_AGENT);
     };
     const auto advance_cursors = [&]() {
-        if (threadIdx.x == 0 && ticket == gridDim.x - 1) {
+        if (threadIdx.x == 0 && ticket == n_blk - 1) {
             p.memory.state[2] = 0;
             rrl_replay::set_ring(p.memory, mpos, msize, a.n);
             if (p.use_recovery_memory) rrl_replay::set_ring(p.recovery_memory, rpos, rsize, a.n);
@@ -144,10 +145,10 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
     }
     double rsum = 0.0, retsum = 0.0;
     unsigned cnt[kCounters] = {0, 0, 0, 0, 0, 0, 0};
-    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int64_t stride = int64_t(n_blk) * kBlock;
     const int64_t n_iter = (a.n + stride - 1) / stride;   // uniform trip count: ballots need whole waves
     for (int64_t it = 0; it < n_iter; ++it) {
-        const int64_t i = it * stride + int64_t(blockIdx.x) * kBlock + threadIdx.x;
+        const int64_t i = it * stride + int64_t(blk) * kBlock + threadIdx.x;
         const bool live = i < a.n;
         int s0 = 0, s1 = 0;       // super-chunks of the workgroup's first and last safety-buffer slot of this pass
         // the two workgroup sums cover a pass whose 256 consecutive slots touch at most two super-chunks: always, unless
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
         bool block_sums = false;
         if (kBlockSuper && counts) {
             const int64_t cap = p.recovery_memory.cap;
-            const int64_t off = it * stride + int64_t(blockIdx.x) * kBlock;
+            const int64_t off = it * stride + int64_t(blk) * kBlock;
             const int64_t first = rrl_replay::ring_slot(p.recovery_memory, rpos, off);
             s0 = int(first / rrl_replay::kSuper);
             s1 = int(rrl_replay::ring_slot(p.recovery_memory, rpos, off + kBlock - 1) / rrl_replay::kSuper);
@@ -308,11 +309,26 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
         double sum = 0.0;
         for (int k = 0; k < kBlock / 16; ++k) sum += block_sum[w][k];       // fixed order inside the workgroup
         if (sum != 0.0) atomicAdd(p.reward_sums + w, sum);
-    } else if (blockIdx.x == 0 && threadIdx.x == 64) {
+    } else if (blk == 0 && threadIdx.x == 64) {
         atomicAdd(p.stats, (unsigned long long)a.n);
     }
     if constexpr (!SPECULATE) draw_ticket();
     advance_cursors();
+}
+
+template <class ENV, bool SPECULATE = false>
+__global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArgs p) {
+    step_push_body<ENV, SPECULATE>(p, blockIdx.x, gridDim.x);
+}
+
+// the same launch for S seeds (pack.hpp): seed s steps its envs on workgroups [first[s], first[s + 1]) -- its own grid as
+// far as the kernel body can tell (cursor ticket, grid stride)
+template <class ENV, bool SPECULATE = false>
+__global__ __launch_bounds__(rrl_host::kBlock) void step_push_pack_kernel(const StepPushArgs* __restrict__ ps,
+                                                                          rrl_pack::Idx ix) {
+    const int s = rrl_pack::seed_of(ix, blockIdx.x);
+    const StepPushArgs p = ps[s];
+    step_push_body<ENV, SPECULATE>(p, blockIdx.x - ix.first[s], ix.first[s + 1] - ix.first[s]);
 }
 
 // host side: argument block shared by the navigation and maze entry points

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rrl_device.hpp"
+#include "pack.hpp"
 #include "rrl_host.hpp"
 
 namespace {
@@ -386,13 +387,12 @@ __device__ __forceinline__ void adam_range(long long n, float* p, const float* g
 
 // several flat buffers (e.g. critic + policy of one update) in ONE launch; every segment keeps its own step
 // counter, advanced by the last of ITS workgroups.
-__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_seg, float lr, float b1, float b2,
-                                                            float eps) {
-    __shared__ float sh[2];
+__device__ __forceinline__ void adam_multi_body(const AdamSegs& a, int n_seg, float lr, float b1, float b2, float eps,
+                                                int blk, float* sh) {
     int k = 0;
-    while (k + 1 < n_seg && (int)blockIdx.x >= a.first_block[k + 1]) ++k;
+    while (k + 1 < n_seg && blk >= a.first_block[k + 1]) ++k;
     const rrl_adam_seg_t sg = a.seg[k];
-    const int block = blockIdx.x - a.first_block[k], blocks = a.first_block[k + 1] - a.first_block[k];
+    const int block = blk - a.first_block[k], blocks = a.first_block[k + 1] - a.first_block[k];
     uint64_t step = 0;
     unsigned long long ticket = ~0ULL;
     if (threadIdx.x == 0) {
@@ -414,6 +414,25 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_se
         sg.step_dev[0] = step + 1;
         sg.step_dev[1] = 0;
     }
+}
+
+__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_seg, float lr, float b1, float b2,
+                                                            float eps) {
+    __shared__ float sh[2];
+    adam_multi_body(a, n_seg, lr, b1, b2, eps, blockIdx.x, sh);
+}
+
+// the same launch for S seeds (pack.hpp)
+struct AdamPack {
+    AdamSegs a;
+    int n_seg;
+    float lr, b1, b2, eps;
+};
+__global__ __launch_bounds__(kBlock) void adam_pack_kernel(const AdamPack* __restrict__ packs, rrl_pack::Idx ix) {
+    __shared__ float sh[2];
+    const int s = rrl_pack::seed_of(ix, blockIdx.x);
+    const AdamPack& pk = packs[s];
+    adam_multi_body(pk.a, pk.n_seg, pk.lr, pk.b1, pk.b2, pk.eps, blockIdx.x - ix.first[s], sh);
 }
 
 // ---- N(0,1) fill: out[2i], out[2i+1] = the Philox normal pair of index i (stream RRL_STREAM_NOISE) ----
@@ -572,10 +591,8 @@ int rrl_adam_step(long long n, float* p, const float* g, float* m, float* v, uin
     return check_launch();
 }
 
-int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2, float eps,
-                        void* stream) {
+static int build_adam_segs(int n_seg, const rrl_adam_seg_t* segs, AdamSegs& a) {
     if (!segs || n_seg <= 0 || n_seg > RRL_ADAM_MAX_SEGS) return RRL_EINVAL;
-    AdamSegs a;
     a.first_block[0] = 0;
     for (int k = 0; k < n_seg; ++k) {
         const rrl_adam_seg_t& sg = segs[k];
@@ -589,8 +606,39 @@ int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float b
         a.first_block[k + 1] = a.first_block[k] + (grid_for(sg.n) < 64 ? grid_for(sg.n) : 64);
     }
     for (int k = n_seg; k < RRL_ADAM_MAX_SEGS; ++k) a.first_block[k + 1] = a.first_block[n_seg];
+    return RRL_OK;
+}
+
+int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2, float eps,
+                        void* stream) {
+    AdamSegs a;
+    const int rc = build_adam_segs(n_seg, segs, a);
+    if (rc != RRL_OK) return rc;
     hipLaunchKernelGGL(adam_multi_kernel, dim3(a.first_block[n_seg]), dim3(kBlock), 0, (hipStream_t)stream, a, n_seg,
                        lr, beta1, beta2, eps);
+    return check_launch();
+}
+
+int rrl_adam_step_multi_packed(int S, const int* n_seg, const rrl_adam_seg_t* const* segs, const float* lr, float beta1,
+                               float beta2, float eps, void* stream) {
+    if (S <= 0 || S > rrl_pack::kMaxSeeds || !n_seg || !segs || !lr) return RRL_EINVAL;
+    std::vector<AdamPack> packs(S);
+    memset(packs.data(), 0, sizeof(AdamPack) * S);           // padding bytes take part in the content hash
+    rrl_pack::Idx ix;
+    ix.S = S;
+    ix.first[0] = 0;
+    for (int s = 0; s < S; ++s) {
+        const int rc = build_adam_segs(n_seg[s], segs[s], packs[s].a);
+        if (rc != RRL_OK) return rc;
+        packs[s].n_seg = n_seg[s];
+        packs[s].lr = lr[s]; packs[s].b1 = beta1; packs[s].b2 = beta2; packs[s].eps = eps;
+        ix.first[s + 1] = ix.first[s] + packs[s].a.first_block[n_seg[s]];
+    }
+    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+    hipStream_t st = (hipStream_t)stream;
+    const void* dev = rrl_pack::upload(packs.data(), sizeof(AdamPack) * S, st);
+    if (!dev) return RRL_ELAUNCH;
+    hipLaunchKernelGGL(adam_pack_kernel, dim3(ix.first[S]), dim3(kBlock), 0, st, (const AdamPack*)dev, ix);
     return check_launch();
 }
 

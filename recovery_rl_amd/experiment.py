@@ -253,6 +253,8 @@ class VectorLoop:
             a.task_action, a.ld_task = p(action), 2
             a.real_action, a.recovery = p(real_action), p(rec_u8)
         self._step_args = a          # keeps the ctypes pointers alive until the launch has been issued
+        from .fast_update import record
+        record("step", env.env_name, getattr(env, "kind", -1), a)
         if env.env_name == "maze":
             rc = env.lib.rrl_maze_step_push_x(C.byref(a), _lib.current_stream())
         else:

@@ -21,6 +21,23 @@ from . import _lib
 from .fused import NN, NT, TN, gemm, mlp3_forward, mlp3_supported
 
 
+# -- launch tape (seed packing, recovery_rl_amd/packed.py) -----------------------------------------------------------
+# While a tape is set, every launch of the grouped path is ALSO appended to it: (kind, ctypes payload...).  The argument
+# blocks of the steady-state iteration never change, so one recorded iteration of every seed is the launch list of the
+# packed iteration: launch k of all seeds goes out as one rrl_*_packed call.
+_TAPE = None
+
+
+def set_tape(tape):
+    global _TAPE
+    _TAPE = tape
+
+
+def record(kind, *payload):
+    if _TAPE is not None:
+        _TAPE.append((kind,) + payload)
+
+
 class FlatNet:
     """Flat parameter / gradient / Adam-state storage for one network, plus the layer views."""
 
@@ -70,6 +87,7 @@ class FlatNet:
         (W1, b1) arrive as T row-tile partials (Stack.backward with fuse_first)."""
         if part is not None:
             return adam_multi(lr, [(self, target, tau, part)], betas, eps)
+        record("unsupported", "rrl_adam_step")
         lib = _lib.load()
         rc = lib.rrl_adam_step(self.flat.numel(), self.flat.data_ptr(), self.grad.data_ptr(),
                                self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(), lr, betas[0],
@@ -92,6 +110,7 @@ def adam_multi(lr, nets, betas=(0.9, 0.999), eps=1e-8):
                                       net.v.data_ptr(), net.step.data_ptr(),
                                       None if target is None else target.flat.data_ptr(), tau, 0.0, None,
                                       gp, n_part, stride, n_first)
+    record("adam", segs, len(nets), float(lr), float(betas[0]), float(betas[1]), float(eps))
     _lib.check(lib.rrl_adam_step_multi(len(nets), segs, lr, betas[0], betas[1], eps, _lib.current_stream()),
                "rrl_adam_step_multi")
 
@@ -198,6 +217,7 @@ class Stack:
         self.x = x
         self.parts = (self.out, 1, 0)       # (tensor, n_part, part_stride): how consumers read the output
         if mlp3_supported(self.net.H, self.net.din, self.net.dout):     # one launch for the whole stack
+            record("unsupported", "rrl_mlp3_forward")
             mlp3_forward(x, P["W1"], P["b1"], P["W2"], P["b2"], P["W3"], P["b3"], out=self.out,
                          h1=self.h1 if save else None, h2=self.h2 if save else None, scratch=self.scratch,
                          finalize=self.finalize)
@@ -300,6 +320,7 @@ class Stack:
 def forward_multi(descs):
     """Independent stack forwards in ONE launch (rrl_mlp3_forward_multi)."""
     arr = (_lib.rrl_stack_t * len(descs))(*descs)
+    record("forward", arr, len(descs))
     _lib.check(_lib.load().rrl_mlp3_forward_multi(len(descs), arr, _lib.current_stream()), "rrl_mlp3_forward_multi")
 
 
@@ -310,6 +331,10 @@ def backward_multi(triples):
     hidden = (_lib.rrl_hidden_bwd_t * n)(*[t[1] for t in triples])
     rest = [t[2] for t in triples if t[2] is not None]          # stacks whose first layer is not fused into `hidden`
     inputs = (_lib.rrl_input_bwd_t * len(rest))(*rest) if rest else None
+    record("head_bwd", heads, n)
+    record("hidden_bwd", hidden, n)
+    if inputs is not None:
+        record("unsupported", "rrl_mlp_input_backward_multi")
     _lib.check(lib.rrl_mlp_head_backward_multi(n, heads, st), "rrl_mlp_head_backward_multi")
     _lib.check(lib.rrl_mlp_hidden_backward_multi(n, hidden, st), "rrl_mlp_hidden_backward_multi")
     if inputs is not None:
@@ -318,6 +343,7 @@ def backward_multi(triples):
 
 def heads_multi(heads):
     arr = (_lib.rrl_policy_head_t * len(heads))(*heads)
+    record("unsupported", "rrl_policy_heads_fwd_multi")
     _lib.check(_lib.load().rrl_policy_heads_fwd_multi(len(heads), arr, _lib.current_stream()),
                "rrl_policy_heads_fwd_multi")
 
@@ -487,6 +513,7 @@ class FastUpdater:
         need = 4 * self.B * 2 + 2 * n_act * 2
         if self._noise_buf is None or self._noise_buf.numel() != need:
             self._noise_buf = torch.zeros(need, dtype=torch.float32, device=self.dev)
+        record("unsupported", "rrl_normal_fill")
         self._check(self.lib.rrl_normal_fill(need // 2, self.noise_seed, 0, _lib.ptr(self.noise_tick), 1,
                                              _lib.ptr(self._noise_buf), _lib.current_stream()), "rrl_normal_fill")
         self._noise = self._noise_buf[:4 * self.B * 2].view(4, self.B, 2)
@@ -551,6 +578,9 @@ class FastUpdater:
         need = 4 * B * 2 + 2 * n_act * 2
         if self._noise_buf is None or self._noise_buf.numel() != need:
             self._noise_buf = torch.zeros(need, dtype=torch.float32, device=self.dev)
+        record("sample", _lib.rrl_sample_args_t(C.pointer(d1), C.pointer(d2) if d2 is not None else None, need // 2,
+                                                self.noise_seed, 0, _lib.ptr(self.noise_tick), 1,
+                                                _lib.ptr(self._noise_buf)), d1, d2)
         self._check(self.lib.rrl_sample_multi(C.byref(d1), C.byref(d2) if d2 is not None else None, need // 2,
                                               self.noise_seed, 0, _lib.ptr(self.noise_tick), 1,
                                               _lib.ptr(self._noise_buf), _lib.current_stream()), "rrl_sample_multi")
@@ -568,7 +598,10 @@ class FastUpdater:
         ag, B = self.agent, self.B
         s, a, r, s2, m = batch
         r, m = r.reshape(-1), m.reshape(-1)
-        self.pol_ab.forward(self.x_pol[:, 0:2])
+        if self.pol_ab.split:      # one-member group: the stand-alone launch's kernel body, and a launch the tape can pack
+            forward_multi([self.pol_ab.forward_desc(self.x_pol[:, 0:2])])
+        else:
+            self.pol_ab.forward(self.x_pol[:, 0:2])
         head2, head = self.pol_next.after_forward(), self.pol_b.after_forward()
         hd2 = self._gauss_desc(head2, eps_next, self.x2u[:, 2:4], self.logp2)
         hd1 = self._gauss_desc(head, eps_pi, self.xpu[:, 2:4], self.logp)

@@ -1,0 +1,146 @@
+"""S independent learners on ONE MI355X, sharing every launch of the lock-step iteration (`--seeds_per_gpu S`).
+
+The reference's unit of parallelism is the seed loop (scripts/navigation1.sh:4-8: ten runs, seeds 1..10, one after the
+other).  One launch of the lock-step iteration occupies <= 64 of the 256 CUs and mostly waits on memory round trips, and
+S graphs replayed on S streams overlap to 1.6x at most (the command processor, not the CUs, is the limit:
+profiles/seed_pack_probe.py).  So the seeds are packed INSIDE the launches: every seed is an ordinary `VectorLoop` (own envs,
+replay rings, networks, optimiser state, Philox keys and device-side ticks); one iteration of each is recorded on a launch
+tape (fast_update.set_tape) -- the argument blocks of the steady-state iteration never change -- and launch k of all tapes
+goes out as ONE rrl_*_packed call in which seed s runs its stand-alone code on its own workgroups.  The packed iteration
+is captured in one hipGraph.  Every seed's state after K packed iterations equals its solo run's bit for bit
+(tests/test_packed_gpu.py).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import fast_update
+
+
+class PackedLoop:
+    MAX_SEEDS = 16
+
+    def __init__(self, loops, online_qrisk=True):
+        """loops: VectorLoops in steady state (past start_steps, batch available), each on the fused grouped path."""
+        if not 1 <= len(loops) <= self.MAX_SEEDS:
+            raise ValueError("1 .. %d seeds per GPU" % self.MAX_SEEDS)
+        self.loops = list(loops)
+        self.S = len(loops)
+        self.online_qrisk = online_qrisk
+        self.lib = _lib.load()
+        self.graph = None
+        self.tapes = None
+        self.stages = None
+
+    # -- recording -------------------------------------------------------------------------------------------------------
+    def record(self):
+        """One REAL iteration of every seed (launched as usual, so every seed advances by one iteration), teed onto a tape."""
+        tapes = []
+        for loop in self.loops:
+            tape = []
+            fast_update.set_tape(tape)
+            try:
+                loop.vector_step(True, False, self.online_qrisk)
+            finally:
+                fast_update.set_tape(None)
+            bad = [op for op in tape if op[0] == "unsupported"]
+            if bad:
+                raise _lib.RRLError("seed packing needs the grouped fused path (hidden_size 256-style stacks, first layer "
+                                    "fused into the hidden-layer backward): %s was launched" % bad[0][1])
+            tapes.append(tape)
+        kinds = [tuple(op[0] for op in t) for t in tapes]
+        if any(k != kinds[0] for k in kinds):
+            raise _lib.RRLError("the seeds' iterations differ in structure: %r" % (kinds,))
+        self.tapes = tapes
+        self.stages = self._build_stages()
+        return len(kinds[0])
+
+    def _build_stages(self):
+        S, p = self.S, C.POINTER
+        stages = []
+        for j, kind in enumerate(op[0] for op in self.tapes[0]):
+            ops = [t[j] for t in self.tapes]
+            if kind == "sample":
+                args = (_lib.rrl_sample_args_t * S)(*[op[1] for op in ops])
+                stages.append((self.lib.rrl_sample_multi_packed, (S, args), ops))
+            elif kind in ("forward", "head_bwd", "hidden_bwd"):
+                typ = {"forward": _lib.rrl_stack_t, "head_bwd": _lib.rrl_head_bwd_t, "hidden_bwd": _lib.rrl_hidden_bwd_t}[kind]
+                fn = {"forward": self.lib.rrl_mlp3_forward_multi_packed,
+                      "head_bwd": self.lib.rrl_mlp_head_backward_multi_packed,
+                      "hidden_bwd": self.lib.rrl_mlp_hidden_backward_multi_packed}[kind]
+                n = (C.c_int * S)(*[op[2] for op in ops])
+                members = (p(typ) * S)(*[C.cast(op[1], p(typ)) for op in ops])
+                stages.append((fn, (S, n, members), ops))
+            elif kind == "adam":
+                b1, b2, eps = ops[0][4], ops[0][5], ops[0][6]
+                assert all(op[4:7] == (b1, b2, eps) for op in ops)
+                n = (C.c_int * S)(*[op[2] for op in ops])
+                segs = (p(_lib.rrl_adam_seg_t) * S)(*[C.cast(op[1], p(_lib.rrl_adam_seg_t)) for op in ops])
+                lr = (C.c_float * S)(*[op[3] for op in ops])
+                stages.append((self.lib.rrl_adam_step_multi_packed, (S, n, segs, lr, b1, b2, eps), ops))
+            elif kind == "step":
+                env_name, env_kind = ops[0][1], ops[0][2]
+                assert all(op[1] == env_name and op[2] == env_kind for op in ops), "one env per packed run"
+                args = (_lib.rrl_step_push_t * S)(*[op[3] for op in ops])
+                if env_name == "maze":
+                    stages.append((self.lib.rrl_maze_step_push_packed, (S, args), ops))
+                else:
+                    stages.append((self.lib.rrl_nav_step_push_packed, (S, env_kind, args), ops))
+            else:
+                raise _lib.RRLError("launch kind %r cannot be packed" % kind)
+        return stages
+
+    # -- running ---------------------------------------------------------------------------------------------------------
+    def launch(self):
+        """One packed iteration: every recorded launch once, for all seeds."""
+        st = _lib.current_stream()
+        for fn, args, _ in self.stages:
+            _lib.check(fn(*args, st), fn.__name__)
+
+    def _advance_host_mirrors(self):
+        for loop in self.loops:
+            cfg = loop.cfg
+            loop.total_numsteps += loop.n
+            loop.host_updates[0] += cfg.updates_per_step
+            loop.updates += cfg.updates_per_step
+            if self.online_qrisk:
+                loop.host_updates[1] += cfg.updates_per_step
+                loop.agent.safety_critic.updates += cfg.updates_per_step
+            from .experiment import uses_constraint_buffer
+            for mem, rows in ((loop.memory, loop.n), (loop.recovery_memory, loop.n if uses_constraint_buffer(cfg) else 0)):
+                mem._len = min(mem._len + rows, mem.capacity)
+
+    def step(self):
+        """Eager packed iteration."""
+        self.launch()
+        self._advance_host_mirrors()
+
+    def capture(self, warmup=2, settle=2):
+        """Record (one real iteration per seed), run `warmup` eager packed iterations (they populate the library's
+        argument-block cache, so the captured launches copy nothing), capture the packed iteration in ONE hipGraph.
+        Returns the number of iterations every seed has advanced."""
+        for _ in range(settle):              # the first iterations size the noise buffer and build the acting workspace
+            for loop in self.loops:
+                loop.vector_step(True, False, self.online_qrisk)
+        self.record()
+        dev = self.loops[0].device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.launch()
+        self.graph = g
+        return settle + 1 + warmup
+
+    def replay(self):
+        self.graph.replay()
+        self._advance_host_mirrors()
+
+    def read_stats(self):
+        return [loop.read_stats() for loop in self.loops]
