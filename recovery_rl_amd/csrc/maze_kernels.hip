@@ -248,26 +248,39 @@ int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, co
 
 int rrl_maze_step_push_packed(int S, const rrl_step_push_t* a, void* stream) {
     if (S <= 0 || S > rrl_pack::kMaxSeeds || !a) return RRL_EINVAL;
-    std::vector<rrl_step::StepPushArgs> ps(S);
-    memset(ps.data(), 0, sizeof(rrl_step::StepPushArgs) * S);
-    rrl_pack::Idx ix;
-    ix.S = S;
-    ix.first[0] = 0;
-    const bool small = a[0].n <= 16384;
+    rrl_pack::Key key;
+    key.pod(7);
+    key.pod(S);
     for (int s = 0; s < S; ++s) {
-        const int rc = rrl_step::fill_args(ps[s], &a[s]);
-        if (rc != RRL_OK) return rc;
-        if (a[s].n <= 0 || (a[s].n <= 16384) != small) return RRL_EINVAL;
-        ix.first[s + 1] = ix.first[s] + grid_for(a[s].n);
+        key.pod(a[s]);
+        if (a[s].memory) key.pod(*a[s].memory);
+        if (a[s].recovery_memory) key.pod(*a[s].recovery_memory);
+        if (a[s].sel_rec_head) key.pod(*a[s].sel_rec_head);
     }
-    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
     hipStream_t st = (hipStream_t)stream;
-    const auto* dev = (const rrl_step::StepPushArgs*)rrl_pack::upload(ps.data(), sizeof(rrl_step::StepPushArgs) * S, st);
-    if (!dev) return RRL_ELAUNCH;
-    if (small)
-        hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<MazeEnv, true>), dim3(ix.first[S]), dim3(kBlock), 0, st, dev, ix);
-    else
-        hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<MazeEnv>), dim3(ix.first[S]), dim3(kBlock), 0, st, dev, ix);
+    rrl_pack::Plan* plan = rrl_pack::lookup(key);
+    if (!plan) {
+        std::vector<rrl_step::StepPushArgs> ps(S);
+        rrl_pack::Idx ix;
+        ix.S = S;
+        ix.first[0] = 0;
+        const bool small = a[0].n <= 16384;
+        for (int s = 0; s < S; ++s) {
+            const int rc = rrl_step::fill_args(ps[s], &a[s]);
+            if (rc != RRL_OK) return rc;
+            if (a[s].n <= 0 || (a[s].n <= 16384) != small) return RRL_EINVAL;
+            ix.first[s + 1] = ix.first[s] + grid_for(a[s].n);
+        }
+        for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+        plan = rrl_pack::store(key, ps.data(), sizeof(rrl_step::StepPushArgs) * S, st);
+        if (!plan) return RRL_ELAUNCH;
+        plan->ix = ix;
+        plan->i0 = small;
+    }
+    const auto* dev = (const rrl_step::StepPushArgs*)plan->dev;
+    const dim3 grid(plan->ix.first[S]), block(kBlock);
+    if (plan->i0) hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<MazeEnv, true>), grid, block, 0, st, dev, plan->ix);
+    else hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<MazeEnv>), grid, block, 0, st, dev, plan->ix);
     return check_launch();
 }
 

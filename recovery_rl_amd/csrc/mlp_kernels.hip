@@ -1232,10 +1232,22 @@ __global__ __launch_bounds__(256) void input_bwd_group_kernel(InputBwdGroup ig) 
 }  // namespace
 
 // ---- packed launches: the same group launch for S seeds side by side (pack.hpp) ----
+template <class Member>
+static bool pack_key(int site, int S, const int* n, const Member* const* members, rrl_pack::Key& key) {
+    if (S <= 0 || S > rrl_pack::kMaxSeeds || !n || !members) return false;
+    key.pod(site);
+    key.pod(S);
+    for (int s = 0; s < S; ++s) {
+        if (n[s] <= 0 || n[s] > kMaxGroup || !members[s]) return false;
+        key.pod(n[s]);
+        key.add(members[s], sizeof(Member) * n[s]);
+    }
+    return true;
+}
+
 template <class Group, class Member, class Build>
 static int build_pack(int S, const int* n, const Member* const* members, std::vector<Group>& groups, rrl_pack::Idx& ix,
                       Build build) {
-    if (S <= 0 || S > rrl_pack::kMaxSeeds || !n || !members) return RRL_EINVAL;
     groups.resize(S);
     ix.S = S;
     ix.first[0] = 0;
@@ -1247,7 +1259,6 @@ static int build_pack(int S, const int* n, const Member* const* members, std::ve
     for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
     return RRL_OK;
 }
-
 
 extern "C" {
 
@@ -1343,14 +1354,21 @@ int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* strea
 }
 
 int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_bwd_t* const* members, void* stream) {
-    std::vector<HiddenGroup> groups;
-    rrl_pack::Idx ix;
-    const int rc = build_pack<HiddenGroup>(S, n, members, groups, ix, build_hidden_group);
-    if (rc != RRL_OK) return rc;
+    rrl_pack::Key key;
+    if (!pack_key(1, S, n, members, key)) return RRL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const void* dev = rrl_pack::upload(groups.data(), sizeof(HiddenGroup) * S, st);
-    if (!dev) return RRL_ELAUNCH;
-    hipLaunchKernelGGL(gemm16_pack_kernel, dim3(ix.first[S]), dim3(64), 0, st, (const HiddenGroup*)dev, ix);
+    rrl_pack::Plan* plan = rrl_pack::lookup(key);
+    if (!plan) {
+        std::vector<HiddenGroup> groups;
+        rrl_pack::Idx ix;
+        const int rc = build_pack<HiddenGroup>(S, n, members, groups, ix, build_hidden_group);
+        if (rc != RRL_OK) return rc;
+        plan = rrl_pack::store(key, groups.data(), sizeof(HiddenGroup) * S, st);
+        if (!plan) return RRL_ELAUNCH;
+        plan->ix = ix;
+    }
+    hipLaunchKernelGGL(gemm16_pack_kernel, dim3(plan->ix.first[S]), dim3(64), 0, st, (const HiddenGroup*)plan->dev,
+                       plan->ix);
     return check_launch();
 }
 
@@ -1494,30 +1512,38 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
 
 // the column-split kernels only (what the steady-state iteration launches at H = 256); every seed on the same path
 int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const* members, void* stream) {
-    std::vector<StackGroup> groups;
-    rrl_pack::Idx ix;
-    int path = -1;
-    const int rc = build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
-        int my;
-        const int r = build_stack_group(nk, m, g, my);
-        if (r != RRL_OK) return r;
-        if ((my != 0 && my != 3) || (path >= 0 && my != path)) return int(RRL_EINVAL);
-        path = my;
-        return int(RRL_OK);
-    });
-    if (rc != RRL_OK) return rc;
+    rrl_pack::Key key;
+    if (!pack_key(2, S, n, members, key)) return RRL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const void* dev = rrl_pack::upload(groups.data(), sizeof(StackGroup) * S, st);
-    if (!dev) return RRL_ELAUNCH;
-    if (path == 0) {
-        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(ix.first[S]), dim3(256), split_lds_floats(1) * 4, st,
-                           (const StackGroup*)dev, ix);
-    } else {
-        static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
-        if (!ok) return RRL_ERANGE;
-        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(ix.first[S]), dim3(256), split_lds_floats(kBigR) * 4, st,
-                           (const StackGroup*)dev, ix);
+    rrl_pack::Plan* plan = rrl_pack::lookup(key);
+    if (!plan) {
+        std::vector<StackGroup> groups;
+        rrl_pack::Idx ix;
+        int path = -1;
+        const int rc = build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
+            int my;
+            const int r = build_stack_group(nk, m, g, my);
+            if (r != RRL_OK) return r;
+            if ((my != 0 && my != 3) || (path >= 0 && my != path)) return int(RRL_EINVAL);
+            path = my;
+            return int(RRL_OK);
+        });
+        if (rc != RRL_OK) return rc;
+        if (path == 3) {
+            static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+            if (!ok) return RRL_ERANGE;
+        }
+        plan = rrl_pack::store(key, groups.data(), sizeof(StackGroup) * S, st);
+        if (!plan) return RRL_ELAUNCH;
+        plan->ix = ix;
+        plan->i0 = path;
     }
+    if (plan->i0 == 0)
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(plan->ix.first[S]), dim3(256), split_lds_floats(1) * 4, st,
+                           (const StackGroup*)plan->dev, plan->ix);
+    else
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(plan->ix.first[S]), dim3(256),
+                           split_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
     return check_launch();
 }
 
@@ -1604,14 +1630,21 @@ int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
 }
 
 int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t* const* members, void* stream) {
-    std::vector<HeadBwdGroup> groups;
-    rrl_pack::Idx ix;
-    const int rc = build_pack<HeadBwdGroup>(S, n, members, groups, ix, build_head_group);
-    if (rc != RRL_OK) return rc;
+    rrl_pack::Key key;
+    if (!pack_key(3, S, n, members, key)) return RRL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const void* dev = rrl_pack::upload(groups.data(), sizeof(HeadBwdGroup) * S, st);
-    if (!dev) return RRL_ELAUNCH;
-    hipLaunchKernelGGL(head_bwd_pack_kernel, dim3(ix.first[S]), dim3(256), 0, st, (const HeadBwdGroup*)dev, ix);
+    rrl_pack::Plan* plan = rrl_pack::lookup(key);
+    if (!plan) {
+        std::vector<HeadBwdGroup> groups;
+        rrl_pack::Idx ix;
+        const int rc = build_pack<HeadBwdGroup>(S, n, members, groups, ix, build_head_group);
+        if (rc != RRL_OK) return rc;
+        plan = rrl_pack::store(key, groups.data(), sizeof(HeadBwdGroup) * S, st);
+        if (!plan) return RRL_ELAUNCH;
+        plan->ix = ix;
+    }
+    hipLaunchKernelGGL(head_bwd_pack_kernel, dim3(plan->ix.first[S]), dim3(256), 0, st, (const HeadBwdGroup*)plan->dev,
+                       plan->ix);
     return check_launch();
 }
 

@@ -616,36 +616,59 @@ int rrl_sample_multi(const rrl_draw_t* first, const rrl_draw_t* second, long lon
     return check_launch();
 }
 
+static void key_draw(rrl_pack::Key& key, const rrl_draw_t* d) {
+    key.pod(d != nullptr);
+    if (d) {
+        key.pod(*d);
+        if (d->rb) key.pod(*d->rb);          // capacity / pinned rows / flags belong to the launch
+    }
+}
+
 int rrl_sample_multi_packed(int S, const rrl_sample_args_t* args, void* stream) {
     if (S <= 0 || S > rrl_pack::kMaxSeeds || !args) return RRL_EINVAL;
-    std::vector<SamplePack> packs(S);
-    memset(packs.data(), 0, sizeof(SamplePack) * S);
-    int threads = 0;
-    size_t lds = 0;
+    rrl_pack::Key key;
+    key.pod(5);
+    key.pod(S);
     for (int s = 0; s < S; ++s) {
-        const rrl_sample_args_t& g = args[s];
-        int t;
-        size_t l;
-        const int rc = build_sample(g.first, g.second, g.noise_pairs, g.noise_seed, g.noise_counter, g.noise_counter_dev,
-                                    g.noise_counter_inc, g.noise_out, packs[s].a, packs[s].b, packs[s].nz, t, l);
-        if (rc != RRL_OK) return rc;
-        threads = t > threads ? t : threads;
-        lds = l > lds ? l : lds;
+        key_draw(key, args[s].first);
+        key_draw(key, args[s].second);
+        key.pod(args[s].noise_pairs); key.pod(args[s].noise_seed); key.pod(args[s].noise_counter);
+        key.pod(args[s].noise_counter_dev); key.pod(args[s].noise_counter_inc); key.pod(args[s].noise_out);
     }
-    rrl_pack::Idx ix;
-    ix.S = S;
-    ix.first[0] = 0;
-    for (int s = 0; s < S; ++s) {
-        noise_blocks(packs[s].nz, threads);
-        ix.first[s + 1] = ix.first[s] + 2 + packs[s].nz.blocks;
-    }
-    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
-    static size_t granted = 64 * 1024;
-    if (!grant_sample_lds(sample_pack_kernel, lds, granted)) return RRL_ERANGE;
     hipStream_t st = (hipStream_t)stream;
-    const void* dev = rrl_pack::upload(packs.data(), sizeof(SamplePack) * S, st);
-    if (!dev) return RRL_ELAUNCH;
-    hipLaunchKernelGGL(sample_pack_kernel, dim3(ix.first[S]), dim3(threads), lds, st, (const SamplePack*)dev, ix);
+    rrl_pack::Plan* plan = rrl_pack::lookup(key);
+    if (!plan) {
+        std::vector<SamplePack> packs(S);
+        int threads = 0;
+        size_t lds = 0;
+        for (int s = 0; s < S; ++s) {
+            const rrl_sample_args_t& g = args[s];
+            int t;
+            size_t l;
+            const int rc = build_sample(g.first, g.second, g.noise_pairs, g.noise_seed, g.noise_counter, g.noise_counter_dev,
+                                        g.noise_counter_inc, g.noise_out, packs[s].a, packs[s].b, packs[s].nz, t, l);
+            if (rc != RRL_OK) return rc;
+            threads = t > threads ? t : threads;
+            lds = l > lds ? l : lds;
+        }
+        rrl_pack::Idx ix;
+        ix.S = S;
+        ix.first[0] = 0;
+        for (int s = 0; s < S; ++s) {
+            noise_blocks(packs[s].nz, threads);
+            ix.first[s + 1] = ix.first[s] + 2 + packs[s].nz.blocks;
+        }
+        for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+        static size_t granted = 64 * 1024;
+        if (!grant_sample_lds(sample_pack_kernel, lds, granted)) return RRL_ERANGE;
+        plan = rrl_pack::store(key, packs.data(), sizeof(SamplePack) * S, st);
+        if (!plan) return RRL_ELAUNCH;
+        plan->ix = ix;
+        plan->i0 = threads;
+        plan->z0 = lds;
+    }
+    hipLaunchKernelGGL(sample_pack_kernel, dim3(plan->ix.first[S]), dim3(plan->i0), plan->z0, st,
+                       (const SamplePack*)plan->dev, plan->ix);
     return check_launch();
 }
 

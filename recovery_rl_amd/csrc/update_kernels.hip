@@ -622,23 +622,36 @@ int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float b
 int rrl_adam_step_multi_packed(int S, const int* n_seg, const rrl_adam_seg_t* const* segs, const float* lr, float beta1,
                                float beta2, float eps, void* stream) {
     if (S <= 0 || S > rrl_pack::kMaxSeeds || !n_seg || !segs || !lr) return RRL_EINVAL;
-    std::vector<AdamPack> packs(S);
-    memset(packs.data(), 0, sizeof(AdamPack) * S);           // padding bytes take part in the content hash
-    rrl_pack::Idx ix;
-    ix.S = S;
-    ix.first[0] = 0;
+    rrl_pack::Key key;
+    key.pod(4);
+    key.pod(S);
+    key.pod(beta1); key.pod(beta2); key.pod(eps);
     for (int s = 0; s < S; ++s) {
-        const int rc = build_adam_segs(n_seg[s], segs[s], packs[s].a);
-        if (rc != RRL_OK) return rc;
-        packs[s].n_seg = n_seg[s];
-        packs[s].lr = lr[s]; packs[s].b1 = beta1; packs[s].b2 = beta2; packs[s].eps = eps;
-        ix.first[s + 1] = ix.first[s] + packs[s].a.first_block[n_seg[s]];
+        if (n_seg[s] <= 0 || n_seg[s] > RRL_ADAM_MAX_SEGS || !segs[s]) return RRL_EINVAL;
+        key.pod(n_seg[s]);
+        key.pod(lr[s]);
+        key.add(segs[s], sizeof(rrl_adam_seg_t) * n_seg[s]);
     }
-    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
     hipStream_t st = (hipStream_t)stream;
-    const void* dev = rrl_pack::upload(packs.data(), sizeof(AdamPack) * S, st);
-    if (!dev) return RRL_ELAUNCH;
-    hipLaunchKernelGGL(adam_pack_kernel, dim3(ix.first[S]), dim3(kBlock), 0, st, (const AdamPack*)dev, ix);
+    rrl_pack::Plan* plan = rrl_pack::lookup(key);
+    if (!plan) {
+        std::vector<AdamPack> packs(S);
+        rrl_pack::Idx ix;
+        ix.S = S;
+        ix.first[0] = 0;
+        for (int s = 0; s < S; ++s) {
+            const int rc = build_adam_segs(n_seg[s], segs[s], packs[s].a);
+            if (rc != RRL_OK) return rc;
+            packs[s].n_seg = n_seg[s];
+            packs[s].lr = lr[s]; packs[s].b1 = beta1; packs[s].b2 = beta2; packs[s].eps = eps;
+            ix.first[s + 1] = ix.first[s] + packs[s].a.first_block[n_seg[s]];
+        }
+        for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+        plan = rrl_pack::store(key, packs.data(), sizeof(AdamPack) * S, st);
+        if (!plan) return RRL_ELAUNCH;
+        plan->ix = ix;
+    }
+    hipLaunchKernelGGL(adam_pack_kernel, dim3(plan->ix.first[S]), dim3(kBlock), 0, st, (const AdamPack*)plan->dev, plan->ix);
     return check_launch();
 }
 
