@@ -496,7 +496,7 @@ def run_config(a, cfg, device, world, rank, updates_per_step=1, min_seconds=MIN_
             "device_counters": dev0 is not None}, loop
 
 
-def run_seed_pack_leg(a, device, seeds=(1, 2, 4, 8), min_seconds=MIN_TIMED_LEG_S):
+def run_seed_pack_leg(a, device, seeds=(1, 2, 4, 8), min_seconds=MIN_TIMED_LEG_S, updates_per_step=1):
     """S independent learners of configs[1] (seeds 1..S: own envs, replay rings, networks, Philox keys) sharing every launch
     of the lock-step iteration on ONE GPU (recovery_rl_amd/packed.py): aggregate env-steps/s and grad-steps/s.  The reference
     runs its ten seeds one after the other (scripts/navigation1.sh:4-8); every packed seed equals its solo run bit for bit
@@ -506,7 +506,8 @@ def run_seed_pack_leg(a, device, seeds=(1, 2, 4, 8), min_seconds=MIN_TIMED_LEG_S
     from recovery_rl_amd.packed import PackedLoop
     out = []
     for S in seeds:
-        loops = [build_loop(arg_utils.get_args(config_argv(a.env, 1 + k, a.num_envs, 1)), device) for k in range(S)]
+        U = updates_per_step
+        loops = [build_loop(arg_utils.get_args(config_argv(a.env, 1 + k, a.num_envs, U)), device) for k in range(S)]
         packed = PackedLoop(loops)
         packed.capture()
         for _ in range(a.warmup):
@@ -516,12 +517,12 @@ def run_seed_pack_leg(a, device, seeds=(1, 2, 4, 8), min_seconds=MIN_TIMED_LEG_S
         elapsed, blocks = timed_blocks(packed.replay, a.steps, 1, device, min_seconds)
         c1 = [int(l.agent.fast.critic.step[0].item()) for l in loops]
         n_steps = a.steps * blocks
-        assert all(y - x == n_steps for x, y in zip(c0, c1)), (c0, c1, n_steps)
-        out.append({"seeds_per_gpu": S, "launches_per_packed_iteration": len(packed.stages),
+        assert all(y - x == n_steps * U for x, y in zip(c0, c1)), (c0, c1, n_steps)
+        out.append({"seeds_per_gpu": S, "updates_per_step": U, "launches_per_packed_iteration": len(packed.stages),
                     "ms_per_packed_iteration": elapsed / n_steps * 1e3,
                     "aggregate_env_steps_per_s": S * a.num_envs * n_steps / elapsed,
-                    "aggregate_sac_grad_steps_per_s": S * n_steps / elapsed,
-                    "aggregate_qrisk_grad_steps_per_s": S * n_steps / elapsed, "timed_seconds": elapsed})
+                    "aggregate_sac_grad_steps_per_s": S * U * n_steps / elapsed,
+                    "aggregate_qrisk_grad_steps_per_s": S * U * n_steps / elapsed, "timed_seconds": elapsed})
         del packed, loops
         torch.cuda.empty_cache()
     base = out[0]["aggregate_env_steps_per_s"]
@@ -667,6 +668,7 @@ def main():
         torch.cuda.empty_cache()
         loop = None
         extra["seed_pack"] = run_seed_pack_leg(a, device)
+        extra["seed_pack_utd_1_256"] = run_seed_pack_leg(a, device, seeds=(1, 4, 8), updates_per_step=16)
         if a.env == "navigation1" and a.num_envs == NUM_ENVS:
             with contextlib.redirect_stdout(sys.stderr):       # the driver announces itself: stdout carries the JSON line only
                 extra["config4"] = {prec: run_config4_leg(device, prec) for prec in ("f32", "f16x3")}

@@ -736,6 +736,14 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
 #define RRL_BIG_R 2
 #endif
 constexpr int kBigR = RRL_BIG_R;     // row tiles per workgroup for batches above kSplitSmallM rows
+#ifndef RRL_PACK_R
+#define RRL_PACK_R 4
+#endif
+#ifndef RRL_PACK_MIN_SEEDS
+#define RRL_PACK_MIN_SEEDS 3
+#endif
+constexpr int kPackR = RRL_PACK_R;   // ... of the packed launch from kPackMinSeeds seeds on
+constexpr int kPackMinSeeds = RRL_PACK_MIN_SEEDS;
 constexpr int kSplitSmallM = 1024;
 constexpr size_t split_lds_floats(int R) {
     return size_t(R) * kStackRows * (kStackMaxH + 20) +
@@ -1448,7 +1456,7 @@ int rrl_debug_fwd_stamps(unsigned long long* host, int n_blocks) {
 }
 #endif
 
-static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& path) {
+static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& path, int big_r = kBigR) {
     if (!st || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
     sg = StackGroup{};
     sg.n = n;
@@ -1473,7 +1481,7 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
         const long long tiles16 = (p.M + kStackRows - 1) / kStackRows;
         if (p.scratch && rrl_mlp3_is_split(p.M, p.H)) {
             my = (p.M <= kSplitSmallM || p.H != 256) ? 0 : 3;      // the multi-row tiles are built for H = 256
-            const int rows = (my == 0 ? 1 : kBigR) * kStackRows;
+            const int rows = (my == 0 ? 1 : big_r) * kStackRows;
             sg.tiles[k] = (p.M + rows - 1) / rows;
             sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G * kSplit;
         } else if (tiles16 * p.G > 256) {
@@ -1520,9 +1528,13 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         std::vector<StackGroup> groups;
         rrl_pack::Idx ix;
         int path = -1;
+        // row tiles per workgroup of the large-batch kernel: with several seeds in the launch there are workgroups to spare,
+        // so each keeps its W2 fragments for kPackR = 4 row tiles (half the weight stream of the solo kernel's 2; per output
+        // element the arithmetic is the same for every R)
+        const int big_r = S >= kPackMinSeeds ? kPackR : kBigR;
         const int rc = build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
             int my;
-            const int r = build_stack_group(nk, m, g, my);
+            const int r = build_stack_group(nk, m, g, my, big_r);
             if (r != RRL_OK) return r;
             if ((my != 0 && my != 3) || (path >= 0 && my != path)) return int(RRL_EINVAL);
             path = my;
@@ -1530,17 +1542,22 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         });
         if (rc != RRL_OK) return rc;
         if (path == 3) {
-            static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+            static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4) &&
+                                   grant_lds((const void*)mlp3_fwd_split_pack_kernel<kPackR>, split_lds_floats(kPackR) * 4);
             if (!ok) return RRL_ERANGE;
         }
         plan = rrl_pack::store(key, groups.data(), sizeof(StackGroup) * S, st);
         if (!plan) return RRL_ELAUNCH;
         plan->ix = ix;
         plan->i0 = path;
+        plan->i1 = big_r;
     }
     if (plan->i0 == 0)
         hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(plan->ix.first[S]), dim3(256), split_lds_floats(1) * 4, st,
                            (const StackGroup*)plan->dev, plan->ix);
+    else if (plan->i1 == kPackR)
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kPackR>, dim3(plan->ix.first[S]), dim3(256),
+                           split_lds_floats(kPackR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
     else
         hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(plan->ix.first[S]), dim3(256),
                            split_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
