@@ -276,9 +276,10 @@ __global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenGroup hg) {
 __global__ __launch_bounds__(64) void gemm16_pack_kernel(const HiddenGroup* __restrict__ groups, rrl_pack::Idx ix) {
     __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
     __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
-    const int s = rrl_pack::seed_of(ix, blockIdx.x);
+    int s, local;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
     // the one member this workgroup serves, not the whole 1.8 KB group, is what it copies out of device memory
-    gemm16_group_body(groups[s], blockIdx.x - ix.first[s], As, Bs);
+    gemm16_group_body(groups[s], local, As, Bs);
 }
 
 __device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int block, float* As, float* Bs) {
@@ -740,7 +741,7 @@ constexpr int kBigR = RRL_BIG_R;     // row tiles per workgroup for batches abov
 #define RRL_PACK_R 4
 #endif
 #ifndef RRL_PACK_MIN_SEEDS
-#define RRL_PACK_MIN_SEEDS 3
+#define RRL_PACK_MIN_SEEDS 99     /* measured: 4 row tiles per workgroup are not faster than 2 at S = 4, 8 (0.401 vs 0.389 ms, 0.676 vs 0.649) */
 #endif
 constexpr int kPackR = RRL_PACK_R;   // ... of the packed launch from kPackMinSeeds seeds on
 constexpr int kPackMinSeeds = RRL_PACK_MIN_SEEDS;
@@ -782,8 +783,9 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg
 template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_pack_kernel(const StackGroup* __restrict__ groups, rrl_pack::Idx ix) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int s = rrl_pack::seed_of(ix, blockIdx.x);
-    mlp3_fwd_split_group_body<R>(groups[s], blockIdx.x - ix.first[s], lds);
+    int s, local;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
+    mlp3_fwd_split_group_body<R>(groups[s], local, lds);
 }
 
 __global__ void sum_partials_kernel(int n, const float* __restrict__ partial, float* __restrict__ out) {
@@ -1126,8 +1128,9 @@ __global__ __launch_bounds__(256) void head_bwd_group_kernel(HeadBwdGroup hg) {
 __global__ __launch_bounds__(256) void head_bwd_pack_kernel(const HeadBwdGroup* __restrict__ groups, rrl_pack::Idx ix) {
     __shared__ float red[kSlices][4][kCols];
     __shared__ float dsh[1024 * 4];
-    const int s = rrl_pack::seed_of(ix, blockIdx.x);
-    head_bwd_group_body(groups[s], blockIdx.x - ix.first[s], red, dsh);
+    int s, local;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
+    head_bwd_group_body(groups[s], local, red, dsh);
 }
 
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
@@ -1373,10 +1376,10 @@ int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_b
         if (rc != RRL_OK) return rc;
         plan = rrl_pack::store(key, groups.data(), sizeof(HiddenGroup) * S, st);
         if (!plan) return RRL_ELAUNCH;
+        plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
     }
-    hipLaunchKernelGGL(gemm16_pack_kernel, dim3(plan->ix.first[S]), dim3(64), 0, st, (const HiddenGroup*)plan->dev,
-                       plan->ix);
+    hipLaunchKernelGGL(gemm16_pack_kernel, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
     return check_launch();
 }
 
@@ -1548,18 +1551,19 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         }
         plan = rrl_pack::store(key, groups.data(), sizeof(StackGroup) * S, st);
         if (!plan) return RRL_ELAUNCH;
+        plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         plan->i0 = path;
         plan->i1 = big_r;
     }
     if (plan->i0 == 0)
-        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(plan->ix.first[S]), dim3(256), split_lds_floats(1) * 4, st,
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(plan->grid), dim3(256), split_lds_floats(1) * 4, st,
                            (const StackGroup*)plan->dev, plan->ix);
     else if (plan->i1 == kPackR)
-        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kPackR>, dim3(plan->ix.first[S]), dim3(256),
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kPackR>, dim3(plan->grid), dim3(256),
                            split_lds_floats(kPackR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
     else
-        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(plan->ix.first[S]), dim3(256),
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(plan->grid), dim3(256),
                            split_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
     return check_launch();
 }
@@ -1658,10 +1662,10 @@ int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t
         if (rc != RRL_OK) return rc;
         plan = rrl_pack::store(key, groups.data(), sizeof(HeadBwdGroup) * S, st);
         if (!plan) return RRL_ELAUNCH;
+        plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
     }
-    hipLaunchKernelGGL(head_bwd_pack_kernel, dim3(plan->ix.first[S]), dim3(256), 0, st, (const HeadBwdGroup*)plan->dev,
-                       plan->ix);
+    hipLaunchKernelGGL(head_bwd_pack_kernel, dim3(plan->grid), dim3(256), 0, st, (const HeadBwdGroup*)plan->dev, plan->ix);
     return check_launch();
 }
 

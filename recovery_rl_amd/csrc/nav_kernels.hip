@@ -1216,11 +1216,12 @@ int rrl_nav_step_push_packed(int S, int env_kind, const rrl_step_push_t* a, void
         for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
         plan = rrl_pack::store(key, ps.data(), sizeof(rrl_step::StepPushArgs) * S, st);
         if (!plan) return RRL_ELAUNCH;
+        plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         plan->i0 = small;
     }
     const auto* dev = (const rrl_step::StepPushArgs*)plan->dev;
-    const dim3 grid(plan->ix.first[S]), block(kBlock);
+    const dim3 grid(plan->grid), block(kBlock);
     if (plan->i0) {
         if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<0>, true>), grid, block, 0, st, dev, plan->ix);
         else hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<1>, true>), grid, block, 0, st, dev, plan->ix);

@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <unordered_map>
@@ -23,14 +24,47 @@ namespace rrl_pack {
 constexpr int kMaxSeeds = 16;
 
 struct Idx {
-    int first[kMaxSeeds + 1];     // workgroups [first[s], first[s + 1]) belong to seed s
+    int first[kMaxSeeds + 1];     // seed s owns first[s + 1] - first[s] workgroups (linear mapping: [first[s], first[s + 1]))
     int S;
+    // XCD-aware mapping (sp > 0): the dispatcher hands workgroup b to XCD b % 8, and every XCD has its own L2.  Seed s is
+    // pinned to the XCDs {s, s + sp, s + 2 sp, ...} (sp = S rounded up to a power of two, p = 8 / sp of them): its weights,
+    // activations and replay rows then live in p L2s instead of all eight, and no L2 holds more than one seed's working
+    // set (linear mapping: every L2 caches every seed's weights -- 4 seeds x ~1.6 MB against 4 MB per L2).
+    int sp, p;
 };
 
 __device__ __forceinline__ int seed_of(const Idx& ix, int block) {
     int s = 0;
     while (s + 1 < ix.S && block >= ix.first[s + 1]) ++s;
     return s;
+}
+
+// (seed, workgroup index inside the seed's own grid) of physical workgroup b; false: b serves nobody (XCD-aware grids are
+// padded to whole rounds of eight)
+__device__ __forceinline__ bool locate(const Idx& ix, int b, int& s, int& local) {
+    if (ix.sp == 0) {
+        s = seed_of(ix, b);
+        local = b - ix.first[s];
+        return true;
+    }
+    const int x = b & 7;
+    s = x % ix.sp;
+    local = (b >> 3) * ix.p + x / ix.sp;
+    return s < ix.S && local < ix.first[s + 1] - ix.first[s];
+}
+
+// host: choose the mapping for `ix` (first[] and S filled in) and return the grid size
+inline int finish(Idx& ix) {
+    static const bool xcd = [] { const char* e = getenv("RRL_PACK_XCD"); return !(e && e[0] == '0'); }();
+    ix.sp = ix.p = 0;
+    if (!xcd || ix.S > 8) return ix.first[ix.S];
+    int sp = 1;
+    while (sp < ix.S) sp <<= 1;
+    ix.sp = sp;
+    ix.p = 8 / sp;
+    int most = 0;
+    for (int s = 0; s < ix.S; ++s) most = ix.first[s + 1] - ix.first[s] > most ? ix.first[s + 1] - ix.first[s] : most;
+    return 8 * ((most + ix.p - 1) / ix.p);
 }
 
 // A packed launch = (device copy of the S argument blocks, block ranges, launch parameters), built once per distinct
@@ -54,6 +88,7 @@ struct Key {
 struct Plan {
     void* dev = nullptr;          // S argument blocks in device memory
     Idx ix{};
+    int grid = 0;                 // workgroups of the launch (finish(ix))
     int i0 = 0, i1 = 0;           // kernel-specific launch parameters (path, threads, ...)
     size_t z0 = 0;                // ... dynamic LDS bytes
     std::vector<char> key, host;  // the input it was built from; staging copy of the blocks (outlives the async transfer)

@@ -487,8 +487,8 @@ struct SamplePack {
 };
 __global__ __launch_bounds__(1024) void sample_pack_kernel(const SamplePack* __restrict__ packs, rrl_pack::Idx ix) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int s = rrl_pack::seed_of(ix, blockIdx.x);
-    const int block = blockIdx.x - ix.first[s];
+    int s, block;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, block)) return;
     // a sampler workgroup copies its own draw, a noise workgroup the noise block, out of device memory
     if (block == 0) { const DrawArgs d = packs[s].a; draw_body(d, smem); return; }
     if (block == 1) { const DrawArgs d = packs[s].b; draw_body(d, smem); return; }
@@ -663,11 +663,12 @@ int rrl_sample_multi_packed(int S, const rrl_sample_args_t* args, void* stream) 
         if (!grant_sample_lds(sample_pack_kernel, lds, granted)) return RRL_ERANGE;
         plan = rrl_pack::store(key, packs.data(), sizeof(SamplePack) * S, st);
         if (!plan) return RRL_ELAUNCH;
+        plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         plan->i0 = threads;
         plan->z0 = lds;
     }
-    hipLaunchKernelGGL(sample_pack_kernel, dim3(plan->ix.first[S]), dim3(plan->i0), plan->z0, st,
+    hipLaunchKernelGGL(sample_pack_kernel, dim3(plan->grid), dim3(plan->i0), plan->z0, st,
                        (const SamplePack*)plan->dev, plan->ix);
     return check_launch();
 }

@@ -326,9 +326,10 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArg
 template <class ENV, bool SPECULATE = false>
 __global__ __launch_bounds__(rrl_host::kBlock) void step_push_pack_kernel(const StepPushArgs* __restrict__ ps,
                                                                           rrl_pack::Idx ix) {
-    const int s = rrl_pack::seed_of(ix, blockIdx.x);
+    int s, local;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
     const StepPushArgs p = ps[s];
-    step_push_body<ENV, SPECULATE>(p, blockIdx.x - ix.first[s], ix.first[s + 1] - ix.first[s]);
+    step_push_body<ENV, SPECULATE>(p, local, ix.first[s + 1] - ix.first[s]);
 }
 
 // host side: argument block shared by the navigation and maze entry points

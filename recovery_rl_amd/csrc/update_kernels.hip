@@ -430,9 +430,10 @@ struct AdamPack {
 };
 __global__ __launch_bounds__(kBlock) void adam_pack_kernel(const AdamPack* __restrict__ packs, rrl_pack::Idx ix) {
     __shared__ float sh[2];
-    const int s = rrl_pack::seed_of(ix, blockIdx.x);
+    int s, local;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
     const AdamPack& pk = packs[s];
-    adam_multi_body(pk.a, pk.n_seg, pk.lr, pk.b1, pk.b2, pk.eps, blockIdx.x - ix.first[s], sh);
+    adam_multi_body(pk.a, pk.n_seg, pk.lr, pk.b1, pk.b2, pk.eps, local, sh);
 }
 
 // ---- N(0,1) fill: out[2i], out[2i+1] = the Philox normal pair of index i (stream RRL_STREAM_NOISE) ----
@@ -649,9 +650,10 @@ int rrl_adam_step_multi_packed(int S, const int* n_seg, const rrl_adam_seg_t* co
         for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
         plan = rrl_pack::store(key, packs.data(), sizeof(AdamPack) * S, st);
         if (!plan) return RRL_ELAUNCH;
+        plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
     }
-    hipLaunchKernelGGL(adam_pack_kernel, dim3(plan->ix.first[S]), dim3(kBlock), 0, st, (const AdamPack*)plan->dev, plan->ix);
+    hipLaunchKernelGGL(adam_pack_kernel, dim3(plan->grid), dim3(kBlock), 0, st, (const AdamPack*)plan->dev, plan->ix);
     return check_launch();
 }
 
