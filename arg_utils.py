@@ -88,6 +88,9 @@ ADDITIVE = [
                                    "values below 0.06; 2.7x faster); "
                                    "default: f32 unless RRL_PLAN_F16X3=1"),
     (("--resume",), S, "", "checkpoint.pt to continue from (lock-step loop; skips pre-training)"),
+    (("--seeds_per_gpu",), I, 1, "lock-step loop: run this many independent seeds (seed, seed + 1, ...: own envs, replay "
+                                 "rings, networks, Philox keys -- the reference's seed loop, scripts/navigation1.sh:4-8) on "
+                                 "ONE GPU, sharing every launch of the iteration (recovery_rl_amd/packed.py)"),
     (("--no_pin_demos",), "store_true", None, "lock-step loop: let the safety buffer's ring overwrite the offline constraint "
                                               "demonstrations (default: they are pinned, as the one-env reference never "
                                               "wraps its 1e6-row ring within a run)"),

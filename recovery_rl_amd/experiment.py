@@ -787,3 +787,72 @@ class SingleEnvView:
         memory.push(self._last[0], action.contiguous(),
                     torch.full((1,), float(reward), dtype=torch.float32, device=dev), self._last[1],
                     torch.full((1,), float(mask), dtype=torch.float32, device=dev))
+
+
+def run_packed(exp_cfg, rank=0, world_size=1):
+    """`--seeds_per_gpu S` (S > 1): S independent experiments -- seeds seed, seed + 1, ..., each with its own log directory,
+    envs, replay rings, networks and pre-training, exactly what S runs of the reference's seed loop
+    (scripts/navigation1.sh:4-8) would create -- advanced together on one GPU: once every seed is in its steady state the
+    iteration of all of them is ONE hipGraph whose launches are shared (packed.PackedLoop); every seed's trajectory is the one
+    its solo run produces.  Logging per seed at the `--log_every` cadence (counters; no per-episode table in this mode).
+    Returns the list of per-seed histories."""
+    import copy
+    from .fast_update import fast_path_supported
+    from .packed import PackedLoop
+    S = int(exp_cfg.seeds_per_gpu)
+    if exp_cfg.num_envs < 2 or not fast_path_supported(exp_cfg) or uses_mb_recovery(exp_cfg) or \
+            not (exp_cfg.use_recovery and exp_cfg.MF_recovery) or world_size > 1:
+        raise ValueError("--seeds_per_gpu needs the lock-step loop (--num_envs > 1) on the fused update path with model-free "
+                         "recovery, one process per GPU")
+    exps = []
+    for k in range(S):
+        cfg = copy.deepcopy(exp_cfg)
+        cfg.seed = exp_cfg.seed + k
+        cfg.logdir_suffix = "%s_seed%d" % (exp_cfg.logdir_suffix, cfg.seed)
+        exp = Experiment(cfg)
+        if not cfg.disable_offline_updates:
+            exp.pretrain_critic_recovery()
+        exp.loop.start()
+        exps.append(exp)
+    cfg = exp_cfg
+    n = cfg.num_envs
+    log_every = cfg.log_every if getattr(cfg, "log_every", 0) else 100
+    # eager until every seed has a batch, has left the random-action phase and trains Q_risk online
+    it = 0
+    while True:
+        ready = [len(e.memory) > cfg.batch_size and e.loop.total_numsteps >= cfg.start_steps and e.online_qrisk_enabled()
+                 for e in exps]
+        if all(ready):
+            break
+        if it > 20 * log_every:
+            raise RuntimeError("--seeds_per_gpu: the seeds did not all reach the steady state (online Q_risk gate)")
+        for e in exps:
+            e.loop.vector_step(do_update=len(e.memory) > cfg.batch_size,
+                               random_actions=cfg.start_steps > e.loop.total_numsteps,
+                               online_qrisk=e.online_qrisk_enabled())
+        it += 1
+    packed = PackedLoop([e.loop for e in exps], online_qrisk=True)
+    it += packed.capture()
+    histories = [[] for _ in exps]
+    logged = it // log_every
+    while True:
+        packed.replay()
+        it += 1
+        if it // log_every > logged:
+            logged = it // log_every
+            done = True
+            for e, hist in zip(exps, histories):
+                stats = e.loop.read_stats()
+                e._absorb(stats)
+                hist.append(dict(stats, iteration=it))
+                print("Seed: {}, Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(
+                    e.exp_cfg.seed, it, stats["env_steps"], stats["episodes"],
+                    round(stats["episode_return_sum"] / max(stats["episodes"], 1), 2)))
+                print("Num Violations So Far: %d" % stats["num_viols"])
+                print("Num Successes So Far: %d" % stats["num_successes"])
+                with open(osp.join(e.logdir, "run_stats.pkl"), "wb") as f:
+                    pickle.dump({"vector_stats": hist, "eval_stats": [], "num_envs": n, "seeds_per_gpu": S}, f)
+                done = done and (stats["env_steps"] > cfg.num_steps or stats["episodes"] > cfg.num_eps)
+            if done:
+                break
+    return histories

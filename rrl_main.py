@@ -14,5 +14,9 @@ if __name__ == '__main__':
         torch.cuda.set_device(dist_utils.local_device(local_rank))
     if world > 1:
         exp_cfg.seed = dist_utils.rank_seed(exp_cfg.seed, rank)     # env, replay and noise streams differ per rank
-    experiment = Experiment(exp_cfg, rank=rank, world_size=world)
-    experiment.run()
+    if getattr(exp_cfg, "seeds_per_gpu", 1) > 1:
+        from recovery_rl_amd.experiment import run_packed
+        run_packed(exp_cfg, rank=rank, world_size=world)
+    else:
+        experiment = Experiment(exp_cfg, rank=rank, world_size=world)
+        experiment.run()

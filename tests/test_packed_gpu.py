@@ -66,3 +66,35 @@ def test_packed_entry_points_reject_what_they_cannot_pack():
     assert lib.rrl_sample_multi_packed(0, None, None) != 0
     assert lib.rrl_mlp3_forward_multi_packed(17, None, None, None) != 0
     assert lib.rrl_nav_step_push_packed(2, 5, None, None) != 0
+
+
+def test_seeds_per_gpu_flag_runs_packed_experiments(tmp_path, capsys):
+    """`rrl_main --seeds_per_gpu 3`: three experiments (seeds 4, 5, 6: own log directories, pre-training, buffers) advanced
+    by one shared graph; each one's counters equal the solo run of the same seed at the same iteration."""
+    import os
+    import pickle
+    from recovery_rl_amd.experiment import Experiment, run_packed
+    argv = ["--env-name", "navigation1", "--cuda", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe",
+            "0.3", "--num_unsafe_transitions", "3000", "--critic_safe_pretraining_steps", "30", "--num_envs", "128",
+            "--seed", "4", "--log_every", "20", "--num_eps", "100000", "--num_steps", str(128 * 60 - 1)]
+    cfg = arg_utils.get_args(argv + ["--seeds_per_gpu", "3", "--logdir", str(tmp_path / "packed")])
+    hists = run_packed(cfg)
+    assert len(hists) == 3 and all(h[-1]["iteration"] == 60 and h[-1]["env_steps"] == 60 * 128 for h in hists)
+    dirs = sorted(os.listdir(tmp_path / "packed"))
+    assert len(dirs) == 3 and dirs[0].endswith("_seed4") and dirs[2].endswith("_seed6")
+    saved = pickle.load(open(tmp_path / "packed" / dirs[1] / "run_stats.pkl", "rb"))
+    assert saved["seeds_per_gpu"] == 3 and saved["vector_stats"][-1] == hists[1][-1]
+    assert hists[0][-1]["sac_updates"] > 40 and hists[0][-1] != hists[1][-1]
+    # the solo run of the middle seed, iteration by iteration through the same phases
+    solo_cfg = arg_utils.get_args(argv[:-8] + ["--seed", "5", "--log_every", "20", "--num_eps", "100000", "--num_steps",
+                                               str(128 * 60 - 1), "--logdir", str(tmp_path / "solo")])
+    solo = Experiment(solo_cfg)
+    solo.pretrain_critic_recovery()
+    loop = solo.loop
+    loop.start()
+    for _ in range(60):
+        loop.vector_step(do_update=len(solo.memory) > solo_cfg.batch_size,
+                         random_actions=solo_cfg.start_steps > loop.total_numsteps, online_qrisk=solo.online_qrisk_enabled())
+    want = loop.read_stats()
+    got = {k: v for k, v in hists[1][-1].items() if k != "iteration"}
+    assert got == want
