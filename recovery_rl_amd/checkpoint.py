@@ -195,7 +195,8 @@ def experiment_state(exp, extra=None):
                                                     "num_unsafe_transitions", "num_viols", "num_successes",
                                                     "viol_and_recovery", "viol_and_no_recovery")},
           "rng": {"torch": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state(dev),
-                  "numpy": np.random.get_state(), "python": random.getstate()},
+                  "numpy": np.random.get_state(), "python": random.getstate(),
+                  "loop_actions": exp.loop.action_rng.get_state()},
           "extra": extra or {}}
     if exp.recovery_policy is not None:
         sd["mpc"] = mpc_state(exp.recovery_policy)
@@ -235,6 +236,8 @@ def load_experiment_state(exp, sd):
     torch.cuda.set_rng_state(sd["rng"]["cuda"], exp.device)
     np.random.set_state(sd["rng"]["numpy"])
     random.setstate(sd["rng"]["python"])
+    if "loop_actions" in sd["rng"]:
+        exp.loop.action_rng.set_state(sd["rng"]["loop_actions"])
     torch.cuda.synchronize(exp.device)
     return sd.get("extra", {})
 

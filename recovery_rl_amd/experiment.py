@@ -30,6 +30,7 @@ from . import distributed as dist_utils
 from .env import make_env, make_vec_env, register_env
 from .replay_memory import ConstraintReplayMemory, ReplayMemory
 from .sac import SAC
+from .fused import mlp3_supported
 from .utils import linear_schedule, trace_range
 
 # order of the device-side counter vector (also the RCCL-aggregated metric vector)
@@ -70,6 +71,10 @@ class VectorLoop:
         self._graph_updates = (0, 0)
         self._actor = None
         self._one = torch.ones((), dtype=torch.int64, device=dev)
+        # the random-action phase (experiment.py:559-560) draws from the loop's OWN generator: a seed's trajectory does not
+        # depend on what else shares the process (S seeds per GPU, packed.py), only on its seed
+        self.action_rng = torch.Generator(device=dev)
+        self.action_rng.manual_seed(int(cfg.seed) + 0x5EED)
         self.episode_log = None           # optional EpisodeLog (per-episode records for run_stats)
         # the fused step also writes env.next_obs / reward / done / constraint / success / ep_done (off: nobody reads them
         # in the steady-state graph; the episode log and the online ensemble re-fit switch them on by themselves)
@@ -131,7 +136,18 @@ class VectorLoop:
             return self._actor.act(obs, cfg.eps_safe, cfg.use_recovery, cfg.MF_recovery,
                                    defer_select=fast.grouped and obs is self.env.obs and self._can_fuse_step())
         if random_actions:
-            action = self.env.sample_actions()
+            action = self.env.sample_actions(generator=self.action_rng)
+        elif (fast is not None and train and obs.shape[0] == self.n and uses_mb_recovery(cfg)
+              and mlp3_supported(fast.policy.H, 2, 4) and mlp3_supported(fast.qrisk.H, 4, 1)):
+            # model-based recovery: task action and the Q_risk gate on the fused kernels (rows the planner does not need
+            # stay where they are); the planner acts for the gated rows only
+            if self._actor is None:
+                from .fast_update import FastActor
+                self._actor = FastActor(fast, self.n)
+            action, recovery = self._actor.act_gate(obs, cfg.eps_safe)
+            rec_action = self.recovery_policy.act(obs, 0, mask=recovery)
+            real_action = torch.where(recovery.bool().unsqueeze(1), rec_action, action)
+            return action, real_action, recovery
         else:
             action = self.agent.select_action(obs, eval=not train)
         if not cfg.use_recovery:

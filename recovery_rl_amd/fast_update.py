@@ -842,6 +842,32 @@ class FastActor:
         return self.task_action, self.real_action, self.recovery
 
 
+    def _act_gate(self, obs, eps_safe, noise=None):
+        """Task action + recovery gate for a controller that acts elsewhere (model-based recovery: MPC.act on the gated rows):
+        -> (task action [n,2], recovery u8[n]); persistent buffers."""
+        f, n, lib, st = self.f, self.n, self.f.lib, _lib.current_stream()
+        if noise is None:
+            noise = f.actor_noise(n)
+        self.pending_select = None
+        head, hn, hs = self.pol.forward(obs, save=False)
+        # the head kernel also copies obs into columns 0..1 of xa: [s | a_task] is assembled without a copy launch
+        _lib.check(lib.rrl_gauss_head_fwd(n, head.data_ptr(), hn, hs, noise[0].data_ptr(), f.scale.data_ptr(),
+                                          f.bias.data_ptr(), self.xa[:, 2:4].data_ptr(), 4, None, None,
+                                          obs.data_ptr(), self.xa.data_ptr(), st), "rrl_gauss_head_fwd")
+        self.qr.finalize = True                  # recovery_select reads a plain [2,n] tensor
+        zq, _, _ = self.qr.forward(self.xa, save=False)
+        # recovery[i] = max(sigmoid(z1), sigmoid(z2)) > eps_safe (experiment.py:566-571); the kernel's action selection runs
+        # on a dummy recovery action: the planner's action is merged in by the caller
+        _lib.check(lib.rrl_recovery_select(n, zq.data_ptr(), eps_safe, self.xa[:, 2:4].data_ptr(), 4,
+                                           self.rec_action.data_ptr(), self.real_action.data_ptr(),
+                                           self.recovery.data_ptr(), self.task_action.data_ptr(), st),
+                   "rrl_recovery_select")
+        return self.task_action, self.recovery
+
+
+FastActor.act_gate = FastActor._act_gate
+
+
 def fast_path_supported(cfg):
     """The fused path covers the Recovery-RL configurations (task SAC + Q_risk, model-free or
     model-based recovery, reward penalty); the comparison algorithms use the autograd path."""
