@@ -149,7 +149,7 @@ class VectorLoop:
             real_action = torch.where(recovery.bool().unsqueeze(1), rec_action, action)
             return action, real_action, recovery
         else:
-            action = self.agent.select_action(obs, eval=not train)
+            action = self.agent.select_action(obs, eval=not train, eps=self._policy_eps(self.agent.policy, obs))
         if not cfg.use_recovery:
             return action, action, None
         risk = self.agent.safety_critic.get_value(obs, action).squeeze(1)
@@ -158,11 +158,22 @@ class VectorLoop:
             # one env: the recovery policy is queried only when the gate fires, as in the reference
             return action, action.clone(), recovery
         if cfg.MF_recovery or cfg.Q_sampling_recovery:
-            rec_action = self.agent.safety_critic.select_action(obs)
+            qr = self.agent.safety_critic
+            rec_action = qr.select_action(obs, eps=self._policy_eps(qr.policy, obs) if cfg.MF_recovery else None)
         else:
             rec_action = self.recovery_policy.act(obs, 0, mask=recovery)
         real_action = torch.where(recovery.unsqueeze(1), rec_action, action)
         return action, real_action, recovery
+
+    def _policy_eps(self, policy, obs):
+        """N(0,1) draws for a policy sampled through its torch module in the lock-step loop (the random-action phase, the
+        configurations outside the fused path): from the loop's own generator, so that a seed's trajectory does not depend on
+        what else shares the process.  One env: None = torch's global generator, as the reference."""
+        if self.n == 1 or getattr(policy, "use_global_rng", False):
+            return None
+        from .model import DeterministicPolicy
+        shape = (policy.num_actions,) if isinstance(policy, DeterministicPolicy) else (obs.shape[0], 2)
+        return torch.randn(*shape, device=self.device, generator=self.action_rng)
 
     def step_and_store(self, action, real_action, recovery):
         """env.step + reward penalty + mask + pushes + counters (experiment.py:420-461)."""

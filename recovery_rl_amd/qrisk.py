@@ -117,7 +117,7 @@ class QRiskWrapper:
         return self.safety_critic(states, actions)                        # :303-307
 
     @torch.no_grad()
-    def select_action(self, state, eval=False, candidates=None):
+    def select_action(self, state, eval=False, candidates=None, eps=None):
         """Recovery action (qrisk.py:198-227).  Accepts a [N,2] CUDA tensor (returns a tensor) or a
         single numpy state (returns numpy, like the reference).  `candidates` [N,1000,dU] injects the
         action_space.sample() draws of the Q-sampling branch (KAT tests)."""
@@ -125,7 +125,7 @@ class QRiskWrapper:
         if single:
             state = torch.as_tensor(np.asarray(state, dtype=np.float32), device=self.device).unsqueeze(0)
         if self.MF_recovery:
-            action, _, mean = self.policy.sample(state)
+            action, _, mean = self.policy.sample(state, eps)
             out = mean if eval else action
         elif self.Q_sampling_recovery:
             # 1000 uniform candidate actions per state, keep the argmin of Q_risk (:214-225)

@@ -95,16 +95,17 @@ class SAC(object):
 
     # -- acting ------------------------------------------------------------------------------
     @torch.no_grad()
-    def select_action(self, state, eval=False):
+    def select_action(self, state, eval=False, eps=None):
         """Task action (sac.py:133-168).  [N,2] CUDA tensor in -> tensor out; a single numpy state
-        in -> numpy out (the reference's calling convention)."""
+        in -> numpy out (the reference's calling convention).  `eps`: the policy's N(0,1) draws (default: torch's global
+        generator, as the reference)."""
         single = not torch.is_tensor(state)
         if single:
             state = torch.as_tensor(np.asarray(state, dtype=np.float32), device=self.device).unsqueeze(0)
         if self.use_constraint_sampling:
             action = self._sqrl_action(state)
         else:
-            sampled, _, mean = self.policy.sample(state)
+            sampled, _, mean = self.policy.sample(state, eps)
             action = mean if eval else sampled
         return action[0].cpu().numpy() if single else action
 
