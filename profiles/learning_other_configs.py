@@ -40,12 +40,19 @@ def run(name, seed):
     else:
         succ = sum(int(ep[-1]["reward"] > -4) for ep in data)
     rec = sum(int(s.get("recovery", False)) for ep in data for s in ep)
+    thr = 0.03 if name == "maze_mf" else 4.0
     return {"config": name, "seed": seed, "episodes": len(data), "total_violations": viol, "total_successes": succ,
-            "env_steps": sum(len(ep) for ep in data), "recovery_steps": rec, "wall_seconds": round(time.time() - t0, 1)}
+            "env_steps": sum(len(ep) for ep in data), "recovery_steps": rec, "wall_seconds": round(time.time() - t0, 1),
+            # per episode (plotting/plot_runs.py:214-235), so that prefixes can be compared with partial reference runs
+            "episode_lengths": [len(ep) for ep in data],
+            "violations": [int(any(s["constraint"] for s in ep)) for ep in data],
+            "successes": [int(-ep[-1]["reward"] < thr) for ep in data],
+            "recovery_steps_per_episode": [sum(int(s.get("recovery", False)) for s in ep) for ep in data]}
 
 
 if __name__ == "__main__":
     names = [sys.argv[1]] if len(sys.argv) > 1 else list(LINES)
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    seeds = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1]
     for n in names:
-        print(json.dumps(run(n, seed)), flush=True)
+        for seed in seeds:
+            print(json.dumps(run(n, seed)), flush=True)

@@ -168,9 +168,11 @@ class VectorLoop:
     def _policy_eps(self, policy, obs):
         """N(0,1) draws for a policy sampled through its torch module in the lock-step loop (the random-action phase, the
         configurations outside the fused path): from the loop's own generator, so that a seed's trajectory does not depend on
-        what else shares the process.  One env: None = torch's global generator, as the reference."""
-        if self.n == 1 or getattr(policy, "use_global_rng", False):
-            return None
+        what else shares the process (seed packing covers the fused path only).  One env, or no fused path: None = torch's
+        global generator, as the reference."""
+        if self.n == 1 or getattr(self.agent, "fast", None) is None:
+            return None      # configurations whose steady state samples through the modules are captured in a hipGraph,
+                             # where torch advances its GLOBAL generator's Philox offset per replay (a private one is not)
         from .model import DeterministicPolicy
         shape = (policy.num_actions,) if isinstance(policy, DeterministicPolicy) else (obs.shape[0], 2)
         return torch.randn(*shape, device=self.device, generator=self.action_rng)
