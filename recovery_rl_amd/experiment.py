@@ -136,7 +136,8 @@ class VectorLoop:
             return self._actor.act(obs, cfg.eps_safe, cfg.use_recovery, cfg.MF_recovery,
                                    defer_select=fast.grouped and obs is self.env.obs and self._can_fuse_step())
         if random_actions:
-            action = self.env.sample_actions(generator=self.action_rng)
+            # one env: action_space.sample() semantics on the global generator, as the reference (experiment.py:560)
+            action = self.env.sample_actions() if self.n == 1 else self.env.sample_actions(generator=self.action_rng)
         elif (fast is not None and train and obs.shape[0] == self.n and uses_mb_recovery(cfg)
               and mlp3_supported(fast.policy.H, 2, 4) and mlp3_supported(fast.qrisk.H, 4, 1)):
             # model-based recovery: task action and the Q_risk gate on the fused kernels (rows the planner does not need
