@@ -150,7 +150,9 @@ class VectorLoop:
             real_action = torch.where(recovery.bool().unsqueeze(1), rec_action, action)
             return action, real_action, recovery
         else:
-            action = self.agent.select_action(obs, eval=not train, eps=self._policy_eps(self.agent.policy, obs))
+            eps = self._policy_eps(self.agent.policy, obs) if self.n > 1 else None
+            action = self.agent.select_action(obs, eval=not train) if eps is None else \
+                self.agent.select_action(obs, eval=not train, eps=eps)
         if not cfg.use_recovery:
             return action, action, None
         risk = self.agent.safety_critic.get_value(obs, action).squeeze(1)
@@ -160,7 +162,8 @@ class VectorLoop:
             return action, action.clone(), recovery
         if cfg.MF_recovery or cfg.Q_sampling_recovery:
             qr = self.agent.safety_critic
-            rec_action = qr.select_action(obs, eps=self._policy_eps(qr.policy, obs) if cfg.MF_recovery else None)
+            eps = self._policy_eps(qr.policy, obs) if (cfg.MF_recovery and self.n > 1) else None
+            rec_action = qr.select_action(obs) if eps is None else qr.select_action(obs, eps=eps)
         else:
             rec_action = self.recovery_policy.act(obs, 0, mask=recovery)
         real_action = torch.where(recovery.unsqueeze(1), rec_action, action)
