@@ -487,6 +487,7 @@ struct StackGroup {
     StackArgs a[kMaxGroup];
     float* partial[kMaxGroup];      // split variant only
     int G[kMaxGroup], tiles[kMaxGroup];
+    int big[kMaxGroup];             // mixed split launch: member k runs kBigR row tiles per workgroup (else 1)
     int first[kMaxGroup + 1];
     int n;
 };
@@ -777,6 +778,39 @@ template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     mlp3_fwd_split_group_body<R>(sg, blockIdx.x, lds);
+}
+
+// Members of BOTH kinds in one launch -- small batches (R = 1) next to large ones (R = kBigR row tiles per workgroup): the
+// 4096-row forwards of the acting pass ride in the launches of the Q_risk update's 256-row forwards that become ready at
+// the same points of the iteration.  Every member runs the body of its own kind: same arithmetic, same bits.
+__device__ __forceinline__ void mlp3_fwd_split_mixed_body(const StackGroup& sg, int block, float* lds) {
+    int k = 0;
+    while (k + 1 < sg.n && block >= sg.first[k + 1]) ++k;
+    const int local = block - sg.first[k];
+    const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
+    const StackArgs a = sg.a[k];
+    const int G = sg.G[k];
+    if (sg.big[k]) {
+        if (a.H == 256) mlp3_fwd_split_body<kBigR, 256>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, lds);
+        else mlp3_fwd_split_body<kBigR, 0>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, lds);
+    } else {
+        float* h2s = lds + kStackRows * (kStackMaxH + 20);
+        if (a.H == 256) mlp3_fwd_split_body<1, 256>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, h2s);
+        else mlp3_fwd_split_body<1, 0>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, h2s);
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp3_fwd_split_mixed_kernel(StackGroup sg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    mlp3_fwd_split_mixed_body(sg, blockIdx.x, lds);
+}
+
+__global__ __launch_bounds__(256) void mlp3_fwd_split_mixed_pack_kernel(const StackGroup* __restrict__ groups,
+                                                                        rrl_pack::Idx ix) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int s, local;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
+    mlp3_fwd_split_mixed_body(groups[s], local, lds);
 }
 
 // the same launch for S seeds (pack.hpp): seed s runs its group on workgroups [first[s], first[s + 1])
@@ -1464,7 +1498,7 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
     sg = StackGroup{};
     sg.n = n;
     sg.first[0] = 0;
-    path = -1;   // 0 split (small batch), 3 split (R = kBigR row tiles), 1 plain R = 1, 2 plain R = 2
+    path = -1;   // 0 split (small batch), 3 split (R = kBigR row tiles), 4 split, both kinds; 1 plain R = 1, 2 plain R = 2
     for (int k = 0; k < n; ++k) {
         const rrl_stack_t& p = st[k];
         const int rc = stack_check(p.G, p.M, p.H, p.din, p.dout, p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.out);
@@ -1486,6 +1520,7 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
             my = (p.M <= kSplitSmallM || p.H != 256) ? 0 : 3;      // the multi-row tiles are built for H = 256
             const int rows = (my == 0 ? 1 : big_r) * kStackRows;
             sg.tiles[k] = (p.M + rows - 1) / rows;
+            sg.big[k] = my == 3;
             sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G * kSplit;
         } else if (tiles16 * p.G > 256) {
             my = 2;
@@ -1496,9 +1531,11 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
             sg.tiles[k] = int(tiles16);
             sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G;
         }
-        if (path >= 0 && my != path) return RRL_EINVAL;
-        path = my;
+        const bool split_mix = (my == 0 || my == 3) && (path == 0 || path == 3 || path == 4);
+        if (path >= 0 && my != path && !split_mix) return RRL_EINVAL;
+        path = (path >= 0 && my != path) ? 4 : my;
     }
+    if (path == 4 && big_r != kBigR) return RRL_EINVAL;      // the mixed kernel is built for kBigR
     for (int k = n; k < kMaxGroup; ++k) sg.first[k + 1] = sg.first[n];
     return RRL_OK;
 }
@@ -1516,6 +1553,8 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
         if (!ok) return RRL_ERANGE;
         hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<kBigR>, dim3(sg.first[n]), dim3(256),
                            split_lds_floats(kBigR) * 4, s, sg);
+    } else if (path == 4) {
+        hipLaunchKernelGGL(mlp3_fwd_split_mixed_kernel, dim3(sg.first[n]), dim3(256), split_lds_floats(kBigR) * 4, s, sg);
     } else if (path == 1) hipLaunchKernelGGL((mlp3_fwd_group_kernel<1>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
     else hipLaunchKernelGGL((mlp3_fwd_group_kernel<2>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
     return check_launch();
@@ -1539,7 +1578,7 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
             int my;
             const int r = build_stack_group(nk, m, g, my, big_r);
             if (r != RRL_OK) return r;
-            if ((my != 0 && my != 3) || (path >= 0 && my != path)) return int(RRL_EINVAL);
+            if ((my != 0 && my != 3 && my != 4) || (path >= 0 && my != path)) return int(RRL_EINVAL);
             path = my;
             return int(RRL_OK);
         });
@@ -1558,6 +1597,9 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
     }
     if (plan->i0 == 0)
         hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(plan->grid), dim3(256), split_lds_floats(1) * 4, st,
+                           (const StackGroup*)plan->dev, plan->ix);
+    else if (plan->i0 == 4)
+        hipLaunchKernelGGL(mlp3_fwd_split_mixed_pack_kernel, dim3(plan->grid), dim3(256), split_lds_floats(kBigR) * 4, st,
                            (const StackGroup*)plan->dev, plan->ix);
     else if (plan->i1 == kPackR)
         hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kPackR>, dim3(plan->grid), dim3(256),

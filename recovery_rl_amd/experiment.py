@@ -79,6 +79,7 @@ class VectorLoop:
         # the fused step also writes env.next_obs / reward / done / constraint / success / ep_done (off: nobody reads them
         # in the steady-state graph; the episode log and the online ensemble re-fit switch them on by themselves)
         self.step_outputs = False
+        self.ride_actor = True            # the acting pass's large forwards share launches with the updates' small ones
         if self.n > 1 and hasattr(recovery_memory, "clamp_stratified"):
             # N envs overwrite the ring in capacity / N iterations: once the policy avoids violations the positive
             # class can drop below int(B * pos_fraction) rows, where the one-env reference would abort
@@ -89,7 +90,7 @@ class VectorLoop:
         self.obs = self.env.reset()
         return self.obs
 
-    def do_updates(self, i_episode=1, online_qrisk=True):
+    def do_updates(self, i_episode=1, online_qrisk=True, fused_act_follows=False):
         """experiment.py:397-416.  The caller has checked len(memory) > batch_size."""
         cfg = self.cfg
         fast = getattr(self.agent, "fast", None)
@@ -97,12 +98,20 @@ class VectorLoop:
         grouped = (fast is not None and fast.grouped and fast.sync_world == 1 and cfg.batch_size == fast.B
                    and hasattr(self.memory, "draw_desc")
                    and (not online_qrisk or qr.clamp_batch_size(cfg.batch_size, len(self.recovery_memory)) == fast.B))
-        for _ in range(cfg.updates_per_step):
+        # the acting pass that follows rides in the LAST update pair's launches (fast_update.qrisk_update_grouped) when it is
+        # the fused acting pass on the env's own observation buffer
+        ride = None
+        if (fused_act_follows and grouped and online_qrisk and self.ride_actor and self._actor is not None
+                and self.obs is self.env.obs
+                and cfg.use_recovery and cfg.MF_recovery and self._can_fuse_step() and self._actor.n == self.n):
+            ride = (self._actor, self.obs)
+        for u in range(cfg.updates_per_step):
             if grouped:
                 # both replay draws + the policy noise in one launch, independent kernels of the two updates grouped
                 # (fast_update.FastUpdater.update_pair): same results as the two calls below, ~30 % fewer launches
                 with trace_range("sample+sac_update+qrisk_update"):
-                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None)
+                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None,
+                                     actor=ride if u == cfg.updates_per_step - 1 else None)
                 self.host_updates[0] += 1
                 if online_qrisk:
                     qr.updates += 1
@@ -305,7 +314,7 @@ class VectorLoop:
     # -- whole iteration -----------------------------------------------------------------------
     def vector_step(self, do_update=True, random_actions=False, online_qrisk=True, i_episode=1):
         if do_update:
-            self.do_updates(i_episode, online_qrisk)
+            self.do_updates(i_episode, online_qrisk, fused_act_follows=not random_actions)
         with trace_range("act"):
             action, real_action, recovery = self.act(self.obs, random_actions)
         self._last_recovery = recovery

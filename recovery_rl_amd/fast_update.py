@@ -565,7 +565,7 @@ class FastUpdater:
                                       p(self.rbias), p(action_view), action_view.stride(0), None, None, None, None,
                                       p(self.recpolicy.p["log_std"]), float(self.qr.policy.min_log_std))
 
-    def update_pair(self, memory, recovery_memory):
+    def update_pair(self, memory, recovery_memory, actor=None):
         """One SAC update and (recovery_memory not None) one Q_risk + recovery-policy update of a lock-step iteration
         (experiment.py:397-416): both replay draws and the iteration's policy noise in ONE launch, then the two
         updates on the grouped kernels.  Same draws, same arithmetic, same parameters as the separate calls."""
@@ -590,7 +590,7 @@ class FastUpdater:
         n = self._noise
         self.sac_update_grouped(batch, n[0], n[1])
         if recovery_memory is not None:
-            self.qrisk_update_grouped(batch_q, n[2], n[3])
+            self.qrisk_update_grouped(batch_q, n[2], n[3], actor=actor)
         return self.losses
 
     def sac_update_grouped(self, batch, eps_next, eps_pi):
@@ -630,7 +630,7 @@ class FastUpdater:
                            (self.policy, None, 0.0, self.pol_b.grad_part)])
         return self.losses
 
-    def qrisk_update_grouped(self, batch, eps_next, eps_pi):
+    def qrisk_update_grouped(self, batch, eps_next, eps_pi, actor=None):
         """qrisk_update with 15 launches instead of 19: the task policy on s' and the recovery policy on s in one
         forward launch (the recovery policy does not depend on the critic step in between), their heads in one, the
         target and online critics in one."""
@@ -642,10 +642,18 @@ class FastUpdater:
         fwd = [self.pol_a.forward_desc(x2u[:, 0:2], save=False)]          # a' from the TASK policy (qrisk.py:119-120)
         if mf:
             fwd.append(self.rec_a.forward_desc(xpu[:, 0:2]))
+        fuse = self.fuse_heads and self.qr_t.split
+        # `actor` = (FastActor, obs): the acting pass of THIS iteration rides along.  The task policy is final once the SAC
+        # update has stepped it, so its 4096-row forward joins this launch; Q_risk(s, a_task) joins the launch that follows
+        # the Q_risk optimiser step; only the recovery policy's forward is left for after its own step (FastActor.act).
+        ride = actor is not None and mf and fuse and actor[0].qr.split and actor[0].pol.split
+        if ride:
+            act, obs = actor
+            act.noise = self.actor_noise(act.n)
+            fwd.append(act.pol.forward_desc(obs, save=False))
         forward_multi(fwd)
         hd_next = self._gauss_desc(self.pol_a.parts, eps_next, x2u[:, 2:4], self.logp2)
         hd_rec = self._stoch_desc(self.rec_a.parts, eps_pi, xpu[:, 2:4]) if mf else None
-        fuse = self.fuse_heads and self.qr_t.split
         if not fuse:
             heads_multi([hd_next] + ([hd_rec] if mf else []))
             hd_next = hd_rec = None
@@ -661,7 +669,14 @@ class FastUpdater:
             raw, rn, rs = self.rec_a.parts
             ls = self.recpolicy.p["log_std"]
             if hd_rec is not None:         # the recovery action is evaluated by the critic stack that consumes it
-                forward_multi([self.qr_b.forward_desc(xpu, in_head=hd_rec)])
+                members = [self.qr_b.forward_desc(xpu, in_head=hd_rec)]
+                if ride:                   # Q_risk(s, a_task) of the acting pass, at the critic this update just stepped
+                    act.qr.finalize = False
+                    task_head = self._gauss_desc(act.pol.parts, act.noise[0], act.xa[:, 2:4], None, n=act.n, obs_in=obs,
+                                                 obs_out=act.xa)
+                    members.append(act.qr.forward_desc(act.xa, save=False, in_head=task_head))
+                    act.rode = True
+                forward_multi(members)
                 zp, n_part, ps = self.qr_b.parts
             else:
                 zp, n_part, ps = self.qr_b.forward(xpu)
@@ -788,9 +803,20 @@ class FastActor:
         defer_select: the recovery gate is left to the env-step kernel (rrl_*_step_push_select); `pending_select` then
         holds its inputs, the task action is the strided view xa[:, 2:4] and the other two are filled by that kernel."""
         f, n, lib, st = self.f, self.n, self.f.lib, _lib.current_stream()
+        self.pending_select = None
+        if getattr(self, "rode", False):
+            # the task policy and Q_risk(s, a_task) were evaluated inside the updates' launches (qrisk_update_grouped): what
+            # is left is the recovery policy, final only now that its optimiser step is done; its head is evaluated by the
+            # step kernel
+            self.rode = False
+            assert defer_select and use_recovery and mf_recovery
+            forward_multi([self.rec.forward_desc(obs, save=False)])
+            rec_head = f._stoch_desc(self.rec.parts, self.noise[1], self.rec_action, n=n)
+            zq, zn, zs = self.qr.parts
+            self.pending_select = (zq, zn, zs, float(eps_safe), None, rec_head)
+            return self.xa[:, 2:4], self.real_action, self.recovery
         if noise is None:
             noise = f.actor_noise(n)
-        self.pending_select = None
         if f.grouped and use_recovery and mf_recovery:
             # task policy and recovery policy on the same observations: one forward launch, one head launch
             forward_multi([self.pol.forward_desc(obs, save=False), self.rec.forward_desc(obs, save=False)])
