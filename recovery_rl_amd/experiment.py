@@ -79,7 +79,7 @@ class VectorLoop:
         # the fused step also writes env.next_obs / reward / done / constraint / success / ep_done (off: nobody reads them
         # in the steady-state graph; the episode log and the online ensemble re-fit switch them on by themselves)
         self.step_outputs = False
-        self.ride_actor = True            # the acting pass's large forwards share launches with the updates' small ones
+XX
         if self.n > 1 and hasattr(recovery_memory, "clamp_stratified"):
             # N envs overwrite the ring in capacity / N iterations: once the policy avoids violations the positive
             # class can drop below int(B * pos_fraction) rows, where the one-env reference would abort
