@@ -515,6 +515,13 @@ typedef struct {
     const float *dh2, *h1, *W2;
     float *dW2, *db2, *dh1;       /* dh1 nullable when `first` consumes it */
     rrl_first_layer_t first;
+    /* fuse_head != 0 (one-output heads with a loss description: RRL_LOSS_SAC_CRITIC .. RRL_LOSS_QRISK_POLICY; full aligned
+     * tiles): this member's head backward runs INSIDE the hidden-layer launch -- `head` is what rrl_mlp_head_backward_multi
+     * would have been given (its dh2 is ignored), dW3 / db3 / loss scalars are produced by extra workgroups of the launch,
+     * and the H x H tiles generate dh2 = [h2 > 0] * dOut * W3 on the fly instead of reading it (`dh2` above may be NULL).
+     * Same values, one launch and one round trip through memory less per stack backward. */
+    rrl_head_bwd_t head;
+    int fuse_head;
 } rrl_hidden_bwd_t;
 typedef struct {
     int G, B, H, din, ldx;

@@ -170,7 +170,9 @@ class rrl_first_layer_t(C.Structure):
 
 class rrl_hidden_bwd_t(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("G", "B", "H")] + [
-        (n, C.c_void_p) for n in ("dh2", "h1", "W2", "dW2", "db2", "dh1")] + [("first", rrl_first_layer_t)]
+        (n, C.c_void_p) for n in ("dh2", "h1", "W2", "dW2", "db2", "dh1")] + [("first", rrl_first_layer_t),
+                                                                                ("head", rrl_head_bwd_t),
+                                                                                ("fuse_head", C.c_int)]
 
 
 class rrl_input_bwd_t(C.Structure):

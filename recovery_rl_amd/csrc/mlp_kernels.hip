@@ -59,6 +59,12 @@ struct GemmArgs {
     long long first_stride;
     int ldx, din, G;
     int skip_c;           // do not write the C tile itself (dh1): nothing reads it once the first layer is done here
+    // GEN tiles (hidden_head_group_kernel): the left operand dh2 is not read but generated from what it is made of,
+    //   dh2[b][j] = [h2[b][j] > 0] * dOut[b] * W3[j]        (one-output heads: the critic-type losses)
+    // with dOut[b] in LDS (evaluated per workgroup from the loss description) -- the head-backward launch that used to write
+    // dh2 (and its round trip through memory) is gone; same products, same bits.
+    const float* gen_h2;  // [G, B, H], the layout of dh2
+    const float* gen_w3;  // [G, H]
 };
 
 struct Frag {
@@ -119,11 +125,19 @@ __device__ __forceinline__ float elem(const float4& q, int t) {
     return t == 0 ? q.x : (t == 1 ? q.y : (t == 2 ? q.z : q.w));
 }
 
-template <int MODE, bool FAST>  // MODE: 0 NT, 1 NN, 2 TN
-__device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g) {
+template <int MODE, bool FAST, bool GEN = false>  // MODE: 0 NT, 1 NN, 2 TN
+__device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g,
+                                            const float* dsh = nullptr) {
+    static_assert(!GEN || (FAST && MODE != 0), "generated operands: full aligned NN / TN tiles");
     const int lane = threadIdx.x;
     const int m0 = by * kTile, n0 = bx * kTile;
-    const float* A = a.A + g * a.sA;
+    const float* A = GEN ? a.gen_h2 + g * a.sA : a.A + g * a.sA;
+    // GEN: W3 of this head; TN tiles use 4 fixed columns of it, NN tiles the k positions of every panel
+    const float* W3 = GEN ? a.gen_w3 + (long long)g * (MODE == 2 ? a.M : a.K) : nullptr;
+    float4 w3c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float drow = 0.f;
+    if constexpr (GEN && MODE == 2) w3c = *reinterpret_cast<const float4*>(W3 + m0 + (lane & 3) * 4);
+    Frag fw;
     const float* B = a.B + g * a.sB;
     float* C = a.C + g * a.sC;
     constexpr bool kStageA = MODE == 2, kStageB = MODE != 0;
@@ -137,13 +151,30 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
         else load_direct<FAST>(fa, A, a.lda, m0, a.M, k0, a.K, lane);
         if (kStageB) load_staged<FAST>(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
         else load_direct<FAST>(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
+        if constexpr (GEN && MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < kVec; ++j) fw.v[j] = *reinterpret_cast<const float4*>(W3 + k0 + 16 * j + 4 * (lane >> 4));
+        }
     };
+    auto gen4 = [](float4 h, float d, float4 w) {       // the head backward's  a > 0 ? fmaf(dOut, W3, 0) : 0
+        return make_float4(h.x > 0.f ? d * w.x : 0.f, h.y > 0.f ? d * w.y : 0.f, h.z > 0.f ? d * w.z : 0.f,
+                           h.w > 0.f ? d * w.w : 0.f);
+    };
+    if constexpr (GEN && MODE == 1) drow = dsh[m0 + (lane & 15)];
 
     const int np = (a.K + kPanel - 1) / kPanel;
     const int i = lane & 15, q = lane >> 4;
     load(0);
     for (int p = 0; p < np; ++p) {
         Frag ca = fa, cb = fb;           // operands of this panel (registers)
+        if constexpr (GEN && MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < kVec; ++j) ca.v[j] = gen4(fa.v[j], drow, fw.v[j]);
+        }
+        if constexpr (GEN && MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < kVec; ++j) fa.v[j] = gen4(fa.v[j], dsh[p * kPanel + (lane >> 2) + 16 * j], w3c);
+        }
         if (kStageA || kStageB) {
             if (p) __syncthreads();      // the previous panel's LDS reads are done
             if (kStageA) store_staged(fa, As, lane);
@@ -954,7 +985,7 @@ __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx
     const float* __restrict__ W3 = hb.W3 + (long long)g * dout * H;
     float* __restrict__ dW3 = hb.dW3;
     float* __restrict__ db3 = hb.db3;
-    float* __restrict__ dh2 = hb.dh2 + (long long)g * B * H;
+    float* __restrict__ dh2 = hb.dh2 ? hb.dh2 + (long long)g * B * H : nullptr;     // null: the hidden-layer tiles generate it
     const int hc = threadIdx.x & (kCols - 1), slice = threadIdx.x / kCols;
     const int h = bx * kCols + hc;
     const bool hok = h < H;
@@ -1019,7 +1050,7 @@ __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx
                         acc[o] = fmaf(go, a[it], acc[o]);
                     }
                 }
-                dh2[(long long)b * H + h] = a[it] > 0.f ? d : 0.f;
+                if (hb.dh2) dh2[(long long)b * H + h] = a[it] > 0.f ? d : 0.f;
             }
         } else {
 #pragma unroll
@@ -1033,7 +1064,7 @@ __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx
                         d = fmaf(go, w[o], d);
                         acc[o] = fmaf(go, a[it], acc[o]);
                     }
-                    if (hok) dh2[(long long)b * H + h] = a[it] > 0.f ? d : 0.f;
+                    if (hok && hb.dh2) dh2[(long long)b * H + h] = a[it] > 0.f ? d : 0.f;
                 }
             }
         }
@@ -1165,6 +1196,92 @@ __global__ __launch_bounds__(256) void head_bwd_pack_kernel(const HeadBwdGroup* 
     int s, local;
     if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
     head_bwd_group_body(groups[s], local, red, dsh);
+}
+
+// ---- head backward INSIDE the hidden-layer launch (one-output heads: the four critic-type losses) -------------------
+// A stack backward was head launch (dW3, db3, loss scalars, dh2 -> memory) -> hidden launch (reads dh2).  Here one launch
+// does both for every fused member: its first blocks run the head body WITHOUT the dh2 store, the 16 x 16 tiles of the two
+// H x H products generate their dh2 operand from (h2, W3, dOut) -- dOut[b] evaluated per workgroup from the loss description
+// into LDS (B values: a few loads per row, all in flight together).  256-thread workgroups: a tile workgroup runs on its
+// first wave, the other three leave at once (the tile code is written for one wave per 16 x 16 tile).
+struct FusedHiddenGroup {
+    HiddenGroup hg;
+    HeadBwdArgs head[kMaxGroup];
+    int fused[kMaxGroup];
+    int head_blocks[kMaxGroup];          // blocks_x * G of the head body (0: member not fused)
+    int blocks_x[kMaxGroup];
+    int first[kMaxGroup + 1];            // block ranges incl. the head blocks
+};
+
+__device__ __forceinline__ float dout_row(const rrl_loss_t& la, int B, int g, int b) {
+    float term;
+    switch (la.kind) {
+        case RRL_LOSS_SAC_CRITIC: return loss::dout_at<RRL_LOSS_SAC_CRITIC>(la, B, g, b, 0, term);
+        case RRL_LOSS_SAC_POLICY: return loss::dout_at<RRL_LOSS_SAC_POLICY>(la, B, g, b, 0, term);
+        case RRL_LOSS_QRISK_CRITIC: return loss::dout_at<RRL_LOSS_QRISK_CRITIC>(la, B, g, b, 0, term);
+        default: return loss::dout_at<RRL_LOSS_QRISK_POLICY>(la, B, g, b, 0, term);
+    }
+}
+
+__device__ __forceinline__ void fused_hidden_body(const FusedHiddenGroup& fg, int block, float* As, float* Bs,
+                                                  float (*red)[4][kCols], float* dsh) {
+    int k = 0;
+    while (k + 1 < fg.hg.n && block >= fg.first[k + 1]) ++k;
+    int local = block - fg.first[k];
+    if (local < fg.head_blocks[k]) {                   // head body: dW3, db3, loss scalars (no dh2 store)
+        const HeadBwdArgs hb = fg.head[k];
+        head_bwd_dispatch(hb, local % fg.blocks_x[k], local / fg.blocks_x[k], red, dsh);
+        return;
+    }
+    if (threadIdx.x >= 64) return;                     // tiles: one wave
+    local -= fg.head_blocks[k];
+    const HiddenGroup& hg = fg.hg;
+    const int g = local / hg.per_head[k], b = local - g * hg.per_head[k];
+    const bool tn = b < hg.tn_tiles[k];
+    const int c = tn ? b : b - hg.tn_tiles[k];
+    const int tx = tn ? hg.tn_tiles_x[k] : hg.nn_tiles_x[k];
+    const GemmArgs ga = tn ? hg.tn[k] : hg.nn[k];
+    if (!fg.fused[k]) {
+        if (tn) {
+            if (hg.fast[k]) gemm16_tile<2, true>(ga, As, Bs, c % tx, c / tx, g);
+            else gemm16_tile<2, false>(ga, As, Bs, c % tx, c / tx, g);
+        } else {
+            if (hg.fast[k]) gemm16_tile<1, true>(ga, As, Bs, c % tx, c / tx, g);
+            else gemm16_tile<1, false>(ga, As, Bs, c % tx, c / tx, g);
+        }
+        return;
+    }
+    // dOut of the rows this tile contracts over (TN: all B rows; NN: its own 16)
+    const rrl_loss_t la = fg.head[k].la;
+    const int B = fg.head[k].B;
+    if (tn) {
+        for (int r = threadIdx.x; r < B; r += 64) dsh[r] = dout_row(la, B, g, r);
+    } else {
+        const int m0 = (c / tx) * kTile;
+        if (threadIdx.x < kTile) dsh[m0 + threadIdx.x] = dout_row(la, B, g, m0 + threadIdx.x);
+    }
+    __syncthreads();
+    if (tn) gemm16_tile<2, true, true>(ga, As, Bs, c % tx, c / tx, g, dsh);
+    else gemm16_tile<1, true, true>(ga, As, Bs, c % tx, c / tx, g, dsh);
+}
+
+__global__ __launch_bounds__(256) void hidden_head_group_kernel(FusedHiddenGroup fg) {
+    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
+    __shared__ float red[kSlices][4][kCols];
+    __shared__ float dsh[1024 * 4];
+    fused_hidden_body(fg, blockIdx.x, As, Bs, red, dsh);
+}
+
+__global__ __launch_bounds__(256) void hidden_head_pack_kernel(const FusedHiddenGroup* __restrict__ groups,
+                                                               rrl_pack::Idx ix) {
+    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
+    __shared__ float red[kSlices][4][kCols];
+    __shared__ float dsh[1024 * 4];
+    int s, local;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
+    fused_hidden_body(groups[s], local, As, Bs, red, dsh);
 }
 
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
@@ -1371,7 +1488,7 @@ static int build_hidden_group(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg
     hg.first[0] = 0;
     for (int k = 0; k < n; ++k) {
         const rrl_hidden_bwd_t& p = ps[k];
-        if (!p.dh2 || !p.h1 || !p.W2 || ((p.dW2 == nullptr) != (p.db2 == nullptr))) return RRL_EINVAL;
+        if ((!p.dh2 && !p.fuse_head) || !p.h1 || !p.W2 || ((p.dW2 == nullptr) != (p.db2 == nullptr))) return RRL_EINVAL;
         if (p.G <= 0 || p.G > 65535 || p.B <= 0 || p.H <= 0) return RRL_ERANGE;
         const bool first = p.first.x != nullptr;
         if (first && (!p.first.W1 || p.first.din <= 0 || p.first.din > 4 || (!p.first.first_part && !p.first.dx_part)))
@@ -1390,7 +1507,56 @@ static int build_hidden_group(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg
     return RRL_OK;
 }
 
+static int head_loss_args(const rrl_loss_t* la, int G, int B, int H, int dout, const float* h2, const float* W3,
+                          float* dW3, float* db3, float* dh2, HeadBwdArgs& hb);
+
+static int build_fused_hidden_group(int n, const rrl_hidden_bwd_t* ps, FusedHiddenGroup& fg) {
+    const int rc = build_hidden_group(n, ps, fg.hg);
+    if (rc != RRL_OK) return rc;
+    fg.first[0] = 0;
+    for (int k = 0; k < n; ++k) {
+        const rrl_hidden_bwd_t& p = ps[k];
+        fg.fused[k] = p.fuse_head != 0;
+        fg.head_blocks[k] = 0;
+        fg.blocks_x[k] = 1;
+        fg.head[k] = HeadBwdArgs{};
+        if (p.fuse_head) {
+            const rrl_head_bwd_t& h = p.head;
+            if (h.loss.kind < RRL_LOSS_SAC_CRITIC || h.loss.kind > RRL_LOSS_QRISK_POLICY || h.dout != 1 || h.G != p.G ||
+                h.B != p.B || h.H != p.H || !fg.hg.fast[k] || p.B % kPanel || p.H % kPanel)
+                return RRL_EINVAL;
+            const int r2 = head_loss_args(&h.loss, h.G, h.B, h.H, h.dout, h.h2, h.W3, h.dW3, h.db3, nullptr, fg.head[k]);
+            if (r2 != RRL_OK) return r2;
+            fg.blocks_x[k] = (p.H + kCols - 1) / kCols;
+            fg.head_blocks[k] = fg.blocks_x[k] * p.G;
+            fg.hg.tn[k].gen_h2 = fg.hg.nn[k].gen_h2 = h.h2;
+            fg.hg.tn[k].gen_w3 = fg.hg.nn[k].gen_w3 = h.W3;
+        }
+        fg.first[k + 1] = fg.first[k] + fg.head_blocks[k] + fg.hg.per_head[k] * p.G;
+    }
+    for (int k = n; k < kMaxGroup; ++k) {
+        fg.first[k + 1] = fg.first[n];
+        fg.fused[k] = fg.head_blocks[k] = 0;
+        fg.blocks_x[k] = 1;
+        fg.head[k] = HeadBwdArgs{};
+    }
+    return RRL_OK;
+}
+
+static bool any_fused(int n, const rrl_hidden_bwd_t* ps) {
+    for (int k = 0; ps && k < n && k < kMaxGroup; ++k)
+        if (ps[k].fuse_head) return true;
+    return false;
+}
+
 int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* stream) {
+    if (any_fused(n, ps)) {
+        FusedHiddenGroup fg;
+        const int rc = build_fused_hidden_group(n, ps, fg);
+        if (rc != RRL_OK) return rc;
+        hipLaunchKernelGGL(hidden_head_group_kernel, dim3(fg.first[n]), dim3(256), 0, (hipStream_t)stream, fg);
+        return check_launch();
+    }
     HiddenGroup hg;
     const int rc = build_hidden_group(n, ps, hg);
     if (rc != RRL_OK) return rc;
@@ -1404,16 +1570,30 @@ int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_b
     hipStream_t st = (hipStream_t)stream;
     rrl_pack::Plan* plan = rrl_pack::lookup(key);
     if (!plan) {
-        std::vector<HiddenGroup> groups;
+        bool fused = false;
+        for (int s = 0; s < S; ++s) fused = fused || any_fused(n[s], members[s]);
         rrl_pack::Idx ix;
-        const int rc = build_pack<HiddenGroup>(S, n, members, groups, ix, build_hidden_group);
-        if (rc != RRL_OK) return rc;
-        plan = rrl_pack::store(key, groups.data(), sizeof(HiddenGroup) * S, st);
+        if (fused) {
+            std::vector<FusedHiddenGroup> groups;
+            const int rc = build_pack<FusedHiddenGroup>(S, n, members, groups, ix, build_fused_hidden_group);
+            if (rc != RRL_OK) return rc;
+            plan = rrl_pack::store(key, groups.data(), sizeof(FusedHiddenGroup) * S, st);
+        } else {
+            std::vector<HiddenGroup> groups;
+            const int rc = build_pack<HiddenGroup>(S, n, members, groups, ix, build_hidden_group);
+            if (rc != RRL_OK) return rc;
+            plan = rrl_pack::store(key, groups.data(), sizeof(HiddenGroup) * S, st);
+        }
         if (!plan) return RRL_ELAUNCH;
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
+        plan->i0 = fused;
     }
-    hipLaunchKernelGGL(gemm16_pack_kernel, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
+    if (plan->i0)
+        hipLaunchKernelGGL(hidden_head_pack_kernel, dim3(plan->grid), dim3(256), 0, st, (const FusedHiddenGroup*)plan->dev,
+                           plan->ix);
+    else
+        hipLaunchKernelGGL(gemm16_pack_kernel, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
     return check_launch();
 }
 
@@ -1626,7 +1806,7 @@ int rrl_mlp_head_backward(int G, int B, int H, int dout, const float* dOut, cons
 
 static int head_loss_args(const rrl_loss_t* la, int G, int B, int H, int dout, const float* h2, const float* W3,
                           float* dW3, float* db3, float* dh2, HeadBwdArgs& hb) {
-    if (!la || !la->out || !h2 || !W3 || !dh2) return RRL_EINVAL;
+    if (!la || !la->out || !h2 || !W3) return RRL_EINVAL;          // dh2 == NULL: the hidden-layer tiles generate it
     if (G <= 0 || B <= 0 || B > 1024 || H <= 0 || dout <= 0 || dout > 4) return RRL_ERANGE;
     if (la->kind != kPlainDOut) {
         if (la->kind < 0 || la->kind > RRL_LOSS_STOCH_HEAD || la->n_part <= 0 || la->n_part > 4) return RRL_ERANGE;

@@ -184,6 +184,7 @@ class Stack:
         self.scratch = z(max(self.nsplit, 1), G, B, net.dout)
         self.finalize = False                       # True: always hand back the summed output tensor
         self.pair_hidden = True                     # dW2 and dh1 of the backward in one launch
+        self.fuse_head = True                       # critic-type head backward inside the hidden-layer launch
         self._init_first(dev, G, B, H, net.din)
 
     def _init_first(self, dev, G, B, H, din):
@@ -265,6 +266,12 @@ class Stack:
             first = _lib.rrl_first_layer_t(p(self.x), p(P["W1"]), self.x.stride(0), net.din,
                                            p(self.first_part) if wg else None, self.first_part.stride(0),
                                            p(self.dx_part) if input_grad else None)
+            # one-output heads with a loss description (the critic-type losses): the head backward runs inside the
+            # hidden-layer launch, whose tiles generate dh2 instead of reading it (rrl_hidden_bwd_t.fuse_head)
+            if self.fuse_head and net.dout == 1 and 0 <= loss.kind <= _lib.LOSS_QRISK_POLICY and B % 128 == 0:
+                hidden = _lib.rrl_hidden_bwd_t(G, B, H, None, p(self.h1), p(P["W2"]), p(Gr["W2"]) if wg else None,
+                                               p(Gr["b2"]) if wg else None, None, first, head, 1)
+                return None, hidden, None
             hidden = _lib.rrl_hidden_bwd_t(G, B, H, p(self.dh2), p(self.h1), p(P["W2"]), p(Gr["W2"]) if wg else None,
                                            p(Gr["b2"]) if wg else None, None, first)
             return head, hidden, None
@@ -327,15 +334,18 @@ def forward_multi(descs):
 def backward_multi(triples):
     """Independent stack backwards, stage by stage: three launches for all of them (head, hidden, input)."""
     lib, st, n = _lib.load(), _lib.current_stream(), len(triples)
-    heads = (_lib.rrl_head_bwd_t * n)(*[t[0] for t in triples])
+    head_list = [t[0] for t in triples if t[0] is not None]     # members whose head backward is not fused into `hidden`
+    heads = (_lib.rrl_head_bwd_t * len(head_list))(*head_list) if head_list else None
     hidden = (_lib.rrl_hidden_bwd_t * n)(*[t[1] for t in triples])
     rest = [t[2] for t in triples if t[2] is not None]          # stacks whose first layer is not fused into `hidden`
     inputs = (_lib.rrl_input_bwd_t * len(rest))(*rest) if rest else None
-    record("head_bwd", heads, n)
+    if heads is not None:
+        record("head_bwd", heads, len(head_list))
     record("hidden_bwd", hidden, n)
     if inputs is not None:
         record("unsupported", "rrl_mlp_input_backward_multi")
-    _lib.check(lib.rrl_mlp_head_backward_multi(n, heads, st), "rrl_mlp_head_backward_multi")
+    if heads is not None:
+        _lib.check(lib.rrl_mlp_head_backward_multi(len(head_list), heads, st), "rrl_mlp_head_backward_multi")
     _lib.check(lib.rrl_mlp_hidden_backward_multi(n, hidden, st), "rrl_mlp_hidden_backward_multi")
     if inputs is not None:
         _lib.check(lib.rrl_mlp_input_backward_multi(len(inputs), inputs, st), "rrl_mlp_input_backward_multi")
@@ -362,6 +372,7 @@ class StackRows(Stack):
         self.h1, self.h2 = parent.h1[:, lo:hi], parent.h2[:, lo:hi]
         self.dh1, self.dh2, self.dx = z(1, self.B, H), z(1, self.B, H), z(1, self.B, parent.net.din)
         self.pair_hidden = True
+        self.fuse_head = True
         self._init_first(dev, 1, self.B, H, parent.net.din)
 
     def forward(self, *a, **k):
@@ -440,6 +451,11 @@ class FastUpdater:
         are all-reduced, and by the stand-alone loss-gradient kernels of fuse_loss = False)."""
         for st in self.stacks():
             st.fuse_first = bool(on) and st.first_part is not None
+
+    def set_fuse_head(self, on):
+        """Critic-type head backward inside the hidden-layer launch (tiles generate dh2) or as its own launch (writes dh2)."""
+        for st in self.stacks():
+            st.fuse_head = bool(on)
 
     def gather_first_grads(self):
         """Write the summed (dW1, db1) partials of the last backward into the flat gradient buffers (inspection and
