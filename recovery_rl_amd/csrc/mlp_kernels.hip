@@ -125,11 +125,32 @@ __device__ __forceinline__ float elem(const float4& q, int t) {
     return t == 0 ? q.x : (t == 1 ? q.y : (t == 2 ? q.z : q.w));
 }
 
-template <int MODE, bool FAST, bool GEN = false>  // MODE: 0 NT, 1 NN, 2 TN
+struct NoPrologue {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// GEN: `prologue` fills dsh (LDS) and runs AFTER the first panel's loads have been issued, so its memory round trip and
+// theirs overlap
+// One wave per tile: with WL the tile's LDS region belongs to its wave alone (several tiles per workgroup, hidden_head_*
+// kernels), so "barrier" = this wave's LDS operations have completed; otherwise the workgroup is the wave (64 threads) and
+// __syncthreads is the same thing
+template <bool WL>
+__device__ __forceinline__ void tile_sync() {
+    if constexpr (WL) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+// GEN tiles keep dOut[r], r < 512, in the pad columns 16..19 of the As tile (rows of kLd = 20 floats, 16 used)
+__device__ __forceinline__ int dsh_index(int r) { return (r >> 2) * kLd + (r & 3); }
+
+template <int MODE, bool FAST, bool GEN = false, class Prologue = NoPrologue, bool WL = false>  // MODE: 0 NT, 1 NN, 2 TN
 __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g,
-                                            const float* dsh = nullptr) {
+                                            const float* dsh = nullptr, Prologue prologue = Prologue()) {
     static_assert(!GEN || (FAST && MODE != 0), "generated operands: full aligned NN / TN tiles");
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int m0 = by * kTile, n0 = bx * kTile;
     const float* A = GEN ? a.gen_h2 + g * a.sA : a.A + g * a.sA;
     // GEN: W3 of this head; TN tiles use 4 fixed columns of it, NN tiles the k positions of every panel
@@ -160,11 +181,16 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
         return make_float4(h.x > 0.f ? d * w.x : 0.f, h.y > 0.f ? d * w.y : 0.f, h.z > 0.f ? d * w.z : 0.f,
                            h.w > 0.f ? d * w.w : 0.f);
     };
-    if constexpr (GEN && MODE == 1) drow = dsh[m0 + (lane & 15)];
+
 
     const int np = (a.K + kPanel - 1) / kPanel;
     const int i = lane & 15, q = lane >> 4;
     load(0);
+    if constexpr (GEN) {
+        prologue();
+        tile_sync<WL>();
+        if constexpr (MODE == 1) drow = dsh[dsh_index(m0 + (lane & 15))];
+    }
     for (int p = 0; p < np; ++p) {
         Frag ca = fa, cb = fb;           // operands of this panel (registers)
         if constexpr (GEN && MODE == 1) {
@@ -173,13 +199,13 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
         }
         if constexpr (GEN && MODE == 2) {
 #pragma unroll
-            for (int j = 0; j < kVec; ++j) fa.v[j] = gen4(fa.v[j], dsh[p * kPanel + (lane >> 2) + 16 * j], w3c);
+            for (int j = 0; j < kVec; ++j) fa.v[j] = gen4(fa.v[j], dsh[dsh_index(p * kPanel + (lane >> 2) + 16 * j)], w3c);
         }
         if (kStageA || kStageB) {
-            if (p) __syncthreads();      // the previous panel's LDS reads are done
+            if (p) tile_sync<WL>();      // the previous panel's LDS reads are done
             if (kStageA) store_staged(fa, As, lane);
             if (kStageB) store_staged(fb, Bs, lane);
-            __syncthreads();
+            tile_sync<WL>();
         }
         if (p + 1 < np) load((p + 1) * kPanel);   // next panel's global loads fly under the MFMAs
         const int klen = min(kPanel, a.K - p * kPanel);
@@ -231,12 +257,12 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
             const int rr = lane & 15, dd = lane >> 4;
             const float xv = dd < a.din ? a.x[(long long)(m0 + rr) * a.ldx + dd] : 0.f;
             const float wv = dd < a.din ? a.W1[((long long)g * a.N + n0 + rr) * a.din + dd] : 0.f;
-            __syncthreads();
+            tile_sync<WL>();
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = vout[r];
             T[272 + rr * 4 + dd] = xv;
             T[336 + rr * 4 + dd] = wv;
-            __syncthreads();
+            tile_sync<WL>();
             float sw = 0.f, sb = 0.f, sx = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -1210,78 +1236,92 @@ struct FusedHiddenGroup {
     int fused[kMaxGroup];
     int head_blocks[kMaxGroup];          // blocks_x * G of the head body (0: member not fused)
     int blocks_x[kMaxGroup];
+    int G[kMaxGroup];
     int first[kMaxGroup + 1];            // block ranges incl. the head blocks
 };
 
-__device__ __forceinline__ float dout_row(const rrl_loss_t& la, int B, int g, int b) {
+// dOut[b] of the rows a tile contracts over, into LDS: TN tiles need all B <= 256 rows (four per lane, every row's loads
+// issued before the first formula is evaluated: ONE memory round trip), NN tiles their own 16
+template <int KIND>
+__device__ __forceinline__ void fill_dout(const rrl_loss_t& la, int B, int g, float* dsh, bool tn, int m0) {
     float term;
-    switch (la.kind) {
-        case RRL_LOSS_SAC_CRITIC: return loss::dout_at<RRL_LOSS_SAC_CRITIC>(la, B, g, b, 0, term);
-        case RRL_LOSS_SAC_POLICY: return loss::dout_at<RRL_LOSS_SAC_POLICY>(la, B, g, b, 0, term);
-        case RRL_LOSS_QRISK_CRITIC: return loss::dout_at<RRL_LOSS_QRISK_CRITIC>(la, B, g, b, 0, term);
-        default: return loss::dout_at<RRL_LOSS_QRISK_POLICY>(la, B, g, b, 0, term);
+    const int lane = threadIdx.x & 63;
+    if (tn) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lane + 64 * i;
+            v[i] = loss::dout_at<KIND>(la, B, g, r < B ? r : B - 1, 0, term);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < B) dsh[dsh_index(lane + 64 * i)] = v[i];
+    } else if (lane < kTile) {
+        dsh[dsh_index(m0 + lane)] = loss::dout_at<KIND>(la, B, g, m0 + lane, 0, term);
     }
 }
 
-__device__ __forceinline__ void fused_hidden_body(const FusedHiddenGroup& fg, int block, float* As, float* Bs,
-                                                  float (*red)[4][kCols], float* dsh) {
+__device__ __forceinline__ void fused_hidden_body(const FusedHiddenGroup& fg, int block, float* lds) {
     int k = 0;
     while (k + 1 < fg.hg.n && block >= fg.first[k + 1]) ++k;
     int local = block - fg.first[k];
     if (local < fg.head_blocks[k]) {                   // head body: dW3, db3, loss scalars (no dh2 store)
         const HeadBwdArgs hb = fg.head[k];
-        head_bwd_dispatch(hb, local % fg.blocks_x[k], local / fg.blocks_x[k], red, dsh);
+        head_bwd_dispatch(hb, local % fg.blocks_x[k], local / fg.blocks_x[k],
+                          reinterpret_cast<float(*)[4][kCols]>(lds), lds + kSlices * 4 * kCols);
         return;
     }
-    if (threadIdx.x >= 64) return;                     // tiles: one wave
-    local -= fg.head_blocks[k];
+    // tiles: FOUR per workgroup, one per wave, each wave on its own As | Bs region and never waiting for another
+    const int wave = threadIdx.x >> 6;
+    float* As = lds + wave * (2 * kPanel * kLd);
+    float* Bs = As + kPanel * kLd;
+    float* dsh = As + 16;                              // pad columns of the As tile (dsh_index)
     const HiddenGroup& hg = fg.hg;
-    const int g = local / hg.per_head[k], b = local - g * hg.per_head[k];
+    const int tile = (local - fg.head_blocks[k]) * 4 + wave;
+    if (tile >= hg.per_head[k] * fg.G[k]) return;
+    const int g = tile / hg.per_head[k], b = tile - g * hg.per_head[k];
     const bool tn = b < hg.tn_tiles[k];
     const int c = tn ? b : b - hg.tn_tiles[k];
     const int tx = tn ? hg.tn_tiles_x[k] : hg.nn_tiles_x[k];
     const GemmArgs ga = tn ? hg.tn[k] : hg.nn[k];
-    if (!fg.fused[k]) {
-        if (tn) {
-            if (hg.fast[k]) gemm16_tile<2, true>(ga, As, Bs, c % tx, c / tx, g);
-            else gemm16_tile<2, false>(ga, As, Bs, c % tx, c / tx, g);
-        } else {
-            if (hg.fast[k]) gemm16_tile<1, true>(ga, As, Bs, c % tx, c / tx, g);
-            else gemm16_tile<1, false>(ga, As, Bs, c % tx, c / tx, g);
-        }
+    if (!fg.fused[k]) {                                // (members of a fused launch have full aligned tiles)
+        if (tn) gemm16_tile<2, true, false, NoPrologue, true>(ga, As, Bs, c % tx, c / tx, g);
+        else gemm16_tile<1, true, false, NoPrologue, true>(ga, As, Bs, c % tx, c / tx, g);
         return;
     }
     // dOut of the rows this tile contracts over (TN: all B rows; NN: its own 16)
     const rrl_loss_t la = fg.head[k].la;
     const int B = fg.head[k].B;
-    if (tn) {
-        for (int r = threadIdx.x; r < B; r += 64) dsh[r] = dout_row(la, B, g, r);
-    } else {
-        const int m0 = (c / tx) * kTile;
-        if (threadIdx.x < kTile) dsh[m0 + threadIdx.x] = dout_row(la, B, g, m0 + threadIdx.x);
-    }
-    __syncthreads();
-    if (tn) gemm16_tile<2, true, true>(ga, As, Bs, c % tx, c / tx, g, dsh);
-    else gemm16_tile<1, true, true>(ga, As, Bs, c % tx, c / tx, g, dsh);
+    const int m0 = (c / tx) * kTile;
+    auto prologue = [&]() {
+        switch (la.kind) {
+            case RRL_LOSS_SAC_CRITIC: fill_dout<RRL_LOSS_SAC_CRITIC>(la, B, g, dsh, tn, m0); break;
+            case RRL_LOSS_SAC_POLICY: fill_dout<RRL_LOSS_SAC_POLICY>(la, B, g, dsh, tn, m0); break;
+            case RRL_LOSS_QRISK_CRITIC: fill_dout<RRL_LOSS_QRISK_CRITIC>(la, B, g, dsh, tn, m0); break;
+            default: fill_dout<RRL_LOSS_QRISK_POLICY>(la, B, g, dsh, tn, m0); break;
+        }
+    };
+    if (tn) gemm16_tile<2, true, true, decltype(prologue), true>(ga, As, Bs, c % tx, c / tx, g, dsh, prologue);
+    else gemm16_tile<1, true, true, decltype(prologue), true>(ga, As, Bs, c % tx, c / tx, g, dsh, prologue);
 }
 
+// LDS: four tile regions (As | Bs) of 20 KB, one per wave = 80 KB: two workgroups = eight tiles per CU, what the 64-thread
+// tile kernel has too (a 256-thread workgroup whose tile ran on one wave held four wave slots at 196 VGPRs: two workgroups =
+// two tiles per CU, three rounds per launch).  A head workgroup lays its buffers over the first region.
+constexpr int kFusedLdsFloats = 4 * 2 * kPanel * kLd;
+static_assert(kSlices * 4 * kCols + 1024 * 4 <= 2 * kPanel * kLd, "head buffers fit a tile region");
+
 __global__ __launch_bounds__(256) void hidden_head_group_kernel(FusedHiddenGroup fg) {
-    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
-    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
-    __shared__ float red[kSlices][4][kCols];
-    __shared__ float dsh[1024 * 4];
-    fused_hidden_body(fg, blockIdx.x, As, Bs, red, dsh);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fused_hidden_body(fg, blockIdx.x, lds);
 }
 
 __global__ __launch_bounds__(256) void hidden_head_pack_kernel(const FusedHiddenGroup* __restrict__ groups,
                                                                rrl_pack::Idx ix) {
-    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
-    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
-    __shared__ float red[kSlices][4][kCols];
-    __shared__ float dsh[1024 * 4];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     int s, local;
     if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
-    fused_hidden_body(groups[s], local, As, Bs, red, dsh);
+    fused_hidden_body(groups[s], local, lds);
 }
 
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
@@ -1509,6 +1549,7 @@ static int build_hidden_group(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg
 
 static int head_loss_args(const rrl_loss_t* la, int G, int B, int H, int dout, const float* h2, const float* W3,
                           float* dW3, float* db3, float* dh2, HeadBwdArgs& hb);
+static bool grant_lds(const void* kernel, size_t bytes);
 
 static int build_fused_hidden_group(int n, const rrl_hidden_bwd_t* ps, FusedHiddenGroup& fg) {
     const int rc = build_hidden_group(n, ps, fg.hg);
@@ -1523,7 +1564,7 @@ static int build_fused_hidden_group(int n, const rrl_hidden_bwd_t* ps, FusedHidd
         if (p.fuse_head) {
             const rrl_head_bwd_t& h = p.head;
             if (h.loss.kind < RRL_LOSS_SAC_CRITIC || h.loss.kind > RRL_LOSS_QRISK_POLICY || h.dout != 1 || h.G != p.G ||
-                h.B != p.B || h.H != p.H || !fg.hg.fast[k] || p.B % kPanel || p.H % kPanel)
+                h.B != p.B || h.H != p.H || !fg.hg.fast[k] || p.B % kPanel || p.H % kPanel || p.B > 256)
                 return RRL_EINVAL;
             const int r2 = head_loss_args(&h.loss, h.G, h.B, h.H, h.dout, h.h2, h.W3, h.dW3, h.db3, nullptr, fg.head[k]);
             if (r2 != RRL_OK) return r2;
@@ -1532,10 +1573,13 @@ static int build_fused_hidden_group(int n, const rrl_hidden_bwd_t* ps, FusedHidd
             fg.hg.tn[k].gen_h2 = fg.hg.nn[k].gen_h2 = h.h2;
             fg.hg.tn[k].gen_w3 = fg.hg.nn[k].gen_w3 = h.W3;
         }
-        fg.first[k + 1] = fg.first[k] + fg.head_blocks[k] + fg.hg.per_head[k] * p.G;
+        if (!fg.hg.fast[k]) return RRL_EINVAL;               // every member of a fused launch: full aligned tiles
+        fg.G[k] = p.G;
+        fg.first[k + 1] = fg.first[k] + fg.head_blocks[k] + (fg.hg.per_head[k] * p.G + 3) / 4;
     }
     for (int k = n; k < kMaxGroup; ++k) {
         fg.first[k + 1] = fg.first[n];
+        fg.G[k] = 1;
         fg.fused[k] = fg.head_blocks[k] = 0;
         fg.blocks_x[k] = 1;
         fg.head[k] = HeadBwdArgs{};
@@ -1554,7 +1598,9 @@ int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* strea
         FusedHiddenGroup fg;
         const int rc = build_fused_hidden_group(n, ps, fg);
         if (rc != RRL_OK) return rc;
-        hipLaunchKernelGGL(hidden_head_group_kernel, dim3(fg.first[n]), dim3(256), 0, (hipStream_t)stream, fg);
+        static const bool ok = grant_lds((const void*)hidden_head_group_kernel, kFusedLdsFloats * 4);
+        if (!ok) return RRL_ERANGE;
+        hipLaunchKernelGGL(hidden_head_group_kernel, dim3(fg.first[n]), dim3(256), kFusedLdsFloats * 4, (hipStream_t)stream, fg);
         return check_launch();
     }
     HiddenGroup hg;
@@ -1577,6 +1623,8 @@ int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_b
             std::vector<FusedHiddenGroup> groups;
             const int rc = build_pack<FusedHiddenGroup>(S, n, members, groups, ix, build_fused_hidden_group);
             if (rc != RRL_OK) return rc;
+            static const bool ok = grant_lds((const void*)hidden_head_pack_kernel, kFusedLdsFloats * 4);
+            if (!ok) return RRL_ERANGE;
             plan = rrl_pack::store(key, groups.data(), sizeof(FusedHiddenGroup) * S, st);
         } else {
             std::vector<HiddenGroup> groups;
@@ -1590,7 +1638,7 @@ int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_b
         plan->i0 = fused;
     }
     if (plan->i0)
-        hipLaunchKernelGGL(hidden_head_pack_kernel, dim3(plan->grid), dim3(256), 0, st, (const FusedHiddenGroup*)plan->dev,
+        hipLaunchKernelGGL(hidden_head_pack_kernel, dim3(plan->grid), dim3(256), kFusedLdsFloats * 4, st, (const FusedHiddenGroup*)plan->dev,
                            plan->ix);
     else
         hipLaunchKernelGGL(gemm16_pack_kernel, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);

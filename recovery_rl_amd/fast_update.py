@@ -184,7 +184,12 @@ class Stack:
         self.scratch = z(max(self.nsplit, 1), G, B, net.dout)
         self.finalize = False                       # True: always hand back the summed output tensor
         self.pair_hidden = True                     # dW2 and dh1 of the backward in one launch
-        self.fuse_head = True                       # critic-type head backward inside the hidden-layer launch
+        # opt-in (set_fuse_head): critic-type head backward inside the hidden-layer launch, whose tiles generate dh2 from
+        # (h2, W3, dOut) instead of reading it -- 19 launches per iteration instead of 22, bit-identical results, but NOT
+        # faster: the fused launch takes 14-15 us, what the two launches it replaces take together (7.2 + 7.5 us), with the
+        # tiles on one wave of four, four wave-local tiles per workgroup, or the dOut prologue under the first loads alike
+        # (0.200-0.202 vs 0.194 ms per iteration; profiles/round3 notes).  Launch COUNT is not what bounds this chain.
+        self.fuse_head = False
         self._init_first(dev, G, B, H, net.din)
 
     def _init_first(self, dev, G, B, H, din):
@@ -268,7 +273,7 @@ class Stack:
                                            p(self.dx_part) if input_grad else None)
             # one-output heads with a loss description (the critic-type losses): the head backward runs inside the
             # hidden-layer launch, whose tiles generate dh2 instead of reading it (rrl_hidden_bwd_t.fuse_head)
-            if self.fuse_head and net.dout == 1 and 0 <= loss.kind <= _lib.LOSS_QRISK_POLICY and B % 128 == 0:
+            if self.fuse_head and net.dout == 1 and 0 <= loss.kind <= _lib.LOSS_QRISK_POLICY and B in (128, 256):
                 hidden = _lib.rrl_hidden_bwd_t(G, B, H, None, p(self.h1), p(P["W2"]), p(Gr["W2"]) if wg else None,
                                                p(Gr["b2"]) if wg else None, None, first, head, 1)
                 return None, hidden, None
@@ -372,7 +377,7 @@ class StackRows(Stack):
         self.h1, self.h2 = parent.h1[:, lo:hi], parent.h2[:, lo:hi]
         self.dh1, self.dh2, self.dx = z(1, self.B, H), z(1, self.B, H), z(1, self.B, parent.net.din)
         self.pair_hidden = True
-        self.fuse_head = True
+        self.fuse_head = False
         self._init_first(dev, 1, self.B, H, parent.net.din)
 
     def forward(self, *a, **k):
