@@ -678,7 +678,7 @@ def main():
         gbs = a.num_envs * STEP_PUSH_ALGO_BYTES / t_k / 1e9
         traffic, traffic_src = committed_pmc("step_push_pmc", a.num_envs) if a.env == "navigation1" else (None, None)
         extra["roofline"] = {
-            "kernel": "step_push_kernel<%s> (rrl_%s_step_push): env step + two replay pushes + episode counters, the "
+            "kernel": "step_push_kernel<%s> (rrl_%s_step_push_x): env step + two replay pushes + episode counters, the "
                       "env kernel of the timed iteration" % ("MazeEnv" if a.env == "maze" else "NavEnv<0>",
                                                              "maze" if a.env == "maze" else "nav"),
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -688,7 +688,7 @@ def main():
             "launch_us": t_k * 1e6, "algorithmic_bytes_per_env_step": STEP_PUSH_ALGO_BYTES,
             "layout": "compact env state (u16 status word, state from pos, no per-env output arrays): what the timed graph launches",
             "note": "N=%d moves only %d KB per launch: latency-bound by construction; bandwidth regime "
-                    "(N up to 2^24, `bench.py --sweep`): profiles/round2_roofline_sweep.json"
+                    "(N up to 2^24, `bench.py --sweep`): profiles/round3_roofline_sweep.json"
                     % (a.num_envs, a.num_envs * STEP_PUSH_ALGO_BYTES // 1024)}
         if a.sweep:
             sweep, sweep_sp, sweep_c = [], [], []
