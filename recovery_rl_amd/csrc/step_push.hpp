@@ -113,8 +113,8 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
     }
     const StepArgs& a = p.step;
     const uint64_t ctr = a.counter_dev ? a.counter + __atomic_load_n(a.counter_dev, __ATOMIC_RELAXED) : a.counter;
-    // the cursors are read with (relaxed) atomic loads and the ticket below is a RELEASE operation, so neither the
-    // compiler nor the memory system may let a workgroup's read of a cursor slip behind its ticket
+    // the cursors are read with (relaxed) atomic loads and the ticket below waits for them (s_waitcnt + compiler barrier), so
+    // neither the compiler nor the memory system may let a workgroup's read of a cursor slip behind its ticket
     const auto ld = [](const int64_t* q) { return (int64_t)__atomic_load_n((const long long*)q, __ATOMIC_RELAXED); };
     const int64_t mpos = ld(&p.memory.state[0]), msize = ld(&p.memory.state[1]);
     int64_t rpos = 0, rsize = 0;
@@ -128,8 +128,14 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
     unsigned long long ticket = ~0ULL;
     const auto draw_ticket = [&]() {
         if (threadIdx.x == 0)
-            ticket = __hip_atomic_fetch_add((unsigned long long*)&p.memory.state[2], 1ULL, __ATOMIC_RELEASE,
+        {
+            // the cursor loads have RETURNED before the ticket is issued (s_waitcnt; "memory": the compiler keeps the order
+            // too).  Not a release operation: at agent scope that is an L2 write-back per workgroup -- 50 -> 150 us for the
+            // 4096 workgroups of a 2^20-env launch -- and nothing written here has to be visible before the kernel ends.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ticket = __hip_atomic_fetch_add((unsigned long long*)&p.memory.state[2], 1ULL, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
     const auto advance_cursors = [&]() {
         if (threadIdx.x == 0 && ticket == n_blk - 1) {
