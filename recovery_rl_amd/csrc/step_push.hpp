@@ -112,13 +112,13 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
         __syncthreads();
     }
     const StepArgs& a = p.step;
-    const uint64_t ctr = a.counter_dev ? a.counter + __atomic_load_n(a.counter_dev, __ATOMIC_RELAXED) : a.counter;
-    // the cursors are read with (relaxed) atomic loads and the ticket below waits for them (s_waitcnt + compiler barrier), so
-    // neither the compiler nor the memory system may let a workgroup's read of a cursor slip behind its ticket
-    const auto ld = [](const int64_t* q) { return (int64_t)__atomic_load_n((const long long*)q, __ATOMIC_RELAXED); };
-    const int64_t mpos = ld(&p.memory.state[0]), msize = ld(&p.memory.state[1]);
+    const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
+    // plain (wave-uniform: scalar) loads of the cursors; the ticket below is issued only after they have RETURNED (s_waitcnt)
+    // and the compiler may not move them past it ("memory" clobber), so a workgroup's read of a cursor cannot slip behind its
+    // ticket.  (Atomic loads here are per-lane vector loads of ONE address: 4 M of them at 2^20 envs, 50 -> 120 us.)
+    const int64_t mpos = p.memory.state[0], msize = p.memory.state[1];
     int64_t rpos = 0, rsize = 0;
-    if (p.use_recovery_memory) { rpos = ld(&p.recovery_memory.state[0]); rsize = ld(&p.recovery_memory.state[1]); }
+    if (p.use_recovery_memory) { rpos = p.recovery_memory.state[0]; rsize = p.recovery_memory.state[1]; }
     // ONE ticket for the three device-side cursors (both replay rings and the RNG tick): a returning device-scope atomic
     // is a ~0.7 us round trip, three in a row were a sixth of this kernel.  The workgroup that draws the last ticket knows
     // that every workgroup has read the cursors, which is all their update has to wait for.  In the latency regime (a few
@@ -132,7 +132,7 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             // the cursor loads have RETURNED before the ticket is issued (s_waitcnt; "memory": the compiler keeps the order
             // too).  Not a release operation: at agent scope that is an L2 write-back per workgroup -- 50 -> 150 us for the
             // 4096 workgroups of a 2^20-env launch -- and nothing written here has to be visible before the kernel ends.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             ticket = __hip_atomic_fetch_add((unsigned long long*)&p.memory.state[2], 1ULL, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -396,13 +396,14 @@ __device__ __forceinline__ void adam_multi_body(const AdamSegs& a, int n_seg, fl
     uint64_t step = 0;
     unsigned long long ticket = ~0ULL;
     if (threadIdx.x == 0) {
-        // (relaxed) atomic load, then the ticket once it has returned: the read of the step count cannot slip behind it
-        step = __atomic_load_n(&sg.step_dev[0], __ATOMIC_RELAXED);
+        // plain load, then the ticket once it has returned ("memory" clobber: the compiler keeps the order): the read of the
+        // step count cannot slip behind the ticket
+        step = sg.step_dev[0];
         const double t = double(step + 1);
         // the ticket is taken as soon as this workgroup has READ the step count: the last of the segment's workgroups
         // to do so knows every other one has read it too and may store t + 1 -- the returning atomic's round trip
         // (~0.7 us) runs under the parameter loads: its value is looked at after them
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the step count has returned (no agent-scope release: that
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the step count has returned (no agent-scope release: that
         ticket = __hip_atomic_fetch_add((unsigned long long*)&sg.step_dev[1], 1ULL, __ATOMIC_RELAXED,   // is an L2 write-back)
                                         __HIP_MEMORY_SCOPE_AGENT);
         sh[0] = lr / float(1.0 - pow(double(b1), t));
