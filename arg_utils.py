@@ -91,6 +91,9 @@ ADDITIVE = [
     (("--seeds_per_gpu",), I, 1, "lock-step loop: run this many independent seeds (seed, seed + 1, ...: own envs, replay "
                                  "rings, networks, Philox keys -- the reference's seed loop, scripts/navigation1.sh:4-8) on "
                                  "ONE GPU, sharing every launch of the iteration (recovery_rl_amd/packed.py)"),
+    (("--info_envs",), I, 0, "lock-step loop: keep the reference's per-step info dicts (run_stats.pkl `train_stats`, "
+                             "experiment.py:421,540-543) for the first K envs, so that plotting/plot_runs.py reads the run "
+                             "unchanged (0 = per-episode table only)"),
     (("--no_pin_demos",), "store_true", None, "lock-step loop: let the safety buffer's ring overwrite the offline constraint "
                                               "demonstrations (default: they are pinned, as the one-env reference never "
                                               "wraps its 1e6-row ring within a run)"),

@@ -65,6 +65,56 @@ class EpisodeLog:
         return out
 
 
+class InfoRing:
+    """Per-STEP `info` stream of the reference (env/navigation1.py:82-89 + `recovery`, experiment.py:421,427) for the first K
+    envs of a lock-step run, so that `run_stats.pkl` carries `train_stats` in the reference's own schema -- a list of episodes,
+    each a list of step dicts -- and plotting/plot_runs.py:147-235 reads the run unchanged.  Opt-in (`--info_envs K`): two small
+    device copies per iteration next to the captured graph (state before the step, one packed row after it), drained at
+    logging cadence; episodes are emitted in completion order (iteration, then env)."""
+    FIELDS = 11      # state 2 | action 2 | next_state 2 | reward | constraint | success | ep_done | recovery
+
+    def __init__(self, k, steps, device, action_high):
+        self.k, self.steps, self.device = int(k), int(steps), device
+        self.rows = torch.zeros(self.steps, self.k, self.FIELDS, dtype=torch.float32, device=device)
+        self.state = torch.zeros(self.k, 2, dtype=torch.float32, device=device)
+        self.filled = 0
+        self.hi = float(action_high)
+        self.open = [[] for _ in range(self.k)]          # unfinished episodes per env (host side)
+
+    def before_step(self, obs):
+        self.state.copy_(obs[:self.k])
+
+    def after_step(self, env, real_action, recovery):
+        if self.filled >= self.steps:
+            raise _lib.RRLError("info ring overflow (drain more often)")
+        k, row = self.k, self.rows[self.filled]
+        row[:, 0:2] = self.state
+        row[:, 2:4] = real_action[:k].clamp(-self.hi, self.hi)          # info['action'] = the clipped executed action
+        row[:, 4:6] = env.next_obs[:k]
+        row[:, 6] = env.reward[:k]
+        row[:, 7] = env.constraint[:k]
+        row[:, 8] = env.success[:k]
+        row[:, 9] = env.ep_done[:k]
+        row[:, 10] = 0 if recovery is None else recovery[:k]
+        self.filled += 1
+
+    def drain(self):
+        """Finished episodes since the last drain, in the reference's schema."""
+        rows = self.rows[:self.filled].cpu().numpy()
+        self.filled = 0
+        done = []
+        for t in range(rows.shape[0]):
+            for e in range(self.k):
+                r = rows[t, e]
+                self.open[e].append({"constraint": int(r[7]), "reward": float(r[6]),
+                                     "state": r[0:2].astype(np.float64), "next_state": r[4:6].astype(np.float64),
+                                     "action": r[2:4].copy(), "success": bool(r[8]), "recovery": bool(r[10])})
+                if r[9]:
+                    done.append(self.open[e])
+                    self.open[e] = []
+        return done
+
+
 def records_from_train_stats(train_stats):
     """The same table from the reference's per-step schema (list of episodes of info dicts)."""
     out = np.zeros(len(train_stats), dtype=EPISODE_DTYPE)

@@ -320,7 +320,7 @@ class VectorLoop:
             self.do_updates(i_episode, online_qrisk, fused_act_follows=not random_actions)
         with trace_range("act"):
             action, real_action, recovery = self.act(self.obs, random_actions)
-        self._last_recovery = recovery
+        self._last_recovery, self._last_real_action = recovery, real_action
         with trace_range("env_step+push"):
             return self.step_and_store(action, real_action, recovery)
 
@@ -651,8 +651,11 @@ class Experiment:
             # different number of log boundaries per pass and issue mismatched metric all-reduces
             raise ValueError("--log_every must be >= 4 with more than one rank")
         from . import checkpoint
-        from .episode_log import EpisodeLog, EPISODE_DTYPE
+        from .episode_log import EpisodeLog, EPISODE_DTYPE, InfoRing
         loop.episode_log = EpisodeLog(n, n * (log_every + 4), self.device)   # a capture adds <= 3 iterations
+        info_k = min(int(getattr(cfg, "info_envs", 0) or 0), n)
+        info = InfoRing(info_k, log_every + 4, self.device, self.env.action_space.high[0]) if info_k else None
+        train_stats = []
         episodes = [np.zeros(0, dtype=EPISODE_DTYPE)]
         history = []
         evals = []
@@ -698,12 +701,24 @@ class Experiment:
                 gate = self.online_qrisk_enabled() if uses_constraint_buffer(cfg) else False
                 steady = have_batch and not random_actions and graph_ok
                 if steady and (loop.graph is None or captured_gate != gate):
-                    it += loop.capture(online_qrisk=gate)
+                    if info is not None:
+                        for _ in range(3):           # the capture's warm-up iterations are real ones: record them too
+                            info.before_step(loop.obs)
+                            loop.vector_step(True, False, gate)
+                            info.after_step(self.env, loop._last_real_action, loop._last_recovery)
+                            it += 1
+                        it += loop.capture(online_qrisk=gate, warmup=0)
+                    else:
+                        it += loop.capture(online_qrisk=gate)
                     captured_gate = gate
+                if info is not None:
+                    info.before_step(loop.obs)
                 if steady:
                     loop.replay()
                 else:
                     loop.vector_step(do_update=have_batch, random_actions=random_actions, online_qrisk=gate)
+                if info is not None:
+                    info.after_step(self.env, loop._last_real_action, loop._last_recovery)
                 it += 1
                 if mb and not cfg.disable_online_updates:
                     info_s, info_a, info_s2 = self.env.prev_obs, self.env.action_clipped, self.env.next_obs
@@ -717,6 +732,8 @@ class Experiment:
                     stats = loop.read_stats()
                     self._absorb(stats)
                     new = loop.episode_log.drain()
+                    if info is not None:
+                        train_stats.extend(info.drain())
                     episodes.append(new)
                     ep_file.write(new.tobytes())
                     ep_file.flush()
@@ -739,7 +756,8 @@ class Experiment:
                         evals.append(self.get_test_rollout_vectorized(stats["episodes"]))
                         next_eval += 10 * n
                     with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
-                        pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n}, f)
+                        pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n,
+                                     **({"train_stats": train_stats, "test_stats": []} if info is not None else {})}, f)
                     if ckpt_every and logged % ckpt_every == 0:
                         write_checkpoint()
                     # multi-rank: all ranks leave at the same log point (the next aggregate would hang otherwise);
@@ -752,7 +770,8 @@ class Experiment:
         write_checkpoint()
         with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
             pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n,
-                         "episode_stats": np.concatenate(episodes)}, f)
+                         "episode_stats": np.concatenate(episodes),
+                         **({"train_stats": train_stats, "test_stats": [], "info_envs": info_k} if info is not None else {})}, f)
         return history
 
     def get_test_rollout_vectorized(self, label):
