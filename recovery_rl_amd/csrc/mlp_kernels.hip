@@ -67,9 +67,11 @@ struct GemmArgs {
     const float* gen_w3;  // [G, H]
 };
 
-struct Frag {
-    float4 v[kVec];
+template <int VEC>
+struct FragT {
+    float4 v[VEC];
 };
+using Frag = FragT<kVec>;
 
 // Loads never branch: the FAST instantiation (every tile full, leading dimensions multiples of 4,
 // 16-byte aligned bases) issues plain float4 loads; the generic one clamps indices into range and
@@ -92,32 +94,33 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ base, long lon
 // lane group q = lane >> 4 consumes k = 16 j + 4 q + t.  An operand whose k index is contiguous in
 // memory (rows = M or N index) is then exactly element t of the lane's j-th float4 of its own row
 // i = lane & 15 -- it feeds the MFMA straight from registers, no LDS.
-template <bool FAST>
-__device__ __forceinline__ void load_direct(Frag& f, const float* __restrict__ src, int ld, int row0,
+template <bool FAST, int VEC>
+__device__ __forceinline__ void load_direct(FragT<VEC>& f, const float* __restrict__ src, int ld, int row0,
                                             int rows, int k0, int K, int lane) {
     const int gr = row0 + (lane & 15);
     const bool ok = gr < rows;
     const long long off = (long long)(ok ? gr : rows - 1) * ld;
 #pragma unroll
-    for (int j = 0; j < kVec; ++j) f.v[j] = load4<FAST>(src, off, k0 + 16 * j + 4 * (lane >> 4), K, ok);
+    for (int j = 0; j < VEC; ++j) f.v[j] = load4<FAST>(src, off, k0 + 16 * j + 4 * (lane >> 4), K, ok);
 }
 
 // An operand stored [k][col] (col contiguous) is staged through LDS: coalesced float4 loads along
 // the columns, one ds_write_b128 each, read back as tile[k][i].
-template <bool FAST>
-__device__ __forceinline__ void load_staged(Frag& f, const float* __restrict__ src, int ld, int col0,
+template <bool FAST, int VEC>
+__device__ __forceinline__ void load_staged(FragT<VEC>& f, const float* __restrict__ src, int ld, int col0,
                                             int cols, int k0, int K, int lane) {
     const int c = col0 + (lane & 3) * 4;
 #pragma unroll
-    for (int j = 0; j < kVec; ++j) {
+    for (int j = 0; j < VEC; ++j) {
         const int k = k0 + (lane >> 2) + 16 * j;
         const bool ok = k < K;
         f.v[j] = load4<FAST>(src, (long long)(ok ? k : K - 1) * ld, c, cols, ok);
     }
 }
-__device__ __forceinline__ void store_staged(const Frag& f, float* tile, int lane) {
+template <int VEC>
+__device__ __forceinline__ void store_staged(const FragT<VEC>& f, float* tile, int lane) {
 #pragma unroll
-    for (int j = 0; j < kVec; ++j)
+    for (int j = 0; j < VEC; ++j)
         *reinterpret_cast<float4*>(tile + ((lane >> 2) + 16 * j) * kLd + (lane & 3) * 4) = f.v[j];
 }
 
@@ -146,7 +149,10 @@ __device__ __forceinline__ void tile_sync() {
 // GEN tiles keep dOut[r], r < 512, in the pad columns 16..19 of the As tile (rows of kLd = 20 floats, 16 used)
 __device__ __forceinline__ int dsh_index(int r) { return (r >> 2) * kLd + (r & 3); }
 
-template <int MODE, bool FAST, bool GEN = false, class Prologue = NoPrologue, bool WL = false>  // MODE: 0 NT, 1 NN, 2 TN
+// PANEL = K elements per panel (a multiple of 16).  The K chunks are consumed in the same ascending order with the same
+// accumulator for every PANEL, so the result does not depend on it; a smaller panel = smaller LDS tiles = more tiles in
+// flight per CU (the packed launches, which have more tiles than LDS for them) at the price of a wave-level sync per panel.
+template <int MODE, bool FAST, bool GEN = false, class Prologue = NoPrologue, bool WL = false, int PANEL = kPanel>  // MODE: 0 NT, 1 NN, 2 TN
 __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g,
                                             const float* dsh = nullptr, Prologue prologue = Prologue()) {
     static_assert(!GEN || (FAST && MODE != 0), "generated operands: full aligned NN / TN tiles");
@@ -158,6 +164,8 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
     float4 w3c = make_float4(0.f, 0.f, 0.f, 0.f);
     float drow = 0.f;
     if constexpr (GEN && MODE == 2) w3c = *reinterpret_cast<const float4*>(W3 + m0 + (lane & 3) * 4);
+    constexpr int VEC = PANEL / 16;
+    using Frag = FragT<VEC>;
     Frag fw;
     const float* B = a.B + g * a.sB;
     float* C = a.C + g * a.sC;
@@ -174,7 +182,7 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
         else load_direct<FAST>(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
         if constexpr (GEN && MODE == 1) {
 #pragma unroll
-            for (int j = 0; j < kVec; ++j) fw.v[j] = *reinterpret_cast<const float4*>(W3 + k0 + 16 * j + 4 * (lane >> 4));
+            for (int j = 0; j < VEC; ++j) fw.v[j] = *reinterpret_cast<const float4*>(W3 + k0 + 16 * j + 4 * (lane >> 4));
         }
     };
     auto gen4 = [](float4 h, float d, float4 w) {       // the head backward's  a > 0 ? fmaf(dOut, W3, 0) : 0
@@ -183,7 +191,7 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
     };
 
 
-    const int np = (a.K + kPanel - 1) / kPanel;
+    const int np = (a.K + PANEL - 1) / PANEL;
     const int i = lane & 15, q = lane >> 4;
     load(0);
     if constexpr (GEN) {
@@ -195,11 +203,11 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
         Frag ca = fa, cb = fb;           // operands of this panel (registers)
         if constexpr (GEN && MODE == 1) {
 #pragma unroll
-            for (int j = 0; j < kVec; ++j) ca.v[j] = gen4(fa.v[j], drow, fw.v[j]);
+            for (int j = 0; j < VEC; ++j) ca.v[j] = gen4(fa.v[j], drow, fw.v[j]);
         }
         if constexpr (GEN && MODE == 2) {
 #pragma unroll
-            for (int j = 0; j < kVec; ++j) fa.v[j] = gen4(fa.v[j], dsh[dsh_index(p * kPanel + (lane >> 2) + 16 * j)], w3c);
+            for (int j = 0; j < VEC; ++j) fa.v[j] = gen4(fa.v[j], dsh[dsh_index(p * PANEL + (lane >> 2) + 16 * j)], w3c);
         }
         if (kStageA || kStageB) {
             if (p) tile_sync<WL>();      // the previous panel's LDS reads are done
@@ -207,10 +215,10 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
             if (kStageB) store_staged(fb, Bs, lane);
             tile_sync<WL>();
         }
-        if (p + 1 < np) load((p + 1) * kPanel);   // next panel's global loads fly under the MFMAs
-        const int klen = min(kPanel, a.K - p * kPanel);
+        if (p + 1 < np) load((p + 1) * PANEL);   // next panel's global loads fly under the MFMAs
+        const int klen = min(PANEL, a.K - p * PANEL);
 #pragma unroll
-        for (int j = 0; j < kVec; ++j) {
+        for (int j = 0; j < VEC; ++j) {
             if (16 * j < klen) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -322,6 +330,7 @@ struct HiddenGroup {
     int n;
 };
 
+template <int PANEL = kPanel>
 __device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int block, float* As, float* Bs);
 
 __global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenGroup hg) {
@@ -330,15 +339,19 @@ __global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenGroup hg) {
     gemm16_group_body(hg, blockIdx.x, As, Bs);
 }
 
+// PANEL = 128: 20 KB of LDS per single-wave workgroup, i.e. 8 tiles in flight per CU -- enough for one seed (1 000-1 500 tiles
+// per launch), three rounds for four seeds.  PANEL = 64 (every member FAST, i.e. K a multiple of 128): 16 tiles per CU.
+template <int PANEL>
 __global__ __launch_bounds__(64) void gemm16_pack_kernel(const HiddenGroup* __restrict__ groups, rrl_pack::Idx ix) {
-    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
-    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
+    __shared__ __attribute__((aligned(16))) float As[PANEL * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[PANEL * kLd];
     int s, local;
     if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
     // the one member this workgroup serves, not the whole 1.8 KB group, is what it copies out of device memory
-    gemm16_group_body(groups[s], local, As, Bs);
+    gemm16_group_body<PANEL>(groups[s], local, As, Bs);
 }
 
+template <int PANEL>
 __device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int block, float* As, float* Bs) {
     int k = 0;
     while (k + 1 < hg.n && block >= hg.first[k + 1]) ++k;
@@ -348,13 +361,13 @@ __device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int blo
     // launch): its fields are then wave-uniform registers whatever the group's home
     if (b < hg.tn_tiles[k]) {
         const GemmArgs ga = hg.tn[k];
-        if (hg.fast[k]) gemm16_tile<2, true>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
-        else gemm16_tile<2, false>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
+        if (hg.fast[k]) gemm16_tile<2, true, false, NoPrologue, false, PANEL>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
+        else gemm16_tile<2, false, false, NoPrologue, false, PANEL>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
     } else {
         const int c = b - hg.tn_tiles[k];
         const GemmArgs ga = hg.nn[k];
-        if (hg.fast[k]) gemm16_tile<1, true>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
-        else gemm16_tile<1, false>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
+        if (hg.fast[k]) gemm16_tile<1, true, false, NoPrologue, false, PANEL>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
+        else gemm16_tile<1, false, false, NoPrologue, false, PANEL>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
     }
 }
 
@@ -1610,6 +1623,27 @@ int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* strea
     return check_launch();
 }
 
+// Packed launches are throughput-bound from a few seeds on (more tiles / workgroups than the chip holds at once), where the
+// solo kernels' shapes -- chosen for the latency of ONE seed -- are not the best ones.  Seeds from which the packed launch
+// switches shape (per output element the arithmetic is the same either way; RRL_PACK_* override the measured defaults):
+//   hidden-layer backward: 64-wide K panels from 2 seeds on, 32-wide from 3 (10 / 5 KB of LDS per tile instead of 20: 16 / 32
+//                          tiles in flight per CU instead of 8; one seed has ~6 tiles per CU and launch, four have 24)
+//   B <= 1024 forwards   : 2 row tiles per workgroup from 3 seeds on (half the workgroups, each W2 fragment used twice)
+// Measured (profiles/packed_ab.sh, ms per packed iteration at 16 updates per step, S = 2 / 3 / 4 / 8): solo shapes
+// 3.12 / 3.99 / 4.06 / 5.77, these 3.02 / 3.66 / 3.72 / 5.13; each alone and the other panel widths in profiles/README.md.
+static int pack_threshold(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static int pack_panel(int S) {
+    static const int min64 = pack_threshold("RRL_PACK_PANEL64_MIN_SEEDS", 2), min32 = pack_threshold("RRL_PACK_PANEL32_MIN_SEEDS", 3);
+    return S >= min32 ? 32 : (S >= min64 ? 64 : kPanel);
+}
+static int pack_small_r2_min_seeds() {
+    static const int v = pack_threshold("RRL_PACK_SMALL_R2_MIN_SEEDS", 3);
+    return v;
+}
+
 int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_bwd_t* const* members, void* stream) {
     rrl_pack::Key key;
     if (!pack_key(1, S, n, members, key)) return RRL_EINVAL;
@@ -1636,12 +1670,17 @@ int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_b
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         plan->i0 = fused;
+        plan->i1 = pack_panel(S);
     }
     if (plan->i0)
         hipLaunchKernelGGL(hidden_head_pack_kernel, dim3(plan->grid), dim3(256), kFusedLdsFloats * 4, st, (const FusedHiddenGroup*)plan->dev,
                            plan->ix);
+    else if (plan->i1 == 64)
+        hipLaunchKernelGGL(gemm16_pack_kernel<64>, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
+    else if (plan->i1 == 32)
+        hipLaunchKernelGGL(gemm16_pack_kernel<32>, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
     else
-        hipLaunchKernelGGL(gemm16_pack_kernel, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
+        hipLaunchKernelGGL(gemm16_pack_kernel<kPanel>, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
     return check_launch();
 }
 
@@ -1721,7 +1760,7 @@ int rrl_debug_fwd_stamps(unsigned long long* host, int n_blocks) {
 }
 #endif
 
-static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& path, int big_r = kBigR) {
+static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& path, int big_r = kBigR, int small_r = 1) {
     if (!st || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
     sg = StackGroup{};
     sg.n = n;
@@ -1746,7 +1785,8 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
         const long long tiles16 = (p.M + kStackRows - 1) / kStackRows;
         if (p.scratch && rrl_mlp3_is_split(p.M, p.H)) {
             my = (p.M <= kSplitSmallM || p.H != 256) ? 0 : 3;      // the multi-row tiles are built for H = 256
-            const int rows = (my == 0 ? 1 : big_r) * kStackRows;
+            if (my == 0 && small_r > 1 && p.H != 256) return RRL_EINVAL;
+            const int rows = (my == 0 ? small_r : big_r) * kStackRows;
             sg.tiles[k] = (p.M + rows - 1) / rows;
             sg.big[k] = my == 3;
             sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G * kSplit;
@@ -1802,9 +1842,15 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         // so each keeps its W2 fragments for kPackR = 4 row tiles (half the weight stream of the solo kernel's 2; per output
         // element the arithmetic is the same for every R)
         const int big_r = S >= kPackMinSeeds ? kPackR : kBigR;
+        // small batches (the updates' B = 256 forwards): kBigR row tiles per workgroup from pack_small_r2_min_seeds() seeds
+        // on, when every member has the hidden width the multi-row tiles are built for
+        bool all256 = true;
+        for (int s = 0; s < S; ++s)
+            for (int k = 0; k < n[s]; ++k) all256 = all256 && members[s] && members[s][k].H == 256;
+        const int small_r = (S >= pack_small_r2_min_seeds() && all256) ? kBigR : 1;
         const int rc = build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
             int my;
-            const int r = build_stack_group(nk, m, g, my, big_r);
+            const int r = build_stack_group(nk, m, g, my, big_r, small_r);
             if (r != RRL_OK) return r;
             if ((my != 0 && my != 3 && my != 4) || (path >= 0 && my != path)) return int(RRL_EINVAL);
             path = my;
@@ -1820,6 +1866,13 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         if (!plan) return RRL_ELAUNCH;
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
+        // small members on multi-row tiles run the large-batch kernel (path 3); a mix of small and large members (path 4)
+        // then has ONE tile shape as well
+        if (small_r > 1 && big_r == kBigR && (path == 0 || path == 4)) {
+            static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+            if (!ok) return RRL_ERANGE;
+            path = 3;
+        }
         plan->i0 = path;
         plan->i1 = big_r;
     }
