@@ -7,7 +7,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r3_packed_prof
 mkdir -p $OUT
 U=${1:-16}
-for S in 1 4; do
+SLIST=${2:-"1 4"}
+for S in $SLIST; do
   rm -rf /tmp/pp$S
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp$S -o p -- python $R/profiles/packed_probe.py $U $S 100 > $OUT/S$S.json 2>/tmp/pp$S.err
   cp $(find /tmp/pp$S -name "*kernel_stats.csv" | head -1) $OUT/S${S}_kernel_stats.csv
