@@ -668,7 +668,7 @@ def main():
         torch.cuda.empty_cache()
         loop = None
         extra["seed_pack"] = run_seed_pack_leg(a, device)
-        extra["seed_pack_utd_1_256"] = run_seed_pack_leg(a, device, seeds=(1, 4, 8), updates_per_step=16)
+        extra["seed_pack_utd_1_256"] = run_seed_pack_leg(a, device, seeds=(1, 4, 8, 16), updates_per_step=16)
         if a.env == "navigation1" and a.num_envs == NUM_ENVS:
             with contextlib.redirect_stdout(sys.stderr):       # the driver announces itself: stdout carries the JSON line only
                 extra["config4"] = {prec: run_config4_leg(device, prec) for prec in ("f32", "f16x3")}

@@ -153,3 +153,28 @@ def test_info_envs_writes_the_reference_per_step_schema(tmp_path):
     # plotting/plot_runs.py:147-235 reads exactly these two keys per step
     m = episode_metrics({"train_stats": ts}, "navigation1")
     assert len(m["ep_lengths"]) == len(ts) and m["train_violations"][-1] == int((rec["constraint_steps"] > 0).sum())
+
+
+def test_info_envs_on_the_unfused_step_of_the_maze(tmp_path):
+    """The same stream when the iteration is NOT the fused step + push launch (--add_both_transitions keeps env.step() and
+    the masked second push, experiment.py:446-448) and on the other env family (scripts/maze.sh:7)."""
+    K = 3
+    cfg = arg_utils.get_args(["--env-name", "maze", "--cuda", "--logdir", str(tmp_path), "--seed", "2",
+                              "--use_recovery", "--MF_recovery", "--gamma_safe", "0.5", "--eps_safe", "0.15",
+                              "--pos_fraction", "0.3", "--num_unsafe_transitions", "2000", "--critic_safe_pretraining_steps",
+                              "20", "--add_both_transitions", "--num_envs", "32", "--num_eps", "100", "--log_every", "20",
+                              "--start_steps", "320", "--info_envs", str(K)])
+    exp = Experiment(cfg)
+    exp.run()
+    data = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))
+    from recovery_rl_amd.episode_log import records_from_train_stats
+    ts, rec = data["train_stats"], data["episode_stats"]
+    rec = rec[rec["env"] < K]
+    assert len(ts) == len(rec) >= K
+    mine = records_from_train_stats(ts)
+    for name in ("length", "constraint_steps", "recovery_steps", "flags"):
+        np.testing.assert_array_equal(mine[name], rec[name], err_msg=name)
+    np.testing.assert_allclose(mine["ret"], rec["ret"], rtol=1e-6)
+    for ep in ts:
+        for a, b in zip(ep[:-1], ep[1:]):
+            np.testing.assert_array_equal(a["next_state"], b["state"])
