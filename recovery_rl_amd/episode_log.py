@@ -41,11 +41,13 @@ class EpisodeLog:
         """Advance the accumulators with one lock-step transition (u8 masks, f32 reward, all [N])."""
         if recovery is not None and recovery.dtype != torch.uint8:
             recovery = recovery.to(torch.uint8)
-        rc = self.lib.rrl_episode_log_append(
-            self.n, _lib.ptr(reward), _lib.ptr(constraint), _lib.ptr(success), _lib.ptr(ep_done),
-            _lib.ptr(recovery), _lib.ptr(self.ep_len), _lib.ptr(self.ep_ret), _lib.ptr(self.ep_viol),
-            _lib.ptr(self.ep_rec), C.byref(self._desc), _lib.current_stream())
-        _lib.check(rc, "rrl_episode_log_append")
+        args = (self.n, _lib.ptr(reward), _lib.ptr(constraint), _lib.ptr(success), _lib.ptr(ep_done),
+                _lib.ptr(recovery), _lib.ptr(self.ep_len), _lib.ptr(self.ep_ret), _lib.ptr(self.ep_viol),
+                _lib.ptr(self.ep_rec), C.byref(self._desc))
+        # seed packing re-issues this launch as it is (one per seed; the table is not on the iteration's critical path)
+        from .fast_update import record
+        record("call", self.lib.rrl_episode_log_append, args, (reward, constraint, success, ep_done, recovery, self))
+        _lib.check(self.lib.rrl_episode_log_append(*args, _lib.current_stream()), "rrl_episode_log_append")
 
     def drain(self):
         """Copy the finished-episode records to the host (sorted by iteration, env) and clear the table."""

@@ -858,8 +858,9 @@ def run_packed(exp_cfg, rank=0, world_size=1):
     envs, replay rings, networks and pre-training, exactly what S runs of the reference's seed loop
     (scripts/navigation1.sh:4-8) would create -- advanced together on one GPU: once every seed is in its steady state the
     iteration of all of them is ONE hipGraph whose launches are shared (packed.PackedLoop); every seed's trajectory is the one
-    its solo run produces.  Logging per seed at the `--log_every` cadence (counters; no per-episode table in this mode).
-    Returns the list of per-seed histories."""
+    its solo run produces.  Logging per seed at the `--log_every` cadence: counters, the per-episode table (`episode_stats`,
+    `episode_stats.bin`) and, with `--info_envs K`, the per-step `train_stats` of the first K envs -- the files the solo
+    lock-step run of that seed writes.  Returns the list of per-seed histories."""
     import copy
     from .fast_update import fast_path_supported
     from .packed import PackedLoop
@@ -868,7 +869,11 @@ def run_packed(exp_cfg, rank=0, world_size=1):
             not (exp_cfg.use_recovery and exp_cfg.MF_recovery) or world_size > 1:
         raise ValueError("--seeds_per_gpu needs the lock-step loop (--num_envs > 1) on the fused update path with model-free "
                          "recovery, one process per GPU")
-    exps = []
+    from .episode_log import EPISODE_DTYPE, EpisodeLog, InfoRing
+    n = exp_cfg.num_envs
+    log_every = exp_cfg.log_every if getattr(exp_cfg, "log_every", 0) else 100
+    info_k = min(int(getattr(exp_cfg, "info_envs", 0) or 0), n)
+    exps, infos, tables, train_stats, ep_files = [], [], [], [], []
     for k in range(S):
         cfg = copy.deepcopy(exp_cfg)
         cfg.seed = exp_cfg.seed + k
@@ -877,46 +882,84 @@ def run_packed(exp_cfg, rank=0, world_size=1):
         if not cfg.disable_offline_updates:
             exp.pretrain_critic_recovery()
         exp.loop.start()
+        # per-episode table and per-step info stream from the first iteration on, as in the solo lock-step run
+        exp.loop.episode_log = EpisodeLog(n, n * (log_every + 8), exp.device)
+        infos.append(InfoRing(info_k, log_every + 8, exp.device, exp.env.action_space.high[0]) if info_k else None)
+        tables.append([np.zeros(0, dtype=EPISODE_DTYPE)])
+        train_stats.append([])
+        ep_files.append(open(osp.join(exp.logdir, "episode_stats.bin"), "wb"))
         exps.append(exp)
     cfg = exp_cfg
-    n = cfg.num_envs
-    log_every = cfg.log_every if getattr(cfg, "log_every", 0) else 100
+    histories = [[] for _ in exps]
+
+    def before():
+        for e, info in zip(exps, infos):
+            if info is not None:
+                info.before_step(e.loop.obs)
+
+    def after():
+        for e, info in zip(exps, infos):
+            if info is not None:
+                info.after_step(e.env, e.loop._last_real_action, e.loop._last_recovery)
+
+    def log_point(it):
+        """Per-seed counters, table and info stream at the logging cadence; True when every seed has reached its budget."""
+        done = True
+        for k, (e, hist) in enumerate(zip(exps, histories)):
+            stats = e.loop.read_stats()
+            e._absorb(stats)
+            hist.append(dict(stats, iteration=it))
+            print("Seed: {}, Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(
+                e.exp_cfg.seed, it, stats["env_steps"], stats["episodes"],
+                round(stats["episode_return_sum"] / max(stats["episodes"], 1), 2)))
+            print("Num Violations So Far: %d" % stats["num_viols"])
+            print("Num Successes So Far: %d" % stats["num_successes"])
+            new = e.loop.episode_log.drain()
+            tables[k].append(new)
+            ep_files[k].write(new.tobytes())
+            ep_files[k].flush()
+            if infos[k] is not None:
+                train_stats[k].extend(infos[k].drain())
+            done = done and (stats["env_steps"] > cfg.num_steps or stats["episodes"] > cfg.num_eps)
+            with open(osp.join(e.logdir, "run_stats.pkl"), "wb") as f:
+                pickle.dump({"vector_stats": hist, "eval_stats": [], "num_envs": n, "seeds_per_gpu": S,
+                             "episode_stats": np.concatenate(tables[k]),
+                             **({"train_stats": train_stats[k], "test_stats": [], "info_envs": info_k}
+                                if infos[k] is not None else {})}, f)
+        return done
+
     # eager until every seed has a batch, has left the random-action phase and trains Q_risk online
-    it = 0
+    it, logged, finished = 0, 0, False
     while True:
         ready = [len(e.memory) > cfg.batch_size and e.loop.total_numsteps >= cfg.start_steps and e.online_qrisk_enabled()
                  for e in exps]
-        if all(ready):
+        if all(ready) or finished:
             break
         if it > 20 * log_every:
             raise RuntimeError("--seeds_per_gpu: the seeds did not all reach the steady state (online Q_risk gate)")
+        before()
         for e in exps:
             e.loop.vector_step(do_update=len(e.memory) > cfg.batch_size,
                                random_actions=cfg.start_steps > e.loop.total_numsteps,
                                online_qrisk=e.online_qrisk_enabled())
-        it += 1
-    packed = PackedLoop([e.loop for e in exps], online_qrisk=True)
-    it += packed.capture()
-    histories = [[] for _ in exps]
-    logged = it // log_every
-    while True:
-        packed.replay()
+        after()
         it += 1
         if it // log_every > logged:
             logged = it // log_every
-            done = True
-            for e, hist in zip(exps, histories):
-                stats = e.loop.read_stats()
-                e._absorb(stats)
-                hist.append(dict(stats, iteration=it))
-                print("Seed: {}, Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(
-                    e.exp_cfg.seed, it, stats["env_steps"], stats["episodes"],
-                    round(stats["episode_return_sum"] / max(stats["episodes"], 1), 2)))
-                print("Num Violations So Far: %d" % stats["num_viols"])
-                print("Num Successes So Far: %d" % stats["num_successes"])
-                with open(osp.join(e.logdir, "run_stats.pkl"), "wb") as f:
-                    pickle.dump({"vector_stats": hist, "eval_stats": [], "num_envs": n, "seeds_per_gpu": S}, f)
-                done = done and (stats["env_steps"] > cfg.num_steps or stats["episodes"] > cfg.num_eps)
-            if done:
-                break
+            finished = log_point(it)
+    if not finished:
+        packed = PackedLoop([e.loop for e in exps], online_qrisk=True)
+        # (a capture advances every seed by <= 5 real iterations: the tables and rings have 8 iterations of head-room)
+        it += packed.capture(around=(before, after) if info_k else None)
+        while True:
+            before()
+            packed.replay()
+            after()
+            it += 1
+            if it // log_every > logged:
+                logged = it // log_every
+                if log_point(it):
+                    break
+    for f in ep_files:
+        f.close()
     return histories

@@ -87,16 +87,28 @@ class PackedLoop:
                     stages.append((self.lib.rrl_maze_step_push_packed, (S, args), ops))
                 else:
                     stages.append((self.lib.rrl_nav_step_push_packed, (S, env_kind, args), ops))
+            elif kind == "call":
+                # launches that stay per seed (the episode table's append): issued one after the other inside the same graph
+                calls = [(op[1], op[2]) for op in ops]
+                stages.append((self._call_each, (calls,), ops))
             else:
                 raise _lib.RRLError("launch kind %r cannot be packed" % kind)
         return stages
+
+    @staticmethod
+    def _call_each(calls, stream):
+        for fn, args in calls:
+            rc = fn(*args, stream)
+            if rc:
+                return rc
+        return 0
 
     # -- running ---------------------------------------------------------------------------------------------------------
     def launch(self):
         """One packed iteration: every recorded launch once, for all seeds."""
         st = _lib.current_stream()
         for fn, args, _ in self.stages:
-            _lib.check(fn(*args, st), fn.__name__)
+            _lib.check(fn(*args, st), getattr(fn, "__name__", "packed stage"))
 
     def _advance_host_mirrors(self):
         for loop in self.loops:
@@ -116,27 +128,37 @@ class PackedLoop:
         self.launch()
         self._advance_host_mirrors()
 
-    def capture(self, warmup=2, settle=2):
+    def capture(self, warmup=2, settle=2, around=None):
         """Record (one real iteration per seed), run `warmup` eager packed iterations (they populate the library's
         argument-block cache, so the captured launches copy nothing), capture the packed iteration in ONE hipGraph.
+        `around` = (before, after): called around every one of these real iterations (the per-step info stream).
         Returns the number of iterations every seed has advanced."""
-        for _ in range(settle):              # the first iterations size the noise buffer and build the acting workspace
+        def real(fn):
+            if around is not None:
+                around[0]()
+            fn()
+            if around is not None:
+                around[1]()
+
+        def settle_once():
             for loop in self.loops:
                 loop.vector_step(True, False, self.online_qrisk)
-        self.record()
+        for _ in range(settle):              # the first iterations size the noise buffer and build the acting workspace
+            real(settle_once)
+        real(self.record)
         dev = self.loops[0].device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.step()
+            for _ in range(max(warmup, 1)):
+                real(self.step)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.launch()
         self.graph = g
-        return settle + 1 + warmup
+        return settle + 1 + max(warmup, 1)
 
     def replay(self):
         self.graph.replay()

@@ -99,3 +99,38 @@ def test_seeds_per_gpu_flag_runs_packed_experiments(tmp_path, capsys):
     want = loop.read_stats()
     got = {k: v for k, v in hists[1][-1].items() if k != "iteration"}
     assert got == want
+
+
+def test_packed_seeds_write_the_files_of_their_solo_runs(tmp_path, capsys):
+    """Per-episode table (run_stats.pkl `episode_stats`, episode_stats.bin) and, with --info_envs, the reference-schema
+    per-step `train_stats` of a packed seed equal what the solo lock-step run of that seed writes, record for record."""
+    import os
+    import pickle
+    import numpy as np
+    from recovery_rl_amd.episode_log import EPISODE_DTYPE
+    from recovery_rl_amd.experiment import Experiment, run_packed
+    argv = ["--env-name", "navigation1", "--cuda", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe",
+            "0.3", "--num_unsafe_transitions", "3000", "--critic_safe_pretraining_steps", "30", "--num_envs", "64",
+            "--log_every", "25", "--num_eps", "100000", "--num_steps", str(64 * 100 - 1), "--start_steps", "640",
+            "--info_envs", "2"]
+    run_packed(arg_utils.get_args(argv + ["--seed", "7", "--seeds_per_gpu", "2", "--logdir", str(tmp_path / "packed")]))
+    dirs = sorted(os.listdir(tmp_path / "packed"))
+    solo = Experiment(arg_utils.get_args(argv + ["--seed", "8", "--logdir", str(tmp_path / "solo")]))
+    solo.run()
+    want = pickle.load(open(os.path.join(solo.logdir, "run_stats.pkl"), "rb"))
+    got = pickle.load(open(tmp_path / "packed" / dirs[1] / "run_stats.pkl", "rb"))
+    assert dirs[1].endswith("_seed8") and got["seeds_per_gpu"] == 2 and got["info_envs"] == 2
+    assert len(want["episode_stats"]) > 100
+    for name in EPISODE_DTYPE.names:
+        np.testing.assert_array_equal(got["episode_stats"][name], want["episode_stats"][name], err_msg=name)
+    raw = np.fromfile(tmp_path / "packed" / dirs[1] / "episode_stats.bin", dtype=EPISODE_DTYPE)
+    np.testing.assert_array_equal(raw["ret"], want["episode_stats"]["ret"])
+    assert len(got["train_stats"]) == len(want["train_stats"]) > 4
+    for ep_a, ep_b in zip(got["train_stats"], want["train_stats"]):
+        assert len(ep_a) == len(ep_b)
+        for a, b in zip(ep_a, ep_b):
+            assert a["reward"] == b["reward"] and a["constraint"] == b["constraint"] and a["recovery"] == b["recovery"]
+            np.testing.assert_array_equal(a["state"], b["state"])
+            np.testing.assert_array_equal(a["action"], b["action"])
+            np.testing.assert_array_equal(a["next_state"], b["next_state"])
+    assert {k: v for k, v in got["vector_stats"][-1].items()} == {k: v for k, v in want["vector_stats"][-1].items()}
