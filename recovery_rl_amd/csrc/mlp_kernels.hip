@@ -1803,7 +1803,7 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
         if (path >= 0 && my != path && !split_mix) return RRL_EINVAL;
         path = (path >= 0 && my != path) ? 4 : my;
     }
-    if (path == 4 && big_r != kBigR) return RRL_EINVAL;      // the mixed kernel is built for kBigR
+    if (path == 4 && big_r != kBigR && small_r != big_r) return RRL_EINVAL;      // the mixed kernel is built for kBigR
     for (int k = n; k < kMaxGroup; ++k) sg.first[k + 1] = sg.first[n];
     return RRL_OK;
 }
@@ -1841,13 +1841,14 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         // row tiles per workgroup of the large-batch kernel: with several seeds in the launch there are workgroups to spare,
         // so each keeps its W2 fragments for kPackR = 4 row tiles (half the weight stream of the solo kernel's 2; per output
         // element the arithmetic is the same for every R)
-        const int big_r = S >= kPackMinSeeds ? kPackR : kBigR;
+        static const int r4_min = pack_threshold("RRL_PACK_R4_MIN_SEEDS", kPackMinSeeds);
+        const int big_r = S >= r4_min ? kPackR : kBigR;
         // small batches (the updates' B = 256 forwards): kBigR row tiles per workgroup from pack_small_r2_min_seeds() seeds
         // on, when every member has the hidden width the multi-row tiles are built for
         bool all256 = true;
         for (int s = 0; s < S; ++s)
             for (int k = 0; k < n[s]; ++k) all256 = all256 && members[s] && members[s][k].H == 256;
-        const int small_r = (S >= pack_small_r2_min_seeds() && all256) ? kBigR : 1;
+        const int small_r = (S >= pack_small_r2_min_seeds() && all256) ? big_r : 1;
         const int rc = build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
             int my;
             const int r = build_stack_group(nk, m, g, my, big_r, small_r);
@@ -1868,8 +1869,9 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         plan->ix = ix;
         // small members on multi-row tiles run the large-batch kernel (path 3); a mix of small and large members (path 4)
         // then has ONE tile shape as well
-        if (small_r > 1 && big_r == kBigR && (path == 0 || path == 4)) {
-            static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+        if (small_r > 1 && (path == 0 || path == 4)) {
+            static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4) &&
+                                   grant_lds((const void*)mlp3_fwd_split_pack_kernel<kPackR>, split_lds_floats(kPackR) * 4);
             if (!ok) return RRL_ERANGE;
             path = 3;
         }

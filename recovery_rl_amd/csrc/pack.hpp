@@ -78,7 +78,9 @@ inline int finish(Idx& ix) {
         ix.r = (ix.S + 7) / 8;
         return 8 * ix.r * most;
     }
-    int sp = 1;
+    // RRL_PACK_MIN_SP (probe): pin a seed to fewer XCDs than S alone would (8 = one XCD per seed even for one seed)
+    static const int min_sp = [] { const char* e = getenv("RRL_PACK_MIN_SP"); return e ? atoi(e) : 1; }();
+    int sp = min_sp > 8 ? 8 : (min_sp < 1 ? 1 : min_sp);
     while (sp < ix.S) sp <<= 1;
     ix.sp = sp;
     ix.p = 8 / sp;
