@@ -29,6 +29,14 @@ using rrl_host::check_launch;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -DRRL_NT_STORES (profiles/nt_store_probe.py builds a second library with it): the intermediates one stage hands to the
+// next (saved activations, dh2, weight gradients) are stored with the non-temporal hint
+#ifdef RRL_NT_STORES
+#define RRL_HANDOVER_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define RRL_HANDOVER_STORE(ptr, v) (*(ptr) = (v))
+#endif
+
 constexpr int kTile = 16;    // output tile edge: one wavefront per 16x16 tile (v_mfma_f32_16x16x4_f32)
 constexpr int kPanel = 128;  // K elements per panel
 constexpr int kLd = 20;      // LDS tile[k][20]: 16 columns + 4 pad, rows 16-byte aligned
@@ -253,7 +261,7 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
                 vout[r] = v;
                 if (store_c) {
                     float* dst = C + (long long)row * a.ldc + col;
-                    *dst = a.accumulate ? (*dst + v) : v;
+                    RRL_HANDOVER_STORE(dst, a.accumulate ? (*dst + v) : v);
                 }
             }
         }
@@ -719,7 +727,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
                         const int rr = 16 * rt + 4 * q + r;
                         float v = acc[r] + bias1[u];
                         v = v > 0.f ? v : 0.f;
-                        if (full || m0 + rr < M) h1g[(long long)rr * H + t * 16 + i] = v;
+                        if (full || m0 + rr < M) RRL_HANDOVER_STORE(&h1g[(long long)rr * H + t * 16 + i], v);
                     }
                 }
             }
@@ -767,7 +775,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
                     const int rr = 16 * rt + 4 * q + r;
                     float v = acc[r] + bias2;
                     v = v > 0.f ? v : 0.f;
-                    if (full || m0 + rr < M) h2g[(long long)rr * H + n2 + i] = v;
+                    if (full || m0 + rr < M) RRL_HANDOVER_STORE(&h2g[(long long)rr * H + n2 + i], v);
                 }
             }
         }
@@ -1089,7 +1097,7 @@ __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx
                         acc[o] = fmaf(go, a[it], acc[o]);
                     }
                 }
-                if (hb.dh2) dh2[(long long)b * H + h] = a[it] > 0.f ? d : 0.f;
+                if (hb.dh2) RRL_HANDOVER_STORE(&dh2[(long long)b * H + h], a[it] > 0.f ? d : 0.f);
             }
         } else {
 #pragma unroll
@@ -1103,7 +1111,7 @@ __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx
                         d = fmaf(go, w[o], d);
                         acc[o] = fmaf(go, a[it], acc[o]);
                     }
-                    if (hok && hb.dh2) dh2[(long long)b * H + h] = a[it] > 0.f ? d : 0.f;
+                    if (hok && hb.dh2) RRL_HANDOVER_STORE(&dh2[(long long)b * H + h], a[it] > 0.f ? d : 0.f);
                 }
             }
         }
