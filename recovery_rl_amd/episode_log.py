@@ -75,8 +75,10 @@ class InfoRing:
     logging cadence; episodes are emitted in completion order (iteration, then env)."""
     FIELDS = 11      # state 2 | action 2 | next_state 2 | reward | constraint | success | ep_done | recovery
 
-    def __init__(self, k, steps, device, action_high):
+    def __init__(self, k, steps, device, action_high, mid_episode=False):
+        """mid_episode: the stream starts inside running episodes (--resume): each env's first, partial, episode is dropped."""
         self.k, self.steps, self.device = int(k), int(steps), device
+        self.partial = [bool(mid_episode)] * int(k)
         self.rows = torch.zeros(self.steps, self.k, self.FIELDS, dtype=torch.float32, device=device)
         self.state = torch.zeros(self.k, 2, dtype=torch.float32, device=device)
         self.filled = 0
@@ -112,7 +114,9 @@ class InfoRing:
                                      "state": r[0:2].astype(np.float64), "next_state": r[4:6].astype(np.float64),
                                      "action": r[2:4].copy(), "success": bool(r[8]), "recovery": bool(r[10])})
                 if r[9]:
-                    done.append(self.open[e])
+                    if not self.partial[e]:
+                        done.append(self.open[e])
+                    self.partial[e] = False
                     self.open[e] = []
         return done
 

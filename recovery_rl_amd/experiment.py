@@ -654,7 +654,8 @@ class Experiment:
         from .episode_log import EpisodeLog, EPISODE_DTYPE, InfoRing
         loop.episode_log = EpisodeLog(n, n * (log_every + 4), self.device)   # a capture adds <= 3 iterations
         info_k = min(int(getattr(cfg, "info_envs", 0) or 0), n)
-        info = InfoRing(info_k, log_every + 4, self.device, self.env.action_space.high[0]) if info_k else None
+        info = InfoRing(info_k, log_every + 4, self.device, self.env.action_space.high[0],
+                        mid_episode=bool(getattr(cfg, "resume", ""))) if info_k else None
         train_stats = []
         episodes = [np.zeros(0, dtype=EPISODE_DTYPE)]
         history = []

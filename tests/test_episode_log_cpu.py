@@ -95,3 +95,22 @@ def test_info_ring_splits_steps_into_reference_episodes():
     assert len(ring.open[0]) == 1 and len(ring.open[1]) == 3     # unfinished episodes stay open
     rec = records_from_train_stats(drained)
     np.testing.assert_array_equal(rec["length"], [3, 4, 3])
+
+
+def test_info_ring_started_mid_episode_drops_the_partial_first_episodes():
+    import types
+
+    import torch
+
+    from recovery_rl_amd.episode_log import InfoRing
+    ring = InfoRing(1, 8, "cpu", action_high=1.0, mid_episode=True)
+    z2 = torch.zeros(1, 2)
+    for t in range(6):
+        ring.before_step(z2)
+        env = types.SimpleNamespace(next_obs=z2, reward=torch.full((1,), float(t)), constraint=torch.zeros(1, dtype=torch.uint8),
+                                    success=torch.zeros(1, dtype=torch.uint8),
+                                    ep_done=torch.tensor([t in (1, 4)], dtype=torch.uint8))
+        ring.after_step(env, z2, None)
+    eps = ring.drain()
+    assert [[s["reward"] for s in ep] for ep in eps] == [[2.0, 3.0, 4.0]]      # steps 0-1 belonged to an episode begun earlier
+    assert len(ring.open[0]) == 1
