@@ -867,9 +867,11 @@ def run_packed(exp_cfg, rank=0, world_size=1):
     from .packed import PackedLoop
     S = int(exp_cfg.seeds_per_gpu)
     if exp_cfg.num_envs < 2 or not fast_path_supported(exp_cfg) or uses_mb_recovery(exp_cfg) or \
-            not (exp_cfg.use_recovery and exp_cfg.MF_recovery) or world_size > 1:
+            not (exp_cfg.use_recovery and exp_cfg.MF_recovery) or getattr(exp_cfg, "dp_mode", "replicas") != "replicas":
         raise ValueError("--seeds_per_gpu needs the lock-step loop (--num_envs > 1) on the fused update path with model-free "
-                         "recovery, one process per GPU")
+                         "recovery (every rank of a multi-GPU launch packs its own seeds: replicas, no exchange)")
+    if getattr(exp_cfg, "resume", "") or getattr(exp_cfg, "checkpoint_every", 0):
+        raise ValueError("--seeds_per_gpu: checkpoints are written and resumed by the solo lock-step run (--seeds_per_gpu 1)")
     from .episode_log import EPISODE_DTYPE, EpisodeLog, InfoRing
     n = exp_cfg.num_envs
     log_every = exp_cfg.log_every if getattr(exp_cfg, "log_every", 0) else 100

@@ -12,9 +12,11 @@ if __name__ == '__main__':
     import torch
     if torch.cuda.is_available():
         torch.cuda.set_device(dist_utils.local_device(local_rank))
+    packed = getattr(exp_cfg, "seeds_per_gpu", 1)
     if world > 1:
-        exp_cfg.seed = dist_utils.rank_seed(exp_cfg.seed, rank)     # env, replay and noise streams differ per rank
-    if getattr(exp_cfg, "seeds_per_gpu", 1) > 1:
+        # env, replay and noise streams differ per rank (a rank that packs S seeds takes S consecutive ones)
+        exp_cfg.seed = dist_utils.rank_seed(exp_cfg.seed, rank * max(packed, 1))
+    if packed > 1:
         from recovery_rl_amd.experiment import run_packed
         run_packed(exp_cfg, rank=rank, world_size=world)
     else:
