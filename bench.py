@@ -667,11 +667,20 @@ def main():
         del loop
         torch.cuda.empty_cache()
         loop = None
-        extra["seed_pack"] = run_seed_pack_leg(a, device)
-        extra["seed_pack_utd_1_256"] = run_seed_pack_leg(a, device, seeds=(1, 4, 8, 16), updates_per_step=16)
+        # secondary legs never take the headline line down with them: a failure is reported in the leg's place
+        def leg(name, fn):
+            try:
+                extra[name] = fn()
+            except Exception as e:      # noqa: BLE001
+                extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.empty_cache()
+        leg("seed_pack", lambda: run_seed_pack_leg(a, device))
+        leg("seed_pack_utd_1_256", lambda: run_seed_pack_leg(a, device, seeds=(1, 4, 8, 16), updates_per_step=16))
         if a.env == "navigation1" and a.num_envs == NUM_ENVS:
-            with contextlib.redirect_stdout(sys.stderr):       # the driver announces itself: stdout carries the JSON line only
-                extra["config4"] = {prec: run_config4_leg(device, prec) for prec in ("f32", "f16x3")}
+            def config4():
+                with contextlib.redirect_stdout(sys.stderr):   # the driver announces itself: stdout carries the JSON line only
+                    return {prec: run_config4_leg(device, prec) for prec in ("f32", "f16x3")}
+            leg("config4", config4)
 
     if rank == 0:
         t_k = time_step_push_kernel(device, a.env, a.num_envs)
