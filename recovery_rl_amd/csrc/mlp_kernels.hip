@@ -75,6 +75,11 @@ struct GemmArgs {
     const float* gen_w3;  // [G, H]
 };
 
+// pointers of an argument block that was copied out of device memory (packed launches): see rrl_pack::to_global
+__device__ __forceinline__ void globalize(GemmArgs& a) {
+    rrl_pack::to_global_all(a.A, a.B, a.C, a.bias, a.mask, a.colsum, a.x, a.W1, a.first_part, a.dx_part, a.gen_h2, a.gen_w3);
+}
+
 template <int VEC>
 struct FragT {
     float4 v[VEC];
@@ -368,14 +373,228 @@ __device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int blo
     // the one problem this workgroup serves is copied out of the group (kernel arguments, or device memory for the packed
     // launch): its fields are then wave-uniform registers whatever the group's home
     if (b < hg.tn_tiles[k]) {
-        const GemmArgs ga = hg.tn[k];
+        GemmArgs ga = hg.tn[k];
+        globalize(ga);
         if (hg.fast[k]) gemm16_tile<2, true, false, NoPrologue, false, PANEL>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
         else gemm16_tile<2, false, false, NoPrologue, false, PANEL>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
     } else {
         const int c = b - hg.tn_tiles[k];
-        const GemmArgs ga = hg.nn[k];
+        GemmArgs ga = hg.nn[k];
+        globalize(ga);
         if (hg.fast[k]) gemm16_tile<1, true, false, NoPrologue, false, PANEL>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
         else gemm16_tile<1, false, false, NoPrologue, false, PANEL>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
+    }
+}
+
+// ---- block form of the hidden-layer backward for the packed launches -------------------------------------------------
+// With many seeds in one launch the 16 x 16 tiles above are bound by operand traffic, not by latency: every tile pulls its
+// own 16 x K slices of both operands through its CU's vector memory path, in half-used 128-byte lines.  Here a
+// four-wave workgroup owns a (32 WM) x (32 WN) block of the output, stages each K panel of the [k][col] operands ONCE for
+// all its waves (whole 128-byte lines, 1 / (2 WM) resp. 1 / (2 WN) of the tile form's loads per output element) in
+// double-buffered LDS, and every wave keeps WM x WN tiles in registers.  Per output element nothing changes: the same
+// v_mfma_f32_16x16x4_f32 steps on the same operands in the same order (k = 16 j + 4 q + t ascending in j, t; even t into one
+// accumulator, odd t into the other), the same epilogue -- a packed seed still equals its solo run bit for bit.
+// FAST geometry only (full blocks, K a multiple of the panel, aligned bases); anything else keeps the tile kernel.
+constexpr int kBlkPanel = 32;    // K elements per staged panel
+
+template <int W>   // W = operand width in columns (32 or 64): LDS rows of W + 4 floats (conflict-free fragment reads)
+__device__ __forceinline__ void blk_load(FragT<kBlkPanel * W / 1024>& f, const float* __restrict__ src, int ld, int col0,
+                                         int k0, int tid) {
+    constexpr int LPR = W / 4, RPP = 256 / LPR;
+#pragma unroll
+    for (int jj = 0; jj < kBlkPanel / RPP; ++jj)
+    {   // native vector load / store: a float4 struct copy between address spaces stays a memcpy through scratch
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + (long long)(k0 + tid / LPR + RPP * jj) * ld + col0 + 4 * (tid % LPR));
+        f.v[jj] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+template <int W>
+__device__ __forceinline__ void blk_store(const FragT<kBlkPanel * W / 1024>& f, float* buf, int tid) {
+    constexpr int LPR = W / 4, RPP = 256 / LPR;
+#pragma unroll
+    for (int jj = 0; jj < kBlkPanel / RPP; ++jj)
+        *reinterpret_cast<f32x4*>(buf + (tid / LPR + RPP * jj) * (W + 4) + 4 * (tid % LPR)) =
+            f32x4{f.v[jj].x, f.v[jj].y, f.v[jj].z, f.v[jj].w};
+}
+
+template <int WM, int WN>
+struct BlkLds {
+    static constexpr int BM = 32 * WM, BN = 32 * WN;
+    static constexpr int kA = kBlkPanel * (BM + 4), kB = kBlkPanel * (BN + 4);
+    static constexpr int kFloats = 2 * kA + 2 * kB > 4 * 400 ? 2 * kA + 2 * kB : 4 * 400;
+};
+
+template <int MODE, int WM, int WN>   // MODE: 1 NN (A direct, B staged), 2 TN (both staged)
+__device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx, int by, int g) {
+    using L = BlkLds<WM, WN>;
+    constexpr int BM = L::BM, BN = L::BN, LDA = BM + 4, LDB = BN + 4, VEC = kBlkPanel / 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int i = lane & 15, q = lane >> 4;
+    const int m0 = by * BM, n0 = bx * BN;             // block origin
+    const int tm0 = wm * WM, tn0 = wn * WN;           // my first row / column tile inside the block
+    const float* A = a.A + g * a.sA;
+    const float* B = a.B + g * a.sB;
+    float* C = a.C + g * a.sC;
+    float* As = lds;                                  // [2][kBlkPanel][LDA]   (TN)
+    float* Bs = lds + 2 * L::kA;                      // [2][kBlkPanel][LDB]
+
+    f32x4 acc0[WM][WN], acc1[WM][WN];
+#pragma unroll
+    for (int x = 0; x < WM; ++x)
+#pragma unroll
+        for (int y = 0; y < WN; ++y) acc0[x][y] = acc1[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float asum[WM];
+#pragma unroll
+    for (int x = 0; x < WM; ++x) asum[x] = 0.f;
+    const bool want_sum = MODE == 2 && a.colsum && bx == 0 && wn == 0;   // the tiles of output column 0 own the column sums
+
+    FragT<kBlkPanel * BM / 1024> ra;                                    // staged operands on their way to LDS
+    FragT<kBlkPanel * BN / 1024> rb;
+    FragT<VEC> fa[WM];                                                  // NN: my rows of A (next panel)
+    auto load = [&](int k0) __attribute__((always_inline)) {
+        if (MODE == 2) blk_load<BM>(ra, A, a.lda, m0, k0, tid);
+        else {
+#pragma unroll
+            for (int x = 0; x < WM; ++x) load_direct<true>(fa[x], A, a.lda, m0 + (tm0 + x) * kTile, a.M, k0, a.K, lane);
+        }
+        blk_load<BN>(rb, B, a.ldb, n0, k0, tid);
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        if (MODE == 2) blk_store<BM>(ra, As + buf * L::kA, tid);
+        blk_store<BN>(rb, Bs + buf * L::kB, tid);
+    };
+
+    // panel p: registers -> LDS buffer p & 1 (its last readers, panel p - 2, are behind the barrier of panel p - 1), panel
+    // p + 1's global loads issued, ONE barrier, MFMAs -- the loads fly under them
+    const int np = a.K / kBlkPanel;
+    load(0);
+    for (int p = 0; p < np; ++p) {
+        FragT<VEC> ca[WM];                    // NN: this panel's rows of A
+#pragma unroll
+        for (int x = 0; x < WM; ++x) ca[x] = fa[x];
+        stage(p & 1);
+        if (p + 1 < np) load((p + 1) * kBlkPanel);
+        __syncthreads();
+        const float* Ap = As + (p & 1) * L::kA;
+        const float* Bp = Bs + (p & 1) * L::kB;
+        // all fragments of the panel first (ds_reads in flight together), then its MFMAs back to back
+        float av[VEC][4][WM], bv[VEC][4][WN];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = 16 * j + 4 * q + t;
+#pragma unroll
+                for (int x = 0; x < WM; ++x) av[j][t][x] = MODE == 2 ? Ap[k * LDA + (tm0 + x) * kTile + i] : elem(ca[x].v[j], t);
+#pragma unroll
+                for (int y = 0; y < WN; ++y) bv[j][t][y] = Bp[k * LDB + (tn0 + y) * kTile + i];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);     // (the scheduler would sink every read to just before its use again)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (MODE == 2 && want_sum) {
+#pragma unroll
+                    for (int x = 0; x < WM; ++x) asum[x] += av[j][t][x];
+                }
+#pragma unroll
+                for (int x = 0; x < WM; ++x)
+#pragma unroll
+                    for (int y = 0; y < WN; ++y) {
+                        if (t & 1) acc1[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t][x], bv[j][t][y], acc1[x][y], 0, 0, 0);
+                        else acc0[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t][x], bv[j][t][y], acc0[x][y], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    __syncthreads();                       // every wave is done with the staged panels: the epilogue re-uses the LDS
+
+    // epilogue, tile by tile, exactly gemm16_tile's: lane holds C[row][col], col = lane & 15, row = 4 (lane >> 4) + r
+    float* T = lds + w * 400;             // this wave's scratch for the first-layer work (the staged panels are done with)
+#pragma unroll
+    for (int x = 0; x < WM; ++x) {
+#pragma unroll
+        for (int y = 0; y < WN; ++y) {
+            const f32x4 acc = acc0[x][y] + acc1[x][y];
+            const int tm = m0 + (tm0 + x) * kTile, tn = n0 + (tn0 + y) * kTile;
+            const int col = tn + i;
+            const float bias = 0.f;
+            float vout[4];
+            const bool store_c = MODE != 1 || !a.skip_c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = tm + 4 * q + r;
+                float v = acc[r] + bias;
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                if (MODE == 1 && a.mask) {
+                    const float s = a.mask[g * a.sMask + (long long)row * a.ldmask + col];
+                    v = s > 0.f ? v : 0.f;
+                }
+                vout[r] = v;
+                if (store_c) {
+                    float* dst = C + (long long)row * a.ldc + col;
+                    RRL_HANDOVER_STORE(dst, a.accumulate ? (*dst + v) : v);
+                }
+            }
+            if constexpr (MODE == 1) {
+                if (a.x) {
+                    const int rr = lane & 15, dd = lane >> 4;
+                    const float xv = dd < a.din ? a.x[(long long)(tm + rr) * a.ldx + dd] : 0.f;
+                    const float wv = dd < a.din ? a.W1[((long long)g * a.N + tn + rr) * a.din + dd] : 0.f;
+                    tile_sync<true>();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[(4 * q + r) * 17 + i] = vout[r];
+                    T[272 + rr * 4 + dd] = xv;
+                    T[336 + rr * 4 + dd] = wv;
+                    tile_sync<true>();
+                    float sw = 0.f, sb = 0.f, sx = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float tc = T[k * 17 + rr];
+                        sw = fmaf(tc, T[272 + k * 4 + dd], sw);
+                        sb += tc;
+                        sx = fmaf(T[rr * 17 + k], T[336 + k * 4 + dd], sx);
+                    }
+                    const int tby = tm / kTile, tbx = tn / kTile;
+                    if (a.first_part && dd < a.din)
+                        a.first_part[tby * a.first_stride + ((long long)g * a.N + tn + rr) * a.din + dd] = sw;
+                    if (a.first_part && dd == 0)
+                        a.first_part[tby * a.first_stride + (long long)a.G * a.N * a.din + (long long)g * a.N + tn + rr] = sb;
+                    if (a.dx_part && dd < a.din)
+                        a.dx_part[(((long long)tbx * a.G + g) * a.M + tm + rr) * a.din + dd] = sx;
+                }
+            }
+        }
+        if (MODE == 2 && want_sum) {
+            float tot = asum[x] + __shfl_xor(asum[x], 16);
+            tot += __shfl_xor(tot, 32);
+            if (lane < 16) a.colsum[g * a.sColsum + m0 + (tm0 + x) * kTile + lane] = tot;
+        }
+    }
+}
+
+// HiddenGroup with its tile counts in BLOCK units (build_hidden_blocks)
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_block_pack_kernel(const HiddenGroup* __restrict__ groups, rrl_pack::Idx ix) {
+    __shared__ __attribute__((aligned(16))) float lds[BlkLds<WM, WN>::kFloats];
+    int s, block;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, block)) return;
+    const HiddenGroup& hg = groups[s];
+    int k = 0;
+    while (k + 1 < hg.n && block >= hg.first[k + 1]) ++k;
+    const int local = block - hg.first[k];
+    const int g = local / hg.per_head[k], b = local - g * hg.per_head[k];
+    if (b < hg.tn_tiles[k]) {
+        GemmArgs ga = hg.tn[k];
+        globalize(ga);
+        gemm_block<2, WM, WN>(ga, lds, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
+    } else {
+        const int c = b - hg.tn_tiles[k];
+        GemmArgs ga = hg.nn[k];
+        globalize(ga);
+        gemm_block<1, WM, WN>(ga, lds, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
     }
 }
 
@@ -561,6 +780,10 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
 // Several independent stacks (different networks and / or different inputs) in one launch: flat grid over
 // (stack, head, row tile).  The acting pass evaluates the task policy and the recovery policy on the same
 // observations (experiment.py:546-577): neither depends on the other.
+__device__ __forceinline__ void globalize(StackArgs& a) {
+    rrl_pack::to_global_all(a.x, a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.h1, a.h2, a.out);
+    rrl_pack::globalize(a.in_head);
+}
 struct StackGroup {
     StackArgs a[kMaxGroup];
     float* partial[kMaxGroup];      // split variant only
@@ -846,10 +1069,13 @@ __device__ __forceinline__ void mlp3_fwd_split_group_body(const StackGroup& sg, 
     const int local = block - sg.first[k];
     const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
     float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + 20);
-    const StackArgs a = sg.a[k];             // this workgroup's member, copied out of the group (see gemm16_group_body)
+    StackArgs a = sg.a[k];                   // this workgroup's member, copied out of the group (see gemm16_group_body)
+    globalize(a);
+    float* partial = sg.partial[k];
+    rrl_pack::to_global(partial);
     const int G = sg.G[k];
-    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, h2s);
-    else mlp3_fwd_split_body<R, 0>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, h2s);
+    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
+    else mlp3_fwd_split_body<R, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
 }
 
 template <int R>
@@ -866,15 +1092,18 @@ __device__ __forceinline__ void mlp3_fwd_split_mixed_body(const StackGroup& sg, 
     while (k + 1 < sg.n && block >= sg.first[k + 1]) ++k;
     const int local = block - sg.first[k];
     const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
-    const StackArgs a = sg.a[k];
+    StackArgs a = sg.a[k];
+    globalize(a);
+    float* partial = sg.partial[k];
+    rrl_pack::to_global(partial);
     const int G = sg.G[k];
     if (sg.big[k]) {
-        if (a.H == 256) mlp3_fwd_split_body<kBigR, 256>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, lds);
-        else mlp3_fwd_split_body<kBigR, 0>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, lds);
+        if (a.H == 256) mlp3_fwd_split_body<kBigR, 256>(a, partial, bx, rest % G, rest / G, G, lds, lds);
+        else mlp3_fwd_split_body<kBigR, 0>(a, partial, bx, rest % G, rest / G, G, lds, lds);
     } else {
         float* h2s = lds + kStackRows * (kStackMaxH + 20);
-        if (a.H == 256) mlp3_fwd_split_body<1, 256>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, h2s);
-        else mlp3_fwd_split_body<1, 0>(a, sg.partial[k], bx, rest % G, rest / G, G, lds, h2s);
+        if (a.H == 256) mlp3_fwd_split_body<1, 256>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
+        else mlp3_fwd_split_body<1, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
     }
 }
 
@@ -1216,6 +1445,11 @@ __device__ __forceinline__ void head_bwd_dispatch(const HeadBwdArgs& hb, int bx,
 
 // independent head backwards (e.g. critic loss on (s,a) and policy loss on (s,pi)) in one launch: flat grid over
 // (problem, head, column block)
+__device__ __forceinline__ void globalize(HeadBwdArgs& hb) {
+    rrl_loss_t& l = hb.la;
+    rrl_pack::to_global_all(l.out, l.out_t, l.v0, l.v1, l.v2, l.v3, l.alpha, l.d_action, l.loss, hb.h2, hb.W3, hb.dW3, hb.db3,
+                            hb.dh2);
+}
 struct HeadBwdGroup {
     HeadBwdArgs p[kMaxGroup];
     int G[kMaxGroup], blocks_x[kMaxGroup];
@@ -1227,7 +1461,8 @@ __device__ __forceinline__ void head_bwd_group_body(const HeadBwdGroup& hg, int 
     int k = 0;
     while (k + 1 < hg.n && block >= hg.first[k + 1]) ++k;
     const int local = block - hg.first[k];
-    const HeadBwdArgs hb = hg.p[k];          // this workgroup's member, copied out of the group (see gemm16_group_body)
+    HeadBwdArgs hb = hg.p[k];                // this workgroup's member, copied out of the group (see gemm16_group_body)
+    globalize(hb);
     head_bwd_dispatch(hb, local % hg.blocks_x[k], local / hg.blocks_x[k], red, dsh);
 }
 
@@ -1304,7 +1539,7 @@ __device__ __forceinline__ void fused_hidden_body(const FusedHiddenGroup& fg, in
     const bool tn = b < hg.tn_tiles[k];
     const int c = tn ? b : b - hg.tn_tiles[k];
     const int tx = tn ? hg.tn_tiles_x[k] : hg.nn_tiles_x[k];
-    const GemmArgs ga = tn ? hg.tn[k] : hg.nn[k];
+    const GemmArgs ga = tn ? hg.tn[k] : hg.nn[k];     // (per WAVE here: not passed through rrl_pack::to_global, whose "s" wants scalars)
     if (!fg.fused[k]) {                                // (members of a fused launch have full aligned tiles)
         if (tn) gemm16_tile<2, true, false, NoPrologue, true>(ga, As, Bs, c % tx, c / tx, g);
         else gemm16_tile<1, true, false, NoPrologue, true>(ga, As, Bs, c % tx, c / tx, g);
@@ -1652,6 +1887,29 @@ static int pack_small_r2_min_seeds() {
     return v;
 }
 
+// Block form of the packed hidden-layer backward (gemm_block_pack_kernel): RRL_PACK_BLOCK = "WM WN" as two digits (22: 64 x 64
+// blocks, 12: 32 x 64, 11: 32 x 32), 0 = the tile kernel; RRL_PACK_BLOCK_MIN_SEEDS = seeds from which it is used.
+static int pack_block(int S) {
+    static const int shape = pack_threshold("RRL_PACK_BLOCK", 12), min_seeds = pack_threshold("RRL_PACK_BLOCK_MIN_SEEDS", 3);
+    return S >= min_seeds ? shape : 0;
+}
+// tile counts of a HiddenGroup -> block counts; false: some member has no whole number of full, aligned blocks
+static bool hidden_blocks(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg, int wm, int wn) {
+    const int bm = 32 * wm, bn = 32 * wn;
+    for (int k = 0; k < n; ++k) {
+        const rrl_hidden_bwd_t& p = ps[k];
+        if (!hg.fast[k] || p.H % bm || p.H % bn || p.B % bm || p.H % kBlkPanel || p.B % kBlkPanel) return false;
+        const int tx = p.H / bn;
+        hg.tn_tiles_x[k] = tx;
+        hg.tn_tiles[k] = p.dW2 ? tx * (p.H / bm) : 0;
+        hg.nn_tiles_x[k] = tx;
+        hg.per_head[k] = hg.tn_tiles[k] + tx * (p.B / bm);
+        hg.first[k + 1] = hg.first[k] + hg.per_head[k] * p.G;
+    }
+    for (int k = n; k < kMaxGroup; ++k) hg.first[k + 1] = hg.first[n];
+    return true;
+}
+
 int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_bwd_t* const* members, void* stream) {
     rrl_pack::Key key;
     if (!pack_key(1, S, n, members, key)) return RRL_EINVAL;
@@ -1661,6 +1919,7 @@ int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_b
         bool fused = false;
         for (int s = 0; s < S; ++s) fused = fused || any_fused(n[s], members[s]);
         rrl_pack::Idx ix;
+        int shape = 0;
         if (fused) {
             std::vector<FusedHiddenGroup> groups;
             const int rc = build_pack<FusedHiddenGroup>(S, n, members, groups, ix, build_fused_hidden_group);
@@ -1670,19 +1929,39 @@ int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_b
             plan = rrl_pack::store(key, groups.data(), sizeof(FusedHiddenGroup) * S, st);
         } else {
             std::vector<HiddenGroup> groups;
-            const int rc = build_pack<HiddenGroup>(S, n, members, groups, ix, build_hidden_group);
+            int rc = build_pack<HiddenGroup>(S, n, members, groups, ix, build_hidden_group);
             if (rc != RRL_OK) return rc;
+            shape = pack_block(S);
+            if (shape) {       // every seed's members in whole blocks, or the launch keeps the tile kernel
+                const int wm = shape / 10, wn = shape % 10;
+                bool ok = (wm == 1 || wm == 2) && (wn == 1 || wn == 2) && wm <= wn;
+                std::vector<HiddenGroup> blocks = groups;
+                for (int s = 0; ok && s < S; ++s) ok = hidden_blocks(n[s], members[s], blocks[s], wm, wn);
+                if (ok) {
+                    groups.swap(blocks);
+                    for (int s = 0; s < S; ++s) ix.first[s + 1] = ix.first[s] + groups[s].first[n[s]];
+                    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+                } else {
+                    shape = 0;
+                }
+            }
             plan = rrl_pack::store(key, groups.data(), sizeof(HiddenGroup) * S, st);
         }
         if (!plan) return RRL_ELAUNCH;
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         plan->i0 = fused;
-        plan->i1 = pack_panel(S);
+        plan->i1 = shape ? -shape : pack_panel(S);
     }
     if (plan->i0)
         hipLaunchKernelGGL(hidden_head_pack_kernel, dim3(plan->grid), dim3(256), kFusedLdsFloats * 4, st, (const FusedHiddenGroup*)plan->dev,
                            plan->ix);
+    else if (plan->i1 == -22)
+        hipLaunchKernelGGL((gemm_block_pack_kernel<2, 2>), dim3(plan->grid), dim3(256), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
+    else if (plan->i1 == -12)
+        hipLaunchKernelGGL((gemm_block_pack_kernel<1, 2>), dim3(plan->grid), dim3(256), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
+    else if (plan->i1 == -11)
+        hipLaunchKernelGGL((gemm_block_pack_kernel<1, 1>), dim3(plan->grid), dim3(256), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
     else if (plan->i1 == 64)
         hipLaunchKernelGGL(gemm16_pack_kernel<64>, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
     else if (plan->i1 == 32)

@@ -19,6 +19,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include "rrl_hip.h"
+
 namespace rrl_pack {
 
 constexpr int kMaxSeeds = 16;
@@ -59,6 +61,32 @@ __device__ __forceinline__ bool locate(const Idx& ix, int b, int& s, int& local)
         local = (b >> 3) * ix.p + x / ix.sp;
     }
     return s < ix.S && local < ix.first[s + 1] - ix.first[s];
+}
+
+// A packed kernel copies its argument block out of DEVICE memory, and a pointer loaded from memory is a generic ("flat")
+// pointer to the compiler: every access through it becomes a flat_load / flat_store, which counts against BOTH the vector
+// memory and the LDS counters and may complete out of order -- each LDS wait then drains every global load in flight
+// (s_waitcnt vmcnt(0) lgkmcnt(0)), i.e. the overlap of the next panel's loads with LDS-fed MFMAs that the solo kernels
+// (pointers in kernel arguments = known global) rely on is gone.  Passing the copied pointers through the global address
+// space tells the compiler what they are; the bits of the pointer (and of every result) do not change.  (The empty asm keeps
+// the optimiser from folding the cast pair away before address spaces are inferred; "s": an argument block is per seed,
+// i.e. wave-uniform, and stays in scalar registers as the base of global_load v, v_offset, s[base].)
+template <class T>
+__device__ __forceinline__ void to_global(T*& p) {
+    auto g = (__attribute__((address_space(1))) T*)p;
+    asm volatile("" : "+s"(g));
+    p = (T*)g;
+}
+template <class... P>
+__device__ __forceinline__ void to_global_all(P&... p) {
+    (to_global(p), ...);
+}
+
+__device__ __forceinline__ void globalize(rrl_replay_t& rb) {
+    to_global_all(rb.s, rb.a, rb.r, rb.s2, rb.m, rb.state, rb.pos_cnt);
+}
+__device__ __forceinline__ void globalize(rrl_policy_head_t& h) {
+    to_global_all(h.head, h.eps, h.scale, h.bias, h.action, h.logp, h.mean_out, h.obs_in, h.obs_out, h.log_std);
 }
 
 // host: choose the mapping for `ix` (first[] and S filled in) and return the grid size

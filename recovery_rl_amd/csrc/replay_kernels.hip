@@ -490,9 +490,15 @@ __global__ __launch_bounds__(1024) void sample_pack_kernel(const SamplePack* __r
     int s, block;
     if (!rrl_pack::locate(ix, blockIdx.x, s, block)) return;
     // a sampler workgroup copies its own draw, a noise workgroup the noise block, out of device memory
-    if (block == 0) { const DrawArgs d = packs[s].a; draw_body(d, smem); return; }
-    if (block == 1) { const DrawArgs d = packs[s].b; draw_body(d, smem); return; }
-    const NoiseArgs nz = packs[s].nz;
+    // (pointers that come out of device memory are passed through the global address space: rrl_pack::to_global)
+    auto glob = [](DrawArgs& d) __attribute__((always_inline)) {
+        rrl_pack::globalize(d.rb);
+        rrl_pack::to_global_all(d.counter_dev, d.out.s, d.out.a, d.out.r, d.out.s2, d.out.m, d.out.idx, d.out.xu, d.out.x2u, d.out.xpu);
+    };
+    if (block == 0) { DrawArgs d = packs[s].a; glob(d); draw_body(d, smem); return; }
+    if (block == 1) { DrawArgs d = packs[s].b; glob(d); draw_body(d, smem); return; }
+    NoiseArgs nz = packs[s].nz;
+    rrl_pack::to_global_all(nz.counter_dev, nz.out);
     sample_group_body(packs[s].a, packs[s].b, nz, block, smem);
 }
 

@@ -334,7 +334,15 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_pack_kernel(const 
                                                                           rrl_pack::Idx ix) {
     int s, local;
     if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
-    const StepPushArgs p = ps[s];
+    StepPushArgs p = ps[s];
+    // copied out of device memory: the pointers are passed through the global address space (rrl_pack::to_global)
+    StepArgs& e = p.step;
+    rrl_pack::to_global_all(e.pos, e.action, e.noise, e.counter_dev, e.next_obs, e.obs, e.reward, e.done, e.constraint, e.success,
+                            e.ep_done, e.t, e.status, p.task_action, p.recovery, p.sel_z, p.sel_rec_action, p.sel_real_out,
+                            p.sel_recovery_out, p.stats, p.reward_sums, p.ep_reward);
+    rrl_pack::globalize(p.sel_rec_head);
+    rrl_pack::globalize(p.memory);
+    rrl_pack::globalize(p.recovery_memory);
     step_push_body<ENV, SPECULATE>(p, local, ix.first[s + 1] - ix.first[s]);
 }
 

@@ -391,7 +391,8 @@ __device__ __forceinline__ void adam_multi_body(const AdamSegs& a, int n_seg, fl
                                                 int blk, float* sh) {
     int k = 0;
     while (k + 1 < n_seg && blk >= a.first_block[k + 1]) ++k;
-    const rrl_adam_seg_t sg = a.seg[k];
+    rrl_adam_seg_t sg = a.seg[k];
+    rrl_pack::to_global_all(sg.p, sg.g, sg.m, sg.v, sg.step_dev, sg.target, sg.g2, sg.g_part);   // packed launch: copied out of memory
     const int block = blk - a.first_block[k], blocks = a.first_block[k + 1] - a.first_block[k];
     uint64_t step = 0;
     unsigned long long ticket = ~0ULL;
