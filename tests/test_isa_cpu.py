@@ -1,0 +1,77 @@
+"""Properties of the COMPILED gfx950 code that the timings rest on, checked on the code objects inside librrl_hip.so
+(no GPU needed: the library is cross-compiled here; `llvm-objdump` ships with ROCm).
+
+* The packed kernels (`*_pack_kernel`, csrc/pack.hpp) copy their argument blocks out of device memory.  A pointer loaded
+  from memory is a generic pointer to the compiler, and accesses through it are FLAT instructions: they count against the
+  vector-memory AND the LDS counter, so every LDS wait drains the global loads in flight.  `rrl_pack::to_global` passes the
+  copied pointers through the global address space; this test keeps it that way (a new pointer field that is not passed
+  through it shows up here as flat loads).
+* No kernel of the hot path keeps data in scratch memory beyond a few spilled scalars.
+"""
+import glob
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from recovery_rl_amd import _lib
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    """{demangled-ish kernel symbol: list of instruction mnemonics} for every kernel of the built library"""
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not in this image")
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    d = tmp_path_factory.mktemp("isa")
+    so = shutil.copy(_lib.SO_PATH, d)                       # the bundles are extracted next to the input file
+    subprocess.run([OBJDUMP, "--offloading", so], cwd=d, check=True, capture_output=True)
+    out = {}
+    for co in sorted(glob.glob(os.path.join(d, "*gfx950"))):
+        text = subprocess.run([OBJDUMP, "-d", co], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+            if m:
+                name = m.group(1)
+                out[name] = []
+            elif name and line.startswith("\t"):
+                out[name].append(line.split()[0])
+    assert out, "no gfx950 code object in the library"
+    return out
+
+
+def test_packed_kernels_use_global_not_flat_memory_instructions(kernels):
+    packed = {k: v for k, v in kernels.items() if "pack_kernel" in k}
+    # every packed launch of the iteration: draws, forwards, head / hidden backward (tile and block form), Adam, env step
+    for piece in ("sample_pack_kernel", "mlp3_fwd_split_pack_kernel", "head_bwd_pack_kernel", "gemm16_pack_kernel",
+                  "gemm_block_pack_kernel", "adam_pack_kernel", "step_push_pack_kernel"):
+        assert any(piece in k for k in packed), piece
+    for name, ins in packed.items():
+        if "hidden_head_pack_kernel" in name:        # opt-in fused variant (per-wave argument blocks), not in the default path
+            continue
+        flat_loads = sum(i.startswith("flat_load") for i in ins)
+        global_loads = sum(i.startswith("global_load") for i in ins)
+        assert flat_loads == 0 and global_loads > 0, (name, flat_loads, global_loads)
+        # (a handful of flat STORES / atomics through generic LDS-or-global helpers exist in the solo twins as well)
+        assert sum(i.startswith(("flat_store", "flat_atomic")) for i in ins) <= 4, name
+
+
+def test_solo_kernels_of_the_iteration_have_no_flat_loads_either(kernels):
+    for piece in ("gemm16_group_kernel", "head_bwd_group_kernel", "mlp3_fwd_split_group_kernel", "adam_multi_kernel",
+                  "sample_group_kernel", "step_push_kernel"):
+        hits = [k for k in kernels if piece in k]
+        assert hits, piece
+        for k in hits:
+            assert sum(i.startswith("flat_load") for i in kernels[k]) <= 3, k
+
+
+def test_hot_kernels_do_not_live_in_scratch(kernels):
+    for name, ins in kernels.items():
+        n = sum(i.startswith("scratch_") for i in ins)
+        assert n <= 16, (name, n)          # the f16x3 planner spills five scalars around its main loop; nothing else does
