@@ -1,8 +1,10 @@
 #!/bin/bash
 # Headline leg (22-launch graph, 4096 envs) under HIP runtime knobs that touch kernel boundaries / graph submission.
 # One line per setting: ms per iteration.  (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is the launcher's default)
+# Every run under its own `timeout`: ROC_SYSTEM_SCOPE_SIGNAL=0 HANGS the bench process (first run of this script, round 3:
+# the call sat in that setting until gpurun's limit; round3_runtime_knobs.txt holds the settings before it).
 mkdir -p gpurun_out
-run() { env "$@" python bench.py --no_cpu_baseline --no_legs --no_planner 2>/dev/null | python -c "
+run() { timeout 120 env "$@" python bench.py --no_cpu_baseline --no_legs --no_planner 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
