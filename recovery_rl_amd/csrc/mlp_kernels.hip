@@ -810,6 +810,18 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_group_kernel(StackGroup sg) {
 // columns, owns 64 hidden-2 columns (64 KB of W2) and emits a PARTIAL last-layer sum; a tiny second kernel
 // adds the four partials in a fixed order (deterministic).
 constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.320 ms per iteration)
+#ifndef RRL_COALESCE_W2
+#define RRL_COALESCE_W2 0     /* opt-in, see kSplitPad below: built and measured at the end of round 3, not the default */
+#endif
+constexpr bool kCoalesceW2 = RRL_COALESCE_W2 != 0;   // multi-row-tile forwards: whole-line W2 loads restaged through LDS
+// pad floats per row of the h1 tile: rows stay 16-byte aligned and 8 consecutive rows start in 8 different bank quads (4 i mod
+// 32, as 20 i mod 32 did), i.e. the ds_read_b128 of layer 2 and layer 1's stores are as conflict-free as with the 20 of the
+// 16-wave kernel above -- but the 32-row tile + the four 1 KB restaging strips are 37.4 KB, four workgroups per CU (the 4096-row
+// forward is 1 024 workgroups = ONE round; at 39.4 KB only three fit and the second round ate what the loads had gained)
+#ifndef RRL_SPLIT_PAD
+#define RRL_SPLIT_PAD 20
+#endif
+constexpr int kSplitPad = RRL_SPLIT_PAD;
 
 // R = row tiles (of 16 rows) per workgroup.  R = 1 for the small update batches (latency-bound: as many workgroups as
 // possible).  Large batches (the acting pass, 4096 rows) are bound by re-streaming W2 from L2 once per row tile (64 MB
@@ -827,7 +839,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     RRL_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = bx * (R * kStackRows);
-    const int H = HC ? HC : a.H, ldh = H + 20, HS = H / kSplit, ld2 = HS + 1;
+    const int H = HC ? HC : a.H, ldh = H + kSplitPad, HS = H / kSplit, ld2 = HS + 1;
     constexpr int kJ = HC ? HC / 16 : kStackMaxH / 16;             // K chunks of layer 2
     constexpr int kU = HC ? HC / 64 : kStackMaxH / 64;             // layer-1 column tiles per wave
     constexpr int kT3 = HC ? HC / (16 * kSplit) : kStackMaxH / (16 * kSplit);
@@ -913,8 +925,22 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         w1b[u] = (q < din) ? wv1 : 0.f;
         bias1[u] = b1[t * 16 + i];
     }
+    // My 16 rows of W2 as MFMA B operands: lane (i, q) holds W2[n2 + i][16 j + 4 q .. + 3] in wv[j].
+    // Loading them in that layout has every 16-lane pass of a global_load_dwordx4 touch 16 different 128-byte lines and use
+    // 16 bytes of each: with several workgroups per CU streaming W2 at once (the 4096-row acting forwards, the packed
+    // forwards) a CU pulls ~15 bytes per cycle and the loads are what the kernel waits for (profiles/
+    // round3_fwd_timing_4096_2.txt: 17 000 of 28 700 cycles).  kCoalesced (the multi-row-tile kernels at H = 256): the wave
+    // loads 8 rows x one whole line per instruction (lane l: row l >> 3, 16 bytes at 4 (l & 7)) and restages each
+    // instruction's 1 KB through its own LDS strip into fragment order after layer 1 -- the same values in the same
+    // registers, so nothing downstream changes.
+    constexpr bool kCoalesced = kCoalesceW2 && R > 1 && HC == 256;
     float4 wv[kJ];
-    {
+    if constexpr (kCoalesced) {
+        const float* wbase = W2 + (long long)(n2 + (lane >> 3)) * H + 4 * (lane & 7);
+#pragma unroll
+        for (int pj = 0; pj < kJ; ++pj)      // wv[2 p + c] for now: rows 8 c .. 8 c + 7, floats 32 p .. 32 p + 31
+            wv[pj] = *reinterpret_cast<const float4*>(wbase + (long long)(8 * (pj & 1)) * H + 32 * (pj >> 1));
+    } else {
         const float* wrow = W2 + (long long)(n2 + i) * H + 4 * q;
 #pragma unroll
         for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
@@ -954,6 +980,25 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
                     }
                 }
             }
+        }
+    }
+    if constexpr (kCoalesced) {
+        // 1 KB strip per wave behind the h1 tile; a wave's LDS instructions execute in order, so write -> read -> next write
+        // need no waits of their own.  Stage (p, c) holds rows 8 c .. 8 c + 7: the lanes whose row i lies there take their two
+        // fragments of panel p from it.
+        float* stg = h1s + R * kStackRows * (kStackMaxH + kSplitPad) + wave * 256;
+        const bool upper = (i >> 3) != 0;
+        const int rd = (i & 7) * 32 + 4 * q;
+#pragma unroll
+        for (int p = 0; p < kJ / 2; ++p) {
+            const float4 r0 = wv[2 * p], r1 = wv[2 * p + 1];
+            *reinterpret_cast<f32x4*>(stg + 4 * lane) = f32x4{r0.x, r0.y, r0.z, r0.w};
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + rd), a1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
+            *reinterpret_cast<f32x4*>(stg + 4 * lane) = f32x4{r1.x, r1.y, r1.z, r1.w};
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(stg + rd), b1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
+            const f32x4 f0 = upper ? b0 : a0, f1 = upper ? b1 : a1;
+            wv[2 * p] = make_float4(f0[0], f0[1], f0[2], f0[3]);
+            wv[2 * p + 1] = make_float4(f1[0], f1[1], f1[2], f1[3]);
         }
     }
     __syncthreads();
@@ -1049,14 +1094,15 @@ constexpr int kPackR = RRL_PACK_R;   // ... of the packed launch from kPackMinSe
 constexpr int kPackMinSeeds = RRL_PACK_MIN_SEEDS;
 constexpr int kSplitSmallM = 1024;
 constexpr size_t split_lds_floats(int R) {
-    return size_t(R) * kStackRows * (kStackMaxH + 20) +
-           (R > 1 ? 0 : size_t(R) * kStackRows * (kStackMaxH / kSplit + 1));      // R > 1: h2 aliases h1
+    return size_t(R) * kStackRows * (kStackMaxH + kSplitPad) +
+           (R > 1 ? (kCoalesceW2 ? 4 * 256 : 0)                                   // R > 1: h2 aliases h1; W2 restaging strips
+                  : size_t(R) * kStackRows * (kStackMaxH / kSplit + 1));
 }
 
 template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + 20);
+    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
     if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
     else mlp3_fwd_split_body<R, 0>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
 }
@@ -1068,7 +1114,7 @@ __device__ __forceinline__ void mlp3_fwd_split_group_body(const StackGroup& sg, 
     while (k + 1 < sg.n && block >= sg.first[k + 1]) ++k;
     const int local = block - sg.first[k];
     const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
-    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + 20);
+    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
     StackArgs a = sg.a[k];                   // this workgroup's member, copied out of the group (see gemm16_group_body)
     globalize(a);
     float* partial = sg.partial[k];
@@ -1101,7 +1147,7 @@ __device__ __forceinline__ void mlp3_fwd_split_mixed_body(const StackGroup& sg, 
         if (a.H == 256) mlp3_fwd_split_body<kBigR, 256>(a, partial, bx, rest % G, rest / G, G, lds, lds);
         else mlp3_fwd_split_body<kBigR, 0>(a, partial, bx, rest % G, rest / G, G, lds, lds);
     } else {
-        float* h2s = lds + kStackRows * (kStackMaxH + 20);
+        float* h2s = lds + kStackRows * (kStackMaxH + kSplitPad);
         if (a.H == 256) mlp3_fwd_split_body<1, 256>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
         else mlp3_fwd_split_body<1, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
     }
