@@ -12,7 +12,9 @@ so = "/tmp/librrl_hip_timing.so"
 os.environ["RRL_HIP_LIB"] = so
 from recovery_rl_amd import _lib  # noqa: E402
 
-subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + _lib.HIPCC_FLAGS + ["-DRRL_FWD_TIMING", "-I", _lib.INCLUDE,
+# RRL_TIMING_FLAGS: extra compile flags for the timing build, e.g. "-DRRL_COALESCE_W2=1 -DRRL_SPLIT_PAD=4"
+subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + _lib.HIPCC_FLAGS + ["-DRRL_FWD_TIMING"] +
+                      os.environ.get("RRL_TIMING_FLAGS", "").split() + ["-I", _lib.INCLUDE,
                       "-o", so] + _lib._sources())
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -46,5 +48,12 @@ for k, nme in enumerate(names):
     print("  %-40s mean %8.1f  min %6d  max %6d ticks" % (nme, d.mean(), d.min(), d.max()))
 tot = t[:, 5] - t[:, 0]
 print("  workgroup total mean %.1f ticks; first start -> last end %d ticks" % (tot.mean(), t[:, 5].max() - t[:, 0].min()))
+# the cycle counters are not comparable across workgroups (per-CU / per-XCD counters); slots 6 / 7 hold the global 100 MHz
+# real-time counter at the workgroup's start and end (10 ns per tick)
+rs, re = t[:, 6], t[:, 7]
+print("  real time (10 ns ticks): starts spread over %d ticks, first start -> last end %d ticks, mean workgroup %.1f ticks"
+      % (rs.max() - rs.min(), re.max() - rs.min(), (re - rs).mean()))
+q = np.percentile(rs - rs.min(), [10, 50, 90, 99])
+print("  start time of the workgroups after the first one: 10 %% %d, 50 %% %d, 90 %% %d, 99 %% %d ticks" % tuple(q))
 order = np.argsort(t[:, 0])
 print("  start spread: %d ticks between the first and the last workgroup start" % (t[:, 0].max() - t[:, 0].min()))

@@ -657,7 +657,12 @@ __device__ unsigned long long rrl_fwd_stamps[8 * 8192];
 #define RRL_STAMP(k)                                                                              \
     do {                                                                                          \
         const unsigned flat_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);    \
-        if (threadIdx.x == 0 && flat_ < 8192) rrl_fwd_stamps[8 * flat_ + (k)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && flat_ < 8192) {                                                   \
+            rrl_fwd_stamps[8 * flat_ + (k)] = __builtin_readcyclecounter();                       \
+            /* the cycle counters are not comparable across (or even within) XCDs; the 100 MHz real-time counter is global */ \
+            if ((k) == 0) rrl_fwd_stamps[8 * flat_ + 6] = __builtin_amdgcn_s_memrealtime();       \
+            if ((k) == 5) rrl_fwd_stamps[8 * flat_ + 7] = __builtin_amdgcn_s_memrealtime();       \
+        }                                                                                         \
     } while (0)
 #else
 #define RRL_STAMP(k)
@@ -811,13 +816,12 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_group_kernel(StackGroup sg) {
 // adds the four partials in a fixed order (deterministic).
 constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.320 ms per iteration)
 #ifndef RRL_COALESCE_W2
-#define RRL_COALESCE_W2 0     /* opt-in, see kSplitPad below: built and measured at the end of round 3, not the default */
+#define RRL_COALESCE_W2 0     /* opt-in: built and measured at the end of round 3, not the default */
 #endif
 constexpr bool kCoalesceW2 = RRL_COALESCE_W2 != 0;   // multi-row-tile forwards: whole-line W2 loads restaged through LDS
-// pad floats per row of the h1 tile: rows stay 16-byte aligned and 8 consecutive rows start in 8 different bank quads (4 i mod
-// 32, as 20 i mod 32 did), i.e. the ds_read_b128 of layer 2 and layer 1's stores are as conflict-free as with the 20 of the
-// 16-wave kernel above -- but the 32-row tile + the four 1 KB restaging strips are 37.4 KB, four workgroups per CU (the 4096-row
-// forward is 1 024 workgroups = ONE round; at 39.4 KB only three fit and the second round ate what the loads had gained)
+// pad floats per row of the h1 tile (a knob of the LDS-footprint experiments: 4 keeps rows 16-byte aligned and as
+// conflict-free as 20; the footprint that matters is the one that puts FOUR workgroups of the 4096-row forward on a CU:
+// 35.3 KB does, 37.4 KB leaves two)
 #ifndef RRL_SPLIT_PAD
 #define RRL_SPLIT_PAD 20
 #endif
@@ -946,6 +950,35 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
     }
     const float bias2 = b2[n2 + i];
+    if constexpr (kCoalesced) {
+        // Restage BEFORE layer 1, in the h1 tile's own space (nothing lives there yet; the x strip of the input head above is
+        // behind its barrier): 1 KB per wave at h1s + 256 wave, no LDS of its own -- the workgroup keeps the LDS footprint that
+        // puts four of them on a CU.  (Strips behind the tile, 37 - 39 KB per workgroup, left only two per CU and the second
+        // round ate the gain: profiles/round3_fwd_timing_coalesce_rt.txt.)  NOT the default yet: in this position the
+        // register allocator keeps raw and restaged fragments side by side (192 VGPRs = two waves per SIMD, the same loss of
+        // occupancy by another route; forcing 128 spills 50 dwords) -- the restage after layer 1 compiled to 128.  A wave's LDS instructions execute in order, so
+        // write -> read -> next write need no waits of their own.  Stage (p, c) holds rows 8 c .. 8 c + 7: the lanes whose
+        // row i lies there take their two fragments of panel p from it.  Layer 1 follows behind a barrier (its stores go to
+        // every wave's strip).
+        float* stg = h1s + wave * 256;
+        const bool upper = (i >> 3) != 0;
+        const int rd = (i & 7) * 32 + 4 * q;
+#pragma unroll
+        for (int p = 0; p < kJ / 2; ++p) {
+            const float4 r0 = wv[2 * p], r1 = wv[2 * p + 1];
+            *reinterpret_cast<f32x4*>(stg + 4 * lane) = f32x4{r0.x, r0.y, r0.z, r0.w};
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + rd), a1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
+            *reinterpret_cast<f32x4*>(stg + 4 * lane) = f32x4{r1.x, r1.y, r1.z, r1.w};
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(stg + rd), b1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
+            const f32x4 f0 = upper ? b0 : a0, f1 = upper ? b1 : a1;
+            wv[2 * p] = make_float4(f0[0], f0[1], f0[2], f0[3]);
+            wv[2 * p + 1] = make_float4(f1[0], f1[1], f1[2], f1[3]);
+            // (without it the scheduler overlaps the stages and keeps raw and restaged fragments alive side by side: 192 VGPRs
+            // = two waves per SIMD instead of four)
+            if (p & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
     const int o3 = min(q, dout - 1);
     float w3v[kT3];
 #pragma unroll
@@ -980,25 +1013,6 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
                     }
                 }
             }
-        }
-    }
-    if constexpr (kCoalesced) {
-        // 1 KB strip per wave behind the h1 tile; a wave's LDS instructions execute in order, so write -> read -> next write
-        // need no waits of their own.  Stage (p, c) holds rows 8 c .. 8 c + 7: the lanes whose row i lies there take their two
-        // fragments of panel p from it.
-        float* stg = h1s + R * kStackRows * (kStackMaxH + kSplitPad) + wave * 256;
-        const bool upper = (i >> 3) != 0;
-        const int rd = (i & 7) * 32 + 4 * q;
-#pragma unroll
-        for (int p = 0; p < kJ / 2; ++p) {
-            const float4 r0 = wv[2 * p], r1 = wv[2 * p + 1];
-            *reinterpret_cast<f32x4*>(stg + 4 * lane) = f32x4{r0.x, r0.y, r0.z, r0.w};
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + rd), a1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
-            *reinterpret_cast<f32x4*>(stg + 4 * lane) = f32x4{r1.x, r1.y, r1.z, r1.w};
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(stg + rd), b1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
-            const f32x4 f0 = upper ? b0 : a0, f1 = upper ? b1 : a1;
-            wv[2 * p] = make_float4(f0[0], f0[1], f0[2], f0[3]);
-            wv[2 * p + 1] = make_float4(f1[0], f1[1], f1[2], f1[3]);
         }
     }
     __syncthreads();
@@ -1095,7 +1109,7 @@ constexpr int kPackMinSeeds = RRL_PACK_MIN_SEEDS;
 constexpr int kSplitSmallM = 1024;
 constexpr size_t split_lds_floats(int R) {
     return size_t(R) * kStackRows * (kStackMaxH + kSplitPad) +
-           (R > 1 ? (kCoalesceW2 ? 4 * 256 : 0)                                   // R > 1: h2 aliases h1; W2 restaging strips
+           (R > 1 ? 0                                                              // R > 1: h2 aliases h1
                   : size_t(R) * kStackRows * (kStackMaxH / kSplit + 1));
 }
 
