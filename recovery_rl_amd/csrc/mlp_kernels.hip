@@ -816,7 +816,7 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_group_kernel(StackGroup sg) {
 // adds the four partials in a fixed order (deterministic).
 constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.320 ms per iteration)
 #ifndef RRL_COALESCE_W2
-#define RRL_COALESCE_W2 0     /* opt-in: built and measured at the end of round 3, not the default */
+#define RRL_COALESCE_W2 0     /* opt-in (with -DRRL_SPLIT_PAD=4): built and measured at the end of round 3, not the default */
 #endif
 constexpr bool kCoalesceW2 = RRL_COALESCE_W2 != 0;   // multi-row-tile forwards: whole-line W2 loads restaged through LDS
 // pad floats per row of the h1 tile (a knob of the LDS-footprint experiments: 4 keeps rows 16-byte aligned and as
@@ -950,35 +950,6 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
     }
     const float bias2 = b2[n2 + i];
-    if constexpr (kCoalesced) {
-        // Restage BEFORE layer 1, in the h1 tile's own space (nothing lives there yet; the x strip of the input head above is
-        // behind its barrier): 1 KB per wave at h1s + 256 wave, no LDS of its own -- the workgroup keeps the LDS footprint that
-        // puts four of them on a CU.  (Strips behind the tile, 37 - 39 KB per workgroup, left only two per CU and the second
-        // round ate the gain: profiles/round3_fwd_timing_coalesce_rt.txt.)  NOT the default yet: in this position the
-        // register allocator keeps raw and restaged fragments side by side (192 VGPRs = two waves per SIMD, the same loss of
-        // occupancy by another route; forcing 128 spills 50 dwords) -- the restage after layer 1 compiled to 128.  A wave's LDS instructions execute in order, so
-        // write -> read -> next write need no waits of their own.  Stage (p, c) holds rows 8 c .. 8 c + 7: the lanes whose
-        // row i lies there take their two fragments of panel p from it.  Layer 1 follows behind a barrier (its stores go to
-        // every wave's strip).
-        float* stg = h1s + wave * 256;
-        const bool upper = (i >> 3) != 0;
-        const int rd = (i & 7) * 32 + 4 * q;
-#pragma unroll
-        for (int p = 0; p < kJ / 2; ++p) {
-            const float4 r0 = wv[2 * p], r1 = wv[2 * p + 1];
-            *reinterpret_cast<f32x4*>(stg + 4 * lane) = f32x4{r0.x, r0.y, r0.z, r0.w};
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + rd), a1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
-            *reinterpret_cast<f32x4*>(stg + 4 * lane) = f32x4{r1.x, r1.y, r1.z, r1.w};
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(stg + rd), b1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
-            const f32x4 f0 = upper ? b0 : a0, f1 = upper ? b1 : a1;
-            wv[2 * p] = make_float4(f0[0], f0[1], f0[2], f0[3]);
-            wv[2 * p + 1] = make_float4(f1[0], f1[1], f1[2], f1[3]);
-            // (without it the scheduler overlaps the stages and keeps raw and restaged fragments alive side by side: 192 VGPRs
-            // = two waves per SIMD instead of four)
-            if (p & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    }
     const int o3 = min(q, dout - 1);
     float w3v[kT3];
 #pragma unroll
@@ -1013,6 +984,43 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
                     }
                 }
             }
+        }
+    }
+    if constexpr (kCoalesced) {
+        // Restage into fragment order after layer 1 (the loads had layer 1 to arrive under).  512-byte strip per wave behind
+        // the h1 tile: with kSplitPad = 4 the workgroup's LDS is the 35.3 KB it was before (tile 33.3 KB + 4 x 512 B), the
+        // footprint that puts FOUR workgroups on a CU -- 37 - 39 KB leave two and the second round eats the gain
+        // (profiles/round3_fwd_timing_coalesce_rt.txt).  A load instruction's 1 KB goes through the strip in two halves: in
+        // stage (p, c, h) the lanes of half h store their 4 rows x 128 bytes to the strip, the other half stores to the pad
+        // slot of an h1 row instead (16 bytes nobody reads: no exec masking, no branches), and the lanes whose row lies in
+        // that group of four (i >> 2 == 2 c + h) take their two fragments of panel p from the strip.  A wave's LDS
+        // instructions execute in order: write -> read -> next write need no waits of their own.
+        // NOT the default yet: this form compiles to 220 VGPRs (two waves per SIMD -- the occupancy the footprint was meant to
+        // keep); the whole-instruction form with 1 KB strips compiled to 128 and was measured.
+        static_assert(!kCoalesceW2 || kSplitPad >= 4, "the pad slot of a row takes one float4");
+        float* stg = h1s + R * kStackRows * (kStackMaxH + kSplitPad) + wave * 128;
+        float* dump = h1s + (lane & 31) * ldh + H;             // pad columns of row lane & 31 (R >= 2: 32 rows exist)
+        float* w0 = (lane < 32) ? stg + 4 * (lane & 31) : dump;   // where my float4 goes in a stage of half 0 / half 1
+        float* w1 = (lane < 32) ? dump : stg + 4 * (lane & 31);
+        const int grp = i >> 2;
+        const int rd = (i & 3) * 32 + 4 * q;
+#pragma unroll
+        for (int p = 0; p < kJ / 2; ++p) {
+            const float4 r0 = wv[2 * p], r1 = wv[2 * p + 1];
+            const f32x4 v0 = {r0.x, r0.y, r0.z, r0.w}, v1 = {r1.x, r1.y, r1.z, r1.w};
+            *reinterpret_cast<f32x4*>(w0) = v0;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + rd), a1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
+            *reinterpret_cast<f32x4*>(w1) = v0;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(stg + rd), b1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
+            *reinterpret_cast<f32x4*>(w0) = v1;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(stg + rd), c1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
+            *reinterpret_cast<f32x4*>(w1) = v1;
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(stg + rd), d1 = *reinterpret_cast<const f32x4*>(stg + rd + 16);
+            const f32x4 f0 = grp == 0 ? a0 : (grp == 1 ? b0 : (grp == 2 ? c0 : d0));
+            const f32x4 f1 = grp == 0 ? a1 : (grp == 1 ? b1 : (grp == 2 ? c1 : d1));
+            wv[2 * p] = make_float4(f0[0], f0[1], f0[2], f0[3]);
+            wv[2 * p + 1] = make_float4(f1[0], f1[1], f1[2], f1[3]);
+            __builtin_amdgcn_sched_barrier(0);      // one panel's eight reads in flight, not every panel's (216 VGPRs)
         }
     }
     __syncthreads();
@@ -1109,7 +1117,7 @@ constexpr int kPackMinSeeds = RRL_PACK_MIN_SEEDS;
 constexpr int kSplitSmallM = 1024;
 constexpr size_t split_lds_floats(int R) {
     return size_t(R) * kStackRows * (kStackMaxH + kSplitPad) +
-           (R > 1 ? 0                                                              // R > 1: h2 aliases h1
+           (R > 1 ? (kCoalesceW2 ? 4 * 128 : 0)                                   // R > 1: h2 aliases h1; W2 restaging strips
                   : size_t(R) * kStackRows * (kStackMaxH / kSplit + 1));
 }
 
