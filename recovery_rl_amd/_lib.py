@@ -44,6 +44,50 @@ EXPORTS = [
     "rrl_ens_train_big_supported", "rrl_ens_big_scratch_floats", "rrl_ens_train_grad_big", "rrl_ens_train_epoch_big",
 ]
 
+# Experimental builds of the library that ride along with the default one (same sources, extra -D flags on the listed files;
+# every other object is the default build's).  They are NEVER what `load()` hands out: a test or an A/B script points
+# RRL_HIP_LIB at one in a child process (tests/test_w2_permute_gpu.py, profiles/ab_lib.py).
+VARIANTS = {
+    # whole-line W2 loads of the multi-row-tile forwards, restaged into fragment order by ds_bpermute
+    "w2perm": {"mlp_kernels.hip": ["-DRRL_COALESCE_W2=2"]},
+    # ... and of the single-row-tile forwards (the updates' B = 256 batches) as well
+    "w2perm_all": {"mlp_kernels.hip": ["-DRRL_COALESCE_W2=3"]},
+}
+
+
+def variant_path(name):
+    return os.path.join(CSRC, "librrl_hip_%s.so" % name)
+
+
+def build_variant(name, verbose=False):
+    """csrc/librrl_hip_<name>.so: the default objects (build() first) with the variant's files recompiled under its flags."""
+    default_so = os.path.join(CSRC, "librrl_hip.so")
+    if not os.path.exists(default_so):
+        build()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(CSRC, "_build")
+    vdir = os.path.join(objdir, name)
+    os.makedirs(vdir, exist_ok=True)
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    objs = []
+    for src in _sources():
+        base = os.path.basename(src)
+        obj = os.path.join(objdir, base[:-4] + ".o")
+        extra = VARIANTS[name].get(base)
+        if extra:
+            obj = os.path.join(vdir, base[:-4] + ".o")
+            cmd = [hipcc] + compile_flags + extra + ["-I", INCLUDE, "-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    out = variant_path(name)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
 
 class RRLError(RuntimeError):
     pass

@@ -818,7 +818,12 @@ constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.
 #ifndef RRL_COALESCE_W2
 #define RRL_COALESCE_W2 0     /* opt-in (with -DRRL_SPLIT_PAD=4): built and measured at the end of round 3, not the default */
 #endif
-constexpr bool kCoalesceW2 = RRL_COALESCE_W2 != 0;   // multi-row-tile forwards: whole-line W2 loads restaged through LDS
+constexpr bool kCoalesceW2 = RRL_COALESCE_W2 != 0;   // multi-row-tile forwards: whole-line W2 loads restaged into fragment order
+// HOW the whole-line loads are restaged: 1 = through per-wave LDS strips (measured, DESIGN 11: the strips or the registers
+// cost a workgroup per CU); 2 = by ds_bpermute_b32 (the LDS crossbar without LDS memory: no footprint, eight temporaries per
+// panel), R > 1 only; 3 = the same for the single-row-tile forwards of the update batches as well
+constexpr bool kPermuteW2 = RRL_COALESCE_W2 >= 2;
+constexpr bool kPermuteW2All = RRL_COALESCE_W2 >= 3;
 // pad floats per row of the h1 tile (a knob of the LDS-footprint experiments: 4 keeps rows 16-byte aligned and as
 // conflict-free as 20; the footprint that matters is the one that puts FOUR workgroups of the 4096-row forward on a CU:
 // 35.3 KB does, 37.4 KB leaves two)
@@ -937,7 +942,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     // loads 8 rows x one whole line per instruction (lane l: row l >> 3, 16 bytes at 4 (l & 7)) and restages each
     // instruction's 1 KB through its own LDS strip into fragment order after layer 1 -- the same values in the same
     // registers, so nothing downstream changes.
-    constexpr bool kCoalesced = kCoalesceW2 && R > 1 && HC == 256;
+    constexpr bool kCoalesced = kCoalesceW2 && (R > 1 || kPermuteW2All) && HC == 256;
     float4 wv[kJ];
     if constexpr (kCoalesced) {
         const float* wbase = W2 + (long long)(n2 + (lane >> 3)) * H + 4 * (lane & 7);
@@ -986,7 +991,38 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
             }
         }
     }
-    if constexpr (kCoalesced) {
+    if constexpr (kCoalesced && kPermuteW2) {
+        // Restage into fragment order after layer 1 by lane permutation, no LDS memory involved (the footprint -- and with it
+        // the four workgroups per CU -- stays what it is).  Panel p = floats 32 p .. 32 p + 31 of my 16 rows arrived as two
+        // registers: reg c of lane l = row 8 c + (l >> 3), floats 32 p + 4 (l & 7) .. + 3.  Fragment jj of the panel (wv[2 p +
+        // jj]) of lane (i, q) is row i, floats 32 p + 16 jj + 4 q .. + 3 = reg (i >> 3) of lane 8 (i & 7) + 4 jj + q.  A
+        // ds_bpermute moves ONE register per source lane, and both rows 8 c + r live in the same source lanes: so pass A
+        // serves fragment 0 of the rows below 8 and fragment 1 of the rows from 8 on (source lanes with l & 4 == 0 send reg
+        // 0, the others reg 1: every source lane is asked exactly once), pass B the two other quarters, and the receiving lane
+        // sorts A / B into fragment 0 / 1 by its own row.  Eight permutes and sixteen selects per panel, 64 + 128 per wave;
+        // the same values land in the same registers as with the fragment-order loads, so nothing downstream changes.
+        const bool low_src = (lane & 4) == 0, low_row = (i & 8) == 0;
+        const int addr_a = 4 * (8 * (i & 7) + (low_row ? 0 : 4) + q);
+        const int addr_b = 4 * (8 * (i & 7) + (low_row ? 4 : 0) + q);
+#pragma unroll
+        for (int p = 0; p < kJ / 2; ++p) {
+            const float r0[4] = {wv[2 * p].x, wv[2 * p].y, wv[2 * p].z, wv[2 * p].w};
+            const float r1[4] = {wv[2 * p + 1].x, wv[2 * p + 1].y, wv[2 * p + 1].z, wv[2 * p + 1].w};
+            float f0[4], f1[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int send_a = __float_as_int(low_src ? r0[c] : r1[c]);
+                const int send_b = __float_as_int(low_src ? r1[c] : r0[c]);
+                const float got_a = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_a, send_a));
+                const float got_b = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_b, send_b));
+                f0[c] = low_row ? got_a : got_b;
+                f1[c] = low_row ? got_b : got_a;
+            }
+            wv[2 * p] = make_float4(f0[0], f0[1], f0[2], f0[3]);
+            wv[2 * p + 1] = make_float4(f1[0], f1[1], f1[2], f1[3]);
+            __builtin_amdgcn_sched_barrier(0);      // one panel's permutes in flight at a time: eight temporaries, not 64
+        }
+    } else if constexpr (kCoalesced) {
         // Restage into fragment order after layer 1 (the loads had layer 1 to arrive under).  512-byte strip per wave behind
         // the h1 tile: with kSplitPad = 4 the workgroup's LDS is the 35.3 KB it was before (tile 33.3 KB + 4 x 512 B), the
         // footprint that puts FOUR workgroups on a CU -- 37 - 39 KB leave two and the second round eats the gain
@@ -997,7 +1033,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         // instructions execute in order: write -> read -> next write need no waits of their own.
         // NOT the default yet: this form compiles to 220 VGPRs (two waves per SIMD -- the occupancy the footprint was meant to
         // keep); the whole-instruction form with 1 KB strips compiled to 128 and was measured.
-        static_assert(!kCoalesceW2 || kSplitPad >= 4, "the pad slot of a row takes one float4");
+        static_assert(!kCoalesceW2 || kPermuteW2 || kSplitPad >= 4, "the pad slot of a row takes one float4");
         float* stg = h1s + R * kStackRows * (kStackMaxH + kSplitPad) + wave * 128;
         float* dump = h1s + (lane & 31) * ldh + H;             // pad columns of row lane & 31 (R >= 2: 32 rows exist)
         float* w0 = (lane < 32) ? stg + 4 * (lane & 31) : dump;   // where my float4 goes in a stage of half 0 / half 1
@@ -1117,7 +1153,7 @@ constexpr int kPackMinSeeds = RRL_PACK_MIN_SEEDS;
 constexpr int kSplitSmallM = 1024;
 constexpr size_t split_lds_floats(int R) {
     return size_t(R) * kStackRows * (kStackMaxH + kSplitPad) +
-           (R > 1 ? (kCoalesceW2 ? 4 * 128 : 0)                                   // R > 1: h2 aliases h1; W2 restaging strips
+           (R > 1 ? (kCoalesceW2 && !kPermuteW2 ? 4 * 128 : 0)                    // R > 1: h2 aliases h1; W2 restaging strips
                   : size_t(R) * kStackRows * (kStackMaxH / kSplit + 1));
 }
 

@@ -1,0 +1,66 @@
+"""GPU half of the whole-line W2 loads + ds_bpermute restage (csrc/mlp_kernels.hip, -DRRL_COALESCE_W2=2 / 3): the
+experimental libraries of `_lib.VARIANTS` against the default library on the same seeded work, each in its own process
+(tests/w2_permute_probe.py under RRL_HIP_LIB).  The restage moves the same values into the same registers, so EVERYTHING must
+be equal bit for bit: activations and outputs of the forward at every shape, and after 2 150 graph replays of the headline
+iteration every network parameter, env position, replay cursor and counter.
+
+The variants were written at the end of round 3 with no GPU minutes left: lane arithmetic and compiled code are checked on
+the CPU (tests/test_w2_permute_cpu.py), this file is their first run on hardware.  It is therefore a non-strict xfail for
+now -- an opt-in experiment must not take the suite of the validated default down -- and reports what it measured in the
+warnings summary (XPASS = bit-identical; the timings say whether it should become the default).
+"""
+import json
+import os
+import subprocess
+import sys
+import warnings
+
+import pytest
+import torch
+
+from recovery_rl_amd import _lib
+
+# every test here is part of the experiment: a defect of the probe itself must not take the validated suite down either
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="opt-in build, first run on hardware (module docstring)")]
+HERE = os.path.dirname(os.path.abspath(__file__))
+_default = {}
+
+
+def run_probe(lib, prefix):
+    env = dict(os.environ)
+    env.pop("RRL_HIP_LIB", None)
+    if lib:
+        env["RRL_HIP_LIB"] = lib
+    r = subprocess.run([sys.executable, os.path.join(HERE, "w2_permute_probe.py"), prefix], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return torch.load(prefix + ".pt"), json.load(open(prefix + ".json"))
+
+
+def default_run(tmp_path_factory):
+    if "run" not in _default:
+        _default["run"] = run_probe("", str(tmp_path_factory.mktemp("w2perm") / "default"))
+    return _default["run"]
+
+
+def test_default_library_probe_is_reproducible(tmp_path_factory, tmp_path):
+    """the comparison below means something only if two runs of ONE library agree bit for bit"""
+    first, _ = default_run(tmp_path_factory)
+    again, _ = run_probe("", str(tmp_path / "again"))
+    assert first.keys() == again.keys()
+    for k in first:
+        assert torch.equal(first[k], again[k]), k
+
+
+@pytest.mark.parametrize("name", sorted(_lib.VARIANTS))
+def test_variant_equals_the_default_library_bit_for_bit(name, tmp_path_factory, tmp_path):
+    path = _lib.variant_path(name)
+    assert os.path.exists(path), "variant library not built: python -c 'import __graft_entry__ as g; g.build()'"
+    base, base_info = default_run(tmp_path_factory)
+    got, info = run_probe(path, str(tmp_path / name))
+    assert os.path.samefile(info["library"], path) and not os.path.samefile(base_info["library"], path)
+    report = {k: (round(base_info[k], 4), round(info[k], 4)) for k in base_info if k.endswith(("_us", "ms_per_iteration"))}
+    different = [k for k in base if not torch.equal(base[k], got[k])]
+    warnings.warn("w2 restage by ds_bpermute, library %s: (default, variant) %s; differing results: %s"
+                  % (name, json.dumps(report), different or "none"))
+    assert base.keys() == got.keys() and not different, different
