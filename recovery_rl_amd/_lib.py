@@ -52,6 +52,8 @@ VARIANTS = {
     "w2perm": {"mlp_kernels.hip": ["-DRRL_COALESCE_W2=2"]},
     # ... and of the single-row-tile forwards (the updates' B = 256 batches) as well
     "w2perm_all": {"mlp_kernels.hip": ["-DRRL_COALESCE_W2=3"]},
+    # ... plus the k-contiguous operand of the 16 x 16 GEMM tiles (dh2 of the hidden-layer backward)
+    "w2perm_bwd": {"mlp_kernels.hip": ["-DRRL_COALESCE_W2=3", "-DRRL_COALESCE_DIRECT=1"]},
 }
 
 

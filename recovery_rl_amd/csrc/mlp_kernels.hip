@@ -103,6 +103,48 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ base, long lon
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---- whole-line loads of a k-contiguous operand, restaged into fragment order by lane permutation (opt-in) ------------
+// The fragment-order load below has every 16-lane pass of a global_load_dwordx4 touch 16 different 128-byte lines and use 16
+// bytes of each.  The whole-line form: register 2 p + c of lane l = row 8 c + (l >> 3), floats 32 p + 4 (l & 7) .. + 3 (8
+// lanes per line, 2 lines per pass); `restage_panels` then moves the values to where the MFMAs expect them: fragment 2 p + jj
+// of lane (i, q) = row i, floats 32 p + 16 jj + 4 q .. + 3 = register (i >> 3) of lane 8 (i & 7) + 4 jj + q.  A ds_bpermute
+// moves ONE register per source lane and both rows 8 c + r live in the same source lanes, so pass A serves fragment 0 of the
+// rows below 8 and fragment 1 of the rows from 8 on (source lanes with l & 4 == 0 send register 0, the others register 1:
+// every source lane is asked exactly once), pass B the two other quarters, and the receiving lane sorts A / B into fragment
+// 0 / 1 by its own row.  Eight permutes and sixteen selects per 32-float panel, no LDS memory; the same values land in the
+// same registers as with fragment-order loads, so nothing downstream changes (lane arithmetic emulated in
+// tests/test_w2_permute_cpu.py, hardware check tests/test_w2_permute_gpu.py).
+template <int NP>
+__device__ __forceinline__ void restage_panels(float4* v, int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const bool low_src = (lane & 4) == 0, low_row = (i & 8) == 0;
+    const int addr_a = 4 * (8 * (i & 7) + (low_row ? 0 : 4) + q);
+    const int addr_b = 4 * (8 * (i & 7) + (low_row ? 4 : 0) + q);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const float r0[4] = {v[2 * p].x, v[2 * p].y, v[2 * p].z, v[2 * p].w};
+        const float r1[4] = {v[2 * p + 1].x, v[2 * p + 1].y, v[2 * p + 1].z, v[2 * p + 1].w};
+        float f0[4], f1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int send_a = __float_as_int(low_src ? r0[c] : r1[c]);
+            const int send_b = __float_as_int(low_src ? r1[c] : r0[c]);
+            const float got_a = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_a, send_a));
+            const float got_b = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_b, send_b));
+            f0[c] = low_row ? got_a : got_b;
+            f1[c] = low_row ? got_b : got_a;
+        }
+        v[2 * p] = make_float4(f0[0], f0[1], f0[2], f0[3]);
+        v[2 * p + 1] = make_float4(f1[0], f1[1], f1[2], f1[3]);
+        __builtin_amdgcn_sched_barrier(0);      // one panel's permutes in flight at a time: eight temporaries, not 8 NP
+    }
+}
+#ifndef RRL_COALESCE_DIRECT
+#define RRL_COALESCE_DIRECT 0     /* opt-in: the k-contiguous operands of the 16 x 16 GEMM tiles (hidden-layer backward: dh2) */
+#endif
+template <bool FAST, int VEC>
+constexpr bool direct_coalesced() { return RRL_COALESCE_DIRECT != 0 && FAST && VEC % 2 == 0; }
+
 // The K order inside a panel is permuted (the sum over k does not care): MFMA step s = 4 j + t of
 // lane group q = lane >> 4 consumes k = 16 j + 4 q + t.  An operand whose k index is contiguous in
 // memory (rows = M or N index) is then exactly element t of the lane's j-th float4 of its own row
@@ -110,6 +152,13 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ base, long lon
 template <bool FAST, int VEC>
 __device__ __forceinline__ void load_direct(FragT<VEC>& f, const float* __restrict__ src, int ld, int row0,
                                             int rows, int k0, int K, int lane) {
+    if constexpr (direct_coalesced<FAST, VEC>()) {      // FAST: every tile full, K a multiple of the panel
+        const float* base = src + (long long)(row0 + (lane >> 3)) * ld + k0 + 4 * (lane & 7);
+#pragma unroll
+        for (int pj = 0; pj < VEC; ++pj)
+            f.v[pj] = *reinterpret_cast<const float4*>(base + (long long)(8 * (pj & 1)) * ld + 32 * (pj >> 1));
+        return;
+    }
     const int gr = row0 + (lane & 15);
     const bool ok = gr < rows;
     const long long off = (long long)(ok ? gr : rows - 1) * ld;
@@ -213,6 +262,10 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
         if constexpr (MODE == 1) drow = dsh[dsh_index(m0 + (lane & 15))];
     }
     for (int p = 0; p < np; ++p) {
+        if constexpr (direct_coalesced<FAST, VEC>()) {      // whole-line loads: into fragment order first
+            if (!kStageA) restage_panels<VEC / 2>(fa.v, lane);
+            if (!kStageB) restage_panels<VEC / 2>(fb.v, lane);
+        }
         Frag ca = fa, cb = fb;           // operands of this panel (registers)
         if constexpr (GEN && MODE == 1) {
 #pragma unroll
@@ -470,6 +523,10 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx
     load(0);
     for (int p = 0; p < np; ++p) {
         FragT<VEC> ca[WM];                    // NN: this panel's rows of A
+        if constexpr (MODE != 2 && direct_coalesced<true, VEC>()) {      // whole-line loads: into fragment order first
+#pragma unroll
+            for (int x = 0; x < WM; ++x) restage_panels<VEC / 2>(fa[x].v, lane);
+        }
 #pragma unroll
         for (int x = 0; x < WM; ++x) ca[x] = fa[x];
         stage(p & 1);
@@ -992,36 +1049,9 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         }
     }
     if constexpr (kCoalesced && kPermuteW2) {
-        // Restage into fragment order after layer 1 by lane permutation, no LDS memory involved (the footprint -- and with it
-        // the four workgroups per CU -- stays what it is).  Panel p = floats 32 p .. 32 p + 31 of my 16 rows arrived as two
-        // registers: reg c of lane l = row 8 c + (l >> 3), floats 32 p + 4 (l & 7) .. + 3.  Fragment jj of the panel (wv[2 p +
-        // jj]) of lane (i, q) is row i, floats 32 p + 16 jj + 4 q .. + 3 = reg (i >> 3) of lane 8 (i & 7) + 4 jj + q.  A
-        // ds_bpermute moves ONE register per source lane, and both rows 8 c + r live in the same source lanes: so pass A
-        // serves fragment 0 of the rows below 8 and fragment 1 of the rows from 8 on (source lanes with l & 4 == 0 send reg
-        // 0, the others reg 1: every source lane is asked exactly once), pass B the two other quarters, and the receiving lane
-        // sorts A / B into fragment 0 / 1 by its own row.  Eight permutes and sixteen selects per panel, 64 + 128 per wave;
-        // the same values land in the same registers as with the fragment-order loads, so nothing downstream changes.
-        const bool low_src = (lane & 4) == 0, low_row = (i & 8) == 0;
-        const int addr_a = 4 * (8 * (i & 7) + (low_row ? 0 : 4) + q);
-        const int addr_b = 4 * (8 * (i & 7) + (low_row ? 4 : 0) + q);
-#pragma unroll
-        for (int p = 0; p < kJ / 2; ++p) {
-            const float r0[4] = {wv[2 * p].x, wv[2 * p].y, wv[2 * p].z, wv[2 * p].w};
-            const float r1[4] = {wv[2 * p + 1].x, wv[2 * p + 1].y, wv[2 * p + 1].z, wv[2 * p + 1].w};
-            float f0[4], f1[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int send_a = __float_as_int(low_src ? r0[c] : r1[c]);
-                const int send_b = __float_as_int(low_src ? r1[c] : r0[c]);
-                const float got_a = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_a, send_a));
-                const float got_b = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_b, send_b));
-                f0[c] = low_row ? got_a : got_b;
-                f1[c] = low_row ? got_b : got_a;
-            }
-            wv[2 * p] = make_float4(f0[0], f0[1], f0[2], f0[3]);
-            wv[2 * p + 1] = make_float4(f1[0], f1[1], f1[2], f1[3]);
-            __builtin_amdgcn_sched_barrier(0);      // one panel's permutes in flight at a time: eight temporaries, not 64
-        }
+        // Restage into fragment order after layer 1 (the loads had layer 1 to arrive under) by lane permutation: no LDS memory
+        // involved, the footprint -- and with it the four workgroups per CU -- stays what it is (`restage_panels`).
+        restage_panels<kJ / 2>(wv, lane);
     } else if constexpr (kCoalesced) {
         // Restage into fragment order after layer 1 (the loads had layer 1 to arrive under).  512-byte strip per wave behind
         // the h1 tile: with kSplitPad = 4 the workgroup's LDS is the 35.3 KB it was before (tile 33.3 KB + 4 x 512 B), the

@@ -139,15 +139,16 @@ def test_default_library_has_no_restage_and_four_waves_per_simd(default_table):
 @pytest.mark.parametrize("name", sorted(_lib.VARIANTS))
 def test_variant_library_restages_by_permute_at_the_default_footprint(name, default_table, tmp_path):
     table = kernel_table(_need(_lib.variant_path(name)), str(tmp_path))
+    all_forwards = name in ("w2perm_all", "w2perm_bwd")
     checked = 0
     for multi_row in (True, False):
-        restaged = multi_row or name == "w2perm_all"
+        restaged = multi_row or all_forwards
         for k, v in _fwd(table, multi_row).items():
             d = default_table[k]
             members = 2 if "mixed" in k else 1                     # the mixed kernel holds a 1-tile and a 2-tile body
             n_perm = v["ins"].get("ds_bpermute_b32", 0) - d["ins"].get("ds_bpermute_b32", 0)
             if restaged:
-                want = 64 * (members if name == "w2perm_all" else 1)
+                want = 64 * (members if all_forwards else 1)
                 assert n_perm == want, (k, n_perm)                 # 8 panels x 8 permutes per restaged body
             else:
                 assert n_perm == 0, k
@@ -159,7 +160,24 @@ def test_variant_library_restages_by_permute_at_the_default_footprint(name, defa
                 assert v["vgpr"] <= 128, (k, v["vgpr"])
             checked += 1
     assert checked >= 8
-    # every other kernel of the library is the default's, instruction for instruction
+    # the GEMM tiles of the backward pass (16 x 16 tile form, block form, the fused hidden + head form): restaged in the
+    # `_bwd` library only -- same loads, same MFMAs, no more registers than a handful, same LDS
+    gemm_restaged = 0
     for k, v in table.items():
-        if "mlp3_fwd_split" not in k:
-            assert v["ins"] == default_table[k]["ins"], k
+        if "mlp3_fwd_split" in k:
+            continue
+        d = default_table[k]
+        if name == "w2perm_bwd" and v["ins"] != d["ins"]:
+            assert any(piece in k for piece in ("gemm16", "gemm_block", "hidden_head", "gemm_kernel")), k
+            assert v["ins"].get("ds_bpermute_b32", 0) > d["ins"].get("ds_bpermute_b32", 0), k
+            assert v["ins"].get("global_load_dwordx4", 0) == d["ins"].get("global_load_dwordx4", 0), k
+            assert v["ins"]["v_mfma_f32_16x16x4_f32"] == d["ins"]["v_mfma_f32_16x16x4_f32"], k
+            assert v["lds"] == d["lds"] and v["scratch"] == d["scratch"] and v["vgpr"] <= d["vgpr"] + 4, (k, v["vgpr"], d["vgpr"])
+            gemm_restaged += 1
+        else:
+            assert v["ins"] == d["ins"], k         # every other kernel is the default's, instruction for instruction
+    if name == "w2perm_bwd":
+        hot = [k for k in table if "gemm16_group_kernel" in k or "gemm16_pack_kernel" in k or "gemm_block_pack_kernel" in k]
+        assert gemm_restaged >= 3 and hot
+        for k in hot:
+            assert table[k]["ins"] != default_table[k]["ins"], k

@@ -1,5 +1,5 @@
-"""GPU half of the whole-line W2 loads + ds_bpermute restage (csrc/mlp_kernels.hip, -DRRL_COALESCE_W2=2 / 3): the
-experimental libraries of `_lib.VARIANTS` against the default library on the same seeded work, each in its own process
+"""GPU half of the whole-line loads + ds_bpermute restage (csrc/mlp_kernels.hip: -DRRL_COALESCE_W2=2 / 3 for W2 in the fused
+forward, -DRRL_COALESCE_DIRECT=1 for the k-contiguous operand of the backward's GEMM tiles): the experimental libraries of `_lib.VARIANTS` against the default library on the same seeded work, each in its own process
 (tests/w2_permute_probe.py under RRL_HIP_LIB).  The restage moves the same values into the same registers, so EVERYTHING must
 be equal bit for bit: activations and outputs of the forward at every shape, and after 2 150 graph replays of the headline
 iteration every network parameter, env position, replay cursor and counter.
