@@ -75,3 +75,34 @@ def test_hot_kernels_do_not_live_in_scratch(kernels):
     for name, ins in kernels.items():
         n = sum(i.startswith("scratch_") for i in ins)
         assert n <= 16, (name, n)          # the f16x3 planner spills five scalars around its main loop; nothing else does
+
+
+# ---- register / LDS budgets the occupancy figures of DESIGN.md rest on (profiles/round3_kernel_resources.txt) -------------
+# (unified VGPR count of the code object's metadata, accumulation registers included; 512 per SIMD lane in granules of 8)
+BUDGETS = (
+    # kernel-name piece, max VGPRs, what the budget buys
+    ("mlp3_fwd_split_group_kernelILi1E", 128, "B = 256 forwards: four waves per SIMD"),
+    ("mlp3_fwd_split_group_kernelILi2E", 128, "4096-row acting forwards: four 4-wave workgroups per CU"),
+    ("mlp3_fwd_split_mixed_kernel", 128, "acting + update forwards in one launch"),
+    ("mlp3_fwd_split_pack_kernelILi2E", 128, "packed forwards"),
+    ("plan_cost_kernelILb0E", 128, "planner f32: four waves per SIMD"),
+    ("plan_cost_kernelILb1E", 128, "planner f16x3"),
+    ("ens_big_fwd_bwd_kernel", 128, "large-batch ensemble step"),
+    ("step_push_kernelIN12_GLOBAL__N_16NavEnv", 104, "fused env step + pushes: >= four waves per SIMD"),
+    ("nav_step_kernel", 64, "env step: eight waves per SIMD (bandwidth regime)"),
+    ("sample_group_kernel", 64, "replay draws"),
+)
+
+
+def test_hot_kernels_keep_their_register_budgets(tmp_path):
+    from test_w2_permute_cpu import kernel_table
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    table = {k: v for k, v in kernel_table(_lib.SO_PATH, str(tmp_path)).items() if "vgpr" in v}
+    assert len(table) > 100
+    for piece, limit, why in BUDGETS:
+        hits = {k: v for k, v in table.items() if piece in k}
+        assert hits, piece
+        for k, v in hits.items():
+            assert v["vgpr"] <= limit, (k, v["vgpr"], limit, why)
+            assert v["scratch"] <= 32, (k, v["scratch"])
