@@ -899,15 +899,27 @@ constexpr int kSplitPad = RRL_SPLIT_PAD;
 // the arguments.  With HC fixed every loop below is straight-line code: no per-chunk bounds branches between the LDS
 // reads and the MFMAs (the run-time version waited for each ds_read right before its four MFMAs: 3 500 cycles for the
 // 2 048 cycles of MFMA issue of one 16-row tile), and the row-bounds checks are hoisted into one uniform branch.
-template <int R, int HC>
+// ZW = column splits per workgroup.  ZW = 2 (opt-in -DRRL_FWD_WIDE=1, stand-alone kernel only so far): an EIGHT-wave workgroup
+// evaluates splits ZW z and ZW z + 1 of its rows -- waves 0..3 the first, 4..7 the second -- on ONE h1 tile that the eight
+// waves compute together (each layer-1 column tile once instead of once per split).  The W2 stream of a launch is (row
+// blocks) x |W2| whatever the split (measured: 24.4 / 17.9 us per 4096-row forward at 16 / 32 rows per workgroup, ~1 us per
+// 10 MB of L2 reads, profiles/round3_w2perm/): twice the rows per workgroup at the same LDS per wave and the same 16 waves
+// per CU halves it.  Per output element nothing changes (same MFMA steps, same partial sums, same order).
+template <int R, int HC, int ZW = 1>
 __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* partial, int bx, int g, int z, int G,
                                                     float* h1s, float* h2s) {
     RRL_STAMP(0);
+    static_assert(ZW == 1 || (HC != 0 && R > 1 && (!kCoalesceW2 || kPermuteW2)), "wide workgroups: H = 256, multi-row tiles");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w4 = ZW == 1 ? wave : (wave & 3);          // my place among the four waves of my column split
+    const int zsub = ZW == 1 ? 0 : (wave >> 2);
+    const int zb = z;                                    // the workgroup's z index (ZW splits each)
+    z = ZW * z + zsub;                                   // my column split
+    constexpr int kW = 4 * ZW;                           // waves per workgroup
     const int m0 = bx * (R * kStackRows);
     const int H = HC ? HC : a.H, ldh = H + kSplitPad, HS = H / kSplit, ld2 = HS + 1;
     constexpr int kJ = HC ? HC / 16 : kStackMaxH / 16;             // K chunks of layer 2
-    constexpr int kU = HC ? HC / 64 : kStackMaxH / 64;             // layer-1 column tiles per wave
+    constexpr int kU = HC ? HC / (16 * kW) : kStackMaxH / (16 * kW);   // layer-1 column tiles per wave
     constexpr int kT3 = HC ? HC / (16 * kSplit) : kStackMaxH / (16 * kSplit);
     const int colbase = z * HS;
     const int M = a.M, din = a.din, dout = a.dout;
@@ -917,12 +929,12 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     const float* b2 = a.b2 + (long long)g * H;
     const float* W3 = a.W3 + (long long)g * dout * H;
     const float* b3 = a.b3 + (long long)g * dout;
-    float* const h1g = (a.h1 && z == 0) ? a.h1 + ((long long)g * M + m0) * H : nullptr;
+    float* const h1g = (a.h1 && zb == 0) ? a.h1 + ((long long)g * M + m0) * H : nullptr;
     float* const h2g = a.h2 ? a.h2 + ((long long)g * M + m0) * H : nullptr;
     const int i = lane & 15, q = lane >> 4;
     const int ntiles1 = H / 16;                    // layer-1 column tiles, 4 waves take them round-robin
-    const bool has_tile2 = HC ? true : wave * 16 < HS;   // my layer-2 tile inside this group's columns
-    const int n2 = colbase + (has_tile2 ? wave * 16 : 0);
+    const bool has_tile2 = HC ? true : w4 * 16 < HS;   // my layer-2 tile inside this group's columns
+    const int n2 = colbase + (has_tile2 ? w4 * 16 : 0);
     const bool full = m0 + R * kStackRows <= M;    // uniform: every row of the workgroup's tiles exists
 
     // ---- all global reads up front, branch-free ---------------------------------------------------------
@@ -986,7 +998,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     float w1b[kU], bias1[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-        const int t = min(wave + 4 * u, ntiles1 - 1);
+        const int t = min(wave + kW * u, ntiles1 - 1);
         const float wv1 = W1[(t * 16 + i) * din + min(q, din - 1)];
         w1b[u] = (q < din) ? wv1 : 0.f;
         bias1[u] = b1[t * 16 + i];
@@ -1023,7 +1035,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     // ---- layer 1 (all H columns; one MFMA step per 16-column tile and row tile) ---------------------------
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-        const int t = wave + 4 * u;
+        const int t = wave + kW * u;
         if (HC || t < ntiles1) {
 #pragma unroll
             for (int rt = 0; rt < R; ++rt) {
@@ -1092,6 +1104,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     __syncthreads();
     RRL_STAMP(2);
     // ---- layer 2: my 16 columns, R row tiles sharing the W2 fragments -----------------------------------------
+    float* const h2z = ZW == 1 ? h2s : h2s + zsub * (R * kStackRows * ld2);      // my split's h2 tile
     if (has_tile2) {
         f32x4 acc0[R], acc1[R];
 #pragma unroll
@@ -1123,7 +1136,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
                 const int rr = 16 * rt + 4 * q + r;
                 float v = acc[r] + bias2;
                 v = v > 0.f ? v : 0.f;
-                h2s[rr * ld2 + wave * 16 + i] = v;
+                h2z[rr * ld2 + w4 * 16 + i] = v;
             }
             if (h2g) {
 #pragma unroll
@@ -1145,11 +1158,11 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     for (int rt = 0; rt < R; ++rt) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int r = 16 * rt + wave * 4 + rr;
+            const int r = 16 * rt + w4 * 4 + rr;
             float v = 0.f;
 #pragma unroll
             for (int it = 0; it < kT3; ++it) {
-                const float hv = h2s[r * ld2 + min(i + 16 * it, HS - 1)];
+                const float hv = h2z[r * ld2 + min(i + 16 * it, HS - 1)];
                 if (HC || i + 16 * it < HS) v = fmaf(hv, w3v[it], v);
             }
             res[rt][rr] = v;
@@ -1160,7 +1173,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const float v = row16_sum(res[rt][rr]);
-            const int r = 16 * rt + wave * 4 + rr;
+            const int r = 16 * rt + w4 * 4 + rr;
             if (i == 0 && q < dout && (full || m0 + r < M))
                 partial[(((long long)z * G + g) * M + m0 + r) * dout + q] = v + bias3;
         }
@@ -1187,12 +1200,61 @@ constexpr size_t split_lds_floats(int R) {
                   : size_t(R) * kStackRows * (kStackMaxH / kSplit + 1));
 }
 
+// Which workgroup evaluates which (row block, head, column split) -- an experiment on the stand-alone kernel (opt-in
+// -DRRL_FWD_XCD_MAP=1 / 2).  All workgroups of a 4096-row forward start in ONE round, four per CU, and in launch order
+// the four on a CU hold four DIFFERENT (head, split) slices of W2: every CU pulls 4 x 64 KB through its L1 at the same time.
+// Workgroups go to the XCDs round-robin (id % 8); inside an XCD (local index m = id / 8) the map gives the same slice to the
+// workgroups that share a CU, so that one L1 fill can serve four of them, under either assumption about the dispatcher:
+//   1: CUs are dealt workgroups round-robin (m, m + 32, m + 64, m + 96 share a CU)     2: a CU is filled first (4 c .. 4 c + 3)
+// A bijection of the grid: every (row block, head, split) is still evaluated exactly once, by the same code.
+#ifndef RRL_FWD_XCD_MAP
+#define RRL_FWD_XCD_MAP 0
+#endif
+__device__ __forceinline__ void split_block_of(int& bx, int& g, int& z) {
+    bx = blockIdx.x, g = blockIdx.y, z = blockIdx.z;
+    if constexpr (RRL_FWD_XCD_MAP != 0) {
+        const int nx = gridDim.x, G = gridDim.y, S = G * kSplit;
+        const int rows_per = nx / 8, q = 32 / S;                       // row blocks per XCD and slice; CUs per slice (map 1)
+        const bool ok = nx % 8 == 0 && S <= 32 && 32 % S == 0 && rows_per % 4 == 0 && (RRL_FWD_XCD_MAP != 1 || rows_per % q == 0);
+        if (!ok) return;
+        const int id = blockIdx.x + nx * (blockIdx.y + G * blockIdx.z);
+        const int k = id % 8, m = id / 8;
+        int s, r;
+        if (RRL_FWD_XCD_MAP == 1) {
+            s = (m % 32) / q;
+            r = q * (m / 32) + m % q;
+        } else {
+            s = (m / 4) % S;
+            r = 4 * (m / (4 * S)) + m % 4;
+        }
+        bx = 8 * r + k, g = s % G, z = s / G;
+    }
+}
+
+#ifndef RRL_FWD_WIDE
+#define RRL_FWD_WIDE 0
+#endif
+#ifndef RRL_WIDE_R
+#define RRL_WIDE_R 4
+#endif
+#if RRL_FWD_WIDE
+constexpr bool kFwdWide = true;
+constexpr int kWideR = RRL_WIDE_R;
+// eight waves, two column splits, kWideR row tiles on one h1 tile (see mlp3_fwd_split_body); H = 256 only
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void mlp3_fwd_split_wide_kernel(StackArgs a, float* partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    mlp3_fwd_split_body<kWideR, 256, 2>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, lds);
+}
+#endif
+
 template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
-    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
-    else mlp3_fwd_split_body<R, 0>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
+    int bx, g, z;
+    split_block_of(bx, g, z);
+    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, bx, g, z, gridDim.y, lds, h2s);
+    else mlp3_fwd_split_body<R, 0>(a, partial, bx, g, z, gridDim.y, lds, h2s);
 }
 
 // flat grid over (stack, column split, head, row tile)
@@ -2147,6 +2209,14 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
         if (M <= kSplitSmallM || H != 256) {
             hipLaunchKernelGGL(mlp3_fwd_split_kernel<1>, dim3((M + kStackRows - 1) / kStackRows, G, kSplit), dim3(256),
                                split_lds_floats(1) * 4, (hipStream_t)stream, a, scratch);
+#if RRL_FWD_WIDE
+        } else if (kFwdWide) {
+            static const bool ok = grant_lds((const void*)mlp3_fwd_split_wide_kernel, split_lds_floats(kWideR) * 4);
+            if (!ok) return RRL_ERANGE;
+            const int rows = kWideR * kStackRows;
+            hipLaunchKernelGGL(mlp3_fwd_split_wide_kernel, dim3((M + rows - 1) / rows, G, kSplit / 2), dim3(512),
+                               split_lds_floats(kWideR) * 4, (hipStream_t)stream, a, scratch);
+#endif
         } else {
             static const bool ok = grant_lds((const void*)mlp3_fwd_split_kernel<kBigR>, split_lds_floats(kBigR) * 4);
             if (!ok) return RRL_ERANGE;
