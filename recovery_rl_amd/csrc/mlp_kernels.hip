@@ -872,6 +872,9 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_group_kernel(StackGroup sg) {
 // columns, owns 64 hidden-2 columns (64 KB of W2) and emits a PARTIAL last-layer sum; a tiny second kernel
 // adds the four partials in a fixed order (deterministic).
 constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.320 ms per iteration)
+#ifndef RRL_FWD_SETPRIO
+#define RRL_FWD_SETPRIO 0     /* experiment: s_setprio level of a wave during layer 2 (1..3), 0 = off */
+#endif
 #ifndef RRL_COALESCE_W2
 #define RRL_COALESCE_W2 0     /* opt-in (with -DRRL_SPLIT_PAD=4): built and measured at the end of round 3, not the default */
 #endif
@@ -1112,6 +1115,9 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
             acc0[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#if RRL_FWD_SETPRIO
+        __builtin_amdgcn_s_setprio(RRL_FWD_SETPRIO);     // experiment: waves in their MFMA phase issue before waves in a prologue / epilogue
+#endif
 #pragma unroll
         for (int j = 0; j < kJ; ++j) {
             if (HC || 16 * j < H) {
@@ -1125,6 +1131,9 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
                 }
             }
         }
+#if RRL_FWD_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // R > 1: the h2 tile reuses the h1 tile's LDS (one 70 KB tile per workgroup instead of 87 KB: two workgroups per
         // CU), so every wave must be done reading h1 first.  (All four waves own a layer-2 tile here: HC fixes H = 256.)
         if (R > 1) __syncthreads();
