@@ -872,6 +872,10 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_group_kernel(StackGroup sg) {
 // columns, owns 64 hidden-2 columns (64 KB of W2) and emits a PARTIAL last-layer sum; a tiny second kernel
 // adds the four partials in a fixed order (deterministic).
 constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.320 ms per iteration)
+#ifndef RRL_FWD_ABLATE
+#define RRL_FWD_ABLATE 0      /* TIMING ABLATIONS, results are WRONG by design (profiles/round3_w2perm/check_6_ablations.txt): bit 0 = W2
+                                 fragments not loaded, bit 1 = layer-2 MFMAs skipped, bit 2 = layer 3 skipped */
+#endif
 #ifndef RRL_FWD_SETPRIO
 #define RRL_FWD_SETPRIO 0     /* experiment: s_setprio level of a wave during layer 2 (1..3), 0 = off */
 #endif
@@ -1021,6 +1025,9 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
 #pragma unroll
         for (int pj = 0; pj < kJ; ++pj)      // wv[2 p + c] for now: rows 8 c .. 8 c + 7, floats 32 p .. 32 p + 31
             wv[pj] = *reinterpret_cast<const float4*>(wbase + (long long)(8 * (pj & 1)) * H + 32 * (pj >> 1));
+    } else if constexpr ((RRL_FWD_ABLATE & 1) != 0) {
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) wv[j] = make_float4(float(lane + j), float(lane - j), float(j), 1.f);
     } else {
         const float* wrow = W2 + (long long)(n2 + i) * H + 4 * q;
 #pragma unroll
@@ -1124,10 +1131,14 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
 #pragma unroll
                 for (int rt = 0; rt < R; ++rt) {
                     const float4 av = *reinterpret_cast<const float4*>(h1s + (16 * rt + i) * ldh + 4 * q + 16 * j);
+#if (RRL_FWD_ABLATE & 2)
+                    asm volatile("" ::"v"(av.x), "v"(av.y), "v"(av.z), "v"(av.w), "v"(wv[j].x), "v"(wv[j].y), "v"(wv[j].z), "v"(wv[j].w));
+#else
                     acc0[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0[rt], 0, 0, 0);
                     acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1[rt], 0, 0, 0);
                     acc0[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0[rt], 0, 0, 0);
                     acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[j].w, acc1[rt], 0, 0, 0);
+#endif
                 }
             }
         }
@@ -1170,7 +1181,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
             const int r = 16 * rt + w4 * 4 + rr;
             float v = 0.f;
 #pragma unroll
-            for (int it = 0; it < kT3; ++it) {
+            for (int it = 0; it < ((RRL_FWD_ABLATE & 4) ? 0 : kT3); ++it) {
                 const float hv = h2z[r * ld2 + min(i + 16 * it, HS - 1)];
                 if (HC || i + 16 * it < HS) v = fmaf(hv, w3v[it], v);
             }
