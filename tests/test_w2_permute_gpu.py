@@ -4,10 +4,12 @@ forward, -DRRL_COALESCE_DIRECT=1 for the k-contiguous operand of the backward's 
 be equal bit for bit: activations and outputs of the forward at every shape, and after 2 150 graph replays of the headline
 iteration every network parameter, env position, replay cursor and counter.
 
-The variants were written at the end of round 3 with no GPU minutes left: lane arithmetic and compiled code are checked on
-the CPU (tests/test_w2_permute_cpu.py), this file is their first run on hardware.  It is therefore a non-strict xfail for
-now -- an opt-in experiment must not take the suite of the validated default down -- and reports what it measured in the
-warnings summary (XPASS = bit-identical; the timings say whether it should become the default).
+The variants were written at the end of round 3 with 3.4 GPU minutes left: lane arithmetic and compiled code are checked on
+the CPU (tests/test_w2_permute_cpu.py), and the torch-free harness profiles/w2perm_check.cpp has shown every one of them equal
+to the default library bit for bit on the MI355X at the level of the C-ABI calls (profiles/round3_w2perm/check_1.txt; none is
+faster).  This file is the same comparison on the whole iteration and has not run on hardware yet: a non-strict
+xfail -- an opt-in experiment, or a defect of the probe itself, must not take the suite of the validated default down -- that
+reports what it measured in the warnings summary (XPASS = bit-identical).
 """
 import json
 import os
