@@ -66,7 +66,9 @@ def time_forward(M=4096, din=4, dout=1, G=2, reps=300):
 
 def iteration(replays):
     cfg = arg_utils.get_args(bench.config2_argv(seed=11))
-    loop = bench.build_loop(cfg, DEV)
+    device = torch.device("cuda", 0)            # as bench.main builds it
+    torch.cuda.set_device(device)
+    loop = bench.build_loop(cfg, device)
     loop.capture(online_qrisk=True)
     for _ in range(replays):
         loop.replay()
