@@ -2,7 +2,7 @@
 # First GPU call of round 4: the whole-line W2 loads + ds_bpermute restage of the fused forward (csrc/mlp_kernels.hip,
 # -DRRL_COALESCE_W2=2 / 3; side libraries librrl_hip_w2perm.so / _w2perm_all.so built by __graft_entry__.build()) on hardware.
 #   1. bit-equality with the default library + timings of the 4096-row / 256-row forward and of the iteration
-#      (tests/test_w2_permute_gpu.py; XPASS = bit-identical, timings in the warnings summary)
+#      (tests/test_w2_permute_gpu.py; timings in the warnings summary)
 #   2. A/B of the headline leg on ONE box (profiles/ab_lib.py: boxes of the pool differ by ~2 %)
 #   3. rocprofv3 kernel stats of the headline leg per library: the average of mlp3_fwd_split_* must move, not only the probe
 #   4. the packed iteration at S = 16 per library (the forward stack is its largest launch: DESIGN 5b)
