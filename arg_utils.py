@@ -97,6 +97,11 @@ ADDITIVE = [
     (("--no_pin_demos",), "store_true", None, "lock-step loop: let the safety buffer's ring overwrite the offline constraint "
                                               "demonstrations (default: they are pinned, as the one-env reference never "
                                               "wraps its 1e6-row ring within a run)"),
+    (("--demo_share",), F, -1.0, "lock-step loop: share of every Q_risk batch drawn from the pinned constraint "
+                                 "demonstrations, the rest from the online rows (0 = one uniform draw over the ring; "
+                                 "default -1: 0.5 with --num_envs > 1 and pinned demonstrations -- the share a one-env "
+                                 "reference run sees from its first to its 400th episode, experiment.py:278-286,438-448 -- "
+                                 "and 0 otherwise; ignored with --pos_fraction)"),
 ]
 
 

@@ -202,6 +202,21 @@ int rrl_creplay_sample_gather(const rrl_replay_t* rb, int32_t n_pos, int32_t n_n
                               float* r, float* s2, float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu,
                               void* stream);
 
+/* Demonstration-share sample -- a vectorisation rule, not a reference function: first n_demo distinct uniform rows of the
+ * pinned range [0, rb->pinned) (the offline constraint demonstrations, experiment.py:278-286), then n_online distinct
+ * uniform rows of the online range [rb->pinned, size).  In a one-env reference run the 20 000 demonstrations stay about
+ * half of recovery_memory from the first to the last episode (uniform draw, replay_memory.py:54-72, qrisk.py:100-105);
+ * N lock-step envs push N rows per iteration, so a uniform draw over the ring would show the safety critic the
+ * demonstrations -- the only violations a safe policy ever produces -- in 2 % of its batch rows.  This draw keeps their
+ * share fixed.  A range with fewer rows than asked gives every row it has and the other range fills the batch
+ * (n_online' = min(n_online, size - pinned), n_demo' = B - n_online', and the other way round); B > size sets the
+ * error flag state[3] = 1.  Same outputs and the same Philox streams as rrl_creplay_sample_gather (demo group = its
+ * positive group, online group = its negative group).  B <= 1024, cap < 2^31, 0 <= pinned < cap. */
+int rrl_replay_sample_gather_split(const rrl_replay_t* rb, int32_t n_demo, int32_t n_online, uint64_t seed,
+                                   uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a,
+                                   float* r, float* s2, float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu,
+                                   void* stream);
+
 /* Description of one policy-head evaluation (used by rrl_policy_heads_fwd_multi, by the input head of rrl_stack_t and
  * by the recovery action of rrl_*_step_push_select). */
 /* rrl_gauss_head_fwd / rrl_stoch_head_fwd calls that do not depend on each other in ONE launch (n <= 4): a' = pi(s')
@@ -226,9 +241,11 @@ typedef struct {
 
 /* The two draws of one lock-step iteration (task buffer -> SAC update, safety buffer -> Q_risk update,
  * experiment.py:397-416) and the iteration's policy noise (rrl_normal_fill) in ONE launch: they do not depend on
- * each other.  A member is a rrl_replay_sample_gather call (stratified = 0, B = n_pos + n_neg) or a
- * rrl_creplay_sample_gather call (stratified = 1); `second` and the noise part (noise_pairs = 0) are optional.
+ * each other.  A member is a rrl_replay_sample_gather call (stratified = RRL_DRAW_UNIFORM, B = n_pos + n_neg), a
+ * rrl_creplay_sample_gather call (RRL_DRAW_STRATIFIED) or a rrl_replay_sample_gather_split call (RRL_DRAW_DEMO_SHARE:
+ * n_pos = n_demo, n_neg = n_online); `second` and the noise part (noise_pairs = 0) are optional.
  * Rows, indices and normals equal the stand-alone launches'. */
+enum { RRL_DRAW_UNIFORM = 0, RRL_DRAW_STRATIFIED = 1, RRL_DRAW_DEMO_SHARE = 2 };
 typedef struct {
     const rrl_replay_t* rb;
     int stratified;
@@ -515,13 +532,6 @@ typedef struct {
     const float *dh2, *h1, *W2;
     float *dW2, *db2, *dh1;       /* dh1 nullable when `first` consumes it */
     rrl_first_layer_t first;
-    /* fuse_head != 0 (one-output heads with a loss description: RRL_LOSS_SAC_CRITIC .. RRL_LOSS_QRISK_POLICY; full aligned
-     * tiles): this member's head backward runs INSIDE the hidden-layer launch -- `head` is what rrl_mlp_head_backward_multi
-     * would have been given (its dh2 is ignored), dW3 / db3 / loss scalars are produced by extra workgroups of the launch,
-     * and the H x H tiles generate dh2 = [h2 > 0] * dOut * W3 on the fly instead of reading it (`dh2` above may be NULL).
-     * Same values, one launch and one round trip through memory less per stack backward. */
-    rrl_head_bwd_t head;
-    int fuse_head;
 } rrl_hidden_bwd_t;
 typedef struct {
     int G, B, H, din, ldx;

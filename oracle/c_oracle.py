@@ -338,6 +338,15 @@ class OracleReplay:
             raise ValueError("Sample larger than population or is negative")
         return (idx, used.value) if return_split else idx
 
+    def sample_split_indices(self, n_demo, n_online, seed, counter, return_split=False):
+        idx = np.zeros(n_demo + n_online, np.int64)
+        used = C.c_int32(n_demo)
+        rc = lib().rrl_oracle_sample_split(C.byref(self._c), C.c_int32(n_demo), C.c_int32(n_online), C.c_uint64(seed),
+                                           C.c_uint64(counter), _p(idx), C.byref(used))
+        if rc != 0:
+            raise ValueError("Sample larger than population or is negative")
+        return (idx, used.value) if return_split else idx
+
     def gather(self, idx):
         B = len(idx)
         idx = np.ascontiguousarray(idx, np.int64)

@@ -746,6 +746,32 @@ int rrl_oracle_sample_stratified_clamped(const rrl_oracle_replay* rb, int32_t n_
     return 0;
 }
 
+/* Demonstration-share draw (the build's vectorisation rule for the safety critic's batch; include/rrl_hip.h
+ * rrl_replay_sample_gather_split): n_demo distinct rows of the pinned range [0, pinned), then n_online distinct rows of
+ * [pinned, size).  What it restores: in a one-env run of the reference the demonstrations pushed at
+ * experiment.py:278-286 stay about half of recovery_memory (uniform draw, replay_memory.py:54-72; batch clamp
+ * qrisk.py:100-105).  A range with too few rows gives all of them, the other fills the batch. */
+int rrl_oracle_sample_split(const rrl_oracle_replay* rb, int32_t n_demo, int32_t n_online, uint64_t seed,
+                            uint64_t counter, int64_t* idx, int32_t* n_demo_used)
+{
+    int32_t B = n_demo + n_online;
+    if (B <= 0 || B > rb->size) return -1;
+    int64_t demo_total = rb->pinned < rb->size ? rb->pinned : rb->size, online_total = rb->size - demo_total;
+    if (n_online > online_total) { n_online = (int32_t)online_total; n_demo = B - n_online; }
+    else if (n_demo > demo_total) { n_demo = (int32_t)demo_total; n_online = B - n_demo; }
+    if (n_demo_used) *n_demo_used = n_demo;
+    if (n_demo > 0) {
+        if (n_demo == demo_total) { for (int32_t i = 0; i < n_demo; ++i) idx[i] = i; }
+        else if (rrl_oracle_sample_indices(demo_total, n_demo, seed, counter, RRL_STREAM_SAMPLE, idx)) return -2;
+    }
+    if (n_online > 0) {
+        if (n_online == online_total) { for (int32_t i = 0; i < n_online; ++i) idx[n_demo + i] = i; }
+        else if (rrl_oracle_sample_indices(online_total, n_online, seed, counter, RRL_STREAM_SAMPLE_NEG, idx + n_demo)) return -2;
+        for (int32_t i = 0; i < n_online; ++i) idx[n_demo + i] += demo_total;
+    }
+    return 0;
+}
+
 int rrl_oracle_gather(const rrl_oracle_replay* rb, int32_t B, const int64_t* idx, float* s,
                       float* a, float* r, float* s2, float* m)
 {

@@ -135,6 +135,9 @@ int rrl_oracle_sample_stratified(const rrl_oracle_replay* rb, int32_t n_pos, int
                                  uint64_t seed, uint64_t counter, int64_t* idx);
 int rrl_oracle_sample_stratified_clamped(const rrl_oracle_replay* rb, int32_t n_pos, int32_t n_neg, int clamp,
                                          uint64_t seed, uint64_t counter, int64_t* idx, int32_t* n_pos_used);
+/* demonstration-share draw: n_demo rows of [0, pinned), then n_online rows of [pinned, size) (vectorisation rule) */
+int rrl_oracle_sample_split(const rrl_oracle_replay* rb, int32_t n_demo, int32_t n_online, uint64_t seed,
+                            uint64_t counter, int64_t* idx, int32_t* n_demo_used);
 int rrl_oracle_gather(const rrl_oracle_replay* rb, int32_t B, const int64_t* idx, float* s,
                       float* a, float* r, float* s2, float* m);
 

@@ -14,7 +14,7 @@ SO_PATH = os.environ.get("RRL_HIP_LIB") or os.path.join(CSRC, "librrl_hip.so")  
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["nav_kernels.hip", "replay_kernels.hip", "maze_kernels.hip", "cem_kernels.hip",
-               "mlp_kernels.hip", "update_kernels.hip", "log_kernels.hip", "plan_kernels.hip", "ens_train_kernels.hip",
+               "mlp_kernels.hip", "mlp_fwd_kernels.hip", "update_kernels.hip", "log_kernels.hip", "plan_kernels.hip", "ens_train_kernels.hip",
                "ens_train_big_kernels.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wno-unused-function",
@@ -25,7 +25,8 @@ EXPORTS = [
     "rrl_nav_step", "rrl_nav_step_compact", "rrl_nav_reset", "rrl_nav_rollout", "rrl_nav_offline_rollouts",
     "rrl_nav_offline",
     "rrl_maze_step", "rrl_maze_reset", "rrl_maze_offline",
-    "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_sample_multi",
+    "rrl_replay_push", "rrl_replay_sample_gather", "rrl_creplay_sample_gather", "rrl_replay_sample_gather_split",
+    "rrl_sample_multi",
     "rrl_nav_step_push", "rrl_maze_step_push", "rrl_nav_step_push_select", "rrl_maze_step_push_select",
     "rrl_nav_step_push_x", "rrl_maze_step_push_x",
     "rrl_sample_multi_packed", "rrl_mlp3_forward_multi_packed", "rrl_mlp_head_backward_multi_packed",
@@ -43,53 +44,6 @@ EXPORTS = [
     "rrl_ens_train_supported", "rrl_ens_scratch_floats", "rrl_ens_train_grad", "rrl_ens_train_epoch",
     "rrl_ens_train_big_supported", "rrl_ens_big_scratch_floats", "rrl_ens_train_grad_big", "rrl_ens_train_epoch_big",
 ]
-
-# Experimental builds of the library that ride along with the default one (same sources, extra -D flags on the listed files;
-# every other object is the default build's).  They are NEVER what `load()` hands out: a test or an A/B script points
-# RRL_HIP_LIB at one in a child process (tests/test_w2_permute_gpu.py, profiles/ab_lib.py).
-VARIANTS = {
-    # whole-line W2 loads of the multi-row-tile forwards, restaged into fragment order by ds_bpermute
-    "w2perm": {"mlp_kernels.hip": ["-DRRL_COALESCE_W2=2"]},
-    # ... and of the single-row-tile forwards (the updates' B = 256 batches) as well
-    "w2perm_all": {"mlp_kernels.hip": ["-DRRL_COALESCE_W2=3"]},
-    # ... plus the k-contiguous operand of the 16 x 16 GEMM tiles (dh2 of the hidden-layer backward)
-    "w2perm_bwd": {"mlp_kernels.hip": ["-DRRL_COALESCE_W2=3", "-DRRL_COALESCE_DIRECT=1"]},
-}
-
-
-def variant_path(name):
-    return os.path.join(CSRC, "librrl_hip_%s.so" % name)
-
-
-def build_variant(name, verbose=False):
-    """csrc/librrl_hip_<name>.so: the default objects (build() first) with the variant's files recompiled under its flags."""
-    default_so = os.path.join(CSRC, "librrl_hip.so")
-    if not os.path.exists(default_so):
-        build()
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(CSRC, "_build")
-    vdir = os.path.join(objdir, name)
-    os.makedirs(vdir, exist_ok=True)
-    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
-    objs = []
-    for src in _sources():
-        base = os.path.basename(src)
-        obj = os.path.join(objdir, base[:-4] + ".o")
-        extra = VARIANTS[name].get(base)
-        if extra:
-            obj = os.path.join(vdir, base[:-4] + ".o")
-            cmd = [hipcc] + compile_flags + extra + ["-I", INCLUDE, "-c", "-o", obj, src]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
-        objs.append(obj)
-    out = variant_path(name)
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return out
-
 
 class RRLError(RuntimeError):
     pass
@@ -147,6 +101,7 @@ class rrl_replay_t(C.Structure):
 
 
 REPLAY_CLAMP_STRATIFIED = 1
+DRAW_UNIFORM, DRAW_STRATIFIED, DRAW_DEMO_SHARE = 0, 1, 2
 
 
 class rrl_episode_log_t(C.Structure):
@@ -216,9 +171,7 @@ class rrl_first_layer_t(C.Structure):
 
 class rrl_hidden_bwd_t(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("G", "B", "H")] + [
-        (n, C.c_void_p) for n in ("dh2", "h1", "W2", "dW2", "db2", "dh1")] + [("first", rrl_first_layer_t),
-                                                                                ("head", rrl_head_bwd_t),
-                                                                                ("fuse_head", C.c_int)]
+        (n, C.c_void_p) for n in ("dh2", "h1", "W2", "dW2", "db2", "dh1")] + [("first", rrl_first_layer_t)]
 
 
 class rrl_input_bwd_t(C.Structure):
@@ -276,6 +229,8 @@ def _declare(lib):
         "rrl_replay_sample_gather": (ci, [rp, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_creplay_sample_gather": (ci, [rp, i32, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp,
                                            vp, vp, vp, vp, vp]),
+        "rrl_replay_sample_gather_split": (ci, [rp, i32, i32, u64, u64, vp, u64, vp, vp, vp, vp, vp,
+                                                vp, vp, vp, vp, vp]),
         "rrl_nav_step_push": (ci, [ci, i64, vp, vp, vp, vp, vp, vp, u64, u64, vp, u64, i32, ci, f32, ci, rp, rp,
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "rrl_maze_step_push": (ci, [i64, vp, vp, vp, vp, vp, vp, u64, u64, vp, u64, i32, ci, f32, ci, rp, rp,

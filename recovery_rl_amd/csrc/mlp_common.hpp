@@ -1,0 +1,79 @@
+// mlp_common.hpp -- pieces shared by the MLP kernel files (mlp_kernels.hip: GEMM tiles and the stack backward;
+// mlp_fwd_kernels.hip: the fused stack forward).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "rrl_device.hpp"
+#include "pack.hpp"
+#include "rrl_host.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxGroup = 4;     // members of a grouped launch
+
+namespace loss {
+
+constexpr float kLogSigMax = 2.f, kLogSigMin = -20.f, kEps = 1e-6f;   // model.py:14-16
+
+// value of a stack output given as np <= 4 partial sums ps floats apart: ((p0 + p1) + p2) + p3, the order of the
+// stand-alone sum kernel.  All loads are issued together (a run-time loop over np chained one memory round trip per
+// part: twelve of them in a row set the 11 us of the critic-loss head backward).
+__device__ __forceinline__ float psum(const float* p, long long idx, int np, long long ps) {
+    const float v0 = p[idx];
+    const float v1 = p[(np > 1 ? ps : 0) + idx];
+    const float v2 = p[(np > 2 ? 2 * ps : 0) + idx];
+    const float v3 = p[(np > 3 ? 3 * ps : 0) + idx];
+    float v = v0;
+    v = np > 1 ? v + v1 : v;
+    v = np > 2 ? v + v2 : v;
+    v = np > 3 ? v + v3 : v;
+    return v;
+}
+
+}  // namespace loss
+
+}  // namespace
+
+// ---- packed launches: the same group launch for S seeds side by side (pack.hpp) ----
+template <class Member>
+static bool pack_key(int site, int S, const int* n, const Member* const* members, rrl_pack::Key& key) {
+    if (S <= 0 || S > rrl_pack::kMaxSeeds || !n || !members) return false;
+    key.pod(site);
+    key.pod(S);
+    for (int s = 0; s < S; ++s) {
+        if (n[s] <= 0 || n[s] > kMaxGroup || !members[s]) return false;
+        key.pod(n[s]);
+        key.add(members[s], sizeof(Member) * n[s]);
+    }
+    return true;
+}
+
+template <class Group, class Member, class Build>
+static int build_pack(int S, const int* n, const Member* const* members, std::vector<Group>& groups, rrl_pack::Idx& ix,
+                      Build build) {
+    groups.resize(S);
+    ix.S = S;
+    ix.first[0] = 0;
+    for (int s = 0; s < S; ++s) {
+        const int rc = build(n[s], members[s], groups[s]);
+        if (rc != RRL_OK) return rc;
+        ix.first[s + 1] = ix.first[s] + groups[s].first[n[s]];
+    }
+    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+    return RRL_OK;
+}
+
+// tiles of R >= 4 need more than the default 64 KB of LDS per workgroup (gfx950 has 160 KB per CU): opt in once
+static bool grant_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}

@@ -1,0 +1,636 @@
+// mlp_fwd_kernels.hip -- fused forward of a whole 2-hidden-layer stack for gfx950 (MI355X): the SAC / Q_risk networks'
+// forward passes of the updates (B = 256 rows) and of the acting pass (one row per env).
+//
+//   out[g] = W3[g] relu(W2[g] relu(W1[g] x + b1[g]) + b2[g]) + b3[g]      x [M, din] shared by the heads
+// One workgroup (16 waves) per 16 rows and head: layer 1 on the VALU (din <= 4), layer 2 on MFMA with
+// the 16 x H activation tile in LDS shared by all waves (wave w owns output columns 16w..16w+15 and
+// streams its 16 rows of W2 straight from L2 into MFMA operands), layer 3 by 16-lane dot products.
+// No intermediate activation touches HBM unless the caller asks for h1 / h2 (needed by backward).
+#include "mlp_common.hpp"
+
+namespace {
+
+using rrl_host::check_launch;
+
+
+struct StackArgs {
+    const float* x;       // [M, din]
+    const float* W1; const float* b1;   // [G,H,din], [G,H]
+    const float* W2; const float* b2;   // [G,H,H],   [G,H]
+    const float* W3; const float* b3;   // [G,dout,H],[G,dout]
+    float* h1; float* h2;               // [G,M,H] or null
+    float* out;                          // [G,M,dout]
+    int M, H, din, dout, ldx;
+    // optional: columns 2..3 of x are not read but computed -- the action a policy head (rrl_gauss_head_fwd /
+    // rrl_stoch_head_fwd) yields for the same row -- so the head needs no launch of its own between the policy stack and
+    // the critic stack that consumes its action (sac.py:192-218, qrisk.py:119-152, experiment.py:546-577)
+    rrl_policy_head_t in_head;
+    int use_in_head;
+};
+
+constexpr int kStackRows = 16;
+constexpr int kStackMaxH = 256;
+
+// Sum over each 16-lane row of a wave, result in every lane, in the order of the xor butterfly 8, 4, 2, 1 (bit-identical
+// to `v += __shfl_xor(v, 8); ... 4; 2; 1`): after step k the row's values repeat with period 16 / 2^k, so the partner
+// lane^m holds the same value as lane + m (mod 16) and a DPP row rotation delivers it -- one VALU instruction with a DPP
+// operand per step instead of a ds_bpermute round trip through the LDS crossbar (~120 cycles each, four dependent
+// ones per output row: 7 000 of the 25 000 cycles of a 64-row forward tile).
+using rrl::row16_sum;
+
+// R = row tiles (of 16 rows) per workgroup: they share the wave's W2 registers, so a big batch re-reads
+// W2 from L2 M / (16 R) times instead of M / 16 (the re-streaming is what bounds M = 4096).
+template <int R>
+__device__ __forceinline__ void mlp3_fwd_body(const StackArgs& a, int bx, int g, float* h1s, float* h2s) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = bx * (R * kStackRows);
+    const int H = a.H, ldh = H + 20;
+    const float* W1 = a.W1 + (long long)g * H * a.din;
+    const float* b1 = a.b1 + (long long)g * H;
+    const float* W2 = a.W2 + (long long)g * H * H;
+    const float* b2 = a.b2 + (long long)g * H;
+    const float* W3 = a.W3 + (long long)g * a.dout * H;
+    const float* b3 = a.b3 + (long long)g * a.dout;
+    const int i = lane & 15, q = lane >> 4;
+    const bool has_tile = wave * 16 < H;          // wave w owns hidden columns [16 w, 16 w + 16)
+    const int n0 = has_tile ? wave * 16 : 0;
+
+    // ---- every global read of the kernel is issued up front, branch-free, in the order of first use ---
+    // layer 1 as ONE MFMA step (K = din <= 4): A = x[row i][d = q], B = W1[n0 + i][d = q]
+    float xa[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int xrow = min(m0 + 16 * t + i, a.M - 1);
+        xa[t] = (q < a.din) ? a.x[(long long)xrow * a.ldx + q] : 0.f;
+    }
+    const float w1b = (q < a.din) ? W1[(n0 + i) * a.din + q] : 0.f;
+    const float bias1 = b1[n0 + i];
+    float4 wv[kStackMaxH / 16];                    // my 16 rows of W2: MFMA B operands of layer 2
+    {
+        const float* wrow = W2 + (long long)(n0 + i) * H + 4 * q;
+#pragma unroll
+        for (int j = 0; j < kStackMaxH / 16; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
+    }
+    const float bias2 = b2[n0 + i];
+    // layer 3 operands: wave w -> rows w, w + 16, ...; 16-lane group o = output index, 16 strided k per lane
+    const int o3 = min(q, a.dout - 1);
+    float w3v[kStackMaxH / 16];
+#pragma unroll
+    for (int it = 0; it < kStackMaxH / 16; ++it) w3v[it] = W3[o3 * H + min(i + 16 * it, H - 1)];
+    const float bias3 = b3[o3];
+
+    // ---- layer 1 ------------------------------------------------------------------------------------
+    if (has_tile) {
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t], w1b, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * t + 4 * q + r;
+                float v = acc[r] + bias1;
+                v = v > 0.f ? v : 0.f;
+                h1s[rr * ldh + n0 + i] = v;
+                if (a.h1 && m0 + rr < a.M) a.h1[((long long)g * a.M + m0 + rr) * H + n0 + i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 2: R x 16 x H tile of h1 in LDS is the A operand of every wave; K order as in gemm16 ----
+    if (has_tile) {
+        f32x4 acc0[R], acc1[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < kStackMaxH / 16; ++j) {
+            if (16 * j < H) {
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    const float4 av = *reinterpret_cast<const float4*>(h1s + (16 * t + i) * ldh + 4 * q + 16 * j);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1[t], 0, 0, 0);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[j].w, acc1[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const f32x4 acc = acc0[t] + acc1[t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * t + 4 * q + r;
+                float v = acc[r] + bias2;
+                v = v > 0.f ? v : 0.f;
+                h2s[rr * ldh + n0 + i] = v;
+                if (a.h2 && m0 + rr < a.M) a.h2[((long long)g * a.M + m0 + rr) * H + n0 + i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 3: 16-lane dot products -----------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int r = 16 * t + wave;
+        float v = 0.f;
+#pragma unroll
+        for (int it = 0; it < kStackMaxH / 16; ++it)
+            if (i + 16 * it < H) v = fmaf(h2s[r * ldh + i + 16 * it], w3v[it], v);
+        v = row16_sum(v);
+        if (i == 0 && q < a.dout && m0 + r < a.M) a.out[((long long)g * a.M + m0 + r) * a.dout + q] = v + bias3;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
+    // row stride H + 20 floats: the 16 rows of a ds_read_b128 lane group land on distinct 16-byte slots
+    __shared__ __attribute__((aligned(16))) float h1s[R * kStackRows * (kStackMaxH + 20)];
+    __shared__ __attribute__((aligned(16))) float h2s[R * kStackRows * (kStackMaxH + 20)];
+    mlp3_fwd_body<R>(a, blockIdx.x, blockIdx.y, h1s, h2s);
+}
+
+// Several independent stacks (different networks and / or different inputs) in one launch: flat grid over
+// (stack, head, row tile).  The acting pass evaluates the task policy and the recovery policy on the same
+// observations (experiment.py:546-577): neither depends on the other.
+__device__ __forceinline__ void globalize(StackArgs& a) {
+    rrl_pack::to_global_all(a.x, a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.h1, a.h2, a.out);
+    rrl_pack::globalize(a.in_head);
+}
+struct StackGroup {
+    StackArgs a[kMaxGroup];
+    float* partial[kMaxGroup];      // split variant only
+    int G[kMaxGroup], tiles[kMaxGroup];
+    int first[kMaxGroup + 1];
+    int n;
+};
+
+template <int R>
+__global__ __launch_bounds__(1024) void mlp3_fwd_group_kernel(StackGroup sg) {
+    __shared__ __attribute__((aligned(16))) float h1s[R * kStackRows * (kStackMaxH + 20)];
+    __shared__ __attribute__((aligned(16))) float h2s[R * kStackRows * (kStackMaxH + 20)];
+    int k = 0;
+    while (k + 1 < sg.n && (int)blockIdx.x >= sg.first[k + 1]) ++k;
+    const int local = blockIdx.x - sg.first[k];
+    mlp3_fwd_body<R>(sg.a[k], local % sg.tiles[k], local / sg.tiles[k], h1s, h2s);
+}
+
+// ---- small-batch variant of the fused stack forward: hidden-2 columns split over S = 4 workgroups -----
+// With B = 256 rows the kernel above has only 16 workgroups (x heads) and each must pull all of W2
+// (256 KB, ~600 wave-level loads) through ONE compute unit, which is what bounds it (~13 us).  Here each
+// (16-row tile, head) is served by 4 workgroups of 4 waves; each recomputes the cheap layer 1 for all
+// columns, owns 64 hidden-2 columns (64 KB of W2) and emits a PARTIAL last-layer sum; a tiny second kernel
+// adds the four partials in a fixed order (deterministic).
+constexpr int kSplit = 4;   // measured: 8 column groups are slower (0.335 vs 0.320 ms per iteration)
+constexpr int kSplitPad = 20;   // pad floats per row of the h1 tile: rows 16-byte aligned, ds_read_b128 conflict-free
+
+// R = row tiles (of 16 rows) per workgroup.  R = 1 for the small update batches (latency-bound: as many workgroups as
+// possible).  Large batches (the acting pass, 4096 rows) are bound by re-streaming W2 from L2 once per row tile (64 MB
+// per network and forward at R = 1: 14-15 us); with R > 1 a wave keeps its W2 fragments for R row tiles and the stream
+// drops R-fold.  Measured at 4096 rows (profiles/mlp_fwd_probe.py; one head / two heads): plain tiling 15.4 / 20.7 us,
+// R = 1 split 13.9 / 24.2, R = 4 10.4 / 16.0, R = 2 9.6 / 15.4 (more workgroups in flight per CU).  Per output element the
+// arithmetic (MFMA order, partial-sum order) is the same for every R.
+// HC = the hidden width as a compile-time constant (256, the reference's --hidden_size default) or 0 = read it from
+// the arguments.  With HC fixed every loop below is straight-line code: no per-chunk bounds branches between the LDS
+// reads and the MFMAs (the run-time version waited for each ds_read right before its four MFMAs: 3 500 cycles for the
+// 2 048 cycles of MFMA issue of one 16-row tile), and the row-bounds checks are hoisted into one uniform branch.
+template <int R, int HC>
+__device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* partial, int bx, int g, int z, int G,
+                                                    float* h1s, float* h2s) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kW = 4;                                // waves per workgroup
+    const int m0 = bx * (R * kStackRows);
+    const int H = HC ? HC : a.H, ldh = H + kSplitPad, HS = H / kSplit, ld2 = HS + 1;
+    constexpr int kJ = HC ? HC / 16 : kStackMaxH / 16;             // K chunks of layer 2
+    constexpr int kU = HC ? HC / (16 * kW) : kStackMaxH / (16 * kW);   // layer-1 column tiles per wave
+    constexpr int kT3 = HC ? HC / (16 * kSplit) : kStackMaxH / (16 * kSplit);
+    const int colbase = z * HS;
+    const int M = a.M, din = a.din, dout = a.dout;
+    const float* W1 = a.W1 + (long long)g * H * din;
+    const float* b1 = a.b1 + (long long)g * H;
+    const float* W2 = a.W2 + (long long)g * H * H;
+    const float* b2 = a.b2 + (long long)g * H;
+    const float* W3 = a.W3 + (long long)g * dout * H;
+    const float* b3 = a.b3 + (long long)g * dout;
+    float* const h1g = (a.h1 && z == 0) ? a.h1 + ((long long)g * M + m0) * H : nullptr;
+    float* const h2g = a.h2 ? a.h2 + ((long long)g * M + m0) * H : nullptr;
+    const int i = lane & 15, q = lane >> 4;
+    const int ntiles1 = H / 16;                    // layer-1 column tiles, 4 waves take them round-robin
+    const bool has_tile2 = HC ? true : wave * 16 < HS;   // my layer-2 tile inside this group's columns
+    const int n2 = colbase + (has_tile2 ? wave * 16 : 0);
+    const bool full = m0 + R * kStackRows <= M;    // uniform: every row of the workgroup's tiles exists
+
+    // ---- all global reads up front, branch-free ---------------------------------------------------------
+    float xa[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int xrow = min(m0 + 16 * t + i, M - 1);
+        const float xv = a.x[(long long)xrow * a.ldx + min(q, din - 1)];
+        xa[t] = (q < din) ? xv : 0.f;
+    }
+    if (a.use_in_head) {
+        // lanes q = 0, 1 carry the observation, lanes q = 2, 3 the action dimension j = q - 2 of the policy head for
+        // their row.  Wave 0 evaluates it for the workgroup's rows (the transcendental chain costs ~1 000 cycles per row
+        // tile: done by every wave of four workgroups per CU it was +3.7 us on the 4096-row forward) and hands the
+        // values to the other waves through LDS (the h2 tile's space: nothing lives there yet); workgroup (z, g) = (0, 0)
+        // stores action and log-probability for the consumers downstream.  Same formulas, same bits as the kernels of
+        // update_kernels.hip.
+        const rrl_policy_head_t& hd = a.in_head;
+        const int j = q & 1;
+        const bool writer = z == 0 && g == 0;
+        float* xs = h2s;                                 // [R * 16][4]
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const int row = min(m0 + 16 * t + i, M - 1);
+                const bool row_ok = m0 + 16 * t + i < M;
+                float val, lp_term = 0.f;
+                const float e = hd.eps ? hd.eps[2 * row + j] : 0.f;
+                const float sc = hd.scale[j], bi = hd.bias[j];
+                if (hd.kind == RRL_HEAD_GAUSS) {
+                    const float mean = loss::psum(hd.head, 4 * row + j, hd.n_part, hd.part_stride);
+                    const float ls = fminf(fmaxf(loss::psum(hd.head, 4 * row + 2 + j, hd.n_part, hd.part_stride),
+                                                 loss::kLogSigMin), loss::kLogSigMax);
+                    const float y = tanhf(mean + expf(ls) * e);
+                    val = y * sc + bi;
+                    lp_term = -0.5f * e * e - ls - 0.918938533204672742f - logf(sc * (1.f - y * y) + loss::kEps);
+                } else {
+                    const float mean = tanhf(loss::psum(hd.head, 2 * row + j, hd.n_part, hd.part_stride)) * sc + bi;
+                    val = mean + expf(fmaxf(hd.log_std[j], hd.min_log_std)) * e;
+                }
+                const float other = __shfl_xor(lp_term, 16);           // lane (i, 2) <-> lane (i, 3)
+                float xv = xa[t];
+                if (q >= 2) {
+                    xv = val;
+                    if (writer && row_ok) {
+                        if (hd.action) hd.action[(long long)row * hd.ld_action + j] = val;
+                        if (hd.logp && q == 2) hd.logp[row] = lp_term + other;
+                    }
+                } else if (hd.obs_in) {
+                    xv = hd.obs_in[2 * row + q];
+                    if (writer && row_ok && hd.obs_out) hd.obs_out[(long long)row * hd.ld_action + q] = xv;
+                }
+                xs[(16 * t + i) * 4 + q] = xv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < R; ++t) xa[t] = xs[(16 * t + i) * 4 + q];
+        __syncthreads();                                 // h2s is reused by layer 2 (and aliases h1s for R > 1)
+    }
+    float w1b[kU], bias1[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+        const int t = min(wave + kW * u, ntiles1 - 1);
+        const float wv1 = W1[(t * 16 + i) * din + min(q, din - 1)];
+        w1b[u] = (q < din) ? wv1 : 0.f;
+        bias1[u] = b1[t * 16 + i];
+    }
+    // My 16 rows of W2 as MFMA B operands: lane (i, q) holds W2[n2 + i][16 j + 4 q .. + 3] in wv[j]
+    float4 wv[kJ];
+    {
+        const float* wrow = W2 + (long long)(n2 + i) * H + 4 * q;
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
+    }
+    const float bias2 = b2[n2 + i];
+    const int o3 = min(q, dout - 1);
+    float w3v[kT3];
+#pragma unroll
+    for (int it = 0; it < kT3; ++it) w3v[it] = W3[o3 * H + colbase + min(i + 16 * it, HS - 1)];
+    const float b3v = b3[o3];
+    const float bias3 = (z == 0) ? b3v : 0.f;
+
+    // ---- layer 1 (all H columns; one MFMA step per 16-column tile and row tile) ---------------------------
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+        const int t = wave + kW * u;
+        if (HC || t < ntiles1) {
+#pragma unroll
+            for (int rt = 0; rt < R; ++rt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[rt], w1b[u], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * rt + 4 * q + r;
+                    float v = acc[r] + bias1[u];
+                    v = v > 0.f ? v : 0.f;
+                    h1s[rr * ldh + t * 16 + i] = v;
+                }
+                if (h1g) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = 16 * rt + 4 * q + r;
+                        float v = acc[r] + bias1[u];
+                        v = v > 0.f ? v : 0.f;
+                        if (full || m0 + rr < M) h1g[(long long)rr * H + t * 16 + i] = v;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 2: my 16 columns, R row tiles sharing the W2 fragments -----------------------------------------
+    if (has_tile2) {
+        f32x4 acc0[R], acc1[R];
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            acc0[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) {
+            if (HC || 16 * j < H) {
+#pragma unroll
+                for (int rt = 0; rt < R; ++rt) {
+                    const float4 av = *reinterpret_cast<const float4*>(h1s + (16 * rt + i) * ldh + 4 * q + 16 * j);
+                    acc0[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0[rt], 0, 0, 0);
+                    acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1[rt], 0, 0, 0);
+                    acc0[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0[rt], 0, 0, 0);
+                    acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wv[j].w, acc1[rt], 0, 0, 0);
+                }
+            }
+        }
+        // R > 1: the h2 tile reuses the h1 tile's LDS (one 70 KB tile per workgroup instead of 87 KB: two workgroups per
+        // CU), so every wave must be done reading h1 first.  (All four waves own a layer-2 tile here: HC fixes H = 256.)
+        if (R > 1) __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+            const f32x4 acc = acc0[rt] + acc1[rt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * rt + 4 * q + r;
+                float v = acc[r] + bias2;
+                v = v > 0.f ? v : 0.f;
+                h2s[rr * ld2 + wave * 16 + i] = v;
+            }
+            if (h2g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * rt + 4 * q + r;
+                    float v = acc[r] + bias2;
+                    v = v > 0.f ? v : 0.f;
+                    if (full || m0 + rr < M) h2g[(long long)rr * H + n2 + i] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 3 partial over my HS columns: wave w -> rows 4 w .. 4 w + 3 of every row tile -----------------
+    float res[R][4];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 16 * rt + wave * 4 + rr;
+            float v = 0.f;
+#pragma unroll
+            for (int it = 0; it < kT3; ++it) {
+                const float hv = h2s[r * ld2 + min(i + 16 * it, HS - 1)];
+                if (HC || i + 16 * it < HS) v = fmaf(hv, w3v[it], v);
+            }
+            res[rt][rr] = v;
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const float v = row16_sum(res[rt][rr]);
+            const int r = 16 * rt + wave * 4 + rr;
+            if (i == 0 && q < dout && (full || m0 + r < M))
+                partial[(((long long)z * G + g) * M + m0 + r) * dout + q] = v + bias3;
+        }
+    }
+}
+
+constexpr int kBigR = 2;     // row tiles per workgroup for batches above kSplitSmallM rows (measured: 4 is slower, 10.4 vs 9.6 us)
+constexpr int kSplitSmallM = 1024;
+constexpr size_t split_lds_floats(int R) {
+    return size_t(R) * kStackRows * (kStackMaxH + kSplitPad) +
+           (R > 1 ? 0 : size_t(R) * kStackRows * (kStackMaxH / kSplit + 1));      // R > 1: the h2 tile aliases the h1 tile
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
+    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
+    else mlp3_fwd_split_body<R, 0>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
+}
+
+// flat grid over (stack, column split, head, row tile)
+template <int R>
+__device__ __forceinline__ void mlp3_fwd_split_group_body(const StackGroup& sg, int block, float* lds) {
+    int k = 0;
+    while (k + 1 < sg.n && block >= sg.first[k + 1]) ++k;
+    const int local = block - sg.first[k];
+    const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
+    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
+    StackArgs a = sg.a[k];                   // this workgroup's member, copied out of the group (see gemm16_group_body)
+    globalize(a);
+    float* partial = sg.partial[k];
+    rrl_pack::to_global(partial);
+    const int G = sg.G[k];
+    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
+    else mlp3_fwd_split_body<R, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    mlp3_fwd_split_group_body<R>(sg, blockIdx.x, lds);
+}
+
+// the same launch for S seeds (pack.hpp): seed s runs its group on workgroups [first[s], first[s + 1])
+template <int R>
+__global__ __launch_bounds__(256) void mlp3_fwd_split_pack_kernel(const StackGroup* __restrict__ groups, rrl_pack::Idx ix) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int s, local;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
+    mlp3_fwd_split_group_body<R>(groups[s], local, lds);
+}
+
+__global__ void sum_partials_kernel(int n, const float* __restrict__ partial, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float v = partial[e];
+#pragma unroll
+    for (int z = 1; z < kSplit; ++z) v += partial[(long long)z * n + e];
+    out[e] = v;
+}
+
+constexpr int kPackSmallR2MinSeeds = 3;   // packed launches: 2 row tiles per workgroup for the B <= 1024 forwards from 3 seeds on
+
+}  // namespace
+
+extern "C" {
+
+int rrl_mlp3_is_split(int M, int H) {
+    (void)M;
+    return ((H % (16 * kSplit)) == 0 && H <= kStackMaxH) ? kSplit : 0;
+}
+
+static int stack_check(int G, int M, int H, int din, int dout, const float* x, const float* W1, const float* b1,
+                       const float* W2, const float* b2, const float* W3, const float* b3, const float* out) {
+    if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return RRL_EINVAL;
+    if (G <= 0 || G > 65535 || M <= 0 || din <= 0 || din > 4 || dout <= 0 || dout > 4) return RRL_ERANGE;
+    if (H <= 0 || H > kStackMaxH || (H % 16) != 0) return RRL_ERANGE;
+    return RRL_OK;
+}
+
+int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int ldx, const float* W1,
+                     const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                     float* h1, float* h2, float* out, float* scratch, int finalize, void* stream) {
+    const int rc = stack_check(G, M, H, din, dout, x, W1, b1, W2, b2, W3, b3, out);
+    if (rc != RRL_OK) return rc;
+    StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx, rrl_policy_head_t{}, 0};
+    if (scratch && rrl_mlp3_is_split(M, H)) {
+        // 4 workgroups (column groups) per row tile + fixed-order sum of their partial last-layer outputs
+        if (M <= kSplitSmallM || H != 256) {
+            hipLaunchKernelGGL(mlp3_fwd_split_kernel<1>, dim3((M + kStackRows - 1) / kStackRows, G, kSplit), dim3(256),
+                               split_lds_floats(1) * 4, (hipStream_t)stream, a, scratch);
+        } else {
+            static const bool ok = grant_lds((const void*)mlp3_fwd_split_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+            if (!ok) return RRL_ERANGE;
+            const int rows = kBigR * kStackRows;
+            hipLaunchKernelGGL(mlp3_fwd_split_kernel<kBigR>, dim3((M + rows - 1) / rows, G, kSplit), dim3(256),
+                               split_lds_floats(kBigR) * 4, (hipStream_t)stream, a, scratch);
+        }
+        if (finalize) {
+            const int n = G * M * dout;
+            hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n,
+                               scratch, out);
+        }
+        return check_launch();
+    }
+    // more than one workgroup per CU (256 CUs): two row tiles per workgroup halve the W2 re-streaming
+    if ((long long)((M + kStackRows - 1) / kStackRows) * G > 256)
+        hipLaunchKernelGGL((mlp3_fwd_kernel<2>), dim3((M + 2 * kStackRows - 1) / (2 * kStackRows), G), dim3(1024), 0,
+                           (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((mlp3_fwd_kernel<1>), dim3((M + kStackRows - 1) / kStackRows, G), dim3(1024), 0,
+                           (hipStream_t)stream, a);
+    return check_launch();
+}
+
+// Every stack of the group takes the path rrl_mlp3_forward would take for it on its own (so the results are the
+// stand-alone launches', bit for bit); the group must be homogeneous: all split (scratch given, partial sums left in
+// scratch = finalize 0) or all on the same non-split tiling.
+static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& path, int big_r = kBigR, int small_r = 1) {
+    if (!st || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
+    sg = StackGroup{};
+    sg.n = n;
+    sg.first[0] = 0;
+    path = -1;   // 0 split (small batch), 3 split (R = kBigR row tiles); 1 plain R = 1, 2 plain R = 2
+    for (int k = 0; k < n; ++k) {
+        const rrl_stack_t& p = st[k];
+        const int rc = stack_check(p.G, p.M, p.H, p.din, p.dout, p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.out);
+        if (rc != RRL_OK) return rc;
+        sg.a[k] = StackArgs{p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.h1, p.h2, p.out, p.M, p.H, p.din, p.dout, p.ldx,
+                            p.in_head, p.use_in_head};
+        if (p.use_in_head) {
+            const rrl_policy_head_t& h = p.in_head;
+            if (p.din != 4 || !h.head || !h.scale || !h.bias || h.n_part <= 0 || h.n_part > 4 ||
+                (h.kind == RRL_HEAD_GAUSS ? !h.eps : (h.kind != RRL_HEAD_STOCH || !h.log_std)) || (h.obs_out && !h.action))
+                return RRL_EINVAL;
+            if (!(p.scratch && rrl_mlp3_is_split(p.M, p.H))) return RRL_EINVAL;   // the column-split kernels only
+        }
+        sg.partial[k] = p.scratch;
+        sg.G[k] = p.G;
+        int my;
+        const long long tiles16 = (p.M + kStackRows - 1) / kStackRows;
+        if (p.scratch && rrl_mlp3_is_split(p.M, p.H)) {
+            my = (p.M <= kSplitSmallM || p.H != 256) ? 0 : 3;      // the multi-row tiles are built for H = 256
+            if (my == 0 && small_r > 1 && p.H != 256) return RRL_EINVAL;
+            const int rows = (my == 0 ? small_r : big_r) * kStackRows;
+            sg.tiles[k] = (p.M + rows - 1) / rows;
+            sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G * kSplit;
+        } else if (tiles16 * p.G > 256) {
+            my = 2;
+            sg.tiles[k] = (p.M + 2 * kStackRows - 1) / (2 * kStackRows);
+            sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G;
+        } else {
+            my = 1;
+            sg.tiles[k] = int(tiles16);
+            sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G;
+        }
+        if (path >= 0 && my != path) return RRL_EINVAL;
+        path = my;
+    }
+    for (int k = n; k < kMaxGroup; ++k) sg.first[k + 1] = sg.first[n];
+    return RRL_OK;
+}
+
+int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
+    StackGroup sg;
+    int path;
+    const int rc = build_stack_group(n, st, sg, path);
+    if (rc != RRL_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (path == 0) {
+        hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<1>, dim3(sg.first[n]), dim3(256), split_lds_floats(1) * 4, s, sg);
+    } else if (path == 3) {
+        static const bool ok = grant_lds((const void*)mlp3_fwd_split_group_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+        if (!ok) return RRL_ERANGE;
+        hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<kBigR>, dim3(sg.first[n]), dim3(256),
+                           split_lds_floats(kBigR) * 4, s, sg);
+    } else if (path == 1) hipLaunchKernelGGL((mlp3_fwd_group_kernel<1>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
+    else hipLaunchKernelGGL((mlp3_fwd_group_kernel<2>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
+    return check_launch();
+}
+
+// the column-split kernels only (what the steady-state iteration launches at H = 256); every seed on the same path
+int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const* members, void* stream) {
+    rrl_pack::Key key;
+    if (!pack_key(2, S, n, members, key)) return RRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    rrl_pack::Plan* plan = rrl_pack::lookup(key);
+    if (!plan) {
+        std::vector<StackGroup> groups;
+        rrl_pack::Idx ix;
+        int path = -1;
+        const int big_r = kBigR;      // (4 row tiles per workgroup measured at S = 4, 8: not faster, profiles/patches/README.md)
+        // small batches (the updates' B = 256 forwards): kBigR row tiles per workgroup from kPackSmallR2MinSeeds seeds
+        // on, when every member has the hidden width the multi-row tiles are built for
+        bool all256 = true;
+        for (int s = 0; s < S; ++s)
+            for (int k = 0; k < n[s]; ++k) all256 = all256 && members[s] && members[s][k].H == 256;
+        const int small_r = (S >= kPackSmallR2MinSeeds && all256) ? big_r : 1;
+        const int rc = build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
+            int my;
+            const int r = build_stack_group(nk, m, g, my, big_r, small_r);
+            if (r != RRL_OK) return r;
+            if ((my != 0 && my != 3) || (path >= 0 && my != path)) return int(RRL_EINVAL);
+            path = my;
+            return int(RRL_OK);
+        });
+        if (rc != RRL_OK) return rc;
+        if (path == 3) {
+            static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+            if (!ok) return RRL_ERANGE;
+        }
+        plan = rrl_pack::store(key, groups.data(), sizeof(StackGroup) * S, st);
+        if (!plan) return RRL_ELAUNCH;
+        plan->grid = rrl_pack::finish(ix);
+        plan->ix = ix;
+        // small members on multi-row tiles run the large-batch kernel (path 3)
+        if (small_r > 1 && path == 0) {
+            static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+            if (!ok) return RRL_ERANGE;
+            path = 3;
+        }
+        plan->i0 = path;
+    }
+    if (plan->i0 == 0)
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(plan->grid), dim3(256), split_lds_floats(1) * 4, st,
+                           (const StackGroup*)plan->dev, plan->ix);
+    else
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(plan->grid), dim3(256),
+                           split_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
+    return check_launch();
+}
+
+}  // extern "C"

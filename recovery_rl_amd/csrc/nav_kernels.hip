@@ -947,7 +947,7 @@ thread_local int rrl_host::last_hip_error = 0;
 
 extern "C" {
 
-int rrl_abi_version(void) { return 3; }   // 2: pos_cnt carries a second count level (RRL_POS_CNT_LEN); 3: rrl_replay_t.pinned
+int rrl_abi_version(void) { return 4; }   // 2: pos_cnt carries a second count level (RRL_POS_CNT_LEN); 3: rrl_replay_t.pinned; 4: RRL_DRAW_DEMO_SHARE
 
 int rrl_last_hip_error(void) { return rrl_host::last_hip_error; }
 

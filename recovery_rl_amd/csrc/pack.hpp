@@ -91,10 +91,8 @@ __device__ __forceinline__ void globalize(rrl_policy_head_t& h) {
 
 // host: choose the mapping for `ix` (first[] and S filled in) and return the grid size
 inline int finish(Idx& ix) {
-    static const bool xcd = [] { const char* e = getenv("RRL_PACK_XCD"); return !(e && e[0] == '0'); }();
     ix.sp = ix.p = 0;
     ix.r = 1;
-    if (!xcd) return ix.first[ix.S];
     int most = 0;
     for (int s = 0; s < ix.S; ++s) most = ix.first[s + 1] - ix.first[s] > most ? ix.first[s + 1] - ix.first[s] : most;
     if (ix.S > 8) {
@@ -106,9 +104,7 @@ inline int finish(Idx& ix) {
         ix.r = (ix.S + 7) / 8;
         return 8 * ix.r * most;
     }
-    // RRL_PACK_MIN_SP (probe): pin a seed to fewer XCDs than S alone would (8 = one XCD per seed even for one seed)
-    static const int min_sp = [] { const char* e = getenv("RRL_PACK_MIN_SP"); return e ? atoi(e) : 1; }();
-    int sp = min_sp > 8 ? 8 : (min_sp < 1 ? 1 : min_sp);
+    int sp = 1;
     while (sp < ix.S) sp <<= 1;
     ix.sp = sp;
     ix.p = 8 / sp;

@@ -26,12 +26,6 @@ constexpr int kTile = 1024;   // rows per workgroup in the masked push
 using rrl_replay::advance_ring;
 using rrl_replay::kChunk;
 
-// timing ablations for profiles/creplay_probe.py (wrong results!): stop the stratified sampler after 1 = the count scan,
-// 2 = the distinct draws, 3 = the rank -> chunk walk, 4 = the reward scan
-#ifndef RRL_CREPLAY_ABLATE
-#define RRL_CREPLAY_ABLATE 0
-#endif
-
 struct Rows {
     const float2* s;
     const float2* a;
@@ -301,9 +295,6 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
     __syncthreads();
     const int64_t total_pos = sup[n_super];
     const int64_t total_neg = size - total_pos;
-#if RRL_CREPLAY_ABLATE == 1
-    return;
-#endif
     if (int64_t(n_pos) > total_pos || int64_t(n_neg) > total_neg) {
         const bool feasible = int64_t(B) <= size && (rb.flags & RRL_REPLAY_CLAMP_STRATIFIED);
         if (!feasible) {
@@ -327,9 +318,6 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
         if (tid == 0) rb.state[3] = 2;
         return;
     }
-#if RRL_CREPLAY_ABLATE == 2
-    return;
-#endif
     if (tid >= B) return;
     // rank -> slot: binary search the super-chunk in LDS, walk its 64 first-level counts (16 independent 16-byte loads),
     // then scan the chunk's 64 rewards
@@ -385,9 +373,6 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
         return;
     }
     const int a = c_first + a_rel;
-#if RRL_CREPLAY_ABLATE == 3
-    if (rem >= 0) return;
-#endif
     const int64_t c0 = int64_t(a) * kChunk;
     // the chunk's bit mask instead of its 64 rewards (256 B and a 64-step compare chain per row: 6 of the kernel's 19 us):
     // the rem-th set bit of the class's candidates, by popcounts of halves
@@ -414,9 +399,6 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
         rb.state[3] = 3;
         return;
     }
-#if RRL_CREPLAY_ABLATE == 4
-    if (slot >= 0) return;
-#endif
     gather_row(rb, slot, tid, out);
 }
 
@@ -431,12 +413,55 @@ __global__ __launch_bounds__(1024) void creplay_sample_gather_kernel(rrl_replay_
                                smem);
 }
 
+// Demonstration-share draw (the lock-step loop's rule for the safety critic's batch, DESIGN "replay"): lanes [0, n_demo)
+// draw distinct rows of the pinned range [0, pinned) -- the offline constraint demonstrations, experiment.py:278-286 --
+// lanes [n_demo, B) distinct rows of the online range [pinned, size).  A range with too few rows gives all it has and
+// the other one fills the batch.  Ranks ARE slots here (demo rank k = slot k, online rank k = slot pinned + k).
+__device__ __forceinline__ void split_sample_gather_body(const rrl_replay_t& rb, int n_demo, int n_online, uint64_t seed,
+                                                         uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,
+                                                         int table_mask, const BatchOut& out, char* smem) {
+    const int B = n_demo + n_online;
+    unsigned long long* table = (unsigned long long*)smem;      // [table_mask + 1]
+    uint32_t* key = (uint32_t*)(table + table_mask + 1);
+    const int64_t size = rb.state[1];
+    const int tid = threadIdx.x;
+    if (int64_t(B) > size) {  // random.sample would raise ValueError
+        if (tid == 0) rb.state[3] = 1;
+        return;
+    }
+    const int64_t demo_total = min(rb.pinned, size), online_total = size - demo_total;
+    if (int64_t(n_online) > online_total) { n_online = int(online_total); n_demo = B - n_online; }
+    else if (int64_t(n_demo) > demo_total) { n_demo = int(demo_total); n_online = B - n_demo; }
+    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
+    rrl::advance_counter_blocks(counter_dev, counter_inc, 1);
+    const bool is_demo = tid < n_demo;
+    const uint64_t population = uint64_t(is_demo ? demo_total : online_total);
+    const uint32_t stream = is_demo ? rrl::kStreamSample : rrl::kStreamSampleNeg;
+    const int gi = is_demo ? tid : tid - n_demo;              // numbered from 0 within the group, like a separate call
+    const bool whole = population == uint64_t(is_demo ? n_demo : n_online);
+    if (!draw_distinct(tid, B, is_demo ? 0 : 1, population, seed, stream, ctr, gi, key, table, table_mask, whole)) {
+        if (tid == 0) rb.state[3] = 2;
+        return;
+    }
+    if (tid >= B) return;
+    const int64_t k = int64_t(key[tid] & 0x7fffffffu);
+    gather_row(rb, is_demo ? k : demo_total + k, tid, out);
+}
+
+__global__ __launch_bounds__(1024) void split_sample_gather_kernel(rrl_replay_t rb, int n_demo, int n_online,
+                                                                   uint64_t seed, uint64_t counter,
+                                                                   uint64_t* counter_dev, uint64_t counter_inc,
+                                                                   int table_mask, BatchOut out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    split_sample_gather_body(rb, n_demo, n_online, seed, counter, counter_dev, counter_inc, table_mask, out, smem);
+}
+
 // The two draws of one lock-step iteration (task buffer for the SAC update, safety buffer for the Q_risk update:
 // experiment.py:397-416) and the iteration's policy noise do not depend on each other: one launch, workgroup 0 and 1
 // are the samplers (exactly the stand-alone kernels' code), the remaining workgroups fill the noise buffer.
 struct DrawArgs {
     rrl_replay_t rb;
-    int mode;            // 0: none, 1: uniform (sample_gather), 2: stratified (creplay_sample_gather)
+    int mode;            // 0: none, 1: uniform (sample_gather), 2: stratified (creplay_sample_gather), 3: demo share (split_sample_gather)
     int B, n_pos, n_neg, n_chunks, table_mask;
     uint64_t seed, counter;
     uint64_t* counter_dev;
@@ -458,6 +483,9 @@ __device__ __forceinline__ void draw_body(const DrawArgs& d, char* smem) {
     else if (d.mode == 2)
         creplay_sample_gather_body(d.rb, d.n_pos, d.n_neg, d.n_chunks, d.seed, d.counter, d.counter_dev, d.counter_inc,
                                    d.table_mask, d.out, smem);
+    else if (d.mode == 3)
+        split_sample_gather_body(d.rb, d.n_pos, d.n_neg, d.seed, d.counter, d.counter_dev, d.counter_inc, d.table_mask,
+                                 d.out, smem);
 }
 
 __device__ __forceinline__ void sample_group_body(const DrawArgs& a, const DrawArgs& b, const NoiseArgs& nz, int block,
@@ -558,13 +586,15 @@ static int draw_setup(const rrl_draw_t& d, DrawArgs& a, int& threads, size_t& ld
     while (table_size < 4 * B) table_size <<= 1;
     a.table_mask = table_size - 1;
     threads = ((B + 63) / 64) * 64;
-    if (!d.stratified) {
+    if (d.stratified == RRL_DRAW_UNIFORM || d.stratified == RRL_DRAW_DEMO_SHARE) {
         if (rb->cap >= (int64_t(1) << 31)) return RRL_ERANGE;
-        a.mode = 1;
+        if (d.stratified == RRL_DRAW_DEMO_SHARE && (rb->pinned < 0 || rb->pinned >= rb->cap)) return RRL_ERANGE;
+        a.mode = d.stratified == RRL_DRAW_UNIFORM ? 1 : 3;
         a.n_chunks = 0;
         lds = size_t(table_size) * 8 + size_t(B) * 4 + 16;
         return RRL_OK;
     }
+    if (d.stratified != RRL_DRAW_STRATIFIED) return RRL_EINVAL;
     if (!rb->pos_cnt) return RRL_EINVAL;
     if (rb->cap > (int64_t(1) << 21)) return RRL_ERANGE;
     a.mode = 2;
@@ -691,6 +721,24 @@ int rrl_replay_sample_gather(const rrl_replay_t* rb, int32_t B, uint64_t seed, u
     const size_t lds = size_t(table_size) * 8 + size_t(B) * 4 + 16;
     hipLaunchKernelGGL(sample_gather_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, *rb,
                        B, seed, counter, counter_dev, counter_inc, table_size - 1, out);
+    return check_launch();
+}
+
+int rrl_replay_sample_gather_split(const rrl_replay_t* rb, int32_t n_demo, int32_t n_online, uint64_t seed,
+                                   uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* s, float* a,
+                                   float* r, float* s2, float* m, int64_t* idx_out, float* xu, float* x2u, float* xpu,
+                                   void* stream) {
+    if (!valid_rb(rb) || !s || !a || !r || !s2 || !m) return RRL_EINVAL;
+    const int B = n_demo + n_online;
+    if (n_demo < 0 || n_online < 0 || B <= 0 || B > 1024 || rb->cap >= (int64_t(1) << 31)) return RRL_ERANGE;
+    if (rb->pinned < 0 || rb->pinned >= rb->cap) return RRL_ERANGE;
+    const BatchOut out{(float2*)s, (float2*)a, r, (float2*)s2, m, idx_out, (float4*)xu, (float4*)x2u, (float4*)xpu};
+    const int threads = ((B + 63) / 64) * 64;
+    int table_size = 64;
+    while (table_size < 4 * B) table_size <<= 1;
+    const size_t lds = size_t(table_size) * 8 + size_t(B) * 4 + 16;
+    hipLaunchKernelGGL(split_sample_gather_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, *rb, n_demo,
+                       n_online, seed, counter, counter_dev, counter_inc, table_size - 1, out);
     return check_launch();
 }
 

@@ -79,10 +79,6 @@ class VectorLoop:
         # the fused step also writes env.next_obs / reward / done / constraint / success / ep_done (off: nobody reads them
         # in the steady-state graph; the episode log and the online ensemble re-fit switch them on by themselves)
         self.step_outputs = False
-        # opt-in: the acting pass's 4096-row forwards share launches with the Q_risk update's 256-row ones (21 launches instead
-        # of 22).  Measured: no gain (0.1975 vs 0.1943 ms) -- a launch lasts as long as its largest member, and the two large
-        # forwards cost ~18 us each wherever they sit
-        self.ride_actor = False
         if self.n > 1 and hasattr(recovery_memory, "clamp_stratified"):
             # N envs overwrite the ring in capacity / N iterations: once the policy avoids violations the positive
             # class can drop below int(B * pos_fraction) rows, where the one-env reference would abort
@@ -93,7 +89,7 @@ class VectorLoop:
         self.obs = self.env.reset()
         return self.obs
 
-    def do_updates(self, i_episode=1, online_qrisk=True, fused_act_follows=False):
+    def do_updates(self, i_episode=1, online_qrisk=True):
         """experiment.py:397-416.  The caller has checked len(memory) > batch_size."""
         cfg = self.cfg
         fast = getattr(self.agent, "fast", None)
@@ -101,20 +97,12 @@ class VectorLoop:
         grouped = (fast is not None and fast.grouped and fast.sync_world == 1 and cfg.batch_size == fast.B
                    and hasattr(self.memory, "draw_desc")
                    and (not online_qrisk or qr.clamp_batch_size(cfg.batch_size, len(self.recovery_memory)) == fast.B))
-        # the acting pass that follows rides in the LAST update pair's launches (fast_update.qrisk_update_grouped) when it is
-        # the fused acting pass on the env's own observation buffer
-        ride = None
-        if (fused_act_follows and grouped and online_qrisk and self.ride_actor and self._actor is not None
-                and self.obs is self.env.obs
-                and cfg.use_recovery and cfg.MF_recovery and self._can_fuse_step() and self._actor.n == self.n):
-            ride = (self._actor, self.obs)
         for u in range(cfg.updates_per_step):
             if grouped:
                 # both replay draws + the policy noise in one launch, independent kernels of the two updates grouped
                 # (fast_update.FastUpdater.update_pair): same results as the two calls below, ~30 % fewer launches
                 with trace_range("sample+sac_update+qrisk_update"):
-                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None,
-                                     actor=ride if u == cfg.updates_per_step - 1 else None)
+                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None)
                 self.host_updates[0] += 1
                 if online_qrisk:
                     qr.updates += 1
@@ -317,7 +305,7 @@ class VectorLoop:
     # -- whole iteration -----------------------------------------------------------------------
     def vector_step(self, do_update=True, random_actions=False, online_qrisk=True, i_episode=1):
         if do_update:
-            self.do_updates(i_episode, online_qrisk, fused_act_follows=not random_actions)
+            self.do_updates(i_episode, online_qrisk)
         with trace_range("act"):
             action, real_action, recovery = self.act(self.obs, random_actions)
         self._last_recovery, self._last_real_action = recovery, real_action
@@ -472,6 +460,21 @@ class Experiment:
         data = self.env.transition_function(cfg.num_unsafe_transitions)
         return data, None
 
+    def _apply_demo_share(self):
+        """Vectorisation rule for the safety critic's training mix (arg_utils --demo_share): with N > 1 envs and pinned
+        demonstrations, int(B * share) rows of every Q_risk batch come from the demonstrations and the rest from the
+        online rows.  The one-env reference draws uniformly from a buffer the 20 000 demonstrations fill from 100 % (first
+        episode) to about half (400th episode; experiment.py:278-286,438-448, replay_memory.py:54-72): at 4096 envs a
+        uniform draw would show them in 2 % of the rows from the 245th iteration on."""
+        cfg = self.exp_cfg
+        share = float(getattr(cfg, "demo_share", -1.0))
+        pinned = getattr(self.recovery_memory, "pinned", 0)
+        if share < 0:
+            share = 0.5 if (cfg.num_envs > 1 and pinned > 0) else 0.0
+        if share > 0 and pinned <= 0:
+            raise ValueError("--demo_share needs pinned demonstrations (lock-step loop without --no_pin_demos)")
+        self.agent.safety_critic.demo_share = share if share > 0 else None
+
     # -- pre-training ----------------------------------------------------------------------------
     def pretrain_critic_recovery(self):
         """experiment.py:261-305."""
@@ -485,6 +488,7 @@ class Experiment:
                 # demonstrations -- the only violations a safe policy ever shows the safety critic; the one-env reference
                 # (4e4 env-steps per run) never wraps its ring, i.e. keeps them for the whole run
                 self.recovery_memory.pin()
+            self._apply_demo_share()
         self.num_unsafe_transitions = n_demo
         self.num_constraint_violations += int(c.sum().item())
         self.loop.num_constraint_violations = self.num_constraint_violations
@@ -665,6 +669,7 @@ class Experiment:
         mb_resume = []
         if getattr(cfg, "resume", ""):
             extra = checkpoint.load(self, cfg.resume)
+            self._apply_demo_share()
             it, next_eval = extra["iteration"], extra["next_eval"]
             history, evals, episodes = extra["history"], extra["evals"], [extra["episodes"]]
             mb_resume = [tuple(x.to(self.device) for x in row) for row in extra["mb_new"]]

@@ -184,12 +184,6 @@ class Stack:
         self.scratch = z(max(self.nsplit, 1), G, B, net.dout)
         self.finalize = False                       # True: always hand back the summed output tensor
         self.pair_hidden = True                     # dW2 and dh1 of the backward in one launch
-        # opt-in (set_fuse_head): critic-type head backward inside the hidden-layer launch, whose tiles generate dh2 from
-        # (h2, W3, dOut) instead of reading it -- 19 launches per iteration instead of 22, bit-identical results, but NOT
-        # faster: the fused launch takes 14-15 us, what the two launches it replaces take together (7.2 + 7.5 us), with the
-        # tiles on one wave of four, four wave-local tiles per workgroup, or the dOut prologue under the first loads alike
-        # (0.200-0.202 vs 0.194 ms per iteration; profiles/round3 notes).  Launch COUNT is not what bounds this chain.
-        self.fuse_head = False
         self._init_first(dev, G, B, H, net.din)
 
     def _init_first(self, dev, G, B, H, din):
@@ -271,12 +265,6 @@ class Stack:
             first = _lib.rrl_first_layer_t(p(self.x), p(P["W1"]), self.x.stride(0), net.din,
                                            p(self.first_part) if wg else None, self.first_part.stride(0),
                                            p(self.dx_part) if input_grad else None)
-            # one-output heads with a loss description (the critic-type losses): the head backward runs inside the
-            # hidden-layer launch, whose tiles generate dh2 instead of reading it (rrl_hidden_bwd_t.fuse_head)
-            if self.fuse_head and net.dout == 1 and 0 <= loss.kind <= _lib.LOSS_QRISK_POLICY and B in (128, 256):
-                hidden = _lib.rrl_hidden_bwd_t(G, B, H, None, p(self.h1), p(P["W2"]), p(Gr["W2"]) if wg else None,
-                                               p(Gr["b2"]) if wg else None, None, first, head, 1)
-                return None, hidden, None
             hidden = _lib.rrl_hidden_bwd_t(G, B, H, p(self.dh2), p(self.h1), p(P["W2"]), p(Gr["W2"]) if wg else None,
                                            p(Gr["b2"]) if wg else None, None, first)
             return head, hidden, None
@@ -339,18 +327,16 @@ def forward_multi(descs):
 def backward_multi(triples):
     """Independent stack backwards, stage by stage: three launches for all of them (head, hidden, input)."""
     lib, st, n = _lib.load(), _lib.current_stream(), len(triples)
-    head_list = [t[0] for t in triples if t[0] is not None]     # members whose head backward is not fused into `hidden`
-    heads = (_lib.rrl_head_bwd_t * len(head_list))(*head_list) if head_list else None
+    head_list = [t[0] for t in triples]
+    heads = (_lib.rrl_head_bwd_t * len(head_list))(*head_list)
     hidden = (_lib.rrl_hidden_bwd_t * n)(*[t[1] for t in triples])
     rest = [t[2] for t in triples if t[2] is not None]          # stacks whose first layer is not fused into `hidden`
     inputs = (_lib.rrl_input_bwd_t * len(rest))(*rest) if rest else None
-    if heads is not None:
-        record("head_bwd", heads, len(head_list))
+    record("head_bwd", heads, len(head_list))
     record("hidden_bwd", hidden, n)
     if inputs is not None:
         record("unsupported", "rrl_mlp_input_backward_multi")
-    if heads is not None:
-        _lib.check(lib.rrl_mlp_head_backward_multi(len(head_list), heads, st), "rrl_mlp_head_backward_multi")
+    _lib.check(lib.rrl_mlp_head_backward_multi(len(head_list), heads, st), "rrl_mlp_head_backward_multi")
     _lib.check(lib.rrl_mlp_hidden_backward_multi(n, hidden, st), "rrl_mlp_hidden_backward_multi")
     if inputs is not None:
         _lib.check(lib.rrl_mlp_input_backward_multi(len(inputs), inputs, st), "rrl_mlp_input_backward_multi")
@@ -377,7 +363,6 @@ class StackRows(Stack):
         self.h1, self.h2 = parent.h1[:, lo:hi], parent.h2[:, lo:hi]
         self.dh1, self.dh2, self.dx = z(1, self.B, H), z(1, self.B, H), z(1, self.B, parent.net.din)
         self.pair_hidden = True
-        self.fuse_head = False
         self._init_first(dev, 1, self.B, H, parent.net.din)
 
     def forward(self, *a, **k):
@@ -456,11 +441,6 @@ class FastUpdater:
         are all-reduced, and by the stand-alone loss-gradient kernels of fuse_loss = False)."""
         for st in self.stacks():
             st.fuse_first = bool(on) and st.first_part is not None
-
-    def set_fuse_head(self, on):
-        """Critic-type head backward inside the hidden-layer launch (tiles generate dh2) or as its own launch (writes dh2)."""
-        for st in self.stacks():
-            st.fuse_head = bool(on)
 
     def gather_first_grads(self):
         """Write the summed (dW1, db1) partials of the last backward into the flat gradient buffers (inspection and
@@ -586,7 +566,7 @@ class FastUpdater:
                                       p(self.rbias), p(action_view), action_view.stride(0), None, None, None, None,
                                       p(self.recpolicy.p["log_std"]), float(self.qr.policy.min_log_std))
 
-    def update_pair(self, memory, recovery_memory, actor=None):
+    def update_pair(self, memory, recovery_memory):
         """One SAC update and (recovery_memory not None) one Q_risk + recovery-policy update of a lock-step iteration
         (experiment.py:397-416): both replay draws and the iteration's policy noise in ONE launch, then the two
         updates on the grouped kernels.  Same draws, same arithmetic, same parameters as the separate calls."""
@@ -594,7 +574,8 @@ class FastUpdater:
         d1, batch = memory.draw_desc(B, rows=self.rows)
         d2 = batch_q = None
         if recovery_memory is not None:
-            d2, batch_q = recovery_memory.draw_desc(B, pos_fraction=qr.pos_fraction, rows=self.rows_q)
+            d2, batch_q = recovery_memory.draw_desc(B, pos_fraction=qr.pos_fraction, rows=self.rows_q,
+                                                    demo_share=qr.demo_share)
         n_act = self.actor_rows
         need = 4 * B * 2 + 2 * n_act * 2
         if self._noise_buf is None or self._noise_buf.numel() != need:
@@ -611,7 +592,7 @@ class FastUpdater:
         n = self._noise
         self.sac_update_grouped(batch, n[0], n[1])
         if recovery_memory is not None:
-            self.qrisk_update_grouped(batch_q, n[2], n[3], actor=actor)
+            self.qrisk_update_grouped(batch_q, n[2], n[3])
         return self.losses
 
     def sac_update_grouped(self, batch, eps_next, eps_pi):
@@ -651,7 +632,7 @@ class FastUpdater:
                            (self.policy, None, 0.0, self.pol_b.grad_part)])
         return self.losses
 
-    def qrisk_update_grouped(self, batch, eps_next, eps_pi, actor=None):
+    def qrisk_update_grouped(self, batch, eps_next, eps_pi):
         """qrisk_update with 15 launches instead of 19: the task policy on s' and the recovery policy on s in one
         forward launch (the recovery policy does not depend on the critic step in between), their heads in one, the
         target and online critics in one."""
@@ -664,14 +645,6 @@ class FastUpdater:
         if mf:
             fwd.append(self.rec_a.forward_desc(xpu[:, 0:2]))
         fuse = self.fuse_heads and self.qr_t.split
-        # `actor` = (FastActor, obs): the acting pass of THIS iteration rides along.  The task policy is final once the SAC
-        # update has stepped it, so its 4096-row forward joins this launch; Q_risk(s, a_task) joins the launch that follows
-        # the Q_risk optimiser step; only the recovery policy's forward is left for after its own step (FastActor.act).
-        ride = actor is not None and mf and fuse and actor[0].qr.split and actor[0].pol.split
-        if ride:
-            act, obs = actor
-            act.noise = self.actor_noise(act.n)
-            fwd.append(act.pol.forward_desc(obs, save=False))
         forward_multi(fwd)
         hd_next = self._gauss_desc(self.pol_a.parts, eps_next, x2u[:, 2:4], self.logp2)
         hd_rec = self._stoch_desc(self.rec_a.parts, eps_pi, xpu[:, 2:4]) if mf else None
@@ -690,14 +663,7 @@ class FastUpdater:
             raw, rn, rs = self.rec_a.parts
             ls = self.recpolicy.p["log_std"]
             if hd_rec is not None:         # the recovery action is evaluated by the critic stack that consumes it
-                members = [self.qr_b.forward_desc(xpu, in_head=hd_rec)]
-                if ride:                   # Q_risk(s, a_task) of the acting pass, at the critic this update just stepped
-                    act.qr.finalize = False
-                    task_head = self._gauss_desc(act.pol.parts, act.noise[0], act.xa[:, 2:4], None, n=act.n, obs_in=obs,
-                                                 obs_out=act.xa)
-                    members.append(act.qr.forward_desc(act.xa, save=False, in_head=task_head))
-                    act.rode = True
-                forward_multi(members)
+                forward_multi([self.qr_b.forward_desc(xpu, in_head=hd_rec)])
                 zp, n_part, ps = self.qr_b.parts
             else:
                 zp, n_part, ps = self.qr_b.forward(xpu)
@@ -825,17 +791,6 @@ class FastActor:
         holds its inputs, the task action is the strided view xa[:, 2:4] and the other two are filled by that kernel."""
         f, n, lib, st = self.f, self.n, self.f.lib, _lib.current_stream()
         self.pending_select = None
-        if getattr(self, "rode", False):
-            # the task policy and Q_risk(s, a_task) were evaluated inside the updates' launches (qrisk_update_grouped): what
-            # is left is the recovery policy, final only now that its optimiser step is done; its head is evaluated by the
-            # step kernel
-            self.rode = False
-            assert defer_select and use_recovery and mf_recovery
-            forward_multi([self.rec.forward_desc(obs, save=False)])
-            rec_head = f._stoch_desc(self.rec.parts, self.noise[1], self.rec_action, n=n)
-            zq, zn, zs = self.qr.parts
-            self.pending_select = (zq, zn, zs, float(eps_safe), None, rec_head)
-            return self.xa[:, 2:4], self.real_action, self.recovery
         if noise is None:
             noise = f.actor_noise(n)
         if f.grouped and use_recovery and mf_recovery:

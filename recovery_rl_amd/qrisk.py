@@ -40,6 +40,9 @@ class QRiskWrapper:
         self.policy = StochasticPolicy(d_obs, d_act, hidden_size, ac_space).to(self.device)
         self.policy_optim = _adam(self.policy.parameters(), args.lr, capturable)
         self.pos_fraction = args.pos_fraction if args.pos_fraction >= 0 else None   # :78
+        # lock-step loop: share of the batch drawn from the pinned demonstrations (set by Experiment once they are
+        # pinned; None = the reference's one uniform draw)
+        self.demo_share = None
         self.MF_recovery = args.MF_recovery
         self.Q_sampling_recovery = args.Q_sampling_recovery
         self.tmp_env = tmp_env
@@ -53,6 +56,9 @@ class QRiskWrapper:
             return min(batch_size, int((1 - self.pos_fraction) * memory_len))
         return min(batch_size, memory_len)
 
+    def _share_kw(self):
+        return {"demo_share": self.demo_share} if self.demo_share and self.pos_fraction is None else {}
+
     def update_parameters(self, memory=None, policy=None, batch_size=None, plot=False,
                           batch=None, eps_next=None, eps_pi=None):
         """One Q_risk step (+ one recovery-policy step if MF_recovery), qrisk.py:86-163.
@@ -62,10 +68,11 @@ class QRiskWrapper:
         if batch is None:
             batch_size = self.clamp_batch_size(batch_size, len(memory))
             if self.fast is not None and batch_size == self.fast.B and hasattr(memory, "_desc"):
-                batch = memory.sample(batch_size=batch_size, pos_fraction=self.pos_fraction, rows=self.fast.rows)
+                batch = memory.sample(batch_size=batch_size, pos_fraction=self.pos_fraction, rows=self.fast.rows,
+                                      **self._share_kw())
                 rows_loaded = True
             else:
-                batch = memory.sample(batch_size=batch_size, pos_fraction=self.pos_fraction)
+                batch = memory.sample(batch_size=batch_size, pos_fraction=self.pos_fraction, **self._share_kw())
         if self.fast is not None and batch[2].shape[0] == self.fast.B:
             if eps_next is None:
                 eps_next, eps_pi = self.fast.noise(1)

@@ -149,7 +149,7 @@ class ReplayMemory:
         return s, a, r, s2, m
 
 
-    def draw_desc(self, batch_size, pos_fraction=None, out=None, rows=None):
+    def draw_desc(self, batch_size, pos_fraction=None, out=None, rows=None, demo_share=None):
         """The arguments of sample() as an rrl_draw_t for rrl_sample_multi (several draws in one launch) and the batch
         tensors it fills.  Same checks, same tick, same rows as sample()."""
         B = int(batch_size)
@@ -158,9 +158,13 @@ class ReplayMemory:
         if pos_fraction is None:
             if self._len_exact and B > self._len:
                 raise ValueError("Sample larger than population or is negative")
-            stratified, n_pos, n_neg = 0, 0, B
+            if demo_share:
+                stratified, n_pos = _lib.DRAW_DEMO_SHARE, int(B * demo_share)
+                n_neg = B - n_pos
+            else:
+                stratified, n_pos, n_neg = _lib.DRAW_UNIFORM, 0, B
         else:
-            stratified, n_pos = 1, int(B * pos_fraction)
+            stratified, n_pos = _lib.DRAW_STRATIFIED, int(B * pos_fraction)
             n_neg = B - n_pos
         p = _lib.ptr
         d = _lib.rrl_draw_t(C.pointer(self._desc), stratified, n_pos, n_neg, self.seed, 0, p(self.tick), 1, p(s), p(a),
@@ -187,7 +191,11 @@ class ConstraintReplayMemory(ReplayMemory):
         self._desc.flags = (self._desc.flags | _lib.REPLAY_CLAMP_STRATIFIED) if on else \
             (self._desc.flags & ~_lib.REPLAY_CLAMP_STRATIFIED)
 
-    def sample(self, batch_size, pos_fraction=None, out=None, rows=None):
+    def sample(self, batch_size, pos_fraction=None, out=None, rows=None, demo_share=None):
+        """`demo_share` (lock-step loop only, ignored with pos_fraction): int(B * demo_share) rows from the pinned
+        demonstrations, the rest from the online rows (rrl_replay_sample_gather_split)."""
+        if pos_fraction is None and demo_share:
+            return self._sample_split(batch_size, demo_share, out, rows)
         if pos_fraction is None:
             return super().sample(batch_size, out=out, rows=rows)
         B = int(batch_size)
@@ -201,4 +209,18 @@ class ConstraintReplayMemory(ReplayMemory):
                                                 _lib.ptr(idx), _lib.ptr(xu), _lib.ptr(x2u), _lib.ptr(xpu),
                                                 _lib.current_stream())
         _lib.check(rc, "rrl_creplay_sample_gather")
+        return s, a, r, s2, m
+
+    def _sample_split(self, batch_size, demo_share, out, rows):
+        B = int(batch_size)
+        if self._len_exact and B > self._len:
+            raise ValueError("Sample larger than population or is negative")
+        n_demo = int(B * demo_share)
+        s, a, r, s2, m, idx = out if out is not None else self._batch(B)
+        xu, x2u, xpu = rows if rows is not None else (None, None, None)
+        rc = self.lib.rrl_replay_sample_gather_split(C.byref(self._desc), n_demo, B - n_demo, self.seed, 0,
+                                                     _lib.ptr(self.tick), 1, _lib.ptr(s), _lib.ptr(a), _lib.ptr(r),
+                                                     _lib.ptr(s2), _lib.ptr(m), _lib.ptr(idx), _lib.ptr(xu),
+                                                     _lib.ptr(x2u), _lib.ptr(xpu), _lib.current_stream())
+        _lib.check(rc, "rrl_replay_sample_gather_split")
         return s, a, r, s2, m

@@ -284,9 +284,6 @@ def test_grouped_launches_equal_the_separate_ones(env_name, extra):
                                   "--seed", "4"] + extra)
         loop = bench.build_loop(cfg, torch.device(DEV), pretrain=5)
         loop.agent.fast.grouped = grouped
-        # this grouped instance also runs the critic-type head backward inside the hidden-layer launch, whose tiles generate
-        # dh2 (rrl_hidden_bwd_t.fuse_head; opt-in: 19 launches, not faster), the kernel-by-kernel one as its own launch
-        loop.agent.fast.set_fuse_head(grouped)
         loops.append(loop)
     for phase in range(2):
         for loop in loops:

@@ -62,23 +62,6 @@ def test_every_packed_seed_equals_its_solo_run(env, S, n_envs):
     assert not torch.equal(got[0]["critic.flat"], got[1]["critic.flat"]) and not torch.equal(got[0]["pos"], got[1]["pos"])
 
 
-@pytest.mark.parametrize("shape,min_seeds", [("22", "2"), ("11", "2"), ("12", "2"), ("0", "2")])
-def test_every_shape_of_the_packed_hidden_layer_backward_keeps_the_solo_bits(shape, min_seeds):
-    """The packed hidden-layer backward has a block form (gemm_block_pack_kernel: 32 x 64 blocks per four-wave workgroup
-    from three seeds on) next to the 16 x 16 tile form.  The shape is read once per process, so the other shapes run in a
-    child process: 64 x 64 and 32 x 32 blocks, the default blocks from TWO seeds on, and tiles only -- each packed seed
-    still ends bit for bit where its solo run ends (Navigation 1 with 3 seeds, Maze with 2)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, RRL_PACK_BLOCK=shape, RRL_PACK_BLOCK_MIN_SEEDS=min_seeds)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "test_every_packed_seed_equals_its_solo_run and (3-256 or 2-384)"], cwd=root, env=env,
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_packed_entry_points_reject_what_they_cannot_pack():
     lib = _lib.load()
     assert lib.rrl_sample_multi_packed(0, None, None) != 0

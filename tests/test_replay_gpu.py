@@ -276,3 +276,92 @@ def test_pinned_rows_are_never_overwritten(cap, pinned, n):
     c = c.reshape(-1).cpu().numpy()
     assert n_pos >= 16 and (c[:16] == 1).all() and (c[16:] == 0).all()
     mem.check_error()
+
+
+@pytest.mark.parametrize("cap,pinned,online,B,share", [
+    (100424, 20000, 40000, 256, 0.5),     # the lock-step loop's default: 128 demonstrations + 128 online rows
+    (100424, 20000, 90000, 256, 0.5),     # ring wrapped: the online range is [pinned, cap)
+    (5000, 1200, 100, 256, 0.5),          # online range short: it gives all 100 rows, the demonstrations fill the batch
+    (5000, 100, 3000, 256, 0.5),          # demonstration range short: all 100 of them, 156 online rows
+    (5000, 1200, 0, 256, 0.5),            # no online row yet (pre-training): the whole batch from the demonstrations
+    (5000, 1200, 2000, 1024, 0.25),
+    (5000, 1200, 2000, 7, 0.3),
+])
+def test_demo_share_draw_matches_oracle(cap, pinned, online, B, share):
+    """rrl_replay_sample_gather_split (vectorisation rule for the safety critic's batch): indices bit-equal to the C
+    checker's, first n_demo rows from [0, pinned), the rest from [pinned, size); stand-alone entry and as a member of
+    rrl_sample_multi; three consecutive calls (the tick advances)."""
+    import ctypes as C
+    from recovery_rl_amd import _lib
+    rng = np.random.RandomState(cap + online)
+    mem, ora = ConstraintReplayMemory(cap, 11, device=DEV), co.OracleReplay(cap)
+    first = rows(rng, pinned, pos_rate=0.08)
+    mem.push(*dev(first))
+    ora.push(*first)
+    mem.pin()
+    ora.pin()
+    left = online
+    while left > 0:
+        k = min(left, 4096)
+        b = rows(rng, k, pos_rate=0.01)
+        mem.push(*dev(b))
+        ora.push(*b)
+        left -= k
+    n_demo = int(B * share)
+    size = len(ora)
+    demo_total = min(pinned, size)
+    exp_demo = n_demo
+    if B - n_demo > size - demo_total:
+        exp_demo = B - (size - demo_total)
+    elif n_demo > demo_total:
+        exp_demo = demo_total
+    for call in range(3):
+        ref, used = ora.sample_split_indices(n_demo, B - n_demo, seed=mem.seed, counter=call, return_split=True)
+        assert used == exp_demo
+        if call == 1:                          # the grouped entry point draws the same rows
+            d, batch = mem.draw_desc(B, demo_share=share)
+            lib = _lib.load()
+            _lib.check(lib.rrl_sample_multi(C.byref(d), None, 0, 0, 0, None, 0, None, _lib.current_stream()), "multi")
+            s, a, r, s2, m = batch
+        else:
+            s, a, r, s2, m = mem.sample(B, demo_share=share)
+        mem.check_error()
+        idx = mem._batch(B)[5].cpu().numpy()
+        assert np.array_equal(idx, ref) and len(set(idx.tolist())) == B
+        assert (idx[:used] < pinned).all() and (idx[used:] >= pinned).all() and (idx < size).all()
+        gs = ora.gather(ref)
+        for got, want in zip((s, a, r, s2, m), gs):
+            assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_demo_share_draw_oversample_flags():
+    mem = ConstraintReplayMemory(4096, 1, device=DEV)
+    mem.push(*dev(rows(np.random.RandomState(0), 100)))
+    mem.pin()
+    mem._len_exact, mem._len = True, 4096         # bypass the host guard: the device flag is what is tested
+    mem.sample(256, demo_share=0.5)
+    with pytest.raises(ValueError):
+        mem.check_error()
+
+
+def test_demo_share_keeps_the_demonstrations_in_the_batch():
+    """What the rule is for: after the ring has wrapped, a uniform draw shows ~2 % demonstration rows, the split draw
+    exactly int(B * share), uniformly over the demonstrations."""
+    cap, pinned = 100000, 2000
+    rng = np.random.RandomState(3)
+    mem = ConstraintReplayMemory(cap, 2, device=DEV)
+    mem.push(*dev(rows(rng, pinned, pos_rate=0.08)))
+    mem.pin()
+    for _ in range(30):
+        mem.push(*dev(rows(rng, 4096)))
+    hits = torch.zeros(cap, device=DEV)
+    uni = 0
+    for _ in range(300):
+        mem.sample(256)
+        uni += int((mem._batch(256)[5] < pinned).sum())
+        mem.sample(256, demo_share=0.5)
+        hits[mem._batch(256)[5]] += 1
+    h = hits.cpu().numpy()
+    assert h[:pinned].sum() == 300 * 128 and h[pinned:].sum() == 300 * 128
+    assert uni / (300 * 256) < 0.04
+    assert 3.0 < h[:pinned].std() < 5.5            # binomial(300, 128 / 2000): std 4.24
