@@ -106,7 +106,7 @@ def spawn_ranks(argv, n_ranks):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def build_loop(cfg, device, fast=True, pretrain=50):
+def build_loop(cfg, device, fast=True, pretrain=50, episode_log=True):
     import torch
     from recovery_rl_amd.env import make_vec_env, register_env
     from recovery_rl_amd.experiment import VectorLoop
@@ -124,15 +124,43 @@ def build_loop(cfg, device, fast=True, pretrain=50):
     s, a, c, s2, m = env.transition_function(cfg.num_unsafe_transitions)
     recovery_memory.push(s.contiguous(), a.contiguous(), c.contiguous(), s2.contiguous(), m.contiguous())
     recovery_memory.pin()                 # as Experiment.pretrain_critic_recovery does for the lock-step loop
+    if cfg.num_envs > 1 and cfg.pos_fraction < 0:
+        # ... and the demonstration share of the Q_risk batch (Experiment._apply_demo_share: 0.5 by default)
+        share = float(getattr(cfg, "demo_share", -1.0))
+        agent.safety_critic.demo_share = (0.5 if share < 0 else share) or None
     for _ in range(pretrain):
         agent.safety_critic.update_parameters(memory=recovery_memory, policy=agent.policy,
                                               batch_size=cfg.batch_size)
     loop = VectorLoop(cfg, env, agent, memory, recovery_memory)
+    if episode_log and cfg.num_envs > 1:
+        # what Experiment.run_vectorized installs: the per-episode table, advanced by the env-step launch itself
+        from recovery_rl_amd.episode_log import EpisodeLog
+        loop.episode_log = EpisodeLog(cfg.num_envs, cfg.num_envs * (LOG_EVERY + 4), device)
     loop.start()
     # leave the random-action / empty-buffer regime (start_steps=100, batch=256) eagerly
     while not (len(memory) > cfg.batch_size and loop.total_numsteps >= cfg.start_steps):
         loop.vector_step(do_update=False, random_actions=True)
     return loop
+
+
+LOG_EVERY = 100      # Experiment.run_vectorized's default logging cadence (--log_every 0)
+
+
+def production_step(step, loops):
+    """`step` plus what the lock-step driver does every LOG_EVERY iterations INSIDE its loop (experiment.py run_vectorized):
+    read the counters and the samplers' error flags, drain the episode table -- two host synchronisations per 100
+    iterations, part of the timed region because they are part of every real run."""
+    count = [0]
+
+    def run():
+        step()
+        count[0] += 1
+        if count[0] % LOG_EVERY == 0:
+            for loop in loops:
+                loop.read_stats()
+                if loop.episode_log is not None:
+                    loop.episode_log.drain()
+    return run
 
 
 def device_update_counts(loop):
@@ -185,10 +213,11 @@ def _graph_of(launch, reps, device):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def step_push_launcher(device, env_name, n, compact=True):
+def step_push_launcher(device, env_name, n, compact=True, log=False):
     """A closure launching ONE step_push_kernel with the bench's buffer shapes.  compact (what the timed graph launches):
     u16 status word instead of step count + four flag arrays, stored state from pos, no per-env output arrays; otherwise the
-    reference-shaped arrays with every optional output."""
+    reference-shaped arrays with every optional output.  log: the per-episode table advanced by the same launch (what the
+    lock-step driver and the timed graph do)."""
     import ctypes as C
     import torch
     from recovery_rl_amd import _lib
@@ -220,7 +249,12 @@ def step_push_launcher(device, env_name, n, compact=True):
     a.horizon, a.auto_reset, a.reward_penalty, a.push_real_action = env.horizon, 1, 0.0, 0
     a.memory, a.recovery_memory = C.pointer(mem._desc), C.pointer(rmem._desc)
     a.stats, a.reward_sums, a.ep_reward = p(stats), p(sums), p(ep_reward)
-    keep = (env, act, real, rec, mem, rmem, stats, sums, ep_reward, a)
+    ep_log = None
+    if log:
+        from recovery_rl_amd.episode_log import EpisodeLog
+        ep_log = EpisodeLog(n, n * 8, device)      # overflowing records are dropped by the kernel (drain() would report it)
+        ep_log.attach(a)
+    keep = (env, act, real, rec, mem, rmem, stats, sums, ep_reward, a, ep_log)
 
     def launch():
         keep[0].num_envs        # (the closure owns the buffers)
@@ -230,10 +264,10 @@ def step_push_launcher(device, env_name, n, compact=True):
     return launch
 
 
-def time_step_push_kernel(device, env_name, n, reps=200, compact=True):
+def time_step_push_kernel(device, env_name, n, reps=200, compact=True, log=False):
     """Average duration of ONE step_push_kernel launch (the env-step + replay-push kernel of the timed iteration)
     over `reps` back-to-back launches with the bench's own buffers shapes: HIP events on the launch stream."""
-    return _graph_of(step_push_launcher(device, env_name, n, compact), reps, device)
+    return _graph_of(step_push_launcher(device, env_name, n, compact, log), reps, device)
 
 
 def time_nav_step_kernel(device, n, reps=200):
@@ -319,6 +353,113 @@ def committed_pmc(name, key):
 # update 0.62 GFLOP, acting = per env 2 x (policy 67 072 + twin Q_risk 133 632 + recovery policy 66 560) MAC
 def iteration_flops(num_envs, updates_per_step=1):
     return updates_per_step * (0.685e9 + 0.62e9) + num_envs * 2.0 * (67072 + 133632 + 66560)
+
+
+def roofline_stages(a, device, iteration_ms):
+    """Where the timed iteration's time goes, measured in this process: the iteration's launches are recorded once (the tape
+    the seed-packing code uses), then every launch is timed on its own -- `reps` back-to-back launches of that one stage in a
+    captured graph, HIP events on the launch stream (as time_step_push_kernel) -- and priced against the roof that bounds it:
+    MLP stages by their algorithmic FLOPs against the f32 MFMA peak, the optimiser / env / replay stages by their algorithmic
+    bytes against HBM.  The stand-alone durations add up to MORE than the iteration (`iteration_us`): in the graph the acting
+    pass's two large forwards run beside the updates on a side stream."""
+    import ctypes as C
+    import torch
+    import arg_utils
+    from recovery_rl_amd import _lib, fast_update
+    cfg = arg_utils.get_args(config_argv(a.env, 1, a.num_envs, 1))
+    loop = build_loop(cfg, device)
+    loop.overlap_act = False               # a serial tape: one launch after the other, as the packed loop records it
+    for _ in range(3):
+        loop.vector_step(True, False, True)
+    tape = []
+    fast_update.set_tape(tape)
+    try:
+        loop.vector_step(True, False, True)
+    finally:
+        fast_update.set_tape(None)
+    torch.cuda.synchronize(device)
+    lib, st = _lib.load(), _lib.current_stream
+
+    def mlp_flops(G, M, H, din, dout):
+        return 2.0 * G * M * (din * H + H * H + H * dout)
+
+    rows = []
+    for op in tape:
+        kind = op[0]
+        if kind == "forward":
+            arr, n = op[1], op[2]
+            fl = sum(mlp_flops(arr[k].G, arr[k].M, arr[k].H, arr[k].din, arr[k].dout) for k in range(n))
+            m_max = max(arr[k].M for k in range(n))
+            name = "forward x%d (%s rows)" % (n, "/".join(str(arr[k].M) for k in range(n)))
+            launch = lambda arr=arr, n=n: lib.rrl_mlp3_forward_multi(n, arr, st())
+            rows.append((name, "acting forward" if m_max > 1024 else "update forward", launch, fl, None))
+        elif kind == "head_bwd":
+            arr, n = op[1], op[2]
+            fl = sum(4.0 * arr[k].G * arr[k].B * arr[k].H * arr[k].dout for k in range(n))
+            rows.append(("head backward x%d" % n, "head backward", lambda arr=arr, n=n: lib.rrl_mlp_head_backward_multi(n, arr, st()), fl, None))
+        elif kind == "hidden_bwd":
+            arr, n = op[1], op[2]
+            fl = 0.0
+            for k in range(n):
+                h = arr[k]
+                fl += 2.0 * h.G * h.B * h.H * h.H * (2 if h.dW2 else 1)           # dh1 (NN) + dW2 (TN)
+                if h.first.x:
+                    fl += 4.0 * h.G * h.B * h.H * h.first.din                     # first-layer backward out of the tiles
+            rows.append(("hidden backward x%d" % n, "hidden backward", lambda arr=arr, n=n: lib.rrl_mlp_hidden_backward_multi(n, arr, st()), fl, None))
+        elif kind == "adam":
+            segs, n, lr, b1, b2, eps = op[1:7]
+            by = 0.0
+            for k in range(n):
+                sgm = segs[k]
+                by += 4.0 * sgm.n * (7 + (2 if sgm.target else 0)) + 4.0 * sgm.n_part * sgm.part_elems
+            rows.append(("Adam x%d" % n, "optimiser", lambda segs=segs, n=n, lr=lr, b1=b1, b2=b2, eps=eps:
+                         lib.rrl_adam_step_multi(n, segs, lr, b1, b2, eps, st()), None, by))
+        elif kind == "sample":
+            g = op[1]
+            by = 2 * cfg.batch_size * (32 + 32 + 3 * 16) + 8.0 * g.noise_pairs
+            launch = lambda g=g: lib.rrl_sample_multi(g.first, g.second, g.noise_pairs, g.noise_seed, g.noise_counter,
+                                                      g.noise_counter_dev, g.noise_counter_inc, g.noise_out, st())
+            rows.append(("replay draws x2 + policy noise", "replay draw", launch, None, by))
+        elif kind == "step":
+            env_name, env_kind, sa = op[1], op[2], op[3]
+            launch = (lambda sa=sa: lib.rrl_maze_step_push_x(C.byref(sa), st())) if env_name == "maze" else \
+                (lambda sa=sa, env_kind=env_kind: lib.rrl_nav_step_push_x(env_kind, C.byref(sa), st()))
+            rows.append(("env step + 2 replay pushes + episode table", "env step", launch, None,
+                         float(a.num_envs) * STEP_PUSH_ALGO_BYTES))
+        else:
+            rows.append((kind, kind, None, None, None))
+    out, total = [], 0.0
+    for name, group, launch, fl, by in rows:
+        if launch is None:
+            continue
+        t = _graph_of(launch, 50, device)
+        total += t
+        r = {"stage": name, "group": group, "us": t * 1e6}
+        if fl is not None:
+            r.update(bound="mfma", flops=fl, achieved_TFLOPs=fl / t / 1e12, frac=fl / t / 1e12 / F32_MFMA_PEAK_TF)
+        else:
+            r.update(bound="hbm", bytes=by, achieved_GBs=by / t / 1e9, frac=by / t / 1e9 / HBM_PEAK_GBS)
+        out.append(r)
+    groups = {}
+    for r in out:
+        gsum = groups.setdefault(r["group"], {"launches": 0, "us": 0.0, "flops": 0.0, "bytes": 0.0})
+        gsum["launches"] += 1
+        gsum["us"] += r["us"]
+        gsum["flops"] += r.get("flops", 0.0)
+        gsum["bytes"] += r.get("bytes", 0.0)
+    summary = []
+    for gname, gs in sorted(groups.items(), key=lambda kv: -kv[1]["us"]):
+        row = {"group": gname, "launches": gs["launches"], "us": gs["us"], "share_of_stand_alone_sum": gs["us"] / (total * 1e6)}
+        if gs["flops"]:
+            row.update(bound="mfma", frac=gs["flops"] / (gs["us"] * 1e-6) / 1e12 / F32_MFMA_PEAK_TF)
+        else:
+            row.update(bound="hbm", frac=gs["bytes"] / (gs["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
+        summary.append(row)
+    return {"launches": len(out), "stand_alone_sum_us": total * 1e6, "iteration_us": iteration_ms * 1e3,
+            "overlap_us": total * 1e6 - iteration_ms * 1e3,
+            "method": "each recorded launch of one iteration re-issued 50x back to back in its own graph, HIP events on the "
+                      "launch stream; FLOPs / bytes are algorithmic (2 M K N per product; parameter + state bytes for Adam)",
+            "dominant": summary[0]["group"], "by_group": summary, "stages": out}
 
 
 def time_planner_kernel(device, n_plans=256, reps=3, precision="f32"):
@@ -476,6 +617,7 @@ def run_config(a, cfg, device, world, rank, updates_per_step=1, min_seconds=MIN_
     from recovery_rl_amd import distributed as dist_utils
     loop = build_loop(cfg, device, fast=not a.autograd_updates)
     step = loop.replay if not a.no_graph else (lambda: loop.vector_step(True, False, True))
+    step = production_step(step, [loop])
     if not a.no_graph:
         loop.capture(online_qrisk=True)
     for _ in range(a.warmup):
@@ -496,6 +638,47 @@ def run_config(a, cfg, device, world, rank, updates_per_step=1, min_seconds=MIN_
             "device_counters": dev0 is not None}, loop
 
 
+def run_config_packed(a, device, world, rank, S, updates_per_step=1, min_seconds=MIN_TIMED_S):
+    """The headline leg with S seeds per GPU (`--seeds_per_gpu S`): rank g packs seeds 1 + g S .. 1 + g S + S - 1 (the
+    reference's seed loop, scripts/navigation1.sh:4-8, folded onto the GPUs: recovery_rl_amd/packed.py) and every launch of
+    the lock-step iteration serves all S of them.  Same shape of result as run_config; the witness of the grad-steps is every
+    seed's device-side Adam step counter."""
+    import torch
+    import arg_utils
+    from recovery_rl_amd import distributed as dist_utils
+    from recovery_rl_amd.packed import PackedLoop
+    U = updates_per_step
+    first = 1 + rank * S
+    loops = [build_loop(arg_utils.get_args(config_argv(a.env, first + k, a.num_envs, U)), device) for k in range(S)]
+    packed = PackedLoop(loops)
+    packed.capture()
+    step = production_step(packed.replay, loops)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(device)
+
+    def totals():
+        st = [l.read_stats() for l in loops]
+        return {k: sum(x[k] for x in st) for k in st[0]}
+    stats0 = totals()
+    c0 = [(int(l.agent.fast.critic.step[0].item()), int(l.agent.fast.qrisk.step[0].item())) for l in loops]
+    elapsed, blocks = timed_blocks(step, a.steps, world, device, min_seconds)
+    stats1 = totals()
+    c1 = [(int(l.agent.fast.critic.step[0].item()), int(l.agent.fast.qrisk.step[0].item())) for l in loops]
+    n_steps = a.steps * blocks
+    local = {k: stats1[k] - stats0[k] for k in stats1}
+    assert local["env_steps"] == n_steps * a.num_envs * S, (local["env_steps"], n_steps, S)
+    assert all(y[0] - x[0] == n_steps * U and y[1] - x[1] == n_steps * U for x, y in zip(c0, c1)), (c0, c1, n_steps)
+    local["sac_updates"] = sum(y[0] - x[0] for x, y in zip(c0, c1))
+    local["qrisk_updates"] = sum(y[1] - x[1] for x, y in zip(c0, c1))
+    agg = dist_utils.aggregate_stats(local, world, device)
+    witness = {"rank": rank, "seeds": list(range(first, first + S)),
+               "adam_steps_per_seed": [y[0] - x[0] for x, y in zip(c0, c1)],
+               "launches_per_packed_iteration": len(packed.stages)}
+    return {"elapsed": elapsed, "blocks": blocks, "steps_total": n_steps, "agg": agg, "device_counters": True,
+            "seed_pack": witness}, loops[0]
+
+
 def run_seed_pack_leg(a, device, seeds=(1, 2, 4, 8), min_seconds=MIN_TIMED_LEG_S, updates_per_step=1):
     """S independent learners of configs[1] (seeds 1..S: own envs, replay rings, networks, Philox keys) sharing every launch
     of the lock-step iteration on ONE GPU (recovery_rl_amd/packed.py): aggregate env-steps/s and grad-steps/s.  The reference
@@ -514,7 +697,7 @@ def run_seed_pack_leg(a, device, seeds=(1, 2, 4, 8), min_seconds=MIN_TIMED_LEG_S
             packed.replay()
         torch.cuda.synchronize(device)
         c0 = [int(l.agent.fast.critic.step[0].item()) for l in loops]
-        elapsed, blocks = timed_blocks(packed.replay, a.steps, 1, device, min_seconds)
+        elapsed, blocks = timed_blocks(production_step(packed.replay, loops), a.steps, 1, device, min_seconds)
         c1 = [int(l.agent.fast.critic.step[0].item()) for l in loops]
         n_steps = a.steps * blocks
         assert all(y - x == n_steps * U for x, y in zip(c0, c1)), (c0, c1, n_steps)
@@ -592,6 +775,9 @@ def main():
     ap.add_argument("--env", choices=sorted(CONFIG_ARGV), default="navigation1",
                     help="navigation1 = configs[1] (the headline); maze = configs[2] and the Maze leg of configs[4]")
     ap.add_argument("--updates_per_step", type=int, default=1, help="SAC (+ Q_risk) updates per lock-step iteration")
+    ap.add_argument("--seeds_per_gpu", type=int, default=1,
+                    help="S > 1: every rank packs S consecutive seeds into its launches (rank g: seeds 1 + g S ...); the "
+                         "line's value is then the aggregate over all N x S seeds")
     ap.add_argument("--utd_sweep", action="store_true",
                     help="also time U = 4, 16, 64 updates per iteration (update-to-data ratio U / num_envs)")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -628,10 +814,30 @@ def main():
 
     U = a.updates_per_step
     cfg = arg_utils.get_args(config_argv(a.env, dist_utils.rank_seed(1, rank), a.num_envs, U))
-    res, loop = run_config(a, cfg, device, world, rank, U, min_seconds=a.min_seconds)
+    S = max(1, a.seeds_per_gpu)
+    if S > 1:
+        res, loop = run_config_packed(a, device, world, rank, S, U, min_seconds=a.min_seconds)
+    else:
+        res, loop = run_config(a, cfg, device, world, rank, U, min_seconds=a.min_seconds)
     elapsed, agg, n_steps = res["elapsed"], res["agg"], res["steps_total"]
 
     extra = {}
+    if S > 1:
+        extra["seed_pack_headline"] = res["seed_pack"]
+    elif world > 1 and not a.no_legs and not a.no_graph:
+        # a multi-GPU node is best used with several seeds per GPU (the solo iteration is latency-bound): S = 4 on every rank
+        del loop
+        torch.cuda.empty_cache()
+        try:
+            r4, loop = run_config_packed(a, device, world, rank, 4, U, min_seconds=MIN_TIMED_LEG_S)
+            extra["seed_pack_multi_gpu"] = {
+                "seeds_per_gpu": 4, "seeds_total": 4 * world, "ms_per_packed_iteration": r4["elapsed"] / r4["steps_total"] * 1e3,
+                "aggregate_env_steps_per_s": r4["agg"]["env_steps"] / r4["elapsed"],
+                "aggregate_sac_grad_steps_per_s": r4["agg"]["sac_updates"] / r4["elapsed"],
+                "aggregate_qrisk_grad_steps_per_s": r4["agg"]["qrisk_updates"] / r4["elapsed"],
+                "timed_seconds": r4["elapsed"], "rank0_witness": r4["seed_pack"]}
+        except Exception as e:      # noqa: BLE001  (every rank raises or none does: the legs are deterministic)
+            extra["seed_pack_multi_gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if a.utd_sweep:
         sweep = []
         for u in (1, 4, 16, 64):
@@ -674,6 +880,7 @@ def main():
             except Exception as e:      # noqa: BLE001
                 extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()
+        leg("roofline_stages", lambda: roofline_stages(a, device, elapsed / n_steps * 1e3))
         leg("seed_pack", lambda: run_seed_pack_leg(a, device))
         leg("seed_pack_utd_1_256", lambda: run_seed_pack_leg(a, device, seeds=(1, 4, 8, 16), updates_per_step=16))
         if a.env == "navigation1" and a.num_envs == NUM_ENVS:
@@ -683,7 +890,7 @@ def main():
             leg("config4", config4)
 
     if rank == 0:
-        t_k = time_step_push_kernel(device, a.env, a.num_envs)
+        t_k = time_step_push_kernel(device, a.env, a.num_envs, log=True)
         gbs = a.num_envs * STEP_PUSH_ALGO_BYTES / t_k / 1e9
         traffic, traffic_src = committed_pmc("step_push_pmc", a.num_envs) if a.env == "navigation1" else (None, None)
         extra["roofline"] = {
@@ -695,7 +902,9 @@ def main():
                 "committed rocprofv3 PMC passes (TCC fetch / write bytes, separate passes), %s entry '%d'; not "
                 "re-measured by this run" % (traffic_src, a.num_envs)) if traffic is not None else None,
             "launch_us": t_k * 1e6, "algorithmic_bytes_per_env_step": STEP_PUSH_ALGO_BYTES,
-            "layout": "compact env state (u16 status word, state from pos, no per-env output arrays): what the timed graph launches",
+            "layout": "compact env state (u16 status word, state from pos, no per-env output arrays) + the per-episode "
+                      "table advanced by the same launch (40 B of accumulators per env-step, not part of the 103 algorithmic "
+                      "bytes): what the timed graph and the lock-step driver launch",
             "note": "N=%d moves only %d KB per launch: latency-bound by construction; bandwidth regime "
                     "(N up to 2^24, `bench.py --sweep`): profiles/round3_roofline_sweep.json"
                     % (a.num_envs, a.num_envs * STEP_PUSH_ALGO_BYTES // 1024)}
@@ -767,7 +976,7 @@ def main():
 
     if rank == 0:
         env_rate = agg["env_steps"] / elapsed
-        flops = iteration_flops(a.num_envs, U) * n_steps * world
+        flops = iteration_flops(a.num_envs, U) * n_steps * world * S
         label = {"navigation1": "Navigation1", "maze": "Maze"}[a.env]
         out = {
             "metric": "env-steps/sec + SAC grad-steps/sec, Navigation1 4096 envs, 1/2/4/8 GPU",
@@ -787,9 +996,14 @@ def main():
                        "num_envs_per_gpu": a.num_envs, "batch_size": cfg.batch_size,
                        "hidden_size": cfg.hidden_size, "updates_per_step": cfg.updates_per_step,
                        "launch": "eager" if a.no_graph else "hipGraph replay",
+                       "loop": "the iteration Experiment.run_vectorized replays: compact env state, per-episode table "
+                               "advanced by the env-step launch, counters read and table drained every %d iterations "
+                               "inside the timed region" % LOG_EVERY,
                        "updates": "autograd + vendor GEMM" if a.autograd_updates else
                                   "hand-written HIP forward/backward (f32 MFMA) + fused Adam",
-                       "parallelism": "replicas x%d (RCCL metric all-reduce only)" % world},
+                       "seeds_per_gpu": S,
+                       "parallelism": "replicas x%d%s (RCCL metric all-reduce only)"
+                                      % (world, ", %d seeds packed per GPU" % S if S > 1 else "")},
             "episodes": agg["episodes"], "violations": agg["num_viols"], "successes": agg["num_successes"],
             # the MLP side of the iteration against the f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
             "roofline_mlp": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TF,
@@ -800,6 +1014,7 @@ def main():
         }
         out.update(extra)
         print(json.dumps(out))
+    dist_utils.shutdown()
 
 
 if __name__ == "__main__":

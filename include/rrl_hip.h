@@ -319,7 +319,10 @@ int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, co
  * replay rows is float(pos), so `obs` is written only (8 B less read, 8 + 4 B less written per env-step than t + flags).
  * next_obs / reward / done / constraint / success / ep_done stay optional outputs (NULL: not written).  The recovery gate
  * (rrl_*_step_push_select) is selected by sel_z != NULL; otherwise real_action (+ recovery, nullable) are read.
- * Replay rows, counters and env state equal the entries above bit for bit. */
+ * Replay rows, counters and env state equal the entries above bit for bit.
+ * log_state != NULL: the per-episode log (rrl_episode_log_append, the fields of rrl_episode_log_t + its four per-env
+ * accumulators) is advanced by this launch as well, from the values the step holds in registers -- the same records, the
+ * same accumulator values as the stand-alone launch fed with this step's per-env outputs, without writing those outputs. */
 typedef struct {
     int64_t n;
     double* pos;
@@ -350,6 +353,13 @@ typedef struct {
     uint64_t* stats;
     double* reward_sums;
     float* ep_reward;
+    int32_t* log_rec_i32;    /* rrl_episode_log_t.rec_i32 / rec_f64 / cap / state */
+    double* log_rec_f64;
+    int64_t log_cap;
+    int64_t* log_state;
+    int32_t* log_len;        /* per-env accumulators [n]: ep_len, ep_ret, ep_viol, ep_rec of rrl_episode_log_append */
+    double* log_ret;
+    int32_t *log_viol, *log_rec;
 } rrl_step_push_t;
 int rrl_nav_step_push_x(int env_kind, const rrl_step_push_t* a, void* stream);
 int rrl_maze_step_push_x(const rrl_step_push_t* a, void* stream);

@@ -1,0 +1,290 @@
+// persist_probe.hip -- SKELETON of a batch-sharded persistent update kernel.
+//
+// Question: if the SAC + Q_risk update pair of one lock-step iteration (B = 256, H = 256; sac.py:170-277, qrisk.py:86-182)
+// ran as ONE persistent kernel in which XCD x carries rows 32 x .. 32 x + 31 of the batch through the whole forward /
+// backward chain on XCD-local barriers (the XCD's L2 is the only coherence point), with device-scope synchronisation only
+// at the three gradient reductions + Adam -- how long would the pair take?  Today: ~145 us as 18 kernel launches.
+//
+// What is real here: the barrier protocol (per-XCD counter in the XCD's L2, L1 invalidation after each barrier; device-scope
+// release / acquire around the three reductions), the stage structure (18 dependent stages with the tile counts a 32-row shard
+// has), the MFMA tile loops (one wave per 16 x 16 tile, v_mfma_f32_16x16x4_f32, K = 256 forward / input-gradient tiles, K = 32
+// weight-gradient tiles), operands read from the buffer the previous stage wrote, the 8-partial gradient reduction + Adam sweep.
+// What is dummy: the data (random), the thin layers (din, dout <= 4: a few hundred FLOP), the loss formulas.
+// A token that every tile passes on (out = in + 1 through the same buffers and the same visibility rules) checks that each
+// stage really saw the previous stage's stores.
+//
+//   hipcc -O3 --offload-arch=gfx950 -o profiles/_ab_persist_probe profiles/persist_probe.hip && profiles/_ab_persist_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H = 256;
+constexpr int kWavesPerWg = 4, kWgPerXcd = 32, kXcds = 8;
+constexpr int kWavesPerXcd = kWavesPerWg * kWgPerXcd;      // 128
+
+enum { FWD = 0, TN = 1, THIN = 2, ADAM = 3 };
+struct Stage {
+    int kind;        // FWD: K = 256 tiles (forward layer 2, input-gradient NN); TN: K = 32 weight-gradient tiles; THIN; ADAM
+    int tiles;       // per XCD
+    int tn_tiles;    // additional K = 32 tiles of the same stage (hidden backward = TN + NN in one stage)
+    int device;      // 1: device-scope barrier after the stage (gradient partials must be visible to every XCD)
+};
+
+// The update pair for a 32-row shard (2 row tiles of 16).  Forward of one stack head = 2 x 16 = 32 tiles (layer 2; layers 1 and
+// 3 are thin).  Input-gradient (NN) of one head = 32 tiles.  Weight gradient (TN) of one head = 16 x 16 = 256 tiles of K = 32.
+__constant__ Stage kProgram[] = {
+    {THIN, 128, 0, 0},          //  1 replay draws + gather of this shard's rows (two buffers), policy noise
+    {FWD, 64, 0, 0},            //  2 policy forward on [s' ; s]               (1 head, 64 rows)
+    {FWD, 192, 0, 0},           //  3 critic_target(s', a'), critic(s, a), critic(s, pi): 3 x 2 heads
+    {THIN, 128, 0, 0},          //  4 losses + head backward (critic loss, policy loss)
+    {FWD, 128, 512, 0},         //  5 hidden backward: critic NN 2 heads (own loss) + 2 heads (policy loss); critic TN 2 heads
+    {THIN, 64, 0, 0},           //  6 policy head backward (needs d action from stage 5)
+    {FWD, 32, 256, 1},          //  7 policy hidden backward: NN + TN (1 head); then device-scope: partials visible
+    {ADAM, 3, 0, 1},            //  8 reduce 8 partials + Adam (critic 2 heads, policy) + soft update; device-scope: weights visible
+    {FWD, 64, 0, 0},            //  9 task policy forward on s', recovery policy forward on s
+    {FWD, 128, 0, 0},           // 10 qrisk_target(s', a'), qrisk(s, a): 2 x 2 heads
+    {THIN, 128, 0, 0},          // 11 loss + head backward
+    {FWD, 64, 512, 1},          // 12 hidden backward NN + TN, 2 heads; device-scope
+    {ADAM, 2, 0, 1},            // 13 reduce + Adam (qrisk) + soft update; device-scope
+    {FWD, 64, 0, 0},            // 14 qrisk(s, pi_rec): 2 heads
+    {THIN, 128, 0, 0},          // 15 loss + head backward
+    {FWD, 64, 0, 0},            // 16 hidden backward NN only (input gradient), 2 heads
+    {THIN, 64, 0, 0},           // 17 recovery policy head backward
+    {FWD, 32, 256, 1},          // 18 recovery policy hidden backward NN + TN; device-scope
+    {ADAM, 1, 0, 1},            // 19 reduce + Adam (recovery policy); device-scope
+};
+constexpr int kStages = sizeof(kProgram) / sizeof(Stage);
+
+struct Args {
+    float* act;          // [8 xcd][2 ping-pong][64 rows x 256]      activations of the shard (what a stage hands to the next)
+    float* weights;      // [6 heads][256 x 256]
+    float* partial;      // [8 xcd][6 heads][256 x 256]              weight-gradient partials
+    float* adam_m;       // [6][256 x 256]
+    float* adam_v;
+    unsigned* token;     // [8 xcd][2][128]                          visibility check
+    unsigned* xcd_bar;   // [8] (64-byte apart)                      XCD-local barrier counters
+    unsigned* dev_bar;   // device-scope barrier counter
+    unsigned* rank_ctr;  // [8] workgroup ranks inside each XCD
+    unsigned* errors;
+    int iters;
+    int mode;            // 0 full, 1 barriers only (no tile work), 2 tile work with kernel-boundary-free but no barriers (lower bound)
+};
+
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+
+// XCD-local barrier: workgroup-scope RMW executes in the XCD's L2; stores are write-through to that L2; the vector L1 is
+// invalidated afterwards so that plain loads see the other CUs' stores
+__device__ __forceinline__ void xcd_barrier(unsigned* bar, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // my stores have left for the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+    }
+    __syncthreads();
+    asm volatile("buffer_inv sc0" ::: "memory");                     // drop my CU's L1 lines
+}
+
+__device__ __forceinline__ void device_barrier(unsigned* bar, unsigned target) {
+    __threadfence();                                                 // release at agent scope: L2 write-back
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(bar, 1u);
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+    }
+    __syncthreads();
+    __threadfence();                                                 // acquire: invalidate what other XCDs may have rewritten
+    asm volatile("buffer_inv sc1" ::: "memory");
+}
+
+// one 16 x 16 output tile: C = A[16 x K] . B[16 x K]^T, both k-contiguous, fragment-order loads (as gemm16_tile's NT mode)
+template <int K>
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                          int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    constexpr int V = K / 16;
+    float4 a[V], b[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        a[j] = *reinterpret_cast<const float4*>(A + i * H + 16 * j + 4 * q);
+        b[j] = *reinterpret_cast<const float4*>(B + i * H + 16 * j + 4 * q);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j].w, acc1, 0, 0, 0);
+    }
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = acc[r];
+        C[(4 * q + r) * H + i] = v > 1.f ? 1.f : (v < -1.f ? -1.f : v);      // keep the dummy values bounded
+    }
+}
+
+__global__ __launch_bounds__(256) void persist_kernel(Args a) {
+    __shared__ unsigned s_rank, s_xcd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        s_xcd = xcc_id();
+        s_rank = atomicAdd(a.rank_ctr + s_xcd, 1u);
+    }
+    __syncthreads();
+    const unsigned xcd = s_xcd, rank = s_rank;
+    // every workgroup has registered (all 256 are resident: one per CU); a placement other than 32 per XCD would leave an
+    // XCD-local barrier waiting forever, so everybody checks all eight counts and leaves together if one is off
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(a.dev_bar, 1u);
+        while (__hip_atomic_load(a.dev_bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 256u) {}
+    }
+    __syncthreads();
+    bool placed = true;
+    for (int x = 0; x < kXcds; ++x)
+        placed = placed && __hip_atomic_load(a.rank_ctr + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)kWgPerXcd;
+    if (!placed) {
+        if (tid == 0 && blockIdx.x == 0) atomicAdd(a.errors, 1u << 16);
+        return;
+    }
+    const int w = rank * kWavesPerWg + wave;                        // my wave among the XCD's 128
+    float* act = a.act + (size_t)xcd * 2 * 64 * H;
+    unsigned* tok = a.token + xcd * 2 * 128;
+    unsigned* xbar = a.xcd_bar + xcd * 16;
+    unsigned xepoch = 0, depoch = 1;      // (the registration barrier was device epoch 1)
+    for (int it = 0; it < a.iters; ++it) {
+        for (int s = 0; s < kStages; ++s) {
+            const Stage st = kProgram[s];
+            const int g = it * kStages + s;                          // global stage number: ping-pong parity
+            const float* src = act + (size_t)(g & 1) * 64 * H;
+            float* dst = act + (size_t)((g + 1) & 1) * 64 * H;
+            if (a.mode != 1) {
+                if (st.kind == FWD || st.kind == TN) {
+                    for (int t = w; t < st.tiles; t += kWavesPerXcd) {
+                        const int rt = t & 3, ct = (t >> 2) & 15, head = (t >> 6) % 6;
+                        mfma_tile<256>(src + rt * 16 * H, a.weights + (size_t)head * H * H + ct * 16 * H,
+                                       dst + rt * 16 * H + ct * 16, lane);
+                    }
+                    for (int t = w; t < st.tn_tiles; t += kWavesPerXcd) {
+                        // dW2 partial tile: contraction over the shard's 32 rows; operands = 16 x 32 slices
+                        const int rt = t & 15, ct = (t >> 4) & 15, head = (t >> 8) % 6;
+                        mfma_tile<32>(src + (rt & 3) * 16 * H + (ct & 7) * 32, src + ((rt + 1) & 3) * 16 * H + (rt & 7) * 32,
+                                      a.partial + ((size_t)xcd * 6 + head) * H * H + rt * 16 * H + ct * 16, lane);
+                    }
+                } else if (st.kind == THIN) {
+                    // a few loads / stores per row: every lane of the XCD touches one float4 of the source and writes one
+                    const int e = (w * 64 + lane) * 4 % (64 * H);
+                    float4 v = *reinterpret_cast<const float4*>(src + e);
+                    v.x = v.x * 0.5f + 0.1f;
+                    *reinterpret_cast<float4*>(dst + e) = v;
+                } else {        // ADAM: my XCD owns 1/8 of every head's parameters; sum the 8 partials, Adam, write weights
+                    for (int head = 0; head < st.tiles; ++head) {
+                        const int per_xcd = H * H / kXcds;               // 8192 floats = 2048 float4 per head and XCD
+                        for (int e4 = w * 64 + lane; e4 < per_xcd / 4; e4 += kWavesPerXcd * 64) {
+                            const size_t off = (size_t)head * H * H + xcd * per_xcd + 4 * e4;
+                            float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                            for (int x = 0; x < kXcds; ++x) {
+                                const float4 p = *reinterpret_cast<const float4*>(a.partial + (size_t)x * 6 * H * H + off);
+                                gsum.x += p.x; gsum.y += p.y; gsum.z += p.z; gsum.w += p.w;
+                            }
+                            float4 m = *reinterpret_cast<float4*>(a.adam_m + off), v = *reinterpret_cast<float4*>(a.adam_v + off);
+                            float4 wt = *reinterpret_cast<float4*>(a.weights + off);
+                            auto upd = [](float& wv, float& mv, float& vv, float gr) {
+                                mv = 0.9f * mv + 0.1f * gr;
+                                vv = 0.999f * vv + 0.001f * gr * gr;
+                                wv -= 3e-4f * mv / (sqrtf(vv) + 1e-8f) * 1e-3f;
+                            };
+                            upd(wt.x, m.x, v.x, gsum.x); upd(wt.y, m.y, v.y, gsum.y);
+                            upd(wt.z, m.z, v.z, gsum.z); upd(wt.w, m.w, v.w, gsum.w);
+                            *reinterpret_cast<float4*>(a.adam_m + off) = m;
+                            *reinterpret_cast<float4*>(a.adam_v + off) = v;
+                            *reinterpret_cast<float4*>(a.weights + off) = wt;
+                        }
+                    }
+                }
+            }
+            // the token: wave w reads its neighbour's token of the previous stage, writes its own for this stage
+            if (lane == 0) {
+                const unsigned prev = tok[(g & 1) * 128 + (w + 1) % kWavesPerXcd];
+                if (prev != (unsigned)g) atomicAdd(a.errors, 1u);
+                tok[((g + 1) & 1) * 128 + w] = (unsigned)g + 1;
+            }
+            if (a.mode == 2) {                                        // lower bound: workgroup-local sync only (WRONG results)
+                __syncthreads();
+                continue;
+            }
+            if (st.device) device_barrier(a.dev_bar, 256u * ++depoch);
+            else xcd_barrier(xbar, (unsigned)kWgPerXcd * ++xepoch);
+        }
+    }
+}
+
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const int iters = argc > 1 ? atoi(argv[1]) : 200;
+    Args a{};
+    hipMalloc(&a.act, sizeof(float) * 8 * 2 * 64 * H);
+    hipMalloc(&a.weights, sizeof(float) * 6 * H * H);
+    hipMalloc(&a.partial, sizeof(float) * 8 * 6 * H * H);
+    hipMalloc(&a.adam_m, sizeof(float) * 6 * H * H);
+    hipMalloc(&a.adam_v, sizeof(float) * 6 * H * H);
+    hipMalloc(&a.token, 4 * 8 * 2 * 128);
+    hipMalloc(&a.xcd_bar, 4 * 16 * 8);
+    hipMalloc(&a.dev_bar, 4);
+    hipMalloc(&a.rank_ctr, 4 * 16);
+    hipMalloc(&a.errors, 4);
+    std::vector<float> h(6 * H * H);
+    srand(1);
+    for (auto& x : h) x = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
+    hipMemcpy(a.weights, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const char* names[3] = {"full skeleton (tile loops + barriers)", "barriers only (15 XCD-local + 4 device-scope per pair... see table)",
+                            "tile loops only, workgroup-local sync (lower bound, wrong data flow)"};
+    int n_dev = 0, n_xcd = 0;
+    {
+        Stage hs[kStages];
+        hipMemcpyFromSymbol(hs, HIP_SYMBOL(kProgram), sizeof(hs));
+        for (int s = 0; s < kStages; ++s) (hs[s].device ? n_dev : n_xcd)++;
+    }
+    printf("program: %d stages per update pair: %d XCD-local barriers + %d device-scope barriers\n", kStages, n_xcd, n_dev);
+    for (int mode = 0; mode < 3; ++mode) {
+        float best = 1e30f;
+        unsigned err = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemset(a.act, 0, sizeof(float) * 8 * 2 * 64 * H);
+            hipMemset(a.partial, 0, sizeof(float) * 8 * 6 * H * H);
+            hipMemset(a.adam_m, 0, sizeof(float) * 6 * H * H);
+            hipMemset(a.adam_v, 0, sizeof(float) * 6 * H * H);
+            hipMemset(a.token, 0, 4 * 8 * 2 * 128);
+            hipMemset(a.xcd_bar, 0, 4 * 16 * 8);
+            hipMemset(a.dev_bar, 0, 4);
+            hipMemset(a.rank_ctr, 0, 4 * 16);
+            hipMemset(a.errors, 0, 4);
+            a.iters = iters;
+            a.mode = mode;
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(persist_kernel, dim3(256), dim3(256), 0, 0, a);
+            hipEventRecord(e1);
+            if (hipEventSynchronize(e1) != hipSuccess) { printf("launch failed\n"); return 1; }
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            best = ms < best ? ms : best;
+            hipMemcpy(&err, a.errors, 4, hipMemcpyDeviceToHost);
+        }
+        printf("mode %d  %-70s %8.2f us per update pair   (token errors %u, placement errors %u)\n", mode, names[mode],
+               best * 1e3f / iters, err & 0xffff, err >> 16);
+    }
+    return 0;
+}

@@ -150,7 +150,9 @@ class rrl_step_push_t(C.Structure):
                 ("reward_penalty", C.c_float), ("push_real_action", C.c_int32), ("memory", C.POINTER(rrl_replay_t)),
                 ("recovery_memory", C.POINTER(rrl_replay_t)), ("next_obs", C.c_void_p), ("reward", C.c_void_p),
                 ("done", C.c_void_p), ("constraint", C.c_void_p), ("success", C.c_void_p), ("ep_done", C.c_void_p),
-                ("stats", C.c_void_p), ("reward_sums", C.c_void_p), ("ep_reward", C.c_void_p)]
+                ("stats", C.c_void_p), ("reward_sums", C.c_void_p), ("ep_reward", C.c_void_p),
+                ("log_rec_i32", C.c_void_p), ("log_rec_f64", C.c_void_p), ("log_cap", C.c_int64), ("log_state", C.c_void_p),
+                ("log_len", C.c_void_p), ("log_ret", C.c_void_p), ("log_viol", C.c_void_p), ("log_rec", C.c_void_p)]
 
 
 class rrl_stack_t(C.Structure):

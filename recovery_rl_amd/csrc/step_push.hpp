@@ -73,6 +73,14 @@ struct StepPushArgs {
                                  // num_successes, recovery_steps, constraint_steps
     double* reward_sums;         // {sum of rewards, sum of finished-episode returns}
     float* ep_reward;            // [n] running episode return
+    // per-episode log advanced here (log_kernels.hip's episode_log_kernel, lane for lane): nullable log_state = off
+    int32_t* log_rec_i32;
+    double* log_rec_f64;
+    int64_t log_cap;
+    int64_t* log_state;          // {count, iteration, ticket (unused here: the cursors' ticket serves)}
+    int32_t* log_len;
+    double* log_ret;
+    int32_t *log_viol, *log_rec;
 };
 
 // Episode counters: every lane keeps its own tallies over the grid-stride loop; they are added up per wave
@@ -119,6 +127,7 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
     const int64_t mpos = p.memory.state[0], msize = p.memory.state[1];
     int64_t rpos = 0, rsize = 0;
     if (p.use_recovery_memory) { rpos = p.recovery_memory.state[0]; rsize = p.recovery_memory.state[1]; }
+    const int64_t log_iteration = p.log_state ? p.log_state[1] : 0;      // read before the ticket, like the cursors
     // ONE ticket for the three device-side cursors (both replay rings and the RNG tick): a returning device-scope atomic
     // is a ~0.7 us round trip, three in a row were a sixth of this kernel.  The workgroup that draws the last ticket knows
     // that every workgroup has read the cursors, which is all their update has to wait for.  In the latency regime (a few
@@ -143,6 +152,7 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             rrl_replay::set_ring(p.memory, mpos, msize, a.n);
             if (p.use_recovery_memory) rrl_replay::set_ring(p.recovery_memory, rpos, rsize, a.n);
             if (a.counter_dev && a.counter_inc) a.counter_dev[0] = ctr - a.counter + a.counter_inc;
+            if (p.log_state) p.log_state[1] = log_iteration + 1;
         }
     };
     if constexpr (SPECULATE) {
@@ -171,6 +181,7 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
                          (cap % rrl_replay::kSuper == 0 && p.recovery_memory.pinned % rrl_replay::kSuper == 0);
         }
         bool cons = false, succ = false, epd = false, rec = false;
+        float log_rew = 0.f;
         if (live) {
             const double2 pp = a.pos[i];
             const float2 task = *reinterpret_cast<const float2*>(p.task_action + i * p.ld_task);
@@ -252,6 +263,7 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
                 rrl_replay::store_values(p.recovery_memory, rrl_replay::ring_slot(p.recovery_memory, rpos, i), rsize, prev, act,
                                          cons ? 1.0f : 0.0f, nobs, mask, block_sums ? super_acc : nullptr, s0);
             // episode accounting
+            log_rew = rew;
             const float er = p.ep_reward[i] + rew;
             rsum += double(rew);
             if (epd) retsum += double(er);
@@ -270,6 +282,46 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
                                                  (unsigned(succ) << 14) | (unsigned(epd) << 15));
             else a.t[i] = ti;
             a.obs[i] = make_float2(float(nx), float(ny));
+        }
+        if (p.log_state) {
+            // episode_log_kernel (log_kernels.hip) for this lane, fed from registers; ONE atomic per wave reserves the
+            // slots of its finished episodes
+            double ret = 0.0;
+            int log_len = 0, viol = 0, recs = 0;
+            if (live) {
+                log_len = p.log_len[i] + 1;
+                ret = p.log_ret[i] + double(log_rew);
+                viol = p.log_viol[i] + int(cons);
+                recs = p.log_rec[i] + int(rec);
+            }
+            const unsigned long long bal = __ballot(epd);
+            if (bal) {
+                const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
+                long long base = 0;
+                if (lane == leader)
+                    base = (long long)atomicAdd((unsigned long long*)&p.log_state[0], (unsigned long long)__popcll(bal));
+                base = __shfl(base, leader, 64);
+                if (epd) {
+                    const long long slot = base + __popcll(bal & ((1ULL << lane) - 1ULL));
+                    if (slot < p.log_cap) {
+                        int32_t* ri = p.log_rec_i32 + slot * RRL_EPLOG_I32;
+                        ri[0] = int32_t(i);
+                        ri[1] = int32_t(log_iteration);
+                        ri[2] = log_len;
+                        ri[3] = viol;
+                        ri[4] = recs;
+                        ri[5] = (succ ? 1 : 0) | (cons ? 2 : 0) | (rec ? 4 : 0);
+                        p.log_rec_f64[slot * 2 + 0] = ret;
+                        p.log_rec_f64[slot * 2 + 1] = double(log_rew);
+                    }
+                }
+            }
+            if (live) {
+                p.log_len[i] = epd ? 0 : log_len;
+                p.log_ret[i] = epd ? 0.0 : ret;
+                p.log_viol[i] = epd ? 0 : viol;
+                p.log_rec[i] = epd ? 0 : recs;
+            }
         }
         if (kBlockSuper && counts) {
             __syncthreads();
@@ -339,7 +391,8 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_pack_kernel(const 
     StepArgs& e = p.step;
     rrl_pack::to_global_all(e.pos, e.action, e.noise, e.counter_dev, e.next_obs, e.obs, e.reward, e.done, e.constraint, e.success,
                             e.ep_done, e.t, e.status, p.task_action, p.recovery, p.sel_z, p.sel_rec_action, p.sel_real_out,
-                            p.sel_recovery_out, p.stats, p.reward_sums, p.ep_reward);
+                            p.sel_recovery_out, p.stats, p.reward_sums, p.ep_reward, p.log_rec_i32, p.log_rec_f64, p.log_state,
+                            p.log_len, p.log_ret, p.log_viol, p.log_rec);
     rrl_pack::globalize(p.sel_rec_head);
     rrl_pack::globalize(p.memory);
     rrl_pack::globalize(p.recovery_memory);
@@ -403,12 +456,28 @@ inline int fill_args(StepPushArgs& p, int64_t n, double* pos, int32_t* t, float*
     p.stats = (unsigned long long*)stats;
     p.reward_sums = reward_sums;
     p.ep_reward = ep_reward;
+    p.log_rec_i32 = nullptr; p.log_rec_f64 = nullptr; p.log_cap = 0; p.log_state = nullptr;
+    p.log_len = nullptr; p.log_ret = nullptr; p.log_viol = p.log_rec = nullptr;
     return RRL_OK;
 }
 
 // rrl_step_push_t (the struct entry points rrl_nav_step_push_x / rrl_maze_step_push_x) -> kernel arguments
+inline int fill_step(StepPushArgs& p, const rrl_step_push_t* a);
+inline int fill_log(StepPushArgs& p, const rrl_step_push_t* a, int rc) {
+    if (rc != RRL_OK || !a->log_state) return rc;
+    if (!a->log_rec_i32 || !a->log_rec_f64 || a->log_cap <= 0 || !a->log_len || !a->log_ret || !a->log_viol || !a->log_rec)
+        return RRL_EINVAL;
+    p.log_rec_i32 = a->log_rec_i32; p.log_rec_f64 = a->log_rec_f64; p.log_cap = a->log_cap; p.log_state = a->log_state;
+    p.log_len = a->log_len; p.log_ret = a->log_ret; p.log_viol = a->log_viol; p.log_rec = a->log_rec;
+    return RRL_OK;
+}
+
 inline int fill_args(StepPushArgs& p, const rrl_step_push_t* a) {
     if (!a) return RRL_EINVAL;
+    return fill_log(p, a, fill_step(p, a));
+}
+
+inline int fill_step(StepPushArgs& p, const rrl_step_push_t* a) {
     if (a->sel_z) {
         const SelectIn sel{a->sel_z, a->sel_n_part, a->sel_part_stride, a->sel_eps_safe, a->sel_rec_action, a->sel_rec_head,
                            a->real_action_out, a->recovery_out};

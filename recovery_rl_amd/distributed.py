@@ -92,3 +92,18 @@ def backend_name(world_size=1):
     """'nccl' (= RCCL on ROCm) / 'gloo' when collectives run, None for a plain single process."""
     import torch.distributed as dist
     return dist.get_backend() if _active(world_size) else None
+
+
+def shutdown(barrier=True):
+    """Tear the process group down (RCCL communicators, the rendezvous store) before the interpreter exits: without it
+    torch warns at exit and a rank can be killed while its peers still wait in the communicator's destructor.
+    barrier=False after an error on this rank (the peers are not at the barrier)."""
+    global _FORCED
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        try:
+            if barrier:
+                dist.barrier()
+        finally:
+            dist.destroy_process_group()
+    _FORCED = False

@@ -49,6 +49,13 @@ class EpisodeLog:
         record("call", self.lib.rrl_episode_log_append, args, (reward, constraint, success, ep_done, recovery, self))
         _lib.check(self.lib.rrl_episode_log_append(*args, _lib.current_stream()), "rrl_episode_log_append")
 
+    def attach(self, a):
+        """Let the fused env-step launch advance this log (rrl_step_push_t.log_*): same records and accumulator values as
+        `append` fed with that step's per-env outputs."""
+        p = _lib.ptr
+        a.log_rec_i32, a.log_rec_f64, a.log_cap, a.log_state = p(self.rec_i32), p(self.rec_f64), self.capacity, p(self.state)
+        a.log_len, a.log_ret, a.log_viol, a.log_rec = p(self.ep_len), p(self.ep_ret), p(self.ep_viol), p(self.ep_rec)
+
     def drain(self):
         """Copy the finished-episode records to the host (sorted by iteration, env) and clear the table."""
         count = int(self.state[0].item())

@@ -79,6 +79,9 @@ class VectorLoop:
         # the fused step also writes env.next_obs / reward / done / constraint / success / ep_done (off: nobody reads them
         # in the steady-state graph; the episode log and the online ensemble re-fit switch them on by themselves)
         self.step_outputs = False
+        # the acting pass's two large forwards run under the updates on a side stream (fast_update.ActOverlap); the packed
+        # loop (one launch per stage for S seeds, one stream) switches it off
+        self.overlap_act = True
         if self.n > 1 and hasattr(recovery_memory, "clamp_stratified"):
             # N envs overwrite the ring in capacity / N iterations: once the policy avoids violations the positive
             # class can drop below int(B * pos_fraction) rows, where the one-env reference would abort
@@ -89,7 +92,7 @@ class VectorLoop:
         self.obs = self.env.reset()
         return self.obs
 
-    def do_updates(self, i_episode=1, online_qrisk=True):
+    def do_updates(self, i_episode=1, online_qrisk=True, act_follows=False):
         """experiment.py:397-416.  The caller has checked len(memory) > batch_size."""
         cfg = self.cfg
         fast = getattr(self.agent, "fast", None)
@@ -97,12 +100,21 @@ class VectorLoop:
         grouped = (fast is not None and fast.grouped and fast.sync_world == 1 and cfg.batch_size == fast.B
                    and hasattr(self.memory, "draw_desc")
                    and (not online_qrisk or qr.clamp_batch_size(cfg.batch_size, len(self.recovery_memory)) == fast.B))
+        overlap = None
+        if (act_follows and grouped and online_qrisk and self.overlap_act and self.obs is self.env.obs
+                and cfg.use_recovery and cfg.MF_recovery and self._can_fuse_step() and self.obs.shape[0] == self.n):
+            from .fast_update import FastActor, recording
+            if self._actor is None:
+                self._actor = FastActor(fast, self.n)
+            if not recording():
+                overlap = self._actor.overlap(self.obs)
         for u in range(cfg.updates_per_step):
             if grouped:
                 # both replay draws + the policy noise in one launch, independent kernels of the two updates grouped
                 # (fast_update.FastUpdater.update_pair): same results as the two calls below, ~30 % fewer launches
                 with trace_range("sample+sac_update+qrisk_update"):
-                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None)
+                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None,
+                                     overlap=overlap if u == cfg.updates_per_step - 1 else None)
                 self.host_updates[0] += 1
                 if online_qrisk:
                     qr.updates += 1
@@ -235,7 +247,8 @@ class VectorLoop:
         """env step + both replay pushes + counters in ONE launch (rrl_nav_step_push_x / rrl_maze_step_push_x).
 
         Per-env outputs of the step (env.next_obs, env.reward, the four flags) are written only when something reads them:
-        `step_outputs` (callers that look at the env's arrays after a step), the episode log, the online ensemble re-fit.
+        `step_outputs` (callers that look at the env's arrays after a step) and the online ensemble re-fit; the episode log
+        is advanced by the same launch from the step's registers (rrl_step_push_t.log_*).
         Without a reader the loop runs on the COMPACT env state: one u16 status word per env instead of the i32 step count
         and four u8 flags, and the stored state taken from `pos` instead of the observation array."""
         import ctypes as C
@@ -245,7 +258,7 @@ class VectorLoop:
         if recovery is not None:
             rec_u8 = recovery if recovery.dtype == torch.uint8 else recovery.to(torch.uint8)
         use_rmem = uses_constraint_buffer(cfg)
-        keep = self.step_outputs or self.episode_log is not None or self.recovery_policy is not None
+        keep = self.step_outputs or self.recovery_policy is not None
         p = _lib.ptr
         out = (lambda t: p(t)) if keep else (lambda t: None)
         a = _lib.rrl_step_push_t()
@@ -264,6 +277,8 @@ class VectorLoop:
         a.next_obs, a.reward = out(env.next_obs), out(env.reward)
         a.done, a.constraint, a.success, a.ep_done = out(env.done), out(env.constraint), out(env.success), out(env.ep_done)
         a.stats, a.reward_sums, a.ep_reward = p(self.stats), p(self.reward_sums), p(self.ep_reward)
+        if self.episode_log is not None:
+            self.episode_log.attach(a)
         select = getattr(self._actor, "pending_select", None) if self._actor is not None else None
         if select is not None:
             # the recovery gate runs inside the step kernel: `action` is the strided task action, `real_action` and
@@ -296,8 +311,6 @@ class VectorLoop:
         mem._len = min(mem._len + self.n, mem.capacity)
         if use_rmem:
             rmem._len = min(rmem._len + self.n, rmem.capacity)
-        if self.episode_log is not None:
-            self.episode_log.append(env.reward, env.constraint, env.success, env.ep_done, rec_u8)
         self.obs = env.obs
         self.total_numsteps += self.n
         return env.obs
@@ -305,7 +318,7 @@ class VectorLoop:
     # -- whole iteration -----------------------------------------------------------------------
     def vector_step(self, do_update=True, random_actions=False, online_qrisk=True, i_episode=1):
         if do_update:
-            self.do_updates(i_episode, online_qrisk)
+            self.do_updates(i_episode, online_qrisk, act_follows=not random_actions)
         with trace_range("act"):
             action, real_action, recovery = self.act(self.obs, random_actions)
         self._last_recovery, self._last_real_action = recovery, real_action
@@ -327,8 +340,13 @@ class VectorLoop:
         qr_updates = self.agent.safety_critic.updates
         lens = (self.memory._len, self.recovery_memory._len)
         g = torch.cuda.CUDAGraph()
+        # configurations that sample a policy through its torch module (e.g. --Q_sampling_recovery with N > 1) draw from
+        # the loop's own generator inside the graph: registered, its Philox offset advances per replay like the global one's
+        g.register_generator_state(self.action_rng)
         with torch.cuda.graph(g):
             self.vector_step(True, False, online_qrisk)
+        # which of the env's two state representations (status word / t + flag arrays) the captured kernels read and write
+        self._graph_status_live = getattr(self.env, "_status_live", None)
         self._graph_updates = (self.host_updates[0] - saved[2][0], self.host_updates[1] - saved[2][1])
         # rows one replay appends to each ring (host mirrors of the device-side sizes)
         self._graph_rows = (self.n, self.n if uses_constraint_buffer(self.cfg) else 0)
@@ -340,6 +358,12 @@ class VectorLoop:
         return warmup
 
     def replay(self):
+        if getattr(self.env, "_status_live", None) != self._graph_status_live:
+            # an eager env.reset() / env.step() / checkpoint load since the capture switched the env to the other
+            # representation: the graph would keep stepping the stale one
+            raise RuntimeError("the env's live state representation changed since the graph was captured "
+                               "(status word live: %r at capture, %r now); capture again"
+                               % (self._graph_status_live, getattr(self.env, "_status_live", None)))
         self.graph.replay()
         self.total_numsteps += self.n
         self.host_updates[0] += self._graph_updates[0]
@@ -660,6 +684,8 @@ class Experiment:
         info_k = min(int(getattr(cfg, "info_envs", 0) or 0), n)
         info = InfoRing(info_k, log_every + 4, self.device, self.env.action_space.high[0],
                         mid_episode=bool(getattr(cfg, "resume", ""))) if info_k else None
+        if info is not None:
+            loop.step_outputs = True        # the per-step info stream reads the env's per-env outputs after every step
         train_stats = []
         episodes = [np.zeros(0, dtype=EPISODE_DTYPE)]
         history = []
@@ -893,6 +919,8 @@ def run_packed(exp_cfg, rank=0, world_size=1):
         # per-episode table and per-step info stream from the first iteration on, as in the solo lock-step run
         exp.loop.episode_log = EpisodeLog(n, n * (log_every + 8), exp.device)
         infos.append(InfoRing(info_k, log_every + 8, exp.device, exp.env.action_space.high[0]) if info_k else None)
+        if info_k:
+            exp.loop.step_outputs = True    # the per-step info stream reads the env's per-env outputs after every step
         tables.append([np.zeros(0, dtype=EPISODE_DTYPE)])
         train_stats.append([])
         ep_files.append(open(osp.join(exp.logdir, "episode_stats.bin"), "wb"))

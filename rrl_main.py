@@ -16,9 +16,14 @@ if __name__ == '__main__':
     if world > 1:
         # env, replay and noise streams differ per rank (a rank that packs S seeds takes S consecutive ones)
         exp_cfg.seed = dist_utils.rank_seed(exp_cfg.seed, rank * max(packed, 1))
-    if packed > 1:
-        from recovery_rl_amd.experiment import run_packed
-        run_packed(exp_cfg, rank=rank, world_size=world)
-    else:
-        experiment = Experiment(exp_cfg, rank=rank, world_size=world)
-        experiment.run()
+    ok = False
+    try:
+        if packed > 1:
+            from recovery_rl_amd.experiment import run_packed
+            run_packed(exp_cfg, rank=rank, world_size=world)
+        else:
+            experiment = Experiment(exp_cfg, rank=rank, world_size=world)
+            experiment.run()
+        ok = True
+    finally:
+        dist_utils.shutdown(barrier=ok)

@@ -204,3 +204,53 @@ def test_bench_gpus_8_dry_run_aggregates_eight_ranks():
     assert abs(r["value"] - 8 * 256 * r["timed_steps_total"] / r["timed_seconds"]) < 1e-6 * r["value"]
     assert abs(r["sac_grad_steps_per_s"] - 8 * r["timed_steps_total"] / r["timed_seconds"]) < 1e-6 * r["sac_grad_steps_per_s"]
     assert r["config"]["parallelism"].startswith("replicas x8")
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_with_two_seeds_per_gpu():
+    """`bench.py --gpus 2 --seeds_per_gpu 2` (gloo dry run, both ranks on the box's GPU): rank g packs seeds 1 + 2 g, 2 + 2 g;
+    the line's value is the aggregate over the four seeds; every seed's device-side Adam counter advanced once per iteration."""
+    env = dict(os.environ, RRL_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--seeds_per_gpu", "2", "--steps", "20",
+                          "--warmup", "5", "--num_envs", "512", "--no_cpu_baseline", "--no_planner", "--no_legs",
+                          "--min_seconds", "0.5"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 2 and r["config"]["seeds_per_gpu"] == 2
+    assert abs(r["value"] - 4 * 512 * r["timed_steps_total"] / r["timed_seconds"]) < 1e-6 * r["value"]
+    assert abs(r["sac_grad_steps_per_s"] - 4 * r["timed_steps_total"] / r["timed_seconds"]) < 1e-6 * r["sac_grad_steps_per_s"]
+    w = r["seed_pack_headline"]
+    assert w["rank"] == 0 and w["seeds"] == [1, 2] and w["adam_steps_per_seed"] == [r["timed_steps_total"]] * 2
+    assert "destroy_process_group" not in out.stderr            # torch's exit warning about a live process group
+
+
+@pytest.mark.gpu
+def test_rrl_main_two_ranks_pack_consecutive_seeds(tmp_path):
+    """`torchrun --nproc-per-node 2 rrl_main.py --seeds_per_gpu 2 --seed 4` (gloo dry run on one GPU): rank 0 runs seeds 4, 5 and
+    rank 1 seeds 6, 7 -- four log directories, each seed's counters equal to the ones the same seed reaches in a one-process
+    packed run (whose members equal their solo runs bit for bit: tests/test_packed_gpu.py)."""
+    import pickle
+    import arg_utils
+    from recovery_rl_amd.experiment import run_packed
+    argv = ["--env-name", "navigation1", "--cuda", "--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe",
+            "0.3", "--num_unsafe_transitions", "3000", "--critic_safe_pretraining_steps", "30", "--num_envs", "128",
+            "--log_every", "20", "--num_eps", "100000", "--num_steps", str(128 * 60 - 1), "--seeds_per_gpu", "2"]
+    env = dict(os.environ, RRL_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(bench.free_port()), os.path.join(ROOT, "rrl_main.py")] + argv + \
+          ["--seed", "4", "--logdir", str(tmp_path / "two_ranks")]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "destroy_process_group" not in out.stderr
+    dirs = sorted(os.listdir(tmp_path / "two_ranks"))
+    assert len(dirs) == 4 and [d.rsplit("_seed", 1)[1] for d in dirs] == ["4", "5", "6", "7"]
+    multi = {d.rsplit("_seed", 1)[1]: pickle.load(open(tmp_path / "two_ranks" / d / "run_stats.pkl", "rb")) for d in dirs}
+    for first in (4, 6):                          # what ONE process packing the same two seeds produces
+        cfg = arg_utils.get_args(argv + ["--seed", str(first), "--logdir", str(tmp_path / ("one_%d" % first))])
+        hists = run_packed(cfg)
+        for k, h in enumerate(hists):
+            got = multi[str(first + k)]["vector_stats"]
+            assert got[-1] == h[-1] and len(got) == len(h), (first + k, got[-1], h[-1])
+    assert multi["4"]["vector_stats"][-1] != multi["6"]["vector_stats"][-1]

@@ -178,3 +178,56 @@ def test_info_envs_on_the_unfused_step_of_the_maze(tmp_path):
     for ep in ts:
         for a, b in zip(ep[:-1], ep[1:]):
             np.testing.assert_array_equal(a["next_state"], b["state"])
+
+
+@pytest.mark.parametrize("env_name,extra", [("navigation1", []), ("maze", ["--pos_fraction=0.3"])])
+def test_log_advanced_by_the_fused_step_equals_the_stand_alone_launch(env_name, extra):
+    """rrl_step_push_t.log_*: the env-step launch advances the episode table from its registers (what the lock-step driver
+    runs: compact env state, no per-env outputs).  Against the same loop on the array path with the stand-alone
+    rrl_episode_log_append fed from the step's outputs: same records, same accumulators, same iteration counter -- eagerly
+    and through a replayed graph."""
+    import bench
+    loops, logs = [], []
+    for fused in (True, False):
+        cfg = arg_utils.get_args(["--env-name", env_name, "--cuda", "--use_recovery", "--MF_recovery", "--num_envs", "768",
+                                  "--seed", "9"] + extra)
+        loop = bench.build_loop(cfg, torch.device(DEV), pretrain=5)
+        log = EpisodeLog(768, 768 * 40, DEV)
+        if fused:
+            loop.episode_log = log
+        else:
+            loop.step_outputs = True
+        loops.append(loop)
+        logs.append(log)
+    for phase in range(2):
+        for loop, log, fused in zip(loops, logs, (True, False)):
+            def one(replay):
+                if replay:
+                    loop.replay()
+                else:
+                    loop.vector_step(True, False, True)
+                if not fused:       # the old path: a launch of its own, fed from the step's per-env outputs
+                    env = loop.env
+                    log.append(env.reward, env.constraint, env.success, env.ep_done, loop._last_recovery)
+            if phase == 0:
+                for _ in range(12):
+                    one(False)
+            else:
+                if fused:
+                    loop.capture(online_qrisk=True)
+                    for _ in range(9):
+                        one(True)
+                else:
+                    for _ in range(12):
+                        one(False)
+        torch.cuda.synchronize()
+        a, b = logs
+        for name in ("ep_len", "ep_ret", "ep_viol", "ep_rec"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (phase, name)
+        assert int(a.state[1].item()) == int(b.state[1].item()) == 12 * (phase + 1)
+        got, want = a.drain(), b.drain()
+        assert len(got) == len(want) > 0
+        for name in EPISODE_DTYPE.names:
+            np.testing.assert_array_equal(got[name], want[name], err_msg=name)
+    assert loops[0].env._status_live and not loops[1].env._status_live
+    assert loops[0].read_stats() == loops[1].read_stats()

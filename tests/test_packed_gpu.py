@@ -134,3 +134,33 @@ def test_packed_seeds_write_the_files_of_their_solo_runs(tmp_path, capsys):
             np.testing.assert_array_equal(a["action"], b["action"])
             np.testing.assert_array_equal(a["next_state"], b["next_state"])
     assert {k: v for k, v in got["vector_stats"][-1].items()} == {k: v for k, v in want["vector_stats"][-1].items()}
+
+
+@pytest.mark.parametrize("env,n_envs,U", [("navigation1", 4096, 1), ("maze", 512, 1), ("navigation1", 256, 3)])
+def test_acting_pass_on_the_side_stream_equals_the_serial_pass(env, n_envs, U):
+    """fast_update.ActOverlap: the task policy's and Q_risk's acting forwards run under the updates on a side stream (parallel
+    branches of the captured graph).  Against the same loop with the serial acting pass: every buffer, parameter, counter and
+    ring equal bit for bit, eagerly and through graph replays; and the overlapped loop really used the side stream."""
+    import arg_utils
+    import bench
+    loops = []
+    for overlap in (True, False):
+        cfg = arg_utils.get_args(bench.config_argv(env, 3, n_envs, U))
+        loop = bench.build_loop(cfg, torch.device(DEV), pretrain=5)
+        loop.overlap_act = overlap
+        loops.append(loop)
+    for phase in range(2):
+        for loop in loops:
+            if phase == 0:
+                for _ in range(5):
+                    loop.vector_step(True, False, True)
+            else:
+                loop.capture(online_qrisk=True)
+                for _ in range(7):
+                    loop.replay()
+        torch.cuda.synchronize()
+        a, b = state_of(loops[0]), state_of(loops[1])
+        for k in a:
+            assert torch.equal(a[k], b[k]), (phase, k)
+        assert loops[0].read_stats() == loops[1].read_stats()
+    assert loops[0]._actor.side is not None and loops[1]._actor.side is None
