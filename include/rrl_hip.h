@@ -32,6 +32,10 @@ extern "C" {
 #define RRL_OK 0
 #define RRL_EINVAL (-1)   /* bad argument (unknown env kind, negative size, null pointer) */
 #define RRL_ELAUNCH (-2)  /* hipLaunchKernel failed; see rrl_last_hip_error() */
+#define RRL_ECAPTURE (-5) /* a packed launch (rrl_*_packed) met an argument block it has not seen before while the stream was
+                           * capturing: building its device copy (hipMalloc + copy) inside the capture would invalidate the
+                           * graph.  Launch the same arguments once before the capture (the warm-up iterations do). */
+#define RRL_EPLANS (-6)   /* more than 8192 distinct argument blocks of packed launches alive: rrl_pack_clear() */
 #define RRL_ERANGE (-3)   /* size outside what the kernel supports (e.g. batch > 1024) */
 
 enum { RRL_ENV_NAV1 = 0, RRL_ENV_NAV2 = 1, RRL_ENV_MAZE = 2 };
@@ -779,6 +783,9 @@ typedef struct {
     float* noise_out;
 } rrl_sample_args_t;
 int rrl_sample_multi_packed(int S, const rrl_sample_args_t* args, void* stream);
+/* Free the cached argument blocks of every packed launch (host and device copies); returns their number.  Call only when no
+ * captured graph that contains a packed launch is alive (the graphs hold the blocks' device addresses as kernel arguments). */
+int rrl_pack_clear(void);
 int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const* members, void* stream);
 int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t* const* members, void* stream);
 int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_bwd_t* const* members, void* stream);

@@ -29,7 +29,7 @@ EXPORTS = [
     "rrl_sample_multi",
     "rrl_nav_step_push", "rrl_maze_step_push", "rrl_nav_step_push_select", "rrl_maze_step_push_select",
     "rrl_nav_step_push_x", "rrl_maze_step_push_x",
-    "rrl_sample_multi_packed", "rrl_mlp3_forward_multi_packed", "rrl_mlp_head_backward_multi_packed",
+    "rrl_sample_multi_packed", "rrl_pack_clear", "rrl_mlp3_forward_multi_packed", "rrl_mlp_head_backward_multi_packed",
     "rrl_mlp_hidden_backward_multi_packed", "rrl_adam_step_multi_packed", "rrl_nav_step_push_packed",
     "rrl_maze_step_push_packed",
     "rrl_cem_sample", "rrl_cem_update", "rrl_cem_begin", "rrl_cem_sample_n", "rrl_cem_update_n", "rrl_cem_finish",
@@ -250,6 +250,7 @@ def _declare(lib):
         "rrl_mlp_input_backward_multi": (ci, [ci, C.POINTER(rrl_input_bwd_t), vp]),
         "rrl_policy_heads_fwd_multi": (ci, [ci, C.POINTER(rrl_policy_head_t), vp]),
         "rrl_sample_multi_packed": (ci, [ci, C.POINTER(rrl_sample_args_t), vp]),
+        "rrl_pack_clear": (ci, []),
         "rrl_mlp3_forward_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_stack_t)), vp]),
         "rrl_mlp_head_backward_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_head_bwd_t)), vp]),
         "rrl_mlp_hidden_backward_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_hidden_bwd_t)), vp]),
@@ -330,10 +331,15 @@ def load():
     return lib
 
 
+_RC_TEXT = {-1: "invalid argument", -2: "launch failed", -3: "size out of range",
+            -5: "a packed launch met a new argument block while the stream was capturing (launch it once before the capture)",
+            -6: "too many distinct argument blocks of packed launches alive (rrl_pack_clear)"}
+
+
 def check(rc, what):
     if rc != 0:
         lib = load()
-        raise RRLError("%s failed: rc=%d hipError=%d" % (what, rc, lib.rrl_last_hip_error()))
+        raise RRLError("%s failed: rc=%d (%s) hipError=%d" % (what, rc, _RC_TEXT.get(rc, "?"), lib.rrl_last_hip_error()))
 
 
 def require_gpu(device):

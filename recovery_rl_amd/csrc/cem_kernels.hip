@@ -58,7 +58,8 @@ __global__ __launch_bounds__(kBlock) void cem_sample_kernel(int64_t M, int pop, 
         const double z = truncnorm2(seed, uint32_t(row), ctr, uint32_t(d));
         samples[e] = float(z * sqrt(cv) + mu);
     }
-    rrl::advance_counter(counter_dev, counter_inc);
+    // an EMPTY device-counted planning set leaves the tick alone, as the host-count path (MPC.act returns before it draws)
+    rrl::advance_counter(counter_dev, (m_dev && M == 0) ? 0 : counter_inc);
 }
 
 __device__ __forceinline__ bool key_less(float ca, int ia, float cb, int ib) {

@@ -273,7 +273,7 @@ int rrl_maze_step_push_packed(int S, const rrl_step_push_t* a, void* stream) {
         }
         for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
         plan = rrl_pack::store(key, ps.data(), sizeof(rrl_step::StepPushArgs) * S, st);
-        if (!plan) return RRL_ELAUNCH;
+        if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         plan->i0 = small;

@@ -613,7 +613,7 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
             if (!ok) return RRL_ERANGE;
         }
         plan = rrl_pack::store(key, groups.data(), sizeof(StackGroup) * S, st);
-        if (!plan) return RRL_ELAUNCH;
+        if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         // small members on multi-row tiles run the large-batch kernel (path 3)

@@ -1135,7 +1135,7 @@ int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_b
             }
             plan = rrl_pack::store(key, groups.data(), sizeof(HiddenGroup) * S, st);
         }
-        if (!plan) return RRL_ELAUNCH;
+        if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         plan->i1 = shape ? -shape : pack_panel(S);
@@ -1244,7 +1244,7 @@ int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t
         const int rc = build_pack<HeadBwdGroup>(S, n, members, groups, ix, build_head_group);
         if (rc != RRL_OK) return rc;
         plan = rrl_pack::store(key, groups.data(), sizeof(HeadBwdGroup) * S, st);
-        if (!plan) return RRL_ELAUNCH;
+        if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
     }

@@ -947,6 +947,8 @@ thread_local int rrl_host::last_hip_error = 0;
 
 extern "C" {
 
+int rrl_pack_clear(void) { return rrl_pack::clear(); }
+
 int rrl_abi_version(void) { return 4; }   // 2: pos_cnt carries a second count level (RRL_POS_CNT_LEN); 3: rrl_replay_t.pinned; 4: RRL_DRAW_DEMO_SHARE
 
 int rrl_last_hip_error(void) { return rrl_host::last_hip_error; }
@@ -1215,7 +1217,7 @@ int rrl_nav_step_push_packed(int S, int env_kind, const rrl_step_push_t* a, void
         }
         for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
         plan = rrl_pack::store(key, ps.data(), sizeof(rrl_step::StepPushArgs) * S, st);
-        if (!plan) return RRL_ELAUNCH;
+        if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         plan->i0 = small;

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -143,7 +144,18 @@ inline std::unordered_map<uint64_t, std::vector<Plan*>>& plans() {
     return m;
 }
 
+inline std::mutex& plan_mutex() {
+    static std::mutex m;
+    return m;
+}
+// why the last store() of this thread returned nullptr (RRL_ELAUNCH: allocation / copy failed)
+inline int& store_error() {
+    static thread_local int e = RRL_ELAUNCH;
+    return e;
+}
+
 inline Plan* lookup(const Key& k) {
+    std::lock_guard<std::mutex> lock(plan_mutex());
     auto it = plans().find(k.hash());
     if (it == plans().end()) return nullptr;
     for (Plan* p : it->second)
@@ -153,9 +165,25 @@ inline Plan* lookup(const Key& k) {
 
 // new plan for `k`: `blocks` (bytes) copied to device memory, stream-ordered.  nullptr: allocation failed, or more distinct
 // inputs than this mechanism is meant for (argument blocks that change on every call)
+inline size_t& plan_count() {
+    static size_t n = 0;
+    return n;
+}
+
 inline Plan* store(const Key& k, const void* blocks, size_t bytes, hipStream_t st) {
-    static size_t count = 0;
-    if (count >= 8192) return nullptr;
+    std::lock_guard<std::mutex> lock(plan_mutex());
+    store_error() = RRL_ELAUNCH;
+    // a miss while the stream is CAPTURING would put a hipMalloc + a pageable copy into the graph and invalidate it with an
+    // opaque error: say what happened instead (the caller's warm-up iterations did not launch this argument block)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        store_error() = RRL_ECAPTURE;
+        return nullptr;
+    }
+    if (plan_count() >= 8192) {          // argument blocks that change on every call are not what this cache is for
+        store_error() = RRL_EPLANS;
+        return nullptr;
+    }
     Plan* p = new Plan();
     p->key = k.bytes;
     p->host.assign(static_cast<const char*>(blocks), static_cast<const char*>(blocks) + bytes);
@@ -166,8 +194,24 @@ inline Plan* store(const Key& k, const void* blocks, size_t bytes, hipStream_t s
         return nullptr;
     }
     plans()[k.hash()].push_back(p);
-    ++count;
+    ++plan_count();
     return p;
+}
+
+// free every plan (device copies included).  Only when no captured graph that launches a packed kernel is alive: the graphs
+// hold the plans' device pointers as kernel arguments.
+inline int clear() {
+    std::lock_guard<std::mutex> lock(plan_mutex());
+    int n = 0;
+    for (auto& kv : plans())
+        for (Plan* p : kv.second) {
+            (void)hipFree(p->dev);
+            delete p;
+            ++n;
+        }
+    plans().clear();
+    plan_count() = 0;
+    return n;
 }
 
 }  // namespace rrl_pack

@@ -578,7 +578,8 @@ __global__ __launch_bounds__(kBlock) void plan_finish_kernel(long long n_groups,
         for (int e = 0; e < n_nets; ++e) s += partial[g * n_nets + e];
         costs[g] = s / float(npart);
     }
-    rrl::advance_counter(counter_dev, counter_inc);
+    // an EMPTY device-counted planning set leaves the tick alone, as the host-count path (MPC.act returns before it plans)
+    rrl::advance_counter(counter_dev, (m_dev && n_groups == 0) ? 0 : counter_inc);
 }
 
 // ---- weight packing -----------------------------------------------------------------------------

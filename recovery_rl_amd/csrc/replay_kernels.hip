@@ -698,7 +698,7 @@ int rrl_sample_multi_packed(int S, const rrl_sample_args_t* args, void* stream) 
         static size_t granted = 64 * 1024;
         if (!grant_sample_lds(sample_pack_kernel, lds, granted)) return RRL_ERANGE;
         plan = rrl_pack::store(key, packs.data(), sizeof(SamplePack) * S, st);
-        if (!plan) return RRL_ELAUNCH;
+        if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
         plan->i0 = threads;

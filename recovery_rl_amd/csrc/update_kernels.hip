@@ -652,7 +652,7 @@ int rrl_adam_step_multi_packed(int S, const int* n_seg, const rrl_adam_seg_t* co
         }
         for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
         plan = rrl_pack::store(key, packs.data(), sizeof(AdamPack) * S, st);
-        if (!plan) return RRL_ELAUNCH;
+        if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
     }

@@ -166,5 +166,12 @@ class PackedLoop:
         self.graph.replay()
         self._advance_host_mirrors()
 
+    def close(self):
+        """Drop the captured graph and free the library's cached argument blocks of the packed launches (device memory):
+        call when this was the last packed loop of the process (the cache is shared by all of them)."""
+        self.graph = None
+        torch.cuda.synchronize(self.loops[0].device)
+        return self.lib.rrl_pack_clear()
+
     def read_stats(self):
         return [loop.read_stats() for loop in self.loops]

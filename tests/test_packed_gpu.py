@@ -164,3 +164,24 @@ def test_acting_pass_on_the_side_stream_equals_the_serial_pass(env, n_envs, U):
             assert torch.equal(a[k], b[k]), (phase, k)
         assert loops[0].read_stats() == loops[1].read_stats()
     assert loops[0]._actor.side is not None and loops[1]._actor.side is None
+
+
+def test_packed_launch_that_would_build_its_argument_block_inside_a_capture_says_so():
+    """A packed launch builds the device copy of its argument blocks the first time it sees them (hipMalloc + copy).  Inside a
+    stream capture that would invalidate the graph with an opaque launch error: the entry points return RRL_ECAPTURE instead
+    (PackedLoop.capture launches every stage eagerly first, so the captured launches only look their blocks up); afterwards
+    the regular capture works, and close() frees the cached blocks."""
+    packed = PackedLoop([make_loop("navigation1", 21 + s, 128) for s in range(2)])
+    packed.record()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(_lib.RRLError, match="capturing"):
+        with torch.cuda.graph(g):
+            packed.launch()
+    del g
+    torch.cuda.synchronize()
+    packed.capture()
+    for _ in range(3):
+        packed.replay()
+    torch.cuda.synchronize()
+    assert packed.loops[0].read_stats()["env_steps"] > 0
+    assert packed.close() >= 7          # one cached block per packed stage kind at least

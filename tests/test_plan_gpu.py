@@ -177,6 +177,35 @@ def test_act_with_the_planning_set_counted_on_the_device_equals_the_host_count_p
     for a, b in zip(o0, o1):
         assert torch.equal(a, b)
     assert torch.equal(p0, p1)
-    if frac > 0:           # the host path skips the CEM for an empty set; the device path launches it for zero problems
-        assert torch.equal(t0, t1) and torch.equal(f0, f1)
+    # (the host path skips the CEM for an empty set; the device path launches it for zero problems, which leaves the ticks alone)
+    assert torch.equal(t0, t1) and torch.equal(f0, f1)
+    if frac > 0:
         assert float(o0[0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("f16x3", [False, True])
+def test_device_counted_planning_stays_on_the_host_count_path_after_an_empty_set(f16x3):
+    """A run of calls with an EMPTY recovery set in the middle (advisor, round 3): the host-count path returns before it
+    draws, so its Philox ticks stand still; the device-count path used to advance them (same bits per call, different rows
+    from the next call on).  Five calls, masks 30 % / empty / 30 % / empty / 100 %: actions, solutions and ticks stay equal."""
+    n = 96
+    _, mpc, agent = build(seed=7, f16x3=f16x3)
+    g = torch.Generator(device=DEV)
+    results = []
+    for device_count in (False, True):
+        mpc.device_count = device_count
+        mpc.prev_sol = torch.zeros(n, mpc.plan_hor * 2, dtype=torch.float64, device=DEV)
+        mpc.optimizer.tick.zero_()
+        mpc.fused.tick.zero_()
+        g.manual_seed(11)
+        outs = []
+        for frac in (0.3, 0.0, 0.3, 0.0, 1.0):
+            obs = torch.randn(n, 2, device=DEV, generator=g) * torch.tensor([1.5, 1.0], device=DEV)
+            mask = torch.rand(n, device=DEV, generator=g) < frac
+            outs.append(mpc.act(obs, 0, mask=mask).clone())
+        results.append((outs, mpc.prev_sol.clone(), mpc.optimizer.tick.clone(), mpc.fused.tick.clone()))
+    (o0, p0, t0, f0), (o1, p1, t1, f1) = results
+    for k, (a, b) in enumerate(zip(o0, o1)):
+        assert torch.equal(a, b), k
+    assert torch.equal(p0, p1) and torch.equal(t0, t1) and torch.equal(f0, f1)
+    assert int(t0[0].item()) > 0
