@@ -616,6 +616,8 @@ def run_config(a, cfg, device, world, rank, updates_per_step=1, min_seconds=MIN_
     import torch
     from recovery_rl_amd import distributed as dist_utils
     loop = build_loop(cfg, device, fast=not a.autograd_updates)
+    loop.overlap_act = a.overlap != "off"
+    loop.overlap_capture = a.overlap if a.overlap != "off" else "chain"
     step = loop.replay if not a.no_graph else (lambda: loop.vector_step(True, False, True))
     step = production_step(step, [loop])
     if not a.no_graph:
@@ -781,6 +783,9 @@ def main():
     ap.add_argument("--utd_sweep", action="store_true",
                     help="also time U = 4, 16, 64 updates per iteration (update-to-data ratio U / num_envs)")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--overlap", choices=("chain", "branches", "off"), default="chain",
+                    help="acting pass beside the updates: 'chain' = a chain of hipGraphs on two streams (default), 'branches' = "
+                         "forked branches inside one hipGraph, 'off' = the serial iteration in one hipGraph")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--planner", action="store_true",
                     help="time the fused planner kernel of config 4 (MFMA roofline) -> roofline_planner; "
@@ -995,7 +1000,9 @@ def main():
                                       a.num_envs, U, U, a.num_envs),
                        "num_envs_per_gpu": a.num_envs, "batch_size": cfg.batch_size,
                        "hidden_size": cfg.hidden_size, "updates_per_step": cfg.updates_per_step,
-                       "launch": "eager" if a.no_graph else "hipGraph replay",
+                       "launch": "eager" if a.no_graph else {
+                           "chain": "hipGraph replay: a chain of graphs on two streams (acting forwards beside the updates)",
+                           "branches": "hipGraph replay: one graph with forked branches", "off": "hipGraph replay: one graph"}[a.overlap],
                        "loop": "the iteration Experiment.run_vectorized replays: compact env state, per-episode table "
                                "advanced by the env-step launch, counters read and table drained every %d iterations "
                                "inside the timed region" % LOG_EVERY,

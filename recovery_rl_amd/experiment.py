@@ -82,6 +82,10 @@ class VectorLoop:
         # the acting pass's two large forwards run under the updates on a side stream (fast_update.ActOverlap); the packed
         # loop (one launch per stage for S seeds, one stream) switches it off
         self.overlap_act = True
+        # how a CAPTURED iteration gets that concurrency: "chain" = a chain of hipGraphs on two streams (fast_update.GraphChain),
+        # "branches" = forked branches inside one hipGraph (do not run concurrently on ROCm 7.2: kept for the measurement)
+        self.overlap_capture = "chain"
+        self._chain = None
         if self.n > 1 and hasattr(recovery_memory, "clamp_stratified"):
             # N envs overwrite the ring in capacity / N iterations: once the policy avoids violations the positive
             # class can drop below int(B * pos_fraction) rows, where the one-env reference would abort
@@ -107,7 +111,7 @@ class VectorLoop:
             if self._actor is None:
                 self._actor = FastActor(fast, self.n)
             if not recording():
-                overlap = self._actor.overlap(self.obs)
+                overlap = self._actor.overlap(self.obs, chain=self._chain)
         for u in range(cfg.updates_per_step):
             if grouped:
                 # both replay draws + the policy noise in one launch, independent kernels of the two updates grouped
@@ -339,12 +343,28 @@ class VectorLoop:
         saved = (self.total_numsteps, self.updates, list(self.host_updates))
         qr_updates = self.agent.safety_critic.updates
         lens = (self.memory._len, self.recovery_memory._len)
-        g = torch.cuda.CUDAGraph()
-        # configurations that sample a policy through its torch module (e.g. --Q_sampling_recovery with N > 1) draw from
-        # the loop's own generator inside the graph: registered, its Philox offset advances per replay like the global one's
-        g.register_generator_state(self.action_rng)
-        with torch.cuda.graph(g):
-            self.vector_step(True, False, online_qrisk)
+        chain_ok = (self.overlap_act and self.overlap_capture == "chain" and self._actor is not None
+                    and getattr(self._actor, "side", None) is not None)      # the warm-up iterations ran the overlapped pass
+        if chain_ok:
+            from .fast_update import GraphChain
+            g = GraphChain(self.device, self._actor.side_stream(), generators=(self.action_rng,))
+            self._chain = g
+            try:
+                g.begin()
+                self.vector_step(True, False, online_qrisk)
+                g.end()
+            except BaseException:
+                g.abort()
+                raise
+            finally:
+                self._chain = None
+        else:
+            g = torch.cuda.CUDAGraph()
+            # configurations that sample a policy through its torch module (e.g. --Q_sampling_recovery with N > 1) draw from
+            # the loop's own generator inside the graph: registered, its Philox offset advances per replay like the global one's
+            g.register_generator_state(self.action_rng)
+            with torch.cuda.graph(g):
+                self.vector_step(True, False, online_qrisk)
         # which of the env's two state representations (status word / t + flag arrays) the captured kernels read and write
         self._graph_status_live = getattr(self.env, "_status_live", None)
         self._graph_updates = (self.host_updates[0] - saved[2][0], self.host_updates[1] - saved[2][1])

@@ -789,30 +789,120 @@ class ActOverlap:
     launches on the same inputs as the serial pass (the [task policy, recovery policy] group launch becomes two): bit-equal
     results."""
 
-    def __init__(self, actor, obs, side):
-        self.actor, self.obs, self.side = actor, obs, side
+    def __init__(self, actor, obs, side, chain=None):
+        self.actor, self.obs, self.side, self.chain = actor, obs, side, chain
         self.state = 0
 
-    def _on_side(self):
+    def _on_side(self, fn):
+        """Issue fn's launches on the side stream, after everything issued so far on the main stream.  Eagerly and inside a
+        single captured graph: a stream fork; while a GraphChain is being captured: a graph segment of its own on the side
+        stream (forked branches INSIDE one hipGraph do not run concurrently on this runtime, separate graph launches on two
+        streams do)."""
+        if self.chain is not None:
+            self.chain.side_segment(fn)
+            return
         self.side.wait_stream(torch.cuda.current_stream(self.actor.f.dev))
-        return torch.cuda.stream(self.side)
+        with torch.cuda.stream(self.side):
+            fn()
 
     def after_sac(self):
         a = self.actor
         a.noise = a.f.actor_noise(a.n)              # this iteration's draws (written by the sample launch)
-        with self._on_side():
-            forward_multi([a.pol.forward_desc(self.obs, save=False)])
+        self._on_side(lambda: forward_multi([a.pol.forward_desc(self.obs, save=False)]))
         self.state = 1
 
     def after_qrisk(self):
         a, f = self.actor, self.actor.f
         assert self.state == 1
-        with self._on_side():
+
+        def launch():
             task_head = f._gauss_desc(a.pol.parts, a.noise[0], a.xa[:, 2:4], None, n=a.n, obs_in=self.obs, obs_out=a.xa)
             a.qr.finalize = False
             forward_multi([a.qr.forward_desc(a.xa, save=False, in_head=task_head)])
+        self._on_side(launch)
         self.state = 2
         a.overlapped = self
+
+    def join(self):
+        """The main stream waits for the side stream's forwards (the step launch reads both branches)."""
+        if self.chain is not None:
+            self.chain.join()
+        else:
+            torch.cuda.current_stream(self.actor.f.dev).wait_stream(self.side)
+
+
+class GraphChain:
+    """One lock-step iteration as a CHAIN of captured hipGraphs on two streams: main segments (replayed on the caller's
+    stream) and side segments (replayed on `side`), with an event from the main stream before every side segment and one
+    back at the join.  Six graph launches per iteration instead of one -- what it buys is real concurrency between the
+    updates' chain of small kernels and the acting pass's two large forwards."""
+
+    def __init__(self, device, side, generators=()):
+        self.device, self.side = device, side
+        self.capture_stream = torch.cuda.Stream(device=device)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.generators = tuple(generators)
+        self.items = []                     # ("main", graph) | ("side", graph, event) | ("join", event)
+        self._cur = None
+
+    def _begin(self, stream):
+        g = torch.cuda.CUDAGraph()
+        for gen in self.generators:
+            g.register_generator_state(gen)
+        self._ctx = torch.cuda.stream(stream)
+        self._ctx.__enter__()
+        g.capture_begin(pool=self.pool)
+        self._cur = g
+
+    def _end(self):
+        g, self._cur = self._cur, None
+        g.capture_end()
+        self._ctx.__exit__(None, None, None)
+        return g
+
+    def begin(self):
+        torch.cuda.synchronize(self.device)
+        self._begin(self.capture_stream)
+
+    def side_segment(self, fn):
+        self.items.append(("main", self._end()))
+        self._begin(self.side)
+        try:
+            fn()
+        finally:
+            g = self._end()
+        self.items.append(("side", g, torch.cuda.Event()))
+        self._begin(self.capture_stream)
+
+    def join(self):
+        self.items.append(("main", self._end()))
+        self.items.append(("join", torch.cuda.Event()))
+        self._begin(self.capture_stream)
+
+    def end(self):
+        self.items.append(("main", self._end()))
+        torch.cuda.synchronize(self.device)
+
+    def abort(self):
+        if self._cur is not None:
+            try:
+                self._end()
+            except Exception:      # noqa: BLE001  (a failed capture is already invalid)
+                pass
+
+    def replay(self):
+        main = torch.cuda.current_stream(self.device)
+        for item in self.items:
+            if item[0] == "main":
+                item[1].replay()
+            elif item[0] == "side":
+                item[2].record(main)
+                self.side.wait_event(item[2])
+                with torch.cuda.stream(self.side):
+                    item[1].replay()
+            else:
+                item[1].record(self.side)
+                main.wait_event(item[1])
 
 
 class FastActor:
@@ -831,14 +921,20 @@ class FastActor:
         self.overlapped = None                  # an ActOverlap that has run this iteration's first two forwards
         self.side = None
 
-    def overlap(self, obs):
-        """-> ActOverlap for update_pair(overlap=...), when the pass that follows is the fused one on `obs`."""
+    def can_overlap(self):
         f = self.f
-        if not (f.grouped and f.fuse_heads and self.qr.split and self.pol.split and self.rec.split):
-            return None
+        return bool(f.grouped and f.fuse_heads and self.qr.split and self.pol.split and self.rec.split)
+
+    def side_stream(self):
         if self.side is None:
-            self.side = torch.cuda.Stream(device=f.dev)
-        return ActOverlap(self, obs, self.side)
+            self.side = torch.cuda.Stream(device=self.f.dev)
+        return self.side
+
+    def overlap(self, obs, chain=None):
+        """-> ActOverlap for update_pair(overlap=...), when the pass that follows is the fused one on `obs`."""
+        if not self.can_overlap():
+            return None
+        return ActOverlap(self, obs, self.side_stream(), chain)
 
     def act(self, obs, eps_safe, use_recovery, mf_recovery, noise=None, defer_select=False):
         """-> (task action [n,2], executed action [n,2], recovery u8[n] or None); persistent buffers.
@@ -852,7 +948,7 @@ class FastActor:
             assert ov.state == 2 and ov.obs is obs and defer_select and use_recovery and mf_recovery and noise is None
             forward_multi([self.rec.forward_desc(obs, save=False)])
             rec_head = f._stoch_desc(self.rec.parts, self.noise[1], self.rec_action, n=n)
-            torch.cuda.current_stream(f.dev).wait_stream(ov.side)          # join: the step launch reads both branches
+            ov.join()                      # the step launch reads both branches
             zq, zn, zs = self.qr.parts
             self.pending_select = (zq, zn, zs, float(eps_safe), None, rec_head)
             return self.xa[:, 2:4], self.real_action, self.recovery

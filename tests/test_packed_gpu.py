@@ -136,8 +136,9 @@ def test_packed_seeds_write_the_files_of_their_solo_runs(tmp_path, capsys):
     assert {k: v for k, v in got["vector_stats"][-1].items()} == {k: v for k, v in want["vector_stats"][-1].items()}
 
 
-@pytest.mark.parametrize("env,n_envs,U", [("navigation1", 4096, 1), ("maze", 512, 1), ("navigation1", 256, 3)])
-def test_acting_pass_on_the_side_stream_equals_the_serial_pass(env, n_envs, U):
+@pytest.mark.parametrize("env,n_envs,U,mode", [("navigation1", 4096, 1, "chain"), ("maze", 512, 1, "chain"),
+                                                ("navigation1", 256, 3, "chain"), ("navigation1", 512, 1, "branches")])
+def test_acting_pass_on_the_side_stream_equals_the_serial_pass(env, n_envs, U, mode):
     """fast_update.ActOverlap: the task policy's and Q_risk's acting forwards run under the updates on a side stream (parallel
     branches of the captured graph).  Against the same loop with the serial acting pass: every buffer, parameter, counter and
     ring equal bit for bit, eagerly and through graph replays; and the overlapped loop really used the side stream."""
@@ -148,6 +149,7 @@ def test_acting_pass_on_the_side_stream_equals_the_serial_pass(env, n_envs, U):
         cfg = arg_utils.get_args(bench.config_argv(env, 3, n_envs, U))
         loop = bench.build_loop(cfg, torch.device(DEV), pretrain=5)
         loop.overlap_act = overlap
+        loop.overlap_capture = mode
         loops.append(loop)
     for phase in range(2):
         for loop in loops:
@@ -164,6 +166,11 @@ def test_acting_pass_on_the_side_stream_equals_the_serial_pass(env, n_envs, U):
             assert torch.equal(a[k], b[k]), (phase, k)
         assert loops[0].read_stats() == loops[1].read_stats()
     assert loops[0]._actor.side is not None and loops[1]._actor.side is None
+    from recovery_rl_amd.fast_update import GraphChain
+    assert isinstance(loops[0].graph, GraphChain) == (mode == "chain") and not isinstance(loops[1].graph, GraphChain)
+    if mode == "chain":     # two side segments (task policy; Q_risk), one join, four main segments
+        kinds = [item[0] for item in loops[0].graph.items]
+        assert kinds == ["main", "side", "main", "side", "main", "join", "main"], kinds
 
 
 def test_packed_launch_that_would_build_its_argument_block_inside_a_capture_says_so():
