@@ -146,7 +146,7 @@ def build_loop(cfg, device, fast=True, pretrain=50, episode_log=True):
 LOG_EVERY = 100      # Experiment.run_vectorized's default logging cadence (--log_every 0)
 
 
-def production_step(step, loops):
+def production_step(step, loops, every=None):
     """`step` plus what the lock-step driver does every LOG_EVERY iterations INSIDE its loop (experiment.py run_vectorized):
     read the counters and the samplers' error flags, drain the episode table -- two host synchronisations per 100
     iterations, part of the timed region because they are part of every real run."""
@@ -155,7 +155,7 @@ def production_step(step, loops):
     def run():
         step()
         count[0] += 1
-        if count[0] % LOG_EVERY == 0:
+        if (LOG_EVERY if every is None else every) and count[0] % (LOG_EVERY if every is None else every) == 0:
             for loop in loops:
                 loop.read_stats()
                 if loop.episode_log is not None:
@@ -338,7 +338,7 @@ def committed_pmc(name, key):
     """(HBM bytes per launch, source file) from the committed rocprofv3 PMC passes under profiles/ (PMC passes cannot run
     inside this process: the figure is NOT measured by this run, `traffic_source` in the JSON line says where it comes
     from).  (None, None) when no measurement exists for this size."""
-    for rnd in ("round3", "round2", "round1"):
+    for rnd in ("round4", "round3", "round2", "round1"):
         rel = os.path.join("profiles", "%s_%s.json" % (rnd, name))
         try:
             rec = json.load(open(os.path.join(ROOT, rel))).get(str(key))
@@ -360,15 +360,13 @@ def roofline_stages(a, device, iteration_ms):
     the seed-packing code uses), then every launch is timed on its own -- `reps` back-to-back launches of that one stage in a
     captured graph, HIP events on the launch stream (as time_step_push_kernel) -- and priced against the roof that bounds it:
     MLP stages by their algorithmic FLOPs against the f32 MFMA peak, the optimiser / env / replay stages by their algorithmic
-    bytes against HBM.  The stand-alone durations add up to MORE than the iteration (`iteration_us`): in the graph the acting
-    pass's two large forwards run beside the updates on a side stream."""
+    bytes against HBM.  `iteration_us` is the timed graph's iteration (incl. the driver's log points) for comparison."""
     import ctypes as C
     import torch
     import arg_utils
     from recovery_rl_amd import _lib, fast_update
     cfg = arg_utils.get_args(config_argv(a.env, 1, a.num_envs, 1))
     loop = build_loop(cfg, device)
-    loop.overlap_act = False               # a serial tape: one launch after the other, as the packed loop records it
     for _ in range(3):
         loop.vector_step(True, False, True)
     tape = []
@@ -456,7 +454,6 @@ def roofline_stages(a, device, iteration_ms):
             row.update(bound="hbm", frac=gs["bytes"] / (gs["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
         summary.append(row)
     return {"launches": len(out), "stand_alone_sum_us": total * 1e6, "iteration_us": iteration_ms * 1e3,
-            "overlap_us": total * 1e6 - iteration_ms * 1e3,
             "method": "each recorded launch of one iteration re-issued 50x back to back in its own graph, HIP events on the "
                       "launch stream; FLOPs / bytes are algorithmic (2 M K N per product; parameter + state bytes for Adam)",
             "dominant": summary[0]["group"], "by_group": summary, "stages": out}
@@ -616,10 +613,8 @@ def run_config(a, cfg, device, world, rank, updates_per_step=1, min_seconds=MIN_
     import torch
     from recovery_rl_amd import distributed as dist_utils
     loop = build_loop(cfg, device, fast=not a.autograd_updates)
-    loop.overlap_act = a.overlap != "off"
-    loop.overlap_capture = a.overlap if a.overlap != "off" else "chain"
     step = loop.replay if not a.no_graph else (lambda: loop.vector_step(True, False, True))
-    step = production_step(step, [loop])
+    step = production_step(step, [loop], every=a.log_every)
     if not a.no_graph:
         loop.capture(online_qrisk=True)
     for _ in range(a.warmup):
@@ -783,9 +778,9 @@ def main():
     ap.add_argument("--utd_sweep", action="store_true",
                     help="also time U = 4, 16, 64 updates per iteration (update-to-data ratio U / num_envs)")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--overlap", choices=("chain", "branches", "off"), default="chain",
-                    help="acting pass beside the updates: 'chain' = a chain of hipGraphs on two streams (default), 'branches' = "
-                         "forked branches inside one hipGraph, 'off' = the serial iteration in one hipGraph")
+    ap.add_argument("--log_every", type=int, default=LOG_EVERY,
+                    help="iterations between the driver's log points inside the timed region (counters read, episode table "
+                         "drained); 0 = never (what the GPU-side iteration alone costs)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--planner", action="store_true",
                     help="time the fused planner kernel of config 4 (MFMA roofline) -> roofline_planner; "
@@ -1000,9 +995,7 @@ def main():
                                       a.num_envs, U, U, a.num_envs),
                        "num_envs_per_gpu": a.num_envs, "batch_size": cfg.batch_size,
                        "hidden_size": cfg.hidden_size, "updates_per_step": cfg.updates_per_step,
-                       "launch": "eager" if a.no_graph else {
-                           "chain": "hipGraph replay: a chain of graphs on two streams (acting forwards beside the updates)",
-                           "branches": "hipGraph replay: one graph with forked branches", "off": "hipGraph replay: one graph"}[a.overlap],
+                       "launch": "eager" if a.no_graph else "hipGraph replay",
                        "loop": "the iteration Experiment.run_vectorized replays: compact env state, per-episode table "
                                "advanced by the env-step launch, counters read and table drained every %d iterations "
                                "inside the timed region" % LOG_EVERY,

@@ -5,7 +5,7 @@ any constraint in the episode -- an episode ends at its first violation, so the 
 plus the env-steps and grad-steps spent until the first window with >= 90 % successes.
 
     python profiles/learning_vec4096.py [updates_per_step=16] [iterations=1500] [first_seed=1] [last_seed=4] [config=2]
-                                        [plan_precision]
+                                        [plan_precision|-] [extra flags ...]
 config 2 = Navigation1 model-free recovery (scripts/navigation1.sh:7), 3 = Maze model-free recovery (scripts/maze.sh:7),
 4 = Navigation2 model-based recovery (scripts/navigation2.sh:14; plan_precision f32 | f16x3).
 """
@@ -35,12 +35,12 @@ CONFIGS = {
 }
 
 
-def run(seed, U, iterations, log_every=25, config=2, precision=""):
+def run(seed, U, iterations, log_every=25, config=2, precision="", extra=()):
     tmp = tempfile.mkdtemp()
     cfg = arg_utils.get_args(["--cuda"] + CONFIGS[config] +
                              ["--logdir", tmp, "--seed", str(seed), "--num_envs", str(N),
                               "--updates_per_step", str(U), "--num_steps", str(N * iterations), "--num_eps", "100000000",
-                              "--log_every", str(log_every)] + (["--plan_precision", precision] if precision else []))
+                              "--log_every", str(log_every)] + (["--plan_precision", precision] if precision else []) + list(extra))
     t0 = time.time()
     with contextlib.redirect_stdout(io.StringIO()):
         exp = Experiment(cfg)
@@ -81,7 +81,9 @@ if __name__ == "__main__":
     hi = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     config = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     precision = sys.argv[6] if len(sys.argv) > 6 else ""
-    out = [run(s, U, iters, config=config, precision=precision) for s in range(lo, hi + 1)]
+    precision = "" if precision == "-" else precision
+    extra = sys.argv[7:]                       # further command-line flags of the run, e.g. --demo_share 0
+    out = [dict(run(s, U, iters, config=config, precision=precision, extra=extra), extra_flags=extra) for s in range(lo, hi + 1)]
     for r in out:
         print({k: v for k, v in r.items() if k != "windows"}, file=sys.stderr)
     print(json.dumps(out))

@@ -68,9 +68,12 @@ struct Args {
     unsigned* xcd_bar;   // [8] (64-byte apart)                      XCD-local barrier counters
     unsigned* dev_bar;   // device-scope barrier counter
     unsigned* rank_ctr;  // [8] workgroup ranks inside each XCD
-    unsigned* errors;
+    unsigned* errors;        // placement errors
+    unsigned* token_errors;  // stale token reads (every lane of every wave checks one token per stage)
     int iters;
     int mode;            // 0 full, 1 barriers only (no tile work), 2 tile work with kernel-boundary-free but no barriers (lower bound)
+    int scope;           // 0: the program's scopes, 1: every barrier XCD-local, 2: every barrier device-scope
+    int inv;             // L1 invalidation after an XCD-local barrier: 0 = buffer_inv sc0, 1 = buffer_inv sc1, 2 = none
 };
 
 __device__ __forceinline__ unsigned xcc_id() {
@@ -81,7 +84,7 @@ __device__ __forceinline__ unsigned xcc_id() {
 
 // XCD-local barrier: workgroup-scope RMW executes in the XCD's L2; stores are write-through to that L2; the vector L1 is
 // invalidated afterwards so that plain loads see the other CUs' stores
-__device__ __forceinline__ void xcd_barrier(unsigned* bar, unsigned target) {
+__device__ __forceinline__ void xcd_barrier(unsigned* bar, unsigned target, int inv) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // my stores have left for the L2
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -89,7 +92,8 @@ __device__ __forceinline__ void xcd_barrier(unsigned* bar, unsigned target) {
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
     }
     __syncthreads();
-    asm volatile("buffer_inv sc0" ::: "memory");                     // drop my CU's L1 lines
+    if (inv == 0) asm volatile("buffer_inv sc0" ::: "memory");       // drop my CU's L1 lines (group scope)
+    else if (inv == 1) asm volatile("buffer_inv sc1" ::: "memory");  // ... device scope
 }
 
 __device__ __forceinline__ void device_barrier(unsigned* bar, unsigned target) {
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
     unsigned* tok = a.token + xcd * 2 * 128;
     unsigned* xbar = a.xcd_bar + xcd * 16;
     unsigned xepoch = 0, depoch = 1;      // (the registration barrier was device epoch 1)
+    unsigned my_errors = 0;
     for (int it = 0; it < a.iters; ++it) {
         for (int s = 0; s < kStages; ++s) {
             const Stage st = kProgram[s];
@@ -213,20 +218,25 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
                     }
                 }
             }
-            // the token: wave w reads its neighbour's token of the previous stage, writes its own for this stage
-            if (lane == 0) {
-                const unsigned prev = tok[(g & 1) * 128 + (w + 1) % kWavesPerXcd];
-                if (prev != (unsigned)g) atomicAdd(a.errors, 1u);
-                tok[((g + 1) & 1) * 128 + w] = (unsigned)g + 1;
+            // the token: wave w reads its neighbours' tokens of the previous stage (a VECTOR load: lane l reads wave w + 1 + l's
+            // token -- a wave-uniform address would go through the scalar cache, which buffer_inv does not touch), writes its
+            // own for this stage; mismatches are counted in a register and reported once at the end
+            {
+                const unsigned prev = tok[(g & 1) * 128 + (w + 1 + lane) % kWavesPerXcd];
+                my_errors += (prev != (unsigned)g) ? 1u : 0u;
+                if (lane == 0) tok[((g + 1) & 1) * 128 + w] = (unsigned)g + 1;
             }
             if (a.mode == 2) {                                        // lower bound: workgroup-local sync only (WRONG results)
                 __syncthreads();
                 continue;
             }
-            if (st.device) device_barrier(a.dev_bar, 256u * ++depoch);
-            else xcd_barrier(xbar, (unsigned)kWgPerXcd * ++xepoch);
+            const bool dev = a.scope == 0 ? st.device != 0 : a.scope == 2;
+            if (dev) device_barrier(a.dev_bar, 256u * ++depoch);
+            else xcd_barrier(xbar, (unsigned)kWgPerXcd * ++xepoch, a.inv);
         }
     }
+    for (int off = 32; off > 0; off >>= 1) my_errors += __shfl_xor(my_errors, off);
+    if (lane == 0 && my_errors) atomicAdd(a.token_errors, my_errors);
 }
 
 int main(int argc, char** argv) {
@@ -243,6 +253,7 @@ int main(int argc, char** argv) {
     hipMalloc(&a.dev_bar, 4);
     hipMalloc(&a.rank_ctr, 4 * 16);
     hipMalloc(&a.errors, 4);
+    hipMalloc(&a.token_errors, 4);
     std::vector<float> h(6 * H * H);
     srand(1);
     for (auto& x : h) x = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
@@ -250,18 +261,29 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    const char* names[3] = {"full skeleton (tile loops + barriers)", "barriers only (15 XCD-local + 4 device-scope per pair... see table)",
-                            "tile loops only, workgroup-local sync (lower bound, wrong data flow)"};
     int n_dev = 0, n_xcd = 0;
     {
         Stage hs[kStages];
         hipMemcpyFromSymbol(hs, HIP_SYMBOL(kProgram), sizeof(hs));
         for (int s = 0; s < kStages; ++s) (hs[s].device ? n_dev : n_xcd)++;
     }
-    printf("program: %d stages per update pair: %d XCD-local barriers + %d device-scope barriers\n", kStages, n_xcd, n_dev);
-    for (int mode = 0; mode < 3; ++mode) {
+    printf("program: %d stages per update pair: %d XCD-local barriers + %d device-scope barriers; %d iterations per run\n", kStages,
+           n_xcd, n_dev, iters);
+    struct Run { int mode, scope, inv; const char* what; };
+    const Run runs[] = {
+        {0, 0, 0, "full skeleton: tile loops + barriers as programmed, buffer_inv sc0 after XCD barriers"},
+        {0, 0, 1, "full skeleton, buffer_inv sc1 after XCD barriers"},
+        {1, 0, 1, "barriers only, as programmed"},
+        {1, 1, 1, "barriers only, EVERY barrier XCD-local (sc1 invalidate)"},
+        {1, 1, 0, "barriers only, every barrier XCD-local (sc0 invalidate)"},
+        {1, 1, 2, "barriers only, every barrier XCD-local (no invalidate)"},
+        {1, 2, 1, "barriers only, EVERY barrier device-scope"},
+        {0, 1, 1, "tile loops + every barrier XCD-local (what the stages between two reductions cost)"},
+        {2, 0, 1, "tile loops only, workgroup-local sync (lower bound of this tile loop, wrong data flow)"},
+    };
+    for (const Run& r : runs) {
         float best = 1e30f;
-        unsigned err = 0;
+        unsigned err = 0, terr = 0;
         for (int rep = 0; rep < 3; ++rep) {
             hipMemset(a.act, 0, sizeof(float) * 8 * 2 * 64 * H);
             hipMemset(a.partial, 0, sizeof(float) * 8 * 6 * H * H);
@@ -272,8 +294,9 @@ int main(int argc, char** argv) {
             hipMemset(a.dev_bar, 0, 4);
             hipMemset(a.rank_ctr, 0, 4 * 16);
             hipMemset(a.errors, 0, 4);
+            hipMemset(a.token_errors, 0, 4);
             a.iters = iters;
-            a.mode = mode;
+            a.mode = r.mode; a.scope = r.scope; a.inv = r.inv;
             hipEventRecord(e0);
             hipLaunchKernelGGL(persist_kernel, dim3(256), dim3(256), 0, 0, a);
             hipEventRecord(e1);
@@ -282,9 +305,10 @@ int main(int argc, char** argv) {
             hipEventElapsedTime(&ms, e0, e1);
             best = ms < best ? ms : best;
             hipMemcpy(&err, a.errors, 4, hipMemcpyDeviceToHost);
+            hipMemcpy(&terr, a.token_errors, 4, hipMemcpyDeviceToHost);
         }
-        printf("mode %d  %-70s %8.2f us per update pair   (token errors %u, placement errors %u)\n", mode, names[mode],
-               best * 1e3f / iters, err & 0xffff, err >> 16);
+        printf("%8.2f us per update pair (%5.2f us per stage)  stale token reads %10u of %u  placement errors %u   %s\n",
+               best * 1e3f / iters, best * 1e3f / iters / kStages, terr, (unsigned)(iters * kStages) * 1024u * 64u, err >> 16, r.what);
     }
     return 0;
 }

@@ -64,12 +64,15 @@ class EpisodeLog:
                                 % (count, self.capacity))
         out = np.zeros(count, dtype=EPISODE_DTYPE)
         if count:
-            ri = self.rec_i32[:count].cpu().numpy()
-            rf = self.rec_f64[:count].cpu().numpy()
+            # records arrive in completion order (one atomic slot per finished episode): sorted by (iteration, env) on the
+            # device -- a key sort of a few thousand 64-bit words -- so that the host only copies (a numpy lexsort of the
+            # 16 000 records 4096 envs finish between two log points cost more than the hundred iterations' launches)
+            ri, rf = self.rec_i32[:count], self.rec_f64[:count]
+            order = torch.argsort(ri[:, 1].to(torch.int64) * (1 << 32) + ri[:, 0].to(torch.int64))
+            ri, rf = ri[order].cpu().numpy(), rf[order].cpu().numpy()
             for k, name in enumerate(("env", "iteration", "length", "constraint_steps", "recovery_steps", "flags")):
                 out[name] = ri[:, k]
             out["ret"], out["last_reward"] = rf[:, 0], rf[:, 1]
-            out = out[np.lexsort((out["env"], out["iteration"]))]
         self.state[0].zero_()
         return out
 

@@ -79,13 +79,6 @@ class VectorLoop:
         # the fused step also writes env.next_obs / reward / done / constraint / success / ep_done (off: nobody reads them
         # in the steady-state graph; the episode log and the online ensemble re-fit switch them on by themselves)
         self.step_outputs = False
-        # the acting pass's two large forwards run under the updates on a side stream (fast_update.ActOverlap); the packed
-        # loop (one launch per stage for S seeds, one stream) switches it off
-        self.overlap_act = True
-        # how a CAPTURED iteration gets that concurrency: "chain" = a chain of hipGraphs on two streams (fast_update.GraphChain),
-        # "branches" = forked branches inside one hipGraph (do not run concurrently on ROCm 7.2: kept for the measurement)
-        self.overlap_capture = "chain"
-        self._chain = None
         if self.n > 1 and hasattr(recovery_memory, "clamp_stratified"):
             # N envs overwrite the ring in capacity / N iterations: once the policy avoids violations the positive
             # class can drop below int(B * pos_fraction) rows, where the one-env reference would abort
@@ -96,7 +89,7 @@ class VectorLoop:
         self.obs = self.env.reset()
         return self.obs
 
-    def do_updates(self, i_episode=1, online_qrisk=True, act_follows=False):
+    def do_updates(self, i_episode=1, online_qrisk=True):
         """experiment.py:397-416.  The caller has checked len(memory) > batch_size."""
         cfg = self.cfg
         fast = getattr(self.agent, "fast", None)
@@ -104,21 +97,12 @@ class VectorLoop:
         grouped = (fast is not None and fast.grouped and fast.sync_world == 1 and cfg.batch_size == fast.B
                    and hasattr(self.memory, "draw_desc")
                    and (not online_qrisk or qr.clamp_batch_size(cfg.batch_size, len(self.recovery_memory)) == fast.B))
-        overlap = None
-        if (act_follows and grouped and online_qrisk and self.overlap_act and self.obs is self.env.obs
-                and cfg.use_recovery and cfg.MF_recovery and self._can_fuse_step() and self.obs.shape[0] == self.n):
-            from .fast_update import FastActor, recording
-            if self._actor is None:
-                self._actor = FastActor(fast, self.n)
-            if not recording():
-                overlap = self._actor.overlap(self.obs, chain=self._chain)
         for u in range(cfg.updates_per_step):
             if grouped:
                 # both replay draws + the policy noise in one launch, independent kernels of the two updates grouped
                 # (fast_update.FastUpdater.update_pair): same results as the two calls below, ~30 % fewer launches
                 with trace_range("sample+sac_update+qrisk_update"):
-                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None,
-                                     overlap=overlap if u == cfg.updates_per_step - 1 else None)
+                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None)
                 self.host_updates[0] += 1
                 if online_qrisk:
                     qr.updates += 1
@@ -322,7 +306,7 @@ class VectorLoop:
     # -- whole iteration -----------------------------------------------------------------------
     def vector_step(self, do_update=True, random_actions=False, online_qrisk=True, i_episode=1):
         if do_update:
-            self.do_updates(i_episode, online_qrisk, act_follows=not random_actions)
+            self.do_updates(i_episode, online_qrisk)
         with trace_range("act"):
             action, real_action, recovery = self.act(self.obs, random_actions)
         self._last_recovery, self._last_real_action = recovery, real_action
@@ -343,28 +327,12 @@ class VectorLoop:
         saved = (self.total_numsteps, self.updates, list(self.host_updates))
         qr_updates = self.agent.safety_critic.updates
         lens = (self.memory._len, self.recovery_memory._len)
-        chain_ok = (self.overlap_act and self.overlap_capture == "chain" and self._actor is not None
-                    and getattr(self._actor, "side", None) is not None)      # the warm-up iterations ran the overlapped pass
-        if chain_ok:
-            from .fast_update import GraphChain
-            g = GraphChain(self.device, self._actor.side_stream(), generators=(self.action_rng,))
-            self._chain = g
-            try:
-                g.begin()
-                self.vector_step(True, False, online_qrisk)
-                g.end()
-            except BaseException:
-                g.abort()
-                raise
-            finally:
-                self._chain = None
-        else:
-            g = torch.cuda.CUDAGraph()
-            # configurations that sample a policy through its torch module (e.g. --Q_sampling_recovery with N > 1) draw from
-            # the loop's own generator inside the graph: registered, its Philox offset advances per replay like the global one's
-            g.register_generator_state(self.action_rng)
-            with torch.cuda.graph(g):
-                self.vector_step(True, False, online_qrisk)
+        g = torch.cuda.CUDAGraph()
+        # configurations that sample a policy through its torch module (e.g. --Q_sampling_recovery with N > 1) draw from
+        # the loop's own generator inside the graph: registered, its Philox offset advances per replay like the global one's
+        g.register_generator_state(self.action_rng)
+        with torch.cuda.graph(g):
+            self.vector_step(True, False, online_qrisk)
         # which of the env's two state representations (status word / t + flag arrays) the captured kernels read and write
         self._graph_status_live = getattr(self.env, "_status_live", None)
         self._graph_updates = (self.host_updates[0] - saved[2][0], self.host_updates[1] - saved[2][1])
@@ -400,12 +368,25 @@ class VectorLoop:
         """One device->host copy of the counter vector (+ the samplers' error flags: a draw the reference would
         abort with ValueError -- random.sample on too small a population, replay_memory.py:28,61-66 -- leaves the
         batch unwritten on the device, so the run must stop here instead of training on stale rows)."""
-        self.memory.check_error()
-        self.recovery_memory.check_error()
-        vals = self.stats.cpu().tolist()
+        mems = [m for m in (self.memory, self.recovery_memory) if hasattr(m, "state") and torch.is_tensor(m.state)]
+        if len(mems) == 2 and self.stats.is_cuda:
+            # ONE device->host copy for the counters, the two error flags and the two f64 sums (four synchronising copies
+            # per log point before: each one is a pipeline bubble of the replayed graph)
+            packed = torch.cat([self.stats.to(torch.int64), mems[0].state[3:4], mems[1].state[3:4],
+                                self.reward_sums.view(torch.int64)]).cpu()
+            n = self.stats.numel()
+            for m, code in zip(mems, packed[n:n + 2].tolist()):
+                if code:
+                    m.check_error()              # raises with the reference's message
+            vals = packed[:n].tolist()
+            sums = packed[n + 2:].view(torch.float64).tolist()
+        else:
+            self.memory.check_error()
+            self.recovery_memory.check_error()
+            vals = self.stats.cpu().tolist()
+            sums = self.reward_sums.cpu().tolist()
         vals[8], vals[9] = self.host_updates
         out = dict(zip(STAT_KEYS, vals))
-        sums = self.reward_sums.cpu().tolist()
         out["reward_sum"], out["episode_return_sum"] = float(sums[0]), float(sums[1])
         return out
 

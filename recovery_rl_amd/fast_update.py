@@ -38,11 +38,6 @@ def record(kind, *payload):
         _TAPE.append((kind,) + payload)
 
 
-def recording():
-    """True while a PackedLoop records the iteration's launches (one stream, one launch per stage for all seeds)."""
-    return _TAPE is not None
-
-
 class FlatNet:
     """Flat parameter / gradient / Adam-state storage for one network, plus the layer views."""
 
@@ -571,7 +566,7 @@ class FastUpdater:
                                       p(self.rbias), p(action_view), action_view.stride(0), None, None, None, None,
                                       p(self.recpolicy.p["log_std"]), float(self.qr.policy.min_log_std))
 
-    def update_pair(self, memory, recovery_memory, overlap=None):
+    def update_pair(self, memory, recovery_memory):
         """One SAC update and (recovery_memory not None) one Q_risk + recovery-policy update of a lock-step iteration
         (experiment.py:397-416): both replay draws and the iteration's policy noise in ONE launch, then the two
         updates on the grouped kernels.  Same draws, same arithmetic, same parameters as the separate calls."""
@@ -596,10 +591,8 @@ class FastUpdater:
         self._actor_noise_fresh = n_act > 0
         n = self._noise
         self.sac_update_grouped(batch, n[0], n[1])
-        if overlap is not None:
-            overlap.after_sac()                 # the task policy is final: its acting forward starts on the side stream
         if recovery_memory is not None:
-            self.qrisk_update_grouped(batch_q, n[2], n[3], overlap=overlap)
+            self.qrisk_update_grouped(batch_q, n[2], n[3])
         return self.losses
 
     def sac_update_grouped(self, batch, eps_next, eps_pi):
@@ -639,7 +632,7 @@ class FastUpdater:
                            (self.policy, None, 0.0, self.pol_b.grad_part)])
         return self.losses
 
-    def qrisk_update_grouped(self, batch, eps_next, eps_pi, overlap=None):
+    def qrisk_update_grouped(self, batch, eps_next, eps_pi):
         """qrisk_update with 15 launches instead of 19: the task policy on s' and the recovery policy on s in one
         forward launch (the recovery policy does not depend on the critic step in between), their heads in one, the
         target and online critics in one."""
@@ -666,8 +659,6 @@ class FastUpdater:
                                       f0=qr.gamma_safe, loss=self.losses[4:]))
         self._sync(self.qrisk.grad)
         self.qrisk.adam(qr.lr, target=self.qrisk_target, tau=qr.tau, part=self.qr_a.grad_part)
-        if overlap is not None:
-            overlap.after_qrisk()               # the safety critic is final: Q_risk(s, a_task) of the acting pass starts
         if mf:                                                             # qrisk.py:150-158, at the UPDATED critic
             raw, rn, rs = self.rec_a.parts
             ls = self.recpolicy.p["log_std"]
@@ -780,131 +771,6 @@ class FastUpdater:
         return self.losses
 
 
-class ActOverlap:
-    """The acting pass of a lock-step iteration under the iteration's updates, on a side stream (parallel branches of the
-    captured hipGraph).  get_action (experiment.py:546-577) needs three networks, each final at a different point of the
-    iteration: the task policy after the SAC step, Q_risk after the safety critic's step, the recovery policy only after
-    its own step at the very end.  So the 4096-row task-policy forward runs while the Q_risk update does, Q_risk(s, a_task)
-    while the recovery policy is updated, and only the recovery policy's forward is left for FastActor.act.  The same
-    launches on the same inputs as the serial pass (the [task policy, recovery policy] group launch becomes two): bit-equal
-    results."""
-
-    def __init__(self, actor, obs, side, chain=None):
-        self.actor, self.obs, self.side, self.chain = actor, obs, side, chain
-        self.state = 0
-
-    def _on_side(self, fn):
-        """Issue fn's launches on the side stream, after everything issued so far on the main stream.  Eagerly and inside a
-        single captured graph: a stream fork; while a GraphChain is being captured: a graph segment of its own on the side
-        stream (forked branches INSIDE one hipGraph do not run concurrently on this runtime, separate graph launches on two
-        streams do)."""
-        if self.chain is not None:
-            self.chain.side_segment(fn)
-            return
-        self.side.wait_stream(torch.cuda.current_stream(self.actor.f.dev))
-        with torch.cuda.stream(self.side):
-            fn()
-
-    def after_sac(self):
-        a = self.actor
-        a.noise = a.f.actor_noise(a.n)              # this iteration's draws (written by the sample launch)
-        self._on_side(lambda: forward_multi([a.pol.forward_desc(self.obs, save=False)]))
-        self.state = 1
-
-    def after_qrisk(self):
-        a, f = self.actor, self.actor.f
-        assert self.state == 1
-
-        def launch():
-            task_head = f._gauss_desc(a.pol.parts, a.noise[0], a.xa[:, 2:4], None, n=a.n, obs_in=self.obs, obs_out=a.xa)
-            a.qr.finalize = False
-            forward_multi([a.qr.forward_desc(a.xa, save=False, in_head=task_head)])
-        self._on_side(launch)
-        self.state = 2
-        a.overlapped = self
-
-    def join(self):
-        """The main stream waits for the side stream's forwards (the step launch reads both branches)."""
-        if self.chain is not None:
-            self.chain.join()
-        else:
-            torch.cuda.current_stream(self.actor.f.dev).wait_stream(self.side)
-
-
-class GraphChain:
-    """One lock-step iteration as a CHAIN of captured hipGraphs on two streams: main segments (replayed on the caller's
-    stream) and side segments (replayed on `side`), with an event from the main stream before every side segment and one
-    back at the join.  Six graph launches per iteration instead of one -- what it buys is real concurrency between the
-    updates' chain of small kernels and the acting pass's two large forwards."""
-
-    def __init__(self, device, side, generators=()):
-        self.device, self.side = device, side
-        self.capture_stream = torch.cuda.Stream(device=device)
-        self.pool = torch.cuda.graph_pool_handle()
-        self.generators = tuple(generators)
-        self.items = []                     # ("main", graph) | ("side", graph, event) | ("join", event)
-        self._cur = None
-
-    def _begin(self, stream):
-        g = torch.cuda.CUDAGraph()
-        for gen in self.generators:
-            g.register_generator_state(gen)
-        self._ctx = torch.cuda.stream(stream)
-        self._ctx.__enter__()
-        g.capture_begin(pool=self.pool)
-        self._cur = g
-
-    def _end(self):
-        g, self._cur = self._cur, None
-        g.capture_end()
-        self._ctx.__exit__(None, None, None)
-        return g
-
-    def begin(self):
-        torch.cuda.synchronize(self.device)
-        self._begin(self.capture_stream)
-
-    def side_segment(self, fn):
-        self.items.append(("main", self._end()))
-        self._begin(self.side)
-        try:
-            fn()
-        finally:
-            g = self._end()
-        self.items.append(("side", g, torch.cuda.Event()))
-        self._begin(self.capture_stream)
-
-    def join(self):
-        self.items.append(("main", self._end()))
-        self.items.append(("join", torch.cuda.Event()))
-        self._begin(self.capture_stream)
-
-    def end(self):
-        self.items.append(("main", self._end()))
-        torch.cuda.synchronize(self.device)
-
-    def abort(self):
-        if self._cur is not None:
-            try:
-                self._end()
-            except Exception:      # noqa: BLE001  (a failed capture is already invalid)
-                pass
-
-    def replay(self):
-        main = torch.cuda.current_stream(self.device)
-        for item in self.items:
-            if item[0] == "main":
-                item[1].replay()
-            elif item[0] == "side":
-                item[2].record(main)
-                self.side.wait_event(item[2])
-                with torch.cuda.stream(self.side):
-                    item[1].replay()
-            else:
-                item[1].record(self.side)
-                main.wait_event(item[1])
-
-
 class FastActor:
     """Batched get_action (experiment.py:546-577) for N envs on the fused kernels: task policy sample,
     Q_risk of (s, a_task), model-free recovery action and the recovery gate -- 8 launches instead of
@@ -918,23 +784,6 @@ class FastActor:
         self.xa = z(n, 4)                       # [s | a_task]
         self.task_action, self.rec_action, self.real_action = z(n, 2), z(n, 2), z(n, 2)
         self.recovery = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.overlapped = None                  # an ActOverlap that has run this iteration's first two forwards
-        self.side = None
-
-    def can_overlap(self):
-        f = self.f
-        return bool(f.grouped and f.fuse_heads and self.qr.split and self.pol.split and self.rec.split)
-
-    def side_stream(self):
-        if self.side is None:
-            self.side = torch.cuda.Stream(device=self.f.dev)
-        return self.side
-
-    def overlap(self, obs, chain=None):
-        """-> ActOverlap for update_pair(overlap=...), when the pass that follows is the fused one on `obs`."""
-        if not self.can_overlap():
-            return None
-        return ActOverlap(self, obs, self.side_stream(), chain)
 
     def act(self, obs, eps_safe, use_recovery, mf_recovery, noise=None, defer_select=False):
         """-> (task action [n,2], executed action [n,2], recovery u8[n] or None); persistent buffers.
@@ -942,16 +791,6 @@ class FastActor:
         holds its inputs, the task action is the strided view xa[:, 2:4] and the other two are filled by that kernel."""
         f, n, lib, st = self.f, self.n, self.f.lib, _lib.current_stream()
         self.pending_select = None
-        ov, self.overlapped = self.overlapped, None
-        if ov is not None:
-            # task policy and Q_risk(s, a_task) ran under the updates (ActOverlap); left: the recovery policy, final only now
-            assert ov.state == 2 and ov.obs is obs and defer_select and use_recovery and mf_recovery and noise is None
-            forward_multi([self.rec.forward_desc(obs, save=False)])
-            rec_head = f._stoch_desc(self.rec.parts, self.noise[1], self.rec_action, n=n)
-            ov.join()                      # the step launch reads both branches
-            zq, zn, zs = self.qr.parts
-            self.pending_select = (zq, zn, zs, float(eps_safe), None, rec_head)
-            return self.xa[:, 2:4], self.real_action, self.recovery
         if noise is None:
             noise = f.actor_noise(n)
         if f.grouped and use_recovery and mf_recovery:

@@ -26,8 +26,6 @@ class PackedLoop:
         if not 1 <= len(loops) <= self.MAX_SEEDS:
             raise ValueError("1 .. %d seeds per GPU" % self.MAX_SEEDS)
         self.loops = list(loops)
-        for loop in self.loops:
-            loop.overlap_act = False      # one stream, one launch per stage for all seeds: no side-stream acting pass
         self.S = len(loops)
         self.online_qrisk = online_qrisk
         self.lib = _lib.load()

@@ -244,7 +244,7 @@ def test_rrl_main_two_ranks_pack_consecutive_seeds(tmp_path):
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "destroy_process_group" not in out.stderr
-    dirs = sorted(os.listdir(tmp_path / "two_ranks"))
+    dirs = sorted(os.listdir(tmp_path / "two_ranks"), key=lambda d: int(d.rsplit("_seed", 1)[1]))
     assert len(dirs) == 4 and [d.rsplit("_seed", 1)[1] for d in dirs] == ["4", "5", "6", "7"]
     multi = {d.rsplit("_seed", 1)[1]: pickle.load(open(tmp_path / "two_ranks" / d / "run_stats.pkl", "rb")) for d in dirs}
     for first in (4, 6):                          # what ONE process packing the same two seeds produces

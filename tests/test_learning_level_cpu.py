@@ -51,14 +51,24 @@ def test_learning_curves_have_the_reference_shape(name):
 
 
 def test_navigation2_runs_are_in_the_range_of_the_reference_runs():
-    """scripts/navigation2.sh:7 (model-free recovery), seeds 1..4: this stack's runs
-    (profiles/round1_learning_other_configs.jsonl) next to the reference's own (tests/golden/ref_learning_nav2_seed*).
-    This configuration has a large seed-to-seed spread on BOTH stacks (reference 238 .. 397 successes, this stack
-    106 .. 391; seed 4 is the worst run of both), so the distributions are compared, not single runs."""
+    """scripts/navigation2.sh:7 (model-free recovery), seeds 1..8: this stack's one-env runs (`python
+    profiles/learning_other_configs.py nav2_mf <seeds>` on one MI355X: profiles/round1_learning_other_configs.jsonl seeds 1-4,
+    round4_learning_nav2_mf_one_env.jsonl seeds 5-8) next to the reference's own (tests/golden/ref_learning_nav2_seed*, recorded
+    by tests/golden/run_reference_training.py).  This configuration has a large seed-to-seed spread on BOTH stacks (reference
+    238 .. 397 successes, this stack 106 .. 391 over seeds 1-4; seed 4 is the worst run of both), so the distributions are
+    compared, not single runs."""
     ref = [json.load(open(p)) for p in sorted(glob.glob(os.path.join(HERE, "golden", "ref_learning_nav2_seed*.json")))]
-    mine = [json.loads(line) for line in open(os.path.join(HERE, "..", "profiles", "round1_learning_other_configs.jsonl"))]
+    mine = []
+    for name in ("round1_learning_other_configs.jsonl", "round4_learning_nav2_mf_one_env.jsonl"):
+        path = os.path.join(HERE, "..", "profiles", name)
+        if os.path.exists(path):
+            mine += [json.loads(line) for line in open(path) if line.strip()]
     mine = [m for m in mine if m["config"] == "nav2_mf"]
-    assert len(ref) >= 1 and len(mine) >= len(ref)
+    assert len(ref) >= 4 and len(mine) >= 4
+    seeds = sorted(set(r["seed"] for r in ref) & set(m.get("seed", 1) for m in mine))
+    assert len(seeds) >= 4, seeds                           # the same seeds on both sides
+    ref = [r for r in ref if r["seed"] in seeds]
+    mine = [m for m in mine if m.get("seed", 1) in seeds]
     r = np.array([x["total_successes"] for x in ref], dtype=np.float64)
     m = np.array([x["total_successes"] for x in mine], dtype=np.float64)
     assert abs(r.mean() - m.mean()) <= 2.0 * max(r.std(), m.std(), 20.0), (r, m)
