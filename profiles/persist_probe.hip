@@ -239,6 +239,126 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
     if (lane == 0 && my_errors) atomicAdd(a.token_errors, my_errors);
 }
 
+
+// ---- second form: the program cut at its device-scope points into SEGMENTS, one launch each (a kernel boundary costs 1.8 us,
+// a device-scope software barrier over 256 workgroups 51 us); inside a segment only XCD-local barriers, and NO cache
+// invalidation: whatever another CU of the XCD wrote is read with device-coherent loads (sc1: they miss the reader's L1 and are
+// served by the XCD's L2), weights with plain loads (they change only at segment boundaries)
+__device__ __forceinline__ float4 load_sc1(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ unsigned load_sc1_u32(const unsigned* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int K>
+__device__ __forceinline__ void mfma_tile_sc1(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                              int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    constexpr int V = K / 16;
+    float4 a[V], b[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        a[j] = load_sc1(A + i * H + 16 * j + 4 * q);                       // written by other CUs of this XCD
+        b[j] = *reinterpret_cast<const float4*>(B + i * H + 16 * j + 4 * q);   // weights: constant inside a segment
+    }
+    wait_loads();
+#pragma unroll
+    for (int j = 0; j < V; ++j) asm volatile("" : "+v"(a[j].x), "+v"(a[j].y), "+v"(a[j].z), "+v"(a[j].w));
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j].w, acc1, 0, 0, 0);
+    }
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = acc[r];
+        C[(4 * q + r) * H + i] = v > 1.f ? 1.f : (v < -1.f ? -1.f : v);
+    }
+}
+
+// stages [s0, s1) of iteration `it`; xepoch0 = XCD-local barriers executed by earlier launches
+__global__ __launch_bounds__(256) void segment_kernel(Args a, int it, int s0, int s1, unsigned xepoch0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned xcd = blockIdx.x % kXcds, rank = blockIdx.x / kXcds;        // round-robin dispatch; checked below
+    if (tid == 0 && xcc_id() != xcd) atomicAdd(a.errors, 1u << 16);
+    const int w = rank * kWavesPerWg + wave;
+    float* act = a.act + (size_t)xcd * 2 * 64 * H;
+    unsigned* tok = a.token + xcd * 2 * 128;
+    unsigned* xbar = a.xcd_bar + xcd * 16;
+    unsigned xepoch = xepoch0, my_errors = 0;
+    for (int s = s0; s < s1; ++s) {
+        const Stage st = kProgram[s];
+        const int g = it * kStages + s;
+        const float* src = act + (size_t)(g & 1) * 64 * H;
+        float* dst = act + (size_t)((g + 1) & 1) * 64 * H;
+        if (a.mode != 1) {
+            if (st.kind == FWD || st.kind == TN) {
+                for (int t = w; t < st.tiles; t += kWavesPerXcd) {
+                    const int rt = t & 3, ct = (t >> 2) & 15, head = (t >> 6) % 6;
+                    mfma_tile_sc1<256>(src + rt * 16 * H, a.weights + (size_t)head * H * H + ct * 16 * H, dst + rt * 16 * H + ct * 16, lane);
+                }
+                for (int t = w; t < st.tn_tiles; t += kWavesPerXcd) {
+                    const int rt = t & 15, ct = (t >> 4) & 15, head = (t >> 8) % 6;
+                    mfma_tile_sc1<32>(src + (rt & 3) * 16 * H + (ct & 7) * 32, src + ((rt + 1) & 3) * 16 * H + (rt & 7) * 32,
+                                      a.partial + ((size_t)xcd * 6 + head) * H * H + rt * 16 * H + ct * 16, lane);
+                }
+            } else if (st.kind == THIN) {
+                const int e = (w * 64 + lane) * 4 % (64 * H);
+                float4 v = load_sc1(src + e);
+                wait_loads();
+                asm volatile("" : "+v"(v.x));
+                v.x = v.x * 0.5f + 0.1f;
+                *reinterpret_cast<float4*>(dst + e) = v;
+            } else {        // ADAM (its inputs were written by the previous LAUNCH: plain loads)
+                for (int head = 0; head < st.tiles; ++head) {
+                    const int per_xcd = H * H / kXcds;
+                    for (int e4 = w * 64 + lane; e4 < per_xcd / 4; e4 += kWavesPerXcd * 64) {
+                        const size_t off = (size_t)head * H * H + xcd * per_xcd + 4 * e4;
+                        float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int x = 0; x < kXcds; ++x) {
+                            const float4 p = *reinterpret_cast<const float4*>(a.partial + (size_t)x * 6 * H * H + off);
+                            gsum.x += p.x; gsum.y += p.y; gsum.z += p.z; gsum.w += p.w;
+                        }
+                        float4 m = *reinterpret_cast<float4*>(a.adam_m + off), v = *reinterpret_cast<float4*>(a.adam_v + off);
+                        float4 wt = *reinterpret_cast<float4*>(a.weights + off);
+                        auto upd = [](float& wv, float& mv, float& vv, float gr) {
+                            mv = 0.9f * mv + 0.1f * gr;
+                            vv = 0.999f * vv + 0.001f * gr * gr;
+                            wv -= 3e-4f * mv / (sqrtf(vv) + 1e-8f) * 1e-3f;
+                        };
+                        upd(wt.x, m.x, v.x, gsum.x); upd(wt.y, m.y, v.y, gsum.y);
+                        upd(wt.z, m.z, v.z, gsum.z); upd(wt.w, m.w, v.w, gsum.w);
+                        *reinterpret_cast<float4*>(a.adam_m + off) = m;
+                        *reinterpret_cast<float4*>(a.adam_v + off) = v;
+                        *reinterpret_cast<float4*>(a.weights + off) = wt;
+                    }
+                }
+            }
+        }
+        {
+            unsigned prev = load_sc1_u32(tok + (g & 1) * 128 + (w + 1 + lane) % kWavesPerXcd);
+            wait_loads();
+            asm volatile("" : "+v"(prev));
+            my_errors += (prev != (unsigned)g) ? 1u : 0u;
+            if (lane == 0) tok[((g + 1) & 1) * 128 + w] = (unsigned)g + 1;
+        }
+        if (s + 1 < s1) xcd_barrier(xbar, (unsigned)kWgPerXcd * ++xepoch, 2);     // XCD-local, no invalidation
+    }
+    for (int off = 32; off > 0; off >>= 1) my_errors += __shfl_xor(my_errors, off);
+    if (lane == 0 && my_errors) atomicAdd(a.token_errors, my_errors);
+}
+
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
@@ -309,6 +429,62 @@ int main(int argc, char** argv) {
         }
         printf("%8.2f us per update pair (%5.2f us per stage)  stale token reads %10u of %u  placement errors %u   %s\n",
                best * 1e3f / iters, best * 1e3f / iters / kStages, terr, (unsigned)(iters * kStages) * 1024u * 64u, err >> 16, r.what);
+    }
+    // ---- segmented form: 6 launches per update pair in a captured graph --------------------------------------------------
+    {
+        Stage hs[kStages];
+        hipMemcpyFromSymbol(hs, HIP_SYMBOL(kProgram), sizeof(hs));
+        std::vector<int> cuts = {0};
+        for (int s = 0; s < kStages; ++s)
+            if (hs[s].device) cuts.push_back(s + 1);
+        if (cuts.back() != kStages) cuts.push_back(kStages);
+        printf("segments per update pair: %d (", (int)cuts.size() - 1);
+        for (size_t k = 0; k + 1 < cuts.size(); ++k) printf("%s[%d,%d)", k ? " " : "", cuts[k], cuts[k + 1]);
+        printf(")\n");
+        hipStream_t st;
+        hipStreamCreate(&st);
+        for (int mode = 0; mode < 2; ++mode) {
+            const int giters = iters < 50 ? iters : 50;
+            hipMemset(a.act, 0, sizeof(float) * 8 * 2 * 64 * H);
+            hipMemset(a.token, 0, 4 * 8 * 2 * 128);
+            hipMemset(a.xcd_bar, 0, 4 * 16 * 8);
+            hipMemset(a.errors, 0, 4);
+            hipMemset(a.token_errors, 0, 4);
+            a.mode = mode;
+            hipGraph_t g;
+            hipGraphExec_t ge;
+            hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+            unsigned xe = 0;
+            for (int it = 0; it < giters; ++it)
+                for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+                    hipLaunchKernelGGL(segment_kernel, dim3(256), dim3(256), 0, st, a, it, cuts[k], cuts[k + 1], xe);
+                    xe += (unsigned)(cuts[k + 1] - cuts[k] - 1);
+                }
+            hipStreamEndCapture(st, &g);
+            hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            // (the epoch bases are baked into the launches: counters and tokens are reset before every replay)
+            hipGraphLaunch(ge, st);                         // warm-up replay
+            hipStreamSynchronize(st);
+            hipMemsetAsync(a.token, 0, 4 * 8 * 2 * 128, st);
+            hipMemsetAsync(a.xcd_bar, 0, 4 * 16 * 8, st);
+            hipMemsetAsync(a.errors, 0, 4, st);
+            hipMemsetAsync(a.token_errors, 0, 4, st);
+            hipEventRecord(e0, st);
+            hipGraphLaunch(ge, st);
+            hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) { printf("graph launch failed\n"); return 1; }
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            unsigned err = 0, terr = 0;
+            hipMemcpy(&err, a.errors, 4, hipMemcpyDeviceToHost);
+            hipMemcpy(&terr, a.token_errors, 4, hipMemcpyDeviceToHost);
+            printf("%8.2f us per update pair (%5.2f us per stage)  stale token reads %10u of %u  placement errors %u   SEGMENTED: %s, "
+                   "kernel boundaries at the device-scope points, XCD-local barriers inside, sc1 loads, no invalidation\n",
+                   ms * 1e3f / giters, ms * 1e3f / giters / kStages, terr, (unsigned)(giters * kStages) * 1024u * 64u, err >> 16,
+                   mode ? "barriers only" : "tile loops + barriers");
+            hipGraphExecDestroy(ge);
+            hipGraphDestroy(g);
+        }
     }
     return 0;
 }

@@ -182,7 +182,20 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
         }
         bool cons = false, succ = false, epd = false, rec = false;
         float log_rew = 0.f;
+        // per-env accumulators (running return; the episode table's four): requested with the first loads of the pass -- behind
+        // the replay stores the compiler would have to keep them (it cannot prove they do not alias), i.e. behind the whole
+        // Philox / Box-Muller chain
+        float ep_rew_in = 0.f;
+        double lg_ret = 0.0;
+        int lg_len = 0, lg_viol = 0, lg_rec = 0;
         if (live) {
+            ep_rew_in = p.ep_reward[i];
+            if (p.log_state) {
+                lg_len = p.log_len[i];
+                lg_ret = p.log_ret[i];
+                lg_viol = p.log_viol[i];
+                lg_rec = p.log_rec[i];
+            }
             const double2 pp = a.pos[i];
             const float2 task = *reinterpret_cast<const float2*>(p.task_action + i * p.ld_task);
             float2 act;
@@ -264,7 +277,7 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
                                          cons ? 1.0f : 0.0f, nobs, mask, block_sums ? super_acc : nullptr, s0);
             // episode accounting
             log_rew = rew;
-            const float er = p.ep_reward[i] + rew;
+            const float er = ep_rew_in + rew;
             rsum += double(rew);
             if (epd) retsum += double(er);
             p.ep_reward[i] = epd ? 0.0f : er;
@@ -289,10 +302,10 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             double ret = 0.0;
             int log_len = 0, viol = 0, recs = 0;
             if (live) {
-                log_len = p.log_len[i] + 1;
-                ret = p.log_ret[i] + double(log_rew);
-                viol = p.log_viol[i] + int(cons);
-                recs = p.log_rec[i] + int(rec);
+                log_len = lg_len + 1;
+                ret = lg_ret + double(log_rew);
+                viol = lg_viol + int(cons);
+                recs = lg_rec + int(rec);
             }
             const unsigned long long bal = __ballot(epd);
             if (bal) {

@@ -85,7 +85,7 @@ BUDGETS = (
     ("plan_cost_kernelILb0E", 128, "planner f32: four waves per SIMD"),
     ("plan_cost_kernelILb1E", 128, "planner f16x3"),
     ("ens_big_fwd_bwd_kernel", 128, "large-batch ensemble step"),
-    ("step_push_kernelIN12_GLOBAL__N_16NavEnv", 104, "fused env step + pushes: >= four waves per SIMD"),
+    ("step_push_kernelIN12_GLOBAL__N_16NavEnv", 120, "fused env step + pushes + episode table: four waves per SIMD (4 x 120 <= 512)"),
     ("nav_step_kernel", 64, "env step: eight waves per SIMD (bandwidth regime)"),
     ("sample_group_kernel", 64, "replay draws"),
 )
