@@ -393,8 +393,10 @@ def roofline_stages(a, device, iteration_ms):
             rows.append((name, "acting forward" if m_max > 1024 else "update forward", launch, fl, None))
         elif kind == "head_bwd":
             arr, n = op[1], op[2]
-            fl = sum(4.0 * arr[k].G * arr[k].B * arr[k].H * arr[k].dout for k in range(n))
-            rows.append(("head backward x%d" % n, "head backward", lambda arr=arr, n=n: lib.rrl_mlp_head_backward_multi(n, arr, st()), fl, None))
+            # thin (dout <= 4): a streaming kernel -- h2 read, dh2 written, the stack outputs and W3 read
+            by = sum(4.0 * arr[k].G * arr[k].B * (2 * arr[k].H + 4 * arr[k].dout) + 8.0 * arr[k].G * arr[k].H * arr[k].dout
+                     for k in range(n))
+            rows.append(("head backward x%d" % n, "head backward", lambda arr=arr, n=n: lib.rrl_mlp_head_backward_multi(n, arr, st()), None, by))
         elif kind == "hidden_bwd":
             arr, n = op[1], op[2]
             fl = 0.0
@@ -646,13 +648,21 @@ def run_config_packed(a, device, world, rank, S, updates_per_step=1, min_seconds
     from recovery_rl_amd.packed import PackedLoop
     U = updates_per_step
     first = 1 + rank * S
-    loops = [build_loop(arg_utils.get_args(config_argv(a.env, first + k, a.num_envs, U)), device) for k in range(S)]
-    packed = PackedLoop(loops)
-    packed.capture()
-    step = production_step(packed.replay, loops)
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize(device)
+    # set-up on every rank, then ONE agreement over the ranks before anybody enters the barriers of the timed region: a rank
+    # that failed here (e.g. out of memory) must not leave the others waiting in a collective
+    failed, loops, packed, step = None, None, None, None
+    try:
+        loops = [build_loop(arg_utils.get_args(config_argv(a.env, first + k, a.num_envs, U)), device) for k in range(S)]
+        packed = PackedLoop(loops)
+        packed.capture()
+        step = production_step(packed.replay, loops)
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize(device)
+    except Exception as e:      # noqa: BLE001
+        failed = "%s: %s" % (type(e).__name__, e)
+    if dist_utils.max_over_ranks(1.0 if failed else 0.0, world, device) > 0:
+        raise RuntimeError("packed set-up failed on %s" % ("this rank: " + failed if failed else "another rank"))
 
     def totals():
         st = [l.read_stats() for l in loops]

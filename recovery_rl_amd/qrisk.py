@@ -137,8 +137,10 @@ class QRiskWrapper:
         elif self.Q_sampling_recovery:
             # 1000 uniform candidate actions per state, keep the argmin of Q_risk (:214-225)
             n, k = state.shape[0], 1000
-            lo = torch.as_tensor(self.ac_space.low, dtype=torch.float32, device=self.device)
-            hi = torch.as_tensor(self.ac_space.high, dtype=torch.float32, device=self.device)
+            if getattr(self, "_ac_bounds", None) is None:        # once: a host -> device copy is not allowed inside a capture
+                self._ac_bounds = (torch.as_tensor(self.ac_space.low, dtype=torch.float32, device=self.device),
+                                   torch.as_tensor(self.ac_space.high, dtype=torch.float32, device=self.device))
+            lo, hi = self._ac_bounds
             cand = lo + (hi - lo) * torch.rand(n, k, lo.numel(), device=self.device) if candidates is None else \
                 torch.as_tensor(candidates, dtype=torch.float32, device=self.device).reshape(n, k, -1)
             q = self.get_value(state.unsqueeze(1).expand(n, k, -1).reshape(n * k, -1),

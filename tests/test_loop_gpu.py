@@ -333,3 +333,54 @@ def test_compact_env_state_loop_equals_the_array_state_loop(tmp_path, env_name, 
         assert torch.equal(getattr(ea.agent.fast, name).flat, getattr(eb.agent.fast, name).flat), name
     st = la.read_stats()
     assert st["episodes"] > 0 and st["env_steps"] == 73 * 192     # 40 eager + 3 capture warm-up + 30 replays
+
+
+def test_q_sampling_recovery_at_many_envs_is_captured_with_its_own_generator(tmp_path):
+    """--Q_sampling_recovery with N > 1 (advisor, round 3): the fused update path is on, acting goes through the torch modules and
+    draws the task policy's noise from the loop's own generator INSIDE the captured graph.  An unregistered generator made torch
+    raise at capture ('Attempt to increase offset for a CUDA generator not in capture mode') -- or, without that check, replay the
+    same noise for ever.  Registered with the graph (VectorLoop.capture), its offset advances per replay."""
+    cfg = make_cfg(tmp_path, ["--use_recovery", "--Q_sampling_recovery", "--gamma_safe", "0.8", "--eps_safe", "0.3",
+                              "--num_envs", "128"])
+    exp = Experiment(cfg)
+    exp.pretrain_critic_recovery()
+    loop = exp.loop
+    assert exp.agent.fast is not None and loop.n == 128
+    loop.start()
+    for k in range(3):
+        loop.vector_step(do_update=k > 1, random_actions=True)
+    loop.capture(online_qrisk=True)
+    acts = []
+    for _ in range(4):
+        loop.replay()
+        acts.append(loop._last_real_action.clone() if torch.is_tensor(loop._last_real_action) else None)
+    torch.cuda.synchronize()
+    st = loop.read_stats()
+    assert st["env_steps"] >= 4 * 128 and st["sac_updates"] >= 4
+    # the policy noise differs from replay to replay: the executed actions are not a replayed constant pattern
+    assert all(a is not None for a in acts)
+    assert not torch.equal(acts[1], acts[2]) and not torch.equal(acts[2], acts[3])
+    assert torch.isfinite(exp.env.pos).all()
+
+
+def test_replay_refuses_a_graph_whose_env_representation_changed(tmp_path):
+    """The captured graph bakes in which of the env's two state representations it steps (u16 status word / step count + flag
+    arrays).  An eager env.step() / reset() after the capture switches the env to the arrays: replay() must not keep stepping
+    the stale status word (advisor, round 3)."""
+    cfg = make_cfg(tmp_path, ["--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe", "0.3", "--num_envs", "256"])
+    exp = Experiment(cfg)
+    exp.pretrain_critic_recovery()
+    loop = exp.loop
+    loop.start()
+    for k in range(3):
+        loop.vector_step(do_update=k > 1, random_actions=True)
+    loop.capture(online_qrisk=True)
+    loop.replay()
+    assert exp.env._status_live                     # the production loop runs on the compact state
+    exp.env.reset()                                 # array API: decodes the status word, makes the arrays live
+    assert not exp.env._status_live
+    with pytest.raises(RuntimeError, match="representation changed"):
+        loop.replay()
+    loop.capture(online_qrisk=True)                 # a fresh capture picks the loop up again
+    loop.replay()
+    torch.cuda.synchronize()
