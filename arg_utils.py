@@ -97,6 +97,10 @@ ADDITIVE = [
     (("--no_pin_demos",), "store_true", None, "lock-step loop: let the safety buffer's ring overwrite the offline constraint "
                                               "demonstrations (default: they are pinned, as the one-env reference never "
                                               "wraps its 1e6-row ring within a run)"),
+    (("--keep_replay_size",), "store_true", None, "lock-step loop: keep --replay_size / --safe_replay_size as given even when "
+                                                  "--num_steps exceeds them (default at --num_envs > 1: both buffers are sized "
+                                                  "to hold the whole run, as the reference's defaults do: replay_size = "
+                                                  "num_steps = 1e6)"),
     (("--demo_share",), F, -1.0, "lock-step loop: share of every Q_risk batch drawn from the pinned constraint "
                                  "demonstrations, the rest from the online rows (0 = one uniform draw over the ring; "
                                  "default -1: 0.5 with --num_envs > 1 and pinned demonstrations -- the share a one-env "

@@ -391,6 +391,32 @@ class VectorLoop:
         return out
 
 
+MAX_COVER_ROWS = 1 << 28          # 8.6 GB per buffer at 32 B per row: far inside 288 GB of HBM
+
+
+def replay_capacities(cfg):
+    """(task buffer, safety buffer) capacities of a run.  Vectorisation rule 4: in the reference a buffer never wraps within a
+    run -- its defaults are replay_size = safe_replay_size = num_steps = 1e6 and a run stops at num_steps env-steps
+    (arg_utils.py, experiment.py:375) -- so both buffers hold a run's WHOLE history.  A lock-step run of N envs is given a step
+    budget N times larger; with the default rings it would keep only the last capacity / N iterations (245 at 4096 envs) and its
+    critics forget everything older: measured on config 4, the learning seeds then show violation bursts every ~250 iterations
+    from iteration ~1 000 on, and none with buffers that cover the run (profiles/round4_learning_vec4096_config4_*.json).  So
+    at N > 1 a capacity below the run's step budget is raised to it (+ the demonstrations, + one iteration of head-room), the
+    relation the reference's defaults have.  The stratified sampler's count tables bound the safety buffer at 2^21 rows with
+    --pos_fraction; `--keep_replay_size` keeps the rings as given."""
+    cap, safe_cap = int(cfg.replay_size), int(cfg.safe_replay_size)
+    n = int(getattr(cfg, "num_envs", 1))
+    if n <= 1 or getattr(cfg, "keep_replay_size", False):
+        return cap, safe_cap
+    steps = int(min(cfg.num_steps, MAX_COVER_ROWS)) + 2 * n
+    cap = max(cap, steps)
+    safe = steps + int(cfg.num_unsafe_transitions)
+    if cfg.pos_fraction >= 0:
+        safe = min(safe, 1 << 21)
+    safe_cap = max(safe_cap, safe)
+    return cap, safe_cap
+
+
 class Experiment:
     def __init__(self, exp_cfg, rank=0, world_size=1):
         self.exp_cfg = exp_cfg
@@ -424,8 +450,13 @@ class Experiment:
         self.experiment_setup()
 
         dev = self.device
-        self.memory = ReplayMemory(exp_cfg.replay_size, exp_cfg.seed, device=dev)
-        self.recovery_memory = ConstraintReplayMemory(exp_cfg.safe_replay_size, exp_cfg.seed, device=dev)
+        cap, safe_cap = replay_capacities(exp_cfg)
+        if (cap, safe_cap) != (exp_cfg.replay_size, exp_cfg.safe_replay_size):
+            print("Replay capacities raised to cover the run: %d / %d rows (--replay_size %d, --safe_replay_size %d, "
+                  "--num_steps %d; --keep_replay_size keeps the rings)" % (cap, safe_cap, exp_cfg.replay_size,
+                                                                         exp_cfg.safe_replay_size, exp_cfg.num_steps))
+        self.memory = ReplayMemory(cap, exp_cfg.seed, device=dev)
+        self.recovery_memory = ConstraintReplayMemory(safe_cap, exp_cfg.seed, device=dev)
         self.all_ep_data = []
 
         self.total_numsteps = 0

@@ -71,3 +71,24 @@ def test_demo_share_flag_defaults():
     assert a.demo_share == -1.0 and a.num_envs == 1
     a = arg_utils.get_args(["--env-name", "navigation2", "--use_recovery", "--num_envs", "4096", "--demo_share", "0.25"])
     assert a.demo_share == 0.25
+
+
+def test_buffers_cover_the_run_at_many_envs_only():
+    """Vectorisation rule 4 (experiment.replay_capacities): one env -> the reference's capacities untouched; N > 1 -> both buffers
+    hold the run's step budget (the reference's defaults: replay_size == num_steps), the stratified sampler's 2^21-row bound
+    respected, --keep_replay_size restores the rings."""
+    import arg_utils
+    from recovery_rl_amd.experiment import replay_capacities
+    one = arg_utils.get_args(["--env-name", "navigation2", "--use_recovery", "--num_steps", "5000000"])
+    assert replay_capacities(one) == (1000000, 1000000)
+    n, steps = 4096, 4096 * 1650
+    many = arg_utils.get_args(["--env-name", "navigation2", "--use_recovery", "--num_envs", str(n), "--num_steps", str(steps),
+                               "--num_unsafe_transitions", "20000"])
+    cap, safe = replay_capacities(many)
+    assert cap == steps + 2 * n and safe == steps + 2 * n + 20000
+    short = arg_utils.get_args(["--env-name", "navigation1", "--num_envs", "64", "--num_steps", "5000"])
+    assert replay_capacities(short) == (1000000, 1000000)                 # a run shorter than the buffers: nothing to raise
+    maze = arg_utils.get_args(["--env-name", "maze", "--num_envs", str(n), "--num_steps", str(steps), "--pos_fraction=0.3"])
+    assert replay_capacities(maze) == (steps + 2 * n, 1 << 21)
+    keep = arg_utils.get_args(["--env-name", "navigation2", "--num_envs", str(n), "--num_steps", str(steps), "--keep_replay_size"])
+    assert replay_capacities(keep) == (1000000, 1000000)
