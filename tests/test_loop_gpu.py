@@ -384,3 +384,16 @@ def test_replay_refuses_a_graph_whose_env_representation_changed(tmp_path):
     loop.capture(online_qrisk=True)                 # a fresh capture picks the loop up again
     loop.replay()
     torch.cuda.synchronize()
+
+
+def test_buffers_of_a_lockstep_run_hold_the_whole_run(tmp_path):
+    """Vectorisation rule 4: --num_envs > 1 with a step budget above the default capacities -> both buffers are sized for the run
+    (the reference's buffers never wrap within a run: replay_size == num_steps == 1e6); one env and --keep_replay_size keep the
+    reference's capacities."""
+    big = make_cfg(tmp_path, ["--use_recovery", "--MF_recovery", "--num_envs", "64", "--num_steps", "2000000"])
+    exp = Experiment(big)
+    assert exp.memory.capacity == 2000000 + 128 and exp.recovery_memory.capacity == 2000000 + 128 + 2000
+    assert exp.memory.s.shape[0] == exp.memory.capacity
+    keep = make_cfg(tmp_path, ["--use_recovery", "--MF_recovery", "--num_envs", "64", "--num_steps", "2000000", "--keep_replay_size"])
+    exp = Experiment(keep)
+    assert exp.memory.capacity == 1000000 and exp.recovery_memory.capacity == 1000000
