@@ -71,3 +71,22 @@ def test_config4_navigation2_model_based_recovery_at_4096_envs(tmp_path, precisi
         a = torch.tensor([[1.0, 0.0], [0.0, 1.0]], device=exp.device)
         mean, _ = mpc.model(torch.cat([s, a], 1).unsqueeze(0).expand(mpc.model.num_nets, -1, -1))
         assert (mean.mean(0) - a).abs().max() < 0.2
+
+
+def test_config4_stays_safe_over_1600_iterations_at_4096_envs(tmp_path):
+    """The behavioural guard of vectorisation rules 3 + 4 (demonstration share of the Q_risk batch; buffers that hold the run):
+    config 4 (Navigation2, model-based recovery, scripts/navigation2.sh:14 + --num_envs 4096, f16x3 planner, 16 updates per
+    iteration), seed 3, 1 675 iterations = 6.9 M env-steps, ~40 s.  With 1e6-row rings and one uniform draw (round 3's loop) this
+    seed learns, stays clean for ~1 300 iterations and then ends in violation bursts: 760 violations, last window 55 %
+    (profiles/round4_learning_vec4096_config4_controls.json; 1 587 with the share alone).  As shipped: none.  The reference's
+    one-env run of this command line has 0 violations on every seed it was run for."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
+    import learning_vec4096 as lv
+    r = lv.run(3, 16, 1650, config=4, precision="f16x3")
+    assert r["iterations"] >= 1650 and r["env_steps"] >= 1650 * N
+    worst = max(w["violation_rate"] for w in r["windows"])
+    assert r["violations"] <= 60 and worst <= 0.01, (r["violations"], worst)        # shipped: 0 violations
+    assert r["final_success_rate"] > 0.97 and r["first_window_with_90pct_success"]["iteration"] <= 300
+    assert r["offline_violations"] > 1000
