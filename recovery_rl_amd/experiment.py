@@ -406,8 +406,8 @@ def replay_capacities(cfg):
     --pos_fraction; `--keep_replay_size` keeps the rings as given."""
     cap, safe_cap = int(cfg.replay_size), int(cfg.safe_replay_size)
     n = int(getattr(cfg, "num_envs", 1))
-    if n <= 1 or getattr(cfg, "keep_replay_size", False):
-        return cap, safe_cap
+    if n <= 1 or getattr(cfg, "keep_replay_size", False) or cfg.num_steps <= min(cap, safe_cap):
+        return cap, safe_cap                 # (the reference's defaults, num_steps == both capacities, stay as they are)
     steps = int(min(cfg.num_steps, MAX_COVER_ROWS)) + 2 * n
     cap = max(cap, steps)
     safe = steps + int(cfg.num_unsafe_transitions)

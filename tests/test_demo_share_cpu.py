@@ -88,6 +88,8 @@ def test_buffers_cover_the_run_at_many_envs_only():
     assert cap == steps + 2 * n and safe == steps + 2 * n + 20000
     short = arg_utils.get_args(["--env-name", "navigation1", "--num_envs", "64", "--num_steps", "5000"])
     assert replay_capacities(short) == (1000000, 1000000)                 # a run shorter than the buffers: nothing to raise
+    default = arg_utils.get_args(["--env-name", "navigation1", "--num_envs", "4096"])
+    assert replay_capacities(default) == (1000000, 1000000)               # num_steps == capacities: the reference's defaults
     maze = arg_utils.get_args(["--env-name", "maze", "--num_envs", str(n), "--num_steps", str(steps), "--pos_fraction=0.3"])
     assert replay_capacities(maze) == (steps + 2 * n, 1 << 21)
     keep = arg_utils.get_args(["--env-name", "navigation2", "--num_envs", str(n), "--num_steps", str(steps), "--keep_replay_size"])
