@@ -254,3 +254,22 @@ def test_rrl_main_two_ranks_pack_consecutive_seeds(tmp_path):
             got = multi[str(first + k)]["vector_stats"]
             assert got[-1] == h[-1] and len(got) == len(h), (first + k, got[-1], h[-1])
     assert multi["4"]["vector_stats"][-1] != multi["6"]["vector_stats"][-1]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_default_legs_add_the_packed_leg():
+    """What the driver's scaling run issues (`bench.py --gpus N --steps K --warmup W`, legs on): at N > 1 the line carries a second
+    leg with S = 4 seeds packed per rank (`seed_pack_multi_gpu`) next to the one-seed-per-GPU headline.  Two gloo ranks on the
+    box's GPU, small envs."""
+    env = dict(os.environ, RRL_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--num_envs", "256", "--no_cpu_baseline", "--no_planner", "--min_seconds", "0.3"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 2 and r["config"]["seeds_per_gpu"] == 1
+    leg = r["seed_pack_multi_gpu"]
+    assert "error" not in leg, leg
+    assert leg["seeds_per_gpu"] == 4 and leg["seeds_total"] == 8 and leg["rank0_witness"]["seeds"] == [1, 2, 3, 4]
+    assert leg["aggregate_env_steps_per_s"] > r["value"]            # eight seeds on the device beat two
