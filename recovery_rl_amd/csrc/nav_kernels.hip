@@ -8,7 +8,6 @@
 // once per wave and pass.  Grid: <= 2048 workgroups of 256 threads, grid-stride.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <type_traits>
 
 #include "replay_device.hpp"
@@ -222,89 +221,11 @@ __global__ __launch_bounds__(kBlock) void nav_step4_kernel(StepArgs a) {
     rrl::advance_counter(a.counter_dev, a.counter_inc);
 }
 
-// Bandwidth-regime variant (n >= 2^19, n even; slower below 2^18): one thread steps TWO consecutive envs.  All loads of
-// both envs are issued before the first dependent f64 operation, the accesses are 16-byte vectors where the layout allows
-// (action, both observation arrays, the two positions; 8 bytes for reward and t, 2 for each mask array), and the reset
-// draws are shared per wave and pass.  Two rather than four envs per thread: 81 VGPRs instead of 115 (six waves per SIMD
-// instead of four) and no SGPR-spill traffic -- measured on the compact kernel, 193 vs 220 us at 2^24 envs without
-// resets.  The per-env arithmetic is the scalar kernel's, call for call, so the results are bit-identical.
-template <int KIND, bool EXT_NOISE>
-__global__ __launch_bounds__(kBlock) void nav_step2_kernel(StepArgs a) {
-    __shared__ uint32_t wave_rows[kBlock / 64][64];
-    __shared__ double2 wave_draws[kBlock / 64][64];
-    const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
-    const int64_t n2 = a.n >> 1, stride = int64_t(gridDim.x) * kBlock;
-    const int64_t n_pass = (n2 + stride - 1) / stride;     // uniform trip count: the reset lists need whole waves
-    for (int64_t pass = 0; pass < n_pass; ++pass) {
-        int64_t q = pass * stride + int64_t(blockIdx.x) * kBlock + threadIdx.x;
-        const bool live = q < n2;
-        if (!live) q = n2 - 1;                             // idle lanes shadow the last pair and store nothing
-        const int64_t i0 = q << 1;
-        double2 p[2], e[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) p[k] = a.pos[i0 + k];
-        const float4 a01 = reinterpret_cast<const float4*>(a.action)[q];
-        const int2 tv = reinterpret_cast<const int2*>(a.t)[q];
-        if constexpr (EXT_NOISE) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) e[k] = a.noise[i0 + k];
-        }
-        const float ax[2] = {a01.x, a01.z}, ay[2] = {a01.y, a01.w};
-        int32_t ti[2] = {tv.x, tv.y};
-        float2 nobs[2], obs[2];
-        float rew[2];
-        uint32_t dn2 = 0, cons2 = 0, succ2 = 0, epd2 = 0;
-        bool fin[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            double ex, ey;
-            if constexpr (EXT_NOISE) {
-                ex = e[k].x;
-                ey = e[k].y;
-            } else {
-                rrl::normal_at(a.seed, uint32_t(i0 + k), rrl::kStreamStep, ctr, ex, ey);
-            }
-            double nx, ny, cost;
-            rrl::nav_transition<KIND>(p[k].x, p[k].y, double(ax[k]), double(ay[k]), ex, ey, nx, ny, cost);
-            const bool cons = rrl::in_obstacle<KIND>(nx, ny);
-            const bool succ = cost > -4.0;
-            const bool dn = succ | cons;
-            ti[k] += 1;
-            const bool epd = dn | (ti[k] == a.horizon);
-            nobs[k] = make_float2(float(nx), float(ny));
-            rew[k] = float(cost);
-            dn2 |= uint32_t(dn) << (8 * k);
-            cons2 |= uint32_t(cons) << (8 * k);
-            succ2 |= uint32_t(succ) << (8 * k);
-            epd2 |= uint32_t(epd) << (8 * k);
-            fin[k] = live & epd & (a.auto_reset != 0);
-            p[k] = make_double2(nx, ny);
-        }
-        double w0[2], w1[2];
-        wave_reset_draws<2>(a.seed, ctr, i0, fin, w0, w1, wave_rows[threadIdx.x >> 6], wave_draws[threadIdx.x >> 6]);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (fin[k]) {
-                ti[k] = 0;
-                p[k] = make_double2(-50.0 + w0[k], 0.0 + w1[k]);     // START_STATE + randn(2), navigation1.py:92
-            }
-            obs[k] = make_float2(float(p[k].x), float(p[k].y));
-        }
-        if (!live) continue;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) a.pos[i0 + k] = p[k];
-        reinterpret_cast<float4*>(a.next_obs)[q] = make_float4(nobs[0].x, nobs[0].y, nobs[1].x, nobs[1].y);
-        if (a.obs) reinterpret_cast<float4*>(a.obs)[q] = make_float4(obs[0].x, obs[0].y, obs[1].x, obs[1].y);
-        reinterpret_cast<float2*>(a.reward)[q] = make_float2(rew[0], rew[1]);
-        reinterpret_cast<uint16_t*>(a.done)[q] = uint16_t(dn2);
-        reinterpret_cast<uint16_t*>(a.constraint)[q] = uint16_t(cons2);
-        reinterpret_cast<uint16_t*>(a.success)[q] = uint16_t(succ2);
-        if (a.ep_done) reinterpret_cast<uint16_t*>(a.ep_done)[q] = uint16_t(epd2);
-        reinterpret_cast<int2*>(a.t)[q] = make_int2(ti[0], ti[1]);
-    }
-    rrl::advance_counter(a.counter_dev, a.counter_inc);
-}
-
+// Bandwidth-regime variant (n >= 2^22, n even): one thread steps TWO consecutive envs.  All loads of both envs are issued before
+// the first dependent f64 operation, the accesses are 16-byte vectors where the layout allows (action, both observation arrays, the
+// two positions; 8 bytes for reward and t, 2 for each mask array).  Two rather than four envs per thread: 81 VGPRs instead of 115
+// (six waves per SIMD instead of four) and no SGPR-spill traffic.  The per-env arithmetic is the scalar kernel's, call for call, so
+// the results are bit-identical.
 // The two-env kernel with HOLD passes sharing one reset draw (see nav_step_compact_hold_kernel below for the scheme): a
 // pass stores next_obs, reward and the four flags at once and parks positions, step counts and finished flags in LDS;
 // after HOLD passes one trip through normal_at() serves every row the wave finished in them, and pos / t / obs go out.
@@ -980,23 +901,13 @@ int rrl_nav_step(int env_kind, int64_t n, double* pos, const float* action, cons
                       al(reward, 8) && al(t, 8) && al(done, 2) && al(constraint, 2) && al(success, 2) && al(ep_done, 2);
     if (vec2) {
         const dim3 grid(grid_for(n >> 1));
-        static const int hold = [] { const char* e = getenv("RRL_NAV_HOLD"); return e ? atoi(e) : 2; }();
-        if (hold == 2) {            // two passes share one reset draw (same scheme as the compact kernel)
-            if (env_kind == RRL_ENV_NAV1) {
-                if (noise) hipLaunchKernelGGL((nav_step2_hold_kernel<0, true, 2>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((nav_step2_hold_kernel<0, false, 2>), grid, block, 0, st, a);
-            } else {
-                if (noise) hipLaunchKernelGGL((nav_step2_hold_kernel<1, true, 2>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((nav_step2_hold_kernel<1, false, 2>), grid, block, 0, st, a);
-            }
-            return check_launch();
-        }
+        // two passes share one reset draw (same scheme as the compact kernel; the plain two-env kernel: 236 vs 225 us at 2^24)
         if (env_kind == RRL_ENV_NAV1) {
-            if (noise) hipLaunchKernelGGL((nav_step2_kernel<0, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((nav_step2_kernel<0, false>), grid, block, 0, st, a);
+            if (noise) hipLaunchKernelGGL((nav_step2_hold_kernel<0, true, 2>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((nav_step2_hold_kernel<0, false, 2>), grid, block, 0, st, a);
         } else {
-            if (noise) hipLaunchKernelGGL((nav_step2_kernel<1, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((nav_step2_kernel<1, false>), grid, block, 0, st, a);
+            if (noise) hipLaunchKernelGGL((nav_step2_hold_kernel<1, true, 2>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((nav_step2_hold_kernel<1, false, 2>), grid, block, 0, st, a);
         }
         return check_launch();
     }
@@ -1046,21 +957,18 @@ int rrl_nav_step_compact(int env_kind, int64_t n, double* pos, const float* acti
     const auto go = [&](auto kind, auto ext) {
         constexpr int K = decltype(kind)::value;
         constexpr bool E = decltype(ext)::value;
-        // envs per thread, measured at 2^24 envs in one process (profiles/nav_step_probe.py, RRL_NAV_V): without resets
+        // envs per thread, measured at 2^24 envs in one process (profiles/nav_step_probe.py): without resets
         // 1 and 2 run at 192 us, 4 at 220 us (115 VGPRs, 236 SGPR-spill reads per pass); with resets 241 / 231 / 236 us --
         // the once-per-wave reset draw batches 64 V envs, and at V = 1 every finished lane costs its wave a second chain.
         // Below 2^22 envs four per thread: 2^20 envs are then ONE round of 4 waves per SIMD (24.5 us; two per thread 34 us).
-        static const int v_env = [] { const char* e = getenv("RRL_NAV_V"); return e ? atoi(e) : 0; }();
-        const int v = v_env ? v_env : (n < (1 << 18) ? 1 : (n < (1 << 22) ? 4 : 2));
+        const int v = n < (1 << 18) ? 1 : (n < (1 << 22) ? 4 : 2);
         if (v == 1) {                 // also the latency regime: a short dependent chain per thread, resets inline
             hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 1>), dim3(grid_for(n)), block, 0, st, a);
         } else if (v == 2) {
             // passes that share one reset draw (parked in LDS): 1 -> 236 us, 2 -> 225 us, 3 -> 228 us, 4 -> 240 us at 2^24
-            // envs (the larger groups cost registers in the apply phase); RRL_NAV_HOLD=1 selects the plain kernel
-            static const int hold = [] { const char* e = getenv("RRL_NAV_HOLD"); return e ? atoi(e) : 2; }();
+            // envs (the larger groups cost registers in the apply phase)
             const dim3 grid2(grid_for((n + 1) >> 1));
-            if (hold == 2) hipLaunchKernelGGL((nav_step_compact_hold_kernel<K, E, 2>), grid2, block, 0, st, a);
-            else hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 2>), grid2, block, 0, st, a);
+            hipLaunchKernelGGL((nav_step_compact_hold_kernel<K, E, 2>), grid2, block, 0, st, a);
         } else {
             hipLaunchKernelGGL((nav_step_compact_kernel<K, E, 4>), dim3(grid_for((n + 3) >> 2)), block, 0, st, a);
         }
