@@ -725,7 +725,7 @@ CONFIG4_ARGV = ["--env-name", "navigation2", "--cuda", "--use_recovery", "--gamm
                 "--num_unsafe_transitions", "20000"]                       # configs[3]: scripts/navigation2.sh:14
 
 
-def run_config4_leg(device, precision, num_envs=NUM_ENVS, iters=30):
+def run_config4_leg(device, precision, num_envs=NUM_ENVS, iters=30, graph=True):
     """BASELINE configs[3] (Navigation2, 4096 envs, model-based recovery: PETS/CEM through rrl_plan_cost) with the gate
     the reference runs with -- Q_risk pre-trained for the default 10 000 steps on 20 000 offline transitions, ensemble
     pre-trained for 50 epochs (experiment.py:261-305) -- so that only the envs whose Q_risk exceeds eps_safe plan.
@@ -747,14 +747,22 @@ def run_config4_leg(device, precision, num_envs=NUM_ENVS, iters=30):
         loop.vector_step(do_update=False, random_actions=True)
     for _ in range(2):
         loop.vector_step(do_update=True, online_qrisk=True)
+    # the steady-state iteration in ONE hipGraph, as Experiment.run_vectorized replays it (MPC.act reads nothing on the host)
+    graph = bool(mpc.device_count and mpc.fused is not None and getattr(loop.agent, "fast", None) is not None) and graph
+    if graph:
+        loop.capture(online_qrisk=True, warmup=0)     # (two eager steady iterations above: the capture executes nothing)
+    step = loop.replay if graph else (lambda: loop.vector_step(do_update=True, online_qrisk=True))
     sizes = torch.zeros(iters, dtype=torch.int32, device=device)
     stats0 = loop.read_stats()
     torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for k in range(iters):
-        loop.vector_step(do_update=True, online_qrisk=True)
+        step()
         if mpc.last_count is not None:
             sizes[k:k + 1].copy_(mpc.last_count)
+    ev1.record()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     stats1 = loop.read_stats()
@@ -769,7 +777,16 @@ def run_config4_leg(device, precision, num_envs=NUM_ENVS, iters=30):
             "recovery_set_sizes": sizes, "planned_actions": sum(sizes),
             "planner_row_steps_per_s": row_steps / dt,
             "planner_TFLOPs_over_whole_iteration": row_steps * PLAN_FLOPS_PER_ROW_STEP / dt / 1e12,
-            "pretrain_seconds": pre_s, "graph": False,
+            "pretrain_seconds": pre_s, "graph": graph,
+            # the planner's algorithmic FLOPs over the WHOLE iteration's time (HIP events around the timed iterations on the
+            # launch stream): a lower bound of the planner kernel's own rate (the updates and the env step are in the time)
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "kernel": "plan_cost_kernel inside the lock-step iteration",
+                         "achieved": row_steps * PLAN_FLOPS_PER_ROW_STEP / (ev0.elapsed_time(ev1) * 1e-3) / 1e12,
+                         "peak": F32_MFMA_PEAK_TF if precision == "f32" else F16_MFMA_PEAK_TF,
+                         "frac": (row_steps * PLAN_FLOPS_PER_ROW_STEP * (1.0 if precision == "f32" else 3.0 * (2 * 2 * 256 * 256 + 2 * 2 * 200 * 200) / PLAN_FLOPS_PER_ROW_STEP)
+                                  / (ev0.elapsed_time(ev1) * 1e-3) / 1e12) / (F32_MFMA_PEAK_TF if precision == "f32" else F16_MFMA_PEAK_TF),
+                         "note": "f32: algorithmic FLOPs / f32 MFMA peak; f16x3: executed f16 products (3 per hidden-layer product) / "
+                                 "f16 MFMA peak; time = the whole iteration"},
             "host_syncs_per_iteration": 0 if mpc.device_count else 1}
 
 

@@ -749,7 +749,7 @@ class Experiment:
         ep_file = open(osp.join(self.logdir, "episode_stats.bin"), "wb")   # append-only, O(new) per log
         ep_file.write(episodes[0].tobytes())
         try:
-            captured_gate = None
+            captured_gate, warm = None, 0
             mb = uses_mb_recovery(cfg)
             # model-based recovery: the ensemble is re-fitted on the transitions gathered since the last
             # fit every recovery_policy_update_freq * horizon iterations (the reference re-fits every
@@ -758,26 +758,37 @@ class Experiment:
             mb_new = mb_resume
             mb_every = cfg.recovery_policy_update_freq * self.env._max_episode_steps
             # env_shard: the updates contain RCCL all-reduces, launched eagerly (not captured)
-            graph_ok = (cfg.target_update_interval == 1 and not cfg.nu_schedule and not mb and not self.env_shard)
+            # model-based recovery: capturable when the controller counts its planning set on the device (no host read in
+            # MPC.act: padded rrl_*_n launches) -- the re-fit and the per-iteration copies for it stay outside the graph
+            rp = self.recovery_policy
+            mb_graph = (not mb) or (rp is not None and rp.fused is not None and rp.device_count and rp.mb_dynamics == "model"
+                                    and rp.has_been_trained and rp.prev_sol.shape[0] == n
+                                    and getattr(self.agent, "fast", None) is not None)
+            graph_ok = (cfg.target_update_interval == 1 and not cfg.nu_schedule and mb_graph and not self.env_shard)
             while True:
                 have_batch = len(self.memory) > cfg.batch_size
                 random_actions = cfg.start_steps > loop.total_numsteps
                 gate = self.online_qrisk_enabled() if uses_constraint_buffer(cfg) else False
                 steady = have_batch and not random_actions and graph_ok
+                replay = steady
                 if steady and (loop.graph is None or captured_gate != gate):
-                    if info is not None:
-                        for _ in range(3):           # the capture's warm-up iterations are real ones: record them too
-                            info.before_step(loop.obs)
-                            loop.vector_step(True, False, gate)
-                            info.after_step(self.env, loop._last_real_action, loop._last_recovery)
-                            it += 1
-                        it += loop.capture(online_qrisk=gate, warmup=0)
+                    if info is not None or mb:
+                        # what an iteration leaves behind is collected per iteration (the per-step info stream; the
+                        # transitions of the online re-fit): the capture's warm-up iterations run through this loop's own
+                        # body -- three eager steady iterations -- and the capture itself executes nothing
+                        if captured_gate != gate:
+                            loop.graph, captured_gate, warm = None, gate, 0
+                        if warm < 3:
+                            warm += 1
+                            replay = False
+                        else:
+                            loop.capture(online_qrisk=gate, warmup=0)
                     else:
                         it += loop.capture(online_qrisk=gate)
-                    captured_gate = gate
+                        captured_gate = gate
                 if info is not None:
                     info.before_step(loop.obs)
-                if steady:
+                if replay:
                     loop.replay()
                 else:
                     loop.vector_step(do_update=have_batch, random_actions=random_actions, online_qrisk=gate)

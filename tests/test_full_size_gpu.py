@@ -56,6 +56,7 @@ def test_config4_navigation2_model_based_recovery_at_4096_envs(tmp_path, precisi
     assert int(exp.memory.state[3].item()) == 0 and int(exp.recovery_memory.state[3].item()) == 0
     assert mpc.fused is not None and mpc.fused.f16x3 == (precision == "f16x3") and mpc.has_been_trained
     assert mpc.device_count and mpc.last_count is not None              # planning set counted on the device
+    assert exp.loop.graph is not None                                   # ... so the model-based iteration is ONE hipGraph too
     # the gate is the pre-trained Q_risk: some, not all, env-steps are under the recovery controller
     assert 0 < last["recovery_steps"] < 0.6 * last["env_steps"], last
     per_log = np.diff([0] + [h["recovery_steps"] for h in hist])
