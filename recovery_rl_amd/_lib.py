@@ -20,6 +20,16 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                "-Wno-bitwise-instead-of-logical"]
 
+# Per-source additions.  The env translation units switch LLVM's atomic optimiser off: it rewrites every same-address
+# atomicAdd as "first active lane adds, v_readfirstlane the result" -- and the readfirstlane puts an s_waitcnt vmcnt(0)
+# right behind the atomic, so the cursor ticket and the episode table's slot reservation of step_push_kernel (single-lane
+# returning atomics whose ~0.7 us round trip is meant to run under the env step) were waited for on the spot.  Every atomic in
+# those sources is issued by one lane per wave already.
+SOURCE_FLAGS = {
+    "nav_kernels.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+    "maze_kernels.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+}
+
 EXPORTS = [
     "rrl_abi_version", "rrl_last_hip_error", "rrl_counter_add",
     "rrl_nav_step", "rrl_nav_step_compact", "rrl_nav_reset", "rrl_nav_rollout", "rrl_nav_offline_rollouts",
@@ -79,7 +89,7 @@ def build(force=False, verbose=False, jobs=None):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
             return obj
-        cmd = [hipcc] + compile_flags + ["-I", INCLUDE, "-c", "-o", obj, src]
+        cmd = [hipcc] + compile_flags + SOURCE_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -211,12 +211,7 @@ int rrl_maze_step_push(int64_t n, double* pos, int32_t* t, float* obs, const flo
     if (rc != RRL_OK || n == 0) return rc;
     // latency regime: the reset draw (one Philox call + the contact test of the candidate; the start region is clear of
     // the walls, so the rejection loop runs once) beside the move instead of after it, and the early cursor ticket
-    if (n <= 16384)
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv, true>), dim3(grid_for(n)), dim3(kBlock), 0,
-                           (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv>), dim3(grid_for(n)), dim3(kBlock), 0,
-                           (hipStream_t)stream, p);
+    rrl_step::launch<MazeEnv>(p, n, (hipStream_t)stream);
     return check_launch();
 }
 
@@ -237,12 +232,7 @@ int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, co
     if (rc != RRL_OK || n == 0) return rc;
     // latency regime: the reset draw (one Philox call + the contact test of the candidate; the start region is clear of
     // the walls, so the rejection loop runs once) beside the move instead of after it, and the early cursor ticket
-    if (n <= 16384)
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv, true>), dim3(grid_for(n)), dim3(kBlock), 0,
-                           (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv>), dim3(grid_for(n)), dim3(kBlock), 0,
-                           (hipStream_t)stream, p);
+    rrl_step::launch<MazeEnv>(p, n, (hipStream_t)stream);
     return check_launch();
 }
 
@@ -264,24 +254,22 @@ int rrl_maze_step_push_packed(int S, const rrl_step_push_t* a, void* stream) {
         rrl_pack::Idx ix;
         ix.S = S;
         ix.first[0] = 0;
-        const bool small = a[0].n <= 16384;
+        const int regime = rrl_step::regime_of(a[0].n);
         for (int s = 0; s < S; ++s) {
             const int rc = rrl_step::fill_args(ps[s], &a[s]);
             if (rc != RRL_OK) return rc;
-            if (a[s].n <= 0 || (a[s].n <= 16384) != small) return RRL_EINVAL;
-            ix.first[s + 1] = ix.first[s] + grid_for(a[s].n);
+            if (a[s].n <= 0 || rrl_step::regime_of(a[s].n) != regime) return RRL_EINVAL;
+            ix.first[s + 1] = ix.first[s] + rrl_step::grid_cover(a[s].n);
         }
         for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
         plan = rrl_pack::store(key, ps.data(), sizeof(rrl_step::StepPushArgs) * S, st);
         if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
-        plan->i0 = small;
+        plan->i0 = regime;
     }
     const auto* dev = (const rrl_step::StepPushArgs*)plan->dev;
-    const dim3 grid(plan->grid), block(kBlock);
-    if (plan->i0) hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<MazeEnv, true>), grid, block, 0, st, dev, plan->ix);
-    else hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<MazeEnv>), grid, block, 0, st, dev, plan->ix);
+    rrl_step::launch_pack<MazeEnv>(dev, plan->ix, plan->grid, plan->i0, st);
     return check_launch();
 }
 
@@ -289,12 +277,7 @@ int rrl_maze_step_push_x(const rrl_step_push_t* a, void* stream) {
     rrl_step::StepPushArgs p;
     const int rc = rrl_step::fill_args(p, a);
     if (rc != RRL_OK || a->n == 0) return rc;
-    if (a->n <= 16384)
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv, true>), dim3(grid_for(a->n)), dim3(kBlock), 0,
-                           (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((rrl_step::step_push_kernel<MazeEnv>), dim3(grid_for(a->n)), dim3(kBlock), 0,
-                           (hipStream_t)stream, p);
+    rrl_step::launch<MazeEnv>(p, a->n, (hipStream_t)stream);
     return check_launch();
 }
 

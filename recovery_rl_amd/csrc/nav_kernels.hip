@@ -1048,15 +1048,8 @@ int rrl_nav_offline(int env_kind, int64_t num_transitions, uint64_t seed, float*
 }
 
 static int nav_step_push_launch(int env_kind, const rrl_step::StepPushArgs& p, int64_t n, void* stream) {
-    const dim3 grid(grid_for(n)), block(kBlock);
-    hipStream_t st = (hipStream_t)stream;
-    if (n <= 16384) {      // a quarter of the SIMDs busy at most: latency-bound, the reset draw runs beside the step draw (at 65536 envs it costs 13 -> 17 us)
-        if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<0>, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<1>, true>), grid, block, 0, st, p);
-    } else {
-        if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<0>>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((rrl_step::step_push_kernel<NavEnv<1>>), grid, block, 0, st, p);
-    }
+    if (env_kind == RRL_ENV_NAV1) rrl_step::launch<NavEnv<0>>(p, n, (hipStream_t)stream);
+    else rrl_step::launch<NavEnv<1>>(p, n, (hipStream_t)stream);
     return check_launch();
 }
 
@@ -1116,29 +1109,23 @@ int rrl_nav_step_push_packed(int S, int env_kind, const rrl_step_push_t* a, void
         rrl_pack::Idx ix;
         ix.S = S;
         ix.first[0] = 0;
-        const bool small = a[0].n <= 16384;
+        const int regime = rrl_step::regime_of(a[0].n);
         for (int s = 0; s < S; ++s) {
             const int rc = rrl_step::fill_args(ps[s], &a[s]);
             if (rc != RRL_OK) return rc;
-            if (a[s].n <= 0 || (a[s].n <= 16384) != small) return RRL_EINVAL;
-            ix.first[s + 1] = ix.first[s] + grid_for(a[s].n);
+            if (a[s].n <= 0 || rrl_step::regime_of(a[s].n) != regime) return RRL_EINVAL;
+            ix.first[s + 1] = ix.first[s] + rrl_step::grid_cover(a[s].n);
         }
         for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
         plan = rrl_pack::store(key, ps.data(), sizeof(rrl_step::StepPushArgs) * S, st);
         if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
-        plan->i0 = small;
+        plan->i0 = regime;
     }
     const auto* dev = (const rrl_step::StepPushArgs*)plan->dev;
-    const dim3 grid(plan->grid), block(kBlock);
-    if (plan->i0) {
-        if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<0>, true>), grid, block, 0, st, dev, plan->ix);
-        else hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<1>, true>), grid, block, 0, st, dev, plan->ix);
-    } else {
-        if (env_kind == RRL_ENV_NAV1) hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<0>>), grid, block, 0, st, dev, plan->ix);
-        else hipLaunchKernelGGL((rrl_step::step_push_pack_kernel<NavEnv<1>>), grid, block, 0, st, dev, plan->ix);
-    }
+    if (env_kind == RRL_ENV_NAV1) rrl_step::launch_pack<NavEnv<0>>(dev, plan->ix, plan->grid, plan->i0, st);
+    else rrl_step::launch_pack<NavEnv<1>>(dev, plan->ix, plan->grid, plan->i0, st);
     return check_launch();
 }
 

@@ -75,13 +75,18 @@ __device__ __forceinline__ void wave_count_add(int32_t* chunk_cnt, int32_t* supe
     }
 }
 
-// write one row into `slot`; keeps both levels of positive counts exact (pos_idx, replay_memory.py:50).
-// Call from converged code (all active lanes of the wave reach it together).
-__device__ __forceinline__ void store_values(const rrl_replay_t& rb, int64_t slot, int64_t size, float2 s,
+// 1 when `slot` holds a positive row now (only buffers that keep positive counts look): the load a push has to wait for
+// before it can update the counts -- callers request it early
+__device__ __forceinline__ int was_positive(const rrl_replay_t& rb, int64_t slot, int64_t size) {
+    return (rb.pos_cnt && slot < size) ? int(rb.r[slot] != 0.0f) : 0;
+}
+
+// write one row into `slot` (`was` = was_positive(rb, slot, size)); keeps both levels of positive counts exact (pos_idx,
+// replay_memory.py:50).  Call from converged code (all active lanes of the wave reach it together).
+__device__ __forceinline__ void store_values(const rrl_replay_t& rb, int64_t slot, int was, float2 s,
                                              float2 a, float r, float2 s2, float m, int* block_acc = nullptr,
                                              int s0 = 0) {
     if (rb.pos_cnt) {
-        const int was = (slot < size) ? int(rb.r[slot] != 0.0f) : 0;
         const int delta = int(r != 0.0f) - was;
         wave_count_add(rb.pos_cnt, rb.pos_cnt + super_base(rb.cap), chunk_masks(rb), int(slot / kChunk),
                        int(slot % kChunk), delta, block_acc, s0);

@@ -36,7 +36,7 @@ struct Rows {
 
 __device__ __forceinline__ void store_row(const rrl_replay_t& rb, int64_t slot, int64_t size,
                                           const Rows& in, int64_t i) {
-    rrl_replay::store_values(rb, slot, size, in.s[i], in.a[i], in.r[i], in.s2[i], in.m[i]);
+    rrl_replay::store_values(rb, slot, rrl_replay::was_positive(rb, slot, size), in.s[i], in.a[i], in.r[i], in.s2[i], in.m[i]);
 }
 
 __global__ __launch_bounds__(kBlock) void push_kernel(rrl_replay_t rb, int64_t n, Rows in) {

@@ -83,8 +83,20 @@ struct StepPushArgs {
     int32_t *log_viol, *log_rec;
 };
 
-// Episode counters: every lane keeps its own tallies over the grid-stride loop; they are added up per wave
-// (ballot-free shuffles), then per workgroup in LDS, and ONE atomic per workgroup and counter reaches memory.
+// Workgroup size of the two variants.  Latency regime (SPECULATE, n <= 16384): 256, up to 64 workgroups.  Bandwidth regime: 1024
+// -- every workgroup ends with up to ten atomics on the SAME few addresses (seven counters, two reward sums, the episode
+// table's slot counter), and same-address atomics retire one per ~9 ns whatever their number in flight: with 256-thread
+// workgroups a 2^20-env launch spent 37 us of its 65 on the cursor ticket alone (round4_step_push_isa.txt).
+// Three launch shapes, by size (regime_of): 0 = latency variant (SPECULATE, 256 threads, ticket); 1 = bandwidth variant with
+// 256 threads (a 65536-env launch has one wave per SIMD: as 64 workgroups of 1024 it would leave three quarters of the CUs
+// idle, 11 -> 16 us); 2 = bandwidth variant with 1024 threads.
+constexpr int64_t kSmall = 16384;     // up to here the latency variant: a quarter of the SIMDs busy at most, the reset draw runs beside the step draw (at 65536 envs it costs 13 -> 17 us)
+constexpr int64_t kMid = 262144;      // up to here one 256-thread workgroup per CU and SIMD slot: 1024 workgroups
+inline int regime_of(int64_t n) { return n <= kSmall ? 0 : (n <= kMid ? 1 : 2); }
+__host__ __device__ constexpr int block_of(int regime) { return regime == 2 ? 1024 : rrl_host::kBlock; }
+
+// Episode counters: counted per wave (one ballot + popcount each), added up per workgroup in LDS, and ONE atomic per
+// workgroup and non-zero counter reaches memory.
 // (One atomic per wave and iteration serialised 115 k atomics on 7 addresses at 2^20 envs: 719 us.)
 constexpr int kCounters = 7;
 
@@ -103,17 +115,30 @@ __device__ __forceinline__ double row16_sum_f64(double v) {
     return v;
 }
 
+// {position, size} of both rings, the RNG tick and the episode table's iteration count after this launch's n rows: by the
+// thread that knows every workgroup has read the old values
+__device__ __forceinline__ void advance_cursors(const StepPushArgs& p, int64_t mpos, int64_t msize, int64_t rpos, int64_t rsize,
+                                                uint64_t ctr, int64_t log_iteration) {
+    const StepArgs& a = p.step;
+    rrl_replay::set_ring(p.memory, mpos, msize, a.n);
+    if (p.use_recovery_memory) rrl_replay::set_ring(p.recovery_memory, rpos, rsize, a.n);
+    if (a.counter_dev && a.counter_inc) a.counter_dev[0] = ctr - a.counter + a.counter_inc;
+    if (p.log_state) p.log_state[1] = log_iteration + 1;
+}
+
 // SPECULATE (latency regime, one pass per thread and one wave per SIMD): the reset draw does not depend on the step, so it
 // is evaluated next to the step's own draw -- two independent Philox + Box-Muller chains interleaved by the scheduler --
 // instead of after it for the lanes whose episode ended (at the bench's termination rate that is every wave: a second
 // ~1 us dependent chain).  Same function, same arguments, same bits; in the bandwidth regime it would be +70 % VALU work.
 // !SPECULATE (bandwidth regime): the second level of the safety buffer's positive counts is summed per workgroup and pass
 // in LDS (one atomic per workgroup and super-chunk instead of one per wave: 64 waves share a super-chunk's counter).
-template <class ENV, bool SPECULATE>
+template <class ENV, bool SPECULATE, int BLOCK>
 __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsigned blk, const unsigned n_blk) {
-    constexpr int kBlock = rrl_host::kBlock;
+    constexpr int kBlock = BLOCK;
     constexpr bool kBlockSuper = !SPECULATE;
     __shared__ int super_acc[2];
+    __shared__ int log_cnt[kBlock / 64];
+    __shared__ long long log_base;
     const bool counts = p.use_recovery_memory && p.recovery_memory.pos_cnt != nullptr;
     if (kBlockSuper) {
         if (threadIdx.x < 2) super_acc[threadIdx.x] = 0;
@@ -128,66 +153,34 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
     int64_t rpos = 0, rsize = 0;
     if (p.use_recovery_memory) { rpos = p.recovery_memory.state[0]; rsize = p.recovery_memory.state[1]; }
     const int64_t log_iteration = p.log_state ? p.log_state[1] : 0;      // read before the ticket, like the cursors
-    // ONE ticket for the three device-side cursors (both replay rings and the RNG tick): a returning device-scope atomic
-    // is a ~0.7 us round trip, three in a row were a sixth of this kernel.  The workgroup that draws the last ticket knows
-    // that every workgroup has read the cursors, which is all their update has to wait for.  In the latency regime (a few
-    // workgroups) it is drawn right after the cursors are read and its value is looked at when the workgroup is done, so
-    // the round trip runs under the env step; with thousands of workgroups that would be a burst of atomics on one
-    // address at launch (+8 us at 2^20 envs) -- there it is drawn at the end, where the workgroups arrive spread out.
     unsigned long long ticket = ~0ULL;
-    const auto draw_ticket = [&]() {
-        if (threadIdx.x == 0)
-        {
-            // the cursor loads have RETURNED before the ticket is issued (s_waitcnt; "memory": the compiler keeps the order
-            // too).  Not a release operation: at agent scope that is an L2 write-back per workgroup -- 50 -> 150 us for the
-            // 4096 workgroups of a 2^20-env launch -- and nothing written here has to be visible before the kernel ends.
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            ticket = __hip_atomic_fetch_add((unsigned long long*)&p.memory.state[2], 1ULL, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    const auto advance_cursors = [&]() {
-        if (threadIdx.x == 0 && ticket == n_blk - 1) {
-            p.memory.state[2] = 0;
-            rrl_replay::set_ring(p.memory, mpos, msize, a.n);
-            if (p.use_recovery_memory) rrl_replay::set_ring(p.recovery_memory, rpos, rsize, a.n);
-            if (a.counter_dev && a.counter_inc) a.counter_dev[0] = ctr - a.counter + a.counter_inc;
-            if (p.log_state) p.log_state[1] = log_iteration + 1;
-        }
-    };
-    if constexpr (SPECULATE) {
-        __syncthreads();            // every thread of this workgroup holds its copies of the cursors
-        draw_ticket();
-    }
     double rsum = 0.0, retsum = 0.0;
     unsigned cnt[kCounters] = {0, 0, 0, 0, 0, 0, 0};
-    const int64_t stride = int64_t(n_blk) * kBlock;
-    const int64_t n_iter = (a.n + stride - 1) / stride;   // uniform trip count: ballots need whole waves
-    for (int64_t it = 0; it < n_iter; ++it) {
-        const int64_t i = it * stride + int64_t(blk) * kBlock + threadIdx.x;
+    // ONE pass: the launch covers its envs (grid_cover), workgroup blk steps envs [256 blk, 256 blk + 256).  No grid-stride loop:
+    // around a loop the compiler keeps every loop-invariant address expression of the ~35 arrays, plus an induction
+    // pointer per array, in scalar registers -- 340 SGPRs spilled into vector lanes, a fifth of the kernel's instructions
+    // v_readlane / v_writelane, 113 VGPRs; without it 43-90 spills and 63-82 VGPRs (profiles/round4_step_push_isa.txt).
+    {
+        const int64_t off = int64_t(blk) * kBlock;
+        const int64_t i = off + threadIdx.x;
         const bool live = i < a.n;
-        int s0 = 0, s1 = 0;       // super-chunks of the workgroup's first and last safety-buffer slot of this pass
-        // the two workgroup sums cover a pass whose 256 consecutive slots touch at most two super-chunks: always, unless
-        // the pass wraps around a ring whose capacity is not a multiple of the super-chunk (then it can touch the last
-        // two super-chunks AND super-chunk 0): that pass sends its waves' nets straight to memory instead
-        bool block_sums = false;
-        if (kBlockSuper && counts) {
-            const int64_t cap = p.recovery_memory.cap;
-            const int64_t off = it * stride + int64_t(blk) * kBlock;
-            const int64_t first = rrl_replay::ring_slot(p.recovery_memory, rpos, off);
-            s0 = int(first / rrl_replay::kSuper);
-            s1 = int(rrl_replay::ring_slot(p.recovery_memory, rpos, off + kBlock - 1) / rrl_replay::kSuper);
-            block_sums = first + kBlock <= cap ||
-                         (cap % rrl_replay::kSuper == 0 && p.recovery_memory.pinned % rrl_replay::kSuper == 0);
-        }
         bool cons = false, succ = false, epd = false, rec = false;
         float log_rew = 0.f;
-        // per-env accumulators (running return; the episode table's four): requested with the first loads of the pass -- behind
-        // the replay stores the compiler would have to keep them (it cannot prove they do not alias), i.e. behind the whole
-        // Philox / Box-Muller chain
+        unsigned long long log_bal = 0;     // latency variant: finished-episode votes of this wave and the leader's reservation
+        long long log_base_raw = 0;
+        // EVERY per-env input is requested here, before anything waits for the cursors: the per-env accumulators (running
+        // return; the episode table's four), position, step count, the task action, the gate's partial sums and the recovery
+        // head's.  (Behind the ticket they queued up behind the cursor round trip in wave 0 of every workgroup; behind the
+        // replay stores the compiler has to keep them there: it cannot prove they do not alias.)
         float ep_rew_in = 0.f;
         double lg_ret = 0.0;
         int lg_len = 0, lg_viol = 0, lg_rec = 0;
+        double2 pp = make_double2(0.0, 0.0);
+        float2 task = make_float2(0.f, 0.f), act_in = task, ra_in = task, obs_in = task;
+        float zu[4] = {0.f, 0.f, 0.f, 0.f}, zw[4] = {0.f, 0.f, 0.f, 0.f}, hh[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float he[2] = {0.f, 0.f};
+        int32_t t_in = 0;
+        bool rec_in = false;
         if (live) {
             ep_rew_in = p.ep_reward[i];
             if (p.log_state) {
@@ -196,42 +189,103 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
                 lg_viol = p.log_viol[i];
                 lg_rec = p.log_rec[i];
             }
-            const double2 pp = a.pos[i];
-            const float2 task = *reinterpret_cast<const float2*>(p.task_action + i * p.ld_task);
-            float2 act;
+            pp = a.pos[i];
+            task = *reinterpret_cast<const float2*>(p.task_action + i * p.ld_task);
             if (p.sel_z) {
-                // up to four partial sums, all loads issued together, added in the fixed order of the sum kernel
+                // up to four partial sums, all loads issued together
                 const int np = p.sel_np;
                 const long long ps = p.sel_ps;
                 const float* zp = p.sel_z + i;
-                const float u0 = zp[0], u1 = zp[np > 1 ? ps : 0], u2 = zp[np > 2 ? 2 * ps : 0], u3 = zp[np > 3 ? 3 * ps : 0];
-                const float w0 = zp[a.n], w1 = zp[(np > 1 ? ps : 0) + a.n], w2 = zp[(np > 2 ? 2 * ps : 0) + a.n],
-                            w3 = zp[(np > 3 ? 3 * ps : 0) + a.n];
-                float z0 = u0, z1 = w0;
-                z0 = np > 1 ? z0 + u1 : z0; z1 = np > 1 ? z1 + w1 : z1;
-                z0 = np > 2 ? z0 + u2 : z0; z1 = np > 2 ? z1 + w2 : z1;
-                z0 = np > 3 ? z0 + u3 : z0; z1 = np > 3 ? z1 + w3 : z1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    zu[k] = zp[np > k ? k * ps : 0];
+                    zw[k] = zp[(np > k ? k * ps : 0) + a.n];
+                }
+                if (p.sel_rec_action) {
+                    ra_in = p.sel_rec_action[i];
+                } else {
+                    const rrl_policy_head_t& hd = p.sel_rec_head;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float* hp = hd.head + 2 * i + j;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) hh[j][k] = hp[hd.n_part > k ? k * hd.part_stride : 0];
+                        he[j] = hd.eps ? hd.eps[2 * i + j] : 0.f;
+                    }
+                }
+            } else {
+                act_in = a.action[i];
+                rec_in = p.recovery ? p.recovery[i] != 0 : false;
+            }
+            // compact layout: the observation IS float(pos) (that is what this kernel and the resets store), so the 8-byte
+            // read is dropped, and the step count comes out of the status word
+            if (a.status) {
+                t_in = int32_t(a.status[i] & 0xfffu);
+            } else {
+                t_in = a.t[i];
+                obs_in = a.obs[i];
+            }
+        }
+        // Latency regime: ONE ticket for the three device-side cursors (both replay rings and the RNG tick): a returning
+        // device-scope atomic is a ~0.7 us round trip, three in a row were a sixth of this kernel.  The workgroup that draws
+        // the last ticket knows that every workgroup has read the cursors, which is all their update has to wait for.  It is
+        // drawn as soon as the cursors have arrived and its value is looked at when the workgroup is done, so the round trip
+        // runs under the env step.  Bandwidth regime: no ticket (thousands of returning atomics on one address: 9 ns each,
+        // serialised) -- the cursors are advanced by advance_cursors_kernel, a one-thread launch behind this one.
+        if constexpr (SPECULATE) {
+            __syncthreads();            // every wave of this workgroup has requested its copies of the cursors
+            if (threadIdx.x == 0) {
+                // the cursor loads have RETURNED before the ticket is issued (s_waitcnt; "memory": the compiler keeps the
+                // order too).  Not a release operation: at agent scope that is an L2 write-back per workgroup, and nothing
+                // written here has to be visible before the kernel ends.
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                ticket = __hip_atomic_fetch_add((unsigned long long*)&p.memory.state[2], 1ULL, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        int s0 = 0, s1 = 0;       // super-chunks of the workgroup's first and last safety-buffer slot of this pass
+        // the two workgroup sums cover a pass whose consecutive slots touch at most two super-chunks: always, unless
+        // the pass wraps around a ring whose capacity is not a multiple of the super-chunk (then it can touch the last
+        // two super-chunks AND super-chunk 0): that pass sends its waves' nets straight to memory instead
+        bool block_sums = false;
+        if (kBlockSuper && counts) {
+            const int64_t cap = p.recovery_memory.cap;
+            const int64_t first = rrl_replay::ring_slot(p.recovery_memory, rpos, off);
+            s0 = int(first / rrl_replay::kSuper);
+            s1 = int(rrl_replay::ring_slot(p.recovery_memory, rpos, off + kBlock - 1) / rrl_replay::kSuper);
+            block_sums = first + kBlock <= cap ||
+                         (cap % rrl_replay::kSuper == 0 && p.recovery_memory.pinned % rrl_replay::kSuper == 0);
+        }
+        if (live) {
+            // the rows this env overwrites: what the positive counts lose (replay_device.hpp), requested before the step
+            const int64_t mslot = rrl_replay::ring_slot(p.memory, mpos, i);
+            const int64_t rslot = p.use_recovery_memory ? rrl_replay::ring_slot(p.recovery_memory, rpos, i) : 0;
+            const int mwas = rrl_replay::was_positive(p.memory, mslot, msize);
+            const int rwas = p.use_recovery_memory ? rrl_replay::was_positive(p.recovery_memory, rslot, rsize) : 0;
+            float2 act;
+            if (p.sel_z) {
+                // the partial sums added in the fixed order of the sum kernel
+                const int np = p.sel_np;
+                float z0 = zu[0], z1 = zw[0];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    z0 = np > k ? z0 + zu[k] : z0;
+                    z1 = np > k ? z1 + zw[k] : z1;
+                }
                 const float q0 = 1.f / (1.f + expf(-z0)), q1 = 1.f / (1.f + expf(-z1));
                 rec = fmaxf(q0, q1) > p.sel_eps;
-                float2 ra;
-                if (p.sel_rec_action) {
-                    ra = p.sel_rec_action[i];
-                } else {
+                float2 ra = ra_in;
+                if (!p.sel_rec_action) {
                     const rrl_policy_head_t& hd = p.sel_rec_head;
                     float v[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const float* hp = hd.head + 2 * i + j;
                         const int hn = hd.n_part;
-                        const float h0 = hp[0], h1 = hp[hn > 1 ? hd.part_stride : 0], h2 = hp[hn > 2 ? 2 * hd.part_stride : 0],
-                                    h3 = hp[hn > 3 ? 3 * hd.part_stride : 0];
-                        float raw = h0;
-                        raw = hn > 1 ? raw + h1 : raw;
-                        raw = hn > 2 ? raw + h2 : raw;
-                        raw = hn > 3 ? raw + h3 : raw;
+                        float raw = hh[j][0];
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) raw = hn > k ? raw + hh[j][k] : raw;
                         const float mean = tanhf(raw) * hd.scale[j] + hd.bias[j];
-                        const float e = hd.eps ? hd.eps[2 * i + j] : 0.f;
-                        v[j] = mean + expf(fmaxf(hd.log_std[j], hd.min_log_std)) * e;
+                        v[j] = mean + expf(fmaxf(hd.log_std[j], hd.min_log_std)) * he[j];
                     }
                     ra = make_float2(v[0], v[1]);
                 }
@@ -239,13 +293,11 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
                 p.sel_real_out[i] = act;
                 p.sel_recovery_out[i] = uint8_t(rec);
             } else {
-                act = a.action[i];
-                rec = p.recovery ? p.recovery[i] != 0 : false;
+                act = act_in;
+                rec = rec_in;
             }
-            // compact layout: the observation IS float(pos) (that is what this kernel and the resets store), so the 8-byte
-            // read is dropped, and the step count comes out of the status word
-            const float2 prev = a.status ? make_float2(float(pp.x), float(pp.y)) : a.obs[i];
-            int32_t ti = a.status ? int32_t(a.status[i] & 0xfffu) : a.t[i];
+            const float2 prev = a.status ? make_float2(float(pp.x), float(pp.y)) : obs_in;
+            int32_t ti = t_in;
             ti += 1;
             double rx = 0.0, ry = 0.0;
             if constexpr (SPECULATE) {
@@ -257,6 +309,17 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             succ = out.success;
             const bool dn = out.done;
             epd = dn | (ti == a.horizon);
+            if constexpr (SPECULATE) {
+                // the episode table's slots for this wave's finished episodes: ONE returning atomic per wave, requested as
+                // soon as the outcomes are known and looked at after the replay stores and the count maintenance (its ~0.7 us
+                // round trip used to sit at the end of the kernel).  Inside the live branch: lanes past n would vote 0 anyway.
+                if (p.log_state) {
+                    log_bal = __ballot(epd);
+                    if (log_bal && (threadIdx.x & 63) == __ffsll((long long)log_bal) - 1)
+                        log_base_raw = (long long)atomicAdd((unsigned long long*)&p.log_state[0],
+                                                            (unsigned long long)__popcll(log_bal));
+                }
+            }
             const float2 nobs = make_float2(float(nx), float(ny));
             const float rew = out.reward;
             // per-env outputs of the step for callers that read them (the episode log, the online ensemble re-fit): the
@@ -271,10 +334,10 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             const float mask = dn ? 0.0f : 1.0f;
             const float prew = rew - (cons ? p.reward_penalty : 0.0f);
             const float2 stored = p.push_real_action ? act : task;
-            rrl_replay::store_values(p.memory, rrl_replay::ring_slot(p.memory, mpos, i), msize, prev, stored, prew, nobs, mask);
+            rrl_replay::store_values(p.memory, mslot, mwas, prev, stored, prew, nobs, mask);
             if (p.use_recovery_memory)
-                rrl_replay::store_values(p.recovery_memory, rrl_replay::ring_slot(p.recovery_memory, rpos, i), rsize, prev, act,
-                                         cons ? 1.0f : 0.0f, nobs, mask, block_sums ? super_acc : nullptr, s0);
+                rrl_replay::store_values(p.recovery_memory, rslot, rwas, prev, act, cons ? 1.0f : 0.0f, nobs, mask,
+                                         block_sums ? super_acc : nullptr, s0);
             // episode accounting
             log_rew = rew;
             const float er = ep_rew_in + rew;
@@ -297,8 +360,7 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             a.obs[i] = make_float2(float(nx), float(ny));
         }
         if (p.log_state) {
-            // episode_log_kernel (log_kernels.hip) for this lane, fed from registers; ONE atomic per wave reserves the
-            // slots of its finished episodes
+            // episode_log_kernel (log_kernels.hip) for this lane, fed from registers
             double ret = 0.0;
             int log_len = 0, viol = 0, recs = 0;
             if (live) {
@@ -307,13 +369,28 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
                 viol = lg_viol + int(cons);
                 recs = lg_rec + int(rec);
             }
-            const unsigned long long bal = __ballot(epd);
+            const unsigned long long bal = SPECULATE ? log_bal : __ballot(epd);
+            const int lane = threadIdx.x & 63;
+            long long base = 0;
+            if constexpr (SPECULATE) {
+                if (bal) base = __shfl(log_base_raw, __ffsll((long long)bal) - 1, 64);
+            } else {
+                // ONE returning atomic per workgroup (per wave: 16 384 of them on one address at 2^20 envs, 146 us): the
+                // waves' counts meet in LDS, thread 0 reserves the workgroup's slots, every wave takes its share in wave order
+                const int w = threadIdx.x >> 6;
+                if (lane == 0) log_cnt[w] = __popcll(bal);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    int tot = 0;
+#pragma unroll
+                    for (int k = 0; k < kBlock / 64; ++k) tot += log_cnt[k];
+                    log_base = tot ? (long long)atomicAdd((unsigned long long*)&p.log_state[0], (unsigned long long)tot) : 0;
+                }
+                __syncthreads();
+                base = log_base;
+                for (int k = 0; k < w; ++k) base += log_cnt[k];
+            }
             if (bal) {
-                const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
-                long long base = 0;
-                if (lane == leader)
-                    base = (long long)atomicAdd((unsigned long long*)&p.log_state[0], (unsigned long long)__popcll(bal));
-                base = __shfl(base, leader, 64);
                 if (epd) {
                     const long long slot = base + __popcll(bal & ((1ULL << lane) - 1ULL));
                     if (slot < p.log_cap) {
@@ -380,26 +457,33 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
         double sum = 0.0;
         for (int k = 0; k < kBlock / 16; ++k) sum += block_sum[w][k];       // fixed order inside the workgroup
         if (sum != 0.0) atomicAdd(p.reward_sums + w, sum);
-    } else if (blk == 0 && threadIdx.x == 64) {
+    } else if (blk == 0 && threadIdx.x == kCounters + 2) {
         atomicAdd(p.stats, (unsigned long long)a.n);
     }
-    if constexpr (!SPECULATE) draw_ticket();
-    advance_cursors();
+    if constexpr (SPECULATE) {
+        if (threadIdx.x == 0 && ticket == n_blk - 1) {
+            p.memory.state[2] = 0;
+            advance_cursors(p, mpos, msize, rpos, rsize, ctr, log_iteration);
+        }
+    }
 }
 
-template <class ENV, bool SPECULATE = false>
-__global__ __launch_bounds__(rrl_host::kBlock) void step_push_kernel(StepPushArgs p) {
-    step_push_body<ENV, SPECULATE>(p, blockIdx.x, gridDim.x);
+template <class ENV, int REGIME>
+__global__ __launch_bounds__(block_of(REGIME)) void step_push_kernel(StepPushArgs p) {
+    step_push_body<ENV, REGIME == 0, block_of(REGIME)>(p, blockIdx.x, gridDim.x);
+}
+
+// bandwidth regime: launched behind step_push_kernel<ENV, false> on the same stream, one thread
+template <class ENV>
+__global__ void advance_cursors_kernel(StepPushArgs p) {
+    advance_cursors(p, p.memory.state[0], p.memory.state[1], p.use_recovery_memory ? p.recovery_memory.state[0] : 0,
+                    p.use_recovery_memory ? p.recovery_memory.state[1] : 0,
+                    rrl::effective_counter(p.step.counter, p.step.counter_dev), p.log_state ? p.log_state[1] : 0);
 }
 
 // the same launch for S seeds (pack.hpp): seed s steps its envs on workgroups [first[s], first[s + 1]) -- its own grid as
-// far as the kernel body can tell (cursor ticket, grid stride)
-template <class ENV, bool SPECULATE = false>
-__global__ __launch_bounds__(rrl_host::kBlock) void step_push_pack_kernel(const StepPushArgs* __restrict__ ps,
-                                                                          rrl_pack::Idx ix) {
-    int s, local;
-    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
-    StepPushArgs p = ps[s];
+// far as the kernel body can tell (cursor ticket)
+__device__ __forceinline__ void globalize(StepPushArgs& p) {
     // copied out of device memory: the pointers are passed through the global address space (rrl_pack::to_global)
     StepArgs& e = p.step;
     rrl_pack::to_global_all(e.pos, e.action, e.noise, e.counter_dev, e.next_obs, e.obs, e.reward, e.done, e.constraint, e.success,
@@ -409,7 +493,56 @@ __global__ __launch_bounds__(rrl_host::kBlock) void step_push_pack_kernel(const 
     rrl_pack::globalize(p.sel_rec_head);
     rrl_pack::globalize(p.memory);
     rrl_pack::globalize(p.recovery_memory);
-    step_push_body<ENV, SPECULATE>(p, local, ix.first[s + 1] - ix.first[s]);
+}
+
+template <class ENV, int REGIME>
+__global__ __launch_bounds__(block_of(REGIME)) void step_push_pack_kernel(const StepPushArgs* __restrict__ ps,
+                                                                          rrl_pack::Idx ix) {
+    int s, local;
+    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
+    StepPushArgs p = ps[s];
+    globalize(p);
+    step_push_body<ENV, REGIME == 0, block_of(REGIME)>(p, local, ix.first[s + 1] - ix.first[s]);
+}
+
+template <class ENV>
+__global__ void advance_cursors_pack_kernel(const StepPushArgs* __restrict__ ps) {
+    StepPushArgs p = ps[blockIdx.x];      // one single-thread workgroup per seed: the argument block is wave-uniform
+    globalize(p);
+    advance_cursors(p, p.memory.state[0], p.memory.state[1], p.use_recovery_memory ? p.recovery_memory.state[0] : 0,
+                    p.use_recovery_memory ? p.recovery_memory.state[1] : 0,
+                    rrl::effective_counter(p.step.counter, p.step.counter_dev), p.log_state ? p.log_state[1] : 0);
+}
+
+// host side: the launch covers its envs, one workgroup per 256 / 1024 (n <= 2^32 - 1: at most 2^24 workgroups)
+inline int grid_cover(int64_t n) {
+    const int b = block_of(regime_of(n));
+    const int64_t g = (n + b - 1) / b;
+    return int(g < 1 ? 1 : g);
+}
+
+// launch of one seed's step: latency variant, or bandwidth variant + the one-thread cursor launch behind it
+template <class ENV>
+inline void launch(const StepPushArgs& p, int64_t n, hipStream_t st) {
+    const dim3 grid(grid_cover(n));
+    const int regime = regime_of(n);
+    if (regime == 0) {
+        hipLaunchKernelGGL((step_push_kernel<ENV, 0>), grid, dim3(block_of(0)), 0, st, p);
+        return;
+    }
+    if (regime == 1) hipLaunchKernelGGL((step_push_kernel<ENV, 1>), grid, dim3(block_of(1)), 0, st, p);
+    else hipLaunchKernelGGL((step_push_kernel<ENV, 2>), grid, dim3(block_of(2)), 0, st, p);
+    hipLaunchKernelGGL((advance_cursors_kernel<ENV>), dim3(1), dim3(1), 0, st, p);
+}
+template <class ENV>
+inline void launch_pack(const StepPushArgs* dev, const rrl_pack::Idx& ix, int grid, int regime, hipStream_t st) {
+    if (regime == 0) {
+        hipLaunchKernelGGL((step_push_pack_kernel<ENV, 0>), dim3(grid), dim3(block_of(0)), 0, st, dev, ix);
+        return;
+    }
+    if (regime == 1) hipLaunchKernelGGL((step_push_pack_kernel<ENV, 1>), dim3(grid), dim3(block_of(1)), 0, st, dev, ix);
+    else hipLaunchKernelGGL((step_push_pack_kernel<ENV, 2>), dim3(grid), dim3(block_of(2)), 0, st, dev, ix);
+    hipLaunchKernelGGL((advance_cursors_pack_kernel<ENV>), dim3(ix.S), dim3(1), 0, st, dev);
 }
 
 // host side: argument block shared by the navigation and maze entry points

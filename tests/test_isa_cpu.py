@@ -85,7 +85,8 @@ BUDGETS = (
     ("plan_cost_kernelILb0E", 128, "planner f32: four waves per SIMD"),
     ("plan_cost_kernelILb1E", 128, "planner f16x3"),
     ("ens_big_fwd_bwd_kernel", 128, "large-batch ensemble step"),
-    ("step_push_kernelIN12_GLOBAL__N_16NavEnv", 120, "fused env step + pushes + episode table: four waves per SIMD (4 x 120 <= 512)"),
+    ("step_push_kernelIN12_GLOBAL__N_16NavEnvILi0EEELi0E", 96, "fused env step + pushes + episode table, latency variant (speculated reset)"),
+    ("step_push_kernelIN12_GLOBAL__N_16NavEnvILi0EEELi2E", 64, "the same, bandwidth variant: 1024-thread workgroups, eight waves per SIMD"),
     ("nav_step_kernel", 64, "env step: eight waves per SIMD (bandwidth regime)"),
     ("sample_group_kernel", 64, "replay draws"),
 )
@@ -103,3 +104,19 @@ def test_hot_kernels_keep_their_register_budgets(tmp_path):
         for k, v in hits.items():
             assert v["vgpr"] <= limit, (k, v["vgpr"], limit, why)
             assert v["scratch"] <= 32, (k, v["scratch"])
+
+
+def test_step_push_has_no_loop_and_few_sgpr_spills(tmp_path):
+    """The fused env-step kernel covers its envs in ONE pass (step_push.hpp: grid_cover).  Around a grid-stride loop the
+    compiler kept every loop-invariant address of its ~35 arrays in scalar registers: 347 SGPRs spilled into vector lanes,
+    1 039 v_readlane / v_writelane among 3 899 instructions (profiles/round4_step_push_isa.txt)."""
+    from isa_util import kernel_table
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    table = kernel_table(_lib.SO_PATH, str(tmp_path))
+    hits = {k: v for k, v in table.items() if "step_push_kernelIN12_GLOBAL__N_16NavEnv" in k}
+    assert len(hits) == 6, sorted(hits)          # two env kinds x three launch shapes
+    for k, v in hits.items():
+        lanes = v["ins"].get("v_readlane_b32", 0) + v["ins"].get("v_writelane_b32", 0)
+        assert lanes <= 400, (k, lanes)
+        assert sum(v["ins"].values()) <= 3300, (k, sum(v["ins"].values()))
