@@ -22,8 +22,8 @@ import csv, sys, collections, re
 by = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     name = r.get('Kernel_Name', '')
-    name = re.sub(r'\(.*', '', name)
     name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    name = re.sub(r'\(.*', '', name)
     by[name][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in by.items():
     for c, v in d.items():

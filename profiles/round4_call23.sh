@@ -1,0 +1,24 @@
+set +e
+mkdir -p gpurun_out
+R=$PWD
+for rep in 1 2; do
+for L in g16only fwdgrid fwdhoist; do
+  export RRL_HIP_LIB=$R/profiles/_ab_$L.so
+  python bench.py --no_legs --no_cpu_baseline --steps 4000 --warmup 400 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', round(d['ms_per_step'],5), round(d['value']/1e6,3))"
+done; done
+cd /tmp && export TMPDIR=/tmp
+for L in g16only fwdgrid fwdhoist; do
+  export RRL_HIP_LIB=$R/profiles/_ab_$L.so
+  rm -rf /tmp/kt_$L
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$L -o p -- python $R/bench.py --no_legs --no_cpu_baseline --steps 1000 --warmup 100 --min_seconds 0 > /tmp/kt_$L.log 2>&1
+  f=$(find /tmp/kt_$L -name "*kernel_stats.csv" | head -1)
+  echo "== $L"; python - "$f" <<'P'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+for r in rows:
+    n=r['Name']
+    if any(k in n for k in ('mlp3_fwd_split_group','gemm16_group','head_bwd_group','adam_multi','sample_group','step_push')):
+        print(n.replace('(anonymous namespace)::','')[:60], r['Calls'], round(float(r['AverageNs'])/1e3,2))
+P
+done

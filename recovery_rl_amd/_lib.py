@@ -28,6 +28,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 SOURCE_FLAGS = {
     "nav_kernels.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "maze_kernels.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+    "update_kernels.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],     # the Adam step ticket, same reason
 }
 
 EXPORTS = [

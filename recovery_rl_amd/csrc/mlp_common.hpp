@@ -39,6 +39,29 @@ __device__ __forceinline__ float psum(const float* p, long long idx, int np, lon
 
 }  // namespace
 
+// ---- solo group launches: the member comes out of the grid -------------------------------------------------------------
+// A solo group kernel is launched on grid (workgroups of the largest member, members[, ...]): blockIdx.y IS the member, so
+// its argument block sits at a kernel-argument address known at wave start and ONE batch of scalar loads fetches it.  A flat
+// grid (the packed form keeps it: its blocks live in device memory anyway) has to walk first[] to find the member before it
+// can ask for the member's block: one more dependent round trip to memory, ~0.5 us of a ~7 us kernel (profiles/
+// round4_levels.txt).  Members with fewer workgroups than the largest leave the surplus empty (exit after that batch).
+// arrive_together: every listed scalar is in a register at this point, i.e. the compiler requests all of them up front and
+// waits once, instead of one s_waitcnt per first use with further scalar loads issued behind it.
+template <class T>
+__device__ __forceinline__ void in_sgpr(const T& v) {
+    asm volatile("" ::"s"(v));
+}
+template <class... T>
+__device__ __forceinline__ void arrive_together(const T&... v) {
+    (in_sgpr(v), ...);
+}
+template <class Group>
+static int largest_member(const Group& g, int n) {
+    int most = 1;
+    for (int k = 0; k < n; ++k) most = g.first[k + 1] - g.first[k] > most ? g.first[k + 1] - g.first[k] : most;
+    return most;
+}
+
 // ---- packed launches: the same group launch for S seeds side by side (pack.hpp) ----
 template <class Member>
 static bool pack_key(int site, int S, const int* n, const Member* const* members, rrl_pack::Key& key) {

@@ -438,10 +438,26 @@ __device__ __forceinline__ void mlp3_fwd_split_group_body(const StackGroup& sg, 
     else mlp3_fwd_split_body<R, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
 }
 
+// Solo launch: grid (row tiles x heads x column splits of the largest member, members) -- see mlp_common.hpp.
+// (Requesting the weights before the input head is evaluated instead of behind its barriers was tried with it: the 4096-row
+// forward went 18.5 -> 23.8 us, the 256-row ones +0.3 us.  Not kept.)
 template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    mlp3_fwd_split_group_body<R>(sg, blockIdx.x, lds);
+    const int k = blockIdx.y;
+    StackArgs a = sg.a[k];
+    float* partial = sg.partial[k];
+    const int G = sg.G[k], tiles = sg.tiles[k];
+    globalize(a);
+    rrl_pack::to_global(partial);
+    arrive_together(a.M, a.H, a.din, a.dout, a.ldx, a.use_in_head, a.in_head.kind, a.in_head.n_part, a.in_head.part_stride,
+                    a.in_head.ld_action, a.in_head.min_log_std, G, tiles);
+    const int local = blockIdx.x;
+    if (local >= tiles * G * kSplit) return;
+    const int bx = local % tiles, rest = local / tiles;
+    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
+    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
+    else mlp3_fwd_split_body<R, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
 }
 
 // the same launch for S seeds (pack.hpp): seed s runs its group on workgroups [first[s], first[s + 1])
@@ -570,12 +586,13 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
     const int rc = build_stack_group(n, st, sg, path);
     if (rc != RRL_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    const int most = largest_member(sg, n);       // split paths: grid (workgroups of the largest member, members)
     if (path == 0) {
-        hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<1>, dim3(sg.first[n]), dim3(256), split_lds_floats(1) * 4, s, sg);
+        hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<1>, dim3(most, n), dim3(256), split_lds_floats(1) * 4, s, sg);
     } else if (path == 3) {
         static const bool ok = grant_lds((const void*)mlp3_fwd_split_group_kernel<kBigR>, split_lds_floats(kBigR) * 4);
         if (!ok) return RRL_ERANGE;
-        hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<kBigR>, dim3(sg.first[n]), dim3(256),
+        hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<kBigR>, dim3(most, n), dim3(256),
                            split_lds_floats(kBigR) * 4, s, sg);
     } else if (path == 1) hipLaunchKernelGGL((mlp3_fwd_group_kernel<1>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
     else hipLaunchKernelGGL((mlp3_fwd_group_kernel<2>), dim3(sg.first[n]), dim3(1024), 0, s, sg);

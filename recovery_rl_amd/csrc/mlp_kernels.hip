@@ -17,6 +17,8 @@
 // arbitrary M, N, K (edges are zero-filled / bounds-checked).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "mlp_common.hpp"
 
 namespace {
@@ -131,7 +133,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 // PANEL = K elements per panel (a multiple of 16).  The K chunks are consumed in the same ascending order with the same
 // accumulator for every PANEL, so the result does not depend on it; a smaller panel = smaller LDS tiles = more tiles in
 // flight per CU (the packed launches, which have more tiles than LDS for them) at the price of a wave-level sync per panel.
-template <int MODE, bool FAST, int PANEL = kPanel>  // MODE: 0 NT, 1 NN, 2 TN
+// DEEP (the solo launches: a handful of tiles per CU, every dependent round trip to memory is ~0.7 us of a ~7 us kernel): TWO
+// panels in flight instead of one -- with K = 2 PANEL every operand of the tile is requested before the first wait -- and the
+// epilogue's operands (bias, relu mask, the first layer's x and W1 rows) requested with them instead of behind the K loop.
+// Same MFMA steps on the same operands in the same order: the same bits.
+template <int MODE, bool FAST, int PANEL = kPanel, bool DEEP = false>  // MODE: 0 NT, 1 NN, 2 TN
 __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g) {
     const int lane = threadIdx.x & 63;
     const int m0 = by * kTile, n0 = bx * kTile;
@@ -144,18 +150,38 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;  // TN: running sum of my A operands (for colsum)
-    Frag fa, fb;
+    Frag fa, fb, na, nb;
 
-    auto load = [&](int k0) {
-        if (kStageA) load_staged<FAST>(fa, A, a.lda, m0, a.M, k0, a.K, lane);
-        else load_direct<FAST>(fa, A, a.lda, m0, a.M, k0, a.K, lane);
-        if (kStageB) load_staged<FAST>(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
-        else load_direct<FAST>(fb, B, a.ldb, n0, a.N, k0, a.K, lane);
+    auto load_into = [&](Frag& ra, Frag& rb, int k0) {
+        if (kStageA) load_staged<FAST>(ra, A, a.lda, m0, a.M, k0, a.K, lane);
+        else load_direct<FAST>(ra, A, a.lda, m0, a.M, k0, a.K, lane);
+        if (kStageB) load_staged<FAST>(rb, B, a.ldb, n0, a.N, k0, a.K, lane);
+        else load_direct<FAST>(rb, B, a.ldb, n0, a.N, k0, a.K, lane);
     };
+    auto load = [&](int k0) { load_into(fa, fb, k0); };
 
     const int np = (a.K + PANEL - 1) / PANEL;
     const int i = lane & 15, q = lane >> 4;
     load(0);
+    if (DEEP && np > 1) load_into(na, nb, PANEL);
+    // DEEP: the epilogue's operands, requested now
+    const int ecol = n0 + (lane & 15);
+    float pre_bias = 0.f, pre_mask[4] = {1.f, 1.f, 1.f, 1.f}, pre_x = 0.f, pre_w = 0.f;
+    if constexpr (DEEP) {
+        if (MODE == 0 && a.bias && ecol < a.N) pre_bias = a.bias[g * a.sBias + ecol];
+        if (MODE == 1 && a.mask && ecol < a.N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + 4 * (lane >> 4) + r;
+                if (row < a.M) pre_mask[r] = a.mask[g * a.sMask + (long long)row * a.ldmask + ecol];
+            }
+        }
+        if (MODE == 1 && a.x) {
+            const int rr = lane & 15, dd = lane >> 4;
+            pre_x = dd < a.din ? a.x[(long long)(m0 + rr) * a.ldx + dd] : 0.f;
+            pre_w = dd < a.din ? a.W1[((long long)g * a.N + n0 + rr) * a.din + dd] : 0.f;
+        }
+    }
     for (int p = 0; p < np; ++p) {
         Frag ca = fa, cb = fb;           // operands of this panel (registers)
         if (kStageA || kStageB) {
@@ -164,7 +190,12 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
             if (kStageB) store_staged(fb, Bs, lane);
             __syncthreads();
         }
-        if (p + 1 < np) load((p + 1) * PANEL);   // next panel's global loads fly under the MFMAs
+        if constexpr (DEEP) {
+            if (p + 1 < np) { fa = na; fb = nb; }                       // the panel behind this one is on its way already
+            if (p + 2 < np) load_into(na, nb, (p + 2) * PANEL);
+        } else {
+            if (p + 1 < np) load((p + 1) * PANEL);   // next panel's global loads fly under the MFMAs
+        }
         const int klen = min(PANEL, a.K - p * PANEL);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -185,7 +216,7 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
 
     // epilogue: lane holds C[row][col], col = lane & 15, row = 4 (lane >> 4) + r
     const int col = n0 + (lane & 15);
-    const float bias = (MODE == 0 && a.bias && col < a.N) ? a.bias[g * a.sBias + col] : 0.f;
+    const float bias = DEEP ? pre_bias : ((MODE == 0 && a.bias && col < a.N) ? a.bias[g * a.sBias + col] : 0.f);
     float vout[4] = {0.f, 0.f, 0.f, 0.f};
     const bool store_c = MODE != 1 || !a.skip_c;
     if (col < a.N) {
@@ -196,7 +227,7 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
                 float v = acc[r] + bias;
                 if (a.relu) v = v > 0.f ? v : 0.f;
                 if (MODE == 1 && a.mask) {
-                    const float s = a.mask[g * a.sMask + (long long)row * a.ldmask + col];
+                    const float s = DEEP ? pre_mask[r] : a.mask[g * a.sMask + (long long)row * a.ldmask + col];
                     v = s > 0.f ? v : 0.f;
                 }
                 vout[r] = v;
@@ -212,8 +243,8 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
             // the tile and the 16 rows of x / W1 it meets, through LDS (the K loop is done with Bs)
             float* T = Bs;                    // [16][17] tile, then xs [16][4] at 272, ws [16][4] at 336
             const int rr = lane & 15, dd = lane >> 4;
-            const float xv = dd < a.din ? a.x[(long long)(m0 + rr) * a.ldx + dd] : 0.f;
-            const float wv = dd < a.din ? a.W1[((long long)g * a.N + n0 + rr) * a.din + dd] : 0.f;
+            const float xv = DEEP ? pre_x : (dd < a.din ? a.x[(long long)(m0 + rr) * a.ldx + dd] : 0.f);
+            const float wv = DEEP ? pre_w : (dd < a.din ? a.W1[((long long)g * a.N + n0 + rr) * a.din + dd] : 0.f);
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = vout[r];
@@ -281,10 +312,37 @@ struct HiddenGroup {
 template <int PANEL = kPanel>
 __device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int block, float* As, float* Bs);
 
-__global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenGroup hg) {
+// Solo launch: grid (tiles per product x heads, members, 2) -- blockIdx.y IS the member and blockIdx.z the product (0: input
+// gradient NN, 1: weight gradient TN), so the ONE argument block the workgroup needs sits at a kernel-argument address known
+// at wave start (mlp_common.hpp).  (The flat grid needs first[] to find the member, the member's tile counts to find the
+// product, the product's argument block, and only then the operands: four dependent round trips before the first MFMA.)
+// Members without a weight gradient leave their z = 1 workgroups empty: they are dispatched last and exit after that batch.
+struct HiddenJob {
+    GemmArgs ga;
+    int tiles, tiles_x, fast, G;      // tiles per head (0: nothing to do), tiles per tile row, FAST geometry, heads
+};
+struct HiddenJobs {
+    HiddenJob job[kMaxGroup][2];      // [member][0: NN, 1: TN]
+};
+__global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenJobs hj) {
     __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
     __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
-    gemm16_group_body(hg, blockIdx.x, As, Bs);
+    const bool is_tn = blockIdx.z != 0;
+    HiddenJob j = hj.job[blockIdx.y][blockIdx.z];
+    GemmArgs& ga = j.ga;
+    globalize(ga);
+    arrive_together(ga.M, ga.N, ga.K, ga.lda, ga.ldb, ga.ldc, ga.ldmask, ga.sA, ga.sB, ga.sC, ga.sBias, ga.sMask, ga.sColsum,
+                    ga.relu, ga.accumulate, ga.first_stride, ga.ldx, ga.din, ga.G, ga.skip_c, j.tiles, j.tiles_x, j.fast, j.G);
+    const int x = blockIdx.x;
+    if (x >= j.tiles * j.G) return;
+    const int g = x / j.tiles, b = x - g * j.tiles;
+    if (is_tn) {
+        if (j.fast) gemm16_tile<2, true, kPanel, true>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
+        else gemm16_tile<2, false, kPanel, true>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
+    } else {
+        if (j.fast) gemm16_tile<1, true, kPanel, true>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
+        else gemm16_tile<1, false, kPanel, true>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
+    }
 }
 
 // PANEL = 128: 20 KB of LDS per single-wave workgroup, i.e. 8 tiles in flight per CU -- enough for one seed (1 000-1 500 tiles
@@ -861,10 +919,20 @@ __device__ __forceinline__ void head_bwd_group_body(const HeadBwdGroup& hg, int 
     head_bwd_dispatch(hb, local % hg.blocks_x[k], local / hg.blocks_x[k], red, dsh);
 }
 
+// solo launch: grid (column blocks x heads of the largest member, members): the member comes out of the grid (mlp_common.hpp)
 __global__ __launch_bounds__(256) void head_bwd_group_kernel(HeadBwdGroup hg) {
     __shared__ float red[kSlices][4][kCols];
     __shared__ float dsh[1024 * 4];
-    head_bwd_group_body(hg, blockIdx.x, red, dsh);
+    const int k = blockIdx.y;
+    HeadBwdArgs hb = hg.p[k];
+    const int blocks_x = hg.blocks_x[k], G = hg.G[k];
+    globalize(hb);
+    const rrl_loss_t& l = hb.la;
+    arrive_together(hb.B, hb.H, hb.dout, hb.need_w, l.kind, l.n_part, l.part_stride, l.f0, l.ld, l.n_heads, l.head_stride,
+                    l.da_parts, l.da_part_stride, blocks_x, G);
+    const int local = blockIdx.x;
+    if (local >= blocks_x * G) return;
+    head_bwd_dispatch(hb, local % blocks_x, local / blocks_x, red, dsh);
 }
 
 __global__ __launch_bounds__(256) void head_bwd_pack_kernel(const HeadBwdGroup* __restrict__ groups, rrl_pack::Idx ix) {
@@ -1073,7 +1141,15 @@ int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* strea
     HiddenGroup hg;
     const int rc = build_hidden_group(n, ps, hg);
     if (rc != RRL_OK) return rc;
-    hipLaunchKernelGGL(gemm16_group_kernel, dim3(hg.first[n]), dim3(64), 0, (hipStream_t)stream, hg);
+    HiddenJobs hj{};
+    int most = 1;
+    for (int k = 0; k < n; ++k) {
+        const int nn_tiles = hg.per_head[k] - hg.tn_tiles[k];
+        hj.job[k][0] = HiddenJob{hg.nn[k], nn_tiles, hg.nn_tiles_x[k], hg.fast[k], ps[k].G};
+        hj.job[k][1] = HiddenJob{hg.tn[k], hg.tn_tiles[k], hg.tn_tiles_x[k], hg.fast[k], ps[k].G};
+        most = std::max(most, std::max(hg.tn_tiles[k], nn_tiles) * ps[k].G);
+    }
+    hipLaunchKernelGGL(gemm16_group_kernel, dim3(most, n, 2), dim3(64), 0, (hipStream_t)stream, hj);
     return check_launch();
 }
 
@@ -1229,7 +1305,7 @@ int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
     HeadBwdGroup hg;
     const int rc = build_head_group(n, ps, hg);
     if (rc != RRL_OK) return rc;
-    hipLaunchKernelGGL(head_bwd_group_kernel, dim3(hg.first[n]), dim3(256), 0, (hipStream_t)stream, hg);
+    hipLaunchKernelGGL(head_bwd_group_kernel, dim3(largest_member(hg, n), n), dim3(256), 0, (hipStream_t)stream, hg);
     return check_launch();
 }
 

@@ -325,55 +325,91 @@ __device__ __forceinline__ float part_sum1(const float* gp, int np, long long ps
     return acc;
 }
 
+// one thread's share of a vectorised pass: two float4 slots `stride` apart, every operand of both requested together
+struct AdamVec {
+    float* p; const float* g; float* m; float* v; float* target; const float* g2;
+    const float* gp; int np; long long ps, pe;          // partial-sum gradient range (pe = 0: none)
+    long long n4, stride;
+};
+struct AdamSlot {
+    float4 P[2], G[2], M[2], V[2], T[2], Hh[2];
+    long long i0, i1;
+    bool two;
+};
+__device__ __forceinline__ void adam_slot_load(const AdamVec& a, long long i0, AdamSlot& s) {
+    const float4* p4 = reinterpret_cast<const float4*>(a.p);
+    const float4* m4 = reinterpret_cast<const float4*>(a.m);
+    const float4* v4 = reinterpret_cast<const float4*>(a.v);
+    const float4* t4 = reinterpret_cast<const float4*>(a.target);
+    const float4* g4 = reinterpret_cast<const float4*>(a.g);
+    const float4* h4 = reinterpret_cast<const float4*>(a.g2);
+    s.i0 = i0;
+    s.i1 = i0 + a.stride;
+    s.two = s.i1 < a.n4;
+    const long long j1 = s.two ? s.i1 : i0;
+    s.P[0] = p4[i0]; s.P[1] = p4[j1];
+    s.G[0] = g4[i0]; s.G[1] = g4[j1];
+    s.M[0] = m4[i0]; s.M[1] = m4[j1];
+    s.V[0] = v4[i0]; s.V[1] = v4[j1];
+    if (4 * i0 < a.pe) s.G[0] = part_sum4(a.gp, a.np, a.ps, i0);          // pe % 4 == 0: a float4 is inside or outside
+    if (4 * j1 < a.pe) s.G[1] = part_sum4(a.gp, a.np, a.ps, j1);
+    s.T[0] = s.P[0]; s.T[1] = s.P[1];
+    s.Hh[0] = s.Hh[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.target) { s.T[0] = t4[i0]; s.T[1] = t4[j1]; }
+    if (a.g2) { s.Hh[0] = h4[i0]; s.Hh[1] = h4[j1]; }
+}
+__device__ __forceinline__ void adam_slot_finish(const AdamVec& a, AdamSlot& s, float step_size, float bc2_sqrt, float b1,
+                                                 float b2, float eps, float tau, float wd) {
+    float4* p4 = reinterpret_cast<float4*>(a.p);
+    float4* m4 = reinterpret_cast<float4*>(a.m);
+    float4* v4 = reinterpret_cast<float4*>(a.v);
+    float4* t4 = reinterpret_cast<float4*>(a.target);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float* pp = reinterpret_cast<float*>(&s.P[u]);
+        float* mm = reinterpret_cast<float*>(&s.M[u]);
+        float* vv = reinterpret_cast<float*>(&s.V[u]);
+        float* tt = reinterpret_cast<float*>(&s.T[u]);
+        const float* gg = reinterpret_cast<const float*>(&s.G[u]);
+        const float* hh = reinterpret_cast<const float*>(&s.Hh[u]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gi = a.g2 ? gg[c] + hh[c] : gg[c];
+            const float pi = adam_elem(pp[c], gi, mm[c], vv[c], step_size, bc2_sqrt, b1, b2, eps, wd);
+            tt[c] = tt[c] * (1.f - tau) + pi * tau;
+        }
+    }
+    p4[s.i0] = s.P[0]; m4[s.i0] = s.M[0]; v4[s.i0] = s.V[0];
+    if (a.target) t4[s.i0] = s.T[0];
+    if (s.two) {
+        p4[s.i1] = s.P[1]; m4[s.i1] = s.M[1]; v4[s.i1] = s.V[1];
+        if (a.target) t4[s.i1] = s.T[1];
+    }
+}
+
+// `first` (optional): the thread's first slot, already loaded by the caller (adam_multi_body requests it BEFORE it waits for
+// the step count and the bias corrections: they are needed by the arithmetic only)
 __device__ __forceinline__ void adam_range(long long n, float* p, const float* g, float* m, float* v,
                                            float step_size, float bc2_sqrt, float b1, float b2, float eps,
                                            float* target, float tau, float wd, const float* g2, int block,
-                                           int blocks, bool vec, const float* gp = nullptr, int np = 0,
-                                           long long ps = 0, long long pe = 0) {
+                                           int blocks, bool vec, const float* gp, int np,
+                                           long long ps, long long pe, AdamSlot& first, bool have_first) {
     const long long stride = (long long)blocks * kBlock;
     long long done = 0;
     if (!gp) pe = 0;
     if (vec) {
-        const long long n4 = n >> 2;
-        float4* p4 = reinterpret_cast<float4*>(p);
-        float4* m4 = reinterpret_cast<float4*>(m);
-        float4* v4 = reinterpret_cast<float4*>(v);
-        float4* t4 = reinterpret_cast<float4*>(target);
-        const float4* g4 = reinterpret_cast<const float4*>(g);
-        const float4* h4 = reinterpret_cast<const float4*>(g2);
-        for (long long i0 = (long long)block * kBlock + threadIdx.x; i0 < n4; i0 += 2 * stride) {
-            const long long i1 = i0 + stride;
-            const bool two = i1 < n4;
-            const long long j1 = two ? i1 : i0;
-            float4 P[2] = {p4[i0], p4[j1]}, G[2] = {g4[i0], g4[j1]}, M[2] = {m4[i0], m4[j1]}, V[2] = {v4[i0], v4[j1]};
-            if (4 * i0 < pe) G[0] = part_sum4(gp, np, ps, i0);          // pe % 4 == 0: a float4 is inside or outside
-            if (4 * j1 < pe) G[1] = part_sum4(gp, np, ps, j1);
-            float4 T[2] = {P[0], P[1]}, Hh[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-            if (target) { T[0] = t4[i0]; T[1] = t4[j1]; }
-            if (g2) { Hh[0] = h4[i0]; Hh[1] = h4[j1]; }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float* pp = reinterpret_cast<float*>(&P[u]);
-                float* mm = reinterpret_cast<float*>(&M[u]);
-                float* vv = reinterpret_cast<float*>(&V[u]);
-                float* tt = reinterpret_cast<float*>(&T[u]);
-                const float* gg = reinterpret_cast<const float*>(&G[u]);
-                const float* hh = reinterpret_cast<const float*>(&Hh[u]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float gi = g2 ? gg[c] + hh[c] : gg[c];
-                    const float pi = adam_elem(pp[c], gi, mm[c], vv[c], step_size, bc2_sqrt, b1, b2, eps, wd);
-                    tt[c] = tt[c] * (1.f - tau) + pi * tau;
-                }
-            }
-            p4[i0] = P[0]; m4[i0] = M[0]; v4[i0] = V[0];
-            if (target) t4[i0] = T[0];
-            if (two) {
-                p4[i1] = P[1]; m4[i1] = M[1]; v4[i1] = V[1];
-                if (target) t4[i1] = T[1];
-            }
+        const AdamVec a{p, g, m, v, target, g2, gp, np, ps, pe, n >> 2, stride};
+        long long i0 = (long long)block * kBlock + threadIdx.x;
+        if (have_first && i0 < a.n4) {
+            adam_slot_finish(a, first, step_size, bc2_sqrt, b1, b2, eps, tau, wd);
+            i0 += 2 * stride;
         }
-        done = n4 << 2;
+        for (; i0 < a.n4; i0 += 2 * stride) {
+            AdamSlot s;
+            adam_slot_load(a, i0, s);
+            adam_slot_finish(a, s, step_size, bc2_sqrt, b1, b2, eps, tau, wd);
+        }
+        done = a.n4 << 2;
     }
     for (long long i = done + (long long)block * kBlock + threadIdx.x; i < n; i += stride) {
         float pi = p[i], mi = m[i], vi = v[i];
@@ -387,19 +423,33 @@ __device__ __forceinline__ void adam_range(long long n, float* p, const float* g
 
 // several flat buffers (e.g. critic + policy of one update) in ONE launch; every segment keeps its own step
 // counter, advanced by the last of ITS workgroups.
+__device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec, float lr, float b1, float b2, float eps,
+                                              int block, int blocks, float* sh);
 __device__ __forceinline__ void adam_multi_body(const AdamSegs& a, int n_seg, float lr, float b1, float b2, float eps,
                                                 int blk, float* sh) {
     int k = 0;
     while (k + 1 < n_seg && blk >= a.first_block[k + 1]) ++k;
     rrl_adam_seg_t sg = a.seg[k];
     rrl_pack::to_global_all(sg.p, sg.g, sg.m, sg.v, sg.step_dev, sg.target, sg.g2, sg.g_part);   // packed launch: copied out of memory
-    const int block = blk - a.first_block[k], blocks = a.first_block[k + 1] - a.first_block[k];
-    uint64_t step = 0;
+    adam_seg_body(sg, a.vec[k] != 0, lr, b1, b2, eps, blk - a.first_block[k], a.first_block[k + 1] - a.first_block[k], sh);
+}
+__device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec, float lr, float b1, float b2, float eps,
+                                              int block, int blocks, float* sh) {
+    // the step count is requested first, then the thread's first two float4 slots of every operand -- before anything waits
+    // for the step count (the partial-sum gradients are added up inside the slot load: a wait of their own)
+    const uint64_t step = sg.step_dev[0];        // every thread (thread 0 uses it): a load under a branch is waited for at its end
+    AdamSlot first;
+    const bool pre = vec && (long long)block * kBlock + threadIdx.x < (sg.n >> 2);
+    if (pre) {
+        const AdamVec av{sg.p, sg.g, sg.m, sg.v, sg.target, sg.g2, sg.g_part, sg.n_part, sg.part_stride,
+                         sg.g_part ? sg.part_elems : 0, sg.n >> 2, (long long)blocks * kBlock};
+        adam_slot_load(av, (long long)block * kBlock + threadIdx.x, first);
+    }
     unsigned long long ticket = ~0ULL;
     if (threadIdx.x == 0) {
-        // plain load, then the ticket once it has returned ("memory" clobber: the compiler keeps the order): the read of the
-        // step count cannot slip behind the ticket
-        step = sg.step_dev[0];
+        // plain load (above), then the ticket once it has returned ("memory" clobber: the compiler keeps the order): the read
+        // of the step count cannot slip behind the ticket
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const double t = double(step + 1);
         // the ticket is taken as soon as this workgroup has READ the step count: the last of the segment's workgroups
         // to do so knows every other one has read it too and may store t + 1 -- the returning atomic's round trip
@@ -412,17 +462,26 @@ __device__ __forceinline__ void adam_multi_body(const AdamSegs& a, int n_seg, fl
     }
     __syncthreads();
     adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, sg.weight_decay, sg.g2,
-               block, blocks, a.vec[k] != 0, sg.g_part, sg.n_part, sg.part_stride, sg.part_elems);
+               block, blocks, vec, sg.g_part, sg.n_part, sg.part_stride, sg.part_elems, first, vec);
     if (threadIdx.x == 0 && ticket == (unsigned long long)blocks - 1) {
         sg.step_dev[0] = step + 1;
         sg.step_dev[1] = 0;
     }
 }
 
+// solo launch: grid (workgroups of the largest segment, segments) -- blockIdx.y IS the segment, its block arrives in one batch
+// of scalar loads (the flat grid of the packed form walks first_block[] first: one more dependent round trip)
 __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_seg, float lr, float b1, float b2,
                                                             float eps) {
     __shared__ float sh[2];
-    adam_multi_body(a, n_seg, lr, b1, b2, eps, blockIdx.x, sh);
+    const int k = blockIdx.y;
+    rrl_adam_seg_t sg = a.seg[k];
+    const int vec = a.vec[k], blocks = a.first_block[k + 1] - a.first_block[k];
+    rrl_pack::to_global_all(sg.p, sg.g, sg.m, sg.v, sg.step_dev, sg.target, sg.g2, sg.g_part);
+    asm volatile("" ::"s"(sg.n), "s"(sg.tau), "s"(sg.weight_decay), "s"(sg.n_part), "s"(sg.part_stride), "s"(sg.part_elems),
+                 "s"(vec), "s"(blocks));
+    if ((int)blockIdx.x >= blocks) return;
+    adam_seg_body(sg, vec != 0, lr, b1, b2, eps, blockIdx.x, blocks, sh);
 }
 
 // the same launch for S seeds (pack.hpp)
@@ -462,7 +521,9 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(long long n, float* p, con
         sh[1] = float(sqrt(1.0 - pow(double(b2), t)));
     }
     __syncthreads();
-    adam_range(n, p, g, m, v, sh[0], sh[1], b1, b2, eps, target, tau, 0.f, nullptr, blockIdx.x, gridDim.x, vec != 0);
+    AdamSlot none;
+    adam_range(n, p, g, m, v, sh[0], sh[1], b1, b2, eps, target, tau, 0.f, nullptr, blockIdx.x, gridDim.x, vec != 0, nullptr, 0, 0,
+               0, none, false);
     rrl::advance_counter(step_dev, 1);
 }
 
@@ -618,7 +679,9 @@ int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float b
     AdamSegs a;
     const int rc = build_adam_segs(n_seg, segs, a);
     if (rc != RRL_OK) return rc;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(a.first_block[n_seg]), dim3(kBlock), 0, (hipStream_t)stream, a, n_seg,
+    int most = 1;
+    for (int k = 0; k < n_seg; ++k) most = a.first_block[k + 1] - a.first_block[k] > most ? a.first_block[k + 1] - a.first_block[k] : most;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(most, n_seg), dim3(kBlock), 0, (hipStream_t)stream, a, n_seg,
                        lr, beta1, beta2, eps);
     return check_launch();
 }
