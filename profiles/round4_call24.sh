@@ -2,7 +2,7 @@ set +e
 mkdir -p gpurun_out
 R=$PWD
 for rep in 1 2; do
-for L in fwdgrid new; do
+for L in prev new; do
   if [ $L = new ]; then unset RRL_HIP_LIB; else export RRL_HIP_LIB=$R/profiles/_ab_$L.so; fi
   python bench.py --no_legs --no_cpu_baseline --steps 4000 --warmup 400 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', round(d['ms_per_step'],5), round(d['value']/1e6,3))"
