@@ -80,6 +80,20 @@ __device__ __forceinline__ void wave_count_add(int32_t* chunk_cnt, int32_t* supe
 __device__ __forceinline__ int was_positive(const rrl_replay_t& rb, int64_t slot, int64_t size) {
     return (rb.pos_cnt && slot < size) ? int(rb.r[slot] != 0.0f) : 0;
 }
+// The same in two halves for callers that want the row's request in flight while they do something else: `safe` = any
+// readable 4 bytes -- the row is read through a selected address instead of under a branch (a load under a branch is waited
+// for where the branch ends) -- and the value is looked at by was_positive_of only.
+struct WasRow {
+    float r;
+    bool look;
+};
+__device__ __forceinline__ WasRow was_positive_request(const rrl_replay_t& rb, int64_t slot, int64_t size, const void* safe) {
+    WasRow w;
+    w.look = rb.pos_cnt && slot < size;
+    w.r = *(w.look ? rb.r + slot : reinterpret_cast<const float*>(safe));
+    return w;
+}
+__device__ __forceinline__ int was_positive_of(const WasRow& w) { return w.look ? int(w.r != 0.0f) : 0; }
 
 // write one row into `slot` (`was` = was_positive(rb, slot, size)); keeps both levels of positive counts exact (pos_idx,
 // replay_memory.py:50).  Call from converged code (all active lanes of the wave reach it together).

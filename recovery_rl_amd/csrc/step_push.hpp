@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pack.hpp"
 #include "replay_device.hpp"
 #include "rrl_device.hpp"
@@ -145,15 +147,9 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
         __syncthreads();
     }
     const StepArgs& a = p.step;
-    const uint64_t ctr = rrl::effective_counter(a.counter, a.counter_dev);
-    // plain (wave-uniform: scalar) loads of the cursors; the ticket below is issued only after they have RETURNED (s_waitcnt)
-    // and the compiler may not move them past it ("memory" clobber), so a workgroup's read of a cursor cannot slip behind its
-    // ticket.  (Atomic loads here are per-lane vector loads of ONE address: 4 M of them at 2^20 envs, 50 -> 120 us.)
-    const int64_t mpos = p.memory.state[0], msize = p.memory.state[1];
-    int64_t rpos = 0, rsize = 0;
-    if (p.use_recovery_memory) { rpos = p.recovery_memory.state[0]; rsize = p.recovery_memory.state[1]; }
-    const int64_t log_iteration = p.log_state ? p.log_state[1] : 0;      // read before the ticket, like the cursors
     unsigned long long ticket = ~0ULL;
+    int64_t mpos = 0, msize = 0, rpos = 0, rsize = 0, log_iteration = 0;      // the cursors (read below, behind the per-env requests)
+    uint64_t ctr = 0;
     double rsum = 0.0, retsum = 0.0;
     unsigned cnt[kCounters] = {0, 0, 0, 0, 0, 0, 0};
     // ONE pass: the launch covers its envs (grid_cover), workgroup blk steps envs [256 blk, 256 blk + 256).  No grid-stride loop:
@@ -181,51 +177,81 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
         float he[2] = {0.f, 0.f};
         int32_t t_in = 0;
         bool rec_in = false;
+        // what the requests below return, untouched until the cursors have been requested too (the first instruction that
+        // looks at one of them waits for all of them)
+        int lg_len_ = 0, lg_viol_ = 0, lg_rec_ = 0;
+        double lg_ret_ = 0.0;
+        float zu_[4] = {0.f, 0.f, 0.f, 0.f}, zw_[4] = {0.f, 0.f, 0.f, 0.f}, hh_[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float he_[2] = {0.f, 0.f};
+        float2 ra_ = task, act_ = task, obs_ = task;
+        uint8_t rec_ = 0;
+        uint16_t st_ = 0;
+        int32_t t_ = 0;
         if (live) {
+            // BRANCH-FREE: an optional array is read through a selected address (its own element, or this env's position --
+            // 16 valid bytes -- when the array is absent) and the value dropped afterwards.  A load under a branch is waited
+            // for where the branch ends (the merged register must hold the value there): the optional groups below were five
+            // round trips in a row instead of one.
+            const void* const safe = a.pos + i;
+            const auto at = [&](const auto* arr, long long idx) {
+                using T = std::remove_cv_t<std::remove_pointer_t<decltype(arr)>>;
+                return arr ? arr + idx : reinterpret_cast<const T*>(safe);
+            };
             ep_rew_in = p.ep_reward[i];
-            if (p.log_state) {
-                lg_len = p.log_len[i];
-                lg_ret = p.log_ret[i];
-                lg_viol = p.log_viol[i];
-                lg_rec = p.log_rec[i];
-            }
+            const bool lg = p.log_state != nullptr;
+            lg_len_ = *at(lg ? p.log_len : nullptr, i);
+            lg_ret_ = *at(lg ? p.log_ret : nullptr, i);
+            lg_viol_ = *at(lg ? p.log_viol : nullptr, i);
+            lg_rec_ = *at(lg ? p.log_rec : nullptr, i);
             pp = a.pos[i];
             task = *reinterpret_cast<const float2*>(p.task_action + i * p.ld_task);
-            if (p.sel_z) {
-                // up to four partial sums, all loads issued together
-                const int np = p.sel_np;
-                const long long ps = p.sel_ps;
-                const float* zp = p.sel_z + i;
+            // the gate's partial sums (up to four, all loads issued together) and the recovery action or the head it comes from
+            const bool sel = p.sel_z != nullptr;
+            const int np = p.sel_np;
+            const long long ps = p.sel_ps;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    zu[k] = zp[np > k ? k * ps : 0];
-                    zw[k] = zp[(np > k ? k * ps : 0) + a.n];
-                }
-                if (p.sel_rec_action) {
-                    ra_in = p.sel_rec_action[i];
-                } else {
-                    const rrl_policy_head_t& hd = p.sel_rec_head;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float* hp = hd.head + 2 * i + j;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) hh[j][k] = hp[hd.n_part > k ? k * hd.part_stride : 0];
-                        he[j] = hd.eps ? hd.eps[2 * i + j] : 0.f;
-                    }
-                }
-            } else {
-                act_in = a.action[i];
-                rec_in = p.recovery ? p.recovery[i] != 0 : false;
+            for (int k = 0; k < 4; ++k) {
+                zu_[k] = *at(p.sel_z, i + (np > k ? k * ps : 0));
+                zw_[k] = *at(p.sel_z, i + (np > k ? k * ps : 0) + a.n);
             }
+            ra_ = *at(sel ? p.sel_rec_action : nullptr, i);
+            const rrl_policy_head_t& hd = p.sel_rec_head;
+            const bool from_head = sel && !p.sel_rec_action;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    hh_[jj][k] = *at(from_head ? hd.head : nullptr, 2 * i + jj + (hd.n_part > k ? k * hd.part_stride : 0));
+                he_[jj] = *at(from_head ? hd.eps : nullptr, 2 * i + jj);
+            }
+            act_ = *at(sel ? nullptr : a.action, i);
+            rec_ = *at(sel ? nullptr : p.recovery, i);
             // compact layout: the observation IS float(pos) (that is what this kernel and the resets store), so the 8-byte
             // read is dropped, and the step count comes out of the status word
-            if (a.status) {
-                t_in = int32_t(a.status[i] & 0xfffu);
-            } else {
-                t_in = a.t[i];
-                obs_in = a.obs[i];
-            }
+            st_ = *at(a.status, i);
+            t_ = *at(a.status ? nullptr : a.t, i);
+            obs_ = *at(a.status ? nullptr : a.obs, i);
         }
+        // plain (wave-uniform: scalar) loads of the cursors; the ticket below is issued only after they have RETURNED (s_waitcnt)
+        // and the compiler may not move them past it ("memory" clobber), so a workgroup's read of a cursor cannot slip behind its
+        // ticket.  (Atomic loads here are per-lane vector loads of ONE address: 4 M of them at 2^20 envs, 50 -> 120 us.)
+        // The four cursors (task ring, safety ring, RNG tick, table iteration) are requested TOGETHER: the optional ones through
+        // a selected address (the task ring's state when absent) instead of under a branch -- a load under a branch is waited for
+        // at the branch's end, and four such round trips in a row opened this kernel (~0.5 us each on cold lines).  Behind the
+        // per-env requests above: both sets are in flight at once.
+        const int64_t* rstate = p.use_recovery_memory ? p.recovery_memory.state : p.memory.state;
+        const int64_t* lstate = p.log_state ? p.log_state : p.memory.state;
+        const uint64_t* cdev = a.counter_dev ? a.counter_dev : reinterpret_cast<const uint64_t*>(p.memory.state);
+        const int64_t mpos_ = p.memory.state[0], msize_ = p.memory.state[1];
+        const int64_t rpos_ = rstate[0], rsize_ = rstate[1], liter_ = lstate[1];
+        const uint64_t tick_ = cdev[0];
+        asm volatile("" ::"s"(mpos_), "s"(msize_), "s"(rpos_), "s"(rsize_), "s"(liter_), "s"(tick_));     // one batch, one wait
+        mpos = mpos_;
+        msize = msize_;
+        rpos = p.use_recovery_memory ? rpos_ : 0;
+        rsize = p.use_recovery_memory ? rsize_ : 0;
+        log_iteration = p.log_state ? liter_ : 0;      // read before the ticket, like the cursors
+        ctr = a.counter_dev ? a.counter + tick_ : a.counter;      // rrl::effective_counter
         // Latency regime: ONE ticket for the three device-side cursors (both replay rings and the RNG tick): a returning
         // device-scope atomic is a ~0.7 us round trip, three in a row were a sixth of this kernel.  The workgroup that draws
         // the last ticket knows that every workgroup has read the cursors, which is all their update has to wait for.  It is
@@ -242,6 +268,25 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
                 ticket = __hip_atomic_fetch_add((unsigned long long*)&p.memory.state[2], 1ULL, __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+        {
+            // what was read through a fallback address is dropped (lanes past n keep the zeros).  (The integers pass through an
+            // empty asm: the compiler would otherwise test / mask / increment them inside the request block above, i.e. wait
+            // for the requests before the cursors are asked for.)
+            unsigned rec_u = rec_, st_u = st_;
+            asm volatile("" : "+v"(rec_u), "+v"(st_u), "+v"(lg_len_), "+v"(lg_viol_), "+v"(lg_rec_), "+v"(t_));
+            const bool lg = p.log_state != nullptr, sel = p.sel_z != nullptr, from_head = sel && !p.sel_rec_action;
+            const rrl_policy_head_t& hd = p.sel_rec_head;
+            if (lg) { lg_len = lg_len_; lg_ret = lg_ret_; lg_viol = lg_viol_; lg_rec = lg_rec_; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { zu[k] = zu_[k]; zw[k] = zw_[k]; hh[0][k] = hh_[0][k]; hh[1][k] = hh_[1][k]; }
+            ra_in = ra_;
+            he[0] = (from_head && hd.eps) ? he_[0] : 0.f;
+            he[1] = (from_head && hd.eps) ? he_[1] : 0.f;
+            act_in = act_;
+            rec_in = (!sel && p.recovery) ? rec_u != 0 : false;
+            t_in = a.status ? int32_t(st_u & 0xfffu) : t_;
+            obs_in = obs_;
         }
         int s0 = 0, s1 = 0;       // super-chunks of the workgroup's first and last safety-buffer slot of this pass
         // the two workgroup sums cover a pass whose consecutive slots touch at most two super-chunks: always, unless
@@ -260,8 +305,9 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             // the rows this env overwrites: what the positive counts lose (replay_device.hpp), requested before the step
             const int64_t mslot = rrl_replay::ring_slot(p.memory, mpos, i);
             const int64_t rslot = p.use_recovery_memory ? rrl_replay::ring_slot(p.recovery_memory, rpos, i) : 0;
-            const int mwas = rrl_replay::was_positive(p.memory, mslot, msize);
-            const int rwas = p.use_recovery_memory ? rrl_replay::was_positive(p.recovery_memory, rslot, rsize) : 0;
+            const rrl_replay::WasRow mrow = rrl_replay::was_positive_request(p.memory, mslot, msize, a.pos + i);
+            const rrl_replay::WasRow rrow = rrl_replay::was_positive_request(
+                p.use_recovery_memory ? p.recovery_memory : p.memory, rslot, p.use_recovery_memory ? rsize : 0, a.pos + i);
             float2 act;
             if (p.sel_z) {
                 // the partial sums added in the fixed order of the sum kernel
@@ -334,9 +380,10 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             const float mask = dn ? 0.0f : 1.0f;
             const float prew = rew - (cons ? p.reward_penalty : 0.0f);
             const float2 stored = p.push_real_action ? act : task;
-            rrl_replay::store_values(p.memory, mslot, mwas, prev, stored, prew, nobs, mask);
+            rrl_replay::store_values(p.memory, mslot, rrl_replay::was_positive_of(mrow), prev, stored, prew, nobs, mask);
             if (p.use_recovery_memory)
-                rrl_replay::store_values(p.recovery_memory, rslot, rwas, prev, act, cons ? 1.0f : 0.0f, nobs, mask,
+                rrl_replay::store_values(p.recovery_memory, rslot, rrl_replay::was_positive_of(rrow), prev, act,
+                                         cons ? 1.0f : 0.0f, nobs, mask,
                                          block_sums ? super_acc : nullptr, s0);
             // episode accounting
             log_rew = rew;
