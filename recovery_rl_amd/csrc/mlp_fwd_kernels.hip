@@ -227,8 +227,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
 #pragma unroll
     for (int t = 0; t < R; ++t) {
         const int xrow = min(m0 + 16 * t + i, M - 1);
-        const float xv = a.x[(long long)xrow * a.ldx + min(q, din - 1)];
-        xa[t] = (q < din) ? xv : 0.f;
+        xa[t] = a.x[(long long)xrow * a.ldx + min(q, din - 1)];      // raw: lanes q >= din are zeroed below, behind the input head
     }
     if (a.use_in_head) {
         // lanes q = 0, 1 carry the observation, lanes q = 2, 3 the action dimension j = q - 2 of the policy head for
@@ -242,26 +241,52 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         const bool writer = z == 0 && g == 0;
         float* xs = h2s;                                 // [R * 16][4]
         if (wave == 0) {
+            // every operand of the head for all R row tiles is requested first, optional ones through a selected address (the
+            // row's own x element when absent) instead of under a branch: a load under a branch is waited for where the
+            // branch ends, and noise / partial sums / observation were four round trips in a row before the weights
+            const bool gauss = hd.kind == RRL_HEAD_GAUSS;
+            const float sc = hd.scale[j], bi = hd.bias[j];
+            float e_[R], mp[R][4], rp[R][4], ob_[R], lstd_;
+            {
+                const float* safe = a.x + (long long)min(m0 + i, M - 1) * a.ldx;
+                lstd_ = *(hd.log_std ? hd.log_std + j : safe);
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    const int row = min(m0 + 16 * t + i, M - 1);
+                    e_[t] = *(hd.eps ? hd.eps + 2 * row + j : safe);
+                    const long long im = gauss ? 4 * row + j : 2 * row + j, ir = gauss ? 4 * row + 2 + j : im;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {      // (min, not a select to part 0: the compiler turns that into branches around the loads)
+                        mp[t][k] = hd.head[min(k, hd.n_part - 1) * hd.part_stride + im];
+                        rp[t][k] = hd.head[min(k, hd.n_part - 1) * hd.part_stride + ir];
+                    }
+                    ob_[t] = *(hd.obs_in ? hd.obs_in + 2 * row + (q & 1) : safe);
+                }
+            }
+            const auto fold = [&](const float (&v)[4]) {
+                float x = v[0];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) x = hd.n_part > k ? x + v[k] : x;
+                return x;
+            };
 #pragma unroll
             for (int t = 0; t < R; ++t) {
                 const int row = min(m0 + 16 * t + i, M - 1);
                 const bool row_ok = m0 + 16 * t + i < M;
                 float val, lp_term = 0.f;
-                const float e = hd.eps ? hd.eps[2 * row + j] : 0.f;
-                const float sc = hd.scale[j], bi = hd.bias[j];
-                if (hd.kind == RRL_HEAD_GAUSS) {
-                    const float mean = loss::psum(hd.head, 4 * row + j, hd.n_part, hd.part_stride);
-                    const float ls = fminf(fmaxf(loss::psum(hd.head, 4 * row + 2 + j, hd.n_part, hd.part_stride),
-                                                 loss::kLogSigMin), loss::kLogSigMax);
+                const float e = hd.eps ? e_[t] : 0.f;
+                if (gauss) {
+                    const float mean = fold(mp[t]);
+                    const float ls = fminf(fmaxf(fold(rp[t]), loss::kLogSigMin), loss::kLogSigMax);
                     const float y = tanhf(mean + expf(ls) * e);
                     val = y * sc + bi;
                     lp_term = -0.5f * e * e - ls - 0.918938533204672742f - logf(sc * (1.f - y * y) + loss::kEps);
                 } else {
-                    const float mean = tanhf(loss::psum(hd.head, 2 * row + j, hd.n_part, hd.part_stride)) * sc + bi;
-                    val = mean + expf(fmaxf(hd.log_std[j], hd.min_log_std)) * e;
+                    const float mean = tanhf(fold(mp[t])) * sc + bi;
+                    val = mean + expf(fmaxf(lstd_, hd.min_log_std)) * e;
                 }
                 const float other = __shfl_xor(lp_term, 16);           // lane (i, 2) <-> lane (i, 3)
-                float xv = xa[t];
+                float xv = (q < din) ? xa[t] : 0.f;
                 if (q >= 2) {
                     xv = val;
                     if (writer && row_ok) {
@@ -269,7 +294,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
                         if (hd.logp && q == 2) hd.logp[row] = lp_term + other;
                     }
                 } else if (hd.obs_in) {
-                    xv = hd.obs_in[2 * row + q];
+                    xv = ob_[t];
                     if (writer && row_ok && hd.obs_out) hd.obs_out[(long long)row * hd.ld_action + q] = xv;
                 }
                 xs[(16 * t + i) * 4 + q] = xv;
@@ -279,6 +304,9 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
 #pragma unroll
         for (int t = 0; t < R; ++t) xa[t] = xs[(16 * t + i) * 4 + q];
         __syncthreads();                                 // h2s is reused by layer 2 (and aliases h1s for R > 1)
+    } else {
+#pragma unroll
+        for (int t = 0; t < R; ++t) xa[t] = (q < din) ? xa[t] : 0.f;
     }
     float w1b[kU], bias1[kU];
 #pragma unroll
