@@ -467,8 +467,10 @@ __device__ __forceinline__ void mlp3_fwd_split_group_body(const StackGroup& sg, 
 }
 
 // Solo launch: grid (row tiles x heads x column splits of the largest member, members) -- see mlp_common.hpp.
-// (Requesting the weights before the input head is evaluated instead of behind its barriers was tried with it: the 4096-row
-// forward went 18.5 -> 23.8 us, the 256-row ones +0.3 us.  Not kept.)
+// (Requesting the weights before the input head is evaluated instead of behind its barriers was tried twice -- as written, and
+// raw with the selects behind the head, for the 256-row forwards only: 4096-row forward 18.5 -> 23.8 us / 256-row ones 7.0 ->
+// 8.3 us.  The 64 KB of W2 per workgroup are a throughput term; ahead of the head's few operands they delay the one wave
+// whose tanh / exp / log chain everybody waits for.  Not kept.)
 template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
