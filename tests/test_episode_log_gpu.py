@@ -180,19 +180,22 @@ def test_info_envs_on_the_unfused_step_of_the_maze(tmp_path):
             np.testing.assert_array_equal(a["next_state"], b["state"])
 
 
-@pytest.mark.parametrize("env_name,extra", [("navigation1", []), ("maze", ["--pos_fraction=0.3"])])
-def test_log_advanced_by_the_fused_step_equals_the_stand_alone_launch(env_name, extra):
+@pytest.mark.parametrize("env_name,extra,n", [("navigation1", [], 768), ("maze", ["--pos_fraction=0.3"], 768),
+                                              ("navigation1", [], 20480), ("navigation1", [], 300000)])
+def test_log_advanced_by_the_fused_step_equals_the_stand_alone_launch(env_name, extra, n):
     """rrl_step_push_t.log_*: the env-step launch advances the episode table from its registers (what the lock-step driver
     runs: compact env state, no per-env outputs).  Against the same loop on the array path with the stand-alone
     rrl_episode_log_append fed from the step's outputs: same records, same accumulators, same iteration counter -- eagerly
-    and through a replayed graph."""
+    and through a replayed graph.  n = 768: the latency variant of the step kernel (slots reserved per wave, early);
+    20480 / 300000: its two bandwidth variants (256- / 1024-thread workgroups, slots reserved once per workgroup, cursors advanced
+    by the one-thread launch behind the step)."""
     import bench
     loops, logs = [], []
     for fused in (True, False):
-        cfg = arg_utils.get_args(["--env-name", env_name, "--cuda", "--use_recovery", "--MF_recovery", "--num_envs", "768",
+        cfg = arg_utils.get_args(["--env-name", env_name, "--cuda", "--use_recovery", "--MF_recovery", "--num_envs", str(n),
                                   "--seed", "9"] + extra)
         loop = bench.build_loop(cfg, torch.device(DEV), pretrain=5)
-        log = EpisodeLog(768, 768 * 40, DEV)
+        log = EpisodeLog(n, n * (40 if n < 10000 else 24), DEV)
         if fused:
             loop.episode_log = log
         else:

@@ -309,14 +309,16 @@ def test_full_size_properties_4096x100():
 
 
 @pytest.mark.parametrize("env", ENVS)
-@pytest.mark.parametrize("with_outputs,n,cap", [(True, 1500, 4000), (False, 1500, 4000), (True, 40000, 100000)])
+@pytest.mark.parametrize("with_outputs,n,cap", [(True, 1500, 4000), (False, 1500, 4000), (True, 40000, 100000),
+                                                (False, 300000, 700000)])
 def test_fused_step_push_matches_oracle_step_plus_pushes(env, with_outputs, n, cap):
     """rrl_nav_step_push == oracle nav_step + two oracle replay pushes + counters, over a wrap-around; with and without
     the optional per-env output arrays (next_obs, reward, flags: NULL = not written, everything else unchanged)."""
     import ctypes as C
     from recovery_rl_amd.replay_memory import ConstraintReplayMemory, ReplayMemory
     lib = _lib.load()
-    rng = np.random.RandomState(4)      # n = 40000: the bandwidth-regime instance (reset after the step, counts per workgroup)
+    rng = np.random.RandomState(4)      # n = 40000 / 300000: the bandwidth-regime instances (256- / 1024-thread workgroups: reset
+                                        # after the step, counts per workgroup, cursors advanced by the launch behind the step)
     venv = make_vec_env(env, n, device=DEV, seed=31)
     venv.reset()
     mem, rmem = ReplayMemory(cap, 1, device=DEV), ConstraintReplayMemory(cap, 1, device=DEV)
