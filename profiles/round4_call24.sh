@@ -8,7 +8,7 @@ for L in prev new; do
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', round(d['ms_per_step'],5), round(d['value']/1e6,3))"
 done; done
 unset RRL_HIP_LIB
-(timeout 1200 python -m pytest tests/test_fast_update_gpu.py tests/test_packed_gpu.py tests/test_loop_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -8) > gpurun_out/r4_pytest_g16.txt 2>&1; tail -4 gpurun_out/r4_pytest_g16.txt | cut -c1-300
+(timeout 1200 python -m pytest tests/test_fast_update_gpu.py tests/test_packed_gpu.py tests/test_loop_gpu.py tests/test_replay_gpu.py tests/test_demo_share_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -8) > gpurun_out/r4_pytest_g16.txt 2>&1; tail -4 gpurun_out/r4_pytest_g16.txt | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt_new
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_new -o p -- python $R/bench.py --no_legs --no_cpu_baseline --steps 1000 --warmup 100 --min_seconds 0 > /tmp/kt_new.log 2>&1

@@ -221,12 +221,12 @@ __device__ __forceinline__ void sample_gather_body(const rrl_replay_t& rb, int B
     unsigned long long* table = (unsigned long long*)smem;      // [table_mask + 1]
     uint32_t* key = (uint32_t*)(table + table_mask + 1);
     const int64_t size = rb.state[1];
+    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);      // requested with the size, not behind its test
     if (int64_t(B) > size) {  // random.sample would raise ValueError
         if (threadIdx.x == 0) rb.state[3] = 1;
         return;
     }
-    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
-    rrl::advance_counter_blocks(counter_dev, counter_inc, 1);        // one workgroup per draw
+    rrl::advance_counter_single(counter_dev, counter_inc, counter, ctr);        // one workgroup per draw
     const int i = threadIdx.x;
     if (!draw_distinct(i, B, 0, uint64_t(size), seed, rrl::kStreamSample, ctr, i, key, table, table_mask)) {
         if (threadIdx.x == 0) rb.state[3] = 2;
@@ -307,7 +307,7 @@ __device__ __forceinline__ void creplay_sample_gather_body(const rrl_replay_t& r
         n_neg = B - n_pos;
     }
     const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
-    rrl::advance_counter_blocks(counter_dev, counter_inc, 1);
+    rrl::advance_counter_single(counter_dev, counter_inc, counter, ctr);
     const bool is_pos = tid < n_pos;
     const uint64_t population = uint64_t(is_pos ? total_pos : total_neg);
     const uint32_t stream = is_pos ? rrl::kStreamSample : rrl::kStreamSampleNeg;
@@ -433,7 +433,7 @@ __device__ __forceinline__ void split_sample_gather_body(const rrl_replay_t& rb,
     if (int64_t(n_online) > online_total) { n_online = int(online_total); n_demo = B - n_online; }
     else if (int64_t(n_demo) > demo_total) { n_demo = int(demo_total); n_online = B - n_demo; }
     const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
-    rrl::advance_counter_blocks(counter_dev, counter_inc, 1);
+    rrl::advance_counter_single(counter_dev, counter_inc, counter, ctr);
     const bool is_demo = tid < n_demo;
     const uint64_t population = uint64_t(is_demo ? demo_total : online_total);
     const uint32_t stream = is_demo ? rrl::kStreamSample : rrl::kStreamSampleNeg;

@@ -196,6 +196,16 @@ __device__ __forceinline__ void advance_counter_blocks(uint64_t* dev, uint64_t i
     }
 }
 
+// ... and when ONE workgroup consumes the tick (the samplers): no ticket, no second read -- thread 0 stores what it read + inc
+// (`ctr` = effective_counter(counter, dev) as read by this workgroup).  The ticket's round trip and the re-read of dev[0]
+// were ~1.5 us in the middle of a 7 us kernel.
+__device__ __forceinline__ void advance_counter_single(uint64_t* dev, uint64_t inc, uint64_t counter, uint64_t ctr) {
+    if (!dev || !inc) return;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's read of the tick has returned ...
+    __syncthreads();                                                  // ... and so has every other wave's
+    if (threadIdx.x == 0) dev[0] = ctr - counter + inc;
+}
+
 __device__ __forceinline__ void advance_counter(uint64_t* dev, uint64_t inc) {
     advance_counter_blocks(dev, inc, gridDim.x);
 }
