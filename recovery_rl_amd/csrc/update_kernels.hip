@@ -458,7 +458,10 @@ __device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec
         ticket = __hip_atomic_fetch_add((unsigned long long*)&sg.step_dev[1], 1ULL, __ATOMIC_RELAXED,   // is an L2 write-back)
                                         __HIP_MEMORY_SCOPE_AGENT);
         sh[0] = lr / float(1.0 - pow(double(b1), t));
-        sh[1] = float(sqrt(1.0 - pow(double(b2), t)));
+    } else if (threadIdx.x == 64) {
+        // the second bias correction on another wave: each double pow is a ~230-instruction dependent chain (~1 us) that the
+        // whole workgroup waits for at the barrier below -- side by side instead of one behind the other
+        sh[1] = float(sqrt(1.0 - pow(double(b2), double(step + 1))));
     }
     __syncthreads();
     adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, sg.weight_decay, sg.g2,
