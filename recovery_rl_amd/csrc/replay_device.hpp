@@ -87,10 +87,12 @@ struct WasRow {
     float r;
     bool look;
 };
+template <bool BRANCH_FREE = true>
 __device__ __forceinline__ WasRow was_positive_request(const rrl_replay_t& rb, int64_t slot, int64_t size, const void* safe) {
     WasRow w;
     w.look = rb.pos_cnt && slot < size;
-    w.r = *(w.look ? rb.r + slot : reinterpret_cast<const float*>(safe));
+    if constexpr (BRANCH_FREE) w.r = *(w.look ? rb.r + slot : reinterpret_cast<const float*>(safe));
+    else w.r = w.look ? rb.r[slot] : 0.f;
     return w;
 }
 __device__ __forceinline__ int was_positive_of(const WasRow& w) { return w.look ? int(w.r != 0.0f) : 0; }

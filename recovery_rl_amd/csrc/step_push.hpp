@@ -193,16 +193,19 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             // for where the branch ends (the merged register must hold the value there): the optional groups below were five
             // round trips in a row instead of one.
             const void* const safe = a.pos + i;
-            const auto at = [&](const auto* arr, long long idx) {
+            // (bandwidth variants: under the branch after all -- with thousands of waves in flight nobody waits for one wave's
+            // round trips, and the stand-in requests are traffic: 50.7 -> 58.8 us at 2^20 envs)
+            const auto rd = [&](const auto* arr, long long idx) {
                 using T = std::remove_cv_t<std::remove_pointer_t<decltype(arr)>>;
-                return arr ? arr + idx : reinterpret_cast<const T*>(safe);
+                if constexpr (SPECULATE) return *(arr ? arr + idx : reinterpret_cast<const T*>(safe));
+                else return arr ? arr[idx] : T{};
             };
             ep_rew_in = p.ep_reward[i];
             const bool lg = p.log_state != nullptr;
-            lg_len_ = *at(lg ? p.log_len : nullptr, i);
-            lg_ret_ = *at(lg ? p.log_ret : nullptr, i);
-            lg_viol_ = *at(lg ? p.log_viol : nullptr, i);
-            lg_rec_ = *at(lg ? p.log_rec : nullptr, i);
+            lg_len_ = rd(lg ? p.log_len : nullptr, i);
+            lg_ret_ = rd(lg ? p.log_ret : nullptr, i);
+            lg_viol_ = rd(lg ? p.log_viol : nullptr, i);
+            lg_rec_ = rd(lg ? p.log_rec : nullptr, i);
             pp = a.pos[i];
             task = *reinterpret_cast<const float2*>(p.task_action + i * p.ld_task);
             // the gate's partial sums (up to four, all loads issued together) and the recovery action or the head it comes from
@@ -211,26 +214,26 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             const long long ps = p.sel_ps;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                zu_[k] = *at(p.sel_z, i + (np > k ? k * ps : 0));
-                zw_[k] = *at(p.sel_z, i + (np > k ? k * ps : 0) + a.n);
+                zu_[k] = rd(p.sel_z, i + (np > k ? k * ps : 0));
+                zw_[k] = rd(p.sel_z, i + (np > k ? k * ps : 0) + a.n);
             }
-            ra_ = *at(sel ? p.sel_rec_action : nullptr, i);
+            ra_ = rd(sel ? p.sel_rec_action : nullptr, i);
             const rrl_policy_head_t& hd = p.sel_rec_head;
             const bool from_head = sel && !p.sel_rec_action;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    hh_[jj][k] = *at(from_head ? hd.head : nullptr, 2 * i + jj + (hd.n_part > k ? k * hd.part_stride : 0));
-                he_[jj] = *at(from_head ? hd.eps : nullptr, 2 * i + jj);
+                    hh_[jj][k] = rd(from_head ? hd.head : nullptr, 2 * i + jj + (hd.n_part > k ? k * hd.part_stride : 0));
+                he_[jj] = rd(from_head ? hd.eps : nullptr, 2 * i + jj);
             }
-            act_ = *at(sel ? nullptr : a.action, i);
-            rec_ = *at(sel ? nullptr : p.recovery, i);
+            act_ = rd(sel ? nullptr : a.action, i);
+            rec_ = rd(sel ? nullptr : p.recovery, i);
             // compact layout: the observation IS float(pos) (that is what this kernel and the resets store), so the 8-byte
             // read is dropped, and the step count comes out of the status word
-            st_ = *at(a.status, i);
-            t_ = *at(a.status ? nullptr : a.t, i);
-            obs_ = *at(a.status ? nullptr : a.obs, i);
+            st_ = rd(a.status, i);
+            t_ = rd(a.status ? nullptr : a.t, i);
+            obs_ = rd(a.status ? nullptr : a.obs, i);
         }
         // plain (wave-uniform: scalar) loads of the cursors; the ticket below is issued only after they have RETURNED (s_waitcnt)
         // and the compiler may not move them past it ("memory" clobber), so a workgroup's read of a cursor cannot slip behind its
@@ -305,8 +308,8 @@ __device__ __forceinline__ void step_push_body(const StepPushArgs& p, const unsi
             // the rows this env overwrites: what the positive counts lose (replay_device.hpp), requested before the step
             const int64_t mslot = rrl_replay::ring_slot(p.memory, mpos, i);
             const int64_t rslot = p.use_recovery_memory ? rrl_replay::ring_slot(p.recovery_memory, rpos, i) : 0;
-            const rrl_replay::WasRow mrow = rrl_replay::was_positive_request(p.memory, mslot, msize, a.pos + i);
-            const rrl_replay::WasRow rrow = rrl_replay::was_positive_request(
+            const rrl_replay::WasRow mrow = rrl_replay::was_positive_request<SPECULATE>(p.memory, mslot, msize, a.pos + i);
+            const rrl_replay::WasRow rrow = rrl_replay::was_positive_request<SPECULATE>(
                 p.use_recovery_memory ? p.recovery_memory : p.memory, rslot, p.use_recovery_memory ? rsize : 0, a.pos + i);
             float2 act;
             if (p.sel_z) {

@@ -118,5 +118,5 @@ def test_step_push_has_no_loop_and_few_sgpr_spills(tmp_path):
     assert len(hits) == 6, sorted(hits)          # two env kinds x three launch shapes
     for k, v in hits.items():
         lanes = v["ins"].get("v_readlane_b32", 0) + v["ins"].get("v_writelane_b32", 0)
-        assert lanes <= 400, (k, lanes)
+        assert lanes <= 500, (k, lanes)
         assert sum(v["ins"].values()) <= 3300, (k, sum(v["ins"].values()))
