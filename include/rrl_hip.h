@@ -507,6 +507,13 @@ int rrl_mlp_head_backward_loss(const rrl_loss_t* loss, int G, int B, int H, int 
  *                                 dOut tensor as in rrl_mlp_head_backward)
  *   rrl_mlp_hidden_backward_multi members = rrl_mlp_hidden_backward calls; dW2 = db2 = NULL: only dh1
  *   rrl_mlp_input_backward_multi  members = rrl_mlp_input_backward calls
+ *   rrl_mlp_backward_pair_multi   = rrl_mlp_head_backward_multi(n, heads) followed by rrl_mlp_hidden_backward_multi(n, hidden),
+ *                                 stack k's two stages linked by heads[k].dh2 == hidden[k].dh2.  When every member is a
+ *                                 critic-loss kind (RRL_LOSS_SAC_CRITIC .. RRL_LOSS_QRISK_POLICY, one output) with full
+ *                                 aligned tiles, both stages go out as ONE launch: the hidden-backward tiles derive dh2
+ *                                 from the saved activation h2, the loss description and W3 themselves, and dh2 is then
+ *                                 NOT written (it is scratch between the two stages, sac.py:216-239 / qrisk.py:150-182
+ *                                 as autograd would hold it).  Anything else: the two launches.  Same gradients, bit for bit.
  * ------------------------------------------------------------------------------------------ */
 /* use_in_head != 0 (din = 4, column-split path only): columns 2..3 of the stack's input are not read from x but computed
  * -- the action in_head yields for the same row (in_head.B is ignored: the stack's M rows) -- so the policy head needs no
@@ -556,6 +563,7 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* stacks, void* stream);
 int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* members, void* stream);
 int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* members, void* stream);
 int rrl_mlp_input_backward_multi(int n, const rrl_input_bwd_t* members, void* stream);
+int rrl_mlp_backward_pair_multi(int n, const rrl_head_bwd_t* heads, const rrl_hidden_bwd_t* hidden, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Fused element-wise pieces of the updates (one launch each instead of a chain of PyTorch ops).

@@ -46,7 +46,7 @@ EXPORTS = [
     "rrl_cem_sample", "rrl_cem_update", "rrl_cem_begin", "rrl_cem_sample_n", "rrl_cem_update_n", "rrl_cem_finish",
     "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss", "rrl_mlp_hidden_backward",
     "rrl_mlp_input_backward", "rrl_mlp3_forward_multi", "rrl_mlp_head_backward_multi", "rrl_mlp_hidden_backward_multi",
-    "rrl_mlp_input_backward_multi", "rrl_policy_heads_fwd_multi",
+    "rrl_mlp_input_backward_multi", "rrl_mlp_backward_pair_multi", "rrl_policy_heads_fwd_multi",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_adam_step_multi", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
@@ -259,6 +259,7 @@ def _declare(lib):
         "rrl_mlp_head_backward_multi": (ci, [ci, C.POINTER(rrl_head_bwd_t), vp]),
         "rrl_mlp_hidden_backward_multi": (ci, [ci, C.POINTER(rrl_hidden_bwd_t), vp]),
         "rrl_mlp_input_backward_multi": (ci, [ci, C.POINTER(rrl_input_bwd_t), vp]),
+        "rrl_mlp_backward_pair_multi": (ci, [ci, C.POINTER(rrl_head_bwd_t), C.POINTER(rrl_hidden_bwd_t), vp]),
         "rrl_policy_heads_fwd_multi": (ci, [ci, C.POINTER(rrl_policy_head_t), vp]),
         "rrl_sample_multi_packed": (ci, [ci, C.POINTER(rrl_sample_args_t), vp]),
         "rrl_pack_clear": (ci, []),

@@ -137,8 +137,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 // panels in flight instead of one -- with K = 2 PANEL every operand of the tile is requested before the first wait -- and the
 // epilogue's operands (bias, relu mask, the first layer's x and W1 rows) requested with them instead of behind the K loop.
 // Same MFMA steps on the same operands in the same order: the same bits.
-template <int MODE, bool FAST, int PANEL = kPanel, bool DEEP = false>  // MODE: 0 NT, 1 NN, 2 TN
-__device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g) {
+// GEN (the fused head + hidden backward, backward_pair_kernel): the left operand dh2 of both products is not read but derived
+// where it is consumed -- a.A points at the saved activation h2 (same shape), and dh2[b][h] = h2[b][h] > 0 ? dOut[b] W3[h] : 0
+// with dOut[b] in LDS (`dsh`, one output per row: the critic-loss kinds) and the head's W3 row `w3` -- the value
+// head_bwd_loss_body would have stored, bit for bit (fmaf(go, w, 0)).  WSYNC: several tiles share a workgroup (one wave each,
+// LDS regions of their own): wave-level syncs instead of workgroup barriers.
+template <int MODE, bool FAST, int PANEL = kPanel, bool DEEP = false, bool GEN = false, bool WSYNC = false>  // MODE: 0 NT, 1 NN, 2 TN
+__device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g,
+                                            const float* dsh = nullptr, const float* w3 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int m0 = by * kTile, n0 = bx * kTile;
     const float* A = a.A + g * a.sA;
@@ -151,19 +157,35 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;  // TN: running sum of my A operands (for colsum)
     Frag fa, fb, na, nb;
+    Frag fw, nw;          // GEN, NN: the W3 elements that go with the k-contiguous dh2 fragments
+    float4 w3c = make_float4(0.f, 0.f, 0.f, 0.f);      // GEN, TN: W3 of the lane's four dh2 columns
+    const auto sync = [&]() {
+        if constexpr (WSYNC) wave_lds_sync();
+        else __syncthreads();
+    };
 
-    auto load_into = [&](Frag& ra, Frag& rb, int k0) {
+    auto load_into = [&](Frag& ra, Frag& rb, Frag& rw, int k0) {
         if (kStageA) load_staged<FAST>(ra, A, a.lda, m0, a.M, k0, a.K, lane);
         else load_direct<FAST>(ra, A, a.lda, m0, a.M, k0, a.K, lane);
         if (kStageB) load_staged<FAST>(rb, B, a.ldb, n0, a.N, k0, a.K, lane);
         else load_direct<FAST>(rb, B, a.ldb, n0, a.N, k0, a.K, lane);
+        if constexpr (GEN && MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) rw.v[j] = *reinterpret_cast<const float4*>(w3 + k0 + 16 * j + 4 * (lane >> 4));
+        }
     };
-    auto load = [&](int k0) { load_into(fa, fb, k0); };
+    auto load = [&](int k0) { load_into(fa, fb, fw, k0); };
+    if constexpr (GEN && MODE == 2) w3c = *reinterpret_cast<const float4*>(w3 + m0 + (lane & 3) * 4);
+    // dh2 from (h2 fragment, dOut, W3): the formula of head_bwd_loss_body for one output
+    const auto gen4 = [](const float4& h, float go, const float4& w) {
+        return make_float4(h.x > 0.f ? fmaf(go, w.x, 0.f) : 0.f, h.y > 0.f ? fmaf(go, w.y, 0.f) : 0.f,
+                           h.z > 0.f ? fmaf(go, w.z, 0.f) : 0.f, h.w > 0.f ? fmaf(go, w.w, 0.f) : 0.f);
+    };
 
     const int np = (a.K + PANEL - 1) / PANEL;
     const int i = lane & 15, q = lane >> 4;
     load(0);
-    if (DEEP && np > 1) load_into(na, nb, PANEL);
+    if (DEEP && np > 1) load_into(na, nb, nw, PANEL);
     // DEEP: the epilogue's operands, requested now
     const int ecol = n0 + (lane & 15);
     float pre_bias = 0.f, pre_mask[4] = {1.f, 1.f, 1.f, 1.f}, pre_x = 0.f, pre_w = 0.f;
@@ -184,15 +206,25 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
     }
     for (int p = 0; p < np; ++p) {
         Frag ca = fa, cb = fb;           // operands of this panel (registers)
+        if constexpr (GEN) {
+            if constexpr (MODE == 2) {           // staged [k = batch row][4 dh2 columns]
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) ca.v[j] = gen4(fa.v[j], dsh[p * PANEL + (lane >> 2) + 16 * j], w3c);
+            } else {                             // direct: row m0 + i, four consecutive hidden columns per fragment
+                const float go = dsh[m0 + (lane & 15)];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) ca.v[j] = gen4(fa.v[j], go, fw.v[j]);
+            }
+        }
         if (kStageA || kStageB) {
-            if (p) __syncthreads();      // the previous panel's LDS reads are done
-            if (kStageA) store_staged(fa, As, lane);
-            if (kStageB) store_staged(fb, Bs, lane);
-            __syncthreads();
+            if (p) sync();               // the previous panel's LDS reads are done
+            if (kStageA) store_staged(ca, As, lane);
+            if (kStageB) store_staged(cb, Bs, lane);
+            sync();
         }
         if constexpr (DEEP) {
-            if (p + 1 < np) { fa = na; fb = nb; }                       // the panel behind this one is on its way already
-            if (p + 2 < np) load_into(na, nb, (p + 2) * PANEL);
+            if (p + 1 < np) { fa = na; fb = nb; fw = nw; }              // the panel behind this one is on its way already
+            if (p + 2 < np) load_into(na, nb, nw, (p + 2) * PANEL);
         } else {
             if (p + 1 < np) load((p + 1) * PANEL);   // next panel's global loads fly under the MFMAs
         }
@@ -245,12 +277,12 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
             const int rr = lane & 15, dd = lane >> 4;
             const float xv = DEEP ? pre_x : (dd < a.din ? a.x[(long long)(m0 + rr) * a.ldx + dd] : 0.f);
             const float wv = DEEP ? pre_w : (dd < a.din ? a.W1[((long long)g * a.N + n0 + rr) * a.din + dd] : 0.f);
-            __syncthreads();
+            sync();
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = vout[r];
             T[272 + rr * 4 + dd] = xv;
             T[336 + rr * 4 + dd] = wv;
-            __syncthreads();
+            sync();
             float sw = 0.f, sb = 0.f, sx = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -1050,6 +1082,68 @@ __global__ __launch_bounds__(256) void head_bwd_pack_kernel(const HeadBwdGroup* 
     head_bwd_group_body(groups[s], local, red, dsh);
 }
 
+// ---- head backward + hidden backward of the critic-loss kinds in ONE launch ----------------------------------------------
+// The two stages are dependent through dh2 [G,B,H] only, and with one output per row dh2[b][h] = h2[b][h] > 0 ? dOut[b] W3[h] : 0
+// is cheaper to derive where the hidden backward consumes it than to write and read back: the tiles evaluate dOut[b] for their
+// head themselves (the loss formulas: a handful of loads and a sigmoid per row) and gemm16_tile<GEN> builds the operand from
+// the saved activation h2.  The head-backward workgroups (dW3, db3, the loss scalars) ride in the same grid and no longer
+// write dh2.  One launch instead of two dependent ones (~5.5 us each time).  Every value is the one the two-launch path
+// produces: same dOut formulas, fmaf(go, w, 0) for dh2, the same MFMA steps in the same order (the K order does not depend on
+// the panel width).
+// grid (x, member, 3): z = 0 input-gradient tiles (NN), z = 1 weight-gradient tiles (TN) -- four tiles per 256-thread
+// workgroup, one wave each, 64-wide K panels (10 KB of LDS per tile) -- z = 2 the head backward's column blocks.
+constexpr int kPairPanel = 64;
+constexpr int kPairTileFloats = 2 * kPairPanel * kLd;
+struct PairJobs {
+    HiddenJob job[kMaxGroup][2];      // [member][0: NN, 1: TN]; ga.A = the saved activation h2
+    HeadBwdArgs head[kMaxGroup];      // dh2 = null
+    int blocks_x[kMaxGroup];
+};
+__device__ __forceinline__ float critic_dout(const rrl_loss_t& la, int B, int g, int b) {
+    float term;
+    switch (la.kind) {
+        case RRL_LOSS_SAC_CRITIC: return loss::dout_at<RRL_LOSS_SAC_CRITIC>(la, B, g, b, 0, term);
+        case RRL_LOSS_SAC_POLICY: return loss::dout_at<RRL_LOSS_SAC_POLICY>(la, B, g, b, 0, term);
+        case RRL_LOSS_QRISK_CRITIC: return loss::dout_at<RRL_LOSS_QRISK_CRITIC>(la, B, g, b, 0, term);
+        default: return loss::dout_at<RRL_LOSS_QRISK_POLICY>(la, B, g, b, 0, term);
+    }
+}
+__global__ __launch_bounds__(256) void backward_pair_kernel(PairJobs pj) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * kPairTileFloats + 1024];      // tiles | dOut; or red | dsh of the head path
+    const int k = blockIdx.y, z = blockIdx.z;
+    HeadBwdArgs hb = pj.head[k];
+    const int blocks_x = pj.blocks_x[k];
+    globalize(hb);
+    const rrl_loss_t& l = hb.la;
+    if (z == 2) {
+        const int G = pj.job[k][0].G;
+        arrive_together(hb.B, hb.H, hb.dout, hb.need_w, l.kind, l.n_part, l.part_stride, l.f0, l.ld, l.n_heads, l.head_stride,
+                        l.da_parts, l.da_part_stride, blocks_x, G);
+        const int local = blockIdx.x;
+        if (local >= blocks_x * G) return;
+        head_bwd_dispatch(hb, local % blocks_x, local / blocks_x, reinterpret_cast<float (*)[4][kCols]>(smem), smem + 1024);
+        return;
+    }
+    HiddenJob j = pj.job[k][z];
+    GemmArgs& ga = j.ga;
+    globalize(ga);
+    arrive_together(ga.M, ga.N, ga.K, ga.lda, ga.ldb, ga.ldc, ga.ldmask, ga.sA, ga.sB, ga.sC, ga.sMask, ga.sColsum,
+                    ga.relu, ga.accumulate, ga.first_stride, ga.ldx, ga.din, ga.G, ga.skip_c, j.tiles, j.tiles_x, j.G, hb.B, hb.H,
+                    l.kind, l.n_part, l.part_stride, l.f0);
+    const int t0 = 4 * blockIdx.x;
+    if (t0 >= j.tiles * j.G) return;
+    const int g = t0 / j.tiles;                    // tiles % 4 == 0 (host-checked): the four tiles serve one head
+    float* dsh = smem + 4 * kPairTileFloats;
+    for (int b = threadIdx.x; b < hb.B; b += 256) dsh[b] = critic_dout(l, hb.B, g, b);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, t = t0 + wave - g * j.tiles;
+    float* As = smem + wave * kPairTileFloats;
+    float* Bs = As + kPairPanel * kLd;
+    const float* w3 = hb.W3 + (long long)g * hb.H;
+    if (z == 1) gemm16_tile<2, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3);
+    else gemm16_tile<1, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3);
+}
+
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
 //   dW1[g][h][d] = sum_b dh1[g][b][h] x[b][d]     db1[g][h] = sum_b dh1[g][b][h]          (need_w)
 //   dx[g][b][d]  = sum_h dh1[g][b][h] W1[g][h][d]                                         (need_x)
@@ -1413,6 +1507,57 @@ int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
     const int rc = build_head_group(n, ps, hg);
     if (rc != RRL_OK) return rc;
     hipLaunchKernelGGL(head_bwd_group_kernel, dim3(largest_member(hg, n), n), dim3(256), 0, (hipStream_t)stream, hg);
+    return check_launch();
+}
+
+// head backward + hidden backward of n stacks: ONE launch (backward_pair_kernel) when every member is a critic-loss kind
+// with one output, full aligned tiles and dh2 as the only link between its two stages; otherwise the two launches of
+// rrl_mlp_head_backward_multi + rrl_mlp_hidden_backward_multi.  Same results either way.
+int rrl_mlp_backward_pair_multi(int n, const rrl_head_bwd_t* heads, const rrl_hidden_bwd_t* hidden, void* stream) {
+    HeadBwdGroup hg;
+    int rc = build_head_group(n, heads, hg);
+    if (rc != RRL_OK) return rc;
+    HiddenGroup hd;
+    rc = build_hidden_group(n, hidden, hd);
+    if (rc != RRL_OK) return rc;
+    bool pair = true;
+    for (int k = 0; k < n && pair; ++k) {
+        const rrl_head_bwd_t& h = heads[k];
+        const rrl_hidden_bwd_t& d = hidden[k];
+        const int kind = h.loss.kind;
+        const int nn_tiles = hd.per_head[k] - hd.tn_tiles[k];
+        pair = kind >= RRL_LOSS_SAC_CRITIC && kind <= RRL_LOSS_QRISK_POLICY && h.dout == 1 && h.dh2 && h.dh2 == d.dh2 &&
+               h.G == d.G && h.B == d.B && h.H == d.H && h.B <= 1024 && hd.fast[k] && (h.H % kPairPanel) == 0 &&
+               (h.B % kPairPanel) == 0 && (nn_tiles % 4) == 0 && (hd.tn_tiles[k] % 4) == 0 &&
+               (reinterpret_cast<uintptr_t>(h.h2) & 15) == 0 && (reinterpret_cast<uintptr_t>(h.W3) & 15) == 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (!pair) {
+        hipLaunchKernelGGL(head_bwd_group_kernel, dim3(largest_member(hg, n), n), dim3(256), 0, st, hg);
+        HiddenJobs hj{};
+        int most = 1;
+        for (int k = 0; k < n; ++k) {
+            const int nn_tiles = hd.per_head[k] - hd.tn_tiles[k];
+            hj.job[k][0] = HiddenJob{hd.nn[k], nn_tiles, hd.nn_tiles_x[k], hd.fast[k], hidden[k].G};
+            hj.job[k][1] = HiddenJob{hd.tn[k], hd.tn_tiles[k], hd.tn_tiles_x[k], hd.fast[k], hidden[k].G};
+            most = std::max(most, std::max(hd.tn_tiles[k], nn_tiles) * hidden[k].G);
+        }
+        hipLaunchKernelGGL(gemm16_group_kernel, dim3(most, n, 2), dim3(64), 0, st, hj);
+        return check_launch();
+    }
+    PairJobs pj{};
+    int most = 1;
+    for (int k = 0; k < n; ++k) {
+        const int nn_tiles = hd.per_head[k] - hd.tn_tiles[k];
+        pj.job[k][0] = HiddenJob{hd.nn[k], nn_tiles, hd.nn_tiles_x[k], 1, hidden[k].G};
+        pj.job[k][1] = HiddenJob{hd.tn[k], hd.tn_tiles[k], hd.tn_tiles_x[k], 1, hidden[k].G};
+        pj.job[k][0].ga.A = pj.job[k][1].ga.A = heads[k].h2;          // dh2 is derived from h2 in the tiles
+        pj.head[k] = hg.p[k];
+        pj.head[k].dh2 = nullptr;
+        pj.blocks_x[k] = hg.blocks_x[k];
+        most = std::max(most, std::max(std::max(hd.tn_tiles[k], nn_tiles) * hidden[k].G / 4, hg.blocks_x[k] * heads[k].G));
+    }
+    hipLaunchKernelGGL(backward_pair_kernel, dim3(most, n, 3), dim3(256), 0, st, pj);
     return check_launch();
 }
 

@@ -336,8 +336,8 @@ def backward_multi(triples):
     record("hidden_bwd", hidden, n)
     if inputs is not None:
         record("unsupported", "rrl_mlp_input_backward_multi")
-    _lib.check(lib.rrl_mlp_head_backward_multi(len(head_list), heads, st), "rrl_mlp_head_backward_multi")
-    _lib.check(lib.rrl_mlp_hidden_backward_multi(n, hidden, st), "rrl_mlp_hidden_backward_multi")
+    # head + hidden backward: one launch for the critic-loss kinds (rrl_mlp_backward_pair_multi), else the two launches
+    _lib.check(lib.rrl_mlp_backward_pair_multi(n, heads, hidden, st), "rrl_mlp_backward_pair_multi")
     if inputs is not None:
         _lib.check(lib.rrl_mlp_input_backward_multi(len(inputs), inputs, st), "rrl_mlp_input_backward_multi")
 
