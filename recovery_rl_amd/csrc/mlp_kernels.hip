@@ -142,9 +142,16 @@ __device__ __forceinline__ void wave_lds_sync() {
 // with dOut[b] in LDS (`dsh`, one output per row: the critic-loss kinds) and the head's W3 row `w3` -- the value
 // head_bwd_loss_body would have stored, bit for bit (fmaf(go, w, 0)).  WSYNC: several tiles share a workgroup (one wave each,
 // LDS regions of their own): wave-level syncs instead of workgroup barriers.
-template <int MODE, bool FAST, int PANEL = kPanel, bool DEEP = false, bool GEN = false, bool WSYNC = false>  // MODE: 0 NT, 1 NN, 2 TN
+// `behind_requests()` runs once the tile's operands have been requested and before the first of them is looked at (GEN: the
+// workgroup evaluates dOut there, its own round trip under the operands').
+struct NothingBehindRequests {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int MODE, bool FAST, int PANEL = kPanel, bool DEEP = false, bool GEN = false, bool WSYNC = false,
+          class BEHIND = NothingBehindRequests>  // MODE: 0 NT, 1 NN, 2 TN
 __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g,
-                                            const float* dsh = nullptr, const float* w3 = nullptr) {
+                                            const float* dsh = nullptr, const float* w3 = nullptr,
+                                            BEHIND behind_requests = BEHIND()) {
     const int lane = threadIdx.x & 63;
     const int m0 = by * kTile, n0 = bx * kTile;
     const float* A = a.A + g * a.sA;
@@ -204,6 +211,7 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
             pre_w = dd < a.din ? a.W1[((long long)g * a.N + n0 + rr) * a.din + dd] : 0.f;
         }
     }
+    behind_requests();
     for (int p = 0; p < np; ++p) {
         Frag ca = fa, cb = fb;           // operands of this panel (registers)
         if constexpr (GEN) {
@@ -1134,14 +1142,20 @@ __global__ __launch_bounds__(256) void backward_pair_kernel(PairJobs pj) {
     if (t0 >= j.tiles * j.G) return;
     const int g = t0 / j.tiles;                    // tiles % 4 == 0 (host-checked): the four tiles serve one head
     float* dsh = smem + 4 * kPairTileFloats;
-    for (int b = threadIdx.x; b < hb.B; b += 256) dsh[b] = critic_dout(l, hb.B, g, b);
-    __syncthreads();
+    // dOut of the head, evaluated by the whole workgroup BEHIND the four tiles' operand requests (all four waves hold a tile:
+    // every wave passes the barrier once)
+    const auto eval_dout = [&]() {
+        for (int b = threadIdx.x; b < hb.B; b += 256) dsh[b] = critic_dout(l, hb.B, g, b);
+        __syncthreads();
+    };
     const int wave = threadIdx.x >> 6, t = t0 + wave - g * j.tiles;
     float* As = smem + wave * kPairTileFloats;
     float* Bs = As + kPairPanel * kLd;
     const float* w3 = hb.W3 + (long long)g * hb.H;
-    if (z == 1) gemm16_tile<2, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3);
-    else gemm16_tile<1, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3);
+    if (z == 1)
+        gemm16_tile<2, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3, eval_dout);
+    else      // (128-wide panels for these tiles -- they stage one operand only, 10 KB either way -- measured: 10.4 -> 13.8 us)
+        gemm16_tile<1, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3, eval_dout);
 }
 
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
