@@ -383,8 +383,27 @@ def roofline_stages(a, device, iteration_ms):
         return 2.0 * G * M * (din * H + H * H + H * dout)
 
     rows = []
-    for op in tape:
+    skip = False
+    for pos, op in enumerate(tape):
         kind = op[0]
+        if skip:                      # the hidden backward that went out with the head backward before it
+            skip = False
+            continue
+        if kind == "head_bwd" and pos + 1 < len(tape) and tape[pos + 1][0] == "hidden_bwd" and tape[pos + 1][2] == op[2]:
+            # what the solo iteration launches for such a pair (fast_update.backward_multi): rrl_mlp_backward_pair_multi -- ONE
+            # launch for the critic-loss kinds, the two launches inside the entry point for the policy-head kinds
+            heads, hid, n = op[1], tape[pos + 1][1], op[2]
+            fl = 0.0
+            for k in range(n):
+                h = hid[k]
+                fl += 2.0 * h.G * h.B * h.H * h.H * (2 if h.dW2 else 1) + 4.0 * h.G * h.B * h.H * heads[k].dout
+                if h.first.x:
+                    fl += 4.0 * h.G * h.B * h.H * h.first.din
+            one = all(0 <= heads[k].loss.kind <= 3 and heads[k].dout == 1 for k in range(n))
+            rows.append(("head + hidden backward x%d (%s)" % (n, "one launch" if one else "two launches"), "backward",
+                         lambda heads=heads, hid=hid, n=n: lib.rrl_mlp_backward_pair_multi(n, heads, hid, st()), fl, None))
+            skip = True
+            continue
         if kind == "forward":
             arr, n = op[1], op[2]
             fl = sum(mlp_flops(arr[k].G, arr[k].M, arr[k].H, arr[k].din, arr[k].dout) for k in range(n))
@@ -435,7 +454,7 @@ def roofline_stages(a, device, iteration_ms):
             continue
         t = _graph_of(launch, 50, device)
         total += t
-        r = {"stage": name, "group": group, "us": t * 1e6}
+        r = {"stage": name, "group": group, "us": t * 1e6, "launches": 2 if name.endswith("(two launches)") else 1}
         if fl is not None:
             r.update(bound="mfma", flops=fl, achieved_TFLOPs=fl / t / 1e12, frac=fl / t / 1e12 / F32_MFMA_PEAK_TF)
         else:
@@ -444,7 +463,7 @@ def roofline_stages(a, device, iteration_ms):
     groups = {}
     for r in out:
         gsum = groups.setdefault(r["group"], {"launches": 0, "us": 0.0, "flops": 0.0, "bytes": 0.0})
-        gsum["launches"] += 1
+        gsum["launches"] += r["launches"]
         gsum["us"] += r["us"]
         gsum["flops"] += r.get("flops", 0.0)
         gsum["bytes"] += r.get("bytes", 0.0)
@@ -456,7 +475,7 @@ def roofline_stages(a, device, iteration_ms):
         else:
             row.update(bound="hbm", frac=gs["bytes"] / (gs["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
         summary.append(row)
-    return {"launches": len(out), "stand_alone_sum_us": total * 1e6, "iteration_us": iteration_ms * 1e3,
+    return {"launches": sum(r["launches"] for r in out), "stand_alone_sum_us": total * 1e6, "iteration_us": iteration_ms * 1e3,
             "method": "each recorded launch of one iteration re-issued 50x back to back in its own graph, HIP events on the "
                       "launch stream; FLOPs / bytes are algorithmic (2 M K N per product; parameter + state bytes for Adam)",
             "dominant": summary[0]["group"], "by_group": summary, "stages": out}

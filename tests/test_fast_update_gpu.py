@@ -394,3 +394,52 @@ def test_first_layer_backward_inside_the_hidden_launch(B):
             pa, pb = getattr(a.fast, name).flat, getattr(b.fast, name).flat
             assert float((pa - pb).abs().max()) < 3e-5, (step, name, float((pa - pb).abs().max()))      # 0.1 lr
     assert int(a.fast.critic.step[0].item()) == 3
+
+
+@pytest.mark.parametrize("hidden,B", ((256, 256), (128, 128)))
+def test_paired_head_and_hidden_backward_equals_the_two_launches(monkeypatch, hidden, B):
+    """rrl_mlp_backward_pair_multi: for the critic-loss kinds with full aligned tiles (256 x 256, 128 x 128) the head backward
+    and the hidden backward go out as ONE launch whose tiles derive dh2 from h2, the loss description and W3; anything else
+    (here: the policy-head kinds of the same updates) takes the two launches inside the same entry point.  Against the same updates issued
+    as rrl_mlp_head_backward_multi + rrl_mlp_hidden_backward_multi: every parameter and gradient bit for bit."""
+    from recovery_rl_amd import fast_update
+    _, a, _ = make_pair(hidden)
+    _, b, _ = make_pair(hidden)
+    for dst, src in ((b.critic, a.critic), (b.critic_target, a.critic_target), (b.policy, a.policy),
+                     (b.safety_critic.safety_critic, a.safety_critic.safety_critic),
+                     (b.safety_critic.safety_critic_target, a.safety_critic.safety_critic_target),
+                     (b.safety_critic.policy, a.safety_critic.policy)):
+        dst.load_state_dict(copy.deepcopy(src.state_dict()))
+    a.enable_fast_path(B)
+    b.enable_fast_path(B)
+    paired = fast_update.backward_multi
+    calls = {"pair": 0, "two": 0}
+
+    def two_launches(triples):
+        lib, st, n = _lib.load(), _lib.current_stream(), len(triples)
+        heads = (_lib.rrl_head_bwd_t * n)(*[t[0] for t in triples])
+        hiddens = (_lib.rrl_hidden_bwd_t * n)(*[t[1] for t in triples])
+        rest = [t[2] for t in triples if t[2] is not None]
+        _lib.check(lib.rrl_mlp_head_backward_multi(n, heads, st), "rrl_mlp_head_backward_multi")
+        _lib.check(lib.rrl_mlp_hidden_backward_multi(n, hiddens, st), "rrl_mlp_hidden_backward_multi")
+        if rest:
+            inputs = (_lib.rrl_input_bwd_t * len(rest))(*rest)
+            _lib.check(lib.rrl_mlp_input_backward_multi(len(rest), inputs, st), "rrl_mlp_input_backward_multi")
+        calls["two"] += 1
+
+    def counted(triples):
+        calls["pair"] += 1
+        return paired(triples)
+
+    for step in range(3):
+        b_sac, b_qr, e1, e2 = batch(B, 90 + step)
+        for ag, fn in ((a, counted), (b, two_launches)):
+            monkeypatch.setattr(fast_update, "backward_multi", fn)
+            ag.update_parameters(None, B, step, safety_critic=ag.safety_critic, batch=b_sac, eps_next=e1, eps_pi=e2)
+            ag.safety_critic.update_parameters(policy=ag.policy, batch=b_qr, eps_next=e1, eps_pi=e2)
+        for name in ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy"):
+            fa, fb = getattr(a.fast, name), getattr(b.fast, name)
+            assert torch.equal(fa.grad, fb.grad), (step, name)
+            assert torch.equal(fa.flat, fb.flat), (step, name)
+        assert torch.equal(a.fast.losses, b.fast.losses)
+    assert calls["pair"] == calls["two"] > 0
