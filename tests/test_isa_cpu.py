@@ -61,8 +61,8 @@ def test_packed_kernels_use_global_not_flat_memory_instructions(kernels):
 
 
 def test_solo_kernels_of_the_iteration_have_no_flat_loads_either(kernels):
-    for piece in ("gemm16_group_kernel", "head_bwd_group_kernel", "mlp3_fwd_split_group_kernel", "adam_multi_kernel",
-                  "sample_group_kernel", "step_push_kernel"):
+    for piece in ("gemm16_group_kernel", "head_bwd_group_kernel", "backward_pair_kernel", "mlp3_fwd_split_group_kernel",
+                  "adam_multi_kernel", "sample_group_kernel", "step_push_kernel"):
         hits = [k for k in kernels if piece in k]
         assert hits, piece
         for k in hits:
@@ -87,6 +87,7 @@ BUDGETS = (
     ("ens_big_fwd_bwd_kernel", 128, "large-batch ensemble step"),
     ("step_push_kernelIN12_GLOBAL__N_16NavEnvILi0EEELi0E", 96, "fused env step + pushes + episode table, latency variant (speculated reset)"),
     ("step_push_kernelIN12_GLOBAL__N_16NavEnvILi0EEELi2E", 64, "the same, bandwidth variant: 1024-thread workgroups, eight waves per SIMD"),
+    ("backward_pair_kernel", 256, "paired head + hidden backward: two 4-wave workgroups (8 tiles) per CU"),
     ("nav_step_kernel", 64, "env step: eight waves per SIMD (bandwidth regime)"),
     ("sample_group_kernel", 64, "replay draws"),
 )
