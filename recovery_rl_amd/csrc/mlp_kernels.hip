@@ -1129,7 +1129,15 @@ __global__ __launch_bounds__(256) void backward_pair_kernel(PairJobs pj) {
                         l.da_parts, l.da_part_stride, blocks_x, G);
         const int local = blockIdx.x;
         if (local >= blocks_x * G) return;
-        head_bwd_dispatch(hb, local % blocks_x, local / blocks_x, reinterpret_cast<float (*)[4][kCols]>(smem), smem + 1024);
+        // (the four critic-loss kinds only: the policy-head kinds never come here, and their code would double the kernel)
+        float (*red)[4][kCols] = reinterpret_cast<float (*)[4][kCols]>(smem);
+        const int bx = local % blocks_x, g = local / blocks_x;
+        switch (l.kind) {
+            case RRL_LOSS_SAC_CRITIC: head_bwd_loss_body<RRL_LOSS_SAC_CRITIC>(hb, bx, g, red, smem + 1024); break;
+            case RRL_LOSS_SAC_POLICY: head_bwd_loss_body<RRL_LOSS_SAC_POLICY>(hb, bx, g, red, smem + 1024); break;
+            case RRL_LOSS_QRISK_CRITIC: head_bwd_loss_body<RRL_LOSS_QRISK_CRITIC>(hb, bx, g, red, smem + 1024); break;
+            default: head_bwd_loss_body<RRL_LOSS_QRISK_POLICY>(hb, bx, g, red, smem + 1024); break;
+        }
         return;
     }
     HiddenJob j = pj.job[k][z];
