@@ -18,6 +18,6 @@ import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n=r['Name']
-    if any(k in n for k in ("backward_pair",'mlp3_fwd_split_group','gemm16_group','head_bwd_group','adam_multi','sample_group','step_push')):
+    if any(k in n for k in ("backward_pair",'mlp3_fwd_split_group','gemm16_group','head_bwd_group','head_bwd_loss','adam_multi','sample_group','step_push')):
         print(n.replace('(anonymous namespace)::','')[:60], r['Calls'], round(float(r['AverageNs'])/1e3,2))
 P

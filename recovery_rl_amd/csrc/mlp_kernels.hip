@@ -1524,11 +1524,30 @@ static int build_head_group(int n, const rrl_head_bwd_t* ps, HeadBwdGroup& hg) {
     return RRL_OK;
 }
 
+// one member with a loss description: its own kernel (head_bwd_loss_kernel<kind>: the same body without the other kinds' code
+// and the group's argument blocks around it); several members, or a plain dOut tensor: the group kernel
+static void launch_head_group(const HeadBwdGroup& hg, int n, hipStream_t st) {
+    if (n == 1) {
+        const HeadBwdArgs& hb = hg.p[0];
+        const dim3 grid(hg.blocks_x[0], hg.G[0]), block(256);
+        switch (hb.la.kind) {
+            case RRL_LOSS_SAC_CRITIC: hipLaunchKernelGGL((head_bwd_loss_kernel<RRL_LOSS_SAC_CRITIC>), grid, block, 0, st, hb); return;
+            case RRL_LOSS_SAC_POLICY: hipLaunchKernelGGL((head_bwd_loss_kernel<RRL_LOSS_SAC_POLICY>), grid, block, 0, st, hb); return;
+            case RRL_LOSS_QRISK_CRITIC: hipLaunchKernelGGL((head_bwd_loss_kernel<RRL_LOSS_QRISK_CRITIC>), grid, block, 0, st, hb); return;
+            case RRL_LOSS_QRISK_POLICY: hipLaunchKernelGGL((head_bwd_loss_kernel<RRL_LOSS_QRISK_POLICY>), grid, block, 0, st, hb); return;
+            case RRL_LOSS_GAUSS_HEAD: hipLaunchKernelGGL((head_bwd_loss_kernel<RRL_LOSS_GAUSS_HEAD>), grid, block, 0, st, hb); return;
+            case RRL_LOSS_STOCH_HEAD: hipLaunchKernelGGL((head_bwd_loss_kernel<RRL_LOSS_STOCH_HEAD>), grid, block, 0, st, hb); return;
+            default: break;
+        }
+    }
+    hipLaunchKernelGGL(head_bwd_group_kernel, dim3(largest_member(hg, n), n), dim3(256), 0, st, hg);
+}
+
 int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
     HeadBwdGroup hg;
     const int rc = build_head_group(n, ps, hg);
     if (rc != RRL_OK) return rc;
-    hipLaunchKernelGGL(head_bwd_group_kernel, dim3(largest_member(hg, n), n), dim3(256), 0, (hipStream_t)stream, hg);
+    launch_head_group(hg, n, (hipStream_t)stream);
     return check_launch();
 }
 
@@ -1555,7 +1574,7 @@ int rrl_mlp_backward_pair_multi(int n, const rrl_head_bwd_t* heads, const rrl_hi
     }
     hipStream_t st = (hipStream_t)stream;
     if (!pair) {
-        hipLaunchKernelGGL(head_bwd_group_kernel, dim3(largest_member(hg, n), n), dim3(256), 0, st, hg);
+        launch_head_group(hg, n, st);
         HiddenJobs hj{};
         int most = 1;
         for (int k = 0; k < n; ++k) {
