@@ -121,3 +121,20 @@ def test_step_push_has_no_loop_and_few_sgpr_spills(tmp_path):
         lanes = v["ins"].get("v_readlane_b32", 0) + v["ins"].get("v_writelane_b32", 0)
         assert lanes <= 500, (k, lanes)
         assert sum(v["ins"].values()) <= 3300, (k, sum(v["ins"].values()))
+
+
+def test_solo_group_kernels_fetch_their_argument_block_in_one_batch(kernels):
+    """A solo group kernel takes its member from blockIdx.y and pins the member's scalars (mlp_common.hpp: arrive_together):
+    ONE batch of scalar loads and one wait before the first vector-memory request -- the flat grid's first[] walk and the
+    compiler's one-wait-per-first-use were two to three dependent round trips of ~0.5 us each (profiles/round4_levels.txt)."""
+    limits = {"gemm16_group_kernel": 1, "head_bwd_group_kernel": 1, "mlp3_fwd_split_group_kernelILi1E": 1,
+              "mlp3_fwd_split_group_kernelILi2E": 1, "adam_multi_kernel": 1, "backward_pair_kernel": 2}
+    for piece, most in limits.items():
+        hits = [k for k in kernels if piece in k]
+        assert hits, piece
+        for k in hits:
+            ins = kernels[k]
+            first = next(i for i, op in enumerate(ins) if op.startswith(("global_load", "buffer_load")))
+            waits = sum(op == "s_waitcnt" for op in ins[:first])           # no vector request is out yet: scalar waits only
+            loads = sum(op.startswith("s_load") for op in ins[:first])
+            assert waits <= most and loads >= 5, (k, waits, loads)
