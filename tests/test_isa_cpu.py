@@ -138,3 +138,19 @@ def test_solo_group_kernels_fetch_their_argument_block_in_one_batch(kernels):
             waits = sum(op == "s_waitcnt" for op in ins[:first])           # no vector request is out yet: scalar waits only
             loads = sum(op.startswith("s_load") for op in ins[:first])
             assert waits <= most and loads >= 5, (k, waits, loads)
+
+
+def test_early_tickets_are_not_waited_for_on_the_spot(kernels):
+    """The cursor ticket of step_push_kernel, its episode-table reservation and Adam's step ticket are returning atomics whose
+    value is needed late.  LLVM's atomic optimiser rewrites such an atomic as "first lane adds, v_readfirstlane the result" with
+    an s_waitcnt right behind the atomic -- the round trip (~0.7 us) is then waited for on the spot.  _lib.SOURCE_FLAGS switches
+    the optimiser off for those sources; this test sees it if the flag is lost."""
+    for piece in ("step_push_kernelIN12_GLOBAL__N_16NavEnvILi0EEELi0E", "adam_multi_kernel"):
+        hits = [k for k in kernels if piece in k]
+        assert hits, piece
+        for k in hits:
+            ins = kernels[k]
+            for i, op in enumerate(ins):
+                if op.startswith("global_atomic_add"):
+                    tail = ins[i + 1:i + 5]
+                    assert not ("s_waitcnt" in tail and "v_readfirstlane_b32" in tail), (k, i, tail)
