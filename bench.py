@@ -32,9 +32,9 @@ if ROOT not in sys.path:
 from recovery_rl_amd import runtime as rrl_runtime  # noqa: E402
 
 # the timed graph is replayed through the runtime's regular command path (2.8 % faster than pre-captured packets for this
-# chain of tiny kernels on ROCm 7.2); opt-in here, reported in the JSON line ("runtime"), RRL_GRAPH_PACKET_CAPTURE=1 or
+# chain of tiny kernels on ROCm 7.2); the same request rrl_main.py makes, reported in the JSON line ("runtime"), RRL_GRAPH_PACKET_CAPTURE=1 or
 # an explicit DEBUG_CLR_GRAPH_PACKET_CAPTURE in the environment wins
-RUNTIME = rrl_runtime.configure(graph_packet_capture=0, log=False)
+RUNTIME = rrl_runtime.configure(graph_packet_capture=rrl_runtime.LAUNCHER_GRAPH_PACKET_CAPTURE, log=False)
 
 NUM_ENVS = 4096
 MIN_TIMED_S = 3.0                # timed region of the headline leg (an external SMI sampler must be able to see it)
@@ -335,11 +335,20 @@ def time_nav_rollout_kernel(device, n=1 << 20, T=100):
     return e0.elapsed_time(e1) * 1e-3 / 3
 
 
+def latest_sweep():
+    """The newest committed `bench.py --sweep` record under profiles/."""
+    for rnd in range(9, 0, -1):
+        rel = os.path.join("profiles", "round%d_roofline_sweep.json" % rnd)
+        if os.path.exists(os.path.join(ROOT, rel)):
+            return rel
+    return "profiles/ (no sweep committed)"
+
+
 def committed_pmc(name, key):
     """(HBM bytes per launch, source file) from the committed rocprofv3 PMC passes under profiles/ (PMC passes cannot run
     inside this process: the figure is NOT measured by this run, `traffic_source` in the JSON line says where it comes
     from).  (None, None) when no measurement exists for this size."""
-    for rnd in ("round4", "round3", "round2", "round1"):
+    for rnd in ("round5", "round4", "round3", "round2", "round1"):
         rel = os.path.join("profiles", "%s_%s.json" % (rnd, name))
         try:
             rec = json.load(open(os.path.join(ROOT, rel))).get(str(key))
@@ -960,8 +969,8 @@ def main():
                       "table advanced by the same launch (40 B of accumulators per env-step, not part of the 103 algorithmic "
                       "bytes): what the timed graph and the lock-step driver launch",
             "note": "N=%d moves only %d KB per launch: latency-bound by construction; bandwidth regime "
-                    "(N up to 2^24, `bench.py --sweep`): profiles/round3_roofline_sweep.json"
-                    % (a.num_envs, a.num_envs * STEP_PUSH_ALGO_BYTES // 1024)}
+                    "(N up to 2^24, `bench.py --sweep`): %s"
+                    % (a.num_envs, a.num_envs * STEP_PUSH_ALGO_BYTES // 1024, latest_sweep())}
         if a.sweep:
             sweep, sweep_sp, sweep_c = [], [], []
             for logn in (12, 16, 20, 24):

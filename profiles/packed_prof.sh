@@ -1,10 +1,11 @@
 #!/bin/bash
 # Per-kernel averages of the packed iteration at S = 1 and S = 4 (U = 16): which launches stretch when seeds share them.
-#   -> gpurun_out/r3_packed_prof/S{1,4}_kernel_stats.csv + S{1,4}.txt
+#   packed_prof.sh [U=16] ["S list"="1 4"] [out dir under gpurun_out = packed_prof]
+#   -> gpurun_out/<out>/S{1,4}_kernel_stats.csv + S{1,4}.txt
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r3_packed_prof
+OUT=$R/gpurun_out/${3:-packed_prof}
 mkdir -p $OUT
 U=${1:-16}
 SLIST=${2:-"1 4"}

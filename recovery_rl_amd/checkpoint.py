@@ -37,9 +37,28 @@ def replay_state(mem):
     return out
 
 
+def capacity_fits(sd, capacity):
+    """A buffer of `capacity` rows can take the checkpointed ring `sd`: same capacity, or a larger one while the ring has
+    never reached its end (rows [0, size) and the write position mean the same in both)."""
+    return sd["capacity"] == capacity or (capacity > sd["capacity"] and sd["size"] < sd["capacity"])
+
+
+def _capacity_error(name, sd, capacity):
+    return ValueError("%s capacity differs: checkpoint %d, run %d (a run resumed through --resume takes the checkpoint's "
+                      "capacities by itself; otherwise pass --replay_size / --safe_replay_size with --keep_replay_size)"
+                      % (name, sd["capacity"], capacity))
+
+
+def peek_capacities(path):
+    """{buffer: (capacity, wrapped)} of a checkpoint, read before the run allocates its buffers."""
+    sd = torch.load(path, map_location="cpu", weights_only=False, mmap=True)
+    return {name: (int(sd[name]["capacity"]), sd[name]["size"] >= sd[name]["capacity"])
+            for name in ("memory", "recovery_memory")}
+
+
 def load_replay_state(mem, sd):
-    if sd["capacity"] != mem.capacity:
-        raise ValueError("replay capacity differs: checkpoint %d, run %d" % (sd["capacity"], mem.capacity))
+    if not capacity_fits(sd, mem.capacity):
+        raise _capacity_error("replay", sd, mem.capacity)
     size = sd["size"]
     for name in ("s", "a", "r", "s2", "m"):
         getattr(mem, name)[:size].copy_(sd[name])
@@ -214,9 +233,8 @@ def load_experiment_state(exp, sd):
     if sd["env"]["num_envs"] != exp.env.num_envs:
         raise ValueError("num_envs differs: checkpoint %d, run %d" % (sd["env"]["num_envs"], exp.env.num_envs))
     for name in ("memory", "recovery_memory"):
-        if sd[name]["capacity"] != getattr(exp, name).capacity:
-            raise ValueError("%s capacity differs: checkpoint %d, run %d"
-                             % (name, sd[name]["capacity"], getattr(exp, name).capacity))
+        if not capacity_fits(sd[name], getattr(exp, name).capacity):
+            raise _capacity_error(name, sd[name], getattr(exp, name).capacity)
     if ("flat" in sd["agent"]) != (exp.agent.fast is not None):
         raise ValueError("checkpoint and run disagree on the fused update path (--no_fast_path)")
     if ("mpc" in sd) != (exp.recovery_policy is not None):

@@ -43,8 +43,14 @@ class PtModel(nn.Module):
         mu = data.double().mean(0, keepdim=True)
         sigma = data.double().std(0, unbiased=False, keepdim=True)
         sigma = torch.where(sigma < 1e-12, torch.ones_like(sigma), sigma)
-        self.inputs_mu.data = mu.float()
-        self.inputs_sigma.data = sigma.float()
+        # written IN PLACE: a captured hipGraph (the model-based iteration, experiment.py `mb_graph`) packs the planner's
+        # weights from these addresses on every replay, so a re-fit must not move them.  The reference's [1, in] shape
+        # (a view of the same storage) is kept.
+        for prm, val in ((self.inputs_mu, mu), (self.inputs_sigma, sigma)):
+            flat = prm.data.reshape(-1)
+            assert flat.data_ptr() == prm.data.data_ptr()
+            flat.copy_(val.float().reshape(-1))
+            prm.data = flat.view(1, -1)
 
     def forward(self, inputs, ret_logvar=False):
         """inputs [E, rows, in] -> (mean, var or logvar) each [E, rows, out/2] (navigation1.py:71-96)."""

@@ -26,11 +26,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // waves per SIMD the register allocator targets: 2 = one workgroup per CU (<= 256 VGPRs), 4 = two (<= 128)
-// timing ablations for profiles/ (wrong results!): 1 = no weight-fragment loads, 2 = no LDS fragment reads,
-// 4 = no activation stores / reductions, 8 = (f16x3) one matrix product instead of three, 16 = no per-row tail
-#ifndef RRL_PLAN_ABLATE
-#define RRL_PLAN_ABLATE 0
-#endif
+// (the timing ablations of rounds 2-4 -- no weight loads / no LDS reads / no stores / one product / no tail -- are
+// profiles/patches/plan_ablate.patch, not product code)
 #ifndef RRL_PLAN_WAVES_PER_EU
 #define RRL_PLAN_WAVES_PER_EU 4
 #endif
@@ -92,11 +89,7 @@ __device__ __forceinline__ void load_b(f32x4 (&b)[NC], const float* __restrict__
                                        int j, int lane) {
 #pragma unroll
     for (int c = 0; c < NCV; ++c) {
-#if RRL_PLAN_ABLATE & 1
-        b[c] = f32x4{float(j), float(lane), 1.f, 2.f};
-#else
         b[c] = *reinterpret_cast<const f32x4*>(wpk + ((size_t)(ct[c] * J + j) * 64 + lane) * 4);
-#endif
     }
 }
 
@@ -106,12 +99,8 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MR][NC], const float* act
     f32x4 a[MR];
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
-#if RRL_PLAN_ABLATE & 2
-        a[r] = f32x4{float(j), float(lane), 1.f, float(r)};
-#else
         a[r] = *reinterpret_cast<const f32x4*>(act + (rt[r] * 16 + (lane & 15)) * kActStride + 16 * j +
                                                (lane >> 4) * 4);
-#endif
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -140,25 +129,18 @@ __device__ __forceinline__ void layer_mma_k32(f32x4 (&acc)[MR][NC], const float*
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             const int off = (rt[r] * 16 + (lane & 15)) * kHalfStride + 32 * jp + (lane >> 4) * 8;
-#if RRL_PLAN_ABLATE & 2
-            ahi[r] = __builtin_bit_cast(f16x8, f32x4{float(jp), float(lane), 1.f, float(r + off)});
-            alo[r] = ahi[r];
-#else
             ahi[r] = *reinterpret_cast<const f16x8*>(ah + off);
             alo[r] = *reinterpret_cast<const f16x8*>(al + off);
-#endif
         }
-#if !(RRL_PLAN_ABLATE & 8)
 #pragma unroll
         for (int r = 0; r < MR; ++r)
 #pragma unroll
             for (int c = 0; c < NCV; ++c)
                 if (tile_on<XR>(r, c))
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[r], __builtin_bit_cast(f16x8, l[c]), acc[r][c], 0, 0, 0);
-#endif
         if (more) load_b<NCV>(l, wpk, ct, J, 2 * jp + 3, lane);
 #pragma unroll
-        for (int prod = 0; prod < ((RRL_PLAN_ABLATE & 8) ? 1 : 2); ++prod)      // ablation 8: one product instead of three
+        for (int prod = 0; prod < 2; ++prod)
 #pragma unroll
             for (int r = 0; r < MR; ++r)
 #pragma unroll
@@ -241,9 +223,6 @@ __device__ __forceinline__ void zero(f32x4 (&acc)[MR][NC]) {
 template <bool F16X3, bool SWISH, int NCV, int XR = -1, int MR, int NC>
 __device__ __forceinline__ void store_act(const f32x4 (&acc)[MR][NC], float* act, const int (&rt)[MR],
                                           const float (&bias)[NC], const int (&ct)[NC], int lane) {
-#if RRL_PLAN_ABLATE & 4
-    if (bias[0] != 12345.f) return;
-#endif
     _Float16* ah = reinterpret_cast<_Float16*>(act);
     _Float16* al = ah + kRows * kHalfStride;
 #pragma unroll
@@ -507,7 +486,7 @@ void plan_cost_kernel(
         }
 
         // ---- per-row tail: cost, predictive distribution, next observation ----
-        if (owner && !(RRL_PLAN_ABLATE & 16)) {
+        if (owner) {
             float q[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {

@@ -458,12 +458,21 @@ __device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec
         ticket = __hip_atomic_fetch_add((unsigned long long*)&sg.step_dev[1], 1ULL, __ATOMIC_RELAXED,   // is an L2 write-back)
                                         __HIP_MEMORY_SCOPE_AGENT);
         sh[0] = lr / float(1.0 - pow(double(b1), t));
+        sh[2] = __uint_as_float(uint32_t(step));
     } else if (threadIdx.x == 64) {
         // the second bias correction on another wave: each double pow is a ~230-instruction dependent chain (~1 us) that the
         // whole workgroup waits for at the barrier below -- side by side instead of one behind the other
         sh[1] = float(sqrt(1.0 - pow(double(b2), double(step + 1))));
+        sh[3] = __uint_as_float(uint32_t(step));
     }
     __syncthreads();
+    // only wave 0's read of the step count is ordered before this workgroup's ticket: a slow wave 1 may have read the count
+    // AFTER the segment's last workgroup stored t + 1.  Wave 0's value is the step's; if wave 1 saw another one it redoes its
+    // correction with wave 0's (workgroup-uniform branch, never taken in practice)
+    if (__float_as_uint(sh[2]) != __float_as_uint(sh[3])) {
+        if (threadIdx.x == 0) sh[1] = float(sqrt(1.0 - pow(double(b2), double(step + 1))));
+        __syncthreads();
+    }
     adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, sg.weight_decay, sg.g2,
                block, blocks, vec, sg.g_part, sg.n_part, sg.part_stride, sg.part_elems, first, vec);
     if (threadIdx.x == 0 && ticket == (unsigned long long)blocks - 1) {
@@ -476,7 +485,7 @@ __device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec
 // of scalar loads (the flat grid of the packed form walks first_block[] first: one more dependent round trip)
 __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_seg, float lr, float b1, float b2,
                                                             float eps) {
-    __shared__ float sh[2];
+    __shared__ float sh[4];
     const int k = blockIdx.y;
     rrl_adam_seg_t sg = a.seg[k];
     const int vec = a.vec[k], blocks = a.first_block[k + 1] - a.first_block[k];
@@ -494,7 +503,7 @@ struct AdamPack {
     float lr, b1, b2, eps;
 };
 __global__ __launch_bounds__(kBlock) void adam_pack_kernel(const AdamPack* __restrict__ packs, rrl_pack::Idx ix) {
-    __shared__ float sh[2];
+    __shared__ float sh[4];
     int s, local;
     if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
     const AdamPack& pk = packs[s];

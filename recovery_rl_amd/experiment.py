@@ -392,9 +392,20 @@ class VectorLoop:
 
 
 MAX_COVER_ROWS = 1 << 28          # 8.6 GB per buffer at 32 B per row: far inside 288 GB of HBM
+ROW_BYTES = 32                    # s, a, s2 f32[2] + r, m f32
 
 
-def replay_capacities(cfg):
+def cover_rows_limit(device=None):
+    """Rows per buffer the automatic growth of rule 4 may ask for: MAX_COVER_ROWS, and never more than a quarter of the
+    device memory that is free right now for each of the two buffers (the samplers' scratch and the networks need the rest)."""
+    limit = MAX_COVER_ROWS
+    if device is not None and torch.cuda.is_available() and torch.device(device).type == "cuda":
+        free, _ = torch.cuda.mem_get_info(torch.device(device))
+        limit = min(limit, int(free // 4 // ROW_BYTES))
+    return limit
+
+
+def replay_capacities(cfg, device=None):
     """(task buffer, safety buffer) capacities of a run.  Vectorisation rule 4: in the reference a buffer never wraps within a
     run -- its defaults are replay_size = safe_replay_size = num_steps = 1e6 and a run stops at num_steps env-steps
     (arg_utils.py, experiment.py:375) -- so both buffers hold a run's WHOLE history.  A lock-step run of N envs is given a step
@@ -408,7 +419,7 @@ def replay_capacities(cfg):
     n = int(getattr(cfg, "num_envs", 1))
     if n <= 1 or getattr(cfg, "keep_replay_size", False) or cfg.num_steps <= min(cap, safe_cap):
         return cap, safe_cap                 # (the reference's defaults, num_steps == both capacities, stay as they are)
-    steps = int(min(cfg.num_steps, MAX_COVER_ROWS)) + 2 * n
+    steps = int(min(cfg.num_steps, cover_rows_limit(device))) + 2 * n
     cap = max(cap, steps)
     safe = steps + int(cfg.num_unsafe_transitions)
     if cfg.pos_fraction >= 0:
@@ -450,14 +461,25 @@ class Experiment:
         self.experiment_setup()
 
         dev = self.device
-        cap, safe_cap = replay_capacities(exp_cfg)
+        cap, safe_cap = replay_capacities(exp_cfg, device=dev)
+        if getattr(exp_cfg, "resume", ""):
+            # a resumed run keeps the buffers it was written with (a larger --num_steps, the usual way to continue, or a
+            # checkpoint from before rule 4 would otherwise ask for other capacities and be refused); they only GROW, and only
+            # while the checkpoint's ring has not wrapped (checkpoint.load_replay_state)
+            from . import checkpoint
+            have = checkpoint.peek_capacities(exp_cfg.resume)
+            cap = cap if (cap > have["memory"][0] and not have["memory"][1]) else have["memory"][0]
+            safe_cap = safe_cap if (safe_cap > have["recovery_memory"][0] and not have["recovery_memory"][1]) \
+                else have["recovery_memory"][0]
         if (cap, safe_cap) != (exp_cfg.replay_size, exp_cfg.safe_replay_size):
-            print("Replay capacities raised to cover the run: %d / %d rows (--replay_size %d, --safe_replay_size %d, "
-                  "--num_steps %d; --keep_replay_size keeps the rings)" % (cap, safe_cap, exp_cfg.replay_size,
-                                                                         exp_cfg.safe_replay_size, exp_cfg.num_steps))
+            print("Replay capacities set to cover the run: %d / %d rows = %.0f + %.0f MB of device memory (--replay_size %d, "
+                  "--safe_replay_size %d, --num_steps %d; --keep_replay_size keeps the rings)"
+                  % (cap, safe_cap, cap * ROW_BYTES / 1e6, safe_cap * ROW_BYTES / 1e6, exp_cfg.replay_size,
+                     exp_cfg.safe_replay_size, exp_cfg.num_steps))
         self.memory = ReplayMemory(cap, exp_cfg.seed, device=dev)
         self.recovery_memory = ConstraintReplayMemory(safe_cap, exp_cfg.seed, device=dev)
         self.all_ep_data = []
+        self.vector_rules = {"demo_share": 0.0, "pinned_demonstrations": 0, "replay_capacities": (cap, safe_cap)}
 
         self.total_numsteps = 0
         self.updates = 0
@@ -530,6 +552,16 @@ class Experiment:
         if share > 0 and pinned <= 0:
             raise ValueError("--demo_share needs pinned demonstrations (lock-step loop without --no_pin_demos)")
         self.agent.safety_critic.demo_share = share if share > 0 else None
+        # the rules that change what the critics train on, next to the results they produced: printed, written into
+        # run_stats.pkl ("vector_rules") and the checkpoint
+        self.vector_rules = {"demo_share": share if share > 0 else 0.0, "pinned_demonstrations": int(pinned),
+                             "replay_capacities": self.vector_rules["replay_capacities"]}
+        if cfg.num_envs > 1:
+            print("Q_risk batch: %s (--demo_share; 0 = the reference's single uniform draw, replay_memory.py:54-72)"
+                  % ("%d of %d rows from the %d pinned demonstrations, the rest from the online rows"
+                     % (int(cfg.batch_size * share), cfg.batch_size, pinned) if share > 0 else
+                     "one uniform draw over the safety buffer" if cfg.pos_fraction < 0 else
+                     "stratified draw, --pos_fraction %g" % cfg.pos_fraction))
 
     # -- pre-training ----------------------------------------------------------------------------
     def pretrain_critic_recovery(self):
@@ -732,6 +764,10 @@ class Experiment:
             history, evals, episodes = extra["history"], extra["evals"], [extra["episodes"]]
             mb_resume = [tuple(x.to(self.device) for x in row) for row in extra["mb_new"]]
             self._global_viols = extra.get("global_viols", 0)
+            was = extra.get("vector_rules", {}).get("demo_share")
+            if was is not None and was != self.vector_rules["demo_share"]:
+                print("WARNING: the checkpoint was written with --demo_share %g, this run continues with %g"
+                      % (was, self.vector_rules["demo_share"]))
             print("Resumed from %s at iteration %d (%d env-steps)" % (cfg.resume, it, loop.total_numsteps))
         # after a resume the offline count comes from the checkpoint's counters (pre-training is skipped)
         start = dist_utils.aggregate_stats(
@@ -745,7 +781,7 @@ class Experiment:
         def write_checkpoint():
             checkpoint.save(self, ckpt_path, {"iteration": it, "next_eval": next_eval, "history": history,
                                               "evals": evals, "episodes": np.concatenate(episodes), "mb_new": mb_new,
-                                              "global_viols": self._global_viols})
+                                              "global_viols": self._global_viols, "vector_rules": self.vector_rules})
         ep_file = open(osp.join(self.logdir, "episode_stats.bin"), "wb")   # append-only, O(new) per log
         ep_file.write(episodes[0].tobytes())
         try:
@@ -832,6 +868,7 @@ class Experiment:
                         next_eval += 10 * n
                     with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
                         pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n,
+                                     "vector_rules": self.vector_rules,
                                      **({"train_stats": train_stats, "test_stats": []} if info is not None else {})}, f)
                     if ckpt_every and logged % ckpt_every == 0:
                         write_checkpoint()
@@ -844,7 +881,7 @@ class Experiment:
             ep_file.close()
         write_checkpoint()
         with open(osp.join(self.logdir, "run_stats.pkl"), "wb") as f:
-            pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n,
+            pickle.dump({"vector_stats": history, "eval_stats": evals, "num_envs": n, "vector_rules": self.vector_rules,
                          "episode_stats": np.concatenate(episodes),
                          **({"train_stats": train_stats, "test_stats": [], "info_envs": info_k} if info is not None else {})}, f)
         return history
@@ -1002,7 +1039,7 @@ def run_packed(exp_cfg, rank=0, world_size=1):
             done = done and (stats["env_steps"] > cfg.num_steps or stats["episodes"] > cfg.num_eps)
             with open(osp.join(e.logdir, "run_stats.pkl"), "wb") as f:
                 pickle.dump({"vector_stats": hist, "eval_stats": [], "num_envs": n, "seeds_per_gpu": S,
-                             "episode_stats": np.concatenate(tables[k]),
+                             "vector_rules": e.vector_rules, "episode_stats": np.concatenate(tables[k]),
                              **({"train_stats": train_stats[k], "test_stats": [], "info_envs": info_k}
                                 if infos[k] is not None else {})}, f)
         return done

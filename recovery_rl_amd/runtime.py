@@ -3,15 +3,17 @@
 `graph_packet_capture`: ROCm's hipGraph replay either re-submits pre-captured AQL packets (runtime default) or walks
 the regular command path (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, a debug variable of the ROCm 7.x runtime).  For the
 lock-step iteration -- one graph of ~20 dependent tiny kernels -- the regular path measured 2.8 % faster on ROCm 7.2 /
-MI355X.  That is a finding about ONE runtime release, so it is opt-in (`RRL_GRAPH_PACKET_CAPTURE=0`
-in the environment or `configure(graph_packet_capture=0)` from the launcher), it is logged, it never overrides an
-explicit DEBUG_CLR_GRAPH_PACKET_CAPTURE, and `settings()` reports what is in force so that a bench line says how it ran.
+MI355X.  That is a finding about ONE runtime release, so it is a LAUNCHER's choice (both launchers of this repository, bench.py and
+rrl_main.py, make the same one: `configure(LAUNCHER_GRAPH_PACKET_CAPTURE)`; `RRL_GRAPH_PACKET_CAPTURE=1` in the environment
+switches it back), it is logged, it never overrides an explicit DEBUG_CLR_GRAPH_PACKET_CAPTURE, and `settings()` reports what is in force so that a bench line says how it ran.
 The variable is read by the runtime at its first call: `configure` must run before anything touches the GPU.
 """
 import os
 import sys
 
 _VAR = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+# what BOTH launchers (bench.py and rrl_main.py) ask for, so that the timed configuration is the one `python -m rrl_main` runs
+LAUNCHER_GRAPH_PACKET_CAPTURE = 0
 _applied = {}
 
 

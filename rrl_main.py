@@ -2,7 +2,9 @@
 (rrl_main.py:1-9).  Under torchrun each rank runs seed + rank on its own GPU."""
 from arg_utils import get_args
 from recovery_rl_amd import runtime
-runtime.configure()        # opt-in runtime settings (RRL_GRAPH_PACKET_CAPTURE); none by default
+# the runtime mode bench.py times (hipGraph replay through the regular command path; RRL_GRAPH_PACKET_CAPTURE=1 or an explicit
+# DEBUG_CLR_GRAPH_PACKET_CAPTURE in the environment wins) -- before anything touches the GPU
+runtime.configure(graph_packet_capture=runtime.LAUNCHER_GRAPH_PACKET_CAPTURE)
 from recovery_rl_amd import distributed as dist_utils
 from recovery_rl_amd.experiment import Experiment
 

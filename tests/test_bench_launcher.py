@@ -26,6 +26,23 @@ def test_gpus_flag_decides_the_world_size():
         bench.resolve_world(1, {"WORLD_SIZE": "2"})
 
 
+def test_bench_and_product_launcher_ask_for_the_same_runtime_mode():
+    """The timed configuration is the one `python -m rrl_main` runs: both launchers pass the same constant to
+    runtime.configure (hipGraph replay mode), and the bench line reports what is in force."""
+    from recovery_rl_amd import runtime
+    want = "configure(graph_packet_capture=%s.LAUNCHER_GRAPH_PACKET_CAPTURE"
+    assert want % "rrl_runtime" in open(os.path.join(ROOT, "bench.py")).read()
+    main = open(os.path.join(ROOT, "rrl_main.py")).read()
+    assert want % "runtime" in main and main.index("runtime.configure(") < main.index("from recovery_rl_amd.experiment")
+    assert runtime.LAUNCHER_GRAPH_PACKET_CAPTURE in (0, 1)
+    r = subprocess.run([sys.executable, "-c", "import rrl_main, os, json; from recovery_rl_amd import runtime; "
+                        "print(json.dumps(runtime.settings()))"], cwd=ROOT, capture_output=True, text=True,
+                       env={k: v for k, v in os.environ.items() if "GRAPH_PACKET_CAPTURE" not in k})
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": str(runtime.LAUNCHER_GRAPH_PACKET_CAPTURE), "set_by_launcher": True}, r.stderr
+    assert bench.RUNTIME["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == got["DEBUG_CLR_GRAPH_PACKET_CAPTURE"]
+
+
 def test_launch_command_is_one_rank_per_gpu_on_localhost():
     cmd = bench.launch_command(["--gpus", "8", "--steps", "20"], 8, 29511)
     assert cmd[1:3] == ["-m", "torch.distributed.run"]

@@ -81,3 +81,34 @@ def test_checkpoint_rejects_a_different_run(tmp_path):
     with pytest.raises(ValueError, match="fused update path"):
         checkpoint.load(slow, ck)
     assert not os.path.exists(ck + ".tmp")
+
+
+def test_resume_with_a_larger_step_budget_keeps_or_grows_the_checkpoints_buffers(tmp_path):
+    """Vectorisation rule 4 sizes both buffers from --num_steps; continuing a run with a larger --num_steps (the usual way to
+    continue) must not be refused for that: the resumed run takes the checkpoint's capacities, and grows them while the
+    checkpoint's rings have not wrapped.  The continued run equals the run that had the larger budget from the start."""
+    flags = FLAGS["mf_recovery"] + ["--replay_size", "1000", "--safe_replay_size", "3000", "--num_eps", "100000"]
+    full = Experiment(_cfg(tmp_path / "full", 0, flags + ["--num_steps", "12799"]))
+    assert full.memory.capacity == 12799 + 128 and full.recovery_memory.capacity == 12799 + 128 + 2000
+    full.run()
+    part = Experiment(_cfg(tmp_path / "part", 0, flags + ["--num_steps", "6399"]))
+    assert part.memory.capacity == 6399 + 128
+    part.run()
+    ck = os.path.join(part.logdir, "checkpoint.pt")
+    assert checkpoint.peek_capacities(ck) == {"memory": (6527, False), "recovery_memory": (8527, False)}
+    cont = Experiment(_cfg(tmp_path / "cont", 0, flags + ["--num_steps", "12799", "--resume", ck]))
+    assert cont.memory.capacity == full.memory.capacity and cont.recovery_memory.capacity == full.recovery_memory.capacity
+    cont.run()
+    a = torch.load(os.path.join(full.logdir, "checkpoint.pt"), map_location="cpu", weights_only=False)
+    b = torch.load(os.path.join(cont.logdir, "checkpoint.pt"), map_location="cpu", weights_only=False)
+    assert a["extra"]["iteration"] == b["extra"]["iteration"] == 200
+    assert not _diff(a["agent"], b["agent"]) and not _diff(a["memory"], b["memory"])
+    assert not _diff(a["recovery_memory"], b["recovery_memory"]) and not _diff(a["env"], b["env"])
+    # the same budget again: the checkpoint's capacities are kept as they are
+    same = Experiment(_cfg(tmp_path / "same", 0, flags + ["--num_steps", "6399", "--resume", ck]))
+    assert same.memory.capacity == 6527 and same.recovery_memory.capacity == 8527
+    # a wrapped ring cannot move into another capacity: the message names the flags that settle it
+    wrapped = dict(a["memory"], size=a["memory"]["capacity"])
+    assert not checkpoint.capacity_fits(wrapped, a["memory"]["capacity"] + 64)
+    with pytest.raises(ValueError, match="--keep_replay_size"):
+        checkpoint.load_replay_state(same.memory, wrapped)

@@ -397,3 +397,29 @@ def test_buffers_of_a_lockstep_run_hold_the_whole_run(tmp_path):
     keep = make_cfg(tmp_path, ["--use_recovery", "--MF_recovery", "--num_envs", "64", "--num_steps", "2000000", "--keep_replay_size"])
     exp = Experiment(keep)
     assert exp.memory.capacity == 1000000 and exp.recovery_memory.capacity == 1000000
+
+
+@pytest.mark.parametrize("share,want", [(None, 0.5), ("0", 0.0), ("0.25", 0.25)])
+def test_demo_share_rule_is_printed_recorded_and_can_be_switched_off(tmp_path, capsys, share, want):
+    """Vectorisation rule 3 changes the safety critic's training distribution at N > 1: the run says so at start-up, writes
+    the effective share into run_stats.pkl and the checkpoint, and `--demo_share 0` keeps the reference's single uniform
+    draw over recovery_memory (replay_memory.py:54-72, qrisk.py:100-105) through the same captured loop."""
+    cfg = make_cfg(tmp_path, ["--use_recovery", "--MF_recovery", "--gamma_safe", "0.8", "--eps_safe", "0.3", "--num_envs", "64",
+                              "--num_steps", "1500", "--log_every", "10"] + (["--demo_share", share] if share else []))
+    exp = Experiment(cfg)
+    hist = exp.run()
+    out = capsys.readouterr().out
+    assert exp.loop.graph is not None and hist[-1]["qrisk_updates"] > 10
+    assert (exp.agent.safety_critic.demo_share or 0.0) == want
+    data = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))
+    assert data["vector_rules"]["demo_share"] == want and data["vector_rules"]["pinned_demonstrations"] == 2000
+    assert data["vector_rules"]["replay_capacities"] == (exp.memory.capacity, exp.recovery_memory.capacity)
+    ck = torch.load(os.path.join(exp.logdir, "checkpoint.pt"), map_location="cpu", weights_only=False)
+    assert ck["extra"]["vector_rules"] == data["vector_rules"]
+    if want:
+        assert "Q_risk batch: %d of 256 rows from the 2000 pinned demonstrations" % int(256 * want) in out
+    else:
+        assert "Q_risk batch: one uniform draw over the safety buffer" in out
+        # the draw the graph replays is the reference's: uniform over [0, size), no split
+        d, _ = exp.recovery_memory.draw_desc(256, demo_share=exp.agent.safety_critic.demo_share)
+        assert d.stratified == 0 and (d.n_pos, d.n_neg) == (0, 256)

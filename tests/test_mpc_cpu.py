@@ -26,6 +26,13 @@ def load_ptmodel(G):
 
 def test_ptmodel_forward_decays_and_input_stats(G):
     m = load_ptmodel(G)
+    ptrs = (m.inputs_mu.data_ptr(), m.inputs_sigma.data_ptr())
+    m.fit_input_stats(G["pt.data"])
+    # re-fits rewrite the statistics in place (a captured hipGraph packs the planner's weights from these addresses) and keep
+    # the reference's [1, in] shape
+    assert (m.inputs_mu.data_ptr(), m.inputs_sigma.data_ptr()) == ptrs and tuple(m.inputs_mu.shape) == (1, 4)
+    m.fit_input_stats(np.asarray(G["pt.data"]) * 2.0 + 1.0)
+    assert (m.inputs_mu.data_ptr(), m.inputs_sigma.data_ptr()) == ptrs
     m.fit_input_stats(G["pt.data"])
     assert np.allclose(m.inputs_mu.numpy(), G["pt.fit_mu"], rtol=1e-6, atol=1e-6)
     assert np.allclose(m.inputs_sigma.numpy(), G["pt.fit_sigma"], rtol=1e-6, atol=1e-6)

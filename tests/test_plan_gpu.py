@@ -209,3 +209,37 @@ def test_device_counted_planning_stays_on_the_host_count_path_after_an_empty_set
         assert torch.equal(a, b), k
     assert torch.equal(p0, p1) and torch.equal(t0, t1) and torch.equal(f0, f1)
     assert int(t0[0].item()) > 0
+
+
+def test_a_captured_pack_sees_the_input_statistics_of_a_later_refit():
+    """The model-based iteration is one hipGraph that re-packs the planner's weights on every replay (experiment.py
+    `mb_graph`); the online re-fit (experiment.py:464-480 -> MPC.train -> fit_input_stats, navigation1.py:61-69) runs between
+    replays.  The statistics must therefore be rewritten IN PLACE: a graph captured before the re-fit has to plan with the
+    normaliser of the re-fitted ensemble, exactly as the eager path does."""
+    env, mpc, _ = build()
+    acs, obs, noise = inputs(mpc, 3, 400, seed=5)
+    out = torch.empty(3, 400, device=DEV)
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        mpc.fused.pack()
+        out.copy_(mpc.fused.cost(acs, obs, noise=noise))
+    torch.cuda.current_stream(DEV).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        mpc.fused.pack()
+        out.copy_(mpc.fused.cost(acs, obs, noise=noise))
+    before = out.clone()
+    ptrs = (mpc.model.inputs_mu.data_ptr(), mpc.model.inputs_sigma.data_ptr())
+    shifted = torch.randn(700, 4, device=DEV) * torch.tensor([0.7, 2.0, 0.3, 0.9], device=DEV) \
+        + torch.tensor([1.5, -0.8, 0.2, -0.1], device=DEV)
+    mpc.model.fit_input_stats(shifted)                          # what recovery_policy.train does between replays
+    assert (mpc.model.inputs_mu.data_ptr(), mpc.model.inputs_sigma.data_ptr()) == ptrs
+    assert tuple(mpc.model.inputs_mu.shape) == (1, 4)           # the reference's shape after a fit
+    g.replay()
+    torch.cuda.synchronize()
+    mpc.fused.pack()
+    want = mpc.fused.cost(acs, obs, noise=noise)
+    assert float((want - before).abs().max()) > 1e-3            # the re-fit matters for these inputs
+    assert torch.equal(out, want)
