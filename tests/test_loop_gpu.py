@@ -412,12 +412,14 @@ def test_demo_share_rule_is_printed_recorded_and_can_be_switched_off(tmp_path, c
     assert exp.loop.graph is not None and hist[-1]["qrisk_updates"] > 10
     assert (exp.agent.safety_critic.demo_share or 0.0) == want
     data = pickle.load(open(os.path.join(exp.logdir, "run_stats.pkl"), "rb"))
-    assert data["vector_rules"]["demo_share"] == want and data["vector_rules"]["pinned_demonstrations"] == 2000
+    pinned = exp.recovery_memory.pinned
+    assert 1000 < pinned == exp.num_unsafe_transitions <= 2000
+    assert data["vector_rules"]["demo_share"] == want and data["vector_rules"]["pinned_demonstrations"] == pinned
     assert data["vector_rules"]["replay_capacities"] == (exp.memory.capacity, exp.recovery_memory.capacity)
     ck = torch.load(os.path.join(exp.logdir, "checkpoint.pt"), map_location="cpu", weights_only=False)
     assert ck["extra"]["vector_rules"] == data["vector_rules"]
     if want:
-        assert "Q_risk batch: %d of 256 rows from the 2000 pinned demonstrations" % int(256 * want) in out
+        assert "Q_risk batch: %d of 256 rows from the %d pinned demonstrations" % (int(256 * want), pinned) in out
     else:
         assert "Q_risk batch: one uniform draw over the safety buffer" in out
         # the draw the graph replays is the reference's: uniform over [0, size), no split
