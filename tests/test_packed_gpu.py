@@ -35,7 +35,8 @@ def state_of(loop):
 
 
 @pytest.mark.parametrize("env,S,n_envs", [("navigation1", 3, 256), ("maze", 2, 384), ("navigation1", 5, 4096),
-                                           ("navigation1", 11, 128), ("navigation1", 14, 128)])   # > 8 seeds: linear / two seeds per XCD
+                                           ("navigation1", 11, 128), ("navigation1", 14, 128),    # > 8 seeds: linear / two seeds per XCD
+                                           ("navigation1", 2, 2048), ("navigation1", 9, 1056), ("navigation1", 16, 1056)])   # acting pass in the stream form: ragged blocks, > 8 seeds
 def test_every_packed_seed_equals_its_solo_run(env, S, n_envs):
     K = 25
     packed = PackedLoop([make_loop(env, 1 + s, n_envs) for s in range(S)])
