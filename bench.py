@@ -717,7 +717,7 @@ def run_config_packed(a, device, world, rank, S, updates_per_step=1, min_seconds
     agg = dist_utils.aggregate_stats(local, world, device)
     witness = {"rank": rank, "seeds": list(range(first, first + S)),
                "adam_steps_per_seed": [y[0] - x[0] for x, y in zip(c0, c1)],
-               "launches_per_packed_iteration": len(packed.stages)}
+               "launches_per_packed_iteration": packed.launches}
     return {"elapsed": elapsed, "blocks": blocks, "steps_total": n_steps, "agg": agg, "device_counters": True,
             "seed_pack": witness}, loops[0]
 
@@ -744,7 +744,7 @@ def run_seed_pack_leg(a, device, seeds=(1, 2, 4, 8), min_seconds=MIN_TIMED_LEG_S
         c1 = [int(l.agent.fast.critic.step[0].item()) for l in loops]
         n_steps = a.steps * blocks
         assert all(y - x == n_steps * U for x, y in zip(c0, c1)), (c0, c1, n_steps)
-        out.append({"seeds_per_gpu": S, "updates_per_step": U, "launches_per_packed_iteration": len(packed.stages),
+        out.append({"seeds_per_gpu": S, "updates_per_step": U, "launches_per_packed_iteration": packed.launches,
                     "ms_per_packed_iteration": elapsed / n_steps * 1e3,
                     "aggregate_env_steps_per_s": S * a.num_envs * n_steps / elapsed,
                     "aggregate_sac_grad_steps_per_s": S * U * n_steps / elapsed,

@@ -775,10 +775,14 @@ int rrl_ens_train_epoch_big(const rrl_ens_t* m, int n_seg, const rrl_adam_seg_t*
  * its stand-alone counterpart for S argument sets at once: seed s runs exactly the stand-alone code on its own workgroups,
  * so every seed's results equal its solo run bit for bit.  The S argument blocks live in device memory (content-addressed
  * cache inside the library: blocks that do not change from call to call are uploaded once).  S <= 16.
+ * Launch structure (round 5): as in the solo group launches the member of a seed's group is blockIdx.y, and the seed follows
+ * from blockIdx.x by arithmetic (XCD-aware placement), so a workgroup's argument block arrives in one batch of scalar loads.
  *   rrl_sample_multi_packed                rrl_sample_multi            (args[s])
  *   rrl_mlp3_forward_multi_packed          rrl_mlp3_forward_multi      (n[s] stacks members[s][0..n[s]); column-split path)
  *   rrl_mlp_head_backward_multi_packed     rrl_mlp_head_backward_multi
  *   rrl_mlp_hidden_backward_multi_packed   rrl_mlp_hidden_backward_multi
+ *   rrl_mlp_backward_pair_multi_packed     rrl_mlp_backward_pair_multi (heads[s], hidden[s]: one launch when every member of
+ *                                          every seed qualifies for the paired form, the two packed launches otherwise)
  *   rrl_adam_step_multi_packed             rrl_adam_step_multi         (lr[s])
  *   rrl_nav_step_push_packed / rrl_maze_step_push_packed    rrl_*_step_push_x (a[s]; one env kind, sizes on one side of 16384)
  * ------------------------------------------------------------------------------------------ */
@@ -797,6 +801,8 @@ int rrl_pack_clear(void);
 int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const* members, void* stream);
 int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t* const* members, void* stream);
 int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_bwd_t* const* members, void* stream);
+int rrl_mlp_backward_pair_multi_packed(int S, const int* n, const rrl_head_bwd_t* const* heads,
+                                       const rrl_hidden_bwd_t* const* hidden, void* stream);
 int rrl_adam_step_multi_packed(int S, const int* n_seg, const rrl_adam_seg_t* const* segs, const float* lr, float beta1,
                                float beta2, float eps, void* stream);
 int rrl_nav_step_push_packed(int S, int env_kind, const rrl_step_push_t* a, void* stream);

@@ -12,6 +12,7 @@
 #   ab:<lib.so>[:<rounds>]  profiles/ab_lib.py: headline leg, in-tree library against <lib.so>, alternating on this box
 #   packed[:<S list>[:<U>]] seed-pack leg only (bench.run_seed_pack_leg) for S in the list at U updates per step
 #   packed_prof:<S>[:<U>]   rocprofv3 kernel table of the packed iteration at S seeds -> <tag>_packed/S<S>.txt
+#   gaps:<S>[:<U>]          rocprofv3 kernel trace of the packed iteration: per kernel duration and gap to the next launch
 #   sweep                   bench.py --sweep (env kernels at N = 2^12 .. 2^24) -> <tag>_sweep.json
 #   py:<script and args>    any profiles/*.py probe -> <tag>_<script>.txt
 set +e
@@ -66,6 +67,12 @@ for stage in "$@"; do
     packed_prof)
       s=${arg%%:*}; u=16; [ "$s" != "$arg" ] && u=${arg#*:}
       bash profiles/packed_prof.sh $u "$s" ${TAG}_packed 2>&1 | tail -36 ;;
+    gaps)
+      # kernel-by-kernel durations and gaps of the packed iteration at S seeds (U updates): gaps:<S>[:<U>]
+      s=${arg%%:*}; u=1; [ "$s" != "$arg" ] && u=${arg#*:}
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/gp$s && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/gp$s -o p -- python $OLDPWD/profiles/packed_probe.py $u $s 200 > /tmp/gp$s.json 2>/tmp/gp$s.err )
+      python profiles/trace_gaps.py $(find /tmp/gp$s -name "*kernel_trace.csv" | head -1) step_push > gpurun_out/${TAG}_gaps_S${s}_U$u.txt 2>&1
+      cat gpurun_out/${TAG}_gaps_S${s}_U$u.txt | cut -c1-160 ;;
     sweep)
       timeout 900 python bench.py --sweep > gpurun_out/${TAG}_sweep.json 2> gpurun_out/${TAG}_sweep.err
       python -c "

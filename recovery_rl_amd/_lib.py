@@ -41,7 +41,7 @@ EXPORTS = [
     "rrl_nav_step_push", "rrl_maze_step_push", "rrl_nav_step_push_select", "rrl_maze_step_push_select",
     "rrl_nav_step_push_x", "rrl_maze_step_push_x",
     "rrl_sample_multi_packed", "rrl_pack_clear", "rrl_mlp3_forward_multi_packed", "rrl_mlp_head_backward_multi_packed",
-    "rrl_mlp_hidden_backward_multi_packed", "rrl_adam_step_multi_packed", "rrl_nav_step_push_packed",
+    "rrl_mlp_hidden_backward_multi_packed", "rrl_mlp_backward_pair_multi_packed", "rrl_adam_step_multi_packed", "rrl_nav_step_push_packed",
     "rrl_maze_step_push_packed",
     "rrl_cem_sample", "rrl_cem_update", "rrl_cem_begin", "rrl_cem_sample_n", "rrl_cem_update_n", "rrl_cem_finish",
     "rrl_gemm_f32", "rrl_mlp3_forward", "rrl_mlp3_is_split", "rrl_mlp_head_backward", "rrl_mlp_head_backward_loss", "rrl_mlp_hidden_backward",
@@ -288,6 +288,8 @@ def _declare(lib):
         "rrl_mlp3_forward_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_stack_t)), vp]),
         "rrl_mlp_head_backward_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_head_bwd_t)), vp]),
         "rrl_mlp_hidden_backward_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_hidden_bwd_t)), vp]),
+        "rrl_mlp_backward_pair_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_head_bwd_t)),
+                                                    C.POINTER(C.POINTER(rrl_hidden_bwd_t)), vp]),
         "rrl_adam_step_multi_packed": (ci, [ci, C.POINTER(ci), C.POINTER(C.POINTER(rrl_adam_seg_t)), C.POINTER(f32), f32,
                                             f32, f32, vp]),
         "rrl_nav_step_push_packed": (ci, [ci, ci, C.POINTER(rrl_step_push_t), vp]),

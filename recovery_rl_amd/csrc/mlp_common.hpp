@@ -91,6 +91,20 @@ static int build_pack(int S, const int* n, const Member* const* members, std::ve
     return RRL_OK;
 }
 
+// 2-D packed launch (rrl_pack::locate_grid): seed s owns `most[s]` workgroups per member row; returns grid.x
+static int finish_members(rrl_pack::Idx& ix, int S, const int* most) {
+    ix.S = S;
+    ix.first[0] = 0;
+    for (int s = 0; s < S; ++s) ix.first[s + 1] = ix.first[s] + (most[s] > 0 ? most[s] : 1);
+    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
+    return rrl_pack::finish(ix);
+}
+// the placement's four scalars in one batch of kernel-argument loads, then (seed, index inside the seed's member row)
+#define RRL_PACK_LOCATE(ix, s, local)                       \
+    int s, local;                                           \
+    arrive_together((ix).sp, (ix).p, (ix).r, (ix).S);      \
+    if (!rrl_pack::locate_grid((ix), blockIdx.x, s, local)) return
+
 // tiles of R >= 4 need more than the default 64 KB of LDS per workgroup (gfx950 has 160 KB per CU): opt in once
 static bool grant_lds(const void* kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return true;

@@ -449,23 +449,6 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float*
     else mlp3_fwd_split_body<R, 0>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
 }
 
-// flat grid over (stack, column split, head, row tile)
-template <int R>
-__device__ __forceinline__ void mlp3_fwd_split_group_body(const StackGroup& sg, int block, float* lds) {
-    int k = 0;
-    while (k + 1 < sg.n && block >= sg.first[k + 1]) ++k;
-    const int local = block - sg.first[k];
-    const int bx = local % sg.tiles[k], rest = local / sg.tiles[k];
-    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
-    StackArgs a = sg.a[k];                   // this workgroup's member, copied out of the group (see gemm16_group_body)
-    globalize(a);
-    float* partial = sg.partial[k];
-    rrl_pack::to_global(partial);
-    const int G = sg.G[k];
-    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
-    else mlp3_fwd_split_body<R, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
-}
-
 // Solo launch: grid (row tiles x heads x column splits of the largest member, members) -- see mlp_common.hpp.
 // (Requesting the weights before the input head is evaluated instead of behind its barriers was tried twice -- as written, and
 // raw with the selects behind the head, for the 256-row forwards only: 4096-row forward 18.5 -> 23.8 us / 256-row ones 7.0 ->
@@ -490,13 +473,27 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg
     else mlp3_fwd_split_body<R, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
 }
 
-// the same launch for S seeds (pack.hpp): seed s runs its group on workgroups [first[s], first[s + 1])
+// the same launch for S seeds (pack.hpp): grid (workgroups of the seeds' largest members under the XCD-aware placement,
+// members) -- blockIdx.y IS the member and the seed follows from blockIdx.x by arithmetic, so the member's argument block
+// sits at an address known at wave start: one batch of scalar loads from the plan's device copy, as in the solo launch
 template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_pack_kernel(const StackGroup* __restrict__ groups, rrl_pack::Idx ix) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int s, local;
-    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
-    mlp3_fwd_split_group_body<R>(groups[s], local, lds);
+    RRL_PACK_LOCATE(ix, s, local);
+    const StackGroup& sg = groups[s];
+    const int k = blockIdx.y;
+    StackArgs a = sg.a[k];
+    float* partial = sg.partial[k];
+    const int G = sg.G[k], tiles = sg.tiles[k];
+    globalize(a);
+    rrl_pack::to_global(partial);
+    arrive_together(a.M, a.H, a.din, a.dout, a.ldx, a.use_in_head, a.in_head.kind, a.in_head.n_part, a.in_head.part_stride,
+                    a.in_head.ld_action, a.in_head.min_log_std, G, tiles);
+    if (local >= tiles * G * kSplit) return;               // (an unused member slot of this seed has tiles = 0)
+    const int bx = local % tiles, rest = local / tiles;
+    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
+    if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
+    else mlp3_fwd_split_body<R, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
 }
 
 __global__ void sum_partials_kernel(int n, const float* __restrict__ partial, float* __restrict__ out) {
@@ -655,27 +652,29 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
             return int(RRL_OK);
         });
         if (rc != RRL_OK) return rc;
-        if (path == 3) {
+        if (path == 3 || (small_r > 1 && path == 0)) {
             static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
             if (!ok) return RRL_ERANGE;
+            path = 3;                 // small members on multi-row tiles run the large-batch kernel
+        }
+        // 2-D grid: a seed owns as many workgroups per member row as its largest member has
+        int most[rrl_pack::kMaxSeeds], members_most = 1;
+        for (int s = 0; s < S; ++s) {
+            most[s] = largest_member(groups[s], n[s]);
+            members_most = n[s] > members_most ? n[s] : members_most;
         }
         plan = rrl_pack::store(key, groups.data(), sizeof(StackGroup) * S, st);
         if (!plan) return rrl_pack::store_error();
-        plan->grid = rrl_pack::finish(ix);
+        plan->grid = finish_members(ix, S, most);
         plan->ix = ix;
-        // small members on multi-row tiles run the large-batch kernel (path 3)
-        if (small_r > 1 && path == 0) {
-            static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
-            if (!ok) return RRL_ERANGE;
-            path = 3;
-        }
         plan->i0 = path;
+        plan->i1 = members_most;
     }
     if (plan->i0 == 0)
-        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(plan->grid), dim3(256), split_lds_floats(1) * 4, st,
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(plan->grid, plan->i1), dim3(256), split_lds_floats(1) * 4, st,
                            (const StackGroup*)plan->dev, plan->ix);
     else
-        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(plan->grid), dim3(256),
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(plan->grid, plan->i1), dim3(256),
                            split_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
     return check_launch();
 }

@@ -17,6 +17,8 @@
 // arbitrary M, N, K (edges are zero-filled / bounds-checked).
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "mlp_common.hpp"
@@ -349,9 +351,6 @@ struct HiddenGroup {
     int n;
 };
 
-template <int PANEL = kPanel>
-__device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int block, float* As, float* Bs);
-
 // Solo launch: grid (tiles per product x heads, members, 2) -- blockIdx.y IS the member and blockIdx.z the product (0: input
 // gradient NN, 1: weight gradient TN), so the ONE argument block the workgroup needs sits at a kernel-argument address known
 // at wave start (mlp_common.hpp).  (The flat grid needs first[] to find the member, the member's tile counts to find the
@@ -364,59 +363,42 @@ struct HiddenJob {
 struct HiddenJobs {
     HiddenJob job[kMaxGroup][2];      // [member][0: NN, 1: TN]
 };
-__global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenJobs hj) {
-    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
-    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
+// the member's job, wherever the jobs live (kernel arguments of the solo launch, the plan's device copy of a packed one)
+template <int PANEL, bool DEEP>
+__device__ __forceinline__ void hidden_jobs_body(const HiddenJobs& hj, int x, float* As, float* Bs) {
     const bool is_tn = blockIdx.z != 0;
     HiddenJob j = hj.job[blockIdx.y][blockIdx.z];
     GemmArgs& ga = j.ga;
     globalize(ga);
     arrive_together(ga.M, ga.N, ga.K, ga.lda, ga.ldb, ga.ldc, ga.ldmask, ga.sA, ga.sB, ga.sC, ga.sBias, ga.sMask, ga.sColsum,
                     ga.relu, ga.accumulate, ga.first_stride, ga.ldx, ga.din, ga.G, ga.skip_c, j.tiles, j.tiles_x, j.fast, j.G);
-    const int x = blockIdx.x;
     if (x >= j.tiles * j.G) return;
     const int g = x / j.tiles, b = x - g * j.tiles;
     if (is_tn) {
-        if (j.fast) gemm16_tile<2, true, kPanel, true>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
-        else gemm16_tile<2, false, kPanel, true>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
+        if (j.fast) gemm16_tile<2, true, PANEL, DEEP>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
+        else gemm16_tile<2, false, PANEL, DEEP>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
     } else {
-        if (j.fast) gemm16_tile<1, true, kPanel, true>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
-        else gemm16_tile<1, false, kPanel, true>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
+        if (j.fast) gemm16_tile<1, true, PANEL, DEEP>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
+        else gemm16_tile<1, false, PANEL, DEEP>(ga, As, Bs, b % j.tiles_x, b / j.tiles_x, g);
     }
 }
+__global__ __launch_bounds__(64) void gemm16_group_kernel(HiddenJobs hj) {
+    __shared__ __attribute__((aligned(16))) float As[kPanel * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[kPanel * kLd];
+    hidden_jobs_body<kPanel, true>(hj, blockIdx.x, As, Bs);
+}
 
-// PANEL = 128: 20 KB of LDS per single-wave workgroup, i.e. 8 tiles in flight per CU -- enough for one seed (1 000-1 500 tiles
-// per launch), three rounds for four seeds.  PANEL = 64 (every member FAST, i.e. K a multiple of 128): 16 tiles per CU.
+// Packed launch (pack.hpp): grid (tiles of the seeds' largest jobs under the XCD-aware placement, members, {NN, TN}) -- member
+// and product out of the grid as in the solo launch, the seed from blockIdx.x by arithmetic: the job's block arrives in one
+// batch of scalar loads from the plan.  PANEL = 128: 20 KB of LDS per single-wave workgroup, i.e. 8 tiles in flight per CU
+// -- enough for one seed (1 000-1 500 tiles per launch); PANEL = 64 (every member FAST, i.e. K a multiple of 128): 16 tiles
+// per CU.  Two K panels in flight (DEEP) as in the solo launch: one wave per workgroup has the registers for it.
 template <int PANEL>
-__global__ __launch_bounds__(64) void gemm16_pack_kernel(const HiddenGroup* __restrict__ groups, rrl_pack::Idx ix) {
+__global__ __launch_bounds__(64) void gemm16_pack_kernel(const HiddenJobs* __restrict__ groups, rrl_pack::Idx ix) {
     __shared__ __attribute__((aligned(16))) float As[PANEL * kLd];
     __shared__ __attribute__((aligned(16))) float Bs[PANEL * kLd];
-    int s, local;
-    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
-    // the one member this workgroup serves, not the whole 1.8 KB group, is what it copies out of device memory
-    gemm16_group_body<PANEL>(groups[s], local, As, Bs);
-}
-
-template <int PANEL>
-__device__ __forceinline__ void gemm16_group_body(const HiddenGroup& hg, int block, float* As, float* Bs) {
-    int k = 0;
-    while (k + 1 < hg.n && block >= hg.first[k + 1]) ++k;
-    const int local = block - hg.first[k];
-    const int g = local / hg.per_head[k], b = local - g * hg.per_head[k];
-    // the one problem this workgroup serves is copied out of the group (kernel arguments, or device memory for the packed
-    // launch): its fields are then wave-uniform registers whatever the group's home
-    if (b < hg.tn_tiles[k]) {
-        GemmArgs ga = hg.tn[k];
-        globalize(ga);
-        if (hg.fast[k]) gemm16_tile<2, true, PANEL>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
-        else gemm16_tile<2, false, PANEL>(ga, As, Bs, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
-    } else {
-        const int c = b - hg.tn_tiles[k];
-        GemmArgs ga = hg.nn[k];
-        globalize(ga);
-        if (hg.fast[k]) gemm16_tile<1, true, PANEL>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
-        else gemm16_tile<1, false, PANEL>(ga, As, Bs, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
-    }
+    RRL_PACK_LOCATE(ix, s, local);
+    hidden_jobs_body<PANEL, true>(groups[s], local, As, Bs);
 }
 
 // ---- block form of the hidden-layer backward for the packed launches -------------------------------------------------
@@ -608,27 +590,21 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx
     }
 }
 
-// HiddenGroup with its tile counts in BLOCK units (build_hidden_blocks)
+// HiddenJobs with their tile counts in BLOCK units (hidden_blocks): grid (blocks, members, {NN, TN}) as above
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_block_pack_kernel(const HiddenGroup* __restrict__ groups, rrl_pack::Idx ix) {
+__global__ __launch_bounds__(256) void gemm_block_pack_kernel(const HiddenJobs* __restrict__ groups, rrl_pack::Idx ix) {
     __shared__ __attribute__((aligned(16))) float lds[BlkLds<WM, WN>::kFloats];
-    int s, block;
-    if (!rrl_pack::locate(ix, blockIdx.x, s, block)) return;
-    const HiddenGroup& hg = groups[s];
-    int k = 0;
-    while (k + 1 < hg.n && block >= hg.first[k + 1]) ++k;
-    const int local = block - hg.first[k];
-    const int g = local / hg.per_head[k], b = local - g * hg.per_head[k];
-    if (b < hg.tn_tiles[k]) {
-        GemmArgs ga = hg.tn[k];
-        globalize(ga);
-        gemm_block<2, WM, WN>(ga, lds, b % hg.tn_tiles_x[k], b / hg.tn_tiles_x[k], g);
-    } else {
-        const int c = b - hg.tn_tiles[k];
-        GemmArgs ga = hg.nn[k];
-        globalize(ga);
-        gemm_block<1, WM, WN>(ga, lds, c % hg.nn_tiles_x[k], c / hg.nn_tiles_x[k], g);
-    }
+    RRL_PACK_LOCATE(ix, s, local);
+    const bool is_tn = blockIdx.z != 0;
+    HiddenJob j = groups[s].job[blockIdx.y][blockIdx.z];
+    GemmArgs& ga = j.ga;
+    globalize(ga);
+    arrive_together(ga.M, ga.N, ga.K, ga.lda, ga.ldb, ga.ldc, ga.ldmask, ga.sA, ga.sB, ga.sC, ga.sBias, ga.sMask, ga.sColsum,
+                    ga.relu, ga.accumulate, ga.first_stride, ga.ldx, ga.din, ga.G, ga.skip_c, j.tiles, j.tiles_x, j.G);
+    if (local >= j.tiles * j.G) return;
+    const int g = local / j.tiles, b = local - g * j.tiles;
+    if (is_tn) gemm_block<2, WM, WN>(ga, lds, b % j.tiles_x, b / j.tiles_x, g);
+    else gemm_block<1, WM, WN>(ga, lds, b % j.tiles_x, b / j.tiles_x, g);
 }
 
 // ---- thin-dimension pieces of the stack backward (dout <= 4, din <= 4) ------------------------------
@@ -1057,19 +1033,9 @@ struct HeadBwdGroup {
     int n;
 };
 
-__device__ __forceinline__ void head_bwd_group_body(const HeadBwdGroup& hg, int block, float (*red)[4][kCols], float* dsh) {
-    int k = 0;
-    while (k + 1 < hg.n && block >= hg.first[k + 1]) ++k;
-    const int local = block - hg.first[k];
-    HeadBwdArgs hb = hg.p[k];                // this workgroup's member, copied out of the group (see gemm16_group_body)
-    globalize(hb);
-    head_bwd_dispatch(hb, local % hg.blocks_x[k], local / hg.blocks_x[k], red, dsh);
-}
-
-// solo launch: grid (column blocks x heads of the largest member, members): the member comes out of the grid (mlp_common.hpp)
-__global__ __launch_bounds__(256) void head_bwd_group_kernel(HeadBwdGroup hg) {
-    __shared__ float red[kSlices][4][kCols];
-    __shared__ float dsh[1024 * 4];
+// the member (blockIdx.y) of a group launch, wherever the group lives (kernel arguments of the solo launch, the plan's device
+// copy of a packed one): its block arrives in one batch of scalar loads (mlp_common.hpp)
+__device__ __forceinline__ void head_bwd_member_body(const HeadBwdGroup& hg, int local, float (*red)[4][kCols], float* dsh) {
     const int k = blockIdx.y;
     HeadBwdArgs hb = hg.p[k];
     const int blocks_x = hg.blocks_x[k], G = hg.G[k];
@@ -1077,17 +1043,23 @@ __global__ __launch_bounds__(256) void head_bwd_group_kernel(HeadBwdGroup hg) {
     const rrl_loss_t& l = hb.la;
     arrive_together(hb.B, hb.H, hb.dout, hb.need_w, l.kind, l.n_part, l.part_stride, l.f0, l.ld, l.n_heads, l.head_stride,
                     l.da_parts, l.da_part_stride, blocks_x, G);
-    const int local = blockIdx.x;
-    if (local >= blocks_x * G) return;
+    if (local >= blocks_x * G) return;                  // (an unused member slot has blocks_x = 0)
     head_bwd_dispatch(hb, local % blocks_x, local / blocks_x, red, dsh);
 }
 
+// solo launch: grid (column blocks x heads of the largest member, members): the member comes out of the grid (mlp_common.hpp)
+__global__ __launch_bounds__(256) void head_bwd_group_kernel(HeadBwdGroup hg) {
+    __shared__ float red[kSlices][4][kCols];
+    __shared__ float dsh[1024 * 4];
+    head_bwd_member_body(hg, blockIdx.x, red, dsh);
+}
+
+// packed launch: the same grid per seed under the XCD-aware placement (pack.hpp, rrl_pack::locate_grid)
 __global__ __launch_bounds__(256) void head_bwd_pack_kernel(const HeadBwdGroup* __restrict__ groups, rrl_pack::Idx ix) {
     __shared__ float red[kSlices][4][kCols];
     __shared__ float dsh[1024 * 4];
-    int s, local;
-    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
-    head_bwd_group_body(groups[s], local, red, dsh);
+    RRL_PACK_LOCATE(ix, s, local);
+    head_bwd_member_body(groups[s], local, red, dsh);
 }
 
 // ---- head backward + hidden backward of the critic-loss kinds in ONE launch ----------------------------------------------
@@ -1116,8 +1088,7 @@ __device__ __forceinline__ float critic_dout(const rrl_loss_t& la, int B, int g,
         default: return loss::dout_at<RRL_LOSS_QRISK_POLICY>(la, B, g, b, 0, term);
     }
 }
-__global__ __launch_bounds__(256) void backward_pair_kernel(PairJobs pj) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * kPairTileFloats + 1024];      // tiles | dOut; or red | dsh of the head path
+__device__ __forceinline__ void backward_pair_body(const PairJobs& pj, int x, float* smem) {
     const int k = blockIdx.y, z = blockIdx.z;
     HeadBwdArgs hb = pj.head[k];
     const int blocks_x = pj.blocks_x[k];
@@ -1127,7 +1098,7 @@ __global__ __launch_bounds__(256) void backward_pair_kernel(PairJobs pj) {
         const int G = pj.job[k][0].G;
         arrive_together(hb.B, hb.H, hb.dout, hb.need_w, l.kind, l.n_part, l.part_stride, l.f0, l.ld, l.n_heads, l.head_stride,
                         l.da_parts, l.da_part_stride, blocks_x, G);
-        const int local = blockIdx.x;
+        const int local = x;
         if (local >= blocks_x * G) return;
         // (the four critic-loss kinds only: the policy-head kinds never come here, and their code would double the kernel)
         float (*red)[4][kCols] = reinterpret_cast<float (*)[4][kCols]>(smem);
@@ -1146,7 +1117,7 @@ __global__ __launch_bounds__(256) void backward_pair_kernel(PairJobs pj) {
     arrive_together(ga.M, ga.N, ga.K, ga.lda, ga.ldb, ga.ldc, ga.ldmask, ga.sA, ga.sB, ga.sC, ga.sMask, ga.sColsum,
                     ga.relu, ga.accumulate, ga.first_stride, ga.ldx, ga.din, ga.G, ga.skip_c, j.tiles, j.tiles_x, j.G, hb.B, hb.H,
                     l.kind, l.n_part, l.part_stride, l.f0);
-    const int t0 = 4 * blockIdx.x;
+    const int t0 = 4 * x;
     if (t0 >= j.tiles * j.G) return;
     const int g = t0 / j.tiles;                    // tiles % 4 == 0 (host-checked): the four tiles serve one head
     float* dsh = smem + 4 * kPairTileFloats;
@@ -1164,6 +1135,17 @@ __global__ __launch_bounds__(256) void backward_pair_kernel(PairJobs pj) {
         gemm16_tile<2, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3, eval_dout);
     else      // (128-wide panels for these tiles -- they stage one operand only, 10 KB either way -- measured: 10.4 -> 13.8 us)
         gemm16_tile<1, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3, eval_dout);
+}
+__global__ __launch_bounds__(256) void backward_pair_kernel(PairJobs pj) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * kPairTileFloats + 1024];      // tiles | dOut; or red | dsh of the head path
+    backward_pair_body(pj, blockIdx.x, smem);
+}
+// the same launch for S seeds (pack.hpp): grid (x under the XCD-aware placement, members, 3) -- 22 -> 19 launches per packed
+// iteration, as in the solo graph
+__global__ __launch_bounds__(256) void backward_pair_pack_kernel(const PairJobs* __restrict__ groups, rrl_pack::Idx ix) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * kPairTileFloats + 1024];
+    RRL_PACK_LOCATE(ix, s, local);
+    backward_pair_body(groups[s], local, smem);
 }
 
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
@@ -1360,11 +1342,10 @@ static int build_hidden_group(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg
     return RRL_OK;
 }
 
-int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* stream) {
-    HiddenGroup hg;
-    const int rc = build_hidden_group(n, ps, hg);
-    if (rc != RRL_OK) return rc;
-    HiddenJobs hj{};
+// the jobs of a group launch (grid (x, member, {NN, TN})) from the tile / block counts of a HiddenGroup; returns the
+// workgroups of the largest job
+static int hidden_jobs(int n, const rrl_hidden_bwd_t* ps, const HiddenGroup& hg, HiddenJobs& hj) {
+    hj = HiddenJobs{};
     int most = 1;
     for (int k = 0; k < n; ++k) {
         const int nn_tiles = hg.per_head[k] - hg.tn_tiles[k];
@@ -1372,6 +1353,15 @@ int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* strea
         hj.job[k][1] = HiddenJob{hg.tn[k], hg.tn_tiles[k], hg.tn_tiles_x[k], hg.fast[k], ps[k].G};
         most = std::max(most, std::max(hg.tn_tiles[k], nn_tiles) * ps[k].G);
     }
+    return most;
+}
+
+int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* stream) {
+    HiddenGroup hg;
+    const int rc = build_hidden_group(n, ps, hg);
+    if (rc != RRL_OK) return rc;
+    HiddenJobs hj;
+    const int most = hidden_jobs(n, ps, hg, hj);
     hipLaunchKernelGGL(gemm16_group_kernel, dim3(most, n, 2), dim3(64), 0, (hipStream_t)stream, hj);
     return check_launch();
 }
@@ -1389,6 +1379,14 @@ static int pack_panel(int S) { return S >= 3 ? 32 : (S >= 2 ? 64 : kPanel); }
 // Block form of the packed hidden-layer backward (gemm_block_pack_kernel<1, 2>: 32 x 64 blocks) from 3 seeds on; 64 x 64 and
 // 32 x 32 blocks measured as well (profiles/patches/README.md)
 static int pack_block(int S) { return S >= 3 ? 12 : 0; }
+// seeds up to which the packed head + hidden backward of the critic-loss kinds is ONE launch (RRL_PACK_PAIR_MAX_SEEDS: A/B runs)
+static int pack_pair_max_seeds() {
+    static const int v = [] {
+        const char* e = getenv("RRL_PACK_PAIR_MAX_SEEDS");
+        return e ? atoi(e) : 2;
+    }();
+    return v;
+}
 // tile counts of a HiddenGroup -> block counts; false: some member has no whole number of full, aligned blocks
 static bool hidden_blocks(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg, int wm, int wn) {
     const int bm = 32 * wm, bn = 32 * wn;
@@ -1406,47 +1404,54 @@ static bool hidden_blocks(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg, in
     return true;
 }
 
+// plan of a packed hidden-layer backward: per seed the jobs (tile form, or block form from pack_block(S) seeds on), the 2-D
+// placement; i1 = kernel shape (-12: 32 x 64 blocks; 128 / 64 / 32: K-panel width of the tile form), i0 = members
+static int hidden_pack_plan(const rrl_pack::Key& key, int S, const int* n, const rrl_hidden_bwd_t* const* members, hipStream_t st,
+                            rrl_pack::Plan*& plan) {
+    std::vector<HiddenJobs> jobs(S);
+    int most[rrl_pack::kMaxSeeds], members_most = 1;
+    int shape = pack_block(S);
+    for (int pass = 0; pass < 2; ++pass) {        // block form for every seed, or (second pass) the tile form for all
+        bool ok = true;
+        for (int s = 0; s < S && ok; ++s) {
+            HiddenGroup hg;
+            const int rc = build_hidden_group(n[s], members[s], hg);
+            if (rc != RRL_OK) return rc;
+            if (shape) ok = hidden_blocks(n[s], members[s], hg, shape / 10, shape % 10);
+            if (ok) most[s] = hidden_jobs(n[s], members[s], hg, jobs[s]);
+            members_most = std::max(members_most, n[s]);
+        }
+        if (ok) break;
+        shape = 0;                                 // some member has no whole number of full, aligned blocks
+    }
+    plan = rrl_pack::store(key, jobs.data(), sizeof(HiddenJobs) * S, st);
+    if (!plan) return rrl_pack::store_error();
+    rrl_pack::Idx ix;
+    plan->grid = finish_members(ix, S, most);
+    plan->ix = ix;
+    plan->i0 = members_most;
+    plan->i1 = shape ? -shape : pack_panel(S);
+    return RRL_OK;
+}
+static void launch_hidden_pack(const rrl_pack::Plan* plan, hipStream_t st) {
+    const dim3 grid(plan->grid, plan->i0, 2);
+    const HiddenJobs* dev = (const HiddenJobs*)plan->dev;
+    if (plan->i1 == -12) hipLaunchKernelGGL((gemm_block_pack_kernel<1, 2>), grid, dim3(256), 0, st, dev, plan->ix);
+    else if (plan->i1 == 64) hipLaunchKernelGGL(gemm16_pack_kernel<64>, grid, dim3(64), 0, st, dev, plan->ix);
+    else if (plan->i1 == 32) hipLaunchKernelGGL(gemm16_pack_kernel<32>, grid, dim3(64), 0, st, dev, plan->ix);
+    else hipLaunchKernelGGL(gemm16_pack_kernel<kPanel>, grid, dim3(64), 0, st, dev, plan->ix);
+}
+
 int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_bwd_t* const* members, void* stream) {
     rrl_pack::Key key;
     if (!pack_key(1, S, n, members, key)) return RRL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     rrl_pack::Plan* plan = rrl_pack::lookup(key);
     if (!plan) {
-        rrl_pack::Idx ix;
-        int shape = 0;
-        {
-            std::vector<HiddenGroup> groups;
-            int rc = build_pack<HiddenGroup>(S, n, members, groups, ix, build_hidden_group);
-            if (rc != RRL_OK) return rc;
-            shape = pack_block(S);
-            if (shape) {       // every seed's members in whole blocks, or the launch keeps the tile kernel
-                const int wm = shape / 10, wn = shape % 10;
-                bool ok = true;
-                std::vector<HiddenGroup> blocks = groups;
-                for (int s = 0; ok && s < S; ++s) ok = hidden_blocks(n[s], members[s], blocks[s], wm, wn);
-                if (ok) {
-                    groups.swap(blocks);
-                    for (int s = 0; s < S; ++s) ix.first[s + 1] = ix.first[s] + groups[s].first[n[s]];
-                    for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
-                } else {
-                    shape = 0;
-                }
-            }
-            plan = rrl_pack::store(key, groups.data(), sizeof(HiddenGroup) * S, st);
-        }
-        if (!plan) return rrl_pack::store_error();
-        plan->grid = rrl_pack::finish(ix);
-        plan->ix = ix;
-        plan->i1 = shape ? -shape : pack_panel(S);
+        const int rc = hidden_pack_plan(key, S, n, members, st, plan);
+        if (rc != RRL_OK) return rc;
     }
-    if (plan->i1 == -12)
-        hipLaunchKernelGGL((gemm_block_pack_kernel<1, 2>), dim3(plan->grid), dim3(256), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
-    else if (plan->i1 == 64)
-        hipLaunchKernelGGL(gemm16_pack_kernel<64>, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
-    else if (plan->i1 == 32)
-        hipLaunchKernelGGL(gemm16_pack_kernel<32>, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
-    else
-        hipLaunchKernelGGL(gemm16_pack_kernel<kPanel>, dim3(plan->grid), dim3(64), 0, st, (const HiddenGroup*)plan->dev, plan->ix);
+    launch_hidden_pack(plan, st);
     return check_launch();
 }
 
@@ -1554,14 +1559,19 @@ int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
 // head backward + hidden backward of n stacks: ONE launch (backward_pair_kernel) when every member is a critic-loss kind
 // with one output, full aligned tiles and dh2 as the only link between its two stages; otherwise the two launches of
 // rrl_mlp_head_backward_multi + rrl_mlp_hidden_backward_multi.  Same results either way.
-int rrl_mlp_backward_pair_multi(int n, const rrl_head_bwd_t* heads, const rrl_hidden_bwd_t* hidden, void* stream) {
+// PairJobs of n stacks (backward_pair_kernel); pair = false: some member does not qualify for the paired form (pj is then
+// unspecified).  most = workgroups of the largest job (grid.x)
+static int build_pair_jobs(int n, const rrl_head_bwd_t* heads, const rrl_hidden_bwd_t* hidden, PairJobs& pj, int& most, bool& pair,
+                           HeadBwdGroup* hg_out = nullptr, HiddenGroup* hd_out = nullptr) {
     HeadBwdGroup hg;
     int rc = build_head_group(n, heads, hg);
     if (rc != RRL_OK) return rc;
     HiddenGroup hd;
     rc = build_hidden_group(n, hidden, hd);
     if (rc != RRL_OK) return rc;
-    bool pair = true;
+    if (hg_out) *hg_out = hg;
+    if (hd_out) *hd_out = hd;
+    pair = true;
     for (int k = 0; k < n && pair; ++k) {
         const rrl_head_bwd_t& h = heads[k];
         const rrl_hidden_bwd_t& d = hidden[k];
@@ -1572,22 +1582,9 @@ int rrl_mlp_backward_pair_multi(int n, const rrl_head_bwd_t* heads, const rrl_hi
                (h.B % kPairPanel) == 0 && (nn_tiles % 4) == 0 && (hd.tn_tiles[k] % 4) == 0 &&
                (reinterpret_cast<uintptr_t>(h.h2) & 15) == 0 && (reinterpret_cast<uintptr_t>(h.W3) & 15) == 0;
     }
-    hipStream_t st = (hipStream_t)stream;
-    if (!pair) {
-        launch_head_group(hg, n, st);
-        HiddenJobs hj{};
-        int most = 1;
-        for (int k = 0; k < n; ++k) {
-            const int nn_tiles = hd.per_head[k] - hd.tn_tiles[k];
-            hj.job[k][0] = HiddenJob{hd.nn[k], nn_tiles, hd.nn_tiles_x[k], hd.fast[k], hidden[k].G};
-            hj.job[k][1] = HiddenJob{hd.tn[k], hd.tn_tiles[k], hd.tn_tiles_x[k], hd.fast[k], hidden[k].G};
-            most = std::max(most, std::max(hd.tn_tiles[k], nn_tiles) * hidden[k].G);
-        }
-        hipLaunchKernelGGL(gemm16_group_kernel, dim3(most, n, 2), dim3(64), 0, st, hj);
-        return check_launch();
-    }
-    PairJobs pj{};
-    int most = 1;
+    if (!pair) return RRL_OK;
+    pj = PairJobs{};
+    most = 1;
     for (int k = 0; k < n; ++k) {
         const int nn_tiles = hd.per_head[k] - hd.tn_tiles[k];
         pj.job[k][0] = HiddenJob{hd.nn[k], nn_tiles, hd.nn_tiles_x[k], 1, hidden[k].G};
@@ -1598,8 +1595,49 @@ int rrl_mlp_backward_pair_multi(int n, const rrl_head_bwd_t* heads, const rrl_hi
         pj.blocks_x[k] = hg.blocks_x[k];
         most = std::max(most, std::max(std::max(hd.tn_tiles[k], nn_tiles) * hidden[k].G / 4, hg.blocks_x[k] * heads[k].G));
     }
+    return RRL_OK;
+}
+
+// head backward + hidden backward of n stacks: ONE launch (backward_pair_kernel) when every member is a critic-loss kind
+// with one output, full aligned tiles and dh2 as the only link between its two stages; otherwise the two launches of
+// rrl_mlp_head_backward_multi + rrl_mlp_hidden_backward_multi.  Same results either way.
+int rrl_mlp_backward_pair_multi(int n, const rrl_head_bwd_t* heads, const rrl_hidden_bwd_t* hidden, void* stream) {
+    PairJobs pj;
+    HeadBwdGroup hg;
+    HiddenGroup hd;
+    int most = 1;
+    bool pair = false;
+    const int rc = build_pair_jobs(n, heads, hidden, pj, most, pair, &hg, &hd);
+    if (rc != RRL_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!pair) {
+        launch_head_group(hg, n, st);
+        HiddenJobs hj;
+        const int m = hidden_jobs(n, hidden, hd, hj);
+        hipLaunchKernelGGL(gemm16_group_kernel, dim3(m, n, 2), dim3(64), 0, st, hj);
+        return check_launch();
+    }
     hipLaunchKernelGGL(backward_pair_kernel, dim3(most, n, 3), dim3(256), 0, st, pj);
     return check_launch();
+}
+
+static int head_pack_plan(const rrl_pack::Key& key, int S, const int* n, const rrl_head_bwd_t* const* members, hipStream_t st,
+                          rrl_pack::Plan*& plan) {
+    std::vector<HeadBwdGroup> groups(S);
+    int most[rrl_pack::kMaxSeeds], members_most = 1;
+    for (int s = 0; s < S; ++s) {
+        const int rc = build_head_group(n[s], members[s], groups[s]);
+        if (rc != RRL_OK) return rc;
+        most[s] = largest_member(groups[s], n[s]);
+        members_most = std::max(members_most, n[s]);
+    }
+    plan = rrl_pack::store(key, groups.data(), sizeof(HeadBwdGroup) * S, st);
+    if (!plan) return rrl_pack::store_error();
+    rrl_pack::Idx ix;
+    plan->grid = finish_members(ix, S, most);
+    plan->ix = ix;
+    plan->i0 = members_most;
+    return RRL_OK;
 }
 
 int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t* const* members, void* stream) {
@@ -1608,16 +1646,60 @@ int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t
     hipStream_t st = (hipStream_t)stream;
     rrl_pack::Plan* plan = rrl_pack::lookup(key);
     if (!plan) {
-        std::vector<HeadBwdGroup> groups;
-        rrl_pack::Idx ix;
-        const int rc = build_pack<HeadBwdGroup>(S, n, members, groups, ix, build_head_group);
+        const int rc = head_pack_plan(key, S, n, members, st, plan);
         if (rc != RRL_OK) return rc;
-        plan = rrl_pack::store(key, groups.data(), sizeof(HeadBwdGroup) * S, st);
-        if (!plan) return rrl_pack::store_error();
-        plan->grid = rrl_pack::finish(ix);
-        plan->ix = ix;
     }
-    hipLaunchKernelGGL(head_bwd_pack_kernel, dim3(plan->grid), dim3(256), 0, st, (const HeadBwdGroup*)plan->dev, plan->ix);
+    hipLaunchKernelGGL(head_bwd_pack_kernel, dim3(plan->grid, plan->i0), dim3(256), 0, st, (const HeadBwdGroup*)plan->dev, plan->ix);
+    return check_launch();
+}
+
+// rrl_mlp_backward_pair_multi for S seeds: ONE launch (backward_pair_pack_kernel) when every member of every seed qualifies
+// for the paired form, the two packed launches otherwise -- the same decision, per seed the same results as the solo entry.
+int rrl_mlp_backward_pair_multi_packed(int S, const int* n, const rrl_head_bwd_t* const* heads,
+                                       const rrl_hidden_bwd_t* const* hidden, void* stream) {
+    rrl_pack::Key key, key_head, key_hidden;
+    if (!pack_key(3, S, n, heads, key_head) || !pack_key(1, S, n, hidden, key_hidden)) return RRL_EINVAL;
+    key.pod(6);
+    key.add(key_head.bytes.data(), key_head.bytes.size());
+    key.add(key_hidden.bytes.data(), key_hidden.bytes.size());
+    hipStream_t st = (hipStream_t)stream;
+    rrl_pack::Plan* plan = rrl_pack::lookup(key);
+    if (!plan) {
+        std::vector<PairJobs> jobs(S);
+        int most[rrl_pack::kMaxSeeds], members_most = 1;
+        // the paired launch keeps the solo kernel's latency shape (one wave per 16 x 16 tile, four tiles per workgroup); from
+        // pack_pair_max_seeds() + 1 seeds on the block form of the hidden backward behind its own head launch is faster
+        // (measured, S = 4: 23.6 us paired against 8.3 + 9.2 us: profiles/round5_packed/)
+        bool pair = S <= pack_pair_max_seeds();
+        for (int s = 0; s < S && pair; ++s) {
+            int m = 1;
+            const int rc = build_pair_jobs(n[s], heads[s], hidden[s], jobs[s], m, pair);
+            if (rc != RRL_OK) return rc;
+            most[s] = m;
+            members_most = std::max(members_most, n[s]);
+        }
+        if (pair) {
+            plan = rrl_pack::store(key, jobs.data(), sizeof(PairJobs) * S, st);
+            if (!plan) return rrl_pack::store_error();
+            rrl_pack::Idx ix;
+            plan->grid = finish_members(ix, S, most);
+            plan->ix = ix;
+            plan->i0 = members_most;
+            plan->i1 = 1;
+        } else {
+            // not pairable: remember that (an empty plan: no device copy needed) and issue the two packed launches
+            PairJobs none{};
+            plan = rrl_pack::store(key, &none, sizeof none, st);
+            if (!plan) return rrl_pack::store_error();
+            plan->i1 = 0;
+        }
+    }
+    if (plan->i1 == 0) {
+        const int rc = rrl_mlp_head_backward_multi_packed(S, n, heads, stream);
+        return rc != RRL_OK ? rc : rrl_mlp_hidden_backward_multi_packed(S, n, hidden, stream);
+    }
+    hipLaunchKernelGGL(backward_pair_pack_kernel, dim3(plan->grid, plan->i0, 3), dim3(256), 0, st, (const PairJobs*)plan->dev,
+                       plan->ix);
     return check_launch();
 }
 

@@ -64,6 +64,26 @@ __device__ __forceinline__ bool locate(const Idx& ix, int b, int& s, int& local)
     return s < ix.S && local < ix.first[s + 1] - ix.first[s];
 }
 
+// The same for a launch whose MEMBER (stack / backward problem / Adam segment of the seed's group) is blockIdx.y -- the
+// round-4 structure of the solo group launches, brought to the packed ones in round 5: first[] then holds the workgroups of
+// every seed's LARGEST member, and under the XCD-aware placement the seed and the index inside its grid follow from b by
+// arithmetic alone.  Nothing is read before the member's argument block -- whose address is then known at wave start, so
+// that ONE batch of scalar loads fetches it from the plan's device copy -- and the block's own workgroup count bounds `local`
+// (a surplus workgroup exits behind that batch).  The linear placement (S > 8 with an uneven last round) keeps the walk.
+__device__ __forceinline__ bool locate_grid(const Idx& ix, int b, int& s, int& local) {
+    if (ix.sp == 0) return locate(ix, b, s, local);
+    const int x = b & 7;
+    if (ix.r > 1) {
+        const int j = b >> 3;
+        s = x + 8 * (j % ix.r);
+        local = j / ix.r;
+    } else {
+        s = x % ix.sp;
+        local = (b >> 3) * ix.p + x / ix.sp;
+    }
+    return s < ix.S;
+}
+
 // A packed kernel copies its argument block out of DEVICE memory, and a pointer loaded from memory is a generic ("flat")
 // pointer to the compiler: every access through it becomes a flat_load / flat_store, which counts against BOTH the vector
 // memory and the LDS counters and may complete out of order -- each LDS wait then drains every global load in flight

@@ -387,7 +387,7 @@ __device__ __forceinline__ void adam_slot_finish(const AdamVec& a, AdamSlot& s, 
     }
 }
 
-// `first` (optional): the thread's first slot, already loaded by the caller (adam_multi_body requests it BEFORE it waits for
+// `first` (optional): the thread's first slot, already loaded by the caller (adam_seg_body requests it BEFORE it waits for
 // the step count and the bias corrections: they are needed by the arithmetic only)
 __device__ __forceinline__ void adam_range(long long n, float* p, const float* g, float* m, float* v,
                                            float step_size, float bc2_sqrt, float b1, float b2, float eps,
@@ -423,16 +423,6 @@ __device__ __forceinline__ void adam_range(long long n, float* p, const float* g
 
 // several flat buffers (e.g. critic + policy of one update) in ONE launch; every segment keeps its own step
 // counter, advanced by the last of ITS workgroups.
-__device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec, float lr, float b1, float b2, float eps,
-                                              int block, int blocks, float* sh);
-__device__ __forceinline__ void adam_multi_body(const AdamSegs& a, int n_seg, float lr, float b1, float b2, float eps,
-                                                int blk, float* sh) {
-    int k = 0;
-    while (k + 1 < n_seg && blk >= a.first_block[k + 1]) ++k;
-    rrl_adam_seg_t sg = a.seg[k];
-    rrl_pack::to_global_all(sg.p, sg.g, sg.m, sg.v, sg.step_dev, sg.target, sg.g2, sg.g_part);   // packed launch: copied out of memory
-    adam_seg_body(sg, a.vec[k] != 0, lr, b1, b2, eps, blk - a.first_block[k], a.first_block[k + 1] - a.first_block[k], sh);
-}
 __device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec, float lr, float b1, float b2, float eps,
                                               int block, int blocks, float* sh) {
     // the step count is requested first, then the thread's first two float4 slots of every operand -- before anything waits
@@ -496,7 +486,9 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_se
     adam_seg_body(sg, vec != 0, lr, b1, b2, eps, blockIdx.x, blocks, sh);
 }
 
-// the same launch for S seeds (pack.hpp)
+// the same launch for S seeds (pack.hpp): grid (workgroups of the seeds' largest segments under the XCD-aware placement,
+// segments) -- blockIdx.y IS the segment and the seed follows from blockIdx.x by arithmetic, so the segment's block arrives in
+// one batch of scalar loads from the plan's device copy, as in the solo launch
 struct AdamPack {
     AdamSegs a;
     int n_seg;
@@ -505,9 +497,19 @@ struct AdamPack {
 __global__ __launch_bounds__(kBlock) void adam_pack_kernel(const AdamPack* __restrict__ packs, rrl_pack::Idx ix) {
     __shared__ float sh[4];
     int s, local;
-    if (!rrl_pack::locate(ix, blockIdx.x, s, local)) return;
+    asm volatile("" ::"s"(ix.sp), "s"(ix.p), "s"(ix.r), "s"(ix.S));
+    if (!rrl_pack::locate_grid(ix, blockIdx.x, s, local)) return;
     const AdamPack& pk = packs[s];
-    adam_multi_body(pk.a, pk.n_seg, pk.lr, pk.b1, pk.b2, pk.eps, local, sh);
+    const int k = blockIdx.y;
+    rrl_adam_seg_t sg = pk.a.seg[k];
+    const int vec = pk.a.vec[k], blocks = pk.a.first_block[k + 1] - pk.a.first_block[k];
+    const float lr = pk.lr, b1 = pk.b1, b2 = pk.b2, eps = pk.eps;
+    const int n_seg = pk.n_seg;
+    rrl_pack::to_global_all(sg.p, sg.g, sg.m, sg.v, sg.step_dev, sg.target, sg.g2, sg.g_part);
+    asm volatile("" ::"s"(sg.n), "s"(sg.tau), "s"(sg.weight_decay), "s"(sg.n_part), "s"(sg.part_stride), "s"(sg.part_elems),
+                 "s"(vec), "s"(blocks), "s"(lr), "s"(b1), "s"(b2), "s"(eps), "s"(n_seg));
+    if (k >= n_seg || local >= blocks) return;
+    adam_seg_body(sg, vec != 0, lr, b1, b2, eps, local, blocks, sh);
 }
 
 // ---- N(0,1) fill: out[2i], out[2i+1] = the Philox normal pair of index i (stream RRL_STREAM_NOISE) ----
@@ -718,20 +720,26 @@ int rrl_adam_step_multi_packed(int S, const int* n_seg, const rrl_adam_seg_t* co
         rrl_pack::Idx ix;
         ix.S = S;
         ix.first[0] = 0;
+        int segs_most = 1;
         for (int s = 0; s < S; ++s) {
+            packs[s] = AdamPack{};
             const int rc = build_adam_segs(n_seg[s], segs[s], packs[s].a);
             if (rc != RRL_OK) return rc;
             packs[s].n_seg = n_seg[s];
             packs[s].lr = lr[s]; packs[s].b1 = beta1; packs[s].b2 = beta2; packs[s].eps = eps;
-            ix.first[s + 1] = ix.first[s] + packs[s].a.first_block[n_seg[s]];
+            int most = 1;                 // 2-D grid: a seed owns as many workgroups per segment row as its largest segment has
+            for (int k = 0; k < n_seg[s]; ++k) most = std::max(most, packs[s].a.first_block[k + 1] - packs[s].a.first_block[k]);
+            ix.first[s + 1] = ix.first[s] + most;
+            segs_most = std::max(segs_most, n_seg[s]);
         }
         for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
         plan = rrl_pack::store(key, packs.data(), sizeof(AdamPack) * S, st);
         if (!plan) return rrl_pack::store_error();
         plan->grid = rrl_pack::finish(ix);
         plan->ix = ix;
+        plan->i0 = segs_most;
     }
-    hipLaunchKernelGGL(adam_pack_kernel, dim3(plan->grid), dim3(kBlock), 0, st, (const AdamPack*)plan->dev, plan->ix);
+    hipLaunchKernelGGL(adam_pack_kernel, dim3(plan->grid, plan->i0), dim3(kBlock), 0, st, (const AdamPack*)plan->dev, plan->ix);
     return check_launch();
 }
 

@@ -332,8 +332,7 @@ def backward_multi(triples):
     hidden = (_lib.rrl_hidden_bwd_t * n)(*[t[1] for t in triples])
     rest = [t[2] for t in triples if t[2] is not None]          # stacks whose first layer is not fused into `hidden`
     inputs = (_lib.rrl_input_bwd_t * len(rest))(*rest) if rest else None
-    record("head_bwd", heads, len(head_list))
-    record("hidden_bwd", hidden, n)
+    record("pair_bwd", heads, hidden, n)
     if inputs is not None:
         record("unsupported", "rrl_mlp_input_backward_multi")
     # head + hidden backward: one launch for the critic-loss kinds (rrl_mlp_backward_pair_multi), else the two launches

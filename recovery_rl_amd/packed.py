@@ -11,6 +11,7 @@ is captured in one hipGraph.  Every seed's state after K packed iterations equal
 (tests/test_packed_gpu.py).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -20,6 +21,8 @@ from . import fast_update
 
 class PackedLoop:
     MAX_SEEDS = 16
+    # seeds up to which the library issues the critic-loss head + hidden backward as one launch (csrc pack_pair_max_seeds)
+    PAIR_MAX_SEEDS = int(os.environ.get("RRL_PACK_PAIR_MAX_SEEDS", "2"))
 
     def __init__(self, loops, online_qrisk=True):
         """loops: VectorLoops in steady state (past start_steps, batch available), each on the fused grouped path."""
@@ -72,6 +75,13 @@ class PackedLoop:
                 n = (C.c_int * S)(*[op[2] for op in ops])
                 members = (p(typ) * S)(*[C.cast(op[1], p(typ)) for op in ops])
                 stages.append((fn, (S, n, members), ops))
+            elif kind == "pair_bwd":
+                # head + hidden backward of every seed's stacks: rrl_mlp_backward_pair_multi for S seeds (one launch for the
+                # critic-loss kinds, the two packed launches otherwise)
+                n = (C.c_int * S)(*[op[3] for op in ops])
+                heads = (p(_lib.rrl_head_bwd_t) * S)(*[C.cast(op[1], p(_lib.rrl_head_bwd_t)) for op in ops])
+                hidden = (p(_lib.rrl_hidden_bwd_t) * S)(*[C.cast(op[2], p(_lib.rrl_hidden_bwd_t)) for op in ops])
+                stages.append((self.lib.rrl_mlp_backward_pair_multi_packed, (S, n, heads, hidden), ops))
             elif kind == "adam":
                 b1, b2, eps = ops[0][4], ops[0][5], ops[0][6]
                 assert all(op[4:7] == (b1, b2, eps) for op in ops)
@@ -94,6 +104,22 @@ class PackedLoop:
             else:
                 raise _lib.RRLError("launch kind %r cannot be packed" % kind)
         return stages
+
+    @property
+    def launches(self):
+        """Kernel launches of one packed iteration: a head + hidden backward stage is ONE launch when every stack of every seed
+        has a critic-loss kind (rrl_mlp_backward_pair_multi_packed), two otherwise; per-seed calls count once per seed."""
+        total = 0
+        for fn, args, ops in self.stages:
+            if ops[0][0] == "pair_bwd":
+                critic = all(_lib.LOSS_SAC_CRITIC <= op[1][k].loss.kind <= _lib.LOSS_QRISK_POLICY
+                             for op in ops for k in range(op[3]))
+                total += 1 if critic and self.S <= self.PAIR_MAX_SEEDS else 2
+            elif ops[0][0] == "call":
+                total += len(ops)
+            else:
+                total += 1
+        return total
 
     @staticmethod
     def _call_each(calls, stream):
