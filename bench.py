@@ -392,26 +392,22 @@ def roofline_stages(a, device, iteration_ms):
         return 2.0 * G * M * (din * H + H * H + H * dout)
 
     rows = []
-    skip = False
     for pos, op in enumerate(tape):
         kind = op[0]
-        if skip:                      # the hidden backward that went out with the head backward before it
-            skip = False
-            continue
-        if kind == "head_bwd" and pos + 1 < len(tape) and tape[pos + 1][0] == "hidden_bwd" and tape[pos + 1][2] == op[2]:
-            # what the solo iteration launches for such a pair (fast_update.backward_multi): rrl_mlp_backward_pair_multi -- ONE
-            # launch for the critic-loss kinds, the two launches inside the entry point for the policy-head kinds
-            heads, hid, n = op[1], tape[pos + 1][1], op[2]
+        if kind == "pair_bwd":
+            # what the solo iteration launches for the head + hidden backward of its stacks (fast_update.backward_multi):
+            # rrl_mlp_backward_pair_multi -- ONE launch whose tiles derive dh2 (critic-loss kinds and, since round 5, the
+            # policy-head kinds)
+            heads, hid, n = op[1], op[2], op[3]
             fl = 0.0
             for k in range(n):
                 h = hid[k]
                 fl += 2.0 * h.G * h.B * h.H * h.H * (2 if h.dW2 else 1) + 4.0 * h.G * h.B * h.H * heads[k].dout
                 if h.first.x:
                     fl += 4.0 * h.G * h.B * h.H * h.first.din
-            one = all(0 <= heads[k].loss.kind <= 3 and heads[k].dout == 1 for k in range(n))
-            rows.append(("head + hidden backward x%d (%s)" % (n, "one launch" if one else "two launches"), "backward",
+            policy = any(heads[k].loss.kind > 3 for k in range(n))
+            rows.append(("head + hidden backward x%d (one launch, %s)" % (n, "policy head" if policy else "critic loss"), "backward",
                          lambda heads=heads, hid=hid, n=n: lib.rrl_mlp_backward_pair_multi(n, heads, hid, st()), fl, None))
-            skip = True
             continue
         if kind == "forward":
             arr, n = op[1], op[2]

@@ -488,7 +488,10 @@ typedef struct {
     const float* d_action;
     float* loss;
     int da_parts;                /* 0/1: d_action is a plain tensor; k: the sum of k partials da_part_stride apart */
-    long long da_part_stride;    /* (the dx_part of rrl_first_layer_t: k = H/16 <= 16) */
+    long long da_part_stride;    /* (the dx_part of rrl_first_layer_t: k = H/16 <= 16, or H/64 when the producer folded) */
+    int da_group;                /* 0/1: the partials are added one after the other; 4: they are column-TILE partials and every
+                                  * four consecutive ones are summed first ((p0 + p1) + p2) + p3, then the group sums one
+                                  * after the other -- the value a producer that folds (rrl_first_layer_t.dx_fold) stores */
 } rrl_loss_t;
 int rrl_mlp_head_backward_loss(const rrl_loss_t* loss, int G, int B, int H, int dout, const float* h2,
                                const float* W3, float* dW3, float* db3, float* dh2, void* stream);
@@ -538,15 +541,21 @@ typedef struct {
  *   dW1 = dh1^T x, db1 = column sums of dh1   -> first_part [B/16][first_stride]: row-tile t's partial of dW1[g][h][d] at
  *                                                 t*first_stride + (g*H + h)*din + d, of db1[g][h] at ... + G*H*din + g*H + h
  *                                                 (the layout of the head of a flat [W1 | b1 | ...] gradient buffer);
- *   dx  = dh1 W1                              -> dx_part [H/16][G][B][din]: column-tile partials.
+ *   dx  = dh1 W1                              -> dx_part [H/16][G][B][din]: column-tile partials; with dx_fold = 1
+ *                                                 [H/64][G][B][din]: the sums ((p0 + p1) + p2) + p3 of four consecutive
+ *                                                 column tiles, folded inside the workgroup that holds them (the paired
+ *                                                 launches of rrl_mlp_backward_pair_multi and the block form of the packed
+ *                                                 hidden backward; the one-tile-per-workgroup launches return RRL_ERANGE).
  * Consumers add the partials in a fixed order: rrl_adam_step_multi (g_part fields of the segment) and the policy-head
- * backward (da_parts of rrl_loss_t).  x = NULL: no first-layer work (then dh1 must be given).  Needs B, H % 128 == 0. */
+ * backward (da_parts / da_group of rrl_loss_t: 16 tile partials with da_group = 4 give the bits of 4 folded ones).
+ * x = NULL: no first-layer work (then dh1 must be given).  Needs B, H % 128 == 0. */
 typedef struct {
     const float *x, *W1;
     int ldx, din;
     float* first_part;
     long long first_stride;
     float* dx_part;
+    int dx_fold;
 } rrl_first_layer_t;
 typedef struct {
     int G, B, H;

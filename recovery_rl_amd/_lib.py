@@ -159,7 +159,7 @@ class rrl_loss_t(C.Structure):
                 ("out_t", C.c_void_p), ("v0", C.c_void_p), ("v1", C.c_void_p), ("v2", C.c_void_p),
                 ("v3", C.c_void_p), ("alpha", C.c_void_p), ("f0", C.c_float), ("ld", C.c_int),
                 ("n_heads", C.c_int), ("head_stride", C.c_longlong), ("d_action", C.c_void_p),
-                ("loss", C.c_void_p), ("da_parts", C.c_int), ("da_part_stride", C.c_longlong)]
+                ("loss", C.c_void_p), ("da_parts", C.c_int), ("da_part_stride", C.c_longlong), ("da_group", C.c_int)]
 
 
 HEAD_GAUSS, HEAD_STOCH = 0, 1
@@ -201,7 +201,7 @@ class rrl_head_bwd_t(C.Structure):
 
 class rrl_first_layer_t(C.Structure):
     _fields_ = [("x", C.c_void_p), ("W1", C.c_void_p), ("ldx", C.c_int), ("din", C.c_int), ("first_part", C.c_void_p),
-                ("first_stride", C.c_longlong), ("dx_part", C.c_void_p)]
+                ("first_stride", C.c_longlong), ("dx_part", C.c_void_p), ("dx_fold", C.c_int)]
 
 
 class rrl_hidden_bwd_t(C.Structure):

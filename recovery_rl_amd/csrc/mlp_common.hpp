@@ -99,10 +99,12 @@ static int finish_members(rrl_pack::Idx& ix, int S, const int* most) {
     for (int s = S; s < rrl_pack::kMaxSeeds; ++s) ix.first[s + 1] = ix.first[S];
     return rrl_pack::finish(ix);
 }
-// the placement's four scalars in one batch of kernel-argument loads, then (seed, index inside the seed's member row)
-#define RRL_PACK_LOCATE(ix, s, local)                       \
-    int s, local;                                           \
-    arrive_together((ix).sp, (ix).p, (ix).r, (ix).S);      \
+// the placement's four scalars in one batch of kernel-argument loads, then (seed, index inside the seed's member row).
+// (`plan` is named for the reader; pinning the pointer as well -- "s"(address) -- makes the compiler copy it out of a vector
+// register in some kernels and fails: "illegal VGPR to SGPR copy")
+#define RRL_PACK_LOCATE(ix, plan, s, local)                                                   \
+    int s, local;                                                                             \
+    arrive_together((ix).sp, (ix).p, (ix).r, (ix).S);                                         \
     if (!rrl_pack::locate_grid((ix), blockIdx.x, s, local)) return
 
 // tiles of R >= 4 need more than the default 64 KB of LDS per workgroup (gfx950 has 160 KB per CU): opt in once

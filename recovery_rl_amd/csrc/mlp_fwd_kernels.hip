@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg
 template <int R>
 __global__ __launch_bounds__(256) void mlp3_fwd_split_pack_kernel(const StackGroup* __restrict__ groups, rrl_pack::Idx ix) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    RRL_PACK_LOCATE(ix, s, local);
+    RRL_PACK_LOCATE(ix, groups, s, local);
     const StackGroup& sg = groups[s];
     const int k = blockIdx.y;
     StackArgs a = sg.a[k];

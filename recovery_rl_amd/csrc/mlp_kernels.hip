@@ -58,6 +58,7 @@ struct GemmArgs {
     long long first_stride;
     int ldx, din, G;
     int skip_c;           // do not write the C tile itself (dh1): nothing reads it once the first layer is done here
+    int dx_fold;          // dx_part holds sums over groups of four consecutive column tiles, folded by the workgroup that holds them
 };
 
 // pointers of an argument block that was copied out of device memory (packed launches): see rrl_pack::to_global
@@ -149,11 +150,16 @@ __device__ __forceinline__ void wave_lds_sync() {
 struct NothingBehindRequests {
     __device__ __forceinline__ void operator()() const {}
 };
+// DOUT (GEN): outputs of the head whose dh2 is derived -- dh2[b][h] = h2[b][h] > 0 ? sum_o dOut[b][o] W3[o][h] : 0 as the
+// fmaf chain over o = 0 .. DOUT - 1 starting from 0 (head_bwd_loss_body's order); dsh is [B][DOUT], w3 [DOUT][H].  One output:
+// the critic-loss kinds, W3 fragments from registers; 2 / 4 outputs (the stochastic / tanh-Gaussian policy heads): the k-
+// contiguous W3 elements of the NN product come from an LDS copy `w3s` ([DOUT][H], staged by behind_requests()).
 template <int MODE, bool FAST, int PANEL = kPanel, bool DEEP = false, bool GEN = false, bool WSYNC = false,
-          class BEHIND = NothingBehindRequests>  // MODE: 0 NT, 1 NN, 2 TN
+          class BEHIND = NothingBehindRequests, int DOUT = 1>  // MODE: 0 NT, 1 NN, 2 TN
 __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g,
                                             const float* dsh = nullptr, const float* w3 = nullptr,
-                                            BEHIND behind_requests = BEHIND()) {
+                                            BEHIND behind_requests = BEHIND(), const float* w3s = nullptr,
+                                            bool keep_sx = false, float* sx_out = nullptr) {
     const int lane = threadIdx.x & 63;
     const int m0 = by * kTile, n0 = bx * kTile;
     const float* A = a.A + g * a.sA;
@@ -166,8 +172,10 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;  // TN: running sum of my A operands (for colsum)
     Frag fa, fb, na, nb;
-    Frag fw, nw;          // GEN, NN: the W3 elements that go with the k-contiguous dh2 fragments
-    float4 w3c = make_float4(0.f, 0.f, 0.f, 0.f);      // GEN, TN: W3 of the lane's four dh2 columns
+    Frag fw, nw;          // GEN, NN, one output: the W3 elements that go with the k-contiguous dh2 fragments
+    float4 w3c[DOUT];     // GEN, TN: W3 of the lane's four dh2 columns, per output
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) w3c[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     const auto sync = [&]() {
         if constexpr (WSYNC) wave_lds_sync();
         else __syncthreads();
@@ -178,17 +186,27 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
         else load_direct<FAST>(ra, A, a.lda, m0, a.M, k0, a.K, lane);
         if (kStageB) load_staged<FAST>(rb, B, a.ldb, n0, a.N, k0, a.K, lane);
         else load_direct<FAST>(rb, B, a.ldb, n0, a.N, k0, a.K, lane);
-        if constexpr (GEN && MODE == 1) {
+        if constexpr (GEN && MODE == 1 && DOUT == 1) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) rw.v[j] = *reinterpret_cast<const float4*>(w3 + k0 + 16 * j + 4 * (lane >> 4));
         }
     };
     auto load = [&](int k0) { load_into(fa, fb, fw, k0); };
-    if constexpr (GEN && MODE == 2) w3c = *reinterpret_cast<const float4*>(w3 + m0 + (lane & 3) * 4);
-    // dh2 from (h2 fragment, dOut, W3): the formula of head_bwd_loss_body for one output
-    const auto gen4 = [](const float4& h, float go, const float4& w) {
-        return make_float4(h.x > 0.f ? fmaf(go, w.x, 0.f) : 0.f, h.y > 0.f ? fmaf(go, w.y, 0.f) : 0.f,
-                           h.z > 0.f ? fmaf(go, w.z, 0.f) : 0.f, h.w > 0.f ? fmaf(go, w.w, 0.f) : 0.f);
+    if constexpr (GEN && MODE == 2) {
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) w3c[o] = *reinterpret_cast<const float4*>(w3 + (long long)o * a.lda + m0 + (lane & 3) * 4);
+    }
+    // dh2 from (h2 fragment, dOut, W3): the formula of head_bwd_loss_body -- d = fmaf(go[o], w[o], d) over the outputs
+    const auto gen4 = [](const float4& h, const float (&go)[DOUT], const float4 (&w)[DOUT]) {
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) {
+            d.x = fmaf(go[o], w[o].x, d.x);
+            d.y = fmaf(go[o], w[o].y, d.y);
+            d.z = fmaf(go[o], w[o].z, d.z);
+            d.w = fmaf(go[o], w[o].w, d.w);
+        }
+        return make_float4(h.x > 0.f ? d.x : 0.f, h.y > 0.f ? d.y : 0.f, h.z > 0.f ? d.z : 0.f, h.w > 0.f ? d.w : 0.f);
     };
 
     const int np = (a.K + PANEL - 1) / PANEL;
@@ -219,11 +237,28 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
         if constexpr (GEN) {
             if constexpr (MODE == 2) {           // staged [k = batch row][4 dh2 columns]
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) ca.v[j] = gen4(fa.v[j], dsh[p * PANEL + (lane >> 2) + 16 * j], w3c);
-            } else {                             // direct: row m0 + i, four consecutive hidden columns per fragment
-                const float go = dsh[m0 + (lane & 15)];
+                for (int j = 0; j < VEC; ++j) {
+                    float go[DOUT];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) ca.v[j] = gen4(fa.v[j], go, fw.v[j]);
+                    for (int o = 0; o < DOUT; ++o) go[o] = dsh[(p * PANEL + (lane >> 2) + 16 * j) * DOUT + o];
+                    ca.v[j] = gen4(fa.v[j], go, w3c);
+                }
+            } else {                             // direct: row m0 + i, four consecutive hidden columns per fragment
+                float go[DOUT];
+#pragma unroll
+                for (int o = 0; o < DOUT; ++o) go[o] = dsh[(m0 + (lane & 15)) * DOUT + o];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    float4 w[DOUT];
+                    if constexpr (DOUT == 1) {
+                        w[0] = fw.v[j];
+                    } else {
+#pragma unroll
+                        for (int o = 0; o < DOUT; ++o)
+                            w[o] = *reinterpret_cast<const float4*>(w3s + o * a.K + p * PANEL + 16 * j + 4 * (lane >> 4));
+                    }
+                    ca.v[j] = gen4(fa.v[j], go, w);
+                }
             }
         }
         if (kStageA || kStageB) {
@@ -305,7 +340,8 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
                 a.first_part[by * a.first_stride + ((long long)g * a.N + n0 + rr) * a.din + dd] = sw;
             if (a.first_part && dd == 0)
                 a.first_part[by * a.first_stride + (long long)a.G * a.N * a.din + (long long)g * a.N + n0 + rr] = sb;
-            if (a.dx_part && dd < a.din)
+            if (keep_sx) *sx_out = sx;         // the caller folds the dx partials of its four tiles (dx_fold)
+            else if (a.dx_part && dd < a.din)
                 a.dx_part[(((long long)bx * a.G + g) * a.M + m0 + rr) * a.din + dd] = sx;
         }
     }
@@ -397,7 +433,7 @@ template <int PANEL>
 __global__ __launch_bounds__(64) void gemm16_pack_kernel(const HiddenJobs* __restrict__ groups, rrl_pack::Idx ix) {
     __shared__ __attribute__((aligned(16))) float As[PANEL * kLd];
     __shared__ __attribute__((aligned(16))) float Bs[PANEL * kLd];
-    RRL_PACK_LOCATE(ix, s, local);
+    RRL_PACK_LOCATE(ix, groups, s, local);
     hidden_jobs_body<PANEL, true>(groups[s], local, As, Bs);
 }
 
@@ -530,8 +566,10 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx
     float* T = lds + w * 400;             // this wave's scratch for the first-layer work (the staged panels are done with)
 #pragma unroll
     for (int x = 0; x < WM; ++x) {
+        float sxv[WN];                    // dx partials of my column tiles (dx_fold)
 #pragma unroll
         for (int y = 0; y < WN; ++y) {
+            sxv[y] = 0.f;
             const f32x4 acc = acc0[x][y] + acc1[x][y];
             const int tm = m0 + (tm0 + x) * kTile, tn = n0 + (tn0 + y) * kTile;
             const int col = tn + i;
@@ -577,8 +615,26 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx
                         a.first_part[tby * a.first_stride + ((long long)g * a.N + tn + rr) * a.din + dd] = sw;
                     if (a.first_part && dd == 0)
                         a.first_part[tby * a.first_stride + (long long)a.G * a.N * a.din + (long long)g * a.N + tn + rr] = sb;
-                    if (a.dx_part && dd < a.din)
+                    if (a.dx_fold) sxv[y] = sx;
+                    else if (a.dx_part && dd < a.din)
                         a.dx_part[(((long long)tbx * a.G + g) * a.M + tm + rr) * a.din + dd] = sx;
+                }
+            }
+        }
+        if constexpr (MODE == 1 && WN == 2) {
+            if (a.x && a.dx_part && a.dx_fold) {          // workgroup-uniform
+                // the block's 64 columns are one group of four column tiles: ((p0 + p1) + p2) + p3 -- the left wave of the
+                // row hands p0 + p1 over through LDS, the right wave adds its two and stores (gemm16's paired launch: the same)
+                float* F = lds + 4 * 400 + (wm * WM + x) * 64;
+                if (wn == 0) F[lane] = sxv[0] + sxv[1];
+                __syncthreads();
+                if (wn == 1) {
+                    float gs = F[lane];
+                    gs += sxv[0];
+                    gs += sxv[1];
+                    const int rr = lane & 15, dd = lane >> 4;
+                    const int tm = m0 + (tm0 + x) * kTile;
+                    if (dd < a.din) a.dx_part[(((long long)bx * a.G + g) * a.M + tm + rr) * a.din + dd] = gs;
                 }
             }
         }
@@ -594,7 +650,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx
 template <int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_block_pack_kernel(const HiddenJobs* __restrict__ groups, rrl_pack::Idx ix) {
     __shared__ __attribute__((aligned(16))) float lds[BlkLds<WM, WN>::kFloats];
-    RRL_PACK_LOCATE(ix, s, local);
+    RRL_PACK_LOCATE(ix, groups, s, local);
     const bool is_tn = blockIdx.z != 0;
     HiddenJob j = groups[s].job[blockIdx.y][blockIdx.z];
     GemmArgs& ga = j.ga;
@@ -629,61 +685,70 @@ namespace loss {
 __device__ __forceinline__ float sigm(float z) { return 1.f / (1.f + expf(-z)); }
 
 
-// dL/d action[b][j]: over the critic heads that consumed the action and, when the critic's first-layer backward came out
-// of the hidden-layer tiles (rrl_first_layer_t), over their column-tile partials -- up to 2 x 16 loads, all issued
-// before the first add, summed head by head, tile by tile.
-__device__ __forceinline__ float d_action_sum(const rrl_loss_t& a, int b, int j) {
-    const float* p = a.d_action + (long long)b * a.ld + j;
-    const int parts = a.da_parts > 1 ? a.da_parts : 1;
-    float da = 0.f;
-    for (int hd = 0; hd < a.n_heads; ++hd) {
-        float v[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = p[hd * a.head_stride + (t < parts ? t : 0) * a.da_part_stride];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) da = t < parts ? da + v[t] : da;
-    }
-    return da;
-}
-
 // The policy-head kinds, split into "request everything" and "evaluate": a thread requests the operands of ALL its elements
 // (two critic heads x 16 column-tile partials of dL/d action, the head's partial sums, noise, scale) before it adds anything.
 // (d_action_sum above adds head 0's partials before it asks for head 1's, and the element loop asked for element 2's operands
 // after element 1's tanh / exp: four to five dependent round trips in a kernel whose critic-loss twin has one -- 7.7 / 9.1 us
 // against 4.6.)  Same additions in the same order: the same bits.
+// NP = partials of a critic head held per element: 4 (the folded layout of H <= 256, or a plain tensor) or 16 (tile partials)
+template <int NP>
 struct HeadIn {
-    float da[2][16];      // dL/d action partials of critic heads 0 and 1 (heads beyond two: added by d_action_tail)
+    float da[2][NP];      // dL/d action partials of critic heads 0 and 1 (heads beyond two: added by d_action_fold)
     float m[4], r[4];     // partial sums of the head's outputs: (mean | raw log-std) or (raw mean | unused)
     float e, sc, x2;      // noise, scale, (stochastic head) v2[j]
 };
-__device__ __forceinline__ void d_action_load(const rrl_loss_t& a, int b, int j, float (&da)[2][16]) {
+// dL/d action[b][j] = sum over the critic heads that consumed the action and, when the critic's first-layer backward came
+// out of the hidden-layer tiles (rrl_first_layer_t), over their partials.  Order (every consumer, every producer layout):
+// head by head; inside a head the partials one after the other (da_group <= 1: they are final -- a plain tensor, or the
+// sums a folding producer stored), or (da_group = 4: column-TILE partials) every four consecutive ones first as
+// ((p0 + p1) + p2) + p3 and the group sums one after the other -- which is what a folding producer stores, so 16 tile
+// partials and 4 folded ones give the same bits.  Up to four final partials per head are requested as 8 loads (NP = 4),
+// anything else as 32 (NP = 16): the caller picks the instantiation once per kernel (needs_np16).
+__device__ __forceinline__ bool needs_np16(const rrl_loss_t& a) { return a.da_parts > 4 || a.da_group == 4; }
+template <int NP>
+__device__ __forceinline__ void d_action_load(const rrl_loss_t& a, int b, int j, float (&da)[2][NP]) {
     const float* p = a.d_action + (long long)b * a.ld + j;
     const int parts = a.da_parts > 1 ? a.da_parts : 1;
+    const long long h1 = (1 < a.n_heads ? 1 : 0) * a.head_stride;
 #pragma unroll
-    for (int hd = 0; hd < 2; ++hd) {
-        const long long ho = (hd < a.n_heads ? hd : 0) * a.head_stride;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) da[hd][t] = p[ho + (t < parts ? t : 0) * a.da_part_stride];
+    for (int t = 0; t < NP; ++t) {
+        const long long off = (t < parts ? t : 0) * a.da_part_stride;
+        da[0][t] = p[off];
+        da[1][t] = p[h1 + off];
     }
 }
-__device__ __forceinline__ float d_action_fold(const rrl_loss_t& a, int b, int j, const float (&v)[2][16]) {
-    const int parts = a.da_parts > 1 ? a.da_parts : 1;
-    float da = 0.f;
+// the sum of one head's partials v[0 .. parts) on top of `da`, in the order above
+template <int NP>
+__device__ __forceinline__ float d_action_head(float da, const float (&v)[NP], int parts, int group) {
+    if constexpr (NP == 16) {
+        if (group == 4) {
 #pragma unroll
-    for (int hd = 0; hd < 2; ++hd) {
-        if (hd < a.n_heads) {
+            for (int t0 = 0; t0 < 16; t0 += 4) {
+                float gs = v[t0];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) da = t < parts ? da + v[hd][t] : da;
+                for (int t = 1; t < 4; ++t) gs = t0 + t < parts ? gs + v[t0 + t] : gs;
+                da = t0 < parts ? da + gs : da;
+            }
+            return da;
         }
     }
-    if (a.n_heads > 2) {          // more than twin critics: the remaining heads the old way
+#pragma unroll
+    for (int t = 0; t < NP; ++t) da = t < parts ? da + v[t] : da;
+    return da;
+}
+template <int NP>
+__device__ __forceinline__ float d_action_fold(const rrl_loss_t& a, int b, int j, const float (&v)[2][NP]) {
+    const int parts = a.da_parts > 1 ? a.da_parts : 1;
+    float da = 0.f;
+    da = d_action_head<NP>(da, v[0], parts, a.da_group);
+    if (1 < a.n_heads) da = d_action_head<NP>(da, v[1], parts, a.da_group);
+    if (a.n_heads > 2) {          // more than twin critics: the remaining heads the same way, one after the other
         const float* p = a.d_action + (long long)b * a.ld + j;
         for (int hd = 2; hd < a.n_heads; ++hd) {
-            float w[16];
+            float w[NP];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) w[t] = p[hd * a.head_stride + (t < parts ? t : 0) * a.da_part_stride];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) da = t < parts ? da + w[t] : da;
+            for (int t = 0; t < NP; ++t) w[t] = p[hd * a.head_stride + (t < parts ? t : 0) * a.da_part_stride];
+            da = d_action_head<NP>(da, w, parts, a.da_group);
         }
     }
     return da;
@@ -698,9 +763,9 @@ __device__ __forceinline__ float psum_fold(const float (&v)[4], int np) {
     for (int k = 1; k < 4; ++k) x = np > k ? x + v[k] : x;
     return x;
 }
-template <int KIND>
-__device__ __forceinline__ void head_in_load(const rrl_loss_t& a, int b, int j, HeadIn& in) {
-    d_action_load(a, b, j, in.da);
+template <int KIND, int NP>
+__device__ __forceinline__ void head_in_load(const rrl_loss_t& a, int b, int j, HeadIn<NP>& in) {
+    d_action_load<NP>(a, b, j, in.da);
     if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
         psum_load(a.out, 4 * b + j, a.n_part, a.part_stride, in.m);
         psum_load(a.out, 4 * b + 2 + j, a.n_part, a.part_stride, in.r);
@@ -715,8 +780,9 @@ __device__ __forceinline__ void head_in_load(const rrl_loss_t& a, int b, int j, 
     }
 }
 // tanh-Gaussian head: d mean -> dx, d raw log-std -> ds (dout_at<RRL_LOSS_GAUSS_HEAD> for o = j and o = 2 + j)
-__device__ __forceinline__ void gauss_head_eval(const rrl_loss_t& a, int b, int j, const HeadIn& in, float& dx, float& ds) {
-    const float da = d_action_fold(a, b, j, in.da);
+template <int NP>
+__device__ __forceinline__ void gauss_head_eval(const rrl_loss_t& a, int b, int j, const HeadIn<NP>& in, float& dx, float& ds) {
+    const float da = d_action_fold<NP>(a, b, j, in.da);
     const float mean = psum_fold(in.m, a.n_part), raw = psum_fold(in.r, a.n_part);
     const float ls = fminf(fmaxf(raw, kLogSigMin), kLogSigMax);
     const float sd = expf(ls), e = in.e, sc = in.sc;
@@ -727,9 +793,10 @@ __device__ __forceinline__ void gauss_head_eval(const rrl_loss_t& a, int b, int 
     ds = inside ? (dx * sd * e - a.f0) : 0.f;
 }
 // stochastic head (dout_at<RRL_LOSS_STOCH_HEAD>): returns dOut, `term` = the element's contribution to dlog_std[j]
-__device__ __forceinline__ float stoch_head_eval(const rrl_loss_t& a, int b, int j, const HeadIn& in, float& term) {
+template <int NP>
+__device__ __forceinline__ float stoch_head_eval(const rrl_loss_t& a, int b, int j, const HeadIn<NP>& in, float& term) {
     const float t = tanhf(psum_fold(in.m, a.n_part));
-    const float da = d_action_fold(a, b, j, in.da);
+    const float da = d_action_fold<NP>(a, b, j, in.da);
     const float sd = expf(fmaxf(in.sc, a.f0));
     term = (in.sc >= a.f0) ? da * sd * in.e : 0.f;
     return da * in.x2 * (1.f - t * t);
@@ -766,28 +833,9 @@ __device__ __forceinline__ float dout_at(const rrl_loss_t& a, int B, int g, int 
         const float w0 = q0 > q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
         if (g == 0) term = fmaxf(q0, q1);
         return g == 0 ? w0 / B * q0 * (1.f - q0) : (1.f - w0) / B * q1 * (1.f - q1);
-    } else if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
-        const int j = o & 1;
-        float da = 0.f;
-        da = d_action_sum(a, b, j);
-        const float mean = psum(a.out, 4 * b + j, np, ps);
-        const float raw = psum(a.out, 4 * b + 2 + j, np, ps);
-        const float ls = fminf(fmaxf(raw, kLogSigMin), kLogSigMax);
-        const float sd = expf(ls), e = a.v0[2 * b + j], sc = a.v1[j];
-        const float y = tanhf(mean + sd * e);
-        const float one_m = 1.f - y * y;
-        const float dx = da * sc * one_m + a.f0 * (2.f * sc * y * one_m) / (sc * one_m + kEps);
-        if (o < 2) return dx;
-        const bool inside = (raw >= kLogSigMin) & (raw <= kLogSigMax);
-        return inside ? (dx * sd * e - a.f0) : 0.f;
     } else {
-        const int j = o;
-        const float t = tanhf(psum(a.out, 2 * b + j, np, ps));
-        float da = 0.f;
-        da = d_action_sum(a, b, j);
-        const float sd = expf(fmaxf(a.v1[j], a.f0));
-        term = (a.v1[j] >= a.f0) ? da * sd * a.v0[2 * b + j] : 0.f;
-        return da * a.v2[j] * (1.f - t * t);
+        static_assert(KIND == RRL_LOSS_QRISK_POLICY, "the policy-head kinds: head_in_load + gauss_head_eval / stoch_head_eval");
+        return 0.f;
     }
 }
 
@@ -807,6 +855,65 @@ template <int KIND>
 constexpr int kind_dout() {
     return (KIND >= RRL_LOSS_SAC_CRITIC && KIND <= RRL_LOSS_QRISK_POLICY) ? 1
            : KIND == RRL_LOSS_GAUSS_HEAD ? 4 : KIND == RRL_LOSS_STOCH_HEAD ? 2 : 0;   // 0: run-time (plain dOut)
+}
+
+// dOut [B][dout] of head g into LDS, by a 256-thread workgroup, from the loss description (the formulas of update_kernels.hip:
+// sac / qrisk *_grad, gauss / stoch_head_bwd); lsum = the thread's partial sums of the loss terms (critics: loss[g]; policies:
+// loss[0], g == 0 only) or of dlog_std[0..1] (stochastic head) -- the per-thread partial sums of the stand-alone kernels, so
+// every bit of the reduced values is theirs.  Used by the head backward and by the tiles of the paired launches.
+template <int KIND, int NP>
+__device__ __forceinline__ void eval_policy_rows(const rrl_loss_t& la, int B, float* dsh, float (&lsum)[2]) {
+    constexpr int DOUT = kind_dout<KIND>();
+    if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
+        // one thread per (row, action dim), two of them per pass: the mean and log-std gradients share tanh/exp
+        for (int e0 = threadIdx.x; e0 < B * 2; e0 += 512) {
+            const bool two = e0 + 256 < B * 2;
+            const int e1 = two ? e0 + 256 : e0;
+            loss::HeadIn<NP> in0, in1;
+            loss::head_in_load<KIND>(la, e0 >> 1, e0 & 1, in0);
+            loss::head_in_load<KIND>(la, e1 >> 1, e1 & 1, in1);
+            float dx, ds;
+            loss::gauss_head_eval(la, e0 >> 1, e0 & 1, in0, dx, ds);
+            dsh[4 * (e0 >> 1) + (e0 & 1)] = dx;
+            dsh[4 * (e0 >> 1) + 2 + (e0 & 1)] = ds;
+            if (two) {
+                loss::gauss_head_eval(la, e1 >> 1, e1 & 1, in1, dx, ds);
+                dsh[4 * (e1 >> 1) + (e1 & 1)] = dx;
+                dsh[4 * (e1 >> 1) + 2 + (e1 & 1)] = ds;
+            }
+        }
+    } else {
+        // one thread per batch row, both action dims: per-thread partial sums of dlog_std as in the stand-alone kernel
+        for (int b = threadIdx.x; b < B; b += 256) {
+            loss::HeadIn<NP> in0, in1;
+            loss::head_in_load<KIND>(la, b, 0, in0);
+            loss::head_in_load<KIND>(la, b, 1, in1);
+            float term;
+            dsh[b * DOUT + 0] = loss::stoch_head_eval(la, b, 0, in0, term);
+            lsum[0] += term;
+            dsh[b * DOUT + 1] = loss::stoch_head_eval(la, b, 1, in1, term);
+            lsum[1] += term;
+        }
+    }
+}
+// dOut [B][dout] of head g into LDS, by a 256-thread workgroup, from the loss description (the formulas of update_kernels.hip:
+// sac / qrisk *_grad, gauss / stoch_head_bwd); lsum = the thread's partial sums of the loss terms (critics: loss[g]; policies:
+// loss[0], g == 0 only) or of dlog_std[0..1] (stochastic head) -- the per-thread partial sums of the stand-alone kernels, so
+// every bit of the reduced values is theirs.  Used by the head backward and by the tiles of the paired launches.
+template <int KIND>
+__device__ __forceinline__ void eval_dout_rows(const rrl_loss_t& la, int B, int g, float* dsh, float (&lsum)[2]) {
+    if constexpr (KIND == RRL_LOSS_GAUSS_HEAD || KIND == RRL_LOSS_STOCH_HEAD) {
+        if (loss::needs_np16(la)) eval_policy_rows<KIND, 16>(la, B, dsh, lsum);      // (workgroup-uniform)
+        else eval_policy_rows<KIND, 4>(la, B, dsh, lsum);
+    } else {
+        // one thread per batch row (one output): the per-thread partial sums of the loss terms are then the ones of the
+        // stand-alone kernels (update_kernels.hip), and so is every bit of the reduced value
+        for (int b = threadIdx.x; b < B; b += 256) {
+            float term;
+            dsh[b] = loss::dout_at<KIND>(la, B, g, b, 0, term);
+            lsum[0] += term;
+        }
+    }
 }
 
 template <int KIND>
@@ -835,47 +942,8 @@ __device__ __forceinline__ void head_bwd_loss_body(const HeadBwdArgs& hb, int bx
     if constexpr (KIND == kPlainDOut) {
         const float* dO = la.out + (long long)g * B * dout;
         for (int e = threadIdx.x; e < B * dout; e += 256) dsh[e] = dO[e];
-    } else if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
-        // one thread per (row, action dim), two of them per pass: the mean and log-std gradients share tanh/exp
-        for (int e0 = threadIdx.x; e0 < B * 2; e0 += 512) {
-            const bool two = e0 + 256 < B * 2;
-            const int e1 = two ? e0 + 256 : e0;
-            loss::HeadIn in0, in1;
-            loss::head_in_load<KIND>(la, e0 >> 1, e0 & 1, in0);
-            loss::head_in_load<KIND>(la, e1 >> 1, e1 & 1, in1);
-            float dx, ds;
-            loss::gauss_head_eval(la, e0 >> 1, e0 & 1, in0, dx, ds);
-            dsh[4 * (e0 >> 1) + (e0 & 1)] = dx;
-            dsh[4 * (e0 >> 1) + 2 + (e0 & 1)] = ds;
-            if (two) {
-                loss::gauss_head_eval(la, e1 >> 1, e1 & 1, in1, dx, ds);
-                dsh[4 * (e1 >> 1) + (e1 & 1)] = dx;
-                dsh[4 * (e1 >> 1) + 2 + (e1 & 1)] = ds;
-            }
-        }
-    } else if constexpr (KIND == RRL_LOSS_STOCH_HEAD) {
-        // one thread per batch row, both action dims: per-thread partial sums of dlog_std as in the stand-alone kernel
-        for (int b = threadIdx.x; b < B; b += 256) {
-            loss::HeadIn in0, in1;
-            loss::head_in_load<KIND>(la, b, 0, in0);
-            loss::head_in_load<KIND>(la, b, 1, in1);
-            float term;
-            dsh[b * dout + 0] = loss::stoch_head_eval(la, b, 0, in0, term);
-            lsum[0] += term;
-            dsh[b * dout + 1] = loss::stoch_head_eval(la, b, 1, in1, term);
-            lsum[1] += term;
-        }
     } else {
-        // one thread per batch row (all its outputs): the per-thread partial sums of the loss terms are then the ones of
-        // the stand-alone kernels (update_kernels.hip), and so is every bit of the reduced value
-        for (int b = threadIdx.x; b < B; b += 256) {
-#pragma unroll
-            for (int o = 0; o < (DOUT ? DOUT : 1); ++o) {
-                float term;
-                dsh[b * dout + o] = loss::dout_at<KIND>(la, B, g, b, o, term);
-                lsum[0] += term;
-            }
-        }
+        eval_dout_rows<KIND>(la, B, g, dsh, lsum);
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -1042,7 +1110,7 @@ __device__ __forceinline__ void head_bwd_member_body(const HeadBwdGroup& hg, int
     globalize(hb);
     const rrl_loss_t& l = hb.la;
     arrive_together(hb.B, hb.H, hb.dout, hb.need_w, l.kind, l.n_part, l.part_stride, l.f0, l.ld, l.n_heads, l.head_stride,
-                    l.da_parts, l.da_part_stride, blocks_x, G);
+                    l.da_parts, l.da_part_stride, l.da_group, blocks_x, G);
     if (local >= blocks_x * G) return;                  // (an unused member slot has blocks_x = 0)
     head_bwd_dispatch(hb, local % blocks_x, local / blocks_x, red, dsh);
 }
@@ -1058,7 +1126,7 @@ __global__ __launch_bounds__(256) void head_bwd_group_kernel(HeadBwdGroup hg) {
 __global__ __launch_bounds__(256) void head_bwd_pack_kernel(const HeadBwdGroup* __restrict__ groups, rrl_pack::Idx ix) {
     __shared__ float red[kSlices][4][kCols];
     __shared__ float dsh[1024 * 4];
-    RRL_PACK_LOCATE(ix, s, local);
+    RRL_PACK_LOCATE(ix, groups, s, local);
     head_bwd_member_body(groups[s], local, red, dsh);
 }
 
@@ -1079,15 +1147,31 @@ struct PairJobs {
     HeadBwdArgs head[kMaxGroup];      // dh2 = null
     int blocks_x[kMaxGroup];
 };
-__device__ __forceinline__ float critic_dout(const rrl_loss_t& la, int B, int g, int b) {
-    float term;
-    switch (la.kind) {
-        case RRL_LOSS_SAC_CRITIC: return loss::dout_at<RRL_LOSS_SAC_CRITIC>(la, B, g, b, 0, term);
-        case RRL_LOSS_SAC_POLICY: return loss::dout_at<RRL_LOSS_SAC_POLICY>(la, B, g, b, 0, term);
-        case RRL_LOSS_QRISK_CRITIC: return loss::dout_at<RRL_LOSS_QRISK_CRITIC>(la, B, g, b, 0, term);
-        default: return loss::dout_at<RRL_LOSS_QRISK_POLICY>(la, B, g, b, 0, term);
+// DOUT = outputs of the members' heads (every member of a paired launch has the same): 1 the four critic-loss kinds, 4 the
+// tanh-Gaussian policy head, 2 the stochastic policy head
+template <int DOUT>
+__device__ __forceinline__ void pair_eval_dout(const rrl_loss_t& la, int B, int g, float* dsh) {
+    float unused[2] = {0.f, 0.f};
+    if constexpr (DOUT == 4) {
+        eval_dout_rows<RRL_LOSS_GAUSS_HEAD>(la, B, g, dsh, unused);
+    } else if constexpr (DOUT == 2) {
+        eval_dout_rows<RRL_LOSS_STOCH_HEAD>(la, B, g, dsh, unused);
+    } else {
+        switch (la.kind) {
+            case RRL_LOSS_SAC_CRITIC: eval_dout_rows<RRL_LOSS_SAC_CRITIC>(la, B, g, dsh, unused); break;
+            case RRL_LOSS_SAC_POLICY: eval_dout_rows<RRL_LOSS_SAC_POLICY>(la, B, g, dsh, unused); break;
+            case RRL_LOSS_QRISK_CRITIC: eval_dout_rows<RRL_LOSS_QRISK_CRITIC>(la, B, g, dsh, unused); break;
+            default: eval_dout_rows<RRL_LOSS_QRISK_POLICY>(la, B, g, dsh, unused); break;
+        }
     }
 }
+constexpr int kPairDsh = 1024;                         // floats of the dOut tile in LDS: B * DOUT <= 1024
+template <int DOUT>
+constexpr int pair_smem_floats() {
+    return 4 * kPairTileFloats + kPairDsh + (DOUT > 1 ? DOUT * 256 : 0);      // tiles | dOut | W3 copy (policy heads, H <= 256)
+}
+
+template <int DOUT>
 __device__ __forceinline__ void backward_pair_body(const PairJobs& pj, int x, float* smem) {
     const int k = blockIdx.y, z = blockIdx.z;
     HeadBwdArgs hb = pj.head[k];
@@ -1097,55 +1181,94 @@ __device__ __forceinline__ void backward_pair_body(const PairJobs& pj, int x, fl
     if (z == 2) {
         const int G = pj.job[k][0].G;
         arrive_together(hb.B, hb.H, hb.dout, hb.need_w, l.kind, l.n_part, l.part_stride, l.f0, l.ld, l.n_heads, l.head_stride,
-                        l.da_parts, l.da_part_stride, blocks_x, G);
+                        l.da_parts, l.da_part_stride, l.da_group, blocks_x, G);
         const int local = x;
         if (local >= blocks_x * G) return;
-        // (the four critic-loss kinds only: the policy-head kinds never come here, and their code would double the kernel)
+        // (only the kinds of this DOUT: the other kinds' code would double the kernel)
         float (*red)[4][kCols] = reinterpret_cast<float (*)[4][kCols]>(smem);
         const int bx = local % blocks_x, g = local / blocks_x;
-        switch (l.kind) {
-            case RRL_LOSS_SAC_CRITIC: head_bwd_loss_body<RRL_LOSS_SAC_CRITIC>(hb, bx, g, red, smem + 1024); break;
-            case RRL_LOSS_SAC_POLICY: head_bwd_loss_body<RRL_LOSS_SAC_POLICY>(hb, bx, g, red, smem + 1024); break;
-            case RRL_LOSS_QRISK_CRITIC: head_bwd_loss_body<RRL_LOSS_QRISK_CRITIC>(hb, bx, g, red, smem + 1024); break;
-            default: head_bwd_loss_body<RRL_LOSS_QRISK_POLICY>(hb, bx, g, red, smem + 1024); break;
+        if constexpr (DOUT == 4) {
+            head_bwd_loss_body<RRL_LOSS_GAUSS_HEAD>(hb, bx, g, red, smem + 1024);
+        } else if constexpr (DOUT == 2) {
+            head_bwd_loss_body<RRL_LOSS_STOCH_HEAD>(hb, bx, g, red, smem + 1024);
+        } else {
+            switch (l.kind) {
+                case RRL_LOSS_SAC_CRITIC: head_bwd_loss_body<RRL_LOSS_SAC_CRITIC>(hb, bx, g, red, smem + 1024); break;
+                case RRL_LOSS_SAC_POLICY: head_bwd_loss_body<RRL_LOSS_SAC_POLICY>(hb, bx, g, red, smem + 1024); break;
+                case RRL_LOSS_QRISK_CRITIC: head_bwd_loss_body<RRL_LOSS_QRISK_CRITIC>(hb, bx, g, red, smem + 1024); break;
+                default: head_bwd_loss_body<RRL_LOSS_QRISK_POLICY>(hb, bx, g, red, smem + 1024); break;
+            }
         }
         return;
     }
+    // (the head's block and the job's block requested in ONE batch -- ~100 scalars -- measured slower: 11.4 us against 10.5
+    // for the critic-loss launch; the compiler splits such a batch where it runs out of scalar registers)
     HiddenJob j = pj.job[k][z];
     GemmArgs& ga = j.ga;
     globalize(ga);
     arrive_together(ga.M, ga.N, ga.K, ga.lda, ga.ldb, ga.ldc, ga.ldmask, ga.sA, ga.sB, ga.sC, ga.sMask, ga.sColsum,
-                    ga.relu, ga.accumulate, ga.first_stride, ga.ldx, ga.din, ga.G, ga.skip_c, j.tiles, j.tiles_x, j.G, hb.B, hb.H,
-                    l.kind, l.n_part, l.part_stride, l.f0);
+                    ga.relu, ga.accumulate, ga.first_stride, ga.ldx, ga.din, ga.G, ga.skip_c, ga.dx_fold, j.tiles, j.tiles_x, j.G,
+                    hb.B, hb.H, l.kind, l.n_part, l.part_stride, l.f0, l.ld, l.n_heads, l.head_stride, l.da_parts, l.da_part_stride,
+                    l.da_group);
     const int t0 = 4 * x;
     if (t0 >= j.tiles * j.G) return;
     const int g = t0 / j.tiles;                    // tiles % 4 == 0 (host-checked): the four tiles serve one head
     float* dsh = smem + 4 * kPairTileFloats;
+    float* w3s = dsh + kPairDsh;
+    const float* w3 = hb.W3 + (long long)g * DOUT * hb.H;
     // dOut of the head, evaluated by the whole workgroup BEHIND the four tiles' operand requests (all four waves hold a tile:
-    // every wave passes the barrier once)
+    // every wave passes the barrier once); the policy heads also copy their W3 [DOUT][H] to LDS for the NN tiles
     const auto eval_dout = [&]() {
-        for (int b = threadIdx.x; b < hb.B; b += 256) dsh[b] = critic_dout(l, hb.B, g, b);
+        if constexpr (DOUT > 1) {
+            for (int e = threadIdx.x; e < DOUT * hb.H; e += 256) w3s[e] = w3[e];
+        }
+        pair_eval_dout<DOUT>(l, hb.B, g, dsh);
         __syncthreads();
     };
     const int wave = threadIdx.x >> 6, t = t0 + wave - g * j.tiles;
     float* As = smem + wave * kPairTileFloats;
     float* Bs = As + kPairPanel * kLd;
-    const float* w3 = hb.W3 + (long long)g * hb.H;
+    using Behind = decltype(eval_dout);
     if (z == 1)
-        gemm16_tile<2, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3, eval_dout);
-    else      // (128-wide panels for these tiles -- they stage one operand only, 10 KB either way -- measured: 10.4 -> 13.8 us)
-        gemm16_tile<1, true, kPairPanel, true, true, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3, eval_dout);
+        gemm16_tile<2, true, kPairPanel, true, true, true, Behind, DOUT>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3,
+                                                                         eval_dout, w3s);
+    else {    // (128-wide panels for these tiles -- they stage one operand only, 10 KB either way -- measured: 10.4 -> 13.8 us)
+        const bool fold = ga.dx_part && ga.dx_fold;          // workgroup-uniform
+        float sx = 0.f;
+        gemm16_tile<1, true, kPairPanel, true, true, true, Behind, DOUT>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3,
+                                                                         eval_dout, w3s, fold, &sx);
+        if (fold) {
+            // the workgroup's four tiles are four consecutive column tiles of one row tile (tiles_x % 4 == 0): their dx
+            // partials as ONE sum ((p0 + p1) + p2) + p3 -- the policy-head backward then reads H / 64 partials per critic
+            // head instead of H / 16 (da_group of rrl_loss_t: the same bits either way)
+            __syncthreads();                       // every wave is done with its tile (and with dsh)
+            dsh[threadIdx.x] = sx;
+            __syncthreads();
+            if (wave == 0) {
+                const int lane = threadIdx.x, rr = lane & 15, dd = lane >> 4;
+                float gs = dsh[lane];
+                gs += dsh[64 + lane];
+                gs += dsh[128 + lane];
+                gs += dsh[192 + lane];
+                const int bx = t % j.tiles_x, by = t / j.tiles_x;
+                if (dd < ga.din)
+                    ga.dx_part[(((long long)(bx >> 2) * ga.G + g) * ga.M + by * kTile + rr) * ga.din + dd] = gs;
+            }
+        }
+    }
 }
+template <int DOUT>
 __global__ __launch_bounds__(256) void backward_pair_kernel(PairJobs pj) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * kPairTileFloats + 1024];      // tiles | dOut; or red | dsh of the head path
-    backward_pair_body(pj, blockIdx.x, smem);
+    __shared__ __attribute__((aligned(16))) float smem[pair_smem_floats<DOUT>()];      // tiles | dOut | W3; or red | dsh of the head path
+    backward_pair_body<DOUT>(pj, blockIdx.x, smem);
 }
-// the same launch for S seeds (pack.hpp): grid (x under the XCD-aware placement, members, 3) -- 22 -> 19 launches per packed
+// the same launch for S seeds (pack.hpp): grid (x under the XCD-aware placement, members, 3) -- 22 -> 17 launches per packed
 // iteration, as in the solo graph
+template <int DOUT>
 __global__ __launch_bounds__(256) void backward_pair_pack_kernel(const PairJobs* __restrict__ groups, rrl_pack::Idx ix) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * kPairTileFloats + 1024];
-    RRL_PACK_LOCATE(ix, s, local);
-    backward_pair_body(groups[s], local, smem);
+    __shared__ __attribute__((aligned(16))) float smem[pair_smem_floats<DOUT>()];
+    RRL_PACK_LOCATE(ix, groups, s, local);
+    backward_pair_body<DOUT>(groups[s], local, smem);
 }
 
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
@@ -1298,6 +1421,7 @@ static bool hidden_args(int G, int B, int H, const float* dh2, const float* h1, 
         nn.x = fl->x; nn.W1 = fl->W1; nn.first_part = fl->first_part; nn.dx_part = fl->dx_part;
         nn.first_stride = fl->first_stride; nn.ldx = fl->ldx; nn.din = fl->din; nn.G = G;
         nn.skip_c = dh1 == nullptr;
+        nn.dx_fold = fl->dx_part ? fl->dx_fold : 0;
     }
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return (H % kTile) == 0 && (B % kTile) == 0 && (H % kPanel) == 0 && (B % kPanel) == 0 && al(dh2) && al(h1) && al(W2);
@@ -1342,6 +1466,14 @@ static int build_hidden_group(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg
     return RRL_OK;
 }
 
+// some member asks for folded dx partials (rrl_first_layer_t.dx_fold): the paired launches and the 32 x 64 block form fold
+// inside a workgroup, a one-tile workgroup cannot
+static bool wants_fold(int n, const rrl_hidden_bwd_t* ps) {
+    for (int k = 0; k < n; ++k)
+        if (ps[k].first.x && ps[k].first.dx_part && ps[k].first.dx_fold) return true;
+    return false;
+}
+
 // the jobs of a group launch (grid (x, member, {NN, TN})) from the tile / block counts of a HiddenGroup; returns the
 // workgroups of the largest job
 static int hidden_jobs(int n, const rrl_hidden_bwd_t* ps, const HiddenGroup& hg, HiddenJobs& hj) {
@@ -1360,6 +1492,7 @@ int rrl_mlp_hidden_backward_multi(int n, const rrl_hidden_bwd_t* ps, void* strea
     HiddenGroup hg;
     const int rc = build_hidden_group(n, ps, hg);
     if (rc != RRL_OK) return rc;
+    if (wants_fold(n, ps)) return RRL_ERANGE;          // one tile per workgroup: nothing to fold with
     HiddenJobs hj;
     const int most = hidden_jobs(n, ps, hg, hj);
     hipLaunchKernelGGL(gemm16_group_kernel, dim3(most, n, 2), dim3(64), 0, (hipStream_t)stream, hj);
@@ -1424,6 +1557,9 @@ static int hidden_pack_plan(const rrl_pack::Key& key, int S, const int* n, const
         if (ok) break;
         shape = 0;                                 // some member has no whole number of full, aligned blocks
     }
+    if (shape != 12)                               // the tile form, one tile per workgroup, cannot fold dx partials
+        for (int s = 0; s < S; ++s)
+            if (wants_fold(n[s], members[s])) return RRL_ERANGE;
     plan = rrl_pack::store(key, jobs.data(), sizeof(HiddenJobs) * S, st);
     if (!plan) return rrl_pack::store_error();
     rrl_pack::Idx ix;
@@ -1479,6 +1615,8 @@ static int head_loss_args(const rrl_loss_t* la, int G, int B, int H, int dout, c
         const int width = la->kind <= RRL_LOSS_QRISK_POLICY ? 1 : (la->kind == RRL_LOSS_GAUSS_HEAD ? 4 : 2);
         if (G != heads || dout != width) return RRL_EINVAL;
         if (la->da_parts < 0 || la->da_parts > 16) return RRL_ERANGE;
+        if ((la->da_group != 0 && la->da_group != 1 && la->da_group != 4) || (la->da_group == 4 && (la->da_parts & 3)))
+            return RRL_ERANGE;
     }
     hb.la = *la;
     hb.B = B; hb.H = H; hb.dout = dout; hb.need_w = dW3 != nullptr && db3 != nullptr;
@@ -1562,7 +1700,7 @@ int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
 // PairJobs of n stacks (backward_pair_kernel); pair = false: some member does not qualify for the paired form (pj is then
 // unspecified).  most = workgroups of the largest job (grid.x)
 static int build_pair_jobs(int n, const rrl_head_bwd_t* heads, const rrl_hidden_bwd_t* hidden, PairJobs& pj, int& most, bool& pair,
-                           HeadBwdGroup* hg_out = nullptr, HiddenGroup* hd_out = nullptr) {
+                           int& dout, HeadBwdGroup* hg_out = nullptr, HiddenGroup* hd_out = nullptr) {
     HeadBwdGroup hg;
     int rc = build_head_group(n, heads, hg);
     if (rc != RRL_OK) return rc;
@@ -1572,15 +1710,21 @@ static int build_pair_jobs(int n, const rrl_head_bwd_t* heads, const rrl_hidden_
     if (hg_out) *hg_out = hg;
     if (hd_out) *hd_out = hd;
     pair = true;
+    dout = 0;
     for (int k = 0; k < n && pair; ++k) {
         const rrl_head_bwd_t& h = heads[k];
         const rrl_hidden_bwd_t& d = hidden[k];
         const int kind = h.loss.kind;
         const int nn_tiles = hd.per_head[k] - hd.tn_tiles[k];
-        pair = kind >= RRL_LOSS_SAC_CRITIC && kind <= RRL_LOSS_QRISK_POLICY && h.dout == 1 && h.dh2 && h.dh2 == d.dh2 &&
-               h.G == d.G && h.B == d.B && h.H == d.H && h.B <= 1024 && hd.fast[k] && (h.H % kPairPanel) == 0 &&
-               (h.B % kPairPanel) == 0 && (nn_tiles % 4) == 0 && (hd.tn_tiles[k] % 4) == 0 &&
+        // every member of one launch has the same number of outputs (the kernel is compiled per DOUT): the critic-loss kinds
+        // (1), the tanh-Gaussian head (4) or the stochastic head (2)
+        const int my = (kind >= RRL_LOSS_SAC_CRITIC && kind <= RRL_LOSS_QRISK_POLICY) ? 1
+                       : kind == RRL_LOSS_GAUSS_HEAD ? 4 : kind == RRL_LOSS_STOCH_HEAD ? 2 : 0;
+        pair = my != 0 && (dout == 0 || dout == my) && h.dout == my && h.dh2 && h.dh2 == d.dh2 &&
+               h.G == d.G && h.B == d.B && h.H == d.H && h.B * my <= kPairDsh && h.H <= 256 && hd.fast[k] &&
+               (h.H % kPairPanel) == 0 && (h.B % kPairPanel) == 0 && (nn_tiles % 4) == 0 && (hd.tn_tiles[k] % 4) == 0 &&
                (reinterpret_cast<uintptr_t>(h.h2) & 15) == 0 && (reinterpret_cast<uintptr_t>(h.W3) & 15) == 0;
+        dout = my;
     }
     if (!pair) return RRL_OK;
     pj = PairJobs{};
@@ -1605,19 +1749,22 @@ int rrl_mlp_backward_pair_multi(int n, const rrl_head_bwd_t* heads, const rrl_hi
     PairJobs pj;
     HeadBwdGroup hg;
     HiddenGroup hd;
-    int most = 1;
+    int most = 1, dout = 0;
     bool pair = false;
-    const int rc = build_pair_jobs(n, heads, hidden, pj, most, pair, &hg, &hd);
+    const int rc = build_pair_jobs(n, heads, hidden, pj, most, pair, dout, &hg, &hd);
     if (rc != RRL_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (!pair) {
+        if (wants_fold(n, hidden)) return RRL_ERANGE;
         launch_head_group(hg, n, st);
         HiddenJobs hj;
         const int m = hidden_jobs(n, hidden, hd, hj);
         hipLaunchKernelGGL(gemm16_group_kernel, dim3(m, n, 2), dim3(64), 0, st, hj);
         return check_launch();
     }
-    hipLaunchKernelGGL(backward_pair_kernel, dim3(most, n, 3), dim3(256), 0, st, pj);
+    if (dout == 4) hipLaunchKernelGGL(backward_pair_kernel<4>, dim3(most, n, 3), dim3(256), 0, st, pj);
+    else if (dout == 2) hipLaunchKernelGGL(backward_pair_kernel<2>, dim3(most, n, 3), dim3(256), 0, st, pj);
+    else hipLaunchKernelGGL(backward_pair_kernel<1>, dim3(most, n, 3), dim3(256), 0, st, pj);
     return check_launch();
 }
 
@@ -1671,10 +1818,13 @@ int rrl_mlp_backward_pair_multi_packed(int S, const int* n, const rrl_head_bwd_t
         // pack_pair_max_seeds() + 1 seeds on the block form of the hidden backward behind its own head launch is faster
         // (measured, S = 4: 23.6 us paired against 8.3 + 9.2 us: profiles/round5_packed/)
         bool pair = S <= pack_pair_max_seeds();
+        int dout = 0;
         for (int s = 0; s < S && pair; ++s) {
-            int m = 1;
-            const int rc = build_pair_jobs(n[s], heads[s], hidden[s], jobs[s], m, pair);
+            int m = 1, my = 0;
+            const int rc = build_pair_jobs(n[s], heads[s], hidden[s], jobs[s], m, pair, my);
             if (rc != RRL_OK) return rc;
+            pair = pair && (dout == 0 || dout == my);
+            dout = my;
             most[s] = m;
             members_most = std::max(members_most, n[s]);
         }
@@ -1685,7 +1835,7 @@ int rrl_mlp_backward_pair_multi_packed(int S, const int* n, const rrl_head_bwd_t
             plan->grid = finish_members(ix, S, most);
             plan->ix = ix;
             plan->i0 = members_most;
-            plan->i1 = 1;
+            plan->i1 = dout;
         } else {
             // not pairable: remember that (an empty plan: no device copy needed) and issue the two packed launches
             PairJobs none{};
@@ -1698,8 +1848,11 @@ int rrl_mlp_backward_pair_multi_packed(int S, const int* n, const rrl_head_bwd_t
         const int rc = rrl_mlp_head_backward_multi_packed(S, n, heads, stream);
         return rc != RRL_OK ? rc : rrl_mlp_hidden_backward_multi_packed(S, n, hidden, stream);
     }
-    hipLaunchKernelGGL(backward_pair_pack_kernel, dim3(plan->grid, plan->i0, 3), dim3(256), 0, st, (const PairJobs*)plan->dev,
-                       plan->ix);
+    const dim3 grid(plan->grid, plan->i0, 3);
+    const PairJobs* dev = (const PairJobs*)plan->dev;
+    if (plan->i1 == 4) hipLaunchKernelGGL(backward_pair_pack_kernel<4>, grid, dim3(256), 0, st, dev, plan->ix);
+    else if (plan->i1 == 2) hipLaunchKernelGGL(backward_pair_pack_kernel<2>, grid, dim3(256), 0, st, dev, plan->ix);
+    else hipLaunchKernelGGL(backward_pair_pack_kernel<1>, grid, dim3(256), 0, st, dev, plan->ix);
     return check_launch();
 }
 

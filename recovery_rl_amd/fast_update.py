@@ -184,6 +184,7 @@ class Stack:
         self.scratch = z(max(self.nsplit, 1), G, B, net.dout)
         self.finalize = False                       # True: always hand back the summed output tensor
         self.pair_hidden = True                     # dW2 and dh1 of the backward in one launch
+        self._folded = False
         self._init_first(dev, G, B, H, net.din)
 
     def _init_first(self, dev, G, B, H, din):
@@ -192,6 +193,11 @@ class Stack:
         Adam -- and column-tile partials of dx, summed by the policy-head backward.  One launch per stack backward less;
         dh1 never goes to memory."""
         self.fuse_first = B % 128 == 0 and H % 128 == 0 and B // 16 <= 64 and H // 16 <= 16
+        # dx partials folded by the producer (rrl_first_layer_t.dx_fold): sums over four consecutive column tiles, H / 64
+        # instead of H / 16 partials for the policy-head backward to add up -- in the paired launches (B x 4 outputs of a
+        # policy head fit their dOut tile) and the block form of the packed ones; fold_dx = False keeps the tile partials
+        # (the one-tile-per-workgroup launches; the consumer then sums them in the same grouped order: the same bits)
+        self.fold_dx = self.fuse_first and B <= 256
         self.n_first = G * H * (din + 1)
         self.first_part = self.dx_part = None
         if self.fuse_first:
@@ -204,10 +210,13 @@ class Stack:
         return (self.first_part, self.n_first) if self.fuse_first else None
 
     def dx_parts(self):
-        """(tensor [G, B, din] view of partial 0, number of partials, partial stride) of dL/dx after backward(input_grad)."""
+        """(tensor [G, B, din] view of partial 0, number of partials, partial stride, group) of dL/dx after
+        backward(input_grad): group = 4 -> tile partials, summed in groups of four first (rrl_loss_t.da_group)."""
         if self.fuse_first:
-            return self.dx_part[0], self.dx_part.shape[0], self.dx_part.stride(0)
-        return self.dx, 1, 0
+            n = self.dx_part.shape[0]
+            return (self.dx_part[0], n // 4, self.dx_part.stride(0), 1) if self._folded else \
+                (self.dx_part[0], n, self.dx_part.stride(0), 4 if n % 4 == 0 else 1)
+        return self.dx, 1, 0, 1
 
     def forward(self, x, params=None, save=True):
         """x [B, din] shared by all heads.  `params` lets a target network reuse this workspace;
@@ -258,13 +267,15 @@ class Stack:
             loss = dout
         else:
             assert dout.is_contiguous()
-            loss = _lib.rrl_loss_t(-1, 1, 0, p(dout), None, None, None, None, None, None, 0.0, 0, 0, 0, None, None)
+            loss = _lib.rrl_loss_t(-1, 1, 0, p(dout), None, None, None, None, None, None, 0.0, 0, 0, 0, None, None, 0, 0, 0)
         head = _lib.rrl_head_bwd_t(loss, G, B, H, net.dout, p(self.h2), p(P["W3"]), p(Gr["W3"]) if wg else None,
                                    p(Gr["b3"]) if wg else None, p(self.dh2))
         if self.fuse_first:
+            # folded dx partials only where a folding launch is taken: a loss description (the paired launches), not a dOut tensor
+            self._folded = bool(self.fold_dx and input_grad and loss.kind >= 0)
             first = _lib.rrl_first_layer_t(p(self.x), p(P["W1"]), self.x.stride(0), net.din,
                                            p(self.first_part) if wg else None, self.first_part.stride(0),
-                                           p(self.dx_part) if input_grad else None)
+                                           p(self.dx_part) if input_grad else None, int(self._folded))
             hidden = _lib.rrl_hidden_bwd_t(G, B, H, p(self.dh2), p(self.h1), p(P["W2"]), p(Gr["W2"]) if wg else None,
                                            p(Gr["b2"]) if wg else None, None, first)
             return head, hidden, None
@@ -362,6 +373,7 @@ class StackRows(Stack):
         self.h1, self.h2 = parent.h1[:, lo:hi], parent.h2[:, lo:hi]
         self.dh1, self.dh2, self.dx = z(1, self.B, H), z(1, self.B, H), z(1, self.B, parent.net.din)
         self.pair_hidden = True
+        self._folded = False
         self._init_first(dev, 1, self.B, H, parent.net.din)
 
     def forward(self, *a, **k):
@@ -481,14 +493,14 @@ class FastUpdater:
         """rrl_loss_t for Stack.backward: the head-backward kernel evaluates the loss gradient itself.
         d_action = the critic's input gradient dx [2, B, 4] whose action columns feed a policy head."""
         p = _lib.ptr
-        ld = n_heads = hs = parts = ps = 0
+        ld = n_heads = hs = parts = ps = group = 0
         da = None
         if d_action is not None:
             if isinstance(d_action, tuple):           # Stack.dx_parts(): column-tile partials of the critic's dx
-                d_action, parts, ps = d_action
+                d_action, parts, ps, group = d_action
             da, ld, n_heads, hs = d_action[0, :, 2:4].data_ptr(), d_action.stride(1), 2, d_action.stride(0)
         return _lib.rrl_loss_t(kind, n_part, part_stride, p(out), p(out_t), p(v0), p(v1), p(v2), p(v3), p(alpha),
-                               float(f0), ld, n_heads, hs, da, p(loss), parts, ps)
+                               float(f0), ld, n_heads, hs, da, p(loss), parts, ps, group)
 
     def _check(self, rc, what):
         _lib.check(rc, what)

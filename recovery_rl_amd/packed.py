@@ -107,14 +107,15 @@ class PackedLoop:
 
     @property
     def launches(self):
-        """Kernel launches of one packed iteration: a head + hidden backward stage is ONE launch when every stack of every seed
-        has a critic-loss kind (rrl_mlp_backward_pair_multi_packed), two otherwise; per-seed calls count once per seed."""
+        """Kernel launches of one packed iteration: a head + hidden backward stage is ONE launch up to PAIR_MAX_SEEDS seeds
+        when its stacks share a loss class (rrl_mlp_backward_pair_multi_packed), two otherwise; per-seed calls count once
+        per seed."""
         total = 0
         for fn, args, ops in self.stages:
             if ops[0][0] == "pair_bwd":
-                critic = all(_lib.LOSS_SAC_CRITIC <= op[1][k].loss.kind <= _lib.LOSS_QRISK_POLICY
-                             for op in ops for k in range(op[3]))
-                total += 1 if critic and self.S <= self.PAIR_MAX_SEEDS else 2
+                kinds = {op[1][k].loss.kind for op in ops for k in range(op[3])}
+                outputs = {1 if kind <= _lib.LOSS_QRISK_POLICY else kind for kind in kinds}     # one kernel per output count
+                total += 1 if min(kinds) >= 0 and len(outputs) == 1 and self.S <= self.PAIR_MAX_SEEDS else 2
             elif ops[0][0] == "call":
                 total += len(ops)
             else:

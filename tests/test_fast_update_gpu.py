@@ -398,10 +398,11 @@ def test_first_layer_backward_inside_the_hidden_launch(B):
 
 @pytest.mark.parametrize("hidden,B", ((256, 256), (128, 128)))
 def test_paired_head_and_hidden_backward_equals_the_two_launches(monkeypatch, hidden, B):
-    """rrl_mlp_backward_pair_multi: for the critic-loss kinds with full aligned tiles (256 x 256, 128 x 128) the head backward
-    and the hidden backward go out as ONE launch whose tiles derive dh2 from h2, the loss description and W3; anything else
-    (here: the policy-head kinds of the same updates) takes the two launches inside the same entry point.  Against the same updates issued
-    as rrl_mlp_head_backward_multi + rrl_mlp_hidden_backward_multi: every parameter and gradient bit for bit."""
+    """rrl_mlp_backward_pair_multi: with full aligned tiles (256 x 256, 128 x 128) the head backward and the hidden backward
+    go out as ONE launch whose tiles derive dh2 from h2, the loss description and W3 -- the critic-loss kinds (one output) and,
+    since round 5, the policy-head kinds (tanh-Gaussian: four outputs, stochastic: two; dh2 = the fmaf chain over the outputs,
+    W3 of the NN tiles through LDS).  Against the same updates issued as rrl_mlp_head_backward_multi +
+    rrl_mlp_hidden_backward_multi: every parameter and gradient bit for bit (sac.py:216-239, qrisk.py:150-158)."""
     from recovery_rl_amd import fast_update
     _, a, _ = make_pair(hidden)
     _, b, _ = make_pair(hidden)
@@ -412,6 +413,12 @@ def test_paired_head_and_hidden_backward_equals_the_two_launches(monkeypatch, hi
         dst.load_state_dict(copy.deepcopy(src.state_dict()))
     a.enable_fast_path(B)
     b.enable_fast_path(B)
+    # the paired launches fold the critic's dx partials over four column tiles inside the workgroup (rrl_first_layer_t.dx_fold);
+    # one-tile workgroups cannot: the two-launch side keeps the 16 tile partials and its consumer adds them in the same
+    # grouped order (rrl_loss_t.da_group = 4) -- the same bits
+    assert a.fast.cri_b.fold_dx == (B <= 256)
+    for st in b.fast.stacks():
+        st.fold_dx = False
     paired = fast_update.backward_multi
     calls = {"pair": 0, "two": 0}
 
