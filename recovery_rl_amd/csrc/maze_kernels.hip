@@ -238,6 +238,8 @@ int rrl_maze_step_push_select(int64_t n, double* pos, int32_t* t, float* obs, co
 
 int rrl_maze_step_push_packed(int S, const rrl_step_push_t* a, void* stream) {
     if (S <= 0 || S > rrl_pack::kMaxSeeds || !a) return RRL_EINVAL;
+    // one seed: the packed launch IS the solo launch (argument block in the kernel arguments, no plan)
+    if (S == 1) return rrl_maze_step_push_x(&a[0], stream);
     rrl_pack::Key key;
     key.pod(7);
     key.pod(S);

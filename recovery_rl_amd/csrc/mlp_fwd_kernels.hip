@@ -630,6 +630,15 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
 int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const* members, void* stream) {
     rrl_pack::Key key;
     if (!pack_key(2, S, n, members, key)) return RRL_EINVAL;
+    // one seed: the packed launch IS the solo launch (argument block in the kernel arguments, no plan)
+    if (S == 1) {
+        StackGroup sg;
+        int path;
+        const int rc = build_stack_group(n[0], members[0], sg, path);
+        if (rc != RRL_OK) return rc;
+        if (path != 0 && path != 3) return RRL_EINVAL;          // the packed entry covers the column-split path only
+        return rrl_mlp3_forward_multi(n[0], members[0], stream);
+    }
     hipStream_t st = (hipStream_t)stream;
     rrl_pack::Plan* plan = rrl_pack::lookup(key);
     if (!plan) {

@@ -475,9 +475,15 @@ struct BlkLds {
     static constexpr int kFloats = 2 * kA + 2 * kB > 4 * 400 ? 2 * kA + 2 * kB : 4 * 400;
 };
 
-template <int MODE, int WM, int WN>   // MODE: 1 NN (A direct, B staged), 2 TN (both staged)
-__device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx, int by, int g) {
+// DOUT > 0 (the paired launch of the packed backward, backward_pair_block_pack_kernel): the left operand dh2 of both products
+// is derived where it goes to LDS / to the MFMA, exactly as in gemm16_tile<GEN> -- a.A points at the saved activation h2,
+// dsh [B][DOUT] is the head's dOut and w3s [DOUT][H] its W3, both in LDS (filled by behind_requests(), which runs once the
+// first panel's operands are requested).  Same values as the head backward stores, same MFMA steps: the same bits.
+template <int MODE, int WM, int WN, int DOUT = 0, class BEHIND = NothingBehindRequests>   // MODE: 1 NN (A direct, B staged), 2 TN (both staged)
+__device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx, int by, int g, const float* dsh = nullptr,
+                                           const float* w3s = nullptr, BEHIND behind_requests = BEHIND()) {
     using L = BlkLds<WM, WN>;
+    constexpr int D = DOUT > 0 ? DOUT : 1;
     constexpr int BM = L::BM, BN = L::BN, LDA = BM + 4, LDB = BN + 4, VEC = kBlkPanel / 16;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     const int i = lane & 15, q = lane >> 4;
@@ -510,8 +516,35 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx
         }
         blk_load<BN>(rb, B, a.ldb, n0, k0, tid);
     };
-    auto stage = [&](int buf) __attribute__((always_inline)) {
-        if (MODE == 2) blk_store<BM>(ra, As + buf * L::kA, tid);
+    // dh2 from (h2 fragment, dOut, W3): d = fmaf(go[o], w[o], d) over the outputs (head_bwd_loss_body's order)
+    const auto gen4 = [](const float4& h, const float (&go)[D], const float4 (&w)[D]) {
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < D; ++o) {
+            d.x = fmaf(go[o], w[o].x, d.x);
+            d.y = fmaf(go[o], w[o].y, d.y);
+            d.z = fmaf(go[o], w[o].z, d.z);
+            d.w = fmaf(go[o], w[o].w, d.w);
+        }
+        return make_float4(h.x > 0.f ? d.x : 0.f, h.y > 0.f ? d.y : 0.f, h.z > 0.f ? d.z : 0.f, h.w > 0.f ? d.w : 0.f);
+    };
+    auto stage = [&](int buf, int k0) __attribute__((always_inline)) {
+        if (MODE == 2) {
+            if constexpr (DOUT > 0) {         // staged [k = batch row][4 dh2 columns per thread]
+                constexpr int LPR = BM / 4, RPP = 256 / LPR;
+                float4 w[D];
+#pragma unroll
+                for (int o = 0; o < D; ++o) w[o] = *reinterpret_cast<const float4*>(w3s + o * a.lda + m0 + 4 * (tid % LPR));
+#pragma unroll
+                for (int jj = 0; jj < kBlkPanel / RPP; ++jj) {
+                    float go[D];
+#pragma unroll
+                    for (int o = 0; o < D; ++o) go[o] = dsh[(k0 + tid / LPR + RPP * jj) * D + o];
+                    ra.v[jj] = gen4(ra.v[jj], go, w);
+                }
+            }
+            blk_store<BM>(ra, As + buf * L::kA, tid);
+        }
         blk_store<BN>(rb, Bs + buf * L::kB, tid);
     };
 
@@ -519,11 +552,28 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, float* lds, int bx
     // p + 1's global loads issued, ONE barrier, MFMAs -- the loads fly under them
     const int np = a.K / kBlkPanel;
     load(0);
+    behind_requests();
     for (int p = 0; p < np; ++p) {
         FragT<VEC> ca[WM];                    // NN: this panel's rows of A
 #pragma unroll
         for (int x = 0; x < WM; ++x) ca[x] = fa[x];
-        stage(p & 1);
+        if constexpr (DOUT > 0 && MODE == 1) {       // direct: row (tm0 + x) * 16 + i, four consecutive hidden columns per fragment
+#pragma unroll
+            for (int x = 0; x < WM; ++x) {
+                float go[D];
+#pragma unroll
+                for (int o = 0; o < D; ++o) go[o] = dsh[(m0 + (tm0 + x) * kTile + i) * D + o];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    float4 w[D];
+#pragma unroll
+                    for (int o = 0; o < D; ++o)
+                        w[o] = *reinterpret_cast<const float4*>(w3s + o * a.K + p * kBlkPanel + 16 * j + 4 * q);
+                    ca[x].v[j] = gen4(ca[x].v[j], go, w);
+                }
+            }
+        }
+        stage(p & 1, p * kBlkPanel);
         if (p + 1 < np) load((p + 1) * kBlkPanel);
         __syncthreads();
         const float* Ap = As + (p & 1) * L::kA;
@@ -861,13 +911,16 @@ constexpr int kind_dout() {
 // sac / qrisk *_grad, gauss / stoch_head_bwd); lsum = the thread's partial sums of the loss terms (critics: loss[g]; policies:
 // loss[0], g == 0 only) or of dlog_std[0..1] (stochastic head) -- the per-thread partial sums of the stand-alone kernels, so
 // every bit of the reduced values is theirs.  Used by the head backward and by the tiles of the paired launches.
+// (rows [b0, b0 + nb) of the batch: all of it for the head backward and the weight-gradient tiles, the tile's own rows for the
+// input-gradient tiles of the paired launches)
 template <int KIND, int NP>
-__device__ __forceinline__ void eval_policy_rows(const rrl_loss_t& la, int B, float* dsh, float (&lsum)[2]) {
+__device__ __forceinline__ void eval_policy_rows(const rrl_loss_t& la, int b0, int nb, float* dsh, float (&lsum)[2]) {
     constexpr int DOUT = kind_dout<KIND>();
     if constexpr (KIND == RRL_LOSS_GAUSS_HEAD) {
         // one thread per (row, action dim), two of them per pass: the mean and log-std gradients share tanh/exp
-        for (int e0 = threadIdx.x; e0 < B * 2; e0 += 512) {
-            const bool two = e0 + 256 < B * 2;
+        const int e_end = 2 * (b0 + nb);
+        for (int e0 = 2 * b0 + threadIdx.x; e0 < e_end; e0 += 512) {
+            const bool two = e0 + 256 < e_end;
             const int e1 = two ? e0 + 256 : e0;
             loss::HeadIn<NP> in0, in1;
             loss::head_in_load<KIND>(la, e0 >> 1, e0 & 1, in0);
@@ -884,7 +937,7 @@ __device__ __forceinline__ void eval_policy_rows(const rrl_loss_t& la, int B, fl
         }
     } else {
         // one thread per batch row, both action dims: per-thread partial sums of dlog_std as in the stand-alone kernel
-        for (int b = threadIdx.x; b < B; b += 256) {
+        for (int b = b0 + threadIdx.x; b < b0 + nb; b += 256) {
             loss::HeadIn<NP> in0, in1;
             loss::head_in_load<KIND>(la, b, 0, in0);
             loss::head_in_load<KIND>(la, b, 1, in1);
@@ -901,14 +954,16 @@ __device__ __forceinline__ void eval_policy_rows(const rrl_loss_t& la, int B, fl
 // loss[0], g == 0 only) or of dlog_std[0..1] (stochastic head) -- the per-thread partial sums of the stand-alone kernels, so
 // every bit of the reduced values is theirs.  Used by the head backward and by the tiles of the paired launches.
 template <int KIND>
-__device__ __forceinline__ void eval_dout_rows(const rrl_loss_t& la, int B, int g, float* dsh, float (&lsum)[2]) {
+__device__ __forceinline__ void eval_dout_rows(const rrl_loss_t& la, int B, int g, float* dsh, float (&lsum)[2], int b0 = 0,
+                                               int nb = -1) {
+    if (nb < 0) nb = B;
     if constexpr (KIND == RRL_LOSS_GAUSS_HEAD || KIND == RRL_LOSS_STOCH_HEAD) {
-        if (loss::needs_np16(la)) eval_policy_rows<KIND, 16>(la, B, dsh, lsum);      // (workgroup-uniform)
-        else eval_policy_rows<KIND, 4>(la, B, dsh, lsum);
+        if (loss::needs_np16(la)) eval_policy_rows<KIND, 16>(la, b0, nb, dsh, lsum);      // (workgroup-uniform)
+        else eval_policy_rows<KIND, 4>(la, b0, nb, dsh, lsum);
     } else {
         // one thread per batch row (one output): the per-thread partial sums of the loss terms are then the ones of the
         // stand-alone kernels (update_kernels.hip), and so is every bit of the reduced value
-        for (int b = threadIdx.x; b < B; b += 256) {
+        for (int b = b0 + threadIdx.x; b < b0 + nb; b += 256) {
             float term;
             dsh[b] = loss::dout_at<KIND>(la, B, g, b, 0, term);
             lsum[0] += term;
@@ -1149,19 +1204,21 @@ struct PairJobs {
 };
 // DOUT = outputs of the members' heads (every member of a paired launch has the same): 1 the four critic-loss kinds, 4 the
 // tanh-Gaussian policy head, 2 the stochastic policy head
+// rows [b0, b0 + nb) of the head's dOut (a weight-gradient workgroup sums over the whole batch; an input-gradient one needs
+// the rows of its own tiles only)
 template <int DOUT>
-__device__ __forceinline__ void pair_eval_dout(const rrl_loss_t& la, int B, int g, float* dsh) {
+__device__ __forceinline__ void pair_eval_dout(const rrl_loss_t& la, int B, int g, float* dsh, int b0, int nb) {
     float unused[2] = {0.f, 0.f};
     if constexpr (DOUT == 4) {
-        eval_dout_rows<RRL_LOSS_GAUSS_HEAD>(la, B, g, dsh, unused);
+        eval_dout_rows<RRL_LOSS_GAUSS_HEAD>(la, B, g, dsh, unused, b0, nb);
     } else if constexpr (DOUT == 2) {
-        eval_dout_rows<RRL_LOSS_STOCH_HEAD>(la, B, g, dsh, unused);
+        eval_dout_rows<RRL_LOSS_STOCH_HEAD>(la, B, g, dsh, unused, b0, nb);
     } else {
         switch (la.kind) {
-            case RRL_LOSS_SAC_CRITIC: eval_dout_rows<RRL_LOSS_SAC_CRITIC>(la, B, g, dsh, unused); break;
-            case RRL_LOSS_SAC_POLICY: eval_dout_rows<RRL_LOSS_SAC_POLICY>(la, B, g, dsh, unused); break;
-            case RRL_LOSS_QRISK_CRITIC: eval_dout_rows<RRL_LOSS_QRISK_CRITIC>(la, B, g, dsh, unused); break;
-            default: eval_dout_rows<RRL_LOSS_QRISK_POLICY>(la, B, g, dsh, unused); break;
+            case RRL_LOSS_SAC_CRITIC: eval_dout_rows<RRL_LOSS_SAC_CRITIC>(la, B, g, dsh, unused, b0, nb); break;
+            case RRL_LOSS_SAC_POLICY: eval_dout_rows<RRL_LOSS_SAC_POLICY>(la, B, g, dsh, unused, b0, nb); break;
+            case RRL_LOSS_QRISK_CRITIC: eval_dout_rows<RRL_LOSS_QRISK_CRITIC>(la, B, g, dsh, unused, b0, nb); break;
+            default: eval_dout_rows<RRL_LOSS_QRISK_POLICY>(la, B, g, dsh, unused, b0, nb); break;
         }
     }
 }
@@ -1218,14 +1275,16 @@ __device__ __forceinline__ void backward_pair_body(const PairJobs& pj, int x, fl
     const float* w3 = hb.W3 + (long long)g * DOUT * hb.H;
     // dOut of the head, evaluated by the whole workgroup BEHIND the four tiles' operand requests (all four waves hold a tile:
     // every wave passes the barrier once); the policy heads also copy their W3 [DOUT][H] to LDS for the NN tiles
+    const int wave = threadIdx.x >> 6, t = t0 + wave - g * j.tiles;
+    const int row_tile = (t0 - g * j.tiles) / j.tiles_x;      // of the workgroup's four tiles (tiles_x % 4 == 0: one tile row)
     const auto eval_dout = [&]() {
         if constexpr (DOUT > 1) {
             for (int e = threadIdx.x; e < DOUT * hb.H; e += 256) w3s[e] = w3[e];
         }
-        pair_eval_dout<DOUT>(l, hb.B, g, dsh);
+        if (z == 1) pair_eval_dout<DOUT>(l, hb.B, g, dsh, 0, hb.B);                 // dW2 sums over the batch
+        else pair_eval_dout<DOUT>(l, hb.B, g, dsh, row_tile * kTile, kTile);          // dh1: the tiles' own 16 rows
         __syncthreads();
     };
-    const int wave = threadIdx.x >> 6, t = t0 + wave - g * j.tiles;
     float* As = smem + wave * kPairTileFloats;
     float* Bs = As + kPairPanel * kLd;
     using Behind = decltype(eval_dout);
@@ -1269,6 +1328,68 @@ __global__ __launch_bounds__(256) void backward_pair_pack_kernel(const PairJobs*
     __shared__ __attribute__((aligned(16))) float smem[pair_smem_floats<DOUT>()];
     RRL_PACK_LOCATE(ix, groups, s, local);
     backward_pair_body<DOUT>(groups[s], local, smem);
+}
+
+// ---- block form of the paired launch for the packed backward (from pack_block(S) seeds on) ------------------------------
+// backward_pair_body with gemm_block<.., DOUT> in the place of the four tiles: a four-wave workgroup owns a 32 x 64 block of dh1
+// (z = 0) or dW2 (z = 1) and derives dh2 as it stages / consumes the saved activation; the head backward's column blocks
+// (z = 2: dW3, db3, the loss scalars) ride in the same grid.  22 -> 17 launches per packed iteration at every seed count.
+template <int DOUT>
+constexpr int pair_block_smem_floats() {
+    return BlkLds<1, 2>::kFloats + kPairDsh + DOUT * 256;       // staged panels | dOut | W3 copy
+}
+template <int DOUT>
+__global__ __launch_bounds__(256) void backward_pair_block_pack_kernel(const PairJobs* __restrict__ groups, rrl_pack::Idx ix) {
+    __shared__ __attribute__((aligned(16))) float smem[pair_block_smem_floats<DOUT>() > 5120 ? pair_block_smem_floats<DOUT>() : 5120];
+    RRL_PACK_LOCATE(ix, groups, s, local);
+    const PairJobs& pj = groups[s];
+    const int k = blockIdx.y, z = blockIdx.z;
+    HeadBwdArgs hb = pj.head[k];
+    const int blocks_x = pj.blocks_x[k];
+    globalize(hb);
+    const rrl_loss_t& l = hb.la;
+    if (z == 2) {
+        const int G = pj.job[k][0].G;
+        arrive_together(hb.B, hb.H, hb.dout, hb.need_w, l.kind, l.n_part, l.part_stride, l.f0, l.ld, l.n_heads, l.head_stride,
+                        l.da_parts, l.da_part_stride, l.da_group, blocks_x, G);
+        if (local >= blocks_x * G) return;
+        float (*red)[4][kCols] = reinterpret_cast<float (*)[4][kCols]>(smem);
+        const int bx = local % blocks_x, g = local / blocks_x;
+        if constexpr (DOUT == 4) {
+            head_bwd_loss_body<RRL_LOSS_GAUSS_HEAD>(hb, bx, g, red, smem + 1024);
+        } else if constexpr (DOUT == 2) {
+            head_bwd_loss_body<RRL_LOSS_STOCH_HEAD>(hb, bx, g, red, smem + 1024);
+        } else {
+            switch (l.kind) {
+                case RRL_LOSS_SAC_CRITIC: head_bwd_loss_body<RRL_LOSS_SAC_CRITIC>(hb, bx, g, red, smem + 1024); break;
+                case RRL_LOSS_SAC_POLICY: head_bwd_loss_body<RRL_LOSS_SAC_POLICY>(hb, bx, g, red, smem + 1024); break;
+                case RRL_LOSS_QRISK_CRITIC: head_bwd_loss_body<RRL_LOSS_QRISK_CRITIC>(hb, bx, g, red, smem + 1024); break;
+                default: head_bwd_loss_body<RRL_LOSS_QRISK_POLICY>(hb, bx, g, red, smem + 1024); break;
+            }
+        }
+        return;
+    }
+    HiddenJob j = pj.job[k][z];                    // tile counts in BLOCK units
+    GemmArgs& ga = j.ga;
+    globalize(ga);
+    arrive_together(ga.M, ga.N, ga.K, ga.lda, ga.ldb, ga.ldc, ga.ldmask, ga.sA, ga.sB, ga.sC, ga.sMask, ga.sColsum,
+                    ga.relu, ga.accumulate, ga.first_stride, ga.ldx, ga.din, ga.G, ga.skip_c, ga.dx_fold, j.tiles, j.tiles_x, j.G,
+                    hb.B, hb.H, l.kind, l.n_part, l.part_stride, l.f0, l.ld, l.n_heads, l.head_stride, l.da_parts, l.da_part_stride,
+                    l.da_group);
+    if (local >= j.tiles * j.G) return;
+    const int g = local / j.tiles, b = local - g * j.tiles;
+    float* dsh = smem + BlkLds<1, 2>::kFloats;
+    float* w3s = dsh + kPairDsh;
+    const float* w3 = hb.W3 + (long long)g * DOUT * hb.H;
+    const auto eval_dout = [&]() {
+        for (int e = threadIdx.x; e < DOUT * hb.H; e += 256) w3s[e] = w3[e];
+        if (z == 1) pair_eval_dout<DOUT>(l, hb.B, g, dsh, 0, hb.B);                                   // dW2 sums over the batch
+        else pair_eval_dout<DOUT>(l, hb.B, g, dsh, (b / j.tiles_x) * BlkLds<1, 2>::BM, BlkLds<1, 2>::BM);   // dh1: the block's own 32 rows
+        __syncthreads();
+    };
+    using Behind = decltype(eval_dout);
+    if (z == 1) gemm_block<2, 1, 2, DOUT, Behind>(ga, smem, b % j.tiles_x, b / j.tiles_x, g, dsh, w3s, eval_dout);
+    else gemm_block<1, 1, 2, DOUT, Behind>(ga, smem, b % j.tiles_x, b / j.tiles_x, g, dsh, w3s, eval_dout);
 }
 
 // input-layer backward: dh1 [G,B,H] (already masked by relu'), x [B,din] shared by the heads
@@ -1512,12 +1633,21 @@ static int pack_panel(int S) { return S >= 3 ? 32 : (S >= 2 ? 64 : kPanel); }
 // Block form of the packed hidden-layer backward (gemm_block_pack_kernel<1, 2>: 32 x 64 blocks) from 3 seeds on; 64 x 64 and
 // 32 x 32 blocks measured as well (profiles/patches/README.md)
 static int pack_block(int S) { return S >= 3 ? 12 : 0; }
-// seeds up to which the packed head + hidden backward of the critic-loss kinds is ONE launch (RRL_PACK_PAIR_MAX_SEEDS: A/B runs)
+// seeds up to which the packed head + hidden backward is ONE launch in the tile form (as the solo graph), and up to which in
+// the block form; beyond, the head launch + the block form of the hidden backward: with many seeds the launches are throughput-
+// bound, the separate head launch costs little and the dh2 generation in every block is what shows (measured per packed
+// iteration, 16 updates: S = 4 paired 3.04 ms against 3.11, S = 8 4.30 = 4.27, S = 16 7.12 against 6.67:
+// profiles/round5_packed/).  (RRL_PACK_PAIR_MAX_SEEDS / RRL_PACK_PAIR_BLOCK_MAX_SEEDS: A/B runs)
+static int env_int(const char* name, int fallback) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : fallback;
+}
 static int pack_pair_max_seeds() {
-    static const int v = [] {
-        const char* e = getenv("RRL_PACK_PAIR_MAX_SEEDS");
-        return e ? atoi(e) : 2;
-    }();
+    static const int v = env_int("RRL_PACK_PAIR_MAX_SEEDS", 2);
+    return v;
+}
+static int pack_pair_block_max_seeds() {
+    static const int v = env_int("RRL_PACK_PAIR_BLOCK_MAX_SEEDS", 6);
     return v;
 }
 // tile counts of a HiddenGroup -> block counts; false: some member has no whole number of full, aligned blocks
@@ -1581,6 +1711,8 @@ static void launch_hidden_pack(const rrl_pack::Plan* plan, hipStream_t st) {
 int rrl_mlp_hidden_backward_multi_packed(int S, const int* n, const rrl_hidden_bwd_t* const* members, void* stream) {
     rrl_pack::Key key;
     if (!pack_key(1, S, n, members, key)) return RRL_EINVAL;
+    // one seed: the packed launch IS the solo launch (argument block in the kernel arguments, no plan)
+    if (S == 1) return rrl_mlp_hidden_backward_multi(n[0], members[0], stream);
     hipStream_t st = (hipStream_t)stream;
     rrl_pack::Plan* plan = rrl_pack::lookup(key);
     if (!plan) {
@@ -1699,8 +1831,10 @@ int rrl_mlp_head_backward_multi(int n, const rrl_head_bwd_t* ps, void* stream) {
 // rrl_mlp_head_backward_multi + rrl_mlp_hidden_backward_multi.  Same results either way.
 // PairJobs of n stacks (backward_pair_kernel); pair = false: some member does not qualify for the paired form (pj is then
 // unspecified).  most = workgroups of the largest job (grid.x)
+static bool hidden_blocks(int n, const rrl_hidden_bwd_t* ps, HiddenGroup& hg, int wm, int wn);
+// blocks = true: the jobs' tile counts in units of 32 x 64 blocks (backward_pair_block_pack_kernel)
 static int build_pair_jobs(int n, const rrl_head_bwd_t* heads, const rrl_hidden_bwd_t* hidden, PairJobs& pj, int& most, bool& pair,
-                           int& dout, HeadBwdGroup* hg_out = nullptr, HiddenGroup* hd_out = nullptr) {
+                           int& dout, HeadBwdGroup* hg_out = nullptr, HiddenGroup* hd_out = nullptr, bool blocks = false) {
     HeadBwdGroup hg;
     int rc = build_head_group(n, heads, hg);
     if (rc != RRL_OK) return rc;
@@ -1726,9 +1860,11 @@ static int build_pair_jobs(int n, const rrl_head_bwd_t* heads, const rrl_hidden_
                (reinterpret_cast<uintptr_t>(h.h2) & 15) == 0 && (reinterpret_cast<uintptr_t>(h.W3) & 15) == 0;
         dout = my;
     }
+    if (pair && blocks) pair = hidden_blocks(n, hidden, hd, 1, 2);          // whole 32 x 64 blocks, or no block form
     if (!pair) return RRL_OK;
     pj = PairJobs{};
     most = 1;
+    const int per_wg = blocks ? 1 : 4;             // tile form: four tiles per workgroup; block form: counts are workgroups
     for (int k = 0; k < n; ++k) {
         const int nn_tiles = hd.per_head[k] - hd.tn_tiles[k];
         pj.job[k][0] = HiddenJob{hd.nn[k], nn_tiles, hd.nn_tiles_x[k], 1, hidden[k].G};
@@ -1737,7 +1873,7 @@ static int build_pair_jobs(int n, const rrl_head_bwd_t* heads, const rrl_hidden_
         pj.head[k] = hg.p[k];
         pj.head[k].dh2 = nullptr;
         pj.blocks_x[k] = hg.blocks_x[k];
-        most = std::max(most, std::max(std::max(hd.tn_tiles[k], nn_tiles) * hidden[k].G / 4, hg.blocks_x[k] * heads[k].G));
+        most = std::max(most, std::max(std::max(hd.tn_tiles[k], nn_tiles) * hidden[k].G / per_wg, hg.blocks_x[k] * heads[k].G));
     }
     return RRL_OK;
 }
@@ -1790,6 +1926,8 @@ static int head_pack_plan(const rrl_pack::Key& key, int S, const int* n, const r
 int rrl_mlp_head_backward_multi_packed(int S, const int* n, const rrl_head_bwd_t* const* members, void* stream) {
     rrl_pack::Key key;
     if (!pack_key(3, S, n, members, key)) return RRL_EINVAL;
+    // one seed: the packed launch IS the solo launch (argument block in the kernel arguments, no plan)
+    if (S == 1) return rrl_mlp_head_backward_multi(n[0], members[0], stream);
     hipStream_t st = (hipStream_t)stream;
     rrl_pack::Plan* plan = rrl_pack::lookup(key);
     if (!plan) {
@@ -1806,7 +1944,9 @@ int rrl_mlp_backward_pair_multi_packed(int S, const int* n, const rrl_head_bwd_t
                                        const rrl_hidden_bwd_t* const* hidden, void* stream) {
     rrl_pack::Key key, key_head, key_hidden;
     if (!pack_key(3, S, n, heads, key_head) || !pack_key(1, S, n, hidden, key_hidden)) return RRL_EINVAL;
-    key.pod(6);
+    // one seed: the packed launch IS the solo launch (argument block in the kernel arguments, no plan)
+    if (S == 1) return rrl_mlp_backward_pair_multi(n[0], heads[0], hidden[0], stream);
+    key.pod(7);
     key.add(key_head.bytes.data(), key_head.bytes.size());
     key.add(key_hidden.bytes.data(), key_hidden.bytes.size());
     hipStream_t st = (hipStream_t)stream;
@@ -1814,14 +1954,15 @@ int rrl_mlp_backward_pair_multi_packed(int S, const int* n, const rrl_head_bwd_t
     if (!plan) {
         std::vector<PairJobs> jobs(S);
         int most[rrl_pack::kMaxSeeds], members_most = 1;
-        // the paired launch keeps the solo kernel's latency shape (one wave per 16 x 16 tile, four tiles per workgroup); from
-        // pack_pair_max_seeds() + 1 seeds on the block form of the hidden backward behind its own head launch is faster
-        // (measured, S = 4: 23.6 us paired against 8.3 + 9.2 us: profiles/round5_packed/)
-        bool pair = S <= pack_pair_max_seeds();
+        // up to pack_pair_max_seeds() seeds the paired launch keeps the solo kernel's latency shape (one wave per 16 x 16 tile,
+        // four tiles per workgroup); beyond, the block form (32 x 64 blocks per four-wave workgroup: measured, S = 4, the
+        // tile-form pair 23.6 us against 8.3 + 9.2 us for the head launch + the block form: profiles/round5_packed/)
+        const bool blocks = S > pack_pair_max_seeds();
+        bool pair = S <= pack_pair_block_max_seeds();
         int dout = 0;
         for (int s = 0; s < S && pair; ++s) {
             int m = 1, my = 0;
-            const int rc = build_pair_jobs(n[s], heads[s], hidden[s], jobs[s], m, pair, my);
+            const int rc = build_pair_jobs(n[s], heads[s], hidden[s], jobs[s], m, pair, my, nullptr, nullptr, blocks);
             if (rc != RRL_OK) return rc;
             pair = pair && (dout == 0 || dout == my);
             dout = my;
@@ -1835,7 +1976,7 @@ int rrl_mlp_backward_pair_multi_packed(int S, const int* n, const rrl_head_bwd_t
             plan->grid = finish_members(ix, S, most);
             plan->ix = ix;
             plan->i0 = members_most;
-            plan->i1 = dout;
+            plan->i1 = dout + (blocks ? 16 : 0);
         } else {
             // not pairable: remember that (an empty plan: no device copy needed) and issue the two packed launches
             PairJobs none{};
@@ -1850,7 +1991,10 @@ int rrl_mlp_backward_pair_multi_packed(int S, const int* n, const rrl_head_bwd_t
     }
     const dim3 grid(plan->grid, plan->i0, 3);
     const PairJobs* dev = (const PairJobs*)plan->dev;
-    if (plan->i1 == 4) hipLaunchKernelGGL(backward_pair_pack_kernel<4>, grid, dim3(256), 0, st, dev, plan->ix);
+    if (plan->i1 == 16 + 4) hipLaunchKernelGGL(backward_pair_block_pack_kernel<4>, grid, dim3(256), 0, st, dev, plan->ix);
+    else if (plan->i1 == 16 + 2) hipLaunchKernelGGL(backward_pair_block_pack_kernel<2>, grid, dim3(256), 0, st, dev, plan->ix);
+    else if (plan->i1 == 16 + 1) hipLaunchKernelGGL(backward_pair_block_pack_kernel<1>, grid, dim3(256), 0, st, dev, plan->ix);
+    else if (plan->i1 == 4) hipLaunchKernelGGL(backward_pair_pack_kernel<4>, grid, dim3(256), 0, st, dev, plan->ix);
     else if (plan->i1 == 2) hipLaunchKernelGGL(backward_pair_pack_kernel<2>, grid, dim3(256), 0, st, dev, plan->ix);
     else hipLaunchKernelGGL(backward_pair_pack_kernel<1>, grid, dim3(256), 0, st, dev, plan->ix);
     return check_launch();

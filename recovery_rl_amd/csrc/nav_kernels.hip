@@ -1092,6 +1092,8 @@ int rrl_nav_step_push_select(int env_kind, int64_t n, double* pos, int32_t* t, f
 
 int rrl_nav_step_push_packed(int S, int env_kind, const rrl_step_push_t* a, void* stream) {
     if ((env_kind != RRL_ENV_NAV1 && env_kind != RRL_ENV_NAV2) || S <= 0 || S > rrl_pack::kMaxSeeds || !a) return RRL_EINVAL;
+    // one seed: the packed launch IS the solo launch (argument block in the kernel arguments, no plan)
+    if (S == 1) return rrl_nav_step_push_x(env_kind, &a[0], stream);
     rrl_pack::Key key;
     key.pod(6);
     key.pod(S);

@@ -662,6 +662,10 @@ static void key_draw(rrl_pack::Key& key, const rrl_draw_t* d) {
 
 int rrl_sample_multi_packed(int S, const rrl_sample_args_t* args, void* stream) {
     if (S <= 0 || S > rrl_pack::kMaxSeeds || !args) return RRL_EINVAL;
+    // one seed: the packed launch IS the solo launch (argument block in the kernel arguments, no plan)
+    if (S == 1)
+        return rrl_sample_multi(args[0].first, args[0].second, args[0].noise_pairs, args[0].noise_seed, args[0].noise_counter,
+                                args[0].noise_counter_dev, args[0].noise_counter_inc, args[0].noise_out, stream);
     rrl_pack::Key key;
     key.pod(5);
     key.pod(S);

@@ -713,6 +713,8 @@ int rrl_adam_step_multi_packed(int S, const int* n_seg, const rrl_adam_seg_t* co
         key.pod(lr[s]);
         key.add(segs[s], sizeof(rrl_adam_seg_t) * n_seg[s]);
     }
+    // one seed: the packed launch IS the solo launch (argument block in the kernel arguments, no plan)
+    if (S == 1) return rrl_adam_step_multi(n_seg[0], segs[0], lr[0], beta1, beta2, eps, stream);
     hipStream_t st = (hipStream_t)stream;
     rrl_pack::Plan* plan = rrl_pack::lookup(key);
     if (!plan) {

@@ -21,8 +21,8 @@ from . import fast_update
 
 class PackedLoop:
     MAX_SEEDS = 16
-    # seeds up to which the library issues the critic-loss head + hidden backward as one launch (csrc pack_pair_max_seeds)
-    PAIR_MAX_SEEDS = int(os.environ.get("RRL_PACK_PAIR_MAX_SEEDS", "2"))
+    # seeds up to which the library issues a head + hidden backward as ONE launch (csrc pack_pair_block_max_seeds)
+    PAIR_MAX_SEEDS = int(os.environ.get("RRL_PACK_PAIR_BLOCK_MAX_SEEDS", "6"))
 
     def __init__(self, loops, online_qrisk=True):
         """loops: VectorLoops in steady state (past start_steps, batch available), each on the fused grouped path."""
@@ -107,9 +107,9 @@ class PackedLoop:
 
     @property
     def launches(self):
-        """Kernel launches of one packed iteration: a head + hidden backward stage is ONE launch up to PAIR_MAX_SEEDS seeds
-        when its stacks share a loss class (rrl_mlp_backward_pair_multi_packed), two otherwise; per-seed calls count once
-        per seed."""
+        """Kernel launches of one packed iteration: a head + hidden backward stage is ONE launch when its stacks share a loss
+        class and there are at most PAIR_MAX_SEEDS seeds (rrl_mlp_backward_pair_multi_packed: tile form up to two seeds,
+        block form beyond), two otherwise; per-seed calls count once per seed."""
         total = 0
         for fn, args, ops in self.stages:
             if ops[0][0] == "pair_bwd":
