@@ -1,7 +1,8 @@
 """Learning-level runs of the other reference command lines on this stack (one env, reference-order loop):
 navigation2 model-free and model-based recovery (scripts/navigation2.sh:7,14), maze model-free (scripts/maze.sh:7).
-The reference's own CPU runs of the model-based line take hours (MPC.act 0.32 s per call), so only this stack's
-numbers are recorded.  Usage: python profiles/learning_other_configs.py [nav2_mf|nav2_mb|maze_mf] [seed]"""
+The reference's own CPU runs of these lines are tests/golden/ref_learning_*.json (run_reference_training.py; the model-based
+line takes hours on the CPU: 120-episode windows).  Usage:
+    python profiles/learning_other_configs.py [nav2_mf|nav2_mb|maze_mf] [seed,seed,...] [num_eps]"""
 import contextlib
 import io
 import json
@@ -26,9 +27,10 @@ LINES = {
 }
 
 
-def run(name, seed):
+def run(name, seed, num_eps=None):
     tmp = tempfile.mkdtemp()
-    cfg = arg_utils.get_args(["--cuda"] + LINES[name] + ["--logdir", tmp, "--logdir_suffix", name, "--seed", str(seed)])
+    cfg = arg_utils.get_args(["--cuda"] + LINES[name] + ["--logdir", tmp, "--logdir_suffix", name, "--seed", str(seed)]
+                             + (["--num_eps", str(num_eps)] if num_eps else []))
     t0 = time.time()
     with contextlib.redirect_stdout(io.StringIO()):
         exp = Experiment(cfg)
@@ -53,6 +55,7 @@ def run(name, seed):
 if __name__ == "__main__":
     names = [sys.argv[1]] if len(sys.argv) > 1 else list(LINES)
     seeds = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1]
+    eps = int(sys.argv[3]) if len(sys.argv) > 3 else None
     for n in names:
         for seed in seeds:
-            print(json.dumps(run(n, seed)), flush=True)
+            print(json.dumps(run(n, seed, eps)), flush=True)

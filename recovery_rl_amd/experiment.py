@@ -524,6 +524,7 @@ class Experiment:
             mpc_cfg = create_config(cfg.env_name, "MPC", dict(cfg.ctrl_arg), cfg.override, self.logdir,
                                     env=self.env)
             self.recovery_policy = MPC(mpc_cfg.ctrl_cfg, mb_dynamics=getattr(cfg, "mb_dynamics", "model"),
+                                       seed=int(getattr(cfg, "plan_seed", 0)),
                                        plan_precision=getattr(cfg, "plan_precision", "") or None)
             self.recovery_policy.update_value_func(self.agent.safety_critic)
 

@@ -169,3 +169,43 @@ def test_safety_critic_gate_at_the_start_state_equals_the_reference_seed_by_seed
         assert min(abs(ref[s_]["q_start_mean"] - 0.2), abs(mine[s_]["q_start_mean"] - 0.2)) < 0.03, s_
     assert len(closed_r ^ closed_m) <= 4, (closed_r, closed_m)
     assert 0.15 <= len(closed_r) / len(common) <= 0.6                # a third of the seeds start with a closed gate
+
+
+def test_model_based_line_like_for_like_windows_over_eight_seeds():
+    """scripts/navigation2.sh:14, seeds 1..8, compared over the SAME window on both stacks: the first K episodes, K = what every
+    reference fixture covers (>= 80; the reference's CPU runs of this line cost hours: 120-episode runs of seeds 2, 5, 6, 7, 8
+    were recorded in round 5).  This stack's side is regenerated by the committed script on the GPU box (`python
+    profiles/learning_other_configs.py nav2_mb 1,2,3,4,5,6,7,8 120` -> profiles/round5_learning_nav2_mb_one_env.jsonl); the
+    -m gpu twin of this test (tests/test_learning_level_gpu.py) runs two seeds of it on the build under test.
+    What the window shows: no violation in any run of either stack; the same seeds start behind a closed gate (2, 5, 6, 8: no
+    success in the window on either stack); the learning seeds learn on both, this stack EARLIER (its recovery controller's
+    regime ends around episode 20-40, the reference's around episode 60-80) on three of the four learning seeds and later on the
+    fourth, so the rates are compared as distributions, one-sided."""
+    path = os.path.join(HERE, "..", "profiles", "round5_learning_nav2_mb_one_env.jsonl")
+    ref, mine = _mb_runs()
+    if os.path.exists(path):
+        mine = {m["seed"]: m for m in (json.loads(line) for line in open(path) if line.strip())}
+    seeds = sorted(set(ref) & set(mine))
+    assert len(seeds) >= 6, seeds
+    K = min(min(ref[s]["episodes"] for s in seeds), min(mine[s]["episodes"] for s in seeds), 120)
+    assert K >= 80
+    stalled_r = {s for s in seeds if sum(ref[s]["successes"][:K]) == 0}
+    stalled_m = {s for s in seeds if sum(mine[s]["successes"][:K]) == 0}
+    for s in seeds:
+        assert sum(ref[s]["violations"][:K]) == 0 and sum(mine[s]["violations"][:K]) == 0, s
+        early_r, early_m = np.mean(ref[s]["recovery_steps"][:10]), np.mean(mine[s]["recovery_steps_per_episode"][:10])
+        assert abs(early_r - early_m) <= 0.35 * max(early_r, early_m) + 4, (s, early_r, early_m)
+    # the seeds that never leave the start inside the window: the same ones, up to seeds whose gate sits at the threshold
+    assert 6 in stalled_r and 6 in stalled_m and len(stalled_r & stalled_m) >= 3
+    assert len(stalled_r ^ stalled_m) <= 2, (stalled_r, stalled_m)
+    learn = [s for s in seeds if s not in stalled_r and s not in stalled_m]
+    assert len(learn) >= 3
+    rate_r = np.array([sum(ref[s]["successes"][:K]) / K for s in learn])
+    rate_m = np.array([sum(mine[s]["successes"][:K]) / K for s in learn])
+    # seed by seed either stack can be ahead (seed 7: the reference); the distributions are compared
+    assert rate_m.mean() >= rate_r.mean() - 2.0 * max(rate_r.std(), rate_m.std(), 0.05), (learn, rate_r, rate_m)
+    # ... and level with the reference once both are past the recovery regime (the window's last 20 episodes)
+    if K >= 100:
+        tail_r = np.array([sum(ref[s]["successes"][K - 20:K]) for s in learn])
+        tail_m = np.array([sum(mine[s]["successes"][K - 20:K]) for s in learn])
+        assert abs(tail_r.mean() - tail_m.mean()) <= 6, (tail_r, tail_m)
