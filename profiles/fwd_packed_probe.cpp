@@ -6,7 +6,7 @@
 //   C  an update's forward:   twin critic (G = 2, din 4, dout 1) + policy (din 2, dout 4) on the seed's 256-row batch, h1 / h2 kept
 // Every seed has its own weights and buffers.  Outputs of a side library are compared with the first library's bit for bit.
 //     hipcc -O2 -o profiles/_ab_fwd_packed_probe profiles/fwd_packed_probe.cpp -ldl
-//     profiles/_ab_fwd_packed_probe recovery_rl_amd/csrc/librrl_hip.so [side.so ...]
+//     profiles/_ab_fwd_packed_probe recovery_rl_amd/csrc/librrl_hip.so [side.so | NAME=VALUE@copy_of_library.so ...]
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -101,7 +101,7 @@ struct Seed {
 
 int main(int argc, char** argv) {
     if (argc < 2) return 1;
-    const int reps = 200, kMax = 16;
+    const int reps = getenv("PROBE_REPS") ? atoi(getenv("PROBE_REPS")) : 200, kMax = 16;   // PROBE_S=<S>: that seed count only
     hipStream_t st;
     HIP(hipStreamCreate(&st));
     std::vector<std::unique_ptr<Seed>> seeds;
@@ -112,12 +112,23 @@ int main(int argc, char** argv) {
     std::vector<std::vector<float>> want;
     const int counts[] = {1, 2, 4, 8, 16};
     for (int k = 1; k < argc; ++k) {
-        void* h = dlopen(argv[k], RTLD_NOW | RTLD_LOCAL);
+        // "NAME=VALUE@library.so": the switch is set while the library is loaded and called for the first time (the libraries
+        // read their switches once); give such a library its own copy of the file, or dlopen returns the handle it already has
+        std::string arg = argv[k], env;
+        const size_t at = arg.find('@');
+        if (at != std::string::npos) {
+            env = arg.substr(0, at);
+            arg = arg.substr(at + 1);
+            const size_t eq = env.find('=');
+            setenv(env.substr(0, eq).c_str(), env.substr(eq + 1).c_str(), 1);
+        }
+        void* h = dlopen(arg.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!h) { printf("dlopen: %s\n", dlerror()); return 4; }
         packed_t fn = (packed_t)dlsym(h, "rrl_mlp3_forward_multi_packed");
         if (!fn) { printf("%s: no packed entry\n", argv[k]); continue; }
         printf("%s\n", argv[k]);
         for (int S : counts) {
+            if (getenv("PROBE_S") && atoi(getenv("PROBE_S")) != S) continue;
             int nA[kMax], nB[kMax], nC[kMax];
             const rrl_stack_t *mA[kMax], *mB[kMax], *mC[kMax];
             for (int s = 0; s < S; ++s) {
@@ -129,8 +140,9 @@ int main(int argc, char** argv) {
             rc |= fn(S, nC, mC, st);
             HIP(hipStreamSynchronize(st));
             if (rc) { printf("  S = %d: rc %d\n", S, rc); continue; }
+            if (!env.empty() && S == 16) unsetenv(env.substr(0, env.find('=')).c_str());
             const char* verdict = "";
-            if (S == 16) {
+            if (S == 16 && !getenv("PROBE_S")) {
                 std::vector<std::vector<float>> got;
                 for (int s = 0; s < S; s += 5)
                     for (auto& v : seeds[s]->outputs()) got.push_back(v);

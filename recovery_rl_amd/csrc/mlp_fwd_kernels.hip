@@ -163,6 +163,7 @@ struct StackGroup {
     StackArgs a[kMaxGroup];
     float* partial[kMaxGroup];      // split variant only
     int G[kMaxGroup], tiles[kMaxGroup];
+    int nb[kMaxGroup];              // row blocks per workgroup (1 except in the packed loop form)
     int first[kMaxGroup + 1];
     int n;
 };
@@ -196,12 +197,17 @@ constexpr int kSplitPad = 20;   // pad floats per row of the h1 tile: rows 16-by
 // the arguments.  With HC fixed every loop below is straight-line code: no per-chunk bounds branches between the LDS
 // reads and the MFMAs (the run-time version waited for each ds_read right before its four MFMAs: 3 500 cycles for the
 // 2 048 cycles of MFMA issue of one 16-row tile), and the row-bounds checks are hoisted into one uniform branch.
-template <int R, int HC>
+// LOOP (packed launches with many workgroups per CU slot, rrl_mlp3_forward_multi_packed): the workgroup keeps its weights and
+// walks `nb` consecutive row blocks of its (stack, head, column group) -- what a workgroup costs besides its MFMAs (argument
+// block, ~150 address instructions, 64 KB of W2 from L2, its launch) is paid once per nb blocks.  On gfx950 VALU work does not
+// run under v_mfma_f32_16x16x4_f32 -- neither a partner wave's nor the wave's own (profiles/mfma_valu_overlap.hip,
+// mfma_valu_inwave.hip) -- so in the throughput regime a SIMD's time is the SUM of its waves' MFMA and VALU cycles and every
+// instruction removed counts.  Per output element the arithmetic is the one-block form's.
+template <int R, int HC, bool LOOP = false>
 __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* partial, int bx, int g, int z, int G,
-                                                    float* h1s, float* h2s) {
+                                                    float* h1s, float* h2s, int nb = 1, int tiles = 1) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kW = 4;                                // waves per workgroup
-    const int m0 = bx * (R * kStackRows);
     const int H = HC ? HC : a.H, ldh = H + kSplitPad, HS = H / kSplit, ld2 = HS + 1;
     constexpr int kJ = HC ? HC / 16 : kStackMaxH / 16;             // K chunks of layer 2
     constexpr int kU = HC ? HC / (16 * kW) : kStackMaxH / (16 * kW);   // layer-1 column tiles per wave
@@ -214,90 +220,161 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
     const float* b2 = a.b2 + (long long)g * H;
     const float* W3 = a.W3 + (long long)g * dout * H;
     const float* b3 = a.b3 + (long long)g * dout;
-    float* const h1g = (a.h1 && z == 0) ? a.h1 + ((long long)g * M + m0) * H : nullptr;
-    float* const h2g = a.h2 ? a.h2 + ((long long)g * M + m0) * H : nullptr;
-    const int i = lane & 15, q = lane >> 4;
     const int ntiles1 = H / 16;                    // layer-1 column tiles, 4 waves take them round-robin
     const bool has_tile2 = HC ? true : wave * 16 < HS;   // my layer-2 tile inside this group's columns
     const int n2 = colbase + (has_tile2 ? wave * 16 : 0);
+
+    float w1b[kU], bias1[kU];
+    float4 wv[kJ];                  // my 16 rows of W2 as MFMA B operands: lane (i, q) holds W2[n2 + i][16 j + 4 q .. + 3] in wv[j]
+    float bias2, w3v[kT3], bias3;
+    const auto load_weights = [&]() {
+        const int i = lane & 15, q = lane >> 4, o3 = min(q, dout - 1);
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int t = min(wave + kW * u, ntiles1 - 1);
+            const float wv1 = W1[(t * 16 + i) * din + min(q, din - 1)];
+            w1b[u] = (q < din) ? wv1 : 0.f;
+            bias1[u] = b1[t * 16 + i];
+        }
+        const float* wrow = W2 + (long long)(n2 + i) * H + 4 * q;
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
+        bias2 = b2[n2 + i];
+#pragma unroll
+        for (int it = 0; it < kT3; ++it) w3v[it] = W3[o3 * H + colbase + min(i + 16 * it, HS - 1)];
+        const float b3v = b3[o3];
+        bias3 = (z == 0) ? b3v : 0.f;
+    };
+    if (LOOP) load_weights();
+    const int blk0 = LOOP ? bx * nb : bx, blk1 = LOOP ? min(blk0 + nb, tiles) : bx + 1;
+    // raw input of a block, lane (i, q): row 16 t + i, column min(q, din - 1) (lanes q >= din are zeroed behind the input head)
+    const auto load_x = [&](int blk, float (&x)[R]) {
+        const int i = lane & 15, q = lane >> 4, m0 = blk * (R * kStackRows);
+        const float* const xblk = a.x + (long long)m0 * a.ldx;
+#pragma unroll
+        for (int t = 0; t < R; ++t) x[t] = xblk[unsigned(min(16 * t + i, M - 1 - m0) * a.ldx + min(q, din - 1))];
+    };
+    // operands of the input head for a block, lane = (row of the block, action dimension j): noise, the <= 4 partial sums of
+    // mean and log-std (or the mean's only), the observation; optional ones through a selected address (the row's own x element
+    // when absent) instead of under a branch: a load under a branch is waited for where the branch ends
+    struct HeadOps { float e, mp[4], rp[4], ob; };
+    const int head_wave = (bx + g + z) & (kW - 1);
+    const auto load_head = [&](int blk, HeadOps& o) {
+        const rrl_policy_head_t& hd = a.in_head;
+        const int m0 = blk * (R * kStackRows), j = lane & 1;
+        const int rb = min(min(lane >> 1, R * kStackRows - 1), M - 1 - m0);    // row relative to the block, clamped to the batch
+        const unsigned row = unsigned(m0 + rb), xoff = unsigned(rb * a.ldx);
+        const float* const xblk = a.x + (long long)m0 * a.ldx;
+        const float* eb = hd.eps ? hd.eps : xblk;
+        const float* obb = hd.obs_in ? hd.obs_in : xblk;
+        rrl_pack::to_global_all(eb, obb);               // (a select of two global pointers is not global to the compiler)
+        o.e = eb[hd.eps ? 2 * row + j : xoff];
+        const bool gauss = hd.kind == RRL_HEAD_GAUSS;
+        const unsigned im = gauss ? 4 * row + j : 2 * row + j, ir = gauss ? im + 2 : im;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {      // (min, not a select to part 0: the compiler turns that into branches around the loads)
+            const float* const hk = hd.head + min(k, hd.n_part - 1) * hd.part_stride;
+            o.mp[k] = hk[im];
+            o.rp[k] = hk[ir];
+        }
+        o.ob = obb[hd.obs_in ? 2 * row + j : xoff + j];
+    };
+    // per-lane bases, computed once: every LDS access and global store of a block is base + a compile-time offset
+    const int li = lane & 15, lq = lane >> 4;
+    float* const h1w = h1s + (4 * lq) * ldh + wave * 16 + li;           // layer 1 writes row 4 q + r, column 16 (wave + 4 u) + i
+    const float* const h1r = h1s + li * ldh + 4 * lq;                   // layer 2 reads row i, columns 16 j + 4 q ..
+    float* const h2w = h2s + (4 * lq) * ld2 + wave * 16 + li;           // layer 2 writes row 4 q + r, column 16 wave + i
+    const float* const h3r = h2s + (wave * 4) * ld2 + li;               // layer 3 reads row 4 wave + rr, columns i + 16 it
+    const unsigned g1off = unsigned((4 * lq) * H + wave * 16 + li);     // the same elements of the h1 / h2 arrays in memory
+    const unsigned g2off = unsigned((4 * lq) * H + n2 + li);
+    float xn[R];                              // LOOP: the next block's input and head operands, requested a block ahead
+    HeadOps hn;
+    if (LOOP) {
+        load_x(blk0, xn);
+        if (a.use_in_head && wave == head_wave) load_head(blk0, hn);
+    }
+    for (int blk = blk0; blk < blk1; ++blk) {
+    int m0 = blk * (R * kStackRows);
+    // (opaque per block: otherwise the loop optimiser keeps one induction pointer per global store of the body -- 40 of them --
+    // and the kernel spills 63 registers to stay at four waves per SIMD)
+    if (LOOP) asm volatile("" : "+s"(m0));
+    // (the lane's coordinates likewise: with them loop-invariant, every one of the body's ~40 store offsets is hoisted as a
+    // zero-extended 64-bit pair and 75 registers spill; recomputed per block they are a dozen instructions)
+    int lane_b = lane;
+    if (LOOP) asm volatile("" : "+v"(lane_b));
+    const int i = lane_b & 15, q = lane_b >> 4;
+    // addresses: a uniform base per block (scalar registers) + a small per-lane offset (32 bits), so that the loop form keeps a
+    // handful of lane offsets across blocks instead of a 64-bit pointer per access
+    float* const h1g = (a.h1 && z == 0) ? a.h1 + ((long long)g * M + m0) * H : nullptr;
+    float* const h2g = a.h2 ? a.h2 + ((long long)g * M + m0) * H : nullptr;
+    float* const pout = partial + (((long long)z * G + g) * M + m0) * dout;
     const bool full = m0 + R * kStackRows <= M;    // uniform: every row of the workgroup's tiles exists
+    const int last = M - 1 - m0;                   // last existing row, relative to the block
 
     // ---- all global reads up front, branch-free ---------------------------------------------------------
     float xa[R];
+    if (LOOP) {
 #pragma unroll
-    for (int t = 0; t < R; ++t) {
-        const int xrow = min(m0 + 16 * t + i, M - 1);
-        xa[t] = a.x[(long long)xrow * a.ldx + min(q, din - 1)];      // raw: lanes q >= din are zeroed below, behind the input head
-    }
+        for (int t = 0; t < R; ++t) xa[t] = xn[t];
+        load_x(min(blk + 1, blk1 - 1), xn);
+    } else load_x(blk, xa);
     if (a.use_in_head) {
-        // lanes q = 0, 1 carry the observation, lanes q = 2, 3 the action dimension j = q - 2 of the policy head for
-        // their row.  Wave 0 evaluates it for the workgroup's rows (the transcendental chain costs ~1 000 cycles per row
-        // tile: done by every wave of four workgroups per CU it was +3.7 us on the 4096-row forward) and hands the
-        // values to the other waves through LDS (the h2 tile's space: nothing lives there yet); workgroup (z, g) = (0, 0)
-        // stores action and log-probability for the consumers downstream.  Same formulas, same bits as the kernels of
+        // Columns 0, 1 of the input are the observation, columns 2, 3 the action the policy head yields for the row.  ONE wave
+        // evaluates it for the workgroup's R * 16 rows, a lane per (row, action dimension j) -- 32 rows fill the wave in one
+        // pass -- and hands the values to the others through LDS (the h2 tile's space: nothing lives there yet); the wave
+        // rotates with the workgroup's index: wave w of every workgroup sits on SIMD w, and with the head always on wave 0 one
+        // SIMD of each CU carried the whole transcendental chain of the four (eight) workgroups that re-evaluate a row's head
+        // (56 of 242 us of the packed 16-seed launch, profiles/round5_fwd_packed/).  Workgroup (z, g) = (0, 0) stores
+        // action and log-probability for the consumers downstream.  Same formulas, same bits as the kernels of
         // update_kernels.hip.
         const rrl_policy_head_t& hd = a.in_head;
-        const int j = q & 1;
         const bool writer = z == 0 && g == 0;
         float* xs = h2s;                                 // [R * 16][4]
-        if (wave == 0) {
-            // every operand of the head for all R row tiles is requested first, optional ones through a selected address (the
-            // row's own x element when absent) instead of under a branch: a load under a branch is waited for where the
-            // branch ends, and noise / partial sums / observation were four round trips in a row before the weights
+        if (wave == head_wave) {
+            const int rl = min(lane_b >> 1, R * kStackRows - 1), j = lane_b & 1;
+            const bool lane_ok = (lane_b >> 1) < R * kStackRows;
+            const unsigned row = unsigned(m0 + min(rl, last));
+            const bool row_ok = lane_ok && rl <= last;
             const bool gauss = hd.kind == RRL_HEAD_GAUSS;
             const float sc = hd.scale[j], bi = hd.bias[j];
-            float e_[R], mp[R][4], rp[R][4], ob_[R], lstd_;
-            {
-                const float* safe = a.x + (long long)min(m0 + i, M - 1) * a.ldx;
-                lstd_ = *(hd.log_std ? hd.log_std + j : safe);
-#pragma unroll
-                for (int t = 0; t < R; ++t) {
-                    const int row = min(m0 + 16 * t + i, M - 1);
-                    e_[t] = *(hd.eps ? hd.eps + 2 * row + j : safe);
-                    const long long im = gauss ? 4 * row + j : 2 * row + j, ir = gauss ? 4 * row + 2 + j : im;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {      // (min, not a select to part 0: the compiler turns that into branches around the loads)
-                        mp[t][k] = hd.head[min(k, hd.n_part - 1) * hd.part_stride + im];
-                        rp[t][k] = hd.head[min(k, hd.n_part - 1) * hd.part_stride + ir];
-                    }
-                    ob_[t] = *(hd.obs_in ? hd.obs_in + 2 * row + (q & 1) : safe);
-                }
-            }
+            const float* lb = hd.log_std ? hd.log_std : hd.scale;
+            rrl_pack::to_global(lb);
+            const float lstd_ = lb[j];
+            HeadOps ho;
+            if (LOOP) {
+                ho = hn;
+                load_head(min(blk + 1, blk1 - 1), hn);
+            } else load_head(blk, ho);
+            const float e_ = ho.e, ob = ho.ob;
+            const float (&mp)[4] = ho.mp;
+            const float (&rp)[4] = ho.rp;
             const auto fold = [&](const float (&v)[4]) {
                 float x = v[0];
 #pragma unroll
                 for (int k = 1; k < 4; ++k) x = hd.n_part > k ? x + v[k] : x;
                 return x;
             };
-#pragma unroll
-            for (int t = 0; t < R; ++t) {
-                const int row = min(m0 + 16 * t + i, M - 1);
-                const bool row_ok = m0 + 16 * t + i < M;
-                float val, lp_term = 0.f;
-                const float e = hd.eps ? e_[t] : 0.f;
-                if (gauss) {
-                    const float mean = fold(mp[t]);
-                    const float ls = fminf(fmaxf(fold(rp[t]), loss::kLogSigMin), loss::kLogSigMax);
-                    const float y = tanhf(mean + expf(ls) * e);
-                    val = y * sc + bi;
-                    lp_term = -0.5f * e * e - ls - 0.918938533204672742f - logf(sc * (1.f - y * y) + loss::kEps);
-                } else {
-                    const float mean = tanhf(fold(mp[t])) * sc + bi;
-                    val = mean + expf(fmaxf(lstd_, hd.min_log_std)) * e;
-                }
-                const float other = __shfl_xor(lp_term, 16);           // lane (i, 2) <-> lane (i, 3)
-                float xv = (q < din) ? xa[t] : 0.f;
-                if (q >= 2) {
-                    xv = val;
-                    if (writer && row_ok) {
-                        if (hd.action) hd.action[(long long)row * hd.ld_action + j] = val;
-                        if (hd.logp && q == 2) hd.logp[row] = lp_term + other;
-                    }
-                } else if (hd.obs_in) {
-                    xv = ob_[t];
-                    if (writer && row_ok && hd.obs_out) hd.obs_out[(long long)row * hd.ld_action + q] = xv;
-                }
-                xs[(16 * t + i) * 4 + q] = xv;
+            float val, lp_term = 0.f;
+            const float e = hd.eps ? e_ : 0.f;
+            if (gauss) {
+                const float mean = fold(mp);
+                const float ls = fminf(fmaxf(fold(rp), loss::kLogSigMin), loss::kLogSigMax);
+                const float y = tanhf(mean + expf(ls) * e);
+                val = y * sc + bi;
+                lp_term = -0.5f * e * e - ls - 0.918938533204672742f - logf(sc * (1.f - y * y) + loss::kEps);
+            } else {
+                const float mean = tanhf(fold(mp)) * sc + bi;
+                val = mean + expf(fmaxf(lstd_, hd.min_log_std)) * e;
+            }
+            const float other = __shfl_xor(lp_term, 1);           // lane (row, 0) <-> lane (row, 1)
+            if (writer && row_ok) {
+                if (hd.action) hd.action[(long long)row * hd.ld_action + j] = val;
+                if (hd.logp && j == 0) hd.logp[row] = lp_term + other;
+                if (hd.obs_in && hd.obs_out) hd.obs_out[(long long)row * hd.ld_action + j] = ob;
+            }
+            if (lane_ok) {
+                xs[rl * 4 + j] = ob;
+                xs[rl * 4 + 2 + j] = val;
             }
         }
         __syncthreads();
@@ -308,28 +385,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
 #pragma unroll
         for (int t = 0; t < R; ++t) xa[t] = (q < din) ? xa[t] : 0.f;
     }
-    float w1b[kU], bias1[kU];
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-        const int t = min(wave + kW * u, ntiles1 - 1);
-        const float wv1 = W1[(t * 16 + i) * din + min(q, din - 1)];
-        w1b[u] = (q < din) ? wv1 : 0.f;
-        bias1[u] = b1[t * 16 + i];
-    }
-    // My 16 rows of W2 as MFMA B operands: lane (i, q) holds W2[n2 + i][16 j + 4 q .. + 3] in wv[j]
-    float4 wv[kJ];
-    {
-        const float* wrow = W2 + (long long)(n2 + i) * H + 4 * q;
-#pragma unroll
-        for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
-    }
-    const float bias2 = b2[n2 + i];
-    const int o3 = min(q, dout - 1);
-    float w3v[kT3];
-#pragma unroll
-    for (int it = 0; it < kT3; ++it) w3v[it] = W3[o3 * H + colbase + min(i + 16 * it, HS - 1)];
-    const float b3v = b3[o3];
-    const float bias3 = (z == 0) ? b3v : 0.f;
+    if (!LOOP) load_weights();
 
     // ---- layer 1 (all H columns; one MFMA step per 16-column tile and row tile) ---------------------------
 #pragma unroll
@@ -340,20 +396,22 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
             for (int rt = 0; rt < R; ++rt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[rt], w1b[u], acc, 0, 0, 0);
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int rr = 16 * rt + 4 * q + r;
-                    float v = acc[r] + bias1[u];
-                    v = v > 0.f ? v : 0.f;
-                    h1s[rr * ldh + t * 16 + i] = v;
+                    v[r] = acc[r] + bias1[u];
+                    v[r] = v[r] > 0.f ? v[r] : 0.f;
+                    h1w[(16 * rt + r) * ldh + 16 * kW * u] = v[r];
                 }
                 if (h1g) {
+                    float* const dst = h1g + g1off + 16 * rt * H + 16 * kW * u;
+                    if (full) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rr = 16 * rt + 4 * q + r;
-                        float v = acc[r] + bias1[u];
-                        v = v > 0.f ? v : 0.f;
-                        if (full || m0 + rr < M) h1g[(long long)rr * H + t * 16 + i] = v;
+                        for (int r = 0; r < 4; ++r) dst[r * H] = v[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * rt + 4 * q + r <= last) dst[r * H] = v[r];
                     }
                 }
             }
@@ -373,7 +431,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
             if (HC || 16 * j < H) {
 #pragma unroll
                 for (int rt = 0; rt < R; ++rt) {
-                    const float4 av = *reinterpret_cast<const float4*>(h1s + (16 * rt + i) * ldh + 4 * q + 16 * j);
+                    const float4 av = *reinterpret_cast<const float4*>(h1r + 16 * rt * ldh + 16 * j);
                     acc0[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wv[j].x, acc0[rt], 0, 0, 0);
                     acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wv[j].y, acc1[rt], 0, 0, 0);
                     acc0[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wv[j].z, acc0[rt], 0, 0, 0);
@@ -387,20 +445,22 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
             const f32x4 acc = acc0[rt] + acc1[rt];
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rr = 16 * rt + 4 * q + r;
-                float v = acc[r] + bias2;
-                v = v > 0.f ? v : 0.f;
-                h2s[rr * ld2 + wave * 16 + i] = v;
+                v[r] = acc[r] + bias2;
+                v[r] = v[r] > 0.f ? v[r] : 0.f;
+                h2w[(16 * rt + r) * ld2] = v[r];
             }
             if (h2g) {
+                float* const dst = h2g + g2off + 16 * rt * H;
+                if (full) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rr = 16 * rt + 4 * q + r;
-                    float v = acc[r] + bias2;
-                    v = v > 0.f ? v : 0.f;
-                    if (full || m0 + rr < M) h2g[(long long)rr * H + n2 + i] = v;
+                    for (int r = 0; r < 4; ++r) dst[r * H] = v[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * rt + 4 * q + r <= last) dst[r * H] = v[r];
                 }
             }
         }
@@ -416,7 +476,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
             float v = 0.f;
 #pragma unroll
             for (int it = 0; it < kT3; ++it) {
-                const float hv = h2s[r * ld2 + min(i + 16 * it, HS - 1)];
+                const float hv = HC ? h3r[(16 * rt + rr) * ld2 + 16 * it] : h2s[r * ld2 + min(i + 16 * it, HS - 1)];
                 if (HC || i + 16 * it < HS) v = fmaf(hv, w3v[it], v);
             }
             res[rt][rr] = v;
@@ -428,9 +488,10 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         for (int rr = 0; rr < 4; ++rr) {
             const float v = row16_sum(res[rt][rr]);
             const int r = 16 * rt + wave * 4 + rr;
-            if (i == 0 && q < dout && (full || m0 + r < M))
-                partial[(((long long)z * G + g) * M + m0 + r) * dout + q] = v + bias3;
+            if (i == 0 && q < dout && (full || r <= last)) pout[unsigned(r * dout + q)] = v + bias3;
         }
+    }
+    if (LOOP) __syncthreads();      // the next block's head / layer 1 write the tiles this block's layer 3 read
     }
 }
 
@@ -442,7 +503,7 @@ constexpr size_t split_lds_floats(int R) {
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
+__global__ __launch_bounds__(256, 4) void mlp3_fwd_split_kernel(StackArgs a, float* partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
     if (a.H == 256) mlp3_fwd_split_body<R, 256>(a, partial, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, lds, h2s);
@@ -455,7 +516,7 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_kernel(StackArgs a, float*
 // 8.3 us.  The 64 KB of W2 per workgroup are a throughput term; ahead of the head's few operands they delay the one wave
 // whose tanh / exp / log chain everybody waits for.  Not kept.)
 template <int R>
-__global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg) {
+__global__ __launch_bounds__(256, 4) void mlp3_fwd_split_group_kernel(StackGroup sg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int k = blockIdx.y;
     StackArgs a = sg.a[k];
@@ -477,7 +538,7 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_group_kernel(StackGroup sg
 // members) -- blockIdx.y IS the member and the seed follows from blockIdx.x by arithmetic, so the member's argument block
 // sits at an address known at wave start: one batch of scalar loads from the plan's device copy, as in the solo launch
 template <int R>
-__global__ __launch_bounds__(256) void mlp3_fwd_split_pack_kernel(const StackGroup* __restrict__ groups, rrl_pack::Idx ix) {
+__global__ __launch_bounds__(256, 4) void mlp3_fwd_split_pack_kernel(const StackGroup* __restrict__ groups, rrl_pack::Idx ix) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     RRL_PACK_LOCATE(ix, groups, s, local);
     const StackGroup& sg = groups[s];
@@ -496,6 +557,31 @@ __global__ __launch_bounds__(256) void mlp3_fwd_split_pack_kernel(const StackGro
     else mlp3_fwd_split_body<R, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
 }
 
+#ifndef RRL_FWD_LOOP_WAVES
+#define RRL_FWD_LOOP_WAVES 3        // resident workgroups per CU of the loop form (one wave of each per SIMD)
+#endif
+// ... and with workgroups that keep their weights for nb row blocks (mlp3_fwd_split_body<.., LOOP>): launched when the seeds
+// together have more row blocks than the chip holds workgroups at once
+template <int R>
+__global__ __launch_bounds__(256, RRL_FWD_LOOP_WAVES) void mlp3_fwd_split_pack_loop_kernel(const StackGroup* __restrict__ groups, rrl_pack::Idx ix) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    RRL_PACK_LOCATE(ix, groups, s, local);
+    const StackGroup& sg = groups[s];
+    const int k = blockIdx.y;
+    StackArgs a = sg.a[k];
+    float* partial = sg.partial[k];
+    const int G = sg.G[k], tiles = sg.tiles[k], nb = sg.nb[k];
+    globalize(a);
+    rrl_pack::to_global(partial);
+    arrive_together(a.M, a.H, a.din, a.dout, a.ldx, a.use_in_head, a.in_head.kind, a.in_head.n_part, a.in_head.part_stride,
+                    a.in_head.ld_action, a.in_head.min_log_std, G, tiles, nb);
+    const int wt = (tiles + nb - 1) / nb;                  // workgroups per (head, column group)
+    if (local >= wt * G * kSplit) return;
+    const int bx = local % wt, rest = local / wt;
+    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
+    mlp3_fwd_split_body<R, 256, true>(a, partial, bx, rest % G, rest / G, G, lds, h2s, nb, tiles);
+}
+
 __global__ void sum_partials_kernel(int n, const float* __restrict__ partial, float* __restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
@@ -506,6 +592,18 @@ __global__ void sum_partials_kernel(int n, const float* __restrict__ partial, fl
 }
 
 constexpr int kPackSmallR2MinSeeds = 3;   // packed launches: 2 row tiles per workgroup for the B <= 1024 forwards from 3 seeds on
+constexpr int kResidentWorkgroups = 256 * RRL_FWD_LOOP_WAVES;  // packed loop form: 256 CUs x resident workgroups of the multi-row forward
+constexpr int kLoopMaxBlocks = 32, kLoopMinBlocks = 8;
+
+static int env_int_fwd(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : fallback;
+}
+// RRL_PACK_FWD_LOOP=0: one row block per workgroup in every packed forward (the form of rounds 3-4; A/B switch of bench and tests)
+static bool pack_fwd_loop() {
+    static const bool on = env_int_fwd("RRL_PACK_FWD_LOOP", 1) != 0;
+    return on;
+}
 
 }  // namespace
 
@@ -562,7 +660,8 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
 // Every stack of the group takes the path rrl_mlp3_forward would take for it on its own (so the results are the
 // stand-alone launches', bit for bit); the group must be homogeneous: all split (scratch given, partial sums left in
 // scratch = finalize 0) or all on the same non-split tiling.
-static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& path, int big_r = kBigR, int small_r = 1) {
+static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& path, int big_r = kBigR, int small_r = 1,
+                             int loop_nb = 1) {
     if (!st || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
     sg = StackGroup{};
     sg.n = n;
@@ -583,6 +682,7 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
         }
         sg.partial[k] = p.scratch;
         sg.G[k] = p.G;
+        sg.nb[k] = 1;
         int my;
         const long long tiles16 = (p.M + kStackRows - 1) / kStackRows;
         if (p.scratch && rrl_mlp3_is_split(p.M, p.H)) {
@@ -590,7 +690,8 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
             if (my == 0 && small_r > 1 && p.H != 256) return RRL_EINVAL;
             const int rows = (my == 0 ? small_r : big_r) * kStackRows;
             sg.tiles[k] = (p.M + rows - 1) / rows;
-            sg.first[k + 1] = sg.first[k] + sg.tiles[k] * p.G * kSplit;
+            sg.nb[k] = loop_nb < sg.tiles[k] ? loop_nb : sg.tiles[k];
+            sg.first[k + 1] = sg.first[k] + (sg.tiles[k] + sg.nb[k] - 1) / sg.nb[k] * p.G * kSplit;
         } else if (tiles16 * p.G > 256) {
             my = 2;
             sg.tiles[k] = (p.M + 2 * kStackRows - 1) / (2 * kStackRows);
@@ -652,19 +753,53 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         for (int s = 0; s < S; ++s)
             for (int k = 0; k < n[s]; ++k) all256 = all256 && members[s] && members[s][k].H == 256;
         const int small_r = (S >= kPackSmallR2MinSeeds && all256) ? big_r : 1;
-        const int rc = build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
-            int my;
-            const int r = build_stack_group(nk, m, g, my, big_r, small_r);
-            if (r != RRL_OK) return r;
-            if ((my != 0 && my != 3) || (path >= 0 && my != path)) return int(RRL_EINVAL);
-            path = my;
-            return int(RRL_OK);
-        });
+        int loop_nb = 1;
+        const auto build_all = [&]() {
+            path = -1;
+            return build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
+                int my;
+                const int r = build_stack_group(nk, m, g, my, big_r, small_r, loop_nb);
+                if (r != RRL_OK) return r;
+                if ((my != 0 && my != 3) || (path >= 0 && my != path)) return int(RRL_EINVAL);
+                path = my;
+                return int(RRL_OK);
+            });
+        };
+        int rc = build_all();
         if (rc != RRL_OK) return rc;
+        // more row blocks than workgroups fit on the chip at once (4 per CU: 35 KB of LDS, 128 registers): workgroups that keep
+        // their weights for nb consecutive row blocks, nb the smallest count with which all of them are resident together
+        // (the acting pass's 4096-row forwards; the updates' 256-row forwards have 8 row blocks per column group and gain nothing)
+        if (path == 3 && all256 && pack_fwd_loop()) {
+            // pinned seeds (pack.hpp) have a share of the chip each: every seed's workgroups must fit its share
+            const int share = rrl_pack::seed_share(S);
+            const auto fits = [&]() {
+                long long all = 0;
+                for (int s = 0; s < S; ++s) {
+                    all += groups[s].first[n[s]];
+                    if (share > 1 && (long long)groups[s].first[n[s]] * share > kResidentWorkgroups) return false;
+                }
+                return all <= kResidentWorkgroups;
+            };
+            while (!fits() && loop_nb < kLoopMaxBlocks) {
+                ++loop_nb;
+                rc = build_all();
+                if (rc != RRL_OK) return rc;
+            }
+            // few blocks per workgroup: the uneven last round of the one-block form costs less than three (instead of four)
+            // workgroups per CU and the coarser grain do (2 / 4 seeds: 63.0 / 109.8 us for the acting pass's two launches against
+            // 57.8 / 106.9; 8 / 16 seeds: 189.6 / 365.0 against 199.5 / 386.5 -- profiles/round5_fwd_packed/)
+            if (loop_nb < kLoopMinBlocks) {
+                loop_nb = 1;
+                rc = build_all();
+                if (rc != RRL_OK) return rc;
+            }
+        }
         if (path == 3 || (small_r > 1 && path == 0)) {
             static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
-            if (!ok) return RRL_ERANGE;
-            path = 3;                 // small members on multi-row tiles run the large-batch kernel
+            static const bool ok2 = grant_lds((const void*)mlp3_fwd_split_pack_loop_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+            if (!ok || !ok2) return RRL_ERANGE;
+            path = loop_nb > 1 ? 4 : 3;   // small members on multi-row tiles run the large-batch kernel; 4 = its loop form
         }
         // 2-D grid: a seed owns as many workgroups per member row as its largest member has
         int most[rrl_pack::kMaxSeeds], members_most = 1;
@@ -682,6 +817,9 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
     if (plan->i0 == 0)
         hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<1>, dim3(plan->grid, plan->i1), dim3(256), split_lds_floats(1) * 4, st,
                            (const StackGroup*)plan->dev, plan->ix);
+    else if (plan->i0 == 4)
+        hipLaunchKernelGGL(mlp3_fwd_split_pack_loop_kernel<kBigR>, dim3(plan->grid, plan->i1), dim3(256),
+                           split_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
     else
         hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(plan->grid, plan->i1), dim3(256),
                            split_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);

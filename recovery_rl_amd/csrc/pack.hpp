@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <cstdlib>
 #include <unordered_map>
 #include <vector>
 
@@ -110,25 +111,48 @@ __device__ __forceinline__ void globalize(rrl_policy_head_t& h) {
     to_global_all(h.head, h.eps, h.scale, h.bias, h.action, h.logp, h.mean_out, h.obs_in, h.obs_out, h.log_std);
 }
 
-// host: choose the mapping for `ix` (first[] and S filled in) and return the grid size
-inline int finish(Idx& ix) {
-    ix.sp = ix.p = 0;
-    ix.r = 1;
-    int most = 0;
-    for (int s = 0; s < ix.S; ++s) most = ix.first[s + 1] - ix.first[s] > most ? ix.first[s + 1] - ix.first[s] : most;
-    if (ix.S > 8) {
+// host: the mapping S seeds get -- false: linear (the seeds share all eight XCDs); true: pinned, seed s on p = 8 / sp XCDs of
+// its own (S <= 8) or r seeds taking turns on every XCD (S > 8, sp = 8, p = 1)
+inline bool pinned_mapping(int S, int& sp, int& p, int& r) {
+    sp = p = 0;
+    r = 1;
+    if (S > 8) {
         // r seeds per XCD; XCDs with fewer seeds idle while the others finish, so only when (almost) every XCD has r:
         // measured at 16 updates per step, S = 16: 7.94 ms against 9.10 linear; S = 12: 7.82 against 7.39
-        if (8 * ((ix.S + 7) / 8) - ix.S > 2) return ix.first[ix.S];
-        ix.sp = 8;
-        ix.p = 1;
-        ix.r = (ix.S + 7) / 8;
-        return 8 * ix.r * most;
+        if (8 * ((S + 7) / 8) - S > 2) return false;
+        sp = 8;
+        p = 1;
+        r = (S + 7) / 8;
+        return true;
     }
-    int sp = 1;
-    while (sp < ix.S) sp <<= 1;
-    ix.sp = sp;
-    ix.p = 8 / sp;
+    sp = 1;
+    while (sp < S) sp <<= 1;
+    // S = 5, 6: one XCD per seed would leave three / two XCDs without work -- the linear mapping keeps all eight busy and loses
+    // only the L2 locality (0.366 / 0.400 ms per packed iteration against 0.493 / 0.469 pinned; S = 3 on two XCDs each: 0.317
+    // pinned against 0.344 linear; S = 7: equal).  RRL_PACK_PINNED=1: always pinned (A/B switch of profiles/).
+    static const bool always = [] {
+        const char* v = getenv("RRL_PACK_PINNED");
+        return v && *v && atoi(v) != 0;
+    }();
+    if (!always && sp == 8 && S <= 6) {
+        sp = 0;
+        return false;
+    }
+    p = 8 / sp;
+    return true;
+}
+// ... and the share of the chip one seed's workgroups can occupy at a time under it, as a divisor (1 = the seeds share the chip)
+inline int seed_share(int S) {
+    int sp, p, r;
+    return pinned_mapping(S, sp, p, r) ? sp * r : 1;
+}
+
+// host: choose the mapping for `ix` (first[] and S filled in) and return the grid size
+inline int finish(Idx& ix) {
+    int most = 0;
+    for (int s = 0; s < ix.S; ++s) most = ix.first[s + 1] - ix.first[s] > most ? ix.first[s + 1] - ix.first[s] : most;
+    if (!pinned_mapping(ix.S, ix.sp, ix.p, ix.r)) return ix.first[ix.S];
+    if (ix.S > 8) return 8 * ix.r * most;
     return 8 * ((most + ix.p - 1) / ix.p);
 }
 
