@@ -1,39 +1,54 @@
 #!/bin/bash
-# SQ counters of the packed launches at S seeds (eager packed iterations): MFMA busy cycles against the kernel's busy cycles.
-#   bash profiles/pmc_packed.sh [S=16] [U=4]    -> gpurun_out/pmc_packed/S<S>.txt
+# SQ instruction mix of every kernel of the packed iteration (profiles/packed_probe.py at S seeds, U updates per step): per
+# kernel the per-wave instruction counts and the busy / wait cycles.   bash profiles/pmc_packed.sh <S> <U>  ->  gpurun_out/pmc/packed_S<S>_U<U>.txt
 set -u
+S=${1:-16}; U=${2:-16}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-S=${1:-16}; U=${2:-4}
-OUT=$R/gpurun_out/pmc_packed
+OUT=$R/gpurun_out/pmc
 mkdir -p $OUT
-rm -rf /tmp/pmc_packed
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS \
-  --kernel-trace --output-format csv -d /tmp/pmc_packed -o p -- python $R/profiles/packed_eager.py $S $U 6 > /tmp/pmc_packed.log 2>&1
-f=$(find /tmp/pmc_packed -name "*counter_collection.csv" | head -1)
-if [ -n "$f" ]; then
-python - "$f" <<'PY' | tee $OUT/S$S.txt
+RAW=$OUT/packed_S${S}_U${U}_raw.txt
+: > $RAW
+i=0
+for G in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA" \
+         "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES"; do
+    i=$((i+1))
+    D=/tmp/pmc_packed_$i
+    rm -rf $D
+    timeout 600 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $D -o p -- python $R/profiles/packed_probe.py $U $S 40 > $D.log 2>&1
+    f=$(find $D -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then
+      python3 - "$f" <<'PY' >> $RAW
 import csv, sys, collections, re
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-meta = {}
+by = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    name = r.get('Kernel_Name', '')
-    if 'pack_kernel' not in name:
-        continue
-    short = re.sub(r'\(anonymous namespace\)::', '', name).split('(')[0][:48]
-    acc[short][r['Counter_Name']].append(float(r['Counter_Value']))
-    meta[short] = (r.get('VGPR_Count', r.get('Arch_VGPR_Count', '?')), r.get('LDS_Block_Size', '?'), r.get('Workgroup_Size', '?'),
-                   r.get('Grid_Size', '?'))
-print("kernel | launches | VGPRs | LDS B/wg | wg size | grid | waves | SQ busy cyc (sum over SEs) | wave cyc | wait_inst/wave_cyc | MFMA busy cyc | MFMA busy / SQ busy | LDS conflict cyc")
-for k in sorted(acc, key=lambda k: -sum(acc[k].get('SQ_BUSY_CYCLES', [0]))):
-    c = {n: sum(v) / len(v) for n, v in acc[k].items()}
-    n = len(next(iter(acc[k].values())))
-    wc = max(c.get('SQ_WAVE_CYCLES', 0.0), 1.0)
-    busy = max(c.get('SQ_BUSY_CYCLES', 0.0), 1.0)
-    print("%-48s | %4d | %s | %s | %s | %s | %.0f | %.3g | %.3g | %.2f | %.3g | %.3f | %.3g" % (
-        k, n, *meta[k], c.get('SQ_WAVES', 0), busy, wc, c.get('SQ_WAIT_INST_ANY', 0) / wc,
-        c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0), c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / busy, c.get('SQ_LDS_BANK_CONFLICT', 0)))
+    name = r.get('Kernel_Name', '').replace('(anonymous namespace)::', '').replace('void ', '')
+    name = re.sub(r'\(.*', '', name)
+    if 'pack' not in name: continue
+    by[name[:60]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, d in by.items():
+    for c, v in d.items():
+        if len(v) >= 10: print("%s\t%s\t%d\t%.1f" % (k, c, len(v), sum(v) / len(v)))
 PY
-else
-  echo "no counter csv"; tail -20 /tmp/pmc_packed.log
-fi
+    else
+      echo "[$G] no csv" >> $RAW; tail -3 $D.log >> $RAW
+    fi
+done
+python3 - $RAW > $OUT/packed_S${S}_U${U}.txt <<'PY'
+import sys, collections
+t = collections.defaultdict(dict)
+for line in open(sys.argv[1]):
+    p = line.rstrip("\n").split("\t")
+    if len(p) == 4: t[p[0]][p[1]] = float(p[3])
+    else: print(line.rstrip())
+for k, d in sorted(t.items()):
+    w = d.get("SQ_WAVES", 0) or 1
+    mf = d.get("SQ_INSTS_MFMA", 0)
+    print(k)
+    print("   waves %d; per wave: VALU (incl. MFMA) %.0f  MFMA %.0f  SALU %.0f  SMEM %.0f  LDS %.0f  VMEM rd %.0f wr %.0f   non-MFMA VALU per MFMA %.2f" % (
+        w, d.get("SQ_INSTS_VALU", 0) / w, mf / w, d.get("SQ_INSTS_SALU", 0) / w, d.get("SQ_INSTS_SMEM", 0) / w,
+        d.get("SQ_INSTS_LDS", 0) / w, d.get("SQ_INSTS_VMEM_RD", 0) / w, d.get("SQ_INSTS_VMEM_WR", 0) / w,
+        (d.get("SQ_INSTS_VALU", 0) - mf) / mf if mf else 0))
+    print("   " + "  ".join("%s %.0f" % (c, v) for c, v in sorted(d.items()) if not c.startswith("SQ_INSTS") and c != "SQ_WAVES"))
+PY
+cat $OUT/packed_S${S}_U${U}.txt

@@ -205,7 +205,7 @@ constexpr int kSplitPad = 20;   // pad floats per row of the h1 tile: rows 16-by
 // instruction removed counts.  Per output element the arithmetic is the one-block form's.
 template <int R, int HC, bool LOOP = false>
 __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* partial, int bx, int g, int z, int G,
-                                                    float* h1s, float* h2s, int nb = 1, int tiles = 1) {
+                                                    float* h1s, float* h2s, int nb = 1, int tiles = 1, float* xs_own = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kW = 4;                                // waves per workgroup
     const int H = HC ? HC : a.H, ldh = H + kSplitPad, HS = H / kSplit, ld2 = HS + 1;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         // update_kernels.hip.
         const rrl_policy_head_t& hd = a.in_head;
         const bool writer = z == 0 && g == 0;
-        float* xs = h2s;                                 // [R * 16][4]
+        float* xs = LOOP ? xs_own : h2s;                 // [R * 16][4]
         if (wave == head_wave) {
             const int rl = min(lane_b >> 1, R * kStackRows - 1), j = lane_b & 1;
             const bool lane_ok = (lane_b >> 1) < R * kStackRows;
@@ -380,7 +380,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < R; ++t) xa[t] = xs[(16 * t + i) * 4 + q];
-        __syncthreads();                                 // h2s is reused by layer 2 (and aliases h1s for R > 1)
+        if (!LOOP) __syncthreads();                      // h2s is reused by layer 2 (and aliases h1s for R > 1)
     } else {
 #pragma unroll
         for (int t = 0; t < R; ++t) xa[t] = (q < din) ? xa[t] : 0.f;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         }
         // R > 1: the h2 tile reuses the h1 tile's LDS (one 70 KB tile per workgroup instead of 87 KB: two workgroups per
         // CU), so every wave must be done reading h1 first.  (All four waves own a layer-2 tile here: HC fixes H = 256.)
-        if (R > 1) __syncthreads();
+        if (R > 1 && !LOOP) __syncthreads();
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
             const f32x4 acc = acc0[rt] + acc1[rt];
@@ -491,12 +491,18 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
             if (i == 0 && q < dout && (full || r <= last)) pout[unsigned(r * dout + q)] = v + bias3;
         }
     }
-    if (LOOP) __syncthreads();      // the next block's head / layer 1 write the tiles this block's layer 3 read
+    // LOOP: the three tiles (h1, h2, the head's values) have LDS of their own, so a block needs two barriers (three with an input
+    // head) instead of four (six): the next block's layer 1 writes h1 behind this block's second barrier (all of layer 2 has
+    // read it), its layer 2 writes h2 behind the next first barrier (every wave's layer 3 of this block is before that in
+    // program order), and the head's values are re-written behind a barrier every reader has passed
     }
 }
 
 constexpr int kBigR = 2;     // row tiles per workgroup for batches above kSplitSmallM rows (measured: 4 is slower, 10.4 vs 9.6 us)
 constexpr int kSplitSmallM = 1024;
+constexpr size_t loop_lds_floats(int R) {          // the loop form: h1, h2 and the input head's values side by side
+    return size_t(R) * kStackRows * (kStackMaxH + kSplitPad) + size_t(R) * kStackRows * (kStackMaxH / kSplit + 1) + size_t(R) * kStackRows * 4;
+}
 constexpr size_t split_lds_floats(int R) {
     return size_t(R) * kStackRows * (kStackMaxH + kSplitPad) +
            (R > 1 ? 0 : size_t(R) * kStackRows * (kStackMaxH / kSplit + 1));      // R > 1: the h2 tile aliases the h1 tile
@@ -578,8 +584,9 @@ __global__ __launch_bounds__(256, RRL_FWD_LOOP_WAVES) void mlp3_fwd_split_pack_l
     const int wt = (tiles + nb - 1) / nb;                  // workgroups per (head, column group)
     if (local >= wt * G * kSplit) return;
     const int bx = local % wt, rest = local / wt;
-    float* h2s = R > 1 ? lds : lds + R * kStackRows * (kStackMaxH + kSplitPad);
-    mlp3_fwd_split_body<R, 256, true>(a, partial, bx, rest % G, rest / G, G, lds, h2s, nb, tiles);
+    float* h2s = lds + R * kStackRows * (kStackMaxH + kSplitPad);
+    float* xs = h2s + R * kStackRows * (kStackMaxH / kSplit + 1);
+    mlp3_fwd_split_body<R, 256, true>(a, partial, bx, rest % G, rest / G, G, lds, h2s, nb, tiles, xs);
 }
 
 __global__ void sum_partials_kernel(int n, const float* __restrict__ partial, float* __restrict__ out) {
@@ -797,7 +804,7 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         }
         if (path == 3 || (small_r > 1 && path == 0)) {
             static const bool ok = grant_lds((const void*)mlp3_fwd_split_pack_kernel<kBigR>, split_lds_floats(kBigR) * 4);
-            static const bool ok2 = grant_lds((const void*)mlp3_fwd_split_pack_loop_kernel<kBigR>, split_lds_floats(kBigR) * 4);
+            static const bool ok2 = grant_lds((const void*)mlp3_fwd_split_pack_loop_kernel<kBigR>, loop_lds_floats(kBigR) * 4);
             if (!ok || !ok2) return RRL_ERANGE;
             path = loop_nb > 1 ? 4 : 3;   // small members on multi-row tiles run the large-batch kernel; 4 = its loop form
         }
@@ -819,7 +826,7 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
                            (const StackGroup*)plan->dev, plan->ix);
     else if (plan->i0 == 4)
         hipLaunchKernelGGL(mlp3_fwd_split_pack_loop_kernel<kBigR>, dim3(plan->grid, plan->i1), dim3(256),
-                           split_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
+                           loop_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
     else
         hipLaunchKernelGGL(mlp3_fwd_split_pack_kernel<kBigR>, dim3(plan->grid, plan->i1), dim3(256),
                            split_lds_floats(kBigR) * 4, st, (const StackGroup*)plan->dev, plan->ix);
