@@ -87,6 +87,8 @@ ADDITIVE = [
                                    "'f16x3' = three f16 MFMA products of hi/lo splits (operands to 2^-22 relative, 3e-8 absolute for "
                                    "values below 0.06; 2.7x faster); "
                                    "default: f32 unless RRL_PLAN_F16X3=1"),
+    (("--graph_iterations",), I, 4, "Lock-step driver: iterations captured per hipGraph (the steady state is replayed in graphs of "
+     "this many iterations wherever that many fit before the next log point; 1 = one iteration per graph)"),
     (("--plan_seed",), I, 0, "Philox key of the model-based recovery controller's own streams (CEM samples, particle noise of "
                              "the planner kernel); everything else keeps following --seed"),
     (("--resume",), S, "", "checkpoint.pt to continue from (lock-step loop; skips pre-training)"),

@@ -147,20 +147,40 @@ def build_loop(cfg, device, fast=True, pretrain=50, episode_log=True):
 LOG_EVERY = 100      # Experiment.run_vectorized's default logging cadence (--log_every 0)
 
 
-def production_step(step, loops, every=None):
+def production_step(step, loops, every=None, advance=None):
     """`step` plus what the lock-step driver does every LOG_EVERY iterations INSIDE its loop (experiment.py run_vectorized):
     read the counters and the samplers' error flags, drain the episode table -- two host synchronisations per 100
-    iterations, part of the timed region because they are part of every real run."""
+    iterations, part of the timed region because they are part of every real run.  `advance(n)` (VectorLoop.advance /
+    PackedLoop.advance): n iterations at once from the loops' many-iteration graphs; `run.many(n)` uses it exactly as the
+    driver does -- whole graphs up to the next log point, single iterations for what is left of a block."""
     count = [0]
+    ev = LOG_EVERY if every is None else every
+
+    def log_point():
+        for loop in loops:
+            loop.read_stats()
+            if loop.episode_log is not None:
+                loop.episode_log.drain()
 
     def run():
         step()
         count[0] += 1
-        if (LOG_EVERY if every is None else every) and count[0] % (LOG_EVERY if every is None else every) == 0:
-            for loop in loops:
-                loop.read_stats()
-                if loop.episode_log is not None:
-                    loop.episode_log.drain()
+        if ev and count[0] % ev == 0:
+            log_point()
+
+    def many(n):
+        while n > 0:
+            m = min(n, ev - count[0] % ev) if ev else n
+            if advance is not None:
+                advance(m)
+            else:
+                for _ in range(m):
+                    step()
+            count[0] += m
+            n -= m
+            if ev and count[0] % ev == 0:
+                log_point()
+    run.many = many
     return run
 
 
@@ -184,8 +204,11 @@ def timed_blocks(step, steps, world, device, min_seconds=MIN_TIMED_S, max_blocks
         dist_utils.barrier(world)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        if hasattr(step, "many"):
+            step.many(steps)
+        else:
+            for _ in range(steps):
+                step()
         torch.cuda.synchronize(device)
         dist_utils.barrier(world)
         dt = dist_utils.max_over_ranks(time.perf_counter() - t0, world, device)
@@ -641,7 +664,7 @@ def run_config(a, cfg, device, world, rank, updates_per_step=1, min_seconds=MIN_
     from recovery_rl_amd import distributed as dist_utils
     loop = build_loop(cfg, device, fast=not a.autograd_updates)
     step = loop.replay if not a.no_graph else (lambda: loop.vector_step(True, False, True))
-    step = production_step(step, [loop], every=a.log_every)
+    step = production_step(step, [loop], every=a.log_every, advance=None if a.no_graph else loop.advance)
     if not a.no_graph:
         loop.capture(online_qrisk=True)
     # untimed: bring a cold box to its working clocks (the first process on a fresh box measured 0.197 ms per iteration for
@@ -687,7 +710,7 @@ def run_config_packed(a, device, world, rank, S, updates_per_step=1, min_seconds
         loops = [build_loop(arg_utils.get_args(config_argv(a.env, first + k, a.num_envs, U)), device) for k in range(S)]
         packed = PackedLoop(loops)
         packed.capture()
-        step = production_step(packed.replay, loops)
+        step = production_step(packed.replay, loops, advance=packed.advance)
         for _ in range(a.warmup):
             step()
         torch.cuda.synchronize(device)
@@ -736,7 +759,8 @@ def run_seed_pack_leg(a, device, seeds=(1, 2, 4, 8), min_seconds=MIN_TIMED_LEG_S
             packed.replay()
         torch.cuda.synchronize(device)
         c0 = [int(l.agent.fast.critic.step[0].item()) for l in loops]
-        elapsed, blocks = timed_blocks(production_step(packed.replay, loops), a.steps, 1, device, min_seconds)
+        elapsed, blocks = timed_blocks(production_step(packed.replay, loops, advance=packed.advance), a.steps, 1, device,
+                                       min_seconds)
         c1 = [int(l.agent.fast.critic.step[0].item()) for l in loops]
         n_steps = a.steps * blocks
         assert all(y - x == n_steps * U for x, y in zip(c0, c1)), (c0, c1, n_steps)
@@ -1057,7 +1081,9 @@ def main():
                        "launch": "eager" if a.no_graph else "hipGraph replay",
                        "loop": "the iteration Experiment.run_vectorized replays: compact env state, per-episode table "
                                "advanced by the env-step launch, counters read and table drained every %d iterations "
-                               "inside the timed region" % LOG_EVERY,
+                               "inside the timed region; replayed as the driver does (--graph_iterations %d iterations per "
+                               "hipGraph up to each log point / block end, single-iteration graphs for the rest)"
+                               % (LOG_EVERY, getattr(cfg, "graph_iterations", 1)),
                        "updates": "autograd + vendor GEMM" if a.autograd_updates else
                                   "hand-written HIP forward/backward (f32 MFMA) + fused Adam",
                        "seeds_per_gpu": S,

@@ -137,25 +137,25 @@ class PackedLoop:
         for fn, args, _ in self.stages:
             _lib.check(fn(*args, st), getattr(fn, "__name__", "packed stage"))
 
-    def _advance_host_mirrors(self):
+    def _advance_host_mirrors(self, iterations=1):
         for loop in self.loops:
             cfg = loop.cfg
-            loop.total_numsteps += loop.n
-            loop.host_updates[0] += cfg.updates_per_step
-            loop.updates += cfg.updates_per_step
+            loop.total_numsteps += loop.n * iterations
+            loop.host_updates[0] += cfg.updates_per_step * iterations
+            loop.updates += cfg.updates_per_step * iterations
             if self.online_qrisk:
-                loop.host_updates[1] += cfg.updates_per_step
-                loop.agent.safety_critic.updates += cfg.updates_per_step
+                loop.host_updates[1] += cfg.updates_per_step * iterations
+                loop.agent.safety_critic.updates += cfg.updates_per_step * iterations
             from .experiment import uses_constraint_buffer
             for mem, rows in ((loop.memory, loop.n), (loop.recovery_memory, loop.n if uses_constraint_buffer(cfg) else 0)):
-                mem._len = min(mem._len + rows, mem.capacity)
+                mem._len = min(mem._len + rows * iterations, mem.capacity)
 
     def step(self):
         """Eager packed iteration."""
         self.launch()
         self._advance_host_mirrors()
 
-    def capture(self, warmup=2, settle=2, around=None):
+    def capture(self, warmup=2, settle=2, around=None, iters=None):
         """Record (one real iteration per seed), run `warmup` eager packed iterations (they populate the library's
         argument-block cache, so the captured launches copy nothing), capture the packed iteration in ONE hipGraph.
         `around` = (before, after): called around every one of these real iterations (the per-step info stream).
@@ -185,16 +185,34 @@ class PackedLoop:
         with torch.cuda.graph(g):
             self.launch()
         self.graph = g
+        # ... and several iterations as one graph (VectorLoop.capture: the queue idles ~2.7 us between two graphs)
+        self.graph_many = None
+        self.graph_many_iters = max(1, int(iters if iters is not None else getattr(self.loops[0].cfg, "graph_iterations", 4)))
+        if self.graph_many_iters > 1:
+            self.graph_many = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_many):
+                for _ in range(self.graph_many_iters):
+                    self.launch()
         return settle + 1 + max(warmup, 1)
 
     def replay(self):
         self.graph.replay()
         self._advance_host_mirrors()
 
+    def advance(self, iterations):
+        """`iterations` packed iterations: the many-iteration graph while that many remain, single ones for the rest."""
+        k = self.graph_many_iters if self.graph_many is not None else 0
+        while k > 1 and iterations >= k:
+            self.graph_many.replay()
+            self._advance_host_mirrors(k)
+            iterations -= k
+        for _ in range(iterations):
+            self.replay()
+
     def close(self):
         """Drop the captured graph and free the library's cached argument blocks of the packed launches (device memory):
         call when this was the last packed loop of the process (the cache is shared by all of them)."""
-        self.graph = None
+        self.graph = self.graph_many = None
         torch.cuda.synchronize(self.loops[0].device)
         return self.lib.rrl_pack_clear()
 

@@ -45,8 +45,9 @@ def test_every_packed_seed_equals_its_solo_run(env, S, n_envs):
     # the launch list of the solo graph: 17 launches (every head + hidden backward pair is one launch: tile form up to two
     # seeds, 32 x 64 blocks beyond)
     assert kinds.count("forward") >= 5 and kinds.count("pair_bwd") == 5 and packed.launches == (17 if S <= 6 else 22)
-    for _ in range(K):
-        packed.replay()
+    packed.replay()
+    packed.advance(K - 1)            # six four-iteration graphs (--graph_iterations 4) + single iterations for the rest
+    assert packed.graph_many_iters == 4 and packed.graph_many is not None
     torch.cuda.synchronize()
     got = [state_of(l) for l in packed.loops]
     stats = packed.read_stats()
@@ -162,3 +163,22 @@ def test_packed_launch_that_would_build_its_argument_block_inside_a_capture_says
     torch.cuda.synchronize()
     assert packed.loops[0].read_stats()["env_steps"] > 0
     assert packed.close() >= 7          # one cached block per packed stage kind at least
+
+
+def test_iterations_from_the_many_iteration_graph_equal_single_replays():
+    """VectorLoop.advance(n): --graph_iterations iterations per hipGraph wherever they fit, single-iteration graphs for the rest --
+    the same launches in the same order as n replay() calls, so every tensor of the run is the same."""
+    a, b = make_loop("navigation1", 3, 512), make_loop("navigation1", 3, 512)
+    assert a.capture(online_qrisk=True) == b.capture(online_qrisk=True, iters=1)
+    assert a.graph_many_iters == 4 and a.graph_many is not None and b.graph_many is None
+    a.advance(11)                    # 4 + 4 + 1 + 1 + 1
+    a.advance(2)
+    for _ in range(13):
+        b.replay()
+    torch.cuda.synchronize()
+    sa, sb = state_of(a), state_of(b)
+    for k in sb:
+        assert torch.equal(sa[k], sb[k]), k
+    assert a.read_stats() == b.read_stats() and a.total_numsteps == b.total_numsteps and a.updates == b.updates
+    assert len(a.memory) == len(b.memory) and len(a.recovery_memory) == len(b.recovery_memory)
+    assert a.host_updates == b.host_updates
