@@ -529,6 +529,10 @@ typedef struct {
     float *h1, *h2, *out, *scratch;
     rrl_policy_head_t in_head;
     int use_in_head;
+    /* nullable (H = 256, column-split path): the same W2 a second time in MFMA fragment order (rrl_w2_pack; kept in step by
+     * rrl_adam_step_multi through rrl_adam_seg_t.w2p).  A wave then fetches its 16 x 256 slice as 16 whole-KB loads instead of
+     * 16 x 16 half-used 128-byte lines: -15 % on every forward launch (profiles/round5_fwd_packed/).  Same values, same bits. */
+    const float* W2p;
 } rrl_stack_t;
 typedef struct {
     rrl_loss_t loss;
@@ -637,9 +641,21 @@ typedef struct {
     const float* g_part;  /* nullable: the first part_elems gradients are the sum of n_part partials part_stride apart */
     int n_part;           /* (first_part of rrl_first_layer_t; added in a fixed order; n_part <= 64, part_elems % 4 == 0) */
     long long part_stride, part_elems;
+    /* nullable: fragment-order copies (rrl_w2_pack layout, hidden width 256) of the w2_heads [256, 256] matrices that start at
+     * element w2_off of p (w2_off % 4 == 0, 16-byte aligned pointers): every updated parameter of that range is stored there
+     * too -- and the Polyak target's into target_w2p -- so that the forward kernels' rrl_stack_t.W2p stays current */
+    float* w2p;
+    float* target_w2p;
+    long long w2_off;
+    int w2_heads;
 } rrl_adam_seg_t;
 int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2, float eps,
                         void* stream);
+/* W2p = the G row-major [H, H] matrices W2 (out, in -- model.py's nn.Linear weights) in the order the forward kernels' MFMA B
+ * operands consume them: W2p[g][n][j][q][i][c] = W2[g][16 n + i][16 j + 4 q + c] (n, j < H / 16; q, c < 4; i < 16), i.e. the float4
+ * lane (i, q) of the wave that owns output columns 16 n .. 16 n + 15 needs for K chunk j sits at float4 index
+ * (n H / 16 + j) 64 + 16 q + i.  H % 16 == 0.  Pure permutation: layout only. */
+int rrl_w2_pack(int G, int H, const float* W2, float* W2p, void* stream);
 /* out[2i], out[2i+1] = N(0,1) pair i of Philox stream RRL_STREAM_NOISE at counter (+ device tick): replaces
  * torch.randn for the policy noise of recovery_rl/model.py:324-340,511-525 (x_t = mean + std * eps). */
 int rrl_normal_fill(long long n_pairs, uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc,

@@ -52,12 +52,17 @@ struct Buf {
         return h;
     }
 };
+typedef int (*pack_t)(int, int, const float*, float*, void*);
+static pack_t g_pack = nullptr;          // rrl_w2_pack of the first library (PROBE_ROW_MAJOR=1: W2 row-major only)
 struct Net {
-    Buf W1, b1, W2, b2, W3, b3;
+    Buf W1, b1, W2, b2, W3, b3, W2p;
     int G, din, dout;
     Net(int G_, int din_, int dout_)
         : W1(size_t(G_) * 256 * din_, 0.5f), b1(size_t(G_) * 256, 0.2f), W2(size_t(G_) * 256 * 256, 1.f / 16), b2(size_t(G_) * 256, 0.2f),
-          W3(size_t(G_) * dout_ * 256, 1.f / 16), b3(size_t(G_) * dout_, 0.2f), G(G_), din(din_), dout(dout_) {}
+          W3(size_t(G_) * dout_ * 256, 1.f / 16), b3(size_t(G_) * dout_, 0.2f), W2p(size_t(G_) * 256 * 256), G(G_), din(din_), dout(dout_) {
+        if (g_pack && g_pack(G, 256, W2.d, W2p.d, nullptr) != 0) { printf("rrl_w2_pack failed\n"); exit(3); }
+        HIP(hipDeviceSynchronize());
+    }
 };
 static rrl_stack_t stack(const Net& n, int M, const float* x, int ldx, float* out, float* scratch, float* h1 = nullptr, float* h2 = nullptr) {
     rrl_stack_t s;
@@ -65,6 +70,7 @@ static rrl_stack_t stack(const Net& n, int M, const float* x, int ldx, float* ou
     s.G = n.G; s.M = M; s.H = 256; s.din = n.din; s.dout = n.dout; s.ldx = ldx; s.x = x;
     s.W1 = n.W1.d; s.b1 = n.b1.d; s.W2 = n.W2.d; s.b2 = n.b2.d; s.W3 = n.W3.d; s.b3 = n.b3.d;
     s.h1 = h1; s.h2 = h2; s.out = out; s.scratch = scratch;
+    s.W2p = g_pack ? n.W2p.d : nullptr;
     return s;
 }
 // one seed's networks and buffers
@@ -104,6 +110,11 @@ int main(int argc, char** argv) {
     const int reps = getenv("PROBE_REPS") ? atoi(getenv("PROBE_REPS")) : 200, kMax = 16;   // PROBE_S=<S>: that seed count only
     hipStream_t st;
     HIP(hipStreamCreate(&st));
+    if (!getenv("PROBE_ROW_MAJOR")) {
+        void* h0 = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+        g_pack = h0 ? (pack_t)dlsym(h0, "rrl_w2_pack") : nullptr;
+    }
+    printf("W2 in fragment order: %s\n", g_pack ? "yes" : "no (row-major loads)");
     std::vector<std::unique_ptr<Seed>> seeds;
     for (int s = 0; s < kMax; ++s) seeds.emplace_back(new Seed());
     hipEvent_t e0, e1;

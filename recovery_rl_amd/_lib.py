@@ -49,7 +49,7 @@ EXPORTS = [
     "rrl_mlp_input_backward_multi", "rrl_mlp_backward_pair_multi", "rrl_policy_heads_fwd_multi",
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
-    "rrl_adam_step", "rrl_adam_step_multi", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
+    "rrl_adam_step", "rrl_adam_step_multi", "rrl_w2_pack", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
     "rrl_plan_supported", "rrl_plan_pack_floats", "rrl_plan_pack", "rrl_plan_cost", "rrl_plan_pack_f16x3",
     "rrl_plan_cost_f16x3", "rrl_plan_cost_n",
     "rrl_ens_train_supported", "rrl_ens_scratch_floats", "rrl_ens_train_grad", "rrl_ens_train_epoch",
@@ -191,7 +191,7 @@ class rrl_step_push_t(C.Structure):
 class rrl_stack_t(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("G", "M", "H", "din", "dout", "ldx")] + [
         (n, C.c_void_p) for n in ("x", "W1", "b1", "W2", "b2", "W3", "b3", "h1", "h2", "out", "scratch")] + [
-        ("in_head", rrl_policy_head_t), ("use_in_head", C.c_int)]
+        ("in_head", rrl_policy_head_t), ("use_in_head", C.c_int), ("W2p", C.c_void_p)]
 
 
 class rrl_head_bwd_t(C.Structure):
@@ -230,7 +230,8 @@ class rrl_adam_seg_t(C.Structure):
     _fields_ = [("n", C.c_longlong), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
                 ("step_dev", C.c_void_p), ("target", C.c_void_p), ("tau", C.c_float), ("weight_decay", C.c_float),
                 ("g2", C.c_void_p), ("g_part", C.c_void_p), ("n_part", C.c_int), ("part_stride", C.c_longlong),
-                ("part_elems", C.c_longlong)]
+                ("part_elems", C.c_longlong), ("w2p", C.c_void_p), ("target_w2p", C.c_void_p), ("w2_off", C.c_longlong),
+                ("w2_heads", C.c_int)]
 
 
 class rrl_plan_weights_t(C.Structure):
@@ -321,6 +322,7 @@ def _declare(lib):
         "rrl_stoch_head_bwd": (ci, [ci, vp, ci, ll, vp, vp, f32, vp, vp, ci, ci, ll, vp, vp, vp]),
         "rrl_adam_step": (ci, [C.c_longlong, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, f32, vp]),
         "rrl_adam_step_multi": (ci, [ci, C.POINTER(rrl_adam_seg_t), f32, f32, f32, f32, vp]),
+        "rrl_w2_pack": (ci, [ci, ci, vp, vp, vp]),
         "rrl_normal_fill": (ci, [ll, u64, u64, vp, u64, vp, vp]),
         "rrl_recovery_select": (ci, [ci, vp, f32, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_plan_supported": (ci, [ci, ci, ci, ci, ci, ci]),

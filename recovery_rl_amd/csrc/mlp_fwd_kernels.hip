@@ -26,6 +26,7 @@ struct StackArgs {
     // the critic stack that consumes its action (sac.py:192-218, qrisk.py:119-152, experiment.py:546-577)
     rrl_policy_head_t in_head;
     int use_in_head;
+    const float* W2p;     // optional: W2 in fragment order (rrl_stack_t.W2p)
 };
 
 constexpr int kStackRows = 16;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(1024) void mlp3_fwd_kernel(StackArgs a) {
 // (stack, head, row tile).  The acting pass evaluates the task policy and the recovery policy on the same
 // observations (experiment.py:546-577): neither depends on the other.
 __device__ __forceinline__ void globalize(StackArgs& a) {
-    rrl_pack::to_global_all(a.x, a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.h1, a.h2, a.out);
+    rrl_pack::to_global_all(a.x, a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.h1, a.h2, a.out, a.W2p);
     rrl_pack::globalize(a.in_head);
 }
 struct StackGroup {
@@ -206,7 +207,8 @@ constexpr int kSplitPad = 20;   // pad floats per row of the h1 tile: rows 16-by
 template <int R, int HC, bool LOOP = false>
 __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* partial, int bx, int g, int z, int G,
                                                     float* h1s, float* h2s, int nb = 1, int tiles = 1, float* xs_own = nullptr) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform, and the compiler may know it)
     constexpr int kW = 4;                                // waves per workgroup
     const int H = HC ? HC : a.H, ldh = H + kSplitPad, HS = H / kSplit, ld2 = HS + 1;
     constexpr int kJ = HC ? HC / 16 : kStackMaxH / 16;             // K chunks of layer 2
@@ -236,9 +238,25 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
             w1b[u] = (q < din) ? wv1 : 0.f;
             bias1[u] = b1[t * 16 + i];
         }
-        const float* wrow = W2 + (long long)(n2 + i) * H + 4 * q;
+        if (HC == 256) {
+            // from the fragment-order copy when there is one: the wave's 16 K chunks are 16 consecutive KB and every load
+            // instruction covers whole 128-byte lines (row-major, lane (i, q) reads 16 bytes of row n2 + i: an instruction touches
+            // 16 lines and uses half of each -- 16.3 -> 13.8 us for the 4096-row forward, 5.7 -> 4.75 for the 256-row one).  ONE
+            // set of loads for both layouts: uniform base and chunk step, per-lane offset (two arms of a branch that both define
+            // the 64 weight registers made the kernel spill 20 of them)
+            const bool frag = a.W2p != nullptr;
+            const char* wbase = frag ? reinterpret_cast<const char*>(a.W2p + (long long)g * H * H) + (n2 / 16) * (kJ * 1024)
+                                     : reinterpret_cast<const char*>(W2 + (long long)n2 * H);
+            rrl_pack::to_global(wbase);
+            const unsigned voff = frag ? unsigned(lane) * 16u : unsigned(i * H + 4 * q) * 4u;
+            const unsigned stepb = frag ? 1024u : 64u;
 #pragma unroll
-        for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
+            for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wbase + j * stepb + voff);
+        } else {
+            const float* wrow = W2 + (long long)(n2 + i) * H + 4 * q;
+#pragma unroll
+            for (int j = 0; j < kJ; ++j) wv[j] = *reinterpret_cast<const float4*>(wrow + min(16 * j, H - 16));
+        }
         bias2 = b2[n2 + i];
 #pragma unroll
         for (int it = 0; it < kT3; ++it) w3v[it] = W3[o3 * H + colbase + min(i + 16 * it, HS - 1)];
@@ -634,7 +652,7 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
                      float* h1, float* h2, float* out, float* scratch, int finalize, void* stream) {
     const int rc = stack_check(G, M, H, din, dout, x, W1, b1, W2, b2, W3, b3, out);
     if (rc != RRL_OK) return rc;
-    StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx, rrl_policy_head_t{}, 0};
+    StackArgs a{x, W1, b1, W2, b2, W3, b3, h1, h2, out, M, H, din, dout, ldx, rrl_policy_head_t{}, 0, nullptr};
     if (scratch && rrl_mlp3_is_split(M, H)) {
         // 4 workgroups (column groups) per row tile + fixed-order sum of their partial last-layer outputs
         if (M <= kSplitSmallM || H != 256) {
@@ -679,7 +697,8 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
         const int rc = stack_check(p.G, p.M, p.H, p.din, p.dout, p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.out);
         if (rc != RRL_OK) return rc;
         sg.a[k] = StackArgs{p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.h1, p.h2, p.out, p.M, p.H, p.din, p.dout, p.ldx,
-                            p.in_head, p.use_in_head};
+                            p.in_head, p.use_in_head, p.H == 256 ? p.W2p : nullptr};
+        if (sg.a[k].W2p && (reinterpret_cast<uintptr_t>(p.W2p) & 15)) return RRL_EINVAL;
         if (p.use_in_head) {
             const rrl_policy_head_t& h = p.in_head;
             if (p.din != 4 || !h.head || !h.scale || !h.bias || h.n_part <= 0 || h.n_part > 4 ||

@@ -330,12 +330,31 @@ struct AdamVec {
     float* p; const float* g; float* m; float* v; float* target; const float* g2;
     const float* gp; int np; long long ps, pe;          // partial-sum gradient range (pe = 0: none)
     long long n4, stride;
+    float* w2p; float* tw2p; long long w2_lo4, w2_hi4;  // fragment-order copies of the [256, 256] matrices in float4s [w2_lo4, w2_hi4)
 };
+// float4 index of parameter float4 `i4` (inside the W2 range that starts at float4 lo4) in the fragment-order copy
+// (rrl_w2_pack, H = 256): element (g, row, col .. col + 3) -> ((n 16 + j) 64 + 16 q + i), n = row / 16, i = row % 16, j = col / 16,
+// q = col / 4 % 4
+__device__ __forceinline__ long long w2_frag4(long long i4, long long lo4) {
+    const unsigned l = unsigned(i4 - lo4);             // < heads * 16384
+    const unsigned gq = l >> 14, row = (l >> 6) & 255, c4 = l & 63;      // 64 float4 per row
+    return (long long)gq * 16384 + ((row >> 4) * 16 + (c4 >> 2)) * 64 + (c4 & 3) * 16 + (row & 15);
+}
 struct AdamSlot {
     float4 P[2], G[2], M[2], V[2], T[2], Hh[2];
     long long i0, i1;
     bool two;
 };
+// Which float4 a thread works on inside the W2 range when the fragment-order copy is kept: within every run of 256 float4
+// (four rows of a [256, 256] matrix) lane t takes row t % 4, float4 t / 4 of the row instead of row t / 64, float4 t % 64 -- four
+// neighbouring lanes then hold rows i .. i + 3 of one (K chunk, lane group) and their stores into the copy are 64 contiguous
+// bytes (row-major order scattered them 16 bytes per line: 6.9 -> 8.1 us per launch, and 6.4 -> 6.7 ms at 16 seeds x 16 updates),
+// while every row-major access still covers 256-byte runs.  A relabelling of who does what: the arithmetic per element is the same.
+__device__ __forceinline__ long long adam_w2_slot(const AdamVec& a, long long i) {
+    if (!a.w2p || i < a.w2_lo4 || i >= a.w2_hi4) return i;
+    const long long rel = i - a.w2_lo4;
+    return a.w2_lo4 + ((rel & ~255LL) | ((rel & 3) << 6) | ((rel & 255) >> 2));
+}
 __device__ __forceinline__ void adam_slot_load(const AdamVec& a, long long i0, AdamSlot& s) {
     const float4* p4 = reinterpret_cast<const float4*>(a.p);
     const float4* m4 = reinterpret_cast<const float4*>(a.m);
@@ -343,9 +362,10 @@ __device__ __forceinline__ void adam_slot_load(const AdamVec& a, long long i0, A
     const float4* t4 = reinterpret_cast<const float4*>(a.target);
     const float4* g4 = reinterpret_cast<const float4*>(a.g);
     const float4* h4 = reinterpret_cast<const float4*>(a.g2);
+    s.two = i0 + a.stride < a.n4;
+    s.i1 = adam_w2_slot(a, i0 + a.stride);
+    i0 = adam_w2_slot(a, i0);
     s.i0 = i0;
-    s.i1 = i0 + a.stride;
-    s.two = s.i1 < a.n4;
     const long long j1 = s.two ? s.i1 : i0;
     s.P[0] = p4[i0]; s.P[1] = p4[j1];
     s.G[0] = g4[i0]; s.G[1] = g4[j1];
@@ -385,6 +405,20 @@ __device__ __forceinline__ void adam_slot_finish(const AdamVec& a, AdamSlot& s, 
         p4[s.i1] = s.P[1]; m4[s.i1] = s.M[1]; v4[s.i1] = s.V[1];
         if (a.target) t4[s.i1] = s.T[1];
     }
+    if (a.w2p) {            // (uniform) the forward kernels' copy of W2 -- and of the target's -- in fragment order
+        float4* w4 = reinterpret_cast<float4*>(a.w2p);
+        float4* tw4 = reinterpret_cast<float4*>(a.tw2p);
+        if (s.i0 >= a.w2_lo4 && s.i0 < a.w2_hi4) {
+            const long long f = w2_frag4(s.i0, a.w2_lo4);
+            w4[f] = s.P[0];
+            if (a.tw2p) tw4[f] = s.T[0];
+        }
+        if (s.two && s.i1 >= a.w2_lo4 && s.i1 < a.w2_hi4) {
+            const long long f = w2_frag4(s.i1, a.w2_lo4);
+            w4[f] = s.P[1];
+            if (a.tw2p) tw4[f] = s.T[1];
+        }
+    }
 }
 
 // `first` (optional): the thread's first slot, already loaded by the caller (adam_seg_body requests it BEFORE it waits for
@@ -393,12 +427,14 @@ __device__ __forceinline__ void adam_range(long long n, float* p, const float* g
                                            float step_size, float bc2_sqrt, float b1, float b2, float eps,
                                            float* target, float tau, float wd, const float* g2, int block,
                                            int blocks, bool vec, const float* gp, int np,
-                                           long long ps, long long pe, AdamSlot& first, bool have_first) {
+                                           long long ps, long long pe, AdamSlot& first, bool have_first,
+                                           float* w2p = nullptr, float* tw2p = nullptr, long long w2_off = 0, int w2_heads = 0) {
     const long long stride = (long long)blocks * kBlock;
     long long done = 0;
     if (!gp) pe = 0;
     if (vec) {
-        const AdamVec a{p, g, m, v, target, g2, gp, np, ps, pe, n >> 2, stride};
+        const AdamVec a{p, g, m, v, target, g2, gp, np, ps, pe, n >> 2, stride,
+                        w2p, target ? tw2p : nullptr, w2_off >> 2, (w2_off >> 2) + (long long)w2_heads * 16384};
         long long i0 = (long long)block * kBlock + threadIdx.x;
         if (have_first && i0 < a.n4) {
             adam_slot_finish(a, first, step_size, bc2_sqrt, b1, b2, eps, tau, wd);
@@ -432,7 +468,8 @@ __device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec
     const bool pre = vec && (long long)block * kBlock + threadIdx.x < (sg.n >> 2);
     if (pre) {
         const AdamVec av{sg.p, sg.g, sg.m, sg.v, sg.target, sg.g2, sg.g_part, sg.n_part, sg.part_stride,
-                         sg.g_part ? sg.part_elems : 0, sg.n >> 2, (long long)blocks * kBlock};
+                         sg.g_part ? sg.part_elems : 0, sg.n >> 2, (long long)blocks * kBlock,
+                         sg.w2p, sg.target ? sg.target_w2p : nullptr, sg.w2_off >> 2, (sg.w2_off >> 2) + (long long)sg.w2_heads * 16384};
         adam_slot_load(av, (long long)block * kBlock + threadIdx.x, first);
     }
     unsigned long long ticket = ~0ULL;
@@ -464,7 +501,8 @@ __device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec
         __syncthreads();
     }
     adam_range(sg.n, sg.p, sg.g, sg.m, sg.v, sh[0], sh[1], b1, b2, eps, sg.target, sg.tau, sg.weight_decay, sg.g2,
-               block, blocks, vec, sg.g_part, sg.n_part, sg.part_stride, sg.part_elems, first, vec);
+               block, blocks, vec, sg.g_part, sg.n_part, sg.part_stride, sg.part_elems, first, vec, sg.w2p, sg.target_w2p,
+               sg.w2_off, sg.w2_heads);
     if (threadIdx.x == 0 && ticket == (unsigned long long)blocks - 1) {
         sg.step_dev[0] = step + 1;
         sg.step_dev[1] = 0;
@@ -479,9 +517,9 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, int n_se
     const int k = blockIdx.y;
     rrl_adam_seg_t sg = a.seg[k];
     const int vec = a.vec[k], blocks = a.first_block[k + 1] - a.first_block[k];
-    rrl_pack::to_global_all(sg.p, sg.g, sg.m, sg.v, sg.step_dev, sg.target, sg.g2, sg.g_part);
+    rrl_pack::to_global_all(sg.p, sg.g, sg.m, sg.v, sg.step_dev, sg.target, sg.g2, sg.g_part, sg.w2p, sg.target_w2p);
     asm volatile("" ::"s"(sg.n), "s"(sg.tau), "s"(sg.weight_decay), "s"(sg.n_part), "s"(sg.part_stride), "s"(sg.part_elems),
-                 "s"(vec), "s"(blocks));
+                 "s"(vec), "s"(blocks), "s"(sg.w2_off), "s"(sg.w2_heads));
     if ((int)blockIdx.x >= blocks) return;
     adam_seg_body(sg, vec != 0, lr, b1, b2, eps, blockIdx.x, blocks, sh);
 }
@@ -505,9 +543,9 @@ __global__ __launch_bounds__(kBlock) void adam_pack_kernel(const AdamPack* __res
     const int vec = pk.a.vec[k], blocks = pk.a.first_block[k + 1] - pk.a.first_block[k];
     const float lr = pk.lr, b1 = pk.b1, b2 = pk.b2, eps = pk.eps;
     const int n_seg = pk.n_seg;
-    rrl_pack::to_global_all(sg.p, sg.g, sg.m, sg.v, sg.step_dev, sg.target, sg.g2, sg.g_part);
+    rrl_pack::to_global_all(sg.p, sg.g, sg.m, sg.v, sg.step_dev, sg.target, sg.g2, sg.g_part, sg.w2p, sg.target_w2p);
     asm volatile("" ::"s"(sg.n), "s"(sg.tau), "s"(sg.weight_decay), "s"(sg.n_part), "s"(sg.part_stride), "s"(sg.part_elems),
-                 "s"(vec), "s"(blocks), "s"(lr), "s"(b1), "s"(b2), "s"(eps), "s"(n_seg));
+                 "s"(sg.w2_off), "s"(sg.w2_heads), "s"(vec), "s"(blocks), "s"(lr), "s"(b1), "s"(b2), "s"(eps), "s"(n_seg));
     if (k >= n_seg || local >= blocks) return;
     adam_seg_body(sg, vec != 0, lr, b1, b2, eps, local, blocks, sh);
 }
@@ -682,10 +720,35 @@ static int build_adam_segs(int n_seg, const rrl_adam_seg_t* segs, AdamSegs& a) {
         a.seg[k] = sg;
         a.vec[k] = aligned16(sg.p) && aligned16(sg.g) && aligned16(sg.m) && aligned16(sg.v) && aligned16(sg.target) &&
                    aligned16(sg.g2);
+        if (sg.w2p) {        // the fragment-order copies ride on the vectorised pass: whole float4s of [256, 256] matrices
+            if (!a.vec[k] || !aligned16(sg.w2p) || !aligned16(sg.target_w2p) || (sg.w2_off & 3) || sg.w2_off < 0 ||
+                sg.w2_heads <= 0 || sg.w2_off + (long long)sg.w2_heads * 65536 > sg.n)
+                return RRL_EINVAL;
+        }
         a.first_block[k + 1] = a.first_block[k] + (grid_for(sg.n) < 64 ? grid_for(sg.n) : 64);
     }
     for (int k = n_seg; k < RRL_ADAM_MAX_SEGS; ++k) a.first_block[k + 1] = a.first_block[n_seg];
     return RRL_OK;
+}
+
+// ---- W2 in MFMA fragment order (rrl_stack_t.W2p): pure permutation, one float4 per thread ----
+__global__ __launch_bounds__(kBlock) void w2_pack_kernel(int G, int H, const float* __restrict__ W2, float* __restrict__ W2p) {
+    const int per_row = H / 4, J = H / 16;
+    const long long n4 = (long long)G * H * per_row;
+    for (long long e = blockIdx.x * (long long)kBlock + threadIdx.x; e < n4; e += (long long)gridDim.x * kBlock) {
+        const int c4 = int(e % per_row), row = int((e / per_row) % H), g = int(e / ((long long)per_row * H));
+        const long long f = (long long)g * H * per_row + ((long long)(row >> 4) * J + (c4 >> 2)) * 64 + (c4 & 3) * 16 + (row & 15);
+        reinterpret_cast<float4*>(W2p)[f] = reinterpret_cast<const float4*>(W2)[e];
+    }
+}
+
+int rrl_w2_pack(int G, int H, const float* W2, float* W2p, void* stream) {
+    if (!W2 || !W2p || !aligned16(W2) || !aligned16(W2p)) return RRL_EINVAL;
+    if (G <= 0 || H <= 0 || (H & 15)) return RRL_ERANGE;
+    const long long n4 = (long long)G * H * (H / 4);
+    const int grid = int(std::min<long long>((n4 + kBlock - 1) / kBlock, 1024));
+    hipLaunchKernelGGL(w2_pack_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, G, H, W2, W2p);
+    return check_launch();
 }
 
 int rrl_adam_step_multi(int n_seg, const rrl_adam_seg_t* segs, float lr, float beta1, float beta2, float eps,

@@ -15,6 +15,8 @@ import math
 
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -50,13 +52,34 @@ class FlatNet:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.step = torch.zeros(2, dtype=torch.int64, device=device)   # {t, ticket}
-        self.p, self.g = {}, {}
+        self.p, self.g, self.offset = {}, {}, {}
         off = 0
         for name, shape in named_shapes:
             n = int(torch.Size(shape).numel())
             self.p[name] = self.flat[off:off + n].view(shape)
             self.g[name] = self.grad[off:off + n].view(shape)
+            self.offset[name] = off
             off += n
+        # W2 a second time in the forward kernels' MFMA fragment order (rrl_w2_pack / rrl_stack_t.W2p; hidden width 256):
+        # written by the fused optimiser launch together with the parameters (adam_multi), re-made from the row-major
+        # values by every EAGER forward (w2_packed()) -- torch code may have written the parameters through the modules'
+        # views since, and a permutation of 64 K floats costs less than finding out
+        shape = self.shapes.get("W2")
+        self.w2p = None
+        if shape is not None and len(shape) == 3 and shape[1] == shape[2] == 256 and self.offset["W2"] % 4 == 0 \
+                and torch.device(device).type == "cuda" and os.environ.get("RRL_W2_FRAG", "1") != "0":   # (0: A/B runs of profiles/)
+            self.w2p = torch.empty(int(torch.Size(shape).numel()), dtype=torch.float32, device=device)
+
+    def w2_packed(self):
+        """The fragment-order copy of W2, current: re-made here unless a hipGraph is being captured (a captured iteration is
+        replayed with nothing but the library's kernels between its launches, and those keep the copy in step)."""
+        if self.w2p is None:
+            return None
+        if not torch.cuda.is_current_stream_capturing():
+            W2 = self.p["W2"]
+            _lib.check(_lib.load().rrl_w2_pack(W2.shape[0], W2.shape[1], W2.data_ptr(), self.w2p.data_ptr(),
+                                               _lib.current_stream()), "rrl_w2_pack")
+        return self.w2p
 
     def rebind_grad(self, storage):
         """Move the gradient buffer into `storage` (a slice of a bucket shared with other networks, so that one
@@ -106,10 +129,14 @@ def adam_multi(lr, nets, betas=(0.9, 0.999), eps=1e-8):
         part = item[3] if len(item) > 3 else None
         gp, n_part, stride, n_first = (None, 0, 0, 0) if part is None else \
             (part[0].data_ptr(), part[0].shape[0], part[0].stride(0), part[1])
+        pack = net.w2p is not None and (target is None or target.w2p is not None)
         segs[k] = _lib.rrl_adam_seg_t(net.flat.numel(), net.flat.data_ptr(), net.grad.data_ptr(), net.m.data_ptr(),
                                       net.v.data_ptr(), net.step.data_ptr(),
                                       None if target is None else target.flat.data_ptr(), tau, 0.0, None,
-                                      gp, n_part, stride, n_first)
+                                      gp, n_part, stride, n_first,
+                                      net.w2p.data_ptr() if pack else None,
+                                      target.w2p.data_ptr() if pack and target is not None else None,
+                                      net.offset["W2"] if pack else 0, net.p["W2"].shape[0] if pack else 0)
     record("adam", segs, len(nets), float(lr), float(betas[0]), float(betas[1]), float(eps))
     _lib.check(lib.rrl_adam_step_multi(len(nets), segs, lr, betas[0], betas[1], eps, _lib.current_stream()),
                "rrl_adam_step_multi")
@@ -252,10 +279,12 @@ class Stack:
         p = _lib.ptr
         if in_head is not None:
             assert self.split and net.din == 4, "the input head lives in the column-split kernels"
+        w2p = (params or self.net).w2_packed() if self.split else None
         return _lib.rrl_stack_t(net.G, x.shape[0], net.H, net.din, net.dout, x.stride(0), p(x), p(P["W1"]), p(P["b1"]),
                                 p(P["W2"]), p(P["b2"]), p(P["W3"]), p(P["b3"]), p(self.h1) if save else None,
                                 p(self.h2) if save else None, p(self.out), p(self.scratch) if self.split else None,
-                                in_head if in_head is not None else _lib.rrl_policy_head_t(), int(in_head is not None))
+                                in_head if in_head is not None else _lib.rrl_policy_head_t(), int(in_head is not None),
+                                p(w2p) if w2p is not None else None)
 
     def backward_descs(self, dout, weight_grads=True, input_grad=False):
         """(rrl_head_bwd_t, rrl_hidden_bwd_t, rrl_input_bwd_t) of backward(dout, weight_grads, input_grad)."""

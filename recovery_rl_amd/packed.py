@@ -24,6 +24,8 @@ class PackedLoop:
     # seeds up to which the library issues a head + hidden backward as ONE launch (csrc pack_pair_block_max_seeds)
     PAIR_MAX_SEEDS = int(os.environ.get("RRL_PACK_PAIR_BLOCK_MAX_SEEDS", "6"))
 
+    FRAG_MAX_SEEDS = 8
+
     def __init__(self, loops, online_qrisk=True):
         """loops: VectorLoops in steady state (past start_steps, batch available), each on the fused grouped path."""
         if not 1 <= len(loops) <= self.MAX_SEEDS:
@@ -35,6 +37,16 @@ class PackedLoop:
         self.graph = None
         self.tapes = None
         self.stages = None
+        # the fragment-order copy of W2 (FlatNet.w2p) pays up to 8 seeds per GPU: -6.5 / -17 / -10 us per packed iteration at
+        # 1 / 4 / 8 seeds; with more, the optimiser launches are bound by L2 / Infinity-Cache bandwidth and the two extra
+        # streams they write cost what the forwards gain (16 seeds x 16 updates: 6.58-6.75 against 6.55-6.59 ms)
+        if self.S > self.FRAG_MAX_SEEDS:
+            for loop in self.loops:
+                fast = getattr(loop.agent, "fast", None)
+                for name in ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy"):
+                    net = getattr(fast, name, None)
+                    if net is not None:
+                        net.w2p = None
 
     # -- recording -------------------------------------------------------------------------------------------------------
     def record(self):

@@ -450,3 +450,56 @@ def test_paired_head_and_hidden_backward_equals_the_two_launches(monkeypatch, hi
             assert torch.equal(fa.flat, fb.flat), (step, name)
         assert torch.equal(a.fast.losses, b.fast.losses)
     assert calls["pair"] == calls["two"] > 0
+
+
+def _frag_order(W2):
+    """rrl_w2_pack's layout in torch: W2p[g][n][j][q][i][c] = W2[g][16 n + i][16 j + 4 q + c]."""
+    G, H, _ = W2.shape
+    return W2.reshape(G, H // 16, 16, H // 16, 4, 4).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)
+
+
+def test_fragment_order_copy_of_w2_follows_the_parameters():
+    """rrl_stack_t.W2p: the forward kernels read W2 a second time in MFMA fragment order.  The copy is made by rrl_w2_pack (every
+    eager forward re-makes it: torch code may have written the parameters), kept in step by the fused optimiser launch (own
+    parameters AND Polyak target) -- so after eager updates, after graph replays and after a write through the modules the copies
+    of all six networks are the permutation of their parameters, and the forward results do not depend on which layout was read."""
+    import arg_utils
+    import bench
+    cfg = arg_utils.get_args(bench.config_argv("navigation1", 5, 256, 1) + ["--num_unsafe_transitions", "3000"])
+    loop = bench.build_loop(cfg, torch.device("cuda:0"), pretrain=10)
+    f = loop.agent.fast
+    nets = {k: getattr(f, k) for k in ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy")}
+    assert all(n.w2p is not None for n in nets.values())
+
+    def check(tag):
+        torch.cuda.synchronize()
+        for k, n in nets.items():
+            assert torch.equal(n.w2p, _frag_order(n.p["W2"])), (tag, k)
+    for _ in range(3):
+        loop.vector_step(True, False, True)
+    check("eager")
+    loop.capture(online_qrisk=True)
+    before = nets["critic"].p["W2"].clone()
+    loop.advance(9)
+    check("graph replays")
+    assert not torch.equal(before, nets["critic"].p["W2"])
+    # a write through the module's view (load_state_dict, a test harness): the next eager forward re-makes the copy
+    with torch.no_grad():
+        loop.agent.policy.linear2.weight.mul_(1.5)
+    assert not torch.equal(nets["policy"].w2p, _frag_order(nets["policy"].p["W2"]))
+    loop.vector_step(True, False, True)
+    check("after a write through the module")
+    # the two layouts give the same forward: bit-identical outputs with and without the copy
+    st = f.q_stack if hasattr(f, "q_stack") else None
+    x = torch.randn(256, 4, device="cuda")
+    net = nets["critic"]
+    from recovery_rl_amd.fast_update import Stack, forward_multi
+    s1, s2 = Stack(net, 256), Stack(net, 256)
+    d1 = s1.forward_desc(x)
+    keep, net.w2p = net.w2p, None
+    d2 = s2.forward_desc(x)
+    net.w2p = keep
+    assert d1.W2p and not d2.W2p
+    forward_multi([d1]); forward_multi([d2])
+    torch.cuda.synchronize()
+    assert torch.equal(s1.scratch, s2.scratch) and torch.equal(s1.h2, s2.h2)
