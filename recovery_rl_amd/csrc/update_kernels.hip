@@ -345,16 +345,6 @@ struct AdamSlot {
     long long i0, i1;
     bool two;
 };
-// Which float4 a thread works on inside the W2 range when the fragment-order copy is kept: within every run of 256 float4
-// (four rows of a [256, 256] matrix) lane t takes row t % 4, float4 t / 4 of the row instead of row t / 64, float4 t % 64 -- four
-// neighbouring lanes then hold rows i .. i + 3 of one (K chunk, lane group) and their stores into the copy are 64 contiguous
-// bytes (row-major order scattered them 16 bytes per line: 6.9 -> 8.1 us per launch, and 6.4 -> 6.7 ms at 16 seeds x 16 updates),
-// while every row-major access still covers 256-byte runs.  A relabelling of who does what: the arithmetic per element is the same.
-__device__ __forceinline__ long long adam_w2_slot(const AdamVec& a, long long i) {
-    if (!a.w2p || i < a.w2_lo4 || i >= a.w2_hi4) return i;
-    const long long rel = i - a.w2_lo4;
-    return a.w2_lo4 + ((rel & ~255LL) | ((rel & 3) << 6) | ((rel & 255) >> 2));
-}
 __device__ __forceinline__ void adam_slot_load(const AdamVec& a, long long i0, AdamSlot& s) {
     const float4* p4 = reinterpret_cast<const float4*>(a.p);
     const float4* m4 = reinterpret_cast<const float4*>(a.m);
@@ -362,10 +352,9 @@ __device__ __forceinline__ void adam_slot_load(const AdamVec& a, long long i0, A
     const float4* t4 = reinterpret_cast<const float4*>(a.target);
     const float4* g4 = reinterpret_cast<const float4*>(a.g);
     const float4* h4 = reinterpret_cast<const float4*>(a.g2);
-    s.two = i0 + a.stride < a.n4;
-    s.i1 = adam_w2_slot(a, i0 + a.stride);
-    i0 = adam_w2_slot(a, i0);
     s.i0 = i0;
+    s.i1 = i0 + a.stride;
+    s.two = s.i1 < a.n4;
     const long long j1 = s.two ? s.i1 : i0;
     s.P[0] = p4[i0]; s.P[1] = p4[j1];
     s.G[0] = g4[i0]; s.G[1] = g4[j1];
@@ -405,7 +394,9 @@ __device__ __forceinline__ void adam_slot_finish(const AdamVec& a, AdamSlot& s, 
         p4[s.i1] = s.P[1]; m4[s.i1] = s.M[1]; v4[s.i1] = s.V[1];
         if (a.target) t4[s.i1] = s.T[1];
     }
-    if (a.w2p) {            // (uniform) the forward kernels' copy of W2 -- and of the target's -- in fragment order
+    // (uniform) the forward kernels' copy of W2 -- and of the target's -- in fragment order.  (Lanes relabelled inside the W2 range so
+    // that four neighbours hold rows i .. i + 3 and store 64 contiguous bytes instead of 16 per line: measured, no difference.)
+    if (a.w2p) {
         float4* w4 = reinterpret_cast<float4*>(a.w2p);
         float4* tw4 = reinterpret_cast<float4*>(a.tw2p);
         if (s.i0 >= a.w2_lo4 && s.i0 < a.w2_hi4) {
@@ -468,8 +459,7 @@ __device__ __forceinline__ void adam_seg_body(const rrl_adam_seg_t& sg, bool vec
     const bool pre = vec && (long long)block * kBlock + threadIdx.x < (sg.n >> 2);
     if (pre) {
         const AdamVec av{sg.p, sg.g, sg.m, sg.v, sg.target, sg.g2, sg.g_part, sg.n_part, sg.part_stride,
-                         sg.g_part ? sg.part_elems : 0, sg.n >> 2, (long long)blocks * kBlock,
-                         sg.w2p, sg.target ? sg.target_w2p : nullptr, sg.w2_off >> 2, (sg.w2_off >> 2) + (long long)sg.w2_heads * 16384};
+                         sg.g_part ? sg.part_elems : 0, sg.n >> 2, (long long)blocks * kBlock, nullptr, nullptr, 0, 0};
         adam_slot_load(av, (long long)block * kBlock + threadIdx.x, first);
     }
     unsigned long long ticket = ~0ULL;
