@@ -108,6 +108,32 @@ def test_timed_blocks_agree_over_ranks():
     assert t0 >= 0.003 * 10 * b0 * 0.9                       # the slow rank's time
 
 
+def test_production_step_advances_whole_graphs_up_to_each_log_point():
+    """bench.production_step: `run.many(n)` hands n iterations to the loop's advance() exactly as the lock-step driver does
+    (experiment.py run_vectorized): never across a log point, the log-point work every `every` iterations, whatever the block
+    size; one-by-one calls of `run()` reach the same log points."""
+    calls, logs = [], []
+
+    class Loop:
+        episode_log = None
+
+        def read_stats(self):
+            logs.append(sum(calls))
+
+    run = bench.production_step(lambda: calls.append(1), [Loop()], every=10, advance=lambda m: calls.append(m))
+    run.many(7)            # 7
+    run.many(7)            # 3 (log at 10) + 4
+    run()                  # a single step in between
+    run.many(26)           # 5 (log at 20) + 10 (log at 30) + 10 (log at 40) + 1
+    assert calls == [7, 3, 4, 1, 5, 10, 10, 1] and sum(calls) == 41
+    assert logs == [10, 20, 30, 40]
+    # without advance(): n single steps, same log points
+    calls.clear(); logs.clear()
+    run = bench.production_step(lambda: calls.append(1), [Loop()], every=4)
+    run.many(9)
+    assert calls == [1] * 9 and logs == [4, 8]
+
+
 @pytest.mark.gpu
 def test_bench_gpus_2_runs_two_ranks_and_reports_them(tmp_path):
     """`python bench.py --gpus 2` end to end on the test box's single GPU (gloo for the 96-byte metric all-reduce, both
