@@ -1637,7 +1637,8 @@ static int pack_block(int S) { return S >= 3 ? 12 : 0; }
 // the block form; beyond, the head launch + the block form of the hidden backward: with many seeds the launches are throughput-
 // bound, the separate head launch costs little and the dh2 generation in every block is what shows (measured per packed
 // iteration, 16 updates: S = 4 paired 3.04 ms against 3.11, S = 8 4.30 = 4.27, S = 16 7.12 against 6.67:
-// profiles/round5_packed/).  (RRL_PACK_PAIR_MAX_SEEDS / RRL_PACK_PAIR_BLOCK_MAX_SEEDS: A/B runs)
+// profiles/round5_packed/; with one update per iteration the paired block form wins up to 8 seeds: 7 / 8 seeds 0.456-0.461 /
+// 0.448-0.454 ms against 0.466-0.485 / 0.459-0.461).  (RRL_PACK_PAIR_MAX_SEEDS / RRL_PACK_PAIR_BLOCK_MAX_SEEDS: A/B runs)
 static int env_int(const char* name, int fallback) {
     const char* e = getenv(name);
     return e ? atoi(e) : fallback;
@@ -1647,7 +1648,7 @@ static int pack_pair_max_seeds() {
     return v;
 }
 static int pack_pair_block_max_seeds() {
-    static const int v = env_int("RRL_PACK_PAIR_BLOCK_MAX_SEEDS", 6);
+    static const int v = env_int("RRL_PACK_PAIR_BLOCK_MAX_SEEDS", 8);
     return v;
 }
 // tile counts of a HiddenGroup -> block counts; false: some member has no whole number of full, aligned blocks

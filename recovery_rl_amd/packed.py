@@ -22,7 +22,7 @@ from . import fast_update
 class PackedLoop:
     MAX_SEEDS = 16
     # seeds up to which the library issues a head + hidden backward as ONE launch (csrc pack_pair_block_max_seeds)
-    PAIR_MAX_SEEDS = int(os.environ.get("RRL_PACK_PAIR_BLOCK_MAX_SEEDS", "6"))
+    PAIR_MAX_SEEDS = int(os.environ.get("RRL_PACK_PAIR_BLOCK_MAX_SEEDS", "8"))
 
     FRAG_MAX_SEEDS = 8
 
