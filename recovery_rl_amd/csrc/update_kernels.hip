@@ -6,6 +6,8 @@
 // Batches are tiny (B = 256): one workgroup, latency-bound by design.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "rrl_device.hpp"
 #include "pack.hpp"
 #include "rrl_host.hpp"
@@ -715,7 +717,12 @@ static int build_adam_segs(int n_seg, const rrl_adam_seg_t* segs, AdamSegs& a) {
                 sg.w2_heads <= 0 || sg.w2_off + (long long)sg.w2_heads * 65536 > sg.n)
                 return RRL_EINVAL;
         }
-        a.first_block[k + 1] = a.first_block[k] + (grid_for(sg.n) < 64 ? grid_for(sg.n) : 64);
+        // workgroups: 64 (the step ticket is one device-scope atomic per workgroup on a single word), up to 96 where that lets
+        // every thread finish in its two float4 slots -- the twin critics' 134 658 parameters are 33 665 float4 = 2.05 per thread
+        // of 64 workgroups, and the ~900 threads with a third slot added a whole dependent load -> store round trip to the launch
+        const long long want = ((sg.n >> 2) + 2 * kBlock - 1) / (2 * kBlock);
+        const int cap = int(std::min<long long>(std::max<long long>(64, want), 96));
+        a.first_block[k + 1] = a.first_block[k] + (grid_for(sg.n) < cap ? grid_for(sg.n) : cap);
     }
     for (int k = n_seg; k < RRL_ADAM_MAX_SEGS; ++k) a.first_block[k + 1] = a.first_block[n_seg];
     return RRL_OK;
