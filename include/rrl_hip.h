@@ -705,7 +705,11 @@ int rrl_episode_log_append(int64_t n, const float* reward, const uint8_t* constr
  *                      lin3_w [E,he,4], lin3_b [E,1,4] (in x out), inputs_mu/sigma [4], max/min_logvar [2].
  *   rrl_plan_cost      cur_obs [M,2], ac_seqs [M,pop,plan_hor*2] f32; noise nullable f32 [plan_hor, M*pop*npart, 2]
  *                      (row = (m*pop + c)*npart + p); when NULL the kernel draws Philox normals (stream
- *                      RRL_STREAM_PLAN, row, counter*16 + t).  partial: scratch f32 [M*pop, n_nets]; costs [M,pop].
+ *                      RRL_STREAM_PLAN, row, counter*16 + t).  scratch: f32 [rrl_plan_scratch_floats(n_nets, M, pop)]
+ *                      (first-step values per candidate / per (candidate, member) + per-member cost sums); costs [M,pop].
+ *                      Two launches + the finish: the first step once per DISTINCT row (the particles of a candidate share
+ *                      (cur_obs, ac_0): MPC.py:393-402), then steps 1..plan_hor-1 per particle without the last step's
+ *                      unread prediction (MPC.py:406-412) -- bit-identical to the literal loop, 74.9 % of its FLOPs.
  * Supported shape (rrl_plan_supported): hq = 256, he = 200, npart = 4 n_nets, 2-D obs and actions.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -717,10 +721,11 @@ typedef struct {
 
 int rrl_plan_supported(int hq, int he, int n_nets, int npart, int d_obs, int d_act);
 long long rrl_plan_pack_floats(int hq, int he, int n_nets);
+long long rrl_plan_scratch_floats(int n_nets, long long M, int pop);     /* M * pop * (5 n_nets + 1) */
 int rrl_plan_pack(const rrl_plan_weights_t* w, float* packed, void* stream);
 int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
                   const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
-                  uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream);
+                  uint64_t* counter_dev, uint64_t counter_inc, float* scratch, float* costs, void* stream);
 
 /* The same evaluation with the three hidden-layer products (Q_risk 256 x 256, ensemble 200 x 200 twice) on the f16 matrix
  * pipe: every f32 activation and weight is split as hi + lo (two f16 carrying 22 bits of the value) and the product is
@@ -732,14 +737,14 @@ int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, lo
 int rrl_plan_pack_f16x3(const rrl_plan_weights_t* w, float* packed, void* stream);
 int rrl_plan_cost_f16x3(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
                         const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
-                        uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream);
+                        uint64_t* counter_dev, uint64_t counter_inc, float* scratch, float* costs, void* stream);
 
 /* rrl_plan_cost / rrl_plan_cost_f16x3 (f16x3 != 0) for M = m_dev[0] planning problems, M read by the kernel (see
  * rrl_cem_begin); the grid covers m_max problems and workgroups past the live ones exit at once.  cur_obs, ac_seqs,
- * partial and costs are sized for m_max.  Results for the live problems equal the host-count entries' bit for bit. */
+ * scratch and costs are sized for m_max.  Results for the live problems equal the host-count entries' bit for bit. */
 int rrl_plan_cost_n(int f16x3, const float* packed, int hq, int he, int n_nets, int npart, const int32_t* m_dev,
                     long long m_max, int pop, int plan_hor, const float* cur_obs, const float* ac_seqs, const float* noise,
-                    uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* partial,
+                    uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* scratch,
                     float* costs, void* stream);
 
 /* --------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ EXPORTS = [
     "rrl_gauss_head_fwd", "rrl_gauss_head_bwd", "rrl_sac_critic_grad", "rrl_sac_policy_grad",
     "rrl_qrisk_critic_grad", "rrl_qrisk_policy_grad", "rrl_stoch_head_fwd", "rrl_stoch_head_bwd",
     "rrl_adam_step", "rrl_adam_step_multi", "rrl_w2_pack", "rrl_normal_fill", "rrl_recovery_select", "rrl_episode_log_append",
-    "rrl_plan_supported", "rrl_plan_pack_floats", "rrl_plan_pack", "rrl_plan_cost", "rrl_plan_pack_f16x3",
+    "rrl_plan_supported", "rrl_plan_pack_floats", "rrl_plan_scratch_floats", "rrl_plan_pack", "rrl_plan_cost", "rrl_plan_pack_f16x3",
     "rrl_plan_cost_f16x3", "rrl_plan_cost_n",
     "rrl_ens_train_supported", "rrl_ens_scratch_floats", "rrl_ens_train_grad", "rrl_ens_train_epoch",
     "rrl_ens_train_big_supported", "rrl_ens_big_scratch_floats", "rrl_ens_train_grad_big", "rrl_ens_train_epoch_big",
@@ -327,6 +327,7 @@ def _declare(lib):
         "rrl_recovery_select": (ci, [ci, vp, f32, vp, ci, vp, vp, vp, vp, vp]),
         "rrl_plan_supported": (ci, [ci, ci, ci, ci, ci, ci]),
         "rrl_plan_pack_floats": (ll, [ci, ci, ci]),
+        "rrl_plan_scratch_floats": (ll, [ci, ll, ci]),
         "rrl_plan_pack": (ci, [C.POINTER(rrl_plan_weights_t), vp, vp]),
         "rrl_plan_cost": (ci, [vp, ci, ci, ci, ci, ll, ci, ci, vp, vp, vp, u64, u64, vp, u64, vp, vp, vp]),
         "rrl_plan_pack_f16x3": (ci, [C.POINTER(rrl_plan_weights_t), vp, vp]),

@@ -11,6 +11,12 @@
 // per-candidate cost leaves the chip.  Arithmetic is v_mfma_f32_16x16x4_f32 (exact f32 fma chains), so
 // results differ from the PyTorch path only by summation order.
 //
+// Only the work the costs depend on is done (round 6; 12.90 of the 17.22 GFLOP per env and CEM iteration the literal
+// loop spends): at t = 0 every particle of a candidate sees the same (cur_obs, ac_0), so plan_first_step_kernel evaluates
+// Q_risk once per candidate and each member once per (candidate, member); the prediction of the last step feeds a
+// cur_obs nothing reads, so plan_cost_kernel ends with a Q_risk-only step.  Rows of an MFMA tile are independent and both
+// kernels run the same phase code: the costs are bit-identical to the literal rollout's.
+//
 // Row order inside a tile: 16 consecutive (m, c) groups x the 4 particles that are bound to ensemble member
 // e (TS-infinity: member = particle / (npart / nets), MPC.py:441-455); tile id = (group block, e).
 #include "rrl_device.hpp"
@@ -257,137 +263,105 @@ __device__ __forceinline__ float reduce16(float v) {   // sum over the 16 lanes 
     return v;
 }
 
+// LDS carve-up shared by the two kernels
+struct PlanLds {
+    float* act;                        // [64][260] f32 activations, or two f16 planes
+    float* xs;                         // [64][4] raw (obs, ac)
+    float* xn;                         // [64][4] standardised ensemble input
+    float (*qpart)[kWaves][kRows];     // [2 heads][8 waves][64 rows] partial last-layer sums of Q_risk
+    float (*epart)[kRows][4];          // [4 column strips][64 rows][4 outputs] partial last-layer sums of the member
+    float* rowstate;                   // [64][4] = {obs x, obs y, cost, -}
+};
+__device__ __forceinline__ PlanLds carve(float* lds) {
+    PlanLds L;
+    L.act = lds;
+    L.xs = L.act + kActFloats;
+    L.xn = L.xs + kRows * 4;
+    L.qpart = reinterpret_cast<float(*)[kWaves][kRows]>(L.xn + kRows * 4);
+    L.epart = reinterpret_cast<float(*)[kRows][4]>(L.xn + kRows * 4 + 2 * kWaves * kRows);
+    L.rowstate = L.xn + kRows * 4 + 2 * kWaves * kRows + 4 * kRows * 4;
+    return L;
+}
+
+// ---- Q_risk twin heads on the 64 rows of xs: 4 -> HQ relu -> HQ relu -> 1; leaves qpart[h][wave][row] ----
+// (pre-activation of the output = b3 + sum over the 8 waves, added by the caller in wave order).  Ends with a barrier.
 template <bool F16X3>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(RRL_PLAN_WAVES_PER_EU, RRL_PLAN_WAVES_PER_EU)))
-void plan_cost_kernel(
-    const float* __restrict__ pk, int n_nets, int npart, long long n_groups, int pop, int plan_hor,
-    const float* __restrict__ cur_obs, const float* __restrict__ ac_seqs, const float* __restrict__ noise,
-    uint64_t seed, uint64_t counter, const uint64_t* __restrict__ counter_dev, float* __restrict__ partial,
-    const int32_t* __restrict__ m_dev) {
-    if (m_dev) {
-        // the number of planning problems was decided on the device (rrl_cem_begin): the grid covers the launch bound,
-        // workgroups past the live tiles leave before they touch anything
-        n_groups = (long long)m_dev[0] * pop;
-        if ((long long)blockIdx.x >= ((n_groups + 15) / 16) * n_nets) return;
-    }
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* act = lds;                                               // [64][260] f32 activations, or two f16 planes
-    float* xs = act + kActFloats;                                   // [64][4] raw (obs, ac)
-    float* xn = xs + kRows * 4;                                     // [64][4] standardised ensemble input
-    float(*qpart)[kWaves][kRows] = reinterpret_cast<float(*)[kWaves][kRows]>(xn + kRows * 4);
-    float(*epart)[kRows][4] = reinterpret_cast<float(*)[kRows][4]>(xn + kRows * 4 + 2 * kWaves * kRows);
-    float* rowstate = xn + kRows * 4 + 2 * kWaves * kRows + 4 * kRows * 4;      // [64][4] = {obs x, obs y, cost, -}
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile indices live in SGPRs
-    const long long tile = blockIdx.x;
-    const int e = int(tile % n_nets);
-    const long long gblock = tile / n_nets;
-    const int ppn = npart / n_nets;                       // particles per net (4)
-    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
-
-    // one thread per row advances the row's rollout state, which lives in LDS between the steps (registers that stay
-    // live across the matrix phases are what the 128-VGPR budget of two workgroups per CU is short of)
-    const bool owner = tid < kRows;
-    if (owner) {
-        const long long group = gblock * 16 + (tid >> 2);
-        f32x4 st = {0.f, 0.f, 0.f, 0.f};
-        if (group < n_groups) {
-            const long long m = group / pop;
-            st[0] = cur_obs[m * 2];
-            st[1] = cur_obs[m * 2 + 1];
-        }
-        *reinterpret_cast<f32x4*>(rowstate + tid * 4) = st;
-    }
-    const float* epk = pk + e_off(e);
-    const float* g = pk + glob_off(n_nets);                // mu[4], sigma[4], max_logvar[2], min_logvar[2]
-
-    const int order = __builtin_amdgcn_readfirstlane(int(blockIdx.x >> 8) & 1);
-    // wave -> tile assignment
+__device__ __forceinline__ void q_phase(const PlanLds& L, const float* __restrict__ pk, int wave, int lane) {
+    const int ln = opaque(lane);
     const int q_rt[4] = {0, 1, 2, 3};
     const int q_ct[2] = {2 * wave, 2 * wave + 1};
+    float* act = L.act;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const float* __restrict__ w = pk + h * kQSize;
+        // epilogue constants first: their latency hides behind the matrix work
+        float b1v[2], b2v[2], w3v[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = q_ct[c] * 16 + (ln & 15);
+            b1v[c] = w[kQB1 + col];
+            b2v[c] = w[kQB2 + col];
+            w3v[c] = w[kQW3 + col];
+        }
+        f32x4 acc[4][2];
+        zero(acc);
+        input_mma<2>(acc, L.xs, q_rt, w + kQW1, q_ct, opaque(lane));
+        store_act<F16X3, false, 2>(acc, act, q_rt, b1v, q_ct, opaque(lane));
+        __syncthreads();
+        zero(acc);
+        if constexpr (F16X3) layer_mma_k32<2, kQTiles / 2>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
+        else layer_mma<2, kQTiles>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
+        // last layer folded in: q[row] = sum_col relu(h2 + b2) w3[col]
+        float s[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[r][i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float bv = b2v[c], w3 = w3v[c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[r][i] += reluf(acc[r][c][i] + bv) * w3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = reduce16(s[r][i]);
+                if ((ln & 15) == 0) L.qpart[h][wave][r * 16 + 4 * (ln >> 4) + i] = v;
+            }
+        __syncthreads();       // act is free again; qpart[h] complete
+    }
+}
+
+// max(sigmoid Q1, sigmoid Q2) of row `row` from the partial sums q_phase left (qrisk.py:184-196; torch.max: NaN propagates)
+__device__ __forceinline__ float q_value(const PlanLds& L, const float* __restrict__ pk, int row) {
+    float q[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float v = pk[h * kQSize + kQB3];
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) v += L.qpart[h][w][row];
+        q[h] = sigmoidf(v);
+    }
+    return (q[0] > q[1] || q[0] != q[0]) ? q[0] : q[1];
+}
+
+// ---- ensemble member (weights at epk) on the 64 rows of xn: 4 -> 200 swish -> 200 swish -> 200 swish -> 4; leaves
+// epart[strip][row][o] (output o = b3[o] + the four strips, added by the caller in a fixed order).  Ends with a barrier.
+// 4 row tiles x 13 column tiles: every wave owns 2 row tiles x 3 column tiles (cs, cs+4, cs+8); the 13th column's four
+// tiles go one each to waves 0..3 (row tile xr of their own pair), so every SIMD carries the same number of MFMAs.
+template <bool F16X3>
+__device__ __forceinline__ void e_phase(const PlanLds& L, const float* __restrict__ epk, int wave, int lane, int tid) {
+    const int ln = opaque(lane);
     const int rh = wave & 1, cs = wave >> 1;
     const int e_rt[2] = {2 * rh, 2 * rh + 1};
     const int e_ct[4] = {cs, cs + 4, cs + 8, wave < 4 ? 12 : cs};   // the 13th column: waves 0..3, one row tile each
     const int xr = wave < 4 ? (wave >> 1) : -1;                     // which of the wave's two row tiles (0/1), or none
-
-    for (int t = 0; t < plan_hor; ++t) {
-        // per-step copy of the lane id the optimiser cannot see through: the lane-dependent addresses of the bias /
-        // last-layer constants are recomputed every step instead of being hoisted out of the loop and spilled
-        const int ln = opaque(lane);
-        if (owner) {
-            const int otid = opaque(tid);        // keeps the 64-bit row addresses out of the loop-invariant (spilled) set
-            const long long group = gblock * 16 + (otid >> 2);
-            float ax = 0.f, ay = 0.f;
-            if (group < n_groups) {
-                ax = ac_seqs[group * (plan_hor * 2) + 2 * t];
-                ay = ac_seqs[group * (plan_hor * 2) + 2 * t + 1];
-            }
-            const f32x4 x = {rowstate[tid * 4], rowstate[tid * 4 + 1], ax, ay};
-            *reinterpret_cast<f32x4*>(xs + tid * 4) = x;
-            f32x4 n;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) n[k] = (x[k] - g[k]) / g[4 + k];
-            *reinterpret_cast<f32x4*>(xn + tid * 4) = n;
-        }
-        __syncthreads();
-
-        // The two networks read the same (obs, ac) and are independent, so their order is free.  Workgroups that
-        // share a CU (dispatch slots alternate every 256 workgroups: 8 XCDs x 32 CUs) run them in opposite order,
-        // which keeps one of them in a matrix phase while the other is in an epilogue or at a barrier.
-#pragma unroll 1
-        for (int phase = 0; phase < 2; ++phase) {
-            if ((phase ^ order) == 0) {
-                // ---- Q_risk twin heads: 4 -> HQ relu -> HQ relu -> 1 ----
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {
-                    const float* __restrict__ w = pk + h * kQSize;
-                    // epilogue constants first: their latency hides behind the matrix work
-                    float b1v[2], b2v[2], w3v[2];
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const int col = q_ct[c] * 16 + (ln & 15);
-                        b1v[c] = w[kQB1 + col];
-                        b2v[c] = w[kQB2 + col];
-                        w3v[c] = w[kQW3 + col];
-                    }
-                    f32x4 acc[4][2];
-                    zero(acc);
-                    input_mma<2>(acc, xs, q_rt, w + kQW1, q_ct, opaque(lane));
-                    store_act<F16X3, false, 2>(acc, act, q_rt, b1v, q_ct, opaque(lane));
-                    __syncthreads();
-                    zero(acc);
-                    if constexpr (F16X3) layer_mma_k32<2, kQTiles / 2>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
-                    else layer_mma<2, kQTiles>(acc, act, q_rt, w + kQW2, q_ct, opaque(lane));
-                    // last layer folded in: q[row] = sum_col relu(h2 + b2) w3[col]
-                    float s[4][4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) s[r][i] = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const float bv = b2v[c], w3 = w3v[c];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s[r][i] += reluf(acc[r][c][i] + bv) * w3;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = reduce16(s[r][i]);
-                            if ((ln & 15) == 0) qpart[h][wave][r * 16 + 4 * (ln >> 4) + i] = v;
-                        }
-                    __syncthreads();       // act is free again; qpart[h] complete
-                }
-            } else {
-                // ---- ensemble member e: 4 -> 200 swish -> 200 swish -> 200 swish -> 4 ----
-                // 4 row tiles x 13 column tiles: every wave owns 2 row tiles x 3 column tiles (cs, cs+4, cs+8);
-                // the 13th column's four tiles go one each to waves 0..3 (row tile xr of their own pair), so
-                // every SIMD carries the same number of MFMAs.
-                // Wave-uniform dispatch on the extra tile: E_STAGE(f, args) = f<NCV, ..., XR>(args)
+    float* act = L.act;
+    // Wave-uniform dispatch on the extra tile: E_STAGE(f, args) = f<NCV, ..., XR>(args)
 #define E_STAGE(CALL4X0, CALL4X1, CALL3)  \
     if (xr == 0) {                        \
         CALL4X0;                          \
@@ -396,138 +370,285 @@ void plan_cost_kernel(
     } else {                              \
         CALL3;                            \
     }
-                // column of this lane in column tile c, re-derived at every use (not kept live across the phases)
-                auto ecol = [&](int c) { return e_ct[c] * 16 + (opaque(lane) & 15); };
-                // per-column constants are requested one phase ahead of their use, never all live at once
-                float eb[4];
+    // column of this lane in column tile c, re-derived at every use (not kept live across the phases)
+    auto ecol = [&](int c) { return e_ct[c] * 16 + (opaque(lane) & 15); };
+    // per-column constants are requested one phase ahead of their use, never all live at once
+    float eb[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB0 + ecol(c)];
-                if constexpr (F16X3) {
-                    // the ensemble's last 32-wide k block covers columns 192..223, its stores only 0..207: the rest
-                    // multiplies zero weights, which needs them FINITE -- the Q_risk phase leaves its own activations
-                    // there, and a NaN / inf among them (a diverged safety critic) would leak into this member's
-                    // prediction as NaN x 0; re-zeroed before every ensemble phase (nobody reads `act` right now: the
-                    // previous phase ended with a barrier, the layer-0 stores below touch columns < 208 only)
-                    _Float16* planes = reinterpret_cast<_Float16*>(act);
-                    for (int i = opaque(tid); i < 2 * kRows * 16; i += kThreads)
-                        planes[(i >> 10) * (kRows * kHalfStride) + ((i >> 4) & (kRows - 1)) * kHalfStride + kHEPad + (i & 15)] =
-                            (_Float16)0.f;
-                }
-                f32x4 acc[2][4];
-                zero(acc);
-                E_STAGE((input_mma<4, 0>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
-                         store_act<F16X3, true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
-                        (input_mma<4, 1>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
-                         store_act<F16X3, true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
-                        (input_mma<3>(acc, xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
-                         store_act<F16X3, true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
+    for (int c = 0; c < 4; ++c) eb[c] = epk[kEB0 + ecol(c)];
+    if constexpr (F16X3) {
+        // the ensemble's last 32-wide k block covers columns 192..223, its stores only 0..207: the rest
+        // multiplies zero weights, which needs them FINITE -- the Q_risk phase leaves its own activations
+        // there, and a NaN / inf among them (a diverged safety critic) would leak into this member's
+        // prediction as NaN x 0; re-zeroed before every ensemble phase (nobody reads `act` right now: the
+        // previous phase ended with a barrier, the layer-0 stores below touch columns < 208 only)
+        _Float16* planes = reinterpret_cast<_Float16*>(act);
+        for (int i = opaque(tid); i < 2 * kRows * 16; i += kThreads)
+            planes[(i >> 10) * (kRows * kHalfStride) + ((i >> 4) & (kRows - 1)) * kHalfStride + kHEPad + (i & 15)] =
+                (_Float16)0.f;
+    }
+    f32x4 acc[2][4];
+    zero(acc);
+    E_STAGE((input_mma<4, 0>(acc, L.xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
+             store_act<F16X3, true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+            (input_mma<4, 1>(acc, L.xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
+             store_act<F16X3, true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+            (input_mma<3>(acc, L.xn, e_rt, epk + kEW0, e_ct, opaque(lane)),
+             store_act<F16X3, true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
 #pragma unroll
-                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB1 + ecol(c)];
-                __syncthreads();
-                zero(acc);
-                if constexpr (F16X3) {
-                    E_STAGE((layer_mma_k32<4, kEBlocks32, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
-                            (layer_mma_k32<4, kEBlocks32, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
-                            (layer_mma_k32<3, kEBlocks32>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
-                } else {
-                    E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
-                            (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
-                            (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
-                }
-                __syncthreads();       // every wave has finished reading layer-1 input
-                E_STAGE((store_act<F16X3, true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
-                        (store_act<F16X3, true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
-                        (store_act<F16X3, true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
+    for (int c = 0; c < 4; ++c) eb[c] = epk[kEB1 + ecol(c)];
+    __syncthreads();
+    zero(acc);
+    if constexpr (F16X3) {
+        E_STAGE((layer_mma_k32<4, kEBlocks32, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                (layer_mma_k32<4, kEBlocks32, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                (layer_mma_k32<3, kEBlocks32>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
+    } else {
+        E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))),
+                (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW1, e_ct, opaque(lane))))
+    }
+    __syncthreads();       // every wave has finished reading layer-1 input
+    E_STAGE((store_act<F16X3, true, 4, 0>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+            (store_act<F16X3, true, 4, 1>(acc, act, e_rt, eb, e_ct, opaque(lane))),
+            (store_act<F16X3, true, 3>(acc, act, e_rt, eb, e_ct, opaque(lane))))
 #pragma unroll
-                for (int c = 0; c < 4; ++c) eb[c] = epk[kEB2 + ecol(c)];
-                __syncthreads();
-                zero(acc);
-                if constexpr (F16X3) {
-                    E_STAGE((layer_mma_k32<4, kEBlocks32, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
-                            (layer_mma_k32<4, kEBlocks32, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
-                            (layer_mma_k32<3, kEBlocks32>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
-                } else {
-                    E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
-                            (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
-                            (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
-                }
+    for (int c = 0; c < 4; ++c) eb[c] = epk[kEB2 + ecol(c)];
+    __syncthreads();
+    zero(acc);
+    if constexpr (F16X3) {
+        E_STAGE((layer_mma_k32<4, kEBlocks32, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                (layer_mma_k32<4, kEBlocks32, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                (layer_mma_k32<3, kEBlocks32>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
+    } else {
+        E_STAGE((layer_mma<4, kETiles, 0>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                (layer_mma<4, kETiles, 1>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))),
+                (layer_mma<3, kETiles>(acc, act, e_rt, epk + kEW2, e_ct, opaque(lane))))
+    }
 #undef E_STAGE
-                // last layer (200 -> 4) folded in: out[row][o] = sum_col swish(h3 + b2) W3[col][o]
-                f32x4 ew3[4];
+    // last layer (200 -> 4) folded in: out[row][o] = sum_col swish(h3 + b2) W3[col][o]
+    f32x4 ew3[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) ew3[c] = *reinterpret_cast<const f32x4*>(epk + kEW3 + ecol(c) * 4);
+    for (int c = 0; c < 4; ++c) ew3[c] = *reinterpret_cast<const f32x4*>(epk + kEW3 + ecol(c) * 4);
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    float s[4][4];
+    for (int r = 0; r < 2; ++r) {
+        float s[4][4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int o = 0; o < 4; ++o) s[i][o] = 0.f;
+            for (int o = 0; o < 4; ++o) s[i][o] = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (c == 3 && xr != r) continue;          // acc[r][3] is zero there, but swish(b) is not
+        for (int c = 0; c < 4; ++c) {
+            if (c == 3 && xr != r) continue;          // acc[r][3] is zero there, but swish(b) is not
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = swishf(acc[r][c][i] + eb[c]);
+            for (int i = 0; i < 4; ++i) {
+                const float v = swishf(acc[r][c][i] + eb[c]);
 #pragma unroll
-                            for (int o = 0; o < 4; ++o) s[i][o] += v * ew3[c][o];
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) {
-                            const float v = reduce16(s[i][o]);
-                            if ((ln & 15) == 0) epart[cs][e_rt[r] * 16 + 4 * (ln >> 4) + i][o] = v;
-                        }
-                }
-                __syncthreads();
+                for (int o = 0; o < 4; ++o) s[i][o] += v * ew3[c][o];
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float v = reduce16(s[i][o]);
+                if ((ln & 15) == 0) L.epart[cs][e_rt[r] * 16 + 4 * (ln >> 4) + i][o] = v;
+            }
+    }
+    __syncthreads();
+}
+
+// The member's predictive distribution for row `row` from the partial sums e_phase left: {mean dx, mean dy, sd x, sd y}
+// (config/navigation1.py:90-96: logvar soft-clamped between min_logvar and max_logvar; sd = sqrt(exp(logvar)))
+__device__ __forceinline__ f32x4 e_value(const PlanLds& L, const float* __restrict__ epk, const float* __restrict__ g,
+                                         int row) {
+    float out[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        out[o] = epk[kEB3 + o] +
+                 ((L.epart[0][row][o] + L.epart[1][row][o]) + (L.epart[2][row][o] + L.epart[3][row][o]));
+    f32x4 d = {out[0], out[1], 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float lv = out[2 + k];
+        lv = g[8 + k] - softplusf(g[8 + k] - lv);
+        lv = g[10 + k] + softplusf(lv - g[10 + k]);
+        d[2 + k] = sqrtf(expf(lv));
+    }
+    return d;
+}
+
+__device__ __forceinline__ void write_inputs(const PlanLds& L, const float* __restrict__ g, int row, f32x4 x) {
+    *reinterpret_cast<f32x4*>(L.xs + row * 4) = x;
+    f32x4 n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) n[k] = (x[k] - g[k]) / g[4 + k];
+    *reinterpret_cast<f32x4*>(L.xn + row * 4) = n;
+}
+
+// First step of the rollout, once per DISTINCT row.  At t = 0 the npart particles of a candidate share
+// (cur_obs, ac_0) (MPC.py:393-402: cur_obs expanded over nopt * npart rows, ac_seqs tiled over the particles), so
+// Q_risk(cur_obs, ac_0) is one value per candidate and the member's predictive distribution one per (candidate, member);
+// only the noise draw differs between the particles.  A workgroup takes 64 consecutive candidates ("groups") through ONE
+// network: blockIdx = (group block, net), net < n_nets = ensemble member, net == n_nets = the twin Q_risk.  MFMA rows are
+// independent and the phases are the rollout kernel's own code, so every value equals, bit for bit, what each of the
+// particle rows would have computed -- given ONE thing: the member's last layer adds its 13th column tile into strip 0
+// for even row tiles and into strip 1 for odd ones (e_phase), so a row's sum order depends on the parity of its row tile.
+// In the rollout kernel candidate j of a 16-candidate block sits in row tile j / 4; here candidate j of the 64-candidate
+// block goes to row (first_step_row) whose row tile has the same parity, bit 2 of j.
+//   q0[group] = max(sigmoid Q1, sigmoid Q2)(cur_obs, ac_0);  e0[group][e] = {mean dx, mean dy, sd x, sd y}
+__device__ __forceinline__ int first_step_row(int j) {       // bits j5 j4 j3 j2 j1 j0 -> row j5 j2 j4 j3 j1 j0
+    return (j & 3) | (((j >> 3) & 3) << 2) | (((j >> 2) & 1) << 4) | ((j >> 5) << 5);
+}
+
+template <bool F16X3>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(RRL_PLAN_WAVES_PER_EU, RRL_PLAN_WAVES_PER_EU)))
+void plan_first_step_kernel(
+    const float* __restrict__ pk, int n_nets, long long n_groups, int pop, int plan_hor,
+    const float* __restrict__ cur_obs, const float* __restrict__ ac_seqs, float* __restrict__ q0,
+    float* __restrict__ e0, const int32_t* __restrict__ m_dev) {
+    if (m_dev) n_groups = (long long)m_dev[0] * pop;
+    const long long tile = blockIdx.x;
+    const int net = int(tile % (n_nets + 1));
+    const long long gblock = tile / (n_nets + 1);
+    if (gblock * kRows >= n_groups) return;           // device-counted planning set: workgroups past the live rows leave
+    if (net < n_nets && plan_hor == 1) return;        // nothing reads the prediction of the last step (MPC.py:406-412)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const PlanLds L = carve(lds);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* g = pk + glob_off(n_nets);                // mu[4], sigma[4], max_logvar[2], min_logvar[2]
+    const bool owner = tid < kRows;
+    const long long group = gblock * kRows + tid;
+    const int row = first_step_row(tid & (kRows - 1));
+    if (owner) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (group < n_groups) {
+            const long long m = group / pop;
+            x[0] = cur_obs[m * 2];
+            x[1] = cur_obs[m * 2 + 1];
+            x[2] = ac_seqs[group * (plan_hor * 2)];
+            x[3] = ac_seqs[group * (plan_hor * 2) + 1];
+        }
+        write_inputs(L, g, row, x);
+    }
+    __syncthreads();
+    if (net == n_nets) {
+        q_phase<F16X3>(L, pk, wave, lane);
+        if (owner && group < n_groups) q0[group] = q_value(L, pk, row);
+    } else {
+        const float* epk = pk + e_off(net);
+        e_phase<F16X3>(L, epk, wave, lane, tid);
+        if (owner && group < n_groups)
+            *reinterpret_cast<f32x4*>(e0 + (group * n_nets + net) * 4) = e_value(L, epk, g, row);
+    }
+}
+
+// Steps 1 .. plan_hor - 1 for every particle row, starting from the first step's values (plan_first_step_kernel) and this
+// row's own noise draw.  The ensemble phase of the LAST step is not run: its prediction would only become a cur_obs that
+// nothing reads (MPC.py:406-412).
+template <bool F16X3>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(RRL_PLAN_WAVES_PER_EU, RRL_PLAN_WAVES_PER_EU)))
+void plan_cost_kernel(
+    const float* __restrict__ pk, int n_nets, int npart, long long n_groups, int pop, int plan_hor,
+    const float* __restrict__ cur_obs, const float* __restrict__ ac_seqs, const float* __restrict__ noise,
+    uint64_t seed, uint64_t counter, const uint64_t* __restrict__ counter_dev, const float* __restrict__ q0,
+    const float* __restrict__ e0, float* __restrict__ partial, const int32_t* __restrict__ m_dev) {
+    if (m_dev) {
+        // the number of planning problems was decided on the device (rrl_cem_begin): the grid covers the launch bound,
+        // workgroups past the live tiles leave before they touch anything
+        n_groups = (long long)m_dev[0] * pop;
+        if ((long long)blockIdx.x >= ((n_groups + 15) / 16) * n_nets) return;
+    }
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const PlanLds L = carve(lds);
+    float* rowstate = L.rowstate;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile indices live in SGPRs
+    const long long tile = blockIdx.x;
+    const int e = int(tile % n_nets);
+    const long long gblock = tile / n_nets;
+    const int ppn = npart / n_nets;                       // particles per net (4)
+    const uint64_t ctr = rrl::effective_counter(counter, counter_dev);
+    const long long nrows = n_groups * npart;
+
+    // the particle noise of step t for one row (explicit array, or Philox: stream RRL_STREAM_PLAN, row, tick * 16 + t)
+    const auto draw = [&](int t, long long row_global, float& z0, float& z1) {
+        if (noise) {
+            z0 = noise[((long long)t * nrows + row_global) * 2];
+            z1 = noise[((long long)t * nrows + row_global) * 2 + 1];
+        } else {
+            double d0, d1;
+            rrl::normal_at(seed, uint32_t(row_global), rrl::kStreamPlan, ctr * 16 + uint64_t(t), d0, d1);
+            z0 = float(d0);
+            z1 = float(d1);
+        }
+    };
+
+    // one thread per row advances the row's rollout state, which lives in LDS between the steps (registers that stay
+    // live across the matrix phases are what the 128-VGPR budget of two workgroups per CU is short of)
+    const bool owner = tid < kRows;
+    const float* epk = pk + e_off(e);
+    const float* g = pk + glob_off(n_nets);                // mu[4], sigma[4], max_logvar[2], min_logvar[2]
+    if (owner) {
+        // step 0: cost = Q_risk(cur_obs, ac_0); obs_1 = cur_obs + (mean + z sd) (obs_postproc: obs + prediction, :131-133)
+        const long long group = gblock * 16 + (tid >> 2);
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+        if (group < n_groups) {
+            const long long m = group / pop;
+            st[0] = cur_obs[m * 2];
+            st[1] = cur_obs[m * 2 + 1];
+            st[2] = q0[group];
+            if (plan_hor > 1) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(e0 + (group * n_nets + e) * 4);
+                float z0, z1;
+                draw(0, group * npart + e * ppn + (tid & 3), z0, z1);
+                st[0] = st[0] + (d[0] + z0 * d[2]);
+                st[1] = st[1] + (d[1] + z1 * d[3]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(rowstate + tid * 4) = st;
+    }
+
+    const int order = __builtin_amdgcn_readfirstlane(int(blockIdx.x >> 8) & 1);
+
+    for (int t = 1; t < plan_hor; ++t) {
+        if (owner) {
+            const int otid = opaque(tid);        // keeps the 64-bit row addresses out of the loop-invariant (spilled) set
+            const long long group = gblock * 16 + (otid >> 2);
+            float ax = 0.f, ay = 0.f;
+            if (group < n_groups) {
+                ax = ac_seqs[group * (plan_hor * 2) + 2 * t];
+                ay = ac_seqs[group * (plan_hor * 2) + 2 * t + 1];
+            }
+            write_inputs(L, g, tid, f32x4{rowstate[tid * 4], rowstate[tid * 4 + 1], ax, ay});
+        }
+        __syncthreads();
+        const bool predict = t + 1 < plan_hor;
+
+        // The two networks read the same (obs, ac) and are independent, so their order is free.  Workgroups that
+        // share a CU (dispatch slots alternate every 256 workgroups: 8 XCDs x 32 CUs) run them in opposite order,
+        // which keeps one of them in a matrix phase while the other is in an epilogue or at a barrier.
+#pragma unroll 1
+        for (int phase = 0; phase < 2; ++phase) {
+            if ((phase ^ order) == 0) q_phase<F16X3>(L, pk, wave, lane);
+            else if (predict) e_phase<F16X3>(L, epk, wave, lane, tid);
         }
 
         // ---- per-row tail: cost, predictive distribution, next observation ----
         if (owner) {
-            float q[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float v = pk[h * kQSize + kQB3];
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) v += qpart[h][w][tid];
-                q[h] = sigmoidf(v);
-            }
             const int otid = opaque(tid);
             const long long group = gblock * 16 + (otid >> 2);
-            const bool live = group < n_groups;
-            const long long row_global = group * npart + e * ppn + (otid & 3);
             f32x4 st = *reinterpret_cast<f32x4*>(rowstate + tid * 4);
-            st[2] += (q[0] > q[1] || q[0] != q[0]) ? q[0] : q[1];      // torch.max: NaN propagates
-            float out[4];
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-                out[o] = epk[kEB3 + o] + ((epart[0][tid][o] + epart[1][tid][o]) + (epart[2][tid][o] + epart[3][tid][o]));
-            float z0 = 0.f, z1 = 0.f;
-            if (live) {
-                if (noise) {
-                    const long long nrows = n_groups * npart;
-                    z0 = noise[((long long)t * nrows + row_global) * 2];
-                    z1 = noise[((long long)t * nrows + row_global) * 2 + 1];
-                } else {
-                    double d0, d1;
-                    rrl::normal_at(seed, uint32_t(row_global), rrl::kStreamPlan, ctr * 16 + uint64_t(t), d0, d1);
-                    z0 = float(d0);
-                    z1 = float(d1);
-                }
+            st[2] += q_value(L, pk, tid);
+            if (predict) {
+                const f32x4 d = e_value(L, epk, g, tid);
+                float z0 = 0.f, z1 = 0.f;
+                if (group < n_groups) draw(t, group * npart + e * ppn + (otid & 3), z0, z1);
+                st[0] = st[0] + (d[0] + z0 * d[2]);
+                st[1] = st[1] + (d[1] + z1 * d[3]);
             }
-            float sd[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {          // config/navigation1.py:90-96
-                float lv = out[2 + k];
-                lv = g[8 + k] - softplusf(g[8 + k] - lv);
-                lv = g[10 + k] + softplusf(lv - g[10 + k]);
-                sd[k] = sqrtf(expf(lv));
-            }
-            st[0] = st[0] + (out[0] + z0 * sd[0]);  // obs_postproc: obs + prediction (:131-133)
-            st[1] = st[1] + (out[1] + z1 * sd[1]);
             *reinterpret_cast<f32x4*>(rowstate + tid * 4) = st;
         }
         // xs / xn are rewritten by the owners only after every wave passed the barriers above
@@ -693,35 +814,52 @@ int rrl_plan_pack_f16x3(const rrl_plan_weights_t* w, float* packed, void* stream
     return plan_pack_impl(w, packed, stream, true);
 }
 
+long long rrl_plan_scratch_floats(int n_nets, long long M, int pop) {
+    if (n_nets <= 0 || M <= 0 || pop <= 0) return RRL_EINVAL;
+    return M * pop * (5LL * n_nets + 1);
+}
+
 static int plan_cost_impl(bool f16x3, const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop,
                           int plan_hor, const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed,
-                          uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs,
+                          uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* scratch, float* costs,
                           void* stream_, const int32_t* m_dev = nullptr) {
-    if (!packed || !cur_obs || !ac_seqs || !partial || !costs || M <= 0 || pop <= 0 || plan_hor <= 0 ||
+    if (!packed || !cur_obs || !ac_seqs || !scratch || !costs || M <= 0 || pop <= 0 || plan_hor <= 0 ||
         plan_hor > 16 || !rrl_plan_supported(hq, he, n_nets, npart, 2, 2))
         return RRL_EINVAL;
     const long long n_groups = M * pop;
     if (n_groups * npart >= (1LL << 32)) return RRL_EINVAL;      // Philox row index is 32 bits
     const long long tiles = ((n_groups + 15) / 16) * n_nets;
+    const long long first_tiles = ((n_groups + kRows - 1) / kRows) * (n_nets + 1);
     if (tiles >= (1LL << 31)) return RRL_EINVAL;
+    // scratch (rrl_plan_scratch_floats): e0 [n_groups][n_nets][4] | partial [n_groups][n_nets] | q0 [n_groups]
+    float* e0 = scratch;
+    float* partial = e0 + n_groups * n_nets * 4;
+    float* q0 = partial + n_groups * n_nets;
     hipStream_t st = (hipStream_t)stream_;
     static bool lds_set = false;
     if (!lds_set) {       // > 64 KB of LDS has to be granted explicitly
-        if (hipFuncSetAttribute((const void*)plan_cost_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kLdsBytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)plan_cost_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kLdsBytes) != hipSuccess) {
-            last_hip_error = int(hipGetLastError());
-            return RRL_ELAUNCH;
-        }
+        const void* kernels[4] = {(const void*)plan_cost_kernel<false>, (const void*)plan_cost_kernel<true>,
+                                  (const void*)plan_first_step_kernel<false>, (const void*)plan_first_step_kernel<true>};
+        for (const void* k : kernels)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) {
+                last_hip_error = int(hipGetLastError());
+                return RRL_ELAUNCH;
+            }
         lds_set = true;
     }
-    if (f16x3)
+    if (f16x3) {
+        hipLaunchKernelGGL(plan_first_step_kernel<true>, dim3((unsigned)first_tiles), dim3(kThreads), kLdsBytes, st, packed,
+                           n_nets, n_groups, pop, plan_hor, cur_obs, ac_seqs, q0, e0, m_dev);
         hipLaunchKernelGGL(plan_cost_kernel<true>, dim3((unsigned)tiles), dim3(kThreads), kLdsBytes, st, packed, n_nets,
-                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial, m_dev);
-    else
+                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, q0, e0,
+                           partial, m_dev);
+    } else {
+        hipLaunchKernelGGL(plan_first_step_kernel<false>, dim3((unsigned)first_tiles), dim3(kThreads), kLdsBytes, st, packed,
+                           n_nets, n_groups, pop, plan_hor, cur_obs, ac_seqs, q0, e0, m_dev);
         hipLaunchKernelGGL(plan_cost_kernel<false>, dim3((unsigned)tiles), dim3(kThreads), kLdsBytes, st, packed, n_nets,
-                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, partial, m_dev);
+                           npart, n_groups, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter, counter_dev, q0, e0,
+                           partial, m_dev);
+    }
     hipLaunchKernelGGL(plan_finish_kernel, dim3(grid_for(n_groups)), dim3(kBlock), 0, st, n_groups, n_nets, npart,
                        partial, costs, counter_dev, counter_inc, m_dev, pop);
     return check_launch();
@@ -729,25 +867,25 @@ static int plan_cost_impl(bool f16x3, const float* packed, int hq, int he, int n
 
 int rrl_plan_cost(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
                   const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
-                  uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream) {
+                  uint64_t* counter_dev, uint64_t counter_inc, float* scratch, float* costs, void* stream) {
     return plan_cost_impl(false, packed, hq, he, n_nets, npart, M, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter,
-                          counter_dev, counter_inc, partial, costs, stream);
+                          counter_dev, counter_inc, scratch, costs, stream);
 }
 
 int rrl_plan_cost_f16x3(const float* packed, int hq, int he, int n_nets, int npart, long long M, int pop, int plan_hor,
                         const float* cur_obs, const float* ac_seqs, const float* noise, uint64_t seed, uint64_t counter,
-                        uint64_t* counter_dev, uint64_t counter_inc, float* partial, float* costs, void* stream) {
+                        uint64_t* counter_dev, uint64_t counter_inc, float* scratch, float* costs, void* stream) {
     return plan_cost_impl(true, packed, hq, he, n_nets, npart, M, pop, plan_hor, cur_obs, ac_seqs, noise, seed, counter,
-                          counter_dev, counter_inc, partial, costs, stream);
+                          counter_dev, counter_inc, scratch, costs, stream);
 }
 
 int rrl_plan_cost_n(int f16x3, const float* packed, int hq, int he, int n_nets, int npart, const int32_t* m_dev,
                     long long m_max, int pop, int plan_hor, const float* cur_obs, const float* ac_seqs, const float* noise,
-                    uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* partial,
+                    uint64_t seed, uint64_t counter, uint64_t* counter_dev, uint64_t counter_inc, float* scratch,
                     float* costs, void* stream) {
     if (!m_dev) return RRL_EINVAL;
     return plan_cost_impl(f16x3 != 0, packed, hq, he, n_nets, npart, m_max, pop, plan_hor, cur_obs, ac_seqs, noise, seed,
-                          counter, counter_dev, counter_inc, partial, costs, stream, m_dev);
+                          counter, counter_dev, counter_inc, scratch, costs, stream, m_dev);
 }
 
 }  // extern "C"

@@ -29,7 +29,7 @@ class FusedPlanner:
         self.packed = torch.zeros(int(n), dtype=torch.float32, device=self.device)
         self.tick = torch.zeros(2, dtype=torch.int64, device=self.device)
         self.seed = (int(mpc.optimizer.seed) ^ 0x706C616E) & 0xFFFFFFFFFFFFFFFF
-        self._partial = None
+        self._scratch = None
 
     @staticmethod
     def supported(mpc):
@@ -56,6 +56,14 @@ class FusedPlanner:
         _lib.check(pack(C.byref(w), _lib.ptr(self.packed), _lib.current_stream()), "rrl_plan_pack")
         self._keep = keep + ens        # the pack kernels read them asynchronously
 
+    def _scratch_for(self, M, pop):
+        """First-step values + per-member cost sums of M planning problems (rrl_plan_scratch_floats); grows, never shrinks
+        (a captured graph holds its address)."""
+        need = int(self.lib.rrl_plan_scratch_floats(self.n_nets, M, pop))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+        return self._scratch
+
     def cost(self, ac_seqs, cur_obs, noise=None):
         """ac_seqs [M, pop, plan_hor*2], cur_obs [M, 2] -> costs [M, pop] (f32)."""
         mpc = self.mpc
@@ -65,14 +73,12 @@ class FusedPlanner:
         if noise is not None:
             noise = noise.to(torch.float32).contiguous()
             assert tuple(noise.shape) == (mpc.plan_hor, M * pop * mpc.npart, 2)
-        need = M * pop * self.n_nets
-        if self._partial is None or self._partial.numel() < need:
-            self._partial = torch.empty(need, dtype=torch.float32, device=self.device)
+        scratch = self._scratch_for(M, pop)
         costs = torch.empty(M, pop, dtype=torch.float32, device=self.device)
         entry = self.lib.rrl_plan_cost_f16x3 if self.f16x3 else self.lib.rrl_plan_cost
         rc = entry(_lib.ptr(self.packed), self.hq, self.he, self.n_nets, mpc.npart, M, pop,
                                     mpc.plan_hor, _lib.ptr(cur_obs), _lib.ptr(ac_seqs), _lib.ptr(noise), self.seed, 0,
-                                    _lib.ptr(self.tick), 1, _lib.ptr(self._partial), _lib.ptr(costs),
+                                    _lib.ptr(self.tick), 1, _lib.ptr(scratch), _lib.ptr(costs),
                                     _lib.current_stream())
         _lib.check(rc, "rrl_plan_cost")
         return costs
@@ -82,12 +88,10 @@ class FusedPlanner:
         synchronisation, the launch covers ws.m_max problems and the workgroups past the live ones exit at once."""
         mpc = self.mpc
         pop = int(ws.samples.shape[1])
-        need = ws.m_max * pop * self.n_nets
-        if self._partial is None or self._partial.numel() < need:
-            self._partial = torch.empty(need, dtype=torch.float32, device=self.device)
+        scratch = self._scratch_for(ws.m_max, pop)
         rc = self.lib.rrl_plan_cost_n(int(self.f16x3), _lib.ptr(self.packed), self.hq, self.he, self.n_nets, mpc.npart,
                                       _lib.ptr(count), ws.m_max, pop, mpc.plan_hor, _lib.ptr(ws.cur_obs),
                                       _lib.ptr(ws.samples), None, self.seed, 0, _lib.ptr(self.tick), 1,
-                                      _lib.ptr(self._partial), _lib.ptr(costs), _lib.current_stream())
+                                      _lib.ptr(scratch), _lib.ptr(costs), _lib.current_stream())
         _lib.check(rc, "rrl_plan_cost_n")
         return costs
