@@ -13,11 +13,12 @@ import random
 import numpy as np
 import torch
 
+from .fast_update import FLAT_NETS as _FLAT_NETS
+
 FORMAT = 1
 
 _ENV_FIELDS = ("pos", "t", "obs", "prev_obs", "next_obs", "reward", "action_clipped", "_flags", "tick")
 _DUALS = ("alpha", "nu", "lambda_RCPO")
-_FLAT_NETS = ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy")
 
 
 def _cpu(t):

@@ -345,6 +345,7 @@ __device__ __forceinline__ void mlp3_fwd_split_body(const StackArgs& a, float* p
         // (56 of 242 us of the packed 16-seed launch, profiles/round5_fwd_packed/).  Workgroup (z, g) = (0, 0) stores
         // action and log-probability for the consumers downstream.  Same formulas, same bits as the kernels of
         // update_kernels.hip.
+        static_assert(R * kStackRows <= 32, "the input head is ONE pass of one wave, a lane per (row, action dimension): 32 rows");
         const rrl_policy_head_t& hd = a.in_head;
         const bool writer = z == 0 && g == 0;
         float* xs = LOOP ? xs_own : h2s;                 // [R * 16][4]

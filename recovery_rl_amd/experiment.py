@@ -433,13 +433,15 @@ MAX_COVER_ROWS = 1 << 28          # 8.6 GB per buffer at 32 B per row: far insid
 ROW_BYTES = 32                    # s, a, s2 f32[2] + r, m f32
 
 
-def cover_rows_limit(device=None):
-    """Rows per buffer the automatic growth of rule 4 may ask for: MAX_COVER_ROWS, and never more than a quarter of the
-    device memory that is free right now for each of the two buffers (the samplers' scratch and the networks need the rest)."""
+def cover_rows_limit(device=None, seeds_per_gpu=1):
+    """Rows per buffer the automatic growth of rule 4 may ask for: MAX_COVER_ROWS, and never more than an eighth of the
+    device's TOTAL memory for each of the two buffers of each seed packed on it (a property of the device and the command
+    line, not of what happens to be free: the same run gets the same capacities on every rank, for every packed seed and
+    on a rerun)."""
     limit = MAX_COVER_ROWS
     if device is not None and torch.cuda.is_available() and torch.device(device).type == "cuda":
-        free, _ = torch.cuda.mem_get_info(torch.device(device))
-        limit = min(limit, int(free // 4 // ROW_BYTES))
+        total = torch.cuda.get_device_properties(torch.device(device)).total_memory
+        limit = min(limit, int(total // 8 // max(int(seeds_per_gpu), 1) // ROW_BYTES))
     return limit
 
 
@@ -457,7 +459,12 @@ def replay_capacities(cfg, device=None):
     n = int(getattr(cfg, "num_envs", 1))
     if n <= 1 or getattr(cfg, "keep_replay_size", False) or cfg.num_steps <= min(cap, safe_cap):
         return cap, safe_cap                 # (the reference's defaults, num_steps == both capacities, stay as they are)
-    steps = int(min(cfg.num_steps, cover_rows_limit(device))) + 2 * n
+    limit = cover_rows_limit(device, getattr(cfg, "seeds_per_gpu", 1))
+    if limit < cfg.num_steps:
+        # the whole-history relation is NOT met: say so where it is decided (and in vector_rules: Experiment.__init__)
+        print("WARNING: vectorisation rule 4 not met: --num_steps %d exceeds the %d rows per buffer this device allows; the "
+              "buffers will wrap and the critics forget the oldest %d env-steps" % (cfg.num_steps, limit, cfg.num_steps - limit))
+    steps = int(min(cfg.num_steps, limit)) + 2 * n
     cap = max(cap, steps)
     safe = steps + int(cfg.num_unsafe_transitions)
     if cfg.pos_fraction >= 0:
@@ -517,7 +524,10 @@ class Experiment:
         self.memory = ReplayMemory(cap, exp_cfg.seed, device=dev)
         self.recovery_memory = ConstraintReplayMemory(safe_cap, exp_cfg.seed, device=dev)
         self.all_ep_data = []
-        self.vector_rules = {"demo_share": 0.0, "pinned_demonstrations": 0, "replay_capacities": (cap, safe_cap)}
+        self.vector_rules = {"demo_share": 0.0, "pinned_demonstrations": 0, "replay_capacities": (cap, safe_cap),
+                             "cover_rows_limit": cover_rows_limit(dev, getattr(exp_cfg, "seeds_per_gpu", 1)),
+                             "buffers_cover_the_run": bool(exp_cfg.num_envs <= 1 or min(cap, safe_cap) >= exp_cfg.num_steps
+                                                           or exp_cfg.pos_fraction >= 0)}
 
         self.total_numsteps = 0
         self.updates = 0
@@ -594,7 +604,8 @@ class Experiment:
         # the rules that change what the critics train on, next to the results they produced: printed, written into
         # run_stats.pkl ("vector_rules") and the checkpoint
         self.vector_rules = {"demo_share": share if share > 0 else 0.0, "pinned_demonstrations": int(pinned),
-                             "replay_capacities": self.vector_rules["replay_capacities"]}
+                             **{k: self.vector_rules[k] for k in ("replay_capacities", "cover_rows_limit",
+                                                                   "buffers_cover_the_run")}}
         if cfg.num_envs > 1:
             print("Q_risk batch: %s (--demo_share; 0 = the reference's single uniform draw, replay_memory.py:54-72)"
                   % ("%d of %d rows from the %d pinned demonstrations, the rest from the online rows"

@@ -40,6 +40,10 @@ def record(kind, *payload):
         _TAPE.append((kind,) + payload)
 
 
+# the FlatNets of a FastUpdater (attribute names): what checkpoints save and what seed packing switches
+FLAT_NETS = ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy")
+
+
 class FlatNet:
     """Flat parameter / gradient / Adam-state storage for one network, plus the layer views."""
 
@@ -108,7 +112,13 @@ class FlatNet:
     def adam(self, lr, target=None, tau=0.0, betas=(0.9, 0.999), eps=1e-8, part=None):
         """`part` = (first_part tensor [T, stride], n_first): the gradients of the leading n_first parameters
         (W1, b1) arrive as T row-tile partials (Stack.backward with fuse_first)."""
-        if part is not None:
+        packed_copy = self.w2p is not None or (target is not None and target.w2p is not None)
+        if part is not None or packed_copy:
+            # with a fragment-order W2 copy the step MUST be the launch that keeps the copy current (own parameters and
+            # Polyak target): a captured iteration re-makes nothing between its launches (w2_packed), so rrl_adam_step
+            # would leave every replayed forward on the W2 of capture time (batch sizes without fuse_first: part = None)
+            if part is None:
+                record("unsupported", "rrl_adam_step_multi without first-layer partials")
             return adam_multi(lr, [(self, target, tau, part)], betas, eps)
         record("unsupported", "rrl_adam_step")
         lib = _lib.load()
@@ -130,6 +140,8 @@ def adam_multi(lr, nets, betas=(0.9, 0.999), eps=1e-8):
         gp, n_part, stride, n_first = (None, 0, 0, 0) if part is None else \
             (part[0].data_ptr(), part[0].shape[0], part[0].stride(0), part[1])
         pack = net.w2p is not None and (target is None or target.w2p is not None)
+        if not pack and (net.w2p is not None or (target is not None and target.w2p is not None)):
+            raise _lib.RRLError("a network and its Polyak target must both keep the fragment-order W2 copy, or neither")
         segs[k] = _lib.rrl_adam_seg_t(net.flat.numel(), net.flat.data_ptr(), net.grad.data_ptr(), net.m.data_ptr(),
                                       net.v.data_ptr(), net.step.data_ptr(),
                                       None if target is None else target.flat.data_ptr(), tau, 0.0, None,

@@ -17,6 +17,7 @@ import torch
 
 from . import _lib
 from . import fast_update
+from .fast_update import FLAT_NETS
 
 
 class PackedLoop:
@@ -40,12 +41,16 @@ class PackedLoop:
         # the fragment-order copy of W2 (FlatNet.w2p) pays up to 8 seeds per GPU: -6.5 / -17 / -10 us per packed iteration at
         # 1 / 4 / 8 seeds; with more, the optimiser launches are bound by L2 / Infinity-Cache bandwidth and the two extra
         # streams they write cost what the forwards gain (16 seeds x 16 updates: 6.58-6.75 against 6.55-6.59 ms)
+        # (switched off on the nets while this packed loop lives -- the recorded descriptors then carry no copy -- and handed
+        # back by close(), so that a loop used solo afterwards has its copy again)
+        self._w2p_taken = []
         if self.S > self.FRAG_MAX_SEEDS:
             for loop in self.loops:
                 fast = getattr(loop.agent, "fast", None)
-                for name in ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy"):
+                for name in FLAT_NETS:
                     net = getattr(fast, name, None)
-                    if net is not None:
+                    if net is not None and net.w2p is not None:
+                        self._w2p_taken.append((net, net.w2p))
                         net.w2p = None
 
     # -- recording -------------------------------------------------------------------------------------------------------
@@ -226,6 +231,9 @@ class PackedLoop:
         call when this was the last packed loop of the process (the cache is shared by all of them)."""
         self.graph = self.graph_many = None
         torch.cuda.synchronize(self.loops[0].device)
+        for net, w2p in self._w2p_taken:       # stale by now: every eager forward re-makes it (FlatNet.w2_packed), and a
+            net.w2p = w2p                      # graph captured from here on starts from an eager iteration's copy
+        self._w2p_taken = []
         return self.lib.rrl_pack_clear()
 
     def read_stats(self):

@@ -39,8 +39,18 @@ def test_bench_and_product_launcher_ask_for_the_same_runtime_mode():
                         "print(json.dumps(runtime.settings()))"], cwd=ROOT, capture_output=True, text=True,
                        env={k: v for k, v in os.environ.items() if "GRAPH_PACKET_CAPTURE" not in k})
     got = json.loads(r.stdout.strip().splitlines()[-1])
-    assert got == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": str(runtime.LAUNCHER_GRAPH_PACKET_CAPTURE), "set_by_launcher": True}, r.stderr
+    measured = runtime.rocm_version() in runtime.MEASURED_ROCM       # the choice is made on the release it was measured on
+    assert got == {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": str(runtime.LAUNCHER_GRAPH_PACKET_CAPTURE) if measured else
+                   "runtime default", "set_by_launcher": measured, "rocm": runtime.rocm_version()}, r.stderr
     assert bench.RUNTIME["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == got["DEBUG_CLR_GRAPH_PACKET_CAPTURE"]
+    # any other release: the launchers leave the runtime default alone; an explicit request is honoured everywhere
+    probe = ("from recovery_rl_amd import runtime; runtime.MEASURED_ROCM = ('0.0',); import json; "
+             "print(json.dumps(runtime.configure(graph_packet_capture=0, log=False)))")
+    for extra, want_set in (({}, False), ({"RRL_GRAPH_PACKET_CAPTURE": "0"}, True)):
+        env = {k: v for k, v in os.environ.items() if "GRAPH_PACKET_CAPTURE" not in k}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", probe], cwd=ROOT, capture_output=True, text=True, env=env)
+        assert json.loads(r.stdout.strip().splitlines()[-1])["set_by_launcher"] is want_set, r.stderr
 
 
 def test_launch_command_is_one_rank_per_gpu_on_localhost():

@@ -458,16 +458,21 @@ def _frag_order(W2):
     return W2.reshape(G, H // 16, 16, H // 16, 4, 4).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)
 
 
-def test_fragment_order_copy_of_w2_follows_the_parameters():
+@pytest.mark.parametrize("batch", (256, 64, 200))
+def test_fragment_order_copy_of_w2_follows_the_parameters(batch):
     """rrl_stack_t.W2p: the forward kernels read W2 a second time in MFMA fragment order.  The copy is made by rrl_w2_pack (every
     eager forward re-makes it: torch code may have written the parameters), kept in step by the fused optimiser launch (own
     parameters AND Polyak target) -- so after eager updates, after graph replays and after a write through the modules the copies
     of all six networks are the permutation of their parameters, and the forward results do not depend on which layout was read."""
     import arg_utils
     import bench
-    cfg = arg_utils.get_args(bench.config_argv("navigation1", 5, 256, 1) + ["--num_unsafe_transitions", "3000"])
+    cfg = arg_utils.get_args(bench.config_argv("navigation1", 5, 256, 1) + ["--num_unsafe_transitions", "3000", "--batch_size",
+                                                                           str(batch)])
     loop = bench.build_loop(cfg, torch.device("cuda:0"), pretrain=10)
     f = loop.agent.fast
+    # batch 64 / 200: the first layer's backward is NOT fused into the hidden-layer launch (grad_part is None), the step is
+    # FlatNet.adam(part=None) -- which must still be the launch that keeps the copies current inside a captured graph
+    assert (f.qr_a.grad_part is not None) == (batch == 256)
     nets = {k: getattr(f, k) for k in ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy")}
     assert all(n.w2p is not None for n in nets.values())
 
