@@ -45,7 +45,29 @@ NAV_STEP_ALGO_BYTES = 39         # algorithmic bytes per
 STEP_PUSH_ALGO_BYTES = 39 + 32 + 32   # + one 32-byte replay row into each of the two buffers (section 8d "replay")
 F32_MFMA_PEAK_TF = 157.3         # MI355X_MICROARCH.md; 155.4 measured on this pool (profiles/mfma_peak.hip)
 F16_MFMA_PEAK_TF = 2500.0                       # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
-PLAN_FLOPS_PER_ROW_STEP = 267264 + 163200      # twin Q_risk (4-256-256-1 x2) + one ensemble member (4-200-200-200-4)
+PLAN_Q_FLOPS, PLAN_E_FLOPS = 267264, 163200     # per row: twin Q_risk (4-256-256-1 x2), one ensemble member (4-200-200-200-4)
+PLAN_FLOPS_PER_ROW_STEP = PLAN_Q_FLOPS + PLAN_E_FLOPS   # the LITERAL loop of MPC.py:404-412: both networks, every row, every step
+
+
+def plan_flops(plans, pop=400, npart=20, nets=5, plan_hor=5):
+    """FLOPs of `plans` evaluations of MPC._compile_cost (one per planning env and CEM iteration): (needed, literal).
+    needed = what the costs depend on and what the kernels execute since round 6: at t = 0 Q_risk once per candidate and each
+    member once per (candidate, member) -- the particles share (cur_obs, ac_0), MPC.py:393-402 --, no prediction at the last
+    step (it feeds a cur_obs nothing reads, :406-412): 12.90 GFLOP at the config-4 shape; literal = every particle row through
+    both networks at every step, as the reference's loop spends them: 17.22 GFLOP."""
+    rows = pop * npart
+    q = PLAN_Q_FLOPS * (pop + rows * (plan_hor - 1))
+    e = PLAN_E_FLOPS * (pop * nets + rows * (plan_hor - 2)) if plan_hor > 1 else 0
+    return plans * float(q + e), plans * float(rows * plan_hor * PLAN_FLOPS_PER_ROW_STEP)
+
+
+def plan_f16_products(plans, pop=400, npart=20, nets=5, plan_hor=5):
+    """f16 MFMA FLOPs the f16x3 kernels execute for `plans` evaluations: three products per hidden-layer product (Q_risk
+    256 x 256 per head, the member's two 200 x 200 layers) on the rows plan_flops counts as needed."""
+    rows = pop * npart
+    q_rows = pop + rows * (plan_hor - 1)
+    e_rows = pop * nets + rows * (plan_hor - 2) if plan_hor > 1 else 0
+    return plans * 3.0 * (2 * 2 * 256 * 256 * q_rows + 2 * 2 * 200 * 200 * e_rows)
 
 CONFIG_ARGV = {
     # configs[1]: scripts/navigation1.sh:7
@@ -382,10 +404,29 @@ def committed_pmc(name, key):
     return None, None
 
 
-# algorithmic FLOPs of one lock-step iteration: SAC update 0.685 GFLOP, Q_risk + recovery
-# update 0.62 GFLOP, acting = per env 2 x (policy 67 072 + twin Q_risk 133 632 + recovery policy 66 560) MAC
-def iteration_flops(num_envs, updates_per_step=1):
-    return updates_per_step * (0.685e9 + 0.62e9) + num_envs * 2.0 * (67072 + 133632 + 66560)
+def iteration_flops(num_envs, updates_per_step=1, batch=256, hidden=256):
+    """MLP FLOPs of one lock-step iteration of config 2: (executed, survey_model).
+    executed = what the iteration's launches compute (2 M K N per product; equals the sum of `roofline_stages` -- checked in
+    tests/test_full_size_gpu.py): per update pair 0.549 + 0.548 GFLOP, acting 2 x (policy 67 072 + twin Q_risk 133 632 +
+    recovery policy 66 560) MAC per env.  survey_model = SURVEY.md section 8(d)'s 0.685 + 0.62 GFLOP per update pair, which
+    prices the reference's literal call list -- including `safety_critic(s, pi)` of recovery_rl/sac.py:216-231, evaluated on
+    every update and used only under the DGD / RCPO / LBAC flags.  This stack does not run that call (nor its backward) when
+    no flag reads it, so the figure the iteration is priced with is `executed`; the other one is kept for comparison."""
+    B, H = batch, hidden
+
+    def fwd(G, M, din, dout):
+        return 2.0 * G * M * (din * H + H * H + H * dout)
+
+    def bwd(G, weights, dout, din):        # dh1 (+ dW2) through the hidden layer, dW3 / dh2 of the head, first-layer partials
+        return 2.0 * G * B * H * H * (2 if weights else 1) + 4.0 * G * B * H * dout + 4.0 * G * B * H * din
+    sac = (fwd(1, 2 * B, 2, 4) + 3 * fwd(2, B, 4, 1)                       # pi(s'), pi(s); Q_t(s', a'), Q(s, a), Q(s, pi)
+           + bwd(2, True, 1, 4) + bwd(2, False, 1, 4) + bwd(1, True, 4, 2))  # critic loss; policy loss through Q; the policy
+    qrisk = (fwd(1, B, 2, 4) + fwd(1, B, 2, 2) + 2 * fwd(2, B, 4, 1)       # pi(s'), rec(s); Qr_t(s', a'), Qr(s, a)
+             + bwd(2, True, 1, 4) + fwd(2, B, 4, 1) + bwd(2, False, 1, 4) + bwd(1, True, 2, 2))
+    acting = fwd(1, num_envs, 2, 4) + fwd(2, num_envs, 4, 1) + fwd(1, num_envs, 2, 2)
+    executed = updates_per_step * (sac + qrisk) + acting
+    survey = updates_per_step * (0.685e9 + 0.62e9) + num_envs * 2.0 * (67072 + 133632 + 66560)
+    return executed, survey
 
 
 def roofline_stages(a, device, iteration_ms):
@@ -429,8 +470,10 @@ def roofline_stages(a, device, iteration_ms):
                 if h.first.x:
                     fl += 4.0 * h.G * h.B * h.H * h.first.din
             policy = any(heads[k].loss.kind > 3 for k in range(n))
+            dout = max(heads[k].dout for k in range(n))
             rows.append(("head + hidden backward x%d (one launch, %s)" % (n, "policy head" if policy else "critic loss"), "backward",
-                         lambda heads=heads, hid=hid, n=n: lib.rrl_mlp_backward_pair_multi(n, heads, hid, st()), fl, None))
+                         lambda heads=heads, hid=hid, n=n: lib.rrl_mlp_backward_pair_multi(n, heads, hid, st()), fl, None,
+                         "backward_pair_kernel<%d>" % dout))
             continue
         if kind == "forward":
             arr, n = op[1], op[2]
@@ -438,13 +481,15 @@ def roofline_stages(a, device, iteration_ms):
             m_max = max(arr[k].M for k in range(n))
             name = "forward x%d (%s rows)" % (n, "/".join(str(arr[k].M) for k in range(n)))
             launch = lambda arr=arr, n=n: lib.rrl_mlp3_forward_multi(n, arr, st())
-            rows.append((name, "acting forward" if m_max > 1024 else "update forward", launch, fl, None))
+            rows.append((name, "acting forward" if m_max > 1024 else "update forward", launch, fl, None,
+                         "mlp3_fwd_split_group_kernel<%d>" % (2 if m_max > 1024 else 1)))
         elif kind == "head_bwd":
             arr, n = op[1], op[2]
             # thin (dout <= 4): a streaming kernel -- h2 read, dh2 written, the stack outputs and W3 read
             by = sum(4.0 * arr[k].G * arr[k].B * (2 * arr[k].H + 4 * arr[k].dout) + 8.0 * arr[k].G * arr[k].H * arr[k].dout
                      for k in range(n))
-            rows.append(("head backward x%d" % n, "head backward", lambda arr=arr, n=n: lib.rrl_mlp_head_backward_multi(n, arr, st()), None, by))
+            rows.append(("head backward x%d" % n, "head backward", lambda arr=arr, n=n: lib.rrl_mlp_head_backward_multi(n, arr, st()), None, by,
+                         "head_bwd_group_kernel"))
         elif kind == "hidden_bwd":
             arr, n = op[1], op[2]
             fl = 0.0
@@ -453,7 +498,8 @@ def roofline_stages(a, device, iteration_ms):
                 fl += 2.0 * h.G * h.B * h.H * h.H * (2 if h.dW2 else 1)           # dh1 (NN) + dW2 (TN)
                 if h.first.x:
                     fl += 4.0 * h.G * h.B * h.H * h.first.din                     # first-layer backward out of the tiles
-            rows.append(("hidden backward x%d" % n, "hidden backward", lambda arr=arr, n=n: lib.rrl_mlp_hidden_backward_multi(n, arr, st()), fl, None))
+            rows.append(("hidden backward x%d" % n, "hidden backward", lambda arr=arr, n=n: lib.rrl_mlp_hidden_backward_multi(n, arr, st()), fl, None,
+                         "gemm16_group_kernel"))
         elif kind == "adam":
             segs, n, lr, b1, b2, eps = op[1:7]
             by = 0.0
@@ -461,28 +507,29 @@ def roofline_stages(a, device, iteration_ms):
                 sgm = segs[k]
                 by += 4.0 * sgm.n * (7 + (2 if sgm.target else 0)) + 4.0 * sgm.n_part * sgm.part_elems
             rows.append(("Adam x%d" % n, "optimiser", lambda segs=segs, n=n, lr=lr, b1=b1, b2=b2, eps=eps:
-                         lib.rrl_adam_step_multi(n, segs, lr, b1, b2, eps, st()), None, by))
+                         lib.rrl_adam_step_multi(n, segs, lr, b1, b2, eps, st()), None, by, "adam_multi_kernel"))
         elif kind == "sample":
             g = op[1]
             by = 2 * cfg.batch_size * (32 + 32 + 3 * 16) + 8.0 * g.noise_pairs
             launch = lambda g=g: lib.rrl_sample_multi(g.first, g.second, g.noise_pairs, g.noise_seed, g.noise_counter,
                                                       g.noise_counter_dev, g.noise_counter_inc, g.noise_out, st())
-            rows.append(("replay draws x2 + policy noise", "replay draw", launch, None, by))
+            rows.append(("replay draws x2 + policy noise", "replay draw", launch, None, by, "sample_group_kernel"))
         elif kind == "step":
             env_name, env_kind, sa = op[1], op[2], op[3]
             launch = (lambda sa=sa: lib.rrl_maze_step_push_x(C.byref(sa), st())) if env_name == "maze" else \
                 (lambda sa=sa, env_kind=env_kind: lib.rrl_nav_step_push_x(env_kind, C.byref(sa), st()))
             rows.append(("env step + 2 replay pushes + episode table", "env step", launch, None,
-                         float(a.num_envs) * STEP_PUSH_ALGO_BYTES))
+                         float(a.num_envs) * STEP_PUSH_ALGO_BYTES, "step_push_kernel"))
         else:
-            rows.append((kind, kind, None, None, None))
+            rows.append((kind, kind, None, None, None, kind))
     out, total = [], 0.0
-    for name, group, launch, fl, by in rows:
+    for name, group, launch, fl, by, kernel in rows:
         if launch is None:
             continue
         t = _graph_of(launch, 50, device)
         total += t
-        r = {"stage": name, "group": group, "us": t * 1e6, "launches": 2 if name.endswith("(two launches)") else 1}
+        r = {"stage": name, "group": group, "kernel": kernel, "us": t * 1e6,
+             "launches": 2 if name.endswith("(two launches)") else 1}
         if fl is not None:
             r.update(bound="mfma", flops=fl, achieved_TFLOPs=fl / t / 1e12, frac=fl / t / 1e12 / F32_MFMA_PEAK_TF)
         else:
@@ -503,7 +550,27 @@ def roofline_stages(a, device, iteration_ms):
         else:
             row.update(bound="hbm", frac=gs["bytes"] / (gs["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
         summary.append(row)
+    # per KERNEL (the granularity of a rocprofv3 --stats table): the one with the most time is the line's `roofline.dominant`
+    kernels = {}
+    for r in out:
+        ks = kernels.setdefault(r["kernel"], {"kernel": r["kernel"], "launches": 0, "us": 0.0, "flops": 0.0, "bytes": 0.0})
+        ks["launches"] += r["launches"]
+        ks["us"] += r["us"]
+        ks["flops"] += r.get("flops", 0.0)
+        ks["bytes"] += r.get("bytes", 0.0)
+    by_kernel = []
+    for ks in sorted(kernels.values(), key=lambda k: -k["us"]):
+        row = {"kernel": ks["kernel"], "launches": ks["launches"], "us": ks["us"], "avg_us": ks["us"] / ks["launches"],
+               "share_of_stand_alone_sum": ks["us"] / (total * 1e6)}
+        if ks["flops"]:
+            tf = ks["flops"] / (ks["us"] * 1e-6) / 1e12
+            row.update(bound="mfma", flops=ks["flops"], achieved=tf, peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", frac=tf / F32_MFMA_PEAK_TF)
+        else:
+            gb = ks["bytes"] / (ks["us"] * 1e-6) / 1e9
+            row.update(bound="hbm", bytes=ks["bytes"], achieved=gb, peak=HBM_PEAK_GBS, unit="GB/s", frac=gb / HBM_PEAK_GBS)
+        by_kernel.append(row)
     return {"launches": sum(r["launches"] for r in out), "stand_alone_sum_us": total * 1e6, "iteration_us": iteration_ms * 1e3,
+            "mlp_flops": sum(r.get("flops", 0.0) for r in out), "by_kernel": by_kernel,
             "method": "each recorded launch of one iteration re-issued 50x back to back in its own graph, HIP events on the "
                       "launch stream; FLOPs / bytes are algorithmic (2 M K N per product; parameter + state bytes for Adam)",
             "dominant": summary[0]["group"], "by_group": summary, "stages": out}
@@ -826,23 +893,31 @@ def run_config4_leg(device, precision, num_envs=NUM_ENVS, iters=30, graph=True):
     assert stats1["env_steps"] - stats0["env_steps"] == iters * num_envs
     assert stats1["recovery_steps"] - stats0["recovery_steps"] == sum(sizes), (stats1["recovery_steps"], sum(sizes))
     row_steps = sum(sizes) * mpc.optimizer.popsize * mpc.npart * mpc.plan_hor * mpc.optimizer.max_iters
+    plans = sum(sizes) * mpc.optimizer.max_iters          # evaluations of _compile_cost: one per planning env and CEM iteration
+    shape = dict(pop=mpc.optimizer.popsize, npart=mpc.npart, nets=mpc.model.num_nets, plan_hor=mpc.plan_hor)
+    needed, literal = plan_flops(plans, **shape)
+    t_ev = ev0.elapsed_time(ev1) * 1e-3
+    peak = F32_MFMA_PEAK_TF if precision == "f32" else F16_MFMA_PEAK_TF
+    executed = needed if precision == "f32" else plan_f16_products(plans, **shape)
     return {"workload": "Navigation2, %d envs, model-based recovery (scripts/navigation2.sh:14 + --num_envs %d), "
                         "pre-trained gate, planner kernel %s" % (num_envs, num_envs, precision),
             "iterations": iters, "timed_seconds": dt, "ms_per_step": dt / iters * 1e3,
             "env_steps_per_s": iters * num_envs / dt, "grad_steps_per_s": iters / dt,
             "recovery_set_sizes": sizes, "planned_actions": sum(sizes),
             "planner_row_steps_per_s": row_steps / dt,
-            "planner_TFLOPs_over_whole_iteration": row_steps * PLAN_FLOPS_PER_ROW_STEP / dt / 1e12,
+            "planner_TFLOPs_over_whole_iteration": needed / dt / 1e12,
             "pretrain_seconds": pre_s, "graph": graph,
-            # the planner's algorithmic FLOPs over the WHOLE iteration's time (HIP events around the timed iterations on the
-            # launch stream): a lower bound of the planner kernel's own rate (the updates and the env step are in the time)
-            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "kernel": "plan_cost_kernel inside the lock-step iteration",
-                         "achieved": row_steps * PLAN_FLOPS_PER_ROW_STEP / (ev0.elapsed_time(ev1) * 1e-3) / 1e12,
-                         "peak": F32_MFMA_PEAK_TF if precision == "f32" else F16_MFMA_PEAK_TF,
-                         "frac": (row_steps * PLAN_FLOPS_PER_ROW_STEP * (1.0 if precision == "f32" else 3.0 * (2 * 2 * 256 * 256 + 2 * 2 * 200 * 200) / PLAN_FLOPS_PER_ROW_STEP)
-                                  / (ev0.elapsed_time(ev1) * 1e-3) / 1e12) / (F32_MFMA_PEAK_TF if precision == "f32" else F16_MFMA_PEAK_TF),
-                         "note": "f32: algorithmic FLOPs / f32 MFMA peak; f16x3: executed f16 products (3 per hidden-layer product) / "
-                                 "f16 MFMA peak; time = the whole iteration"},
+            # the planner's NEEDED FLOPs (plan_flops) over the WHOLE iteration's time (HIP events around the timed iterations on
+            # the launch stream): a lower bound of the planner kernels' own rate (the updates and the env step are in the time)
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s",
+                         "kernel": "plan_first_step_kernel + plan_cost_kernel inside the lock-step iteration",
+                         "achieved": needed / t_ev / 1e12, "peak": peak, "frac": executed / t_ev / 1e12 / peak,
+                         "literal_rollout_TFLOPs": literal / t_ev / 1e12,
+                         "note": "f32: needed FLOPs (12.90 GFLOP per planning env and CEM iteration: first step once per "
+                                 "distinct row, no prediction at the last step) / f32 MFMA peak; f16x3: executed f16 products (3 "
+                                 "per hidden-layer product) / f16 MFMA peak; time = the whole iteration.  literal_rollout_TFLOPs "
+                                 "prices the same time with the 17.22 GFLOP of the reference's literal loop (the figure of "
+                                 "rounds 1-5), for comparison only"},
             "host_syncs_per_iteration": 0 if mpc.device_count else 1}
 
 
@@ -1029,29 +1104,35 @@ def main():
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):       # the controller announces itself: stdout carries the JSON line only
                 t_p, row_steps = time_planner_kernel(device)
-            tf = row_steps * PLAN_FLOPS_PER_ROW_STEP / t_p / 1e12
+            plans = row_steps // (400 * 20 * 5)               # time_planner_kernel: n_plans evaluations at the config-4 shape
+            needed, literal = plan_flops(plans)
+            tf = needed / t_p / 1e12
             extra["roofline_planner"] = {
-                "kernel": "plan_cost_kernel (rrl_plan_cost, model-based recovery of config 4)", "bound": "mfma",
-                "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
+                "kernel": "plan_first_step_kernel + plan_cost_kernel (rrl_plan_cost, model-based recovery of config 4)",
+                "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
                 "traffic": committed_pmc("planner_traffic", 256)[0],
                 "traffic_source": committed_pmc("planner_traffic", 256)[1], "launch_ms": t_p * 1e3,
-                "row_steps_per_s": row_steps / t_p,
-                "note": "f32-in/f32-acc MFMA (exact f32); algorithmic %d FLOP per particle-step"
+                "row_steps_per_s": row_steps / t_p, "needed_GFLOP_per_plan": needed / plans / 1e9,
+                "literal_GFLOP_per_plan": literal / plans / 1e9, "literal_rollout_TFLOPs": literal / t_p / 1e12,
+                "note": "f32-in/f32-acc MFMA (exact f32); priced with the NEEDED FLOPs of MPC._compile_cost (first step once "
+                        "per candidate / per (candidate, member), no prediction at the last step: what the kernels execute "
+                        "since round 6); literal_rollout_TFLOPs = the same time priced with every particle row through both "
+                        "networks at every step (%d FLOP per particle-step, the figure of rounds 1-5), for comparison only"
                         % PLAN_FLOPS_PER_ROW_STEP}
             with contextlib.redirect_stdout(sys.stderr):
                 t_h, row_steps = time_planner_kernel(device, precision="f16x3")
-            tf_h = row_steps * PLAN_FLOPS_PER_ROW_STEP / t_h / 1e12
+            tf_h = needed / t_h / 1e12
             # three f16 products per algorithmic product: the matrix pipe executes 3x the algorithmic flops of the hidden
             # layers, priced against the dense f16 MFMA peak
-            hidden = 2 * 2 * 256 * 256 + 2 * 2 * 200 * 200
+            f16 = plan_f16_products(plans)
             extra["roofline_planner_f16x3"] = {
-                "kernel": "plan_cost_kernel<f16x3> (rrl_plan_cost_f16x3, opt-in --plan_precision f16x3): hidden layers as "
-                          "three v_mfma_f32_16x16x32_f16 products of hi/lo splits",
-                "bound": "mfma", "achieved": tf_h, "unit": "TFLOP/s (algorithmic f32-equivalent)",
+                "kernel": "plan_first_step_kernel<f16x3> + plan_cost_kernel<f16x3> (rrl_plan_cost_f16x3, opt-in --plan_precision "
+                          "f16x3): hidden layers as three v_mfma_f32_16x16x32_f16 products of hi/lo splits",
+                "bound": "mfma", "achieved": tf_h, "unit": "TFLOP/s (needed, f32-equivalent)",
                 "vs_f32_mfma_peak": tf_h / F32_MFMA_PEAK_TF, "launch_ms": t_h * 1e3, "row_steps_per_s": row_steps / t_h,
                 "speedup_vs_f32_kernel": t_p / t_h,
-                "executed_f16_TFLOPs": row_steps * (3 * hidden) / t_h / 1e12, "peak": F16_MFMA_PEAK_TF,
-                "frac": row_steps * (3 * hidden) / t_h / 1e12 / F16_MFMA_PEAK_TF,
+                "executed_f16_TFLOPs": f16 / t_h / 1e12, "peak": F16_MFMA_PEAK_TF,
+                "frac": f16 / t_h / 1e12 / F16_MFMA_PEAK_TF,
                 "note": "costs agree with the f32 kernel to < 2e-5 (tests/test_plan_gpu.py); the K=32 f16 MFMA shape sustains 2460 TF on "
                         "this pool (profiles/mfma_f16_rate.hip)"}
         if not a.no_cpu_baseline and world == 1:
@@ -1059,7 +1140,7 @@ def main():
 
     if rank == 0:
         env_rate = agg["env_steps"] / elapsed
-        flops = iteration_flops(a.num_envs, U) * n_steps * world * S
+        flops_exec, flops_survey = (f * n_steps * world * S for f in iteration_flops(a.num_envs, U, cfg.batch_size, cfg.hidden_size))
         label = {"navigation1": "Navigation1", "maze": "Maze"}[a.env]
         out = {
             "metric": "env-steps/sec + SAC grad-steps/sec, Navigation1 4096 envs, 1/2/4/8 GPU",
@@ -1092,12 +1173,23 @@ def main():
             "episodes": agg["episodes"], "violations": agg["num_viols"], "successes": agg["num_successes"],
             # the MLP side of the iteration against the f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
             "roofline_mlp": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TF,
-                             "achieved": flops / elapsed / 1e12,
-                             "frac": flops / elapsed / 1e12 / (F32_MFMA_PEAK_TF * world),
-                             "note": "algorithmic FLOPs of SAC + Q_risk updates (B=256) and acting (N envs) per "
-                                     "iteration / iteration time; tiny problems: launch- and latency-bound"},
+                             "achieved": flops_exec / elapsed / 1e12,
+                             "frac": flops_exec / elapsed / 1e12 / (F32_MFMA_PEAK_TF * world),
+                             "flops_per_iteration": flops_exec / (n_steps * world * S),
+                             "survey_model_frac": flops_survey / elapsed / 1e12 / (F32_MFMA_PEAK_TF * world),
+                             "note": "EXECUTED MLP FLOPs of the iteration (SAC + Q_risk updates at B rows, acting at N envs: "
+                                     "iteration_flops, = the sum of roofline_stages) / iteration time; tiny problems: launch- "
+                                     "and latency-bound.  survey_model_frac prices SURVEY 8(d)'s 0.685 + 0.62 GFLOP per update "
+                                     "pair, which includes the reference's always-evaluated, never-used safety_critic(s, pi) of "
+                                     "recovery_rl/sac.py:216-231 -- a call this stack does not run"},
         }
         out.update(extra)
+        stages = out.get("roofline_stages")
+        if isinstance(stages, dict) and stages.get("by_kernel") and isinstance(out.get("roofline"), dict):
+            # the section-8(d) entry above is the ENV kernel (6 % of the iteration); the kernel with the most time in the
+            # iteration, with its own roof, rides along so that the line names the kernel that matters
+            out["roofline"]["dominant"] = dict(stages["by_kernel"][0], source="roofline_stages.by_kernel (measured in this run: "
+                                               "each recorded launch re-issued 50x in its own graph, HIP events)")
         print(json.dumps(out))
     dist_utils.shutdown()
 

@@ -22,6 +22,7 @@ import itertools
 import os
 import os.path as osp
 import pickle
+import time
 
 import numpy as np
 import torch
@@ -825,6 +826,7 @@ class Experiment:
              for k in dist_utils.METRIC_KEYS}, self.world_size, self.device)
         self._global_offline_viols, self._global_rmem_len = start["num_viols"], start["env_steps"]
         logged = it // log_every
+        t_loop = time.time()                # history entries carry the seconds since here (of THIS process: a resumed run restarts at 0)
         ckpt_every = getattr(cfg, "checkpoint_every", 0)
         ckpt_path = osp.join(self.logdir, "checkpoint.pt")
 
@@ -909,7 +911,7 @@ class Experiment:
                         self._global_rmem_len = dist_utils.aggregate_stats(
                             {k: (len(self.recovery_memory) if k == "env_steps" else 0)
                              for k in dist_utils.METRIC_KEYS}, self.world_size, self.device)["env_steps"]
-                    history.append(dict(stats, iteration=it))
+                    history.append(dict(stats, iteration=it, wall_s=time.time() - t_loop))
                     if self.rank == 0:
                         print("Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(
                             it, agg["env_steps"], agg["episodes"],

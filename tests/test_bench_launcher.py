@@ -326,3 +326,18 @@ def test_bench_gpus_2_default_legs_add_the_packed_leg():
     assert "error" not in leg, leg
     assert leg["seeds_per_gpu"] == 4 and leg["seeds_total"] == 8 and leg["rank0_witness"]["seeds"] == [1, 2, 3, 4]
     assert leg["aggregate_env_steps_per_s"] > 0 and leg["ms_per_packed_iteration"] > 0
+
+
+def test_flop_models_price_what_the_kernels_execute():
+    """iteration_flops: the executed MLP FLOPs of the config-2 iteration (3.287 GFLOP at 4096 envs, U = 1) beside SURVEY 8(d)'s
+    model with the reference's unused safety_critic(s, pi) call; plan_flops: needed (12.90 GFLOP: first step once per distinct
+    row, no prediction at the last step) beside the literal loop's 17.22 GFLOP per planning env and CEM iteration."""
+    executed, survey = bench.iteration_flops(4096, 1)
+    assert abs(executed - 3.287e9) < 1e6 and abs(survey - 3.4944e9) < 1e6
+    e16, s16 = bench.iteration_flops(4096, 16)
+    assert abs((e16 - executed) / 15 - (0.54919e9 + 0.54841e9)) < 1e5 and abs((s16 - survey) / 15 - 1.305e9) < 1e3
+    needed, literal = bench.plan_flops(1)
+    assert abs(needed - 12.9026e9) < 1e5 and literal == 400 * 20 * 5 * 430464
+    assert abs(needed / literal - 0.749) < 1e-3
+    one_step = bench.plan_flops(1, plan_hor=1)                     # a one-step plan: Q_risk on the 400 candidates, nothing else
+    assert one_step[0] == 400 * 267264

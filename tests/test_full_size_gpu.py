@@ -91,3 +91,21 @@ def test_config4_stays_safe_over_1600_iterations_at_4096_envs(tmp_path):
     assert r["violations"] <= 60 and worst <= 0.01, (r["violations"], worst)        # shipped: 0 violations
     assert r["final_success_rate"] > 0.97 and r["first_window_with_90pct_success"]["iteration"] <= 300
     assert r["offline_violations"] > 1000
+
+
+def test_bench_stage_table_prices_the_flops_the_iteration_model_states():
+    """bench.roofline_stages re-issues the recorded launches of ONE config-2 iteration with their algorithmic FLOPs; their sum is
+    what bench.iteration_flops (the figure `roofline_mlp` is priced with) states analytically -- to 1 % --, and every kernel of
+    the timed graph appears in `by_kernel` with a roof."""
+    import argparse
+    import bench
+    a = argparse.Namespace(env="navigation1", num_envs=N)
+    st = bench.roofline_stages(a, torch.device("cuda:0"), 0.15)
+    executed, survey = bench.iteration_flops(N, 1)
+    assert abs(st["mlp_flops"] / executed - 1.0) < 0.01, (st["mlp_flops"], executed)
+    assert survey > executed                                  # the reference's unused safety_critic(s, pi) is not executed
+    names = {k["kernel"] for k in st["by_kernel"]}
+    assert {"backward_pair_kernel<1>", "backward_pair_kernel<4>", "backward_pair_kernel<2>", "adam_multi_kernel",
+            "step_push_kernel", "sample_group_kernel"} <= names
+    assert all(0 < k["frac"] < 1 and k["bound"] in ("mfma", "hbm") for k in st["by_kernel"])
+    assert st["by_kernel"][0]["us"] == max(k["us"] for k in st["by_kernel"])
