@@ -559,6 +559,36 @@ __global__ __launch_bounds__(256, 4) void mlp3_fwd_split_group_kernel(StackGroup
     else mlp3_fwd_split_body<R, 0>(a, partial, bx, rest % G, rest / G, G, lds, h2s);
 }
 
+// Members of very different sizes (round 6: a 4096-row acting forward riding with an update's 256-row forwards) on a FLAT
+// grid of exactly first[n] workgroups, in member order, every member on the tiles of its stand-alone launch (one row tile
+// per workgroup up to kSplitSmallM rows, kBigR above).  On the (largest member, members) grid above the small members'
+// surplus workgroups -- 960 of 1024 -- each took a 35 KB LDS slot for the ~1.5 us their argument batch needs before they can
+// leave: 21.4 us for a launch whose large member alone takes 16.2.  Measured forms (profiles/round6_rider_forms.txt; the
+// three forwards of the acting pass + the two update launches they ride in, 42.9 us as five launches): small members on
+// two-row tiles, small first 41.0 / large first 41.9; small members on one-row tiles, small first 39.0 / LARGE FIRST 37.6
+// (the twin Q_risk at 4096 rows fills the chip's 1024 resident workgroups exactly: what comes behind it starts as its
+// workgroups retire).  The price of the flat grid is the member search in front of the argument batch (one more dependent
+// scalar round trip, ~0.5 us of 10-18).
+__global__ __launch_bounds__(256, 4) void mlp3_fwd_split_flat_group_kernel(StackGroup sg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    arrive_together(sg.first[1], sg.first[2], sg.first[3]);
+    const int x = blockIdx.x;
+    const int k = (x >= sg.first[1]) + (x >= sg.first[2]) + (x >= sg.first[3]);     // first[k + 1] = first[n] past the last member
+    StackArgs a = sg.a[k];
+    float* partial = sg.partial[k];
+    const int G = sg.G[k], tiles = sg.tiles[k];
+    globalize(a);
+    rrl_pack::to_global(partial);
+    arrive_together(a.M, a.H, a.din, a.dout, a.ldx, a.use_in_head, a.in_head.kind, a.in_head.n_part, a.in_head.part_stride,
+                    a.in_head.ld_action, a.in_head.min_log_std, G, tiles);
+    const int local = x - sg.first[k];
+    const int bx = local % tiles, rest = local / tiles;
+    if (a.M <= kSplitSmallM)
+        mlp3_fwd_split_body<1, 256>(a, partial, bx, rest % G, rest / G, G, lds, lds + kStackRows * (kStackMaxH + kSplitPad));
+    else
+        mlp3_fwd_split_body<kBigR, 256>(a, partial, bx, rest % G, rest / G, G, lds, lds);
+}
+
 // the same launch for S seeds (pack.hpp): grid (workgroups of the seeds' largest members under the XCD-aware placement,
 // members) -- blockIdx.y IS the member and the seed follows from blockIdx.x by arithmetic, so the member's argument block
 // sits at an address known at wave start: one batch of scalar loads from the plan's device copy, as in the solo launch
@@ -685,14 +715,29 @@ int rrl_mlp3_forward(int G, int M, int H, int din, int dout, const float* x, int
 
 // Every stack of the group takes the path rrl_mlp3_forward would take for it on its own (so the results are the
 // stand-alone launches', bit for bit); the group must be homogeneous: all split (scratch given, partial sums left in
-// scratch = finalize 0) or all on the same non-split tiling.
+// scratch = finalize 0) or all on the same non-split tiling.  One exception (round 6): small-batch members of hidden width
+// 256 may share a launch with a member on the multi-row tiles (an acting-pass forward riding with an update's forwards,
+// fast_update.FastUpdater.qrisk_update_grouped): path 5, the flat grid on which every member keeps the tiles of its
+// stand-alone launch (mlp3_fwd_split_flat_group_kernel); in a packed launch (flat = false) the small members take the multi-row
+// tiles too (small_r = big_r, as from three seeds on) -- the rows of a tile are independent, the results are the one-row-tile
+// launch's bit for bit.
 static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& path, int big_r = kBigR, int small_r = 1,
-                             int loop_nb = 1) {
+                             int loop_nb = 1, bool flat = true) {
     if (!st || n <= 0 || n > kMaxGroup) return RRL_EINVAL;
     sg = StackGroup{};
     sg.n = n;
     sg.first[0] = 0;
     path = -1;   // 0 split (small batch), 3 split (R = kBigR row tiles); 1 plain R = 1, 2 plain R = 2
+    bool any_big = false, all_split256 = true;
+    for (int k = 0; k < n; ++k) {
+        const bool split = st[k].scratch && rrl_mlp3_is_split(st[k].M, st[k].H);
+        all_split256 = all_split256 && split && st[k].H == 256;
+        any_big = any_big || (split && st[k].H == 256 && st[k].M > kSplitSmallM);
+    }
+    bool any_small = false;
+    for (int k = 0; k < n; ++k) any_small = any_small || st[k].M <= kSplitSmallM;
+    const bool mixed = any_big && any_small && all_split256;
+    if (mixed && !flat) small_r = big_r;              // packed launches: every member on the multi-row tiles
     for (int k = 0; k < n; ++k) {
         const rrl_stack_t& p = st[k];
         const int rc = stack_check(p.G, p.M, p.H, p.din, p.dout, p.x, p.W1, p.b1, p.W2, p.b2, p.W3, p.b3, p.out);
@@ -716,6 +761,7 @@ static int build_stack_group(int n, const rrl_stack_t* st, StackGroup& sg, int& 
             my = (p.M <= kSplitSmallM || p.H != 256) ? 0 : 3;      // the multi-row tiles are built for H = 256
             if (my == 0 && small_r > 1 && p.H != 256) return RRL_EINVAL;
             const int rows = (my == 0 ? small_r : big_r) * kStackRows;
+            if (mixed) my = 5;       // 5 = path 3 on the flat grid (rrl_mlp3_forward_multi; the packed builder reads it as 3)
             sg.tiles[k] = (p.M + rows - 1) / rows;
             sg.nb[k] = loop_nb < sg.tiles[k] ? loop_nb : sg.tiles[k];
             sg.first[k + 1] = sg.first[k] + (sg.tiles[k] + sg.nb[k] - 1) / sg.nb[k] * p.G * kSplit;
@@ -749,6 +795,11 @@ int rrl_mlp3_forward_multi(int n, const rrl_stack_t* st, void* stream) {
         if (!ok) return RRL_ERANGE;
         hipLaunchKernelGGL(mlp3_fwd_split_group_kernel<kBigR>, dim3(most, n), dim3(256),
                            split_lds_floats(kBigR) * 4, s, sg);
+    } else if (path == 5) {
+        constexpr size_t lds_floats = split_lds_floats(kBigR) > split_lds_floats(1) ? split_lds_floats(kBigR) : split_lds_floats(1);
+        static const bool ok = grant_lds((const void*)mlp3_fwd_split_flat_group_kernel, lds_floats * 4);
+        if (!ok) return RRL_ERANGE;
+        hipLaunchKernelGGL(mlp3_fwd_split_flat_group_kernel, dim3(sg.first[n]), dim3(256), lds_floats * 4, s, sg);
     } else if (path == 1) hipLaunchKernelGGL((mlp3_fwd_group_kernel<1>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
     else hipLaunchKernelGGL((mlp3_fwd_group_kernel<2>), dim3(sg.first[n]), dim3(1024), 0, s, sg);
     return check_launch();
@@ -764,7 +815,7 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
         int path;
         const int rc = build_stack_group(n[0], members[0], sg, path);
         if (rc != RRL_OK) return rc;
-        if (path != 0 && path != 3) return RRL_EINVAL;          // the packed entry covers the column-split path only
+        if (path != 0 && path != 3 && path != 5) return RRL_EINVAL;          // the packed entry covers the column-split path only
         return rrl_mlp3_forward_multi(n[0], members[0], stream);
     }
     hipStream_t st = (hipStream_t)stream;
@@ -785,8 +836,9 @@ int rrl_mlp3_forward_multi_packed(int S, const int* n, const rrl_stack_t* const*
             path = -1;
             return build_pack<StackGroup>(S, n, members, groups, ix, [&](int nk, const rrl_stack_t* m, StackGroup& g) {
                 int my;
-                const int r = build_stack_group(nk, m, g, my, big_r, small_r, loop_nb);
+                const int r = build_stack_group(nk, m, g, my, big_r, small_r, loop_nb, false);
                 if (r != RRL_OK) return r;
+                if (my == 5) my = 3;          // mixed members: multi-row tiles for all of them (the placement is the pack's)
                 if ((my != 0 && my != 3) || (path >= 0 && my != path)) return int(RRL_EINVAL);
                 path = my;
                 return int(RRL_OK);

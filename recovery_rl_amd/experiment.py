@@ -71,6 +71,7 @@ class VectorLoop:
         self.host_updates = [0, 0]        # SAC / Q_risk update counts are known on the host
         self._graph_updates = (0, 0)
         self._actor = None
+        self.carry_actor = os.environ.get("RRL_CARRY_ACTOR", "1") != "0"
         self._one = torch.ones((), dtype=torch.int64, device=dev)
         # the random-action phase (experiment.py:559-560) draws from the loop's OWN generator: a seed's trajectory does not
         # depend on what else shares the process (S seeds per GPU, packed.py), only on its seed
@@ -90,8 +91,8 @@ class VectorLoop:
         self.obs = self.env.reset()
         return self.obs
 
-    def do_updates(self, i_episode=1, online_qrisk=True):
-        """experiment.py:397-416.  The caller has checked len(memory) > batch_size."""
+    def do_updates(self, i_episode=1, online_qrisk=True, rider=None):
+        """experiment.py:397-416.  The caller has checked len(memory) > batch_size.  rider: see actor_rider()."""
         cfg = self.cfg
         fast = getattr(self.agent, "fast", None)
         qr = self.agent.safety_critic
@@ -103,7 +104,8 @@ class VectorLoop:
                 # both replay draws + the policy noise in one launch, independent kernels of the two updates grouped
                 # (fast_update.FastUpdater.update_pair): same results as the two calls below, ~30 % fewer launches
                 with trace_range("sample+sac_update+qrisk_update"):
-                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None)
+                    fast.update_pair(self.memory, self.recovery_memory if online_qrisk else None,
+                                     rider=rider if u == cfg.updates_per_step - 1 else None)
                 self.host_updates[0] += 1
                 if online_qrisk:
                     qr.updates += 1
@@ -111,6 +113,7 @@ class VectorLoop:
                     self.host_updates[1] += 1
                 self.updates += 1
                 continue
+            assert rider is None
             with trace_range("sample+sac_update"):
                 self.agent.update_parameters(self.memory, cfg.batch_size, self.updates,
                                              safety_critic=self.agent.safety_critic,
@@ -305,9 +308,27 @@ class VectorLoop:
         return env.obs
 
     # -- whole iteration -----------------------------------------------------------------------
+    def actor_rider(self, do_update, random_actions, online_qrisk):
+        """(FastActor, obs) when the acting pass that follows this iteration's updates can take its task-policy and Q_risk
+        forwards along in the Q_risk update's launches (FastUpdater.qrisk_update_grouped): the grouped fused updates with an
+        online Q_risk update, the fused acting pass with the gate in the step kernel, on the loop's own observations.
+        `carry_actor = False` (or RRL_CARRY_ACTOR=0) keeps the acting pass's own two launches (A/B and the bit-identity test)."""
+        cfg = self.cfg
+        fast = getattr(self.agent, "fast", None)
+        if not (self.carry_actor and do_update and online_qrisk and not random_actions and fast is not None
+                and cfg.use_recovery and cfg.MF_recovery and fast.can_carry_actor() and fast.sync_world == 1
+                and cfg.batch_size == fast.B and hasattr(self.memory, "draw_desc")
+                and self.agent.safety_critic.clamp_batch_size(cfg.batch_size, len(self.recovery_memory)) == fast.B
+                and self.obs is self.env.obs and self.obs.shape[0] == self.n and self._can_fuse_step()):
+            return None
+        if self._actor is None:
+            from .fast_update import FastActor
+            self._actor = FastActor(fast, self.n)
+        return (self._actor, self.obs) if self._actor.qr.split else None
+
     def vector_step(self, do_update=True, random_actions=False, online_qrisk=True, i_episode=1):
         if do_update:
-            self.do_updates(i_episode, online_qrisk)
+            self.do_updates(i_episode, online_qrisk, rider=self.actor_rider(do_update, random_actions, online_qrisk))
         with trace_range("act"):
             action, real_action, recovery = self.act(self.obs, random_actions)
         self._last_recovery, self._last_real_action = recovery, real_action
@@ -826,7 +847,9 @@ class Experiment:
              for k in dist_utils.METRIC_KEYS}, self.world_size, self.device)
         self._global_offline_viols, self._global_rmem_len = start["num_viols"], start["env_steps"]
         logged = it // log_every
-        t_loop = time.time()                # history entries carry the seconds since here (of THIS process: a resumed run restarts at 0)
+        t_loop = time.time()
+        self.log_wall = []                  # (iteration, seconds since here) per log point: this process's clock, kept out of
+                                            # the history (a resumed run's history equals the uninterrupted run's)
         ckpt_every = getattr(cfg, "checkpoint_every", 0)
         ckpt_path = osp.join(self.logdir, "checkpoint.pt")
 
@@ -911,7 +934,8 @@ class Experiment:
                         self._global_rmem_len = dist_utils.aggregate_stats(
                             {k: (len(self.recovery_memory) if k == "env_steps" else 0)
                              for k in dist_utils.METRIC_KEYS}, self.world_size, self.device)["env_steps"]
-                    history.append(dict(stats, iteration=it, wall_s=time.time() - t_loop))
+                    history.append(dict(stats, iteration=it))
+                    self.log_wall.append((it, time.time() - t_loop))
                     if self.rank == 0:
                         print("Iter: {}, total numsteps: {}, episodes: {}, mean episode reward: {}".format(
                             it, agg["env_steps"], agg["episodes"],

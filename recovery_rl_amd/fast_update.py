@@ -618,10 +618,12 @@ class FastUpdater:
                                       p(self.rbias), p(action_view), action_view.stride(0), None, None, None, None,
                                       p(self.recpolicy.p["log_std"]), float(self.qr.policy.min_log_std))
 
-    def update_pair(self, memory, recovery_memory):
+    def update_pair(self, memory, recovery_memory, rider=None):
         """One SAC update and (recovery_memory not None) one Q_risk + recovery-policy update of a lock-step iteration
         (experiment.py:397-416): both replay draws and the iteration's policy noise in ONE launch, then the two
-        updates on the grouped kernels.  Same draws, same arithmetic, same parameters as the separate calls."""
+        updates on the grouped kernels.  Same draws, same arithmetic, same parameters as the separate calls.
+        `rider` = (FastActor, obs): the acting pass that follows this update takes two of its three forwards along in the
+        Q_risk update's launches (FastActor.ride_*; the LAST update pair of an iteration only)."""
         B, qr = self.B, self.qr
         d1, batch = memory.draw_desc(B, rows=self.rows)
         d2 = batch_q = None
@@ -644,7 +646,7 @@ class FastUpdater:
         n = self._noise
         self.sac_update_grouped(batch, n[0], n[1])
         if recovery_memory is not None:
-            self.qrisk_update_grouped(batch_q, n[2], n[3])
+            self.qrisk_update_grouped(batch_q, n[2], n[3], rider=rider)
         return self.losses
 
     def sac_update_grouped(self, batch, eps_next, eps_pi):
@@ -684,10 +686,21 @@ class FastUpdater:
                            (self.policy, None, 0.0, self.pol_b.grad_part)])
         return self.losses
 
-    def qrisk_update_grouped(self, batch, eps_next, eps_pi):
+    def can_carry_actor(self):
+        """The acting pass's task-policy and Q_risk forwards can ride in this update's forward launches (qrisk_update_grouped):
+        model-free recovery, policy heads evaluated by the consuming stacks, every stack on the column-split kernels."""
+        return bool(self.grouped and self.qr.MF_recovery and self.fuse_heads and self.qr_t.split and self.qr_b.split
+                    and self.pol_a.split and self.rec_a.split and self.sync_world == 1)
+
+    def qrisk_update_grouped(self, batch, eps_next, eps_pi, rider=None):
         """qrisk_update with 15 launches instead of 19: the task policy on s' and the recovery policy on s in one
         forward launch (the recovery policy does not depend on the critic step in between), their heads in one, the
-        target and online critics in one."""
+        target and online critics in one.
+        rider = (FastActor, obs) (can_carry_actor()): the acting pass that follows needs the task policy on the N observations
+        -- final since the SAC step -- and Q_risk(obs, a_task) -- final since this update's critic step: the first rides in
+        this update's first forward launch, the second in its forward at the updated critic.  The acting pass is left with
+        the recovery policy's forward (final only after this update's last step): 17 -> 16 launches per iteration, and the
+        two 256-row launches that waited alone on the chip run under the 4096-row ones.  Same kernels, same inputs: same bits."""
         qr, B = self.qr, self.B
         s, a, c, s2, m = batch
         c, m = c.reshape(-1), m.reshape(-1)
@@ -697,6 +710,9 @@ class FastUpdater:
         if mf:
             fwd.append(self.rec_a.forward_desc(xpu[:, 0:2]))
         fuse = self.fuse_heads and self.qr_t.split
+        if rider is not None:
+            assert self.can_carry_actor()
+            fwd.insert(0, rider[0].ride_policy(rider[1]))       # the large member first (mlp_fwd_kernels.hip: measured forms)
         forward_multi(fwd)
         hd_next = self._gauss_desc(self.pol_a.parts, eps_next, x2u[:, 2:4], self.logp2)
         hd_rec = self._stoch_desc(self.rec_a.parts, eps_pi, xpu[:, 2:4]) if mf else None
@@ -715,7 +731,7 @@ class FastUpdater:
             raw, rn, rs = self.rec_a.parts
             ls = self.recpolicy.p["log_std"]
             if hd_rec is not None:         # the recovery action is evaluated by the critic stack that consumes it
-                forward_multi([self.qr_b.forward_desc(xpu, in_head=hd_rec)])
+                forward_multi(([rider[0].ride_qrisk()] if rider else []) + [self.qr_b.forward_desc(xpu, in_head=hd_rec)])
                 zp, n_part, ps = self.qr_b.parts
             else:
                 zp, n_part, ps = self.qr_b.forward(xpu)
@@ -836,6 +852,37 @@ class FastActor:
         self.xa = z(n, 4)                       # [s | a_task]
         self.task_action, self.rec_action, self.real_action = z(n, 2), z(n, 2), z(n, 2)
         self.recovery = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._ride = None
+
+    # -- two of the three forwards of act(defer_select=True) as riders of the Q_risk update's launches -----------------------
+    def ride_policy(self, obs):
+        """rrl_stack_t of the task policy's forward on the acting observations, for a launch the caller issues (any time after
+        the SAC step of this iteration).  Starts a ride: ride_qrisk() and act() complete it."""
+        assert obs.shape[0] == self.n and self.f.can_carry_actor() and self.qr.split
+        self._ride = {"obs": obs, "noise": self.f.actor_noise(self.n), "qrisk": False}
+        return self.pol.forward_desc(obs, save=False)
+
+    def ride_qrisk(self):
+        """rrl_stack_t of Q_risk(obs, a_task) with the task head evaluated by the stack (it stores the action in xa for the
+        step kernel), for a launch the caller issues after the policy rider's launch and the safety critic's step."""
+        f, r = self.f, self._ride
+        task_head = f._gauss_desc(self.pol.parts, r["noise"][0], self.xa[:, 2:4], None, n=self.n, obs_in=r["obs"],
+                                  obs_out=self.xa)
+        self.qr.finalize = False
+        r["qrisk"] = True
+        return self.qr.forward_desc(self.xa, save=False, in_head=task_head)
+
+    def _finish_ride(self, obs, eps_safe):
+        """What is left of act(defer_select=True) after both riders: the recovery policy's forward (its step is the last of
+        the iteration's updates); its head and the gate run in the env-step kernel."""
+        f, r = self.f, self._ride
+        self._ride = None
+        assert r["qrisk"] and obs is r["obs"], "the acting pass of a ride must follow its two riders, on the same observations"
+        forward_multi([self.rec.forward_desc(obs, save=False)])
+        rec_head = f._stoch_desc(self.rec.parts, r["noise"][1], self.rec_action, n=self.n)
+        zq, zn, zs = self.qr.parts
+        self.pending_select = (zq, zn, zs, float(eps_safe), None, rec_head)
+        return self.xa[:, 2:4], self.real_action, self.recovery
 
     def act(self, obs, eps_safe, use_recovery, mf_recovery, noise=None, defer_select=False):
         """-> (task action [n,2], executed action [n,2], recovery u8[n] or None); persistent buffers.
@@ -843,6 +890,9 @@ class FastActor:
         holds its inputs, the task action is the strided view xa[:, 2:4] and the other two are filled by that kernel."""
         f, n, lib, st = self.f, self.n, self.f.lib, _lib.current_stream()
         self.pending_select = None
+        if self._ride is not None:
+            assert noise is None and defer_select and use_recovery and mf_recovery
+            return self._finish_ride(obs, eps_safe)
         if noise is None:
             noise = f.actor_noise(n)
         if f.grouped and use_recovery and mf_recovery:

@@ -425,3 +425,53 @@ def test_demo_share_rule_is_printed_recorded_and_can_be_switched_off(tmp_path, c
         # the draw the graph replays is the reference's: uniform over [0, size), no split
         d, _ = exp.recovery_memory.draw_desc(256, demo_share=exp.agent.safety_critic.demo_share)
         assert d.stratified == 0 and (d.n_pos, d.n_neg) == (0, 256)
+
+
+@pytest.mark.parametrize("updates_per_step", (1, 2))
+def test_acting_forwards_riding_in_the_update_launches_change_no_bit(tmp_path, updates_per_step):
+    """Round 6: the acting pass's task-policy forward rides in the Q_risk update's first forward launch and its Q_risk forward
+    in the forward at the updated critic (VectorLoop.actor_rider, FastUpdater.qrisk_update_grouped: 17 -> 16 launches, 4096-row
+    and 256-row members in one multi-row-tile launch).  Same kernels on the same inputs in another launch: the loop with the
+    riders equals the loop without them in every replay row, env state, counter and network parameter -- eagerly and from the
+    graph, at the bench's shape (hidden 256, batch 256, 4096 envs), also with two update pairs per iteration (the riders go
+    with the last one)."""
+    import bench
+    from recovery_rl_amd import fast_update
+    loops = []
+    for carry in (True, False):
+        cfg = arg_utils.get_args(bench.config_argv("navigation1", 7, 4096, updates_per_step) +
+                                 ["--num_unsafe_transitions", "3000", "--logdir", str(tmp_path)])
+        loop = bench.build_loop(cfg, torch.device(DEV), pretrain=10)
+        loop.carry_actor = carry
+        for _ in range(2):                # (the first acting pass sizes the iteration's noise fill: a launch of its own)
+            loop.vector_step(True, False, True)
+        tape = []
+        fast_update.set_tape(tape)
+        try:
+            loop.vector_step(True, False, True)
+        finally:
+            fast_update.set_tape(None)
+        launches = [op for op in tape if op[0] != "unsupported"]
+        assert not [op for op in tape if op[0] == "unsupported"]
+        assert len(launches) == (16 if carry else 17) + 14 * (updates_per_step - 1)
+        rows = [[op[1][k].M for k in range(op[2])] for op in tape if op[0] == "forward"]
+        if carry:
+            assert rows[-4:] == [[4096, 256, 256], [256, 256], [4096, 256], [4096]]
+        else:
+            assert rows[-4:] == [[256, 256], [256], [4096, 4096], [4096]]
+        for _ in range(3):
+            loop.vector_step(True, False, True)
+        loop.capture(online_qrisk=True)
+        loop.advance(13)
+        torch.cuda.synchronize()
+        loops.append(loop)
+    la, lb = loops
+    assert torch.equal(la.env.pos, lb.env.pos) and torch.equal(la.env.obs, lb.env.obs)
+    assert torch.equal(la.stats, lb.stats) and torch.equal(la.reward_sums, lb.reward_sums)
+    for ma, mb in ((la.memory, lb.memory), (la.recovery_memory, lb.recovery_memory)):
+        assert torch.equal(ma.state, mb.state)
+        for x, y in ((ma.s, mb.s), (ma.a, mb.a), (ma.r, mb.r), (ma.s2, mb.s2), (ma.m, mb.m)):
+            assert torch.equal(x, y)
+    for name in ("critic", "critic_target", "policy", "qrisk", "qrisk_target", "recpolicy"):
+        assert torch.equal(getattr(la.agent.fast, name).flat, getattr(lb.agent.fast, name).flat), name
+    assert int(la.read_stats()["env_steps"]) == la.total_numsteps == lb.total_numsteps
