@@ -393,7 +393,7 @@ def committed_pmc(name, key):
     """(HBM bytes per launch, source file) from the committed rocprofv3 PMC passes under profiles/ (PMC passes cannot run
     inside this process: the figure is NOT measured by this run, `traffic_source` in the JSON line says where it comes
     from).  (None, None) when no measurement exists for this size."""
-    for rnd in ("round5", "round4", "round3", "round2", "round1"):
+    for rnd in ("round6", "round5", "round4", "round3", "round2", "round1"):
         rel = os.path.join("profiles", "%s_%s.json" % (rnd, name))
         try:
             rec = json.load(open(os.path.join(ROOT, rel))).get(str(key))
