@@ -62,7 +62,7 @@ def test_packed_kernels_use_global_not_flat_memory_instructions(kernels):
 
 def test_solo_kernels_of_the_iteration_have_no_flat_loads_either(kernels):
     for piece in ("gemm16_group_kernel", "head_bwd_group_kernel", "backward_pair_kernel", "mlp3_fwd_split_group_kernel",
-                  "adam_multi_kernel", "sample_group_kernel", "step_push_kernel"):
+                  "mlp3_fwd_split_flat_group_kernel", "adam_multi_kernel", "sample_group_kernel", "step_push_kernel"):
         hits = [k for k in kernels if piece in k]
         assert hits, piece
         for k in hits:
@@ -84,6 +84,8 @@ BUDGETS = (
     ("mlp3_fwd_split_pack_kernelILi2E", 128, "packed forwards"),
     ("plan_cost_kernelILb0E", 128, "planner f32: four waves per SIMD"),
     ("plan_cost_kernelILb1E", 128, "planner f16x3"),
+    ("plan_first_step_kernel", 128, "planner, first step once per distinct row: the rollout kernel's phases, same occupancy"),
+    ("mlp3_fwd_split_flat_group_kernel", 128, "acting forward riding with 256-row update forwards (both tile forms in one kernel)"),
     ("ens_big_fwd_bwd_kernel", 128, "large-batch ensemble step"),
     ("step_push_kernelIN12_GLOBAL__N_16NavEnvILi0EEELi0E", 96, "fused env step + pushes + episode table, latency variant (speculated reset)"),
     ("step_push_kernelIN12_GLOBAL__N_16NavEnvILi0EEELi2E", 64, "the same, bandwidth variant: 1024-thread workgroups, eight waves per SIMD"),
