@@ -14,6 +14,22 @@ def _np(x):
     return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
 
 
+def behaviour(info):
+    """Where an episode went and what the two controllers did, from its per-step info dicts (keys of env.step's info on both
+    stacks: state, next_state, action = the executed action, recovery)."""
+    s = np.array([_np(x["state"]).reshape(-1) for x in info], dtype=np.float64)
+    ns = np.array([_np(x["next_state"]).reshape(-1) for x in info], dtype=np.float64)
+    a = np.array([_np(x["action"]).reshape(-1) for x in info], dtype=np.float64)
+    rec = np.array([bool(x.get("recovery", False)) for x in info])
+    out = {"final": ns[-1].round(2).tolist(), "max_x": float(s[:, 0].max()), "mean_abs_y": float(np.abs(s[:, 1]).mean()),
+           "task_action_mean": a[~rec].mean(0).round(3).tolist() if (~rec).any() else None}
+    if rec.any():
+        out.update(rec_action_mean=a[rec].mean(0).round(3).tolist(), rec_action_norm=float(np.sqrt((a[rec] ** 2).sum(1)).mean()),
+                   rec_x_range=[float(s[rec, 0].min()), float(s[rec, 0].max())], rec_abs_y=float(np.abs(s[rec, 1]).mean()),
+                   rec_first_step=int(np.argmax(rec)))
+    return out
+
+
 class Probe:
     def __init__(self, eps_safe):
         self.eps_safe = float(eps_safe)
@@ -27,12 +43,14 @@ class Probe:
     def plan(self):
         self._plans += 1
 
-    def end_episode(self, steps, success, violation, recovery_steps):
+    def end_episode(self, steps, success, violation, recovery_steps, info=None):
         g = np.asarray(self._gate if self._gate else [0.0])
         self.episodes.append({"steps": int(steps), "success": int(success), "violation": int(violation),
                               "recovery_steps": int(recovery_steps), "planner_calls": self._plans,
                               "gate_mean": float(g.mean()), "gate_max": float(g.max()),
                               "gate_on": float((g > self.eps_safe).mean())})
+        if info is not None:
+            self.episodes[-1].update(behaviour(info))
         self._gate, self._plans = [], 0
 
     # -- the ensemble ------------------------------------------------------------------------------------------------

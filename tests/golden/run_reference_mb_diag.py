@@ -70,7 +70,7 @@ def main():
         def rollout(i_episode):
             info = real_rollout(i_episode)
             probe.end_episode(len(info), info[-1]["reward"] > -4, any(s["constraint"] for s in info),
-                              sum(int(bool(s.get("recovery", False))) for s in info))
+                              sum(int(bool(s.get("recovery", False))) for s in info), info=info)
             return info
         exp.get_train_rollout = rollout
         exp.run()

@@ -42,3 +42,23 @@ def test_first_episodes_of_the_model_based_line_next_to_the_reference(seed):
         # episodes of this seed, 0.1 against 38.3 recovery steps per episode in episodes 20-40; both without a violation and level from episode
         # ~80 on -- DESIGN section 7 says so): the comparison is one-sided
         assert s_r >= 5 and s_m >= s_r - 10, (s_m, s_r)
+
+
+def test_leaving_the_recovery_regime_does_not_depend_on_which_path_computes(tmp_path):
+    """Round 6: seed 1 of the model-based line through the hand-written kernels and with the updates and the
+    planner swapped for torch modules + autograd (`math=torch`: the reference's mathematics line by line for everything the gate
+    and the recovery action depend on; the recorded runs include the re-fit as well) reaches its first success in the same early
+    episodes -- what decides how long the stalemate between the task policy and the recovery controller lasts
+    is the offline demonstration set, not the arithmetic (profiles/round6_mb_diag.json holds the full record, the reference's
+    side included)."""
+    import mb_diag
+    first = {}
+    for variant in ("-", "math=torch"):
+        r = mb_diag.run(1, 20, variant=variant)
+        assert r["planner_fused"] == (variant == "-") and r["updates_fused"] == (variant == "-")
+        assert not any(e["violation"] for e in r["episodes"])
+        first[variant] = next((i for i, e in enumerate(r["episodes"]) if e["success"]), None)
+        # the ensemble is at the env's noise floor from the pre-training on
+        assert 0.003 < np.mean([f["before"]["mse"] for f in r["refits"]]) < 0.008
+    assert first["-"] is not None and first["math=torch"] is not None, first
+    assert first["-"] <= 16 and first["math=torch"] <= 16 and abs(first["-"] - first["math=torch"]) <= 6, first
