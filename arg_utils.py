@@ -105,6 +105,10 @@ ADDITIVE = [
                                                   "--num_steps exceeds them (default at --num_envs > 1: both buffers are sized "
                                                   "to hold the whole run, as the reference's defaults do: replay_size = "
                                                   "num_steps = 1e6)"),
+    (("--keep_plan_warm_start",), "store_true", None, "lock-step loop, model-based recovery: keep an env's CEM warm start "
+                                                      "(MPC.prev_sol) across its episodes, as the one-env reference does "
+                                                      "(default at --num_envs > 1: an episode's first plan starts from the "
+                                                      "mid-point action sequence, MPC.py:174 -- vectorisation rule 5)"),
     (("--demo_share",), F, -1.0, "lock-step loop: share of every Q_risk batch drawn from the pinned constraint "
                                  "demonstrations, the rest from the online rows (0 = one uniform draw over the ring; "
                                  "default -1: 0.5 with --num_envs > 1 and pinned demonstrations -- the share a one-env "

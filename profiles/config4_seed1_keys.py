@@ -25,7 +25,54 @@ from recovery_rl_amd.experiment import Experiment  # noqa: E402
 N = 4096
 
 
-def run(precision, plan_seed, seed=1, iterations=1675, U=16):
+def step_probe(exp):
+    """Round 6: what the two learned models say about the LAST step of all envs (the fused step keeps state, executed action
+    and next state for the online re-fit): the ensemble's one-step error and predicted sd, and the safety critic's value of the
+    executed action -- on the rows under the recovery controller and on the others -- beside what happened (constraint flags)."""
+    env, loop, mpc, qr = exp.env, exp.loop, exp.recovery_policy, exp.agent.safety_critic
+    with torch.no_grad():
+        s, a, s2 = env.prev_obs.float(), env.action_clipped.float(), env.next_obs.float()
+        rec = loop._last_recovery.bool() if loop._last_recovery is not None else torch.zeros(s.shape[0], dtype=torch.bool, device=s.device)
+        x = torch.cat([s, a], 1)[None].expand(mpc.model.num_nets, -1, -1).contiguous()
+        mean, var = mpc.model(x)
+        err = ((mean - (s2 - s)[None]) ** 2).sum(-1).mean(0)              # per env, mean over members
+        sd = var.sqrt().mean(-1).mean(0)
+        q = qr.get_value(s, a).reshape(-1)
+        cons = env.constraint.bool()
+        out = {"recovery_rows": int(rec.sum()), "violations_this_step": int(cons.sum()),
+               "violations_this_step_under_recovery": int((cons & rec).sum()),
+               "ens_mse_all": float(err.mean()), "ens_sd_all": float(sd.mean()), "q_exec_all": float(q.mean())}
+        near = (s[:, 0] > -34) & (s[:, 0] < -16) & (s[:, 1].abs() < 12)    # the obstacle's caution zone (navigation2.py:43)
+        out["rows_near_obstacle"] = int(near.sum())
+        for name, m in (("recovery", rec), ("near", near), ("violating", cons)):
+            if bool(m.any()):
+                out["ens_mse_" + name] = float(err[m].mean())
+                out["q_exec_" + name] = float(q[m].mean())
+                out["q_exec_" + name + "_min"] = float(q[m].min())
+        if bool(cons.any()):
+            out["q_exec_violating_below_eps"] = float((q[cons] < exp.exp_cfg.eps_safe).float().mean())
+        # the critic's landscape over the action circle on the recovery rows: is there a safe action (min over 16 directions
+        # of Q_risk(s, a)) -- the planner's miss -- or is every direction rated unsafe -- the critic's?
+        if bool(rec.any()):
+            import math
+            sr, ar = s[rec], a[rec]
+            dirs = torch.tensor([[math.cos(k * math.pi / 8), math.sin(k * math.pi / 8)] for k in range(16)], device=s.device)
+            qd = torch.stack([qr.get_value(sr, d.expand_as(sr)).reshape(-1) for d in dirs], 1)          # [rows, 16]
+            qe = q[rec]
+            away = torch.stack([-torch.ones_like(sr[:, 0]), torch.zeros_like(sr[:, 0])], 1)           # straight back (-x)
+            out.update(q_dir_min_recovery=float(qd.min(1).values.mean()), q_dir_max_recovery=float(qd.max(1).values.mean()),
+                       q_away_recovery=float(qr.get_value(sr, away).mean()),
+                       planner_regret_recovery=float((qe - qd.min(1).values).mean()),
+                       recovery_rows_with_a_safe_direction=float((qd.min(1).values < exp.exp_cfg.eps_safe).float().mean()),
+                       recovery_rows_executing_unsafe=float((qe > exp.exp_cfg.eps_safe).float().mean()),
+                       exec_action_norm_recovery=float(ar.norm(dim=1).mean()),
+                       exec_action_mean_recovery=[round(float(v), 3) for v in ar.mean(0)],
+                       recovery_rows_x=[round(float(v), 2) for v in torch.quantile(sr[:, 0], torch.tensor([0.1, 0.5, 0.9], device=s.device))],
+                       recovery_rows_abs_y=float(sr[:, 1].abs().mean()))
+    return out
+
+
+def run(precision, plan_seed, seed=1, iterations=1675, U=16, probe=False):
     tmp = tempfile.mkdtemp()
     cfg = arg_utils.get_args(["--cuda", "--env-name", "navigation2", "--use_recovery", "--gamma_safe", "0.65", "--eps_safe",
                               "0.2", "--logdir_suffix", "RRL_MB", "--num_unsafe_transitions", "20000", "--logdir", tmp,
@@ -46,6 +93,8 @@ def run(precision, plan_seed, seed=1, iterations=1675, U=16):
                 row["planning_set"] = int(mpc.last_count[0].item())      # of the log point's own iteration
             x = exp.env.pos[:, 0].float()
             row["x_quantiles"] = [round(float(v), 2) for v in torch.quantile(x, torch.tensor([0.1, 0.5, 0.9], device=x.device))]
+            if probe:
+                row.update(step_probe(exp))
             rows.append(row)
             return st
         loop.read_stats = read_stats
@@ -70,6 +119,6 @@ def run(precision, plan_seed, seed=1, iterations=1675, U=16):
 
 if __name__ == "__main__":
     r = run(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 1,
-            int(sys.argv[4]) if len(sys.argv) > 4 else 1675)
+            int(sys.argv[4]) if len(sys.argv) > 4 else 1675, probe=len(sys.argv) > 5 and sys.argv[5] == "probe")
     print(json.dumps({k: v for k, v in r.items() if k != "windows"}), file=sys.stderr)
     print(json.dumps(r))

@@ -105,6 +105,7 @@ class MPC:
         n = getattr(env, "num_envs", 1)
         mid = np.tile((self.ac_lb + self.ac_ub) / 2, [self.plan_hor])           # MPC.py:174
         self.prev_sol = torch.as_tensor(mid, dtype=torch.float64, device=self.device).repeat(n, 1)
+        self._mid = torch.as_tensor(mid, dtype=torch.float64, device=self.device)
         self.init_var = torch.as_tensor(np.tile(np.square(self.ac_ub - self.ac_lb) / 16, [self.plan_hor]),
                                         dtype=torch.float64, device=self.device)            # :175-176
         self.train_in = torch.zeros(0, self.dO + self.dU, device=self.device)
@@ -230,6 +231,20 @@ class MPC:
         mid = np.tile((self.ac_lb + self.ac_ub) / 2, [self.plan_hor])
         self.prev_sol[:] = torch.as_tensor(mid, dtype=torch.float64, device=self.device)
         self.optimizer.reset()
+
+    def forget_plans(self, ended):
+        """Vectorisation rule 5 (lock-step loop, N > 1): the envs whose episode just ended start their next plan from the
+        mid-point sequence (what prev_sol is before the first plan, MPC.py:174) instead of from the shifted solution of their
+        last plan.  The reference never resets prev_sol (experiment.py never calls MPC.reset): its ONE env plans at every
+        gate event, a few steps or at most an episode apart, in the part of the arena it is learning in.  Of 4096 envs with a
+        trained task policy each plans once in hundreds of iterations: the warm start is a plan for another place, and it sits
+        AT the action bound (the recovery direction saturates at -0.98), where CEM's variance clamp (optimizers.py:96-99:
+        var <= ((mean - lb) / 2)^2 = 1e-4) freezes it -- five iterations cannot turn it.  Measured on config 4, seed 1
+        (profiles/round6_config4_seed1/): inside a violation burst the safety critic rates a safe direction at 0.03 on 100 % of
+        the rows under the recovery controller and the executed action at > eps_safe on 16-50 % of them, all at the obstacle's
+        far corner (x = -21.5, |y| = 8), all with x-component -0.93 .. -0.98 -- the direction that was 'away' where the env
+        planned last.  ended: uint8 / bool [N]."""
+        self.prev_sol.copy_(torch.where(ended.bool().unsqueeze(1), self._mid, self.prev_sol))
 
     def update_value_func(self, value_func):
         self.value_func = value_func

@@ -72,6 +72,9 @@ class VectorLoop:
         self._graph_updates = (0, 0)
         self._actor = None
         self.carry_actor = os.environ.get("RRL_CARRY_ACTOR", "1") != "0"
+        # vectorisation rule 5: at N > 1 an env's CEM warm start does not survive its episode (MPC.forget_plans)
+        self.forget_plans = bool(recovery_policy is not None and self.n > 1 and hasattr(recovery_policy, "forget_plans")
+                                 and not getattr(cfg, "keep_plan_warm_start", False))
         self._one = torch.ones((), dtype=torch.int64, device=dev)
         # the random-action phase (experiment.py:559-560) draws from the loop's OWN generator: a seed's trajectory does not
         # depend on what else shares the process (S seeds per GPU, packed.py), only on its seed
@@ -225,6 +228,8 @@ class VectorLoop:
         self.ep_reward *= (~ep_done).to(torch.float32)
         if self.episode_log is not None:
             self.episode_log.append(reward, info["constraint"], info["success"], info["ep_done"], recovery)
+        if self.forget_plans:
+            self.recovery_policy.forget_plans(ep_done)
         self.obs = obs
         self.total_numsteps += self.n
         return obs
@@ -303,6 +308,8 @@ class VectorLoop:
         mem._len = min(mem._len + self.n, mem.capacity)
         if use_rmem:
             rmem._len = min(rmem._len + self.n, rmem.capacity)
+        if self.forget_plans:
+            self.recovery_policy.forget_plans(env.ep_done)        # vectorisation rule 5 (the step wrote the episode-end flags)
         self.obs = env.obs
         self.total_numsteps += self.n
         return env.obs
@@ -549,7 +556,10 @@ class Experiment:
         self.vector_rules = {"demo_share": 0.0, "pinned_demonstrations": 0, "replay_capacities": (cap, safe_cap),
                              "cover_rows_limit": cover_rows_limit(dev, getattr(exp_cfg, "seeds_per_gpu", 1)),
                              "buffers_cover_the_run": bool(exp_cfg.num_envs <= 1 or min(cap, safe_cap) >= exp_cfg.num_steps
-                                                           or exp_cfg.pos_fraction >= 0)}
+                                                           or exp_cfg.pos_fraction >= 0),
+                             "plan_warm_start": "kept across episodes (the reference)" if (
+                                 exp_cfg.num_envs <= 1 or getattr(exp_cfg, "keep_plan_warm_start", False))
+                             else "per episode (rule 5)"}
 
         self.total_numsteps = 0
         self.updates = 0
@@ -627,7 +637,7 @@ class Experiment:
         # run_stats.pkl ("vector_rules") and the checkpoint
         self.vector_rules = {"demo_share": share if share > 0 else 0.0, "pinned_demonstrations": int(pinned),
                              **{k: self.vector_rules[k] for k in ("replay_capacities", "cover_rows_limit",
-                                                                   "buffers_cover_the_run")}}
+                                                                   "buffers_cover_the_run", "plan_warm_start")}}
         if cfg.num_envs > 1:
             print("Q_risk batch: %s (--demo_share; 0 = the reference's single uniform draw, replay_memory.py:54-72)"
                   % ("%d of %d rows from the %d pinned demonstrations, the rest from the online rows"

@@ -21,7 +21,7 @@ def test_defaults_of_all_55_reference_flags(G):
         assert k in mine, k
         assert mine[k] == v and type(mine[k]) is type(v), (k, mine[k], v)
     extra = set(mine) - set(ref)
-    assert extra == {"num_envs", "log_every", "mb_dynamics", "checkpoint_every", "resume", "no_fast_path", "dp_mode", "plan_precision", "no_pin_demos", "seeds_per_gpu", "info_envs", "demo_share", "keep_replay_size", "plan_seed", "graph_iterations"}
+    assert extra == {"num_envs", "log_every", "mb_dynamics", "checkpoint_every", "resume", "no_fast_path", "dp_mode", "plan_precision", "no_pin_demos", "seeds_per_gpu", "info_envs", "demo_share", "keep_replay_size", "plan_seed", "graph_iterations", "keep_plan_warm_start"}
     assert mine["num_envs"] == 1 and mine["mb_dynamics"] == "model"
 
 

@@ -93,6 +93,49 @@ def test_config4_stays_safe_over_1600_iterations_at_4096_envs(tmp_path):
     assert r["offline_violations"] > 1000
 
 
+def test_config4_seed_1_has_no_violation_under_the_recovery_controller(tmp_path):
+    """The behavioural guard of vectorisation rule 5 (an env's CEM warm start does not survive its episode, MPC.forget_plans):
+    seed 1 of config 4 -- the seed whose violation bursts followed the planner's Philox key through rounds 4 and 5 (2 077 / 1 734
+    / 0 violations with the f16x3 planner under keys 0 / 1 / 2, 1 825 / 1 700 of them WITH the recovery controller active; 0 / 5 175
+    / 6 278 with the f32 one).  Round 6 found the mechanism (profiles/round6_config4_seed1/): an env plans once in hundreds of
+    iterations, its warm start is a plan for another place and sits at the action bound, where CEM's variance clamp freezes it;
+    inside a burst the critic rates a safe direction at 0.03 on every row under the recovery controller while the executed action
+    is rated unsafe on 16-50 % of them.  With the rule: 43 / 0 / 0 (f16x3) and 0 / 20 (f32, keys 1 / 2) violations of ~125 k
+    episodes, NONE under the recovery controller.  The reference's one-env run of this command line has 0 violations."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
+    import learning_vec4096 as lv
+    r = lv.run(1, 16, 1650, config=4, precision="f16x3")
+    assert r["iterations"] >= 1650 and r["episodes"] > 100000
+    assert r["viol_and_recovery"] == 0, r["viol_and_recovery"]                    # the recovery controller never drives an env in
+    assert r["violations"] <= 150, r["violations"]                                  # (43: gate misses just below eps_safe)
+    assert max(w["violation_rate"] for w in r["windows"]) <= 0.06
+    assert r["final_success_rate"] > 0.85
+
+
+def test_plan_warm_start_rule_resets_exactly_the_ended_envs(tmp_path):
+    """MPC.forget_plans (rule 5) in isolation + its switches: the rows whose episode ended go back to the mid-point sequence, the
+    others keep their shifted solution; one env and --keep_plan_warm_start keep the reference's carry-over."""
+    from recovery_rl_amd.experiment import Experiment
+    base = ["--env-name", "navigation2", "--cuda", "--use_recovery", "--gamma_safe", "0.65", "--eps_safe", "0.2", "--logdir",
+            str(tmp_path), "--num_unsafe_transitions", "2000", "--critic_safe_pretraining_steps", "10", "--seed", "2"]
+    exp = Experiment(arg_utils.get_args(base + ["--num_envs", "64"]))
+    mpc = exp.recovery_policy
+    assert exp.loop.forget_plans and exp.vector_rules["plan_warm_start"].startswith("per episode")
+    mpc.prev_sol.copy_(torch.rand_like(mpc.prev_sol) - 0.5)
+    before = mpc.prev_sol.clone()
+    ended = torch.zeros(64, dtype=torch.uint8, device=mpc.prev_sol.device)
+    ended[[3, 17, 63]] = 1
+    mpc.forget_plans(ended)
+    keep = ended == 0
+    assert torch.equal(mpc.prev_sol[keep], before[keep]) and bool((mpc.prev_sol[~keep] == 0).all())
+    kept = Experiment(arg_utils.get_args(base + ["--num_envs", "64", "--keep_plan_warm_start"]))
+    one = Experiment(arg_utils.get_args(base))
+    assert not kept.loop.forget_plans and not one.loop.forget_plans
+    assert kept.vector_rules["plan_warm_start"].startswith("kept") and one.vector_rules["plan_warm_start"].startswith("kept")
+
+
 def test_bench_stage_table_prices_the_flops_the_iteration_model_states():
     """bench.roofline_stages re-issues the recorded launches of ONE config-2 iteration with their algorithmic FLOPs; their sum is
     what bench.iteration_flops (the figure `roofline_mlp` is priced with) states analytically -- to 1 % --, and every kernel of
