@@ -62,3 +62,25 @@ def test_leaving_the_recovery_regime_does_not_depend_on_which_path_computes(tmp_
         assert 0.003 < np.mean([f["before"]["mse"] for f in r["refits"]]) < 0.008
     assert first["-"] is not None and first["math=torch"] is not None, first
     assert first["-"] <= 16 and first["math=torch"] <= 16 and abs(first["-"] - first["math=torch"]) <= 6, first
+
+
+def test_on_the_references_demonstrations_this_stack_stalls_like_the_reference():
+    """Round 6: a seed fixes the same initial networks on both stacks but not the same offline demonstrations
+    (Philox here, the global MT19937 stream there).  Seed 1 of the model-based line on this stack's own draws reaches its first
+    success by episode ~11; on the REFERENCE's demonstration set of seed 1 (tests/golden/ref_demos_nav2_seed1.npz:
+    Experiment.constraint_demo_data of the imported reference, gen_ref_demos.py) it stays in the stalemate between task policy
+    and recovery controller exactly as the reference's own run does -- no success, ~40 recovery steps per episode
+    (tests/golden/ref_mb_diag_seed1.json: [.. 31, 34, 35, 33, 39, 40, 38, 40, 41 ..])."""
+    import mb_diag
+    os.environ["RRL_MB_DIAG_DEMOS"] = os.path.join(HERE, "golden", "ref_demos_nav2_seed1.npz")
+    try:
+        r = mb_diag.run(1, 18)
+    finally:
+        del os.environ["RRL_MB_DIAG_DEMOS"]
+    rec = [e["recovery_steps"] for e in r["episodes"]]
+    assert not any(e["success"] or e["violation"] for e in r["episodes"])
+    assert 33 <= np.mean(rec[8:18]) <= 46, rec
+    ref = json.load(open(os.path.join(HERE, "golden", "ref_mb_diag_seed1.json")))
+    ref_rec = [e["recovery_steps"] for e in ref["episodes"]]
+    assert abs(np.mean(rec[8:18]) - np.mean(ref_rec[8:18])) <= 6, (rec, ref_rec)
+    assert not any(e["success"] for e in ref["episodes"][:18])
