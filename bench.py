@@ -481,8 +481,11 @@ def roofline_stages(a, device, iteration_ms):
             m_max = max(arr[k].M for k in range(n))
             name = "forward x%d (%s rows)" % (n, "/".join(str(arr[k].M) for k in range(n)))
             launch = lambda arr=arr, n=n: lib.rrl_mlp3_forward_multi(n, arr, st())
-            rows.append((name, "acting forward" if m_max > 1024 else "update forward", launch, fl, None,
-                         "mlp3_fwd_split_group_kernel<%d>" % (2 if m_max > 1024 else 1)))
+            m_min = min(arr[k].M for k in range(n))
+            # (members of different sizes -- an acting forward riding with 256-row update forwards -- go on the flat grid)
+            kernel = "mlp3_fwd_split_flat_group_kernel" if m_min <= 1024 < m_max else \
+                "mlp3_fwd_split_group_kernel<%d>" % (2 if m_max > 1024 else 1)
+            rows.append((name, "acting forward" if m_max > 1024 else "update forward", launch, fl, None, kernel))
         elif kind == "head_bwd":
             arr, n = op[1], op[2]
             # thin (dout <= 4): a streaming kernel -- h2 read, dh2 written, the stack outputs and W3 read
