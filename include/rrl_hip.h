@@ -505,7 +505,10 @@ int rrl_mlp_head_backward_loss(const rrl_loss_t* loss, int G, int B, int H, int 
  * entry point on its own workgroups: results are bit-identical to the separate launches.  n <= 4.
  *   rrl_mlp3_forward_multi        members = rrl_mlp3_forward calls; all members must take the same path (all with
  *                                 scratch on the split path -- partial sums stay in scratch, finalize = 0 -- or all
- *                                 on the same plain tiling), else RRL_EINVAL
+ *                                 on the same plain tiling), else RRL_EINVAL.  Split-path members of hidden width 256
+ *                                 may differ in size (round 6: a 4096-row acting forward riding with an update's 256-row
+ *                                 forwards): they then run on a flat grid of exactly the workgroups each member needs,
+ *                                 every member on the tiles of its stand-alone launch -- list the large member first
  *   rrl_mlp_head_backward_multi   members = rrl_mlp_head_backward_loss calls (loss.kind = -1: loss.out is a plain
  *                                 dOut tensor as in rrl_mlp_head_backward)
  *   rrl_mlp_hidden_backward_multi members = rrl_mlp_hidden_backward calls; dW2 = db2 = NULL: only dh1

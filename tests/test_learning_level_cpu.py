@@ -256,3 +256,25 @@ def test_model_based_escape_time_follows_the_demonstration_set_not_the_kernels()
     assert not any(r["violations"] for r in mine)                     # no constraint violation in any of this stack's 46 runs
     # the ensemble is accurate from the pre-training on, on every run: one-step error at the env's noise floor (2 x 0.05^2)
     assert all(0.003 < np.mean(r["prefit_mse"]) < 0.008 and 0.045 < np.mean(r["pred_sd"]) < 0.06 for r in mine)
+
+
+def test_headline_update_to_data_ratio_learns_on_every_seed():
+    """Round 6: the bench's headline runs ONE update pair per 4096 env-steps.  The committed record
+    (profiles/round6_utd_trade.json: config 2 at 4096 envs, seeds 1-8, U in {1, 2, 4, 8, 16}, 600 iterations through
+    Experiment.run; regenerate with `python profiles/utd_trade.py 600 1 8 1,2,4,8,16` on the GPU box) says that every seed at
+    every U reaches a 25-iteration window with >= 90 % successes and ends at 100 %; U = 1 gets there in the least loop time, U = 8
+    in the fewest env-steps; violations stay below 0.05 % of the episodes."""
+    rec = json.load(open(os.path.join(HERE, "..", "profiles", "round6_utd_trade.json")))
+    by = {}
+    for r in rec["runs"]:
+        by.setdefault(r["updates_per_step"], []).append(r)
+    assert sorted(by) == [1, 2, 4, 8, 16] and all(len(v) == 8 for v in by.values())
+    med = {}
+    for U, runs in by.items():
+        assert all("to_90pct" in r and r["final_success_rate"] > 0.99 for r in runs), U
+        assert all(r["violations"] <= 0.0005 * r["episodes"] for r in runs), U
+        med[U] = (np.median([r["to_90pct"]["loop_seconds"] for r in runs]), np.median([r["to_90pct"]["env_steps"] for r in runs]),
+                  np.median([r["to_90pct"]["grad_steps"] for r in runs]))
+    assert med[1][0] < 0.5 * med[16][0]                       # wall clock: U = 1 learns the task > 2x sooner than U = 16 (4.7x)
+    assert med[8][1] <= min(m[1] for m in med.values())       # env-steps: U = 8 (and 16) need the fewest
+    assert med[1][2] < med[16][2] / 5                          # gradient steps: a seventh
