@@ -40,7 +40,9 @@ def main():
         print("seed", seed, "rows", cols[0].shape[0], "violations", int(cols[2].sum()))
         for k, v in zip("sacnm", cols):
             out["seed%d.%s" % (seed, k)] = v
-    np.savez_compressed(os.path.join(HERE, "..", "..", "profiles", "_ab_ref_demos.npz"), **out)
+    profiles = os.path.join(HERE, "..", "..", "profiles")
+    if os.path.isdir(profiles):                      # (a scratch copy of this directory alone regenerates the fixture only)
+        np.savez_compressed(os.path.join(profiles, "_ab_ref_demos.npz"), **out)
     np.savez_compressed(os.path.join(HERE, "ref_demos_nav2_seed1.npz"), **{k: v for k, v in out.items() if k.startswith("seed1.")})
 
 
