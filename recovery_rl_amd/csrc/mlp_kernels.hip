@@ -154,13 +154,22 @@ struct NothingBehindRequests {
 // fmaf chain over o = 0 .. DOUT - 1 starting from 0 (head_bwd_loss_body's order); dsh is [B][DOUT], w3 [DOUT][H].  One output:
 // the critic-loss kinds, W3 fragments from registers; 2 / 4 outputs (the stochastic / tanh-Gaussian policy heads): the k-
 // contiguous W3 elements of the NN product come from an LDS copy `w3s` ([DOUT][H], staged by behind_requests()).
+// SHARE (round 6; GEN, four tiles per 256-thread workgroup that consume the SAME left operand -- the four column tiles of one
+// row tile in both planes of backward_pair_kernel): every wave requests and derives a QUARTER of each dh2 panel (16 of its
+// 64 k) and hands it to the others through LDS (`Ash`: two buffers `ash_stride` floats apart, one workgroup barrier per
+// panel) instead of all four requesting and deriving all of it.  These tiles are bound by the number of memory requests a
+// CU can issue, not by a latency chain (profiles/round6_pair_allk_ab.txt): 8 -> 5 (TN) and 12 -> 5 (NN) operand requests
+// per wave and panel.  Same values, same MFMA steps in the same order.
 template <int MODE, bool FAST, int PANEL = kPanel, bool DEEP = false, bool GEN = false, bool WSYNC = false,
-          class BEHIND = NothingBehindRequests, int DOUT = 1>  // MODE: 0 NT, 1 NN, 2 TN
+          class BEHIND = NothingBehindRequests, int DOUT = 1, bool SHARE = false>  // MODE: 0 NT, 1 NN, 2 TN
 __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float* Bs, int bx, int by, int g,
                                             const float* dsh = nullptr, const float* w3 = nullptr,
                                             BEHIND behind_requests = BEHIND(), const float* w3s = nullptr,
-                                            bool keep_sx = false, float* sx_out = nullptr) {
+                                            bool keep_sx = false, float* sx_out = nullptr, float* Ash = nullptr,
+                                            int ash_stride = 0) {
+    static_assert(!SHARE || (GEN && FAST && WSYNC && MODE != 0 && PANEL == 64), "SHARE: the paired backward's tiles");
     const int lane = threadIdx.x & 63;
+    const int wave = SHARE ? int(threadIdx.x >> 6) : 0;
     const int m0 = by * kTile, n0 = bx * kTile;
     const float* A = a.A + g * a.sA;
     constexpr int VEC = PANEL / 16;
@@ -182,13 +191,22 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
     };
 
     auto load_into = [&](Frag& ra, Frag& rb, Frag& rw, int k0) {
-        if (kStageA) load_staged<FAST>(ra, A, a.lda, m0, a.M, k0, a.K, lane);
-        else load_direct<FAST>(ra, A, a.lda, m0, a.M, k0, a.K, lane);
+        if constexpr (SHARE) {       // this wave's quarter of the left operand: chunk j = wave of load_staged / load_direct
+            if (kStageA) ra.v[0] = load4<FAST>(A, (long long)(k0 + (lane >> 2) + 16 * wave) * a.lda, m0 + (lane & 3) * 4, a.M, true);
+            else ra.v[0] = load4<FAST>(A, (long long)(m0 + (lane & 15)) * a.lda, k0 + 16 * wave + 4 * (lane >> 4), a.K, true);
+        } else {
+            if (kStageA) load_staged<FAST>(ra, A, a.lda, m0, a.M, k0, a.K, lane);
+            else load_direct<FAST>(ra, A, a.lda, m0, a.M, k0, a.K, lane);
+        }
         if (kStageB) load_staged<FAST>(rb, B, a.ldb, n0, a.N, k0, a.K, lane);
         else load_direct<FAST>(rb, B, a.ldb, n0, a.N, k0, a.K, lane);
         if constexpr (GEN && MODE == 1 && DOUT == 1) {
+            if constexpr (SHARE) {
+                rw.v[0] = *reinterpret_cast<const float4*>(w3 + k0 + 16 * wave + 4 * (lane >> 4));
+            } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) rw.v[j] = *reinterpret_cast<const float4*>(w3 + k0 + 16 * j + 4 * (lane >> 4));
+                for (int j = 0; j < VEC; ++j) rw.v[j] = *reinterpret_cast<const float4*>(w3 + k0 + 16 * j + 4 * (lane >> 4));
+            }
         }
     };
     auto load = [&](int k0) { load_into(fa, fb, fw, k0); };
@@ -234,7 +252,28 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
     behind_requests();
     for (int p = 0; p < np; ++p) {
         Frag ca = fa, cb = fb;           // operands of this panel (registers)
-        if constexpr (GEN) {
+        float* Ab = SHARE ? Ash + (p & 1) * ash_stride : nullptr;          // SHARE: this panel's dh2, all four quarters
+        if constexpr (SHARE) {
+            float go[DOUT];
+            float4 w[DOUT];
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int o = 0; o < DOUT; ++o) go[o] = dsh[(p * PANEL + (lane >> 2) + 16 * wave) * DOUT + o];
+                *reinterpret_cast<float4*>(Ab + ((lane >> 2) + 16 * wave) * kLd + (lane & 3) * 4) = gen4(fa.v[0], go, w3c);
+            } else {
+#pragma unroll
+                for (int o = 0; o < DOUT; ++o) {
+                    go[o] = dsh[(m0 + (lane & 15)) * DOUT + o];
+                    if constexpr (DOUT == 1) w[o] = fw.v[0];
+                    else w[o] = *reinterpret_cast<const float4*>(w3s + o * a.K + p * PANEL + 16 * wave + 4 * (lane >> 4));
+                }
+                *reinterpret_cast<float4*>(Ab + (wave * 64 + lane) * 4) = gen4(fa.v[0], go, w);
+            }
+            if (p) sync();               // (wave level) my previous panel's reads of Bs are done
+            store_staged(cb, Bs, lane);
+            __syncthreads();             // every quarter of this panel's dh2 is in Ab (its last readers were two panels ago)
+        }
+        if constexpr (GEN && !SHARE) {
             if constexpr (MODE == 2) {           // staged [k = batch row][4 dh2 columns]
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
@@ -261,11 +300,16 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
                 }
             }
         }
-        if (kStageA || kStageB) {
+        if (!SHARE && (kStageA || kStageB)) {
             if (p) sync();               // the previous panel's LDS reads are done
             if (kStageA) store_staged(ca, As, lane);
             if (kStageB) store_staged(cb, Bs, lane);
             sync();
+        }
+        float4 a4[VEC];                  // SHARE, NN: the lane's k-contiguous fragments of dh2, read back from Ab
+        if constexpr (SHARE && MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a4[j] = *reinterpret_cast<const float4*>(Ab + (j * 64 + lane) * 4);
         }
         if constexpr (DEEP) {
             if (p + 1 < np) { fa = na; fb = nb; fw = nw; }              // the panel behind this one is on its way already
@@ -280,7 +324,8 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, float* As, float*
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int k = 16 * j + 4 * q + t;
-                    const float av = kStageA ? As[k * kLd + i] : elem(ca.v[j], t);
+                    const float av = SHARE ? (MODE == 2 ? Ab[k * kLd + i] : elem(a4[j], t))
+                                           : (kStageA ? As[k * kLd + i] : elem(ca.v[j], t));
                     const float bv = kStageB ? Bs[k * kLd + i] : elem(cb.v[j], t);
                     if (MODE == 2) asum += av;
                     if (t & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1, 0, 0, 0);
@@ -1289,13 +1334,14 @@ __device__ __forceinline__ void backward_pair_body(const PairJobs& pj, int x, fl
     float* Bs = As + kPairPanel * kLd;
     using Behind = decltype(eval_dout);
     if (z == 1)
-        gemm16_tile<2, true, kPairPanel, true, true, true, Behind, DOUT>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3,
-                                                                         eval_dout, w3s);
+        gemm16_tile<2, true, kPairPanel, true, true, true, Behind, DOUT, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh,
+                                                                               w3, eval_dout, w3s, false, nullptr, smem,
+                                                                               kPairTileFloats);
     else {    // (128-wide panels for these tiles -- they stage one operand only, 10 KB either way -- measured: 10.4 -> 13.8 us)
         const bool fold = ga.dx_part && ga.dx_fold;          // workgroup-uniform
         float sx = 0.f;
-        gemm16_tile<1, true, kPairPanel, true, true, true, Behind, DOUT>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh, w3,
-                                                                         eval_dout, w3s, fold, &sx);
+        gemm16_tile<1, true, kPairPanel, true, true, true, Behind, DOUT, true>(ga, As, Bs, t % j.tiles_x, t / j.tiles_x, g, dsh,
+                                                                               w3, eval_dout, w3s, fold, &sx, smem, kPairTileFloats);
         if (fold) {
             // the workgroup's four tiles are four consecutive column tiles of one row tile (tiles_x % 4 == 0): their dx
             // partials as ONE sum ((p0 + p1) + p2) + p3 -- the policy-head backward then reads H / 64 partials per critic
